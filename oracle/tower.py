@@ -1,0 +1,252 @@
+"""Oracle: numpy restatement of the reference's embedding tower, triplet hinge
+loss, their backward pass and the optimizers.  TEST INFRASTRUCTURE (see
+oracle/__init__.py) -- the product never imports this.
+
+Every function is written for an explicit ``dtype`` so the same code gives the
+fp32 restatement (what TF1 computes) and its fp64 twin (the arbiter when two
+fp32 summation orders disagree).
+
+Parity status:
+  * hinge loss  -- pinned by the hand-derived known answer of the reference's
+    tests/test_losses.py:13-18 input (18.06 @ margin 0.1, 18.48 @ 0.8).
+  * VNet tower, backward, Adam, LARS -- PARITY UNPINNED: the arithmetic lives in
+    tensorflow-gpu==1.13.1 (README.md:21), which is not in /root/reference and
+    not installable here; the reference holds no golden vector for them.  The
+    restatement follows the reference call sites cited per function and TF 1.13
+    op semantics, and is gradient-checked against torch CPU autograd in tests.
+
+Reference citations are relative to /root/reference/.
+"""
+import numpy as np
+
+L2_EPS = 1e-12          # tf.nn.l2_normalize default epsilon (models.py:58,61)
+LRELU_ALPHA = 0.2       # tf.nn.leaky_relu default alpha (models.py:21)
+
+
+# ----------------------------------------------------------------------------
+# forward pieces
+# ----------------------------------------------------------------------------
+def l2_normalize(x, dtype=np.float32):
+    """tf.nn.l2_normalize(x, axis=-1): x * rsqrt(max(sum(x^2), 1e-12)).
+
+    models.py:58 (input) and models.py:61 (output).  Note: NOT x / max(|x|, eps).
+    Returns (y, inv_norm[...,1])."""
+    x = np.asarray(x, dtype=dtype)
+    ss = np.sum(np.square(x), axis=-1, keepdims=True, dtype=dtype)
+    inv = (dtype(1.0) / np.sqrt(np.maximum(ss, dtype(L2_EPS)))).astype(dtype)
+    return (x * inv).astype(dtype), inv
+
+
+def leaky_relu(x, alpha=LRELU_ALPHA):
+    """tf.nn.leaky_relu: max(alpha*x, x) (models.py:21 default activation_fn)."""
+    return np.maximum(x * x.dtype.type(alpha), x)
+
+
+def fully_connected(x, W, b, alpha=LRELU_ALPHA):
+    """slim.fully_connected with leaky_relu: lrelu(x @ W + b); W is [in, out]
+    (models.py:19-30)."""
+    return leaky_relu(x @ W + b, alpha)
+
+
+def vnet_forward(x, W1, b1, W2, b2, dtype=np.float32, alpha=LRELU_ALPHA):
+    """VNet.create_model (models.py:46-62).
+
+    x [R,F] -> l2norm -> FC(H)+lrelu -> FC(D)+lrelu -> l2norm.
+    Returns the reference's dict keys plus the intermediates backward needs."""
+    x = np.asarray(x, dtype)
+    W1, b1, W2, b2 = (np.asarray(a, dtype) for a in (W1, b1, W2, b2))
+    x_hat, _ = l2_normalize(x, dtype)
+    layer_1 = fully_connected(x_hat, W1, b1, alpha).astype(dtype)
+    layer_2 = fully_connected(layer_1, W2, b2, alpha).astype(dtype)
+    l2, inv2 = l2_normalize(layer_2, dtype)
+    return {"x_hat": x_hat, "layer_1": layer_1, "layer_2": layer_2,
+            "l2_norm": l2, "inv_norm_2": inv2}
+
+
+def hinge_loss(triplets, margin=0.1, dtype=np.float32):
+    """HingeLoss.calculate_loss (losses.py:20-49).  triplets [B,3,D].
+
+    Squared L2 distances; outputs keep the split axis ([B,1]) like tf.split."""
+    t = np.asarray(triplets, dtype)
+    anchors, positives, negatives = t[:, 0:1, :], t[:, 1:2, :], t[:, 2:3, :]
+    pos_dist = np.sum(np.square(anchors - positives), axis=-1, dtype=dtype)
+    neg_dist = np.sum(np.square(anchors - negatives), axis=-1, dtype=dtype)
+    hinge_dist = np.maximum(pos_dist - neg_dist + dtype(margin), dtype(0))
+    hinge_loss_ = np.mean(hinge_dist, dtype=dtype)
+    return {"hinge_loss": dtype(hinge_loss_), "anchors": anchors,
+            "positives": positives, "negatives": negatives,
+            "pos_dist": pos_dist, "neg_dist": neg_dist,
+            "hinge_dist": hinge_dist}
+
+
+def calc_var(triplets, dtype=np.float32):
+    """train.py:67-71: mean over everything of (t - mean over [batch,channel])^2."""
+    t = np.asarray(triplets, dtype)
+    mean = np.mean(t, axis=(0, 1), dtype=dtype)
+    return dtype(np.mean(np.square(t - mean), dtype=dtype))
+
+
+# ----------------------------------------------------------------------------
+# indexed triplets (build-defined extension: in-batch negatives; PARITY UNPINNED,
+# no reference counterpart -- SURVEY.md section 8a "no reference row")
+# ----------------------------------------------------------------------------
+def hinge_loss_indexed(E, tri, valid, margin, dtype=np.float32):
+    """Loss over triplets given as row indices into E [R,D].
+
+    tri int[B,3] = (anchor row, positive row, negative row); valid bool[B]
+    masks triplets out (hinge := 0, no gradient) but they still count in the
+    mean's denominator B."""
+    E = np.asarray(E, dtype)
+    a, p, n = E[tri[:, 0]], E[tri[:, 1]], E[tri[:, 2]]
+    pos = np.sum(np.square(a - p), axis=-1, dtype=dtype)
+    neg = np.sum(np.square(a - n), axis=-1, dtype=dtype)
+    hinge = np.maximum(pos - neg + dtype(margin), dtype(0))
+    hinge = np.where(valid, hinge, dtype(0)).astype(dtype)
+    loss = dtype(np.sum(hinge, dtype=dtype) / dtype(len(tri)))
+    return {"hinge_loss": loss, "pos_dist": pos, "neg_dist": neg,
+            "hinge_dist": hinge}
+
+
+def hinge_loss_indexed_backward(E, tri, valid, margin, dtype=np.float32):
+    """dLoss/dE for hinge_loss_indexed, accumulated over shared rows."""
+    E = np.asarray(E, dtype)
+    B = len(tri)
+    a, p, n = E[tri[:, 0]], E[tri[:, 1]], E[tri[:, 2]]
+    pos = np.sum(np.square(a - p), axis=-1, dtype=dtype)
+    neg = np.sum(np.square(a - n), axis=-1, dtype=dtype)
+    act = ((pos - neg + dtype(margin)) >= 0) & valid
+    s = (act.astype(dtype) * dtype(2.0) / dtype(B))[:, None]
+    dE = np.zeros_like(E)
+    np.add.at(dE, tri[:, 0], s * (n - p))
+    np.add.at(dE, tri[:, 1], -s * (a - p))
+    np.add.at(dE, tri[:, 2], s * (a - n))
+    return dE.astype(dtype)
+
+
+# ----------------------------------------------------------------------------
+# backward (what optimizer.compute_gradients builds, train.py:141)
+# ----------------------------------------------------------------------------
+def hinge_loss_backward(triplets, margin, dtype=np.float32):
+    """d mean(hinge) / d triplets  [B,3,D].
+
+    TF's MaximumGrad routes the gradient to x where x >= y, so a triplet with
+    pos-neg+margin == 0 exactly is still 'active'."""
+    t = np.asarray(triplets, dtype)
+    B = t.shape[0]
+    a, p, n = t[:, 0, :], t[:, 1, :], t[:, 2, :]
+    pos = np.sum(np.square(a - p), axis=-1, dtype=dtype)
+    neg = np.sum(np.square(a - n), axis=-1, dtype=dtype)
+    act = ((pos - neg + dtype(margin)) >= 0).astype(dtype)[:, None]
+    s = act * dtype(2.0) / dtype(B)
+    d = np.empty_like(t)
+    d[:, 0, :] = s * (n - p)          # 2(a-p) - 2(a-n)
+    d[:, 1, :] = -s * (a - p)
+    d[:, 2, :] = s * (a - n)
+    return d
+
+
+def l2_normalize_backward(z, inv, g, dtype=np.float32):
+    """Gradient of y = z * rsqrt(max(sum z^2, eps)) wrt z.
+
+    Where the sum is above eps: dz = inv * (g - y * sum(y*g)); where it is
+    clamped the factor is a constant: dz = inv * g."""
+    z = np.asarray(z, dtype)
+    g = np.asarray(g, dtype)
+    y = z * inv
+    ss = np.sum(np.square(z), axis=-1, keepdims=True, dtype=dtype)
+    dot = np.sum(y * g, axis=-1, keepdims=True, dtype=dtype)
+    full = inv * (g - y * dot)
+    clamped = inv * g
+    return np.where(ss > dtype(L2_EPS), full, clamped).astype(dtype)
+
+
+def leaky_relu_backward(y_post, g, alpha=LRELU_ALPHA):
+    """LeakyReluGrad: g where features > 0 else alpha*g.  The sign of the
+    post-activation equals the sign of the pre-activation (alpha > 0)."""
+    return np.where(y_post > 0, g, g * g.dtype.type(alpha))
+
+
+def vnet_backward(fwd, W2, dE, dtype=np.float32, alpha=LRELU_ALPHA):
+    """Backprop dE [R,D] (grad wrt the l2-normalised output) to the four
+    parameter tensors.  The input is a placeholder (train.py:265): no dX."""
+    W2 = np.asarray(W2, dtype)
+    dZ2 = l2_normalize_backward(fwd["layer_2"], fwd["inv_norm_2"], dE, dtype)
+    dZ2 = leaky_relu_backward(fwd["layer_2"], dZ2, alpha).astype(dtype)
+    dW2 = (fwd["layer_1"].T @ dZ2).astype(dtype)
+    db2 = np.sum(dZ2, axis=0, dtype=dtype)
+    dH1 = (dZ2 @ W2.T).astype(dtype)
+    dZ1 = leaky_relu_backward(fwd["layer_1"], dH1, alpha).astype(dtype)
+    dW1 = (fwd["x_hat"].T @ dZ1).astype(dtype)
+    db1 = np.sum(dZ1, axis=0, dtype=dtype)
+    return {"dW1": dW1, "db1": db1, "dW2": dW2, "db2": db2,
+            "dZ2": dZ2, "dZ1": dZ1}
+
+
+def train_step_grads(x, params, margin, dtype=np.float32):
+    """One reference step's loss + gradients for x [3B,F] in a,p,n row order
+    (train.py:313 reshape, :128 reshape back, :130 loss, :141 gradients;
+    regularization_penalty=0 and clip_gradient_norm=0 as in train.py:221-222)."""
+    W1, b1, W2, b2 = params
+    fwd = vnet_forward(x, W1, b1, W2, b2, dtype)
+    D = fwd["l2_norm"].shape[-1]
+    trip = fwd["l2_norm"].reshape(-1, 3, D)
+    loss = hinge_loss(trip, margin, dtype)
+    dE = hinge_loss_backward(trip, margin, dtype).reshape(-1, D)
+    grads = vnet_backward(fwd, W2, dE, dtype)
+    return fwd, loss, grads
+
+
+# ----------------------------------------------------------------------------
+# optimizers + LR schedule (train.py:108-125,146)
+# ----------------------------------------------------------------------------
+def exponential_decay(base_lr, global_step, decay_steps, decay_rate,
+                      staircase=True):
+    """tf.train.exponential_decay (train.py:108-113)."""
+    p = global_step / float(decay_steps)
+    if staircase:
+        p = np.floor(p)
+    return base_lr * (decay_rate ** p)
+
+
+def adam_step(w, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8,
+              dtype=np.float32):
+    """tf.train.AdamOptimizer update at (1-based) step t -- TF form, epsilon
+    OUTSIDE the bias correction:
+        lr_t = lr * sqrt(1-b2^t) / (1-b1^t)
+        m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; w <- w - lr_t m/(sqrt v + eps)
+    Returns new (w, m, v).  PARITY UNPINNED (TF 1.13 source recalled)."""
+    w, g, m, v = (np.asarray(a, dtype) for a in (w, g, m, v))
+    lr_t = dtype(lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
+    m = (dtype(beta1) * m + dtype(1.0 - beta1) * g).astype(dtype)
+    v = (dtype(beta2) * v + dtype(1.0 - beta2) * g * g).astype(dtype)
+    w = (w - lr_t * m / (np.sqrt(v) + dtype(eps))).astype(dtype)
+    return w, m, v
+
+
+def lars_step(w, g, acc, lr, momentum=0.9, weight_decay=1e-4, eeta=1e-3,
+              epsilon=0.0, dtype=np.float32):
+    """tf.contrib.opt.LARSOptimizer (train.py:354) per-variable update with the
+    contrib defaults -- recalled from TF 1.13 source, PARITY UNPINNED:
+        trust = eeta*|w| / (|g| + wd*|w| + eps)   (1.0 if |w|==0 or |g|==0)
+        scaled_lr = lr*trust ; g <- g + wd*w
+        acc <- momentum*acc + scaled_lr*g ; w <- w - acc
+    (the scaled lr is folded into the momentum accumulator, as MomentumOptimizer
+    does with its learning_rate)."""
+    w, g, acc = (np.asarray(a, dtype) for a in (w, g, acc))
+    w_norm = np.sqrt(np.sum(np.square(w, dtype=np.float64)))
+    g_norm = np.sqrt(np.sum(np.square(g, dtype=np.float64)))
+    if w_norm > 0 and g_norm > 0:
+        trust = eeta * w_norm / (g_norm + weight_decay * w_norm + epsilon)
+    else:
+        trust = 1.0
+    scaled_lr = dtype(lr * trust)
+    g = (g + dtype(weight_decay) * w).astype(dtype)
+    acc = (dtype(momentum) * acc + scaled_lr * g).astype(dtype)
+    w = (w - acc).astype(dtype)
+    return w, acc
+
+
+def xavier_uniform(rng, fan_in, fan_out, dtype=np.float32):
+    """slim's default weights_initializer (xavier, uniform): U(+-sqrt(6/(in+out)))."""
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=(fan_in, fan_out)).astype(dtype)

@@ -1,0 +1,263 @@
+"""Pin the oracle: golden fixtures produced by the reference's own modules
+(tests/golden/make_golden.py), the hand-derived loss known answers, Random123
+known-answer vectors for Philox, and torch-CPU autograd for the gradients."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sampler, synth, tower
+
+
+def _kat(golden_dir):
+    with open(os.path.join(golden_dir, "known_answers.json")) as f:
+        return json.load(f)
+
+
+# ---------------------------------------------------------------- sampler ----
+@pytest.mark.parametrize("seed", [0, 1234])
+@pytest.mark.parametrize("n_rows", [3, 10000])
+def test_reference_sampler_matches_golden(golden_dir, seed, n_rows):
+    g = np.load(os.path.join(golden_dir, f"sampler_ref_seed{seed}_n{n_rows}.npz"))
+    got = sampler.reference_triplets(g["pairs"], int(g["n_rows"]), int(g["seed"]))
+    np.testing.assert_array_equal(got, g["triplets"])
+    # the rule itself: negative never equals anchor or positive
+    assert not np.any(got[:, 2] == got[:, 0])
+    assert not np.any(got[:, 2] == got[:, 1])
+
+
+def test_reference_negative_stream_kat(golden_dir):
+    want = _kat(golden_dir)["neg_stream_seed1234_n10000"]
+    assert want == [8915, 1318, 7221, 7540, 664, 6137, 6833, 8471]
+    rs = np.random.RandomState(1234)
+    assert [int(rs.randint(0, 10000)) for _ in range(8)] == want
+
+
+def test_philox_random123_known_answers():
+    def run(ctr, key):
+        return [int(v) for v in sampler.philox4x32_10(ctr, key)]
+    assert run((0, 0, 0, 0), (0, 0)) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert run((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2) == \
+        [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert run((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344),
+               (0xA4093822, 0x299F31D0)) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+@pytest.mark.parametrize("n_rows,batch", [(10000, 128), (3, 32), (5, 17)])
+def test_device_sampler_scalar_vs_vector(n_rows, batch):
+    rng = np.random.RandomState(1)
+    pairs = rng.randint(0, n_rows, size=(100, 2))
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+    for step in (0, 1, 7, 2 ** 33 + 5):
+        a = sampler.device_triplets(pairs, n_rows, 1234, step, batch)
+        b = sampler.device_triplets_vec(pairs, n_rows, 1234, step, batch)
+        np.testing.assert_array_equal(a, b)
+        assert not np.any(a[:, 2] == a[:, 0]) and not np.any(a[:, 2] == a[:, 1])
+        assert a[:, 2].min() >= 0 and a[:, 2].max() < n_rows
+        # sequential pair stream with wrap-around (inputs.py:110-122)
+        q = (step * batch + np.arange(batch)) % len(pairs)
+        np.testing.assert_array_equal(a[:, :2], pairs[q])
+
+
+def test_device_sampler_rank_slices_agree():
+    pairs = synth.cowatch_pairs(1000, 300, 0)
+    full = sampler.device_triplets_vec(pairs, 1000, 7, 3, 64)
+    halves = [sampler.device_triplets_vec(pairs, 1000, 7, 3, 32, slot0=r * 32,
+                                          batch_global=64) for r in (0, 1)]
+    np.testing.assert_array_equal(full, np.concatenate(halves))
+
+
+def test_device_sampler_is_uniform():
+    pairs = np.array([[0, 1]])
+    n = np.concatenate([sampler.device_triplets_vec(pairs, 10, 5, s, 4096)[:, 2]
+                        for s in range(4)])
+    counts = np.bincount(n, minlength=10)
+    assert counts[0] == 0 and counts[1] == 0
+    assert np.all(np.abs(counts[2:] / counts[2:].sum() - 1 / 8) < 0.01)
+
+
+def test_inbatch_spec():
+    pairs = synth.cowatch_pairs(50, 40, 1)
+    for step in range(5):
+        rows, tri, valid, s = sampler.device_inbatch(pairs, 9, step, 16)
+        assert 1 <= s <= 15
+        ap = rows.reshape(-1, 2)
+        for i in range(16):
+            j = (i + s) % 16
+            assert tuple(tri[i]) == (2 * i, 2 * i + 1, 2 * j + 1)
+            assert valid[i] == (ap[j, 1] not in (ap[i, 0], ap[i, 1]))
+    assert sampler.num_batches(10, 3, 4) == 7
+
+
+# ------------------------------------------------------------------ synth ----
+def test_synth_features_match_imitation_data(golden_dir):
+    g = np.load(os.path.join(golden_dir, "imitation_features_seed0.npz"))
+    got = synth.features_numpy(8, 1500, seed=0)
+    np.testing.assert_array_equal(got, g["features"])
+    assert got.dtype == np.float64 and got.min() >= 0 and got.max() < 1
+    assert _kat(golden_dir)["gen_triplets_shape"] == [4, 3, 16]
+
+
+def test_synth_pairs_shape():
+    p = synth.cowatch_pairs(10000, 3000, 0)
+    assert p.dtype == np.int32 and p.shape[1] == 2
+    assert not np.any(p[:, 0] == p[:, 1])
+    assert 3000 * 5 < len(p) < 3000 * 29
+    kat_pairs = [[1, 2], [3, 4], [4, 5], [5, 6], [7, 8], [8, 9]]
+    assert len(kat_pairs) == 6
+
+
+def test_get_all_cowatch_kat(golden_dir):
+    k = _kat(golden_dir)
+    assert k["get_all_cowatch_len"] == 6
+    assert k["get_all_cowatch_sorted"] == [[1, 2], [3, 4], [4, 5], [5, 6], [7, 8], [8, 9]]
+
+
+# ------------------------------------------------------------------- loss ----
+@pytest.mark.parametrize("margin", [0.1, 0.8])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hinge_loss_known_answer(golden_dir, margin, dtype):
+    k = _kat(golden_dir)
+    out = tower.hinge_loss(np.array(k["loss_input"], dtype), margin, dtype)
+    want = k[f"loss_margin_{margin}"]
+    assert out["pos_dist"].shape == (5, 1) and out["hinge_dist"].shape == (5, 1)
+    np.testing.assert_allclose(out["pos_dist"][:, 0], k["loss_pos_dist"])
+    np.testing.assert_allclose(out["neg_dist"][:, 0], k["loss_neg_dist"])
+    np.testing.assert_allclose(out["hinge_dist"][:, 0], want["hinge_dist"], rtol=1e-6)
+    np.testing.assert_allclose(out["hinge_loss"], want["hinge_loss"], rtol=1e-6)
+    assert out["anchors"].shape == (5, 1, 2)
+
+
+def test_eval_mean_dist_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "evaluate_mean_dist.npz"))
+    emb, cw = g["embeddings"], g["eval_cowatches"]
+    d = np.mean(np.sum(np.square(emb[cw[:, 0]] - emb[cw[:, 1]]), axis=-1))
+    np.testing.assert_allclose(d, float(g["mean_dist"]), rtol=1e-6)
+
+
+# ---------------------------------------------------------- tower + grads ----
+def _torch_reference(x, params, margin):
+    """The same graph written with torch ops (NOT F.normalize / nn.Linear
+    defaults -- TF semantics spelled out) so autograd checks the hand backward."""
+    W1, b1, W2, b2 = [torch.tensor(p, dtype=torch.float64, requires_grad=True)
+                      for p in params]
+    x = torch.tensor(x, dtype=torch.float64)
+
+    def l2n(t):
+        return t * torch.rsqrt(torch.clamp((t * t).sum(-1, keepdim=True), min=1e-12))
+
+    def lrelu(t):
+        return torch.maximum(0.2 * t, t)
+
+    h1 = lrelu(l2n(x) @ W1 + b1)
+    z = lrelu(h1 @ W2 + b2)
+    e = l2n(z).reshape(-1, 3, z.shape[-1])
+    a, p, n = e[:, 0], e[:, 1], e[:, 2]
+    hinge = torch.clamp(((a - p) ** 2).sum(-1) - ((a - n) ** 2).sum(-1) + margin, min=0)
+    loss = hinge.mean()
+    loss.backward()
+    return loss.item(), e.detach().numpy(), [t.grad.numpy() for t in (W1, b1, W2, b2)]
+
+
+def _small_problem(B=6, F=40, H=24, D=8, seed=0):
+    rng = np.random.RandomState(seed)
+    x = rng.random_sample((3 * B, F))
+    params = [tower.xavier_uniform(rng, F, H, np.float64), 0.1 * rng.randn(H),
+              tower.xavier_uniform(rng, H, D, np.float64), 0.1 * rng.randn(D)]
+    return x, params
+
+
+def test_tower_and_grads_vs_torch_autograd_fp64():
+    x, params = _small_problem()
+    fwd, loss, grads = tower.train_step_grads(x, params, 0.8, np.float64)
+    tl, te, tg = _torch_reference(x, params, 0.8)
+    np.testing.assert_allclose(loss["hinge_loss"], tl, rtol=1e-12)
+    np.testing.assert_allclose(fwd["l2_norm"].reshape(te.shape), te, atol=1e-13)
+    for name, g in zip(("dW1", "db1", "dW2", "db2"), tg):
+        np.testing.assert_allclose(grads[name], g, atol=1e-13, err_msg=name)
+    assert np.any(loss["hinge_dist"] > 0)
+
+
+def test_tower_fp32_close_to_fp64():
+    x, params = _small_problem(B=16, F=300, H=200, D=32, seed=3)
+    f32, l32, g32 = tower.train_step_grads(x, params, 0.8, np.float32)
+    f64, l64, g64 = tower.train_step_grads(x, params, 0.8, np.float64)
+    assert f32["l2_norm"].dtype == np.float32
+    np.testing.assert_allclose(f32["l2_norm"], f64["l2_norm"], atol=1e-5)
+    np.testing.assert_allclose(l32["hinge_loss"], l64["hinge_loss"], atol=1e-5)
+    np.testing.assert_allclose(np.linalg.norm(f32["l2_norm"], axis=-1), 1, atol=1e-5)
+
+
+def test_l2_normalize_is_tf_form_not_torch_form():
+    x = np.array([[3e-7, 4e-7]], np.float64)      # |x|^2 = 2.5e-13 < eps
+    y, inv = tower.l2_normalize(x, np.float64)
+    np.testing.assert_allclose(inv, 1e6)          # rsqrt(1e-12), not 1/|x|
+    np.testing.assert_allclose(y, x * 1e6)
+    g = np.array([[1.0, 2.0]])
+    np.testing.assert_allclose(tower.l2_normalize_backward(x, inv, g, np.float64), g * 1e6)
+
+
+def test_indexed_loss_matches_plain_loss_on_reference_layout():
+    rng = np.random.RandomState(2)
+    E = rng.randn(30, 8)
+    tri = np.arange(30).reshape(10, 3)
+    valid = np.ones(10, bool)
+    a = tower.hinge_loss_indexed(E, tri, valid, 0.8, np.float64)
+    b = tower.hinge_loss(E.reshape(10, 3, 8), 0.8, np.float64)
+    np.testing.assert_allclose(a["hinge_loss"], b["hinge_loss"])
+    da = tower.hinge_loss_indexed_backward(E, tri, valid, 0.8, np.float64)
+    db = tower.hinge_loss_backward(E.reshape(10, 3, 8), 0.8, np.float64)
+    np.testing.assert_allclose(da, db.reshape(30, 8))
+
+
+def test_indexed_loss_backward_vs_autograd():
+    rng = np.random.RandomState(4)
+    E = rng.randn(16, 8)
+    _, tri, valid, _ = sampler.device_inbatch(np.array([[1, 2], [3, 4], [2, 5], [6, 1]]),
+                                              3, 0, 8)
+    valid = valid.astype(bool)
+    Et = torch.tensor(E, requires_grad=True)
+    a, p, n = Et[tri[:, 0]], Et[tri[:, 1]], Et[tri[:, 2]]
+    h = torch.clamp(((a - p) ** 2).sum(-1) - ((a - n) ** 2).sum(-1) + 0.8, min=0)
+    (h * torch.tensor(valid)).sum().div(8).backward()
+    got = tower.hinge_loss_indexed_backward(E, tri, valid, 0.8, np.float64)
+    np.testing.assert_allclose(got, Et.grad.numpy(), atol=1e-13)
+
+
+# -------------------------------------------------------------- optimizers ---
+def test_adam_tf_form():
+    w = np.array([1.0, -2.0]); g = np.array([0.5, 0.25])
+    m = np.zeros(2); v = np.zeros(2)
+    w1, m1, v1 = tower.adam_step(w, g, m, v, 1, 0.01, dtype=np.float64)
+    lr_t = 0.01 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    np.testing.assert_allclose(m1, 0.1 * g)
+    np.testing.assert_allclose(v1, 0.001 * g * g)
+    np.testing.assert_allclose(w1, w - lr_t * m1 / (np.sqrt(v1) + 1e-8))
+    # differs from torch.optim.Adam's epsilon placement when g is tiny
+    g2 = np.array([1e-9, 1e-9])
+    w2, _, _ = tower.adam_step(w, g2, m, v, 1, 0.01, dtype=np.float64)
+    tw = torch.tensor(w, requires_grad=True)
+    opt = torch.optim.Adam([tw], lr=0.01)
+    tw.grad = torch.tensor(g2); opt.step()
+    assert np.abs(w2 - tw.detach().numpy()).max() > 1e-4
+
+
+def test_lars_and_lr_schedule():
+    w = np.array([3.0, 4.0]); g = np.array([0.6, 0.8]); acc = np.zeros(2)
+    w1, acc1 = tower.lars_step(w, g, acc, 1.0, dtype=np.float64)
+    trust = 1e-3 * 5.0 / (1.0 + 1e-4 * 5.0)
+    np.testing.assert_allclose(acc1, trust * (g + 1e-4 * w))
+    np.testing.assert_allclose(w1, w - acc1)
+    w0, _ = tower.lars_step(np.zeros(2), g, acc, 1.0, dtype=np.float64)
+    np.testing.assert_allclose(w0, -g)           # trust 1 when |w| == 0
+    assert tower.exponential_decay(1.0, 999999, 1000000, 0.96) == 1.0
+    np.testing.assert_allclose(tower.exponential_decay(1.0, 2500000, 1000000, 0.96), 0.96 ** 2)
+
+
+def test_calc_var():
+    t = np.random.RandomState(0).randn(5, 3, 4)
+    want = np.mean((t - t.mean(axis=(0, 1))) ** 2)
+    np.testing.assert_allclose(tower.calc_var(t, np.float64), want)
