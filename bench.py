@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Headline benchmark: triplets/s of the full training step (sample + gather +
+tower fwd + hinge loss + backward + Adam) on synthetic imitation_data-shaped
+input, BASELINE.json config 1 at N=1:
+
+    1 x MI355X, 1M videos x 1500-d fp32 in HBM, 5000 hidden, 256-d embedding,
+    batch 4096 triplets, in-batch negatives, margin 0.8, Adam.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling --
+every rank keeps batch 4096; the catalogue becomes config 3's 10M rows,
+row-sharded, with an RCCL all-to-all of sampled rows and an all-reduce of the
+gradients per step.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the
+1500x5000 projection GEMMs, MFMA-bound), timed live with events on the launch
+stream over the timed steps; `gather` reports the HBM side the metric also
+names; `cpu_baseline` is the CPU oracle (numpy restatement of the reference
+step) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F, H, D = 1500, 5000, 256
+BATCH = 4096
+MARGIN = 0.8
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: matrix FP32 (spec)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def synth_pairs(n_videos, n_users, seed):
+    """imitation_data.py:56-85-shaped co-watch pairs (own generator, product side)."""
+    rng = np.random.RandomState(seed)
+    lens = rng.randint(2, 31, size=n_users)
+    vids = rng.randint(0, n_videos, size=int(lens.sum()))
+    last = np.zeros(len(vids), dtype=bool)
+    last[np.cumsum(lens) - 1] = True
+    keep = ~last[:-1] & (vids[:-1] != vids[1:])
+    pairs = np.stack([vids[:-1][keep], vids[1:][keep]], axis=1)
+    rng.shuffle(pairs)
+    return pairs.astype(np.int32)
+
+
+class KernelTimer:
+    """Event pairs around individual launches on the current stream."""
+
+    def __init__(self):
+        self.ev = {}
+        self.on = False
+
+    def wrap(self, name, fn):
+        def timed(*a, **k):
+            if not self.on:
+                return fn(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **k)
+            e.record()
+            self.ev.setdefault(name, []).append((s, e))
+            return r
+        return timed
+
+    def mean_ms(self, name):
+        v = [s.elapsed_time(e) for s, e in self.ev.get(name, [])]
+        return float(np.mean(v)) if v else None
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle's restatement of one reference training step (numpy gather as
+    inputs.py:158 + fp32 tower fwd/bwd + Adam), timed on the host cores."""
+    from oracle import sampler as osampler, tower as otower
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    n_rows, B = 50000, 256
+    rng = np.random.RandomState(0)
+    table = rng.random_sample((n_rows, F)).astype(np.float32)
+    pairs = synth_pairs(n_rows, 5000, 0)
+    W = [otower.xavier_uniform(rng, F, H), np.zeros(H, np.float32),
+         otower.xavier_uniform(rng, H, D), np.zeros(D, np.float32)]
+    m = [np.zeros_like(w) for w in W]
+    v = [np.zeros_like(w) for w in W]
+
+    def one_step(step):
+        rows, tri, valid, _ = osampler.device_inbatch(pairs, 1234, step, B)
+        x = osampler.gather(table, rows)
+        fwd = otower.vnet_forward(x, *W, dtype=np.float32)
+        otower.hinge_loss_indexed(fwd["l2_norm"], tri, valid.astype(bool), MARGIN, np.float32)
+        dE = otower.hinge_loss_indexed_backward(fwd["l2_norm"], tri, valid.astype(bool), MARGIN, np.float32)
+        g = otower.vnet_backward(fwd, W[2], dE, np.float32)
+        for i, k in enumerate(("dW1", "db1", "dW2", "db2")):
+            W[i], m[i], v[i] = otower.adam_step(W[i], g[k], m[i], v[i], step + 1, 0.01)
+
+    one_step(0)
+    t0, n = time.time(), 0
+    while time.time() - t0 < budget_s:
+        one_step(n + 1)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n * B / dt, 1), "unit": "triplets/s", "cores": int(threads), "kind": "port",
+            "sample": "%d oracle steps (numpy fp32 restatement of the reference step incl. gather "
+                      "and Adam) of %d in-batch triplets on a %dx%d host table, %.1f s"
+                      % (n, B, n_rows, F, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=None, help="catalogue rows (default: 1M, or 10M when --gpus > 1)")
+    ap.add_argument("--mode", default="inbatch", choices=["inbatch", "uniform"])
+    ap.add_argument("--batch", type=int, default=BATCH, help="triplets per GPU per step")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                     "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        sys.exit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    from cdml_amd import dist as cdist, engine, ops, train
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_rows = args.rows or (1000000 if world == 1 else 10000000)
+    B = args.batch
+    if world > 1:
+        lo, hi, _ = cdist.shard_bounds(n_rows, world, rank)
+        table = engine.FeatureTable.synthetic(hi - lo, F, seed=0, device=dev, row0=lo, n_rows_global=n_rows)
+        exchange, grad_sync = cdist.RowExchange(n_rows), cdist.GradSync()
+    else:
+        table = engine.FeatureTable.synthetic(n_rows, F, seed=0, device=dev)
+        exchange = grad_sync = None
+    pairs = torch.from_numpy(synth_pairs(n_rows, max(n_rows // 3, 1000), seed=0)).to(dev)
+
+    ts = train.TrainStep(table, pairs, B, output_size=D, hidden_size=H, margin=MARGIN, mode=args.mode,
+                         optimizer="adam", base_learning_rate=0.01, seed=1234, weight_seed=42,
+                         device=dev, exchange=exchange, grad_sync=grad_sync, slot0=rank * B,
+                         batch_global=world * B, use_graph=args.graph)
+
+    # per-kernel event timers on the launch stream (off during graph replay)
+    kt = KernelTimer()
+    timers_on = not args.no_kernel_timers and not args.graph
+    if timers_on:
+        real_fwd, real_bww = ops.fc_lrelu_fwd, ops.fc_bwd_weight
+        L = ts.layout
+
+        def fwd(x, W, b, y, M, K, N, *a, **k):
+            name = "fc1_fwd" if K == L.Fp else "fc2_fwd"
+            return kt.wrap(name, real_fwd)(x, W, b, y, M, K, N, *a, **k)
+
+        def bww(x, dy, dW, db, ws, M, K, N):
+            name = "dW1" if K == L.Fp else "dW2"
+            return kt.wrap(name, real_bww)(x, dy, dW, db, ws, M, K, N)
+        ops.fc_lrelu_fwd, ops.fc_bwd_weight = fwd, bww
+        ts.fetch = kt.wrap("fetch", ts.fetch)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        ts.step()
+    sync_all()
+    kt.on = timers_on
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts.step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kt.on = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = ts.loss()
+    assert np.isfinite(loss), "non-finite loss"
+
+    if rank == 0:
+        rpt = ts.rows_per_triplet
+        R = B * rpt
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "triplets/sec", "value": round(world * B * args.steps / elapsed, 1),
+            "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config1: %d videos x %d-d fp32 in HBM, %d hidden, %d-d embed, "
+                                   "batch %d triplets/GPU, %s negatives, margin %.1f, Adam, full step "
+                                   "(sample+gather+fwd+loss+bwd+opt)"
+                                   % (n_rows, F, H, D, B, "in-batch" if args.mode == "inbatch" else "uniform random", MARGIN),
+                       "global_batch": world * B, "rows_per_triplet": rpt,
+                       "parallelism": "dp%d" % world + ("" if world == 1 else " row-sharded table, all-to-all rows + all-reduce grads"),
+                       "hipgraph": bool(args.graph)},
+            "loss": round(loss, 6),
+        }
+        flops_gemm = 2.0 * R * F * H                        # algorithmic, unpadded
+        if timers_on:
+            cand = {k: kt.mean_ms(k) for k in ("fc1_fwd", "dW1")}
+            dom = max(cand, key=lambda k: cand[k] or 0)
+            t_ms = cand[dom]
+            ach = flops_gemm / (t_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                               "launch_ms": round(t_ms, 4), "flop_per_launch": flops_gemm}
+            kern = {}
+            for k in ("fc1_fwd", "fc2_fwd", "dW1", "dW2", "fetch"):
+                if kt.mean_ms(k) is not None:
+                    kern[k + "_ms"] = round(kt.mean_ms(k), 4)
+            out["kernels"] = kern
+            t_f = kt.mean_ms("fetch")
+            if t_f and world == 1:
+                gbytes = 2.0 * R * F * 4                     # rows read + normalised rows written
+                g_ach = gbytes / (t_f * 1e-3) / 1e9
+                out["gather"] = {"bound": "hbm", "achieved": round(g_ach, 1), "peak": PEAK_HBM_GBS,
+                                 "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4),
+                                 "bytes_per_launch": gbytes, "launch_ms": round(t_f, 4)}
+        step_flops = R * (2.0 * F * H + 2.0 * H * D) + R * (2.0 * F * H + 4.0 * H * D)
+        out["step_tflops"] = round(step_flops / (elapsed / args.steps) / 1e12, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

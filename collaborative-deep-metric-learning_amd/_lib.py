@@ -1,0 +1,85 @@
+"""ctypes binding of libcdml_hip.so (the C ABI declared in include/cdml.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call
+fails, the product raises.  PyTorch is used only for device memory and streams.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libcdml_hip.so"
+
+
+class CdmlError(RuntimeError):
+    """A C-ABI call returned a negative cdml_status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"cdml status {code}: {message}")
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", _LIB_NAME)
+
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_u64 = C.c_uint64
+_f = C.c_float
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/cdml.h declares
+SIGNATURES = {
+    "cdml_version": (_i, []),
+    "cdml_last_error": (C.c_char_p, []),
+    "cdml_fill_uniform_table": (_i, [_p, _i64, _i64, _i, _i64, _u64, _p]),
+    "cdml_sample_uniform": (_i, [_p, _i64, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _p]),
+    "cdml_sample_inbatch": (_i, [_p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _p, _p]),
+    "cdml_step_advance": (_i, [_p, _p]),
+    "cdml_gather_rows": (_i, [_p, _i64, _i64, _i64, _p, _i, _i, _i, _p, _i64, _p, _p, _p]),
+    "cdml_sample_gather": (_i, [_i, _p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _i64, _i64, _i,
+                                _p, _p, _p, _i64, _p]),
+    "cdml_l2norm_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p]),
+    "cdml_l2norm_bwd": (_i, [_p, _i64, _p, _i64, _i, _i, _f, _p, _i64, _p]),
+    "cdml_fc_lrelu_fwd": (_i, [_p, _i64, _p, _i64, _p, _f, _i, _i, _i, _p, _i64, _p]),
+    "cdml_fc_bwd_data": (_i, [_p, _i64, _p, _i64, _p, _i64, _f, _i, _i, _i, _p, _i64, _p]),
+    "cdml_fc_bwd_weight_workspace": (_sz, [_i, _i, _i]),
+    "cdml_fc_bwd_weight": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _sz, _p]),
+    "cdml_triplet_hinge": (_i, [_p, _i64, _i, _i, _f, _p, _p, _p, _p, _p, _i64, _p]),
+    "cdml_triplet_hinge_inbatch": (_i, [_p, _i64, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p,
+                                        _i64, _p]),
+    "cdml_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _i64, _p, _p]),
+    "cdml_lars_scratch_floats": (_sz, []),
+    "cdml_lars_step": (_i, [_p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p, _p]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load libcdml_hip.so (built by __graft_entry__.build()); raise if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise CdmlError(-2, f"{path} not found: build it with "
+                            f"`python -c 'import __graft_entry__ as g; g.build()'` "
+                            f"(there is no CPU fallback)")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; raise CdmlError on failure."""
+    lib = load_library()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise CdmlError(rc, lib.cdml_last_error().decode("utf-8", "replace"))
+    return rc

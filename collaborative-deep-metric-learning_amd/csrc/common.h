@@ -1,0 +1,112 @@
+// Shared host/device helpers for libcdml_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/cdml.h"
+
+namespace cdml {
+
+// ---- per-thread error message ------------------------------------------------
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+#define CDML_REQUIRE(cond, code, ...)                  \
+  do {                                                 \
+    if (!(cond)) return ::cdml::fail((code), __VA_ARGS__); \
+  } while (0)
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return fail(CDML_E_HIP, "%s: %s", what, hipGetErrorString(e));
+  return CDML_OK;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;
+
+// ---- device helpers -----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Philox4x32-10 (Salmon et al., Random123); spec + known answers: oracle/sampler.py
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+    uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    c = u32x4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    k0 += W0;
+    k1 += W1;
+  }
+  return c;
+}
+
+__device__ __forceinline__ uint32_t pick(const u32x4 &v, int i) {
+  return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+constexpr int kMaxWords = 64;             // oracle/sampler.py MAX_WORDS
+constexpr uint32_t kPurposeUniformNeg = 0;
+constexpr uint32_t kPurposeInbatchShift = 1;
+constexpr uint32_t kTableTag = 0x7AB1E000u;
+
+// Word stream of (seed, step, slot, purpose); bounded() = Lemire multiply-shift.
+struct WordStream {
+  uint32_t slot, step_lo, step_hi, purpose, k0, k1;
+  int j;
+  u32x4 blk;
+  __device__ WordStream(uint64_t seed, uint64_t step, uint32_t slot_, uint32_t purpose_)
+      : slot(slot_), step_lo((uint32_t)step), step_hi((uint32_t)(step >> 32)),
+        purpose(purpose_), k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), j(0) {}
+  __device__ bool exhausted() const { return j >= kMaxWords; }
+  __device__ uint32_t next() {
+    if ((j & 3) == 0)
+      blk = philox4x32_10(u32x4{slot, step_lo, step_hi, (purpose << 24) | (uint32_t)(j >> 2)}, k0, k1);
+    uint32_t w = pick(blk, j & 3);
+    ++j;
+    return w;
+  }
+  // returns -1 when the stream is exhausted
+  __device__ int64_t bounded(uint32_t n) {
+    uint32_t thresh = (0u - n) % n;
+    while (!exhausted()) {
+      uint64_t m = (uint64_t)next() * n;
+      if ((uint32_t)m >= thresh) return (int64_t)(m >> 32);
+    }
+    return -1;
+  }
+};
+
+__device__ __forceinline__ int32_t sample_uniform_negative(uint64_t seed, uint64_t step,
+                                                           uint32_t slot, int32_t a, int32_t p,
+                                                           uint32_t n_rows) {
+  WordStream ws(seed, step, slot, kPurposeUniformNeg);
+  for (;;) {
+    int64_t n = ws.bounded(n_rows);
+    if (n < 0) break;
+    if (n != a && n != p) return (int32_t)n;
+  }
+  for (uint32_t n = 0; n < n_rows; ++n)  // deterministic fallback
+    if ((int32_t)n != a && (int32_t)n != p) return (int32_t)n;
+  return 0;
+}
+
+__device__ __forceinline__ int32_t sample_inbatch_shift(uint64_t seed, uint64_t step, int batch) {
+  WordStream ws(seed, step, 0u, kPurposeInbatchShift);
+  int64_t r = ws.bounded((uint32_t)(batch - 1));
+  return 1 + (int32_t)(r < 0 ? 0 : r);
+}
+
+}  // namespace cdml

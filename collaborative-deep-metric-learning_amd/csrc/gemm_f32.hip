@@ -1,0 +1,437 @@
+// fp32 MFMA GEMMs of the embedding tower (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// Reference: the two slim.fully_connected layers of VNet (models.py:59-60 via
+// :19-30) and their autodiff (train.py:141): per row 2*F*H + 2*H*D flop forward
+// and 2*F*H + 4*H*D backward (no dX: the input is a placeholder, train.py:265).
+//
+// Roofline: MFMA.  fp32-in/fp32-acc MFMA is an exact k-ordered fmaf chain, so
+// the 1e-5 parity bound against the fp32 reference path holds; peak 157.3 TF.
+//
+// One kernel template covers the three operand layouts:
+//   fwd         y  = lrelu(x  @ W + b)      A k-contiguous, B k-strided
+//   bwd data    dx = (dy @ W^T) * lrelu'    A k-contiguous, B k-contiguous
+//   bwd weight  dW = x^T @ dy (+ colsum dy) A k-strided,    B k-strided, split-K
+// Block = 4 waves (2x2), wave tile = (32*TM) x (32*TN) via TM*TN 32x32x2 MFMAs
+// per k-pair, BK = 32, register-staged double-buffered LDS (one barrier per
+// K-tile).  k-contiguous operands sit in LDS as [row][BK+4] and are read with
+// ds_read_b128 (4 k per lane; lane-half h takes k = 8g+4h+t for MFMA t, the
+// other operand uses the same k permutation); k-strided operands sit as
+// [k][cols] and are read with ds_read_b32.  Both patterns are bank-conflict
+// free.  Workgroups are dealt to XCDs in contiguous chunks of a grouped raster
+// so the tiles sharing an A/B panel hit the same L2.
+#include "common.h"
+
+namespace cdml {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kThreads = 256;
+constexpr int BK = 32;
+constexpr int KPAD = 4;
+
+enum { EPI_STORE = 0, EPI_BIAS_LRELU = 1, EPI_LRELU_MASK = 2, EPI_SLAB_COLSUM = 3 };
+
+struct GemmArgs {
+  const float *A; int64_t lda;
+  const float *B; int64_t ldb;
+  float *C; int64_t ldc;
+  const float *bias;             // EPI_BIAS_LRELU
+  const float *aux; int64_t ldaux;  // EPI_LRELU_MASK (may be null)
+  float *colsum;                 // EPI_SLAB_COLSUM: [splits][N] (may be null)
+  float alpha;
+  int M, N, K;                   // output M x N, contraction K
+  int k_per_split;               // multiple of BK; blockIdx.y = split
+  int64_t slab_stride;           // elements between split outputs
+  int tiles_m, tiles_n;
+};
+
+// XCD-aware bijective remap (blocks b and b+8 share an XCD) followed by a
+// grouped raster: 8 M-tiles x all N-tiles per group.
+__device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int tiles_n, int &tm,
+                                              int &tn) {
+  const int xcd = bid & 7, local = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  constexpr int GROUP_M = 8;
+  const int width = GROUP_M * tiles_n;
+  const int group = logical / width;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(tiles_m - first_m, GROUP_M);
+  const int in_group = logical - group * width;
+  tm = first_m + in_group % gsize;
+  tn = in_group / gsize;
+}
+
+template <bool AKC, bool BKC, int TM, int TN, int EPI>
+__global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int A_TILE = AKC ? BM * (BK + KPAD) : BK * BM;
+  constexpr int B_TILE = BKC ? BN * (BK + KPAD) : BK * BN;
+  constexpr int A_REGS = BM / 32, B_REGS = BN / 32;  // float4 staging registers per thread
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int split = blockIdx.y;
+  const int k_begin = split * g.k_per_split;
+  const int k_end = min(g.K, k_begin + g.k_per_split);
+  const int n_ktiles = (k_end - k_begin + BK - 1) / BK;
+
+  float4 ra[A_REGS], rb[B_REGS];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool do_colsum = (EPI == EPI_SLAB_COLSUM) && g.colsum && tm == 0;
+
+  auto load_tile = [&](int kt) {
+    const int k0 = k_begin + kt * BK;
+    if (AKC) {  // rows [m0, m0+BM) x k [k0, k0+32): 8 float4 per row
+#pragma unroll
+      for (int p = 0; p < A_REGS; ++p) {
+        const int row = m0 + p * 32 + (t >> 3);
+        ra[p] = (row < g.M)
+                    ? *reinterpret_cast<const float4 *>(g.A + (int64_t)row * g.lda + k0 + (t & 7) * 4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {  // k rows [k0, k0+32) x cols [m0, m0+BM)
+      constexpr int C4 = BM / 4, KR = kThreads / C4;
+#pragma unroll
+      for (int p = 0; p < A_REGS; ++p) {
+        const int k = k0 + p * KR + t / C4;
+        ra[p] = (k < k_end)
+                    ? *reinterpret_cast<const float4 *>(g.A + (int64_t)k * g.lda + m0 + (t % C4) * 4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (BKC) {
+#pragma unroll
+      for (int p = 0; p < B_REGS; ++p) {
+        const int row = n0 + p * 32 + (t >> 3);
+        rb[p] = *reinterpret_cast<const float4 *>(g.B + (int64_t)row * g.ldb + k0 + (t & 7) * 4);
+      }
+    } else {
+      constexpr int C4 = BN / 4, KR = kThreads / C4;
+#pragma unroll
+      for (int p = 0; p < B_REGS; ++p) {
+        const int k = k0 + p * KR + t / C4;
+        rb[p] = (k < k_end)
+                    ? *reinterpret_cast<const float4 *>(g.B + (int64_t)k * g.ldb + n0 + (t % C4) * 4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == EPI_SLAB_COLSUM && do_colsum) {
+          bsum.x += rb[p].x; bsum.y += rb[p].y; bsum.z += rb[p].z; bsum.w += rb[p].w;
+        }
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    float *sA = smem + buf * (A_TILE + B_TILE);
+    float *sB = sA + A_TILE;
+    if (AKC) {
+#pragma unroll
+      for (int p = 0; p < A_REGS; ++p)
+        *reinterpret_cast<float4 *>(sA + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = ra[p];
+    } else {
+      constexpr int C4 = BM / 4, KR = kThreads / C4;
+#pragma unroll
+      for (int p = 0; p < A_REGS; ++p)
+        *reinterpret_cast<float4 *>(sA + (p * KR + t / C4) * BM + (t % C4) * 4) = ra[p];
+    }
+    if (BKC) {
+#pragma unroll
+      for (int p = 0; p < B_REGS; ++p)
+        *reinterpret_cast<float4 *>(sB + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = rb[p];
+    } else {
+      constexpr int C4 = BN / 4, KR = kThreads / C4;
+#pragma unroll
+      for (int p = 0; p < B_REGS; ++p)
+        *reinterpret_cast<float4 *>(sB + (p * KR + t / C4) * BN + (t % C4) * 4) = rb[p];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  if (n_ktiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < n_ktiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < n_ktiles) load_tile(kt + 1);  // global loads in flight under the MFMAs
+
+    const float *sA = smem + buf * (A_TILE + B_TILE);
+    const float *sB = sA + A_TILE;
+#pragma unroll
+    for (int grp = 0; grp < BK / 8; ++grp) {
+      float a[TM][4], b[TN][4];
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int row = wm * 32 * TM + mi * 32 + l31;
+        if (AKC) {
+          const float4 v = *reinterpret_cast<const float4 *>(sA + row * (BK + KPAD) + 8 * grp + 4 * h);
+          a[mi][0] = v.x; a[mi][1] = v.y; a[mi][2] = v.z; a[mi][3] = v.w;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a[mi][u] = sA[(8 * grp + 4 * h + u) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int col = wn * 32 * TN + ni * 32 + l31;
+        if (BKC) {
+          const float4 v = *reinterpret_cast<const float4 *>(sB + col * (BK + KPAD) + 8 * grp + 4 * h);
+          b[ni][0] = v.x; b[ni][1] = v.y; b[ni][2] = v.z; b[ni][3] = v.w;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) b[ni][u] = sB[(8 * grp + 4 * h + u) * BN + col];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][u], b[ni][u], acc[mi][ni], 0, 0, 0);
+    }
+
+    if (kt + 1 < n_ktiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float *C = g.C + (EPI == EPI_SLAB_COLSUM ? (int64_t)split * g.slab_stride : 0);
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int col = n0 + wn * 32 * TN + ni * 32 + l31;
+      float bias = 0.f;
+      if (EPI == EPI_BIAS_LRELU) bias = g.bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < g.M) {
+          float v = acc[mi][ni][r];
+          if (EPI == EPI_BIAS_LRELU) {
+            v += bias;
+            v = fmaxf(v, v * g.alpha);
+          } else if (EPI == EPI_LRELU_MASK) {
+            if (g.aux) v *= (g.aux[(int64_t)row * g.ldaux + col] > 0.f) ? 1.f : g.alpha;
+          }
+          C[(int64_t)row * g.ldc + col] = v;
+        }
+      }
+    }
+  }
+
+  if (EPI == EPI_SLAB_COLSUM && do_colsum) {
+    // threads with equal (t % C4) hold partial sums of the same 4 columns
+    constexpr int C4 = BN / 4, KR = kThreads / C4;
+    __syncthreads();
+    float4 *red = reinterpret_cast<float4 *>(smem);
+    red[t] = bsum;
+    __syncthreads();
+    if (t < C4) {
+      float4 s = red[t];
+      for (int j = 1; j < KR; ++j) {
+        const float4 v = red[t + j * C4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      *reinterpret_cast<float4 *>(g.colsum + (int64_t)split * g.N + n0 + t * 4) = s;
+    }
+  }
+}
+
+// out[i] = sum_z slab[z][i] in a fixed order (deterministic split-K combine).
+__global__ void __launch_bounds__(kThreads)
+k_sum_slabs(const float *__restrict__ slabs, int64_t slab_stride, int splits, int64_t n4,
+            float *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 s = reinterpret_cast<const float4 *>(slabs)[i];
+    for (int z = 1; z < splits; ++z) {
+      const float4 v = reinterpret_cast<const float4 *>(slabs + (int64_t)z * slab_stride)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4 *>(out)[i] = s;
+  }
+}
+
+// dW[K][lddw] <- slab[K][N] rows (when lddw != N the combine is row-wise)
+__global__ void __launch_bounds__(kThreads)
+k_sum_slabs_2d(const float *__restrict__ slabs, int64_t slab_stride, int splits, int rows, int N,
+               float *__restrict__ out, int64_t ldo) {
+  const int n4 = N >> 2;
+  const int64_t total = (int64_t)rows * n4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / n4;
+    const int c = (int)(i - r * n4);
+    float4 s = reinterpret_cast<const float4 *>(slabs)[i];
+    for (int z = 1; z < splits; ++z) {
+      const float4 v = reinterpret_cast<const float4 *>(slabs + (int64_t)z * slab_stride)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4 *>(out + r * ldo)[c] = s;
+  }
+}
+
+template <bool AKC, bool BKC, int EPI>
+int launch_gemm(GemmArgs g, int tm_sel, int tn_sel, int splits, hipStream_t s) {
+  const dim3 block(kThreads);
+  if (tm_sel == 2 && tn_sel == 2) {
+    g.tiles_m = (g.M + 127) / 128; g.tiles_n = g.N / 128;
+    hipLaunchKernelGGL((k_gemm_f32<AKC, BKC, 2, 2, EPI>), dim3(g.tiles_m * g.tiles_n, splits), block, 0, s, g);
+  } else if (tm_sel == 1 && tn_sel == 2) {
+    g.tiles_m = (g.M + 63) / 64; g.tiles_n = g.N / 128;
+    hipLaunchKernelGGL((k_gemm_f32<AKC, BKC, 1, 2, EPI>), dim3(g.tiles_m * g.tiles_n, splits), block, 0, s, g);
+  } else {
+    g.tiles_m = (g.M + 63) / 64; g.tiles_n = g.N / 64;
+    hipLaunchKernelGGL((k_gemm_f32<AKC, BKC, 1, 1, EPI>), dim3(g.tiles_m * g.tiles_n, splits), block, 0, s, g);
+  }
+  return check_launch("gemm_f32");
+}
+
+// Pick the largest tile that still gives the chip enough workgroups
+// (256 CUs x 2 resident blocks).
+void pick_tile(int M, int N, bool m_must_divide, int &tm, int &tn) {
+  const int64_t want = 384;
+  auto tiles = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * (N / bn); };
+  const bool ok128m = !m_must_divide || (M % 128 == 0);
+  if (N % 128 == 0 && ok128m && tiles(128, 128) >= want) { tm = 2; tn = 2; return; }
+  if (N % 128 == 0 && tiles(64, 128) >= want) { tm = 1; tn = 2; return; }
+  if (tiles(64, 64) >= want || N % 128 != 0) { tm = 1; tn = 1; return; }
+  if (ok128m && tiles(128, 128) >= 192) { tm = 2; tn = 2; return; }
+  tm = 1; tn = (tiles(64, 128) >= 128) ? 2 : 1;
+}
+
+int check_mat(const char *who, const void *p, int64_t ld, int64_t min_ld) {
+  CDML_REQUIRE(p, CDML_E_BADARG, "%s: null pointer", who);
+  CDML_REQUIRE(aligned16(p) && (ld & 3) == 0 && ld >= min_ld, CDML_E_ALIGN,
+               "%s: base must be 16-B aligned, leading dimension a multiple of 4 and >= %lld", who,
+               (long long)min_ld);
+  return CDML_OK;
+}
+
+// Split-K supplies the parallelism for the weight gradient, so take the
+// largest tile that divides the output.
+void pick_tile_bwd_weight(int K, int N, int &tm, int &tn) {
+  if (K % 128 == 0 && N % 128 == 0) { tm = 2; tn = 2; }
+  else if (N % 128 == 0) { tm = 1; tn = 2; }
+  else { tm = 1; tn = 1; }
+}
+
+int bwd_weight_splits(int M, int K, int N) {
+  int tm, tn;
+  pick_tile_bwd_weight(K, N, tm, tn);
+  const int64_t tiles = (int64_t)(K / (64 * tm)) * (N / (64 * tn));
+  int64_t splits = (480 + tiles - 1) / tiles;
+  const int64_t max_by_k = (M + 255) / 256;  // at least 256 contraction rows per split
+  if (splits > max_by_k) splits = max_by_k;
+  if (splits > 32) splits = 32;
+  if (splits < 1) splits = 1;
+  return (int)splits;
+}
+
+}  // namespace
+}  // namespace cdml
+
+using namespace cdml;
+
+extern "C" int cdml_fc_lrelu_fwd(const float *x, int64_t ldx, const float *W, int64_t ldw,
+                                 const float *b, float alpha, int M, int K, int N, float *y,
+                                 int64_t ldy, cdml_stream_t stream) {
+  CDML_REQUIRE(M > 0 && K > 0 && N > 0 && b, CDML_E_BADARG, "fc_lrelu_fwd: bad argument");
+  CDML_REQUIRE(K % 32 == 0 && N % 64 == 0, CDML_E_UNSUPPORTED,
+               "fc_lrelu_fwd: K must be a multiple of 32 and N of 64 (pad with zeros), got K=%d N=%d", K, N);
+  int rc;
+  if ((rc = check_mat("fc_lrelu_fwd x", x, ldx, K))) return rc;
+  if ((rc = check_mat("fc_lrelu_fwd W", W, ldw, N))) return rc;
+  if ((rc = check_mat("fc_lrelu_fwd y", y, ldy, N))) return rc;
+  GemmArgs g{};
+  g.A = x; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = y; g.ldc = ldy;
+  g.bias = b; g.alpha = alpha; g.M = M; g.N = N; g.K = K; g.k_per_split = K;
+  int tm, tn;
+  pick_tile(M, N, false, tm, tn);
+  return launch_gemm<true, false, EPI_BIAS_LRELU>(g, tm, tn, 1, (hipStream_t)stream);
+}
+
+extern "C" int cdml_fc_bwd_data(const float *dy, int64_t lddy, const float *W, int64_t ldw,
+                                const float *x_post, int64_t ldxp, float alpha, int M, int K, int N,
+                                float *dx, int64_t lddx, cdml_stream_t stream) {
+  CDML_REQUIRE(M > 0 && K > 0 && N > 0, CDML_E_BADARG, "fc_bwd_data: bad argument");
+  CDML_REQUIRE(N % 32 == 0 && K % 64 == 0, CDML_E_UNSUPPORTED,
+               "fc_bwd_data: N must be a multiple of 32 and K of 64, got K=%d N=%d", K, N);
+  int rc;
+  if ((rc = check_mat("fc_bwd_data dy", dy, lddy, N))) return rc;
+  if ((rc = check_mat("fc_bwd_data W", W, ldw, N))) return rc;
+  if ((rc = check_mat("fc_bwd_data dx", dx, lddx, K))) return rc;
+  if (x_post && (rc = check_mat("fc_bwd_data x_post", x_post, ldxp, K))) return rc;
+  GemmArgs g{};  // dx[M][K] = dy[M][N] @ W[K][N]^T : output cols = K, contraction = N
+  g.A = dy; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dx; g.ldc = lddx;
+  g.aux = x_post; g.ldaux = ldxp; g.alpha = alpha; g.M = M; g.N = K; g.K = N; g.k_per_split = N;
+  int tm, tn;
+  pick_tile(M, K, false, tm, tn);
+  return launch_gemm<true, true, EPI_LRELU_MASK>(g, tm, tn, 1, (hipStream_t)stream);
+}
+
+extern "C" size_t cdml_fc_bwd_weight_workspace(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0 || K % 64 || N % 64) return 0;
+  const int splits = bwd_weight_splits(M, K, N);
+  return ((size_t)splits * K * N + (size_t)splits * N) * sizeof(float);
+}
+
+extern "C" int cdml_fc_bwd_weight(const float *x, int64_t ldx, const float *dy, int64_t lddy, int M,
+                                  int K, int N, float *dW, int64_t lddw, float *db, void *workspace,
+                                  size_t workspace_bytes, cdml_stream_t stream) {
+  CDML_REQUIRE(M > 0 && K > 0 && N > 0, CDML_E_BADARG, "fc_bwd_weight: bad argument");
+  CDML_REQUIRE(K % 64 == 0 && N % 64 == 0, CDML_E_UNSUPPORTED,
+               "fc_bwd_weight: K and N must be multiples of 64, got K=%d N=%d", K, N);
+  int rc;
+  if ((rc = check_mat("fc_bwd_weight x", x, ldx, K))) return rc;
+  if ((rc = check_mat("fc_bwd_weight dy", dy, lddy, N))) return rc;
+  if ((rc = check_mat("fc_bwd_weight dW", dW, lddw, N))) return rc;
+  const size_t need = cdml_fc_bwd_weight_workspace(M, K, N);
+  CDML_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), CDML_E_BADARG,
+               "fc_bwd_weight: workspace of %zu bytes (16-B aligned) required", need);
+  const int splits = bwd_weight_splits(M, K, N);
+  float *slabs = static_cast<float *>(workspace);
+  float *colsum = slabs + (size_t)splits * K * N;
+  GemmArgs g{};  // dW[K][N] = x[M][K]^T @ dy[M][N] : output rows = K, contraction = M
+  g.A = x; g.lda = ldx; g.B = dy; g.ldb = lddy; g.C = slabs; g.ldc = N;
+  g.colsum = db ? colsum : nullptr; g.M = K; g.N = N; g.K = M;
+  int kps = (M + splits - 1) / splits;
+  kps = (kps + BK - 1) / BK * BK;
+  g.k_per_split = kps;
+  g.slab_stride = (int64_t)K * N;
+  int tm, tn;
+  pick_tile_bwd_weight(K, N, tm, tn);
+  if ((rc = launch_gemm<false, false, EPI_SLAB_COLSUM>(g, tm, tn, splits, (hipStream_t)stream))) return rc;
+  const int64_t total4 = (int64_t)K * N / 4;
+  int grid = (int)((total4 + kThreads - 1) / kThreads);
+  if (grid > kNumCU * 8) grid = kNumCU * 8;
+  hipLaunchKernelGGL(k_sum_slabs_2d, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, slabs,
+                     g.slab_stride, splits, K, N, dW, lddw);
+  if ((rc = check_launch("fc_bwd_weight combine"))) return rc;
+  if (db) {
+    hipLaunchKernelGGL(k_sum_slabs, dim3((N / 4 + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                       (hipStream_t)stream, colsum, (int64_t)N, splits, (int64_t)(N / 4), db);
+    rc = check_launch("fc_bwd_weight bias combine");
+  }
+  return rc;
+}

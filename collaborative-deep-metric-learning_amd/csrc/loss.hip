@@ -1,0 +1,288 @@
+// Row l2-normalise (fwd/bwd) and the fused triplet hinge loss + gradient.
+//
+// Reference: tf.nn.l2_normalize at models.py:58,61; HingeLoss.calculate_loss
+// losses.py:32-38 (squared-L2 pos/neg distance, max(pos-neg+margin,0), batch
+// mean) and its autodiff (train.py:141).  TF's MaximumGrad is inclusive: a
+// triplet with pos-neg+margin == 0 still passes gradient.
+//
+// Roofline: HBM (3*D*4 B read + 3*D*4 B written per triplet).  One wave per
+// triplet / row, 16-B lane accesses, wave-shuffle reductions, no atomics: the
+// batch mean is a second single-block pass in a fixed order (deterministic).
+#include "common.h"
+
+namespace cdml {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWavesPerBlock = kThreads / kWave;
+constexpr float kL2Eps = 1e-12f;
+
+__device__ __forceinline__ float4 ld4(const float *p, int q) {
+  return reinterpret_cast<const float4 *>(p)[q];
+}
+__device__ __forceinline__ void st4(float *p, int q, float4 v) {
+  reinterpret_cast<float4 *>(p)[q] = v;
+}
+__device__ __forceinline__ float sq4(float4 a) { return a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+// ------------------------------------------------------------------ l2 norm ---
+__global__ void __launch_bounds__(kThreads)
+k_l2norm_fwd(const float *__restrict__ x, int64_t ldx, int M, int N, float *__restrict__ y,
+             int64_t ldy, float *__restrict__ inv_out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nq = N >> 2;
+  for (int r = blockIdx.x * kWavesPerBlock + wave; r < M; r += gridDim.x * kWavesPerBlock) {
+    const float *xr = x + (int64_t)r * ldx;
+    float ss = 0.f;
+    for (int q = lane; q < nq; q += kWave) ss += sq4(ld4(xr, q));
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, kL2Eps));
+    if (inv_out && lane == 0) inv_out[r] = inv;
+    float *yr = y + (int64_t)r * ldy;
+    for (int q = lane; q < nq; q += kWave) st4(yr, q, mul4(ld4(xr, q), inv));
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_l2norm_bwd(const float *__restrict__ z, int64_t ldz, const float *__restrict__ g, int64_t ldg,
+             int M, int N, float alpha, float *__restrict__ dz, int64_t lddz) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nq = N >> 2;
+  for (int r = blockIdx.x * kWavesPerBlock + wave; r < M; r += gridDim.x * kWavesPerBlock) {
+    const float *zr = z + (int64_t)r * ldz;
+    const float *gr = g + (int64_t)r * ldg;
+    float ss = 0.f, zg = 0.f;
+    for (int q = lane; q < nq; q += kWave) {
+      const float4 a = ld4(zr, q);
+      ss += sq4(a);
+      zg += dot4(a, ld4(gr, q));
+    }
+    ss = wave_sum(ss);
+    zg = wave_sum(zg);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, kL2Eps));
+    // y = z*inv, dot = sum(y*g) = inv*zg;  dz = inv*(g - y*dot)  (or inv*g when clamped)
+    const float c = (ss > kL2Eps) ? inv * inv * zg : 0.f;
+    float *dr = dz + (int64_t)r * lddz;
+    for (int q = lane; q < nq; q += kWave) {
+      const float4 a = ld4(zr, q), b = ld4(gr, q);
+      float4 d = make_float4(inv * (b.x - a.x * c), inv * (b.y - a.y * c), inv * (b.z - a.z * c),
+                             inv * (b.w - a.w * c));
+      if (alpha >= 0.f) {
+        d.x *= (a.x > 0.f) ? 1.f : alpha;
+        d.y *= (a.y > 0.f) ? 1.f : alpha;
+        d.z *= (a.z > 0.f) ? 1.f : alpha;
+        d.w *= (a.w > 0.f) ? 1.f : alpha;
+      }
+      st4(dr, q, d);
+    }
+  }
+}
+
+// -------------------------------------------------------------- hinge loss ----
+// Squared distance pair of one triplet, reduced over the wave.  Kept in one
+// function so every wave that recomputes a triplet gets bit-identical values.
+__device__ __forceinline__ void dist_pair(const float *a, const float *p, const float *n, int nq,
+                                          int lane, float &pos, float &neg) {
+  float sp = 0.f, sn = 0.f;
+  for (int q = lane; q < nq; q += kWave) {
+    const float4 va = ld4(a, q);
+    sp += sq4(sub4(va, ld4(p, q)));
+    sn += sq4(sub4(va, ld4(n, q)));
+  }
+  pos = wave_sum(sp);
+  neg = wave_sum(sn);
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_triplet_hinge(const float *__restrict__ e, int64_t lde, int B, int D, float margin,
+                float *__restrict__ pos_o, float *__restrict__ neg_o, float *__restrict__ hinge_o,
+                float *__restrict__ de, int64_t ldde) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nq = D >> 2;
+  const float two_over_b = 2.0f / (float)B;
+  for (int i = blockIdx.x * kWavesPerBlock + wave; i < B; i += gridDim.x * kWavesPerBlock) {
+    const float *a = e + (int64_t)(3 * i) * lde, *p = a + lde, *n = p + lde;
+    float pos, neg;
+    dist_pair(a, p, n, nq, lane, pos, neg);
+    const float t = pos - neg + margin;
+    if (lane == 0) {
+      pos_o[i] = pos;
+      neg_o[i] = neg;
+      hinge_o[i] = fmaxf(t, 0.f);
+    }
+    if (de) {
+      const float s = (t >= 0.f) ? two_over_b : 0.f;
+      float *da = de + (int64_t)(3 * i) * ldde, *dp = da + ldde, *dn = dp + ldde;
+      for (int q = lane; q < nq; q += kWave) {
+        const float4 va = ld4(a, q), vp = ld4(p, q), vn = ld4(n, q);
+        st4(da, q, mul4(sub4(vn, vp), s));
+        st4(dp, q, mul4(sub4(vp, va), s));
+        st4(dn, q, mul4(sub4(va, vn), s));
+      }
+    }
+  }
+}
+
+// In-batch negatives: slot i owns rows a_i (2i) and p_i (2i+1).  p_i is the
+// positive of triplet i and the negative of triplet k = (i - shift) mod B, so the
+// wave of slot i recomputes triplet k's activity and writes both rows' complete
+// gradients: no atomics, fixed summation order.
+__global__ void __launch_bounds__(kThreads)
+k_triplet_hinge_inbatch(const float *__restrict__ e, int64_t lde, const int32_t *__restrict__ rows,
+                        const int32_t *__restrict__ shift_p, int B, int D, float margin,
+                        float *__restrict__ pos_o, float *__restrict__ neg_o,
+                        float *__restrict__ hinge_o, uint8_t *__restrict__ valid_o,
+                        float *__restrict__ de, int64_t ldde) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nq = D >> 2;
+  const int shift = *shift_p;
+  const float two_over_b = 2.0f / (float)B;
+  for (int i = blockIdx.x * kWavesPerBlock + wave; i < B; i += gridDim.x * kWavesPerBlock) {
+    const int j = (i + shift) % B;
+    const int k = (i - shift % B + B) % B;
+    const float *a = e + (int64_t)(2 * i) * lde, *p = a + lde;
+    const float *n = e + (int64_t)(2 * j + 1) * lde;
+    const int32_t va_id = rows[2 * i], vp_id = rows[2 * i + 1], vn_id = rows[2 * j + 1];
+    const bool valid_i = (vn_id != va_id) && (vn_id != vp_id);
+    float pos, neg;
+    dist_pair(a, p, n, nq, lane, pos, neg);
+    const float t = pos - neg + margin;
+    if (lane == 0) {
+      pos_o[i] = pos;
+      neg_o[i] = neg;
+      hinge_o[i] = valid_i ? fmaxf(t, 0.f) : 0.f;
+      if (valid_o) valid_o[i] = valid_i ? 1 : 0;
+    }
+    if (de) {
+      const float *ak = e + (int64_t)(2 * k) * lde, *pk = ak + lde;  // triplet k: (a_k,p_k,p_i)
+      const bool valid_k = (vp_id != rows[2 * k]) && (vp_id != rows[2 * k + 1]);
+      float posk, negk;
+      dist_pair(ak, pk, p, nq, lane, posk, negk);
+      const float si = (valid_i && t >= 0.f) ? two_over_b : 0.f;
+      const float sk = (valid_k && (posk - negk + margin) >= 0.f) ? two_over_b : 0.f;
+      float *da = de + (int64_t)(2 * i) * ldde, *dp = da + ldde;
+      for (int q = lane; q < nq; q += kWave) {
+        const float4 va = ld4(a, q), vp = ld4(p, q), vn = ld4(n, q), vak = ld4(ak, q);
+        st4(da, q, mul4(sub4(vn, vp), si));
+        const float4 g1 = mul4(sub4(vp, va), si);    // as positive of triplet i
+        const float4 g2 = mul4(sub4(vak, vp), sk);   // as negative of triplet k
+        st4(dp, q, make_float4(g1.x + g2.x, g1.y + g2.y, g1.z + g2.z, g1.w + g2.w));
+      }
+    }
+  }
+}
+
+// stats[0..3] = mean hinge, mean pos, mean neg, fraction of triplets with hinge > 0.
+__global__ void __launch_bounds__(1024)
+k_loss_stats(const float *__restrict__ pos, const float *__restrict__ neg,
+             const float *__restrict__ hinge, int B, float *__restrict__ stats) {
+  __shared__ float s[4][1024 / kWave];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < B; i += 1024) {
+    const float h = hinge[i];
+    acc[0] += h;
+    acc[1] += pos[i];
+    acc[2] += neg[i];
+    acc[3] += (h > 0.f) ? 1.f : 0.f;
+  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float v = wave_sum(acc[c]);
+    if (lane == 0) s[c][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = 0.f;
+    for (int w = 0; w < 1024 / kWave; ++w) v += s[threadIdx.x][w];
+    stats[threadIdx.x] = v / (float)B;
+  }
+}
+
+int grid_rows(int rows) {
+  int64_t b = ((int64_t)rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (b > kNumCU * 8) b = kNumCU * 8;
+  return (int)(b < 1 ? 1 : b);
+}
+
+int check_rows(const char *who, const void *p, int64_t ld, int N) {
+  CDML_REQUIRE(p, CDML_E_BADARG, "%s: null pointer", who);
+  CDML_REQUIRE((N & 3) == 0 && ld >= N && (ld & 3) == 0 && aligned16(p), CDML_E_ALIGN,
+               "%s: width and leading dimension must be multiples of 4, base 16-B aligned", who);
+  return CDML_OK;
+}
+
+}  // namespace
+}  // namespace cdml
+
+using namespace cdml;
+
+extern "C" int cdml_l2norm_fwd(const float *x, int64_t ldx, int M, int N, float *y, int64_t ldy,
+                               float *inv_out, cdml_stream_t stream) {
+  CDML_REQUIRE(M > 0 && N > 0, CDML_E_BADARG, "l2norm_fwd: bad shape");
+  int rc;
+  if ((rc = check_rows("l2norm_fwd", x, ldx, N))) return rc;
+  if ((rc = check_rows("l2norm_fwd", y, ldy, N))) return rc;
+  hipLaunchKernelGGL(k_l2norm_fwd, dim3(grid_rows(M)), dim3(kThreads), 0, (hipStream_t)stream, x, ldx,
+                     M, N, y, ldy, inv_out);
+  return check_launch("l2norm_fwd");
+}
+
+extern "C" int cdml_l2norm_bwd(const float *z, int64_t ldz, const float *g, int64_t ldg, int M, int N,
+                               float lrelu_alpha, float *dz, int64_t lddz, cdml_stream_t stream) {
+  CDML_REQUIRE(M > 0 && N > 0, CDML_E_BADARG, "l2norm_bwd: bad shape");
+  int rc;
+  if ((rc = check_rows("l2norm_bwd", z, ldz, N))) return rc;
+  if ((rc = check_rows("l2norm_bwd", g, ldg, N))) return rc;
+  if ((rc = check_rows("l2norm_bwd", dz, lddz, N))) return rc;
+  hipLaunchKernelGGL(k_l2norm_bwd, dim3(grid_rows(M)), dim3(kThreads), 0, (hipStream_t)stream, z, ldz,
+                     g, ldg, M, N, lrelu_alpha, dz, lddz);
+  return check_launch("l2norm_bwd");
+}
+
+extern "C" int cdml_triplet_hinge(const float *e, int64_t lde, int B, int D, float margin, float *pos,
+                                  float *neg, float *hinge, float *stats, float *de, int64_t ldde,
+                                  cdml_stream_t stream) {
+  CDML_REQUIRE(B > 0 && D > 0 && pos && neg && hinge, CDML_E_BADARG, "triplet_hinge: bad argument");
+  int rc;
+  if ((rc = check_rows("triplet_hinge", e, lde, D))) return rc;
+  if (de && (rc = check_rows("triplet_hinge", de, ldde, D))) return rc;
+  hipLaunchKernelGGL(k_triplet_hinge, dim3(grid_rows(B)), dim3(kThreads), 0, (hipStream_t)stream, e,
+                     lde, B, D, margin, pos, neg, hinge, de, ldde);
+  if ((rc = check_launch("triplet_hinge"))) return rc;
+  if (stats) {
+    hipLaunchKernelGGL(k_loss_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, pos, neg, hinge, B,
+                       stats);
+    rc = check_launch("triplet_hinge stats");
+  }
+  return rc;
+}
+
+extern "C" int cdml_triplet_hinge_inbatch(const float *e, int64_t lde, const int32_t *rows,
+                                          const int32_t *shift, int B, int D, float margin,
+                                          float *pos, float *neg, float *hinge, uint8_t *valid_out,
+                                          float *stats, float *de, int64_t ldde,
+                                          cdml_stream_t stream) {
+  CDML_REQUIRE(B >= 2 && D > 0 && rows && shift && pos && neg && hinge, CDML_E_BADARG,
+               "triplet_hinge_inbatch: bad argument");
+  int rc;
+  if ((rc = check_rows("triplet_hinge_inbatch", e, lde, D))) return rc;
+  if (de && (rc = check_rows("triplet_hinge_inbatch", de, ldde, D))) return rc;
+  hipLaunchKernelGGL(k_triplet_hinge_inbatch, dim3(grid_rows(B)), dim3(kThreads), 0,
+                     (hipStream_t)stream, e, lde, rows, shift, B, D, margin, pos, neg, hinge,
+                     valid_out, de, ldde);
+  if ((rc = check_launch("triplet_hinge_inbatch"))) return rc;
+  if (stats) {
+    hipLaunchKernelGGL(k_loss_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, pos, neg, hinge, B,
+                       stats);
+    rc = check_launch("triplet_hinge_inbatch stats");
+  }
+  return rc;
+}

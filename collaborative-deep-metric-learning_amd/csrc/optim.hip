@@ -1,0 +1,163 @@
+// Fused optimizer updates (train.py:108-125,146) + ABI base (version, errors).
+//
+// Adam: tf.train.AdamOptimizer (build_graph's default, train.py:82), the arithmetic
+// of TF's ApplyAdam functor: m += (g-m)(1-b1); v += (g*g-v)(1-b2); w -= alpha*m/(sqrt(v)+eps).
+// LARS: tf.contrib.opt.LARSOptimizer with contrib defaults (train.py:354).
+// Roofline: HBM -- Adam streams 7 floats per parameter (r: w,g,m,v  w: w,m,v),
+// LARS 5 (+2 for the norm pass).  16-B lane accesses, grid-stride.
+#include "common.h"
+#include <string.h>
+
+namespace cdml {
+
+char *err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kLarsBlocks = 1024;
+
+__global__ void __launch_bounds__(kThreads)
+k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
+       float *__restrict__ v, int64_t n, float lr_imm, const float *__restrict__ lr_dev, float b1,
+       float b2, float eps, int64_t t_imm, const uint64_t *__restrict__ t_dev) {
+  __shared__ float s_lr_t;
+  if (threadIdx.x == 0) {
+    const double t = (double)t_imm + (t_dev ? (double)(*t_dev) : 0.0);
+    const double lr = lr_dev ? (double)(*lr_dev) : (double)lr_imm;
+    s_lr_t = (float)(lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  }
+  __syncthreads();
+  const float lr_t = s_lr_t;
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 w4 = reinterpret_cast<float4 *>(w)[i];
+    const float4 g4 = reinterpret_cast<const float4 *>(g)[i];
+    float4 m4 = reinterpret_cast<float4 *>(m)[i];
+    float4 v4 = reinterpret_cast<float4 *>(v)[i];
+#define CDML_ADAM1(c)                              \
+  m4.c += (g4.c - m4.c) * omb1;                    \
+  v4.c += (g4.c * g4.c - v4.c) * omb2;             \
+  w4.c -= (m4.c * lr_t) / (sqrtf(v4.c) + eps);
+    CDML_ADAM1(x) CDML_ADAM1(y) CDML_ADAM1(z) CDML_ADAM1(w)
+#undef CDML_ADAM1
+    reinterpret_cast<float4 *>(w)[i] = w4;
+    reinterpret_cast<float4 *>(m)[i] = m4;
+    reinterpret_cast<float4 *>(v)[i] = v4;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * omb1;
+    const float vi = v[i] + (gi * gi - v[i]) * omb2;
+    m[i] = mi;
+    v[i] = vi;
+    w[i] = w[i] - (mi * lr_t) / (sqrtf(vi) + eps);
+  }
+}
+
+// scratch layout: [0]=|w|^2, [1]=|g|^2, then kLarsBlocks x 2 block partials
+__global__ void __launch_bounds__(kThreads)
+k_lars_norm_partial(const float *__restrict__ w, const float *__restrict__ g, int64_t n,
+                    float *__restrict__ scratch) {
+  __shared__ double s[2][kThreads / kWave];
+  float sw = 0.f, sg = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float a = w[i], b = g[i];
+    sw += a * a;
+    sg += b * b;
+  }
+  sw = wave_sum(sw);
+  sg = wave_sum(sg);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  if (lane == 0) { s[0][wave] = sw; s[1][wave] = sg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int k = 0; k < kThreads / kWave; ++k) { a += s[0][k]; b += s[1][k]; }
+    scratch[2 + 2 * blockIdx.x] = (float)a;
+    scratch[3 + 2 * blockIdx.x] = (float)b;
+  }
+}
+
+__global__ void k_lars_norm_final(float *__restrict__ scratch, int blocks) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int k = 0; k < blocks; ++k) { a += scratch[2 + 2 * k]; b += scratch[3 + 2 * k]; }
+    scratch[0] = (float)a;
+    scratch[1] = (float)b;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_lars_apply(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ acc, int64_t n,
+             float lr_imm, const float *__restrict__ lr_dev, float momentum, float wd, float eeta,
+             float eps, const float *__restrict__ scratch) {
+  const float lr = lr_dev ? *lr_dev : lr_imm;
+  const float wn = sqrtf(scratch[0]), gn = sqrtf(scratch[1]);
+  const float trust = (wn > 0.f && gn > 0.f) ? eeta * wn / (gn + wd * wn + eps) : 1.0f;
+  const float slr = lr * trust;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float wi = w[i];
+    const float gi = g[i] + wd * wi;
+    const float a = momentum * acc[i] + slr * gi;
+    acc[i] = a;
+    w[i] = wi - a;
+  }
+}
+
+int grid_elems(int64_t n, int per_thread) {
+  int64_t b = (n / per_thread + kThreads - 1) / kThreads;
+  if (b > kNumCU * 8) b = kNumCU * 8;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+}  // namespace cdml
+
+using namespace cdml;
+
+extern "C" int cdml_version(void) { return 1000; }
+extern "C" const char *cdml_last_error(void) { return err_buf(); }
+
+extern "C" int cdml_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float lr,
+                              const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
+                              const uint64_t *t_dev, cdml_stream_t stream) {
+  CDML_REQUIRE(w && g && m && v && n > 0, CDML_E_BADARG, "adam_step: bad argument");
+  CDML_REQUIRE(t >= (t_dev ? 0 : 1), CDML_E_BADARG, "adam_step: step t is 1-based");
+  CDML_REQUIRE(aligned16(w) && aligned16(g) && aligned16(m) && aligned16(v), CDML_E_ALIGN,
+               "adam_step: buffers must be 16-B aligned");
+  hipLaunchKernelGGL(k_adam, dim3(grid_elems(n, 4)), dim3(kThreads), 0, (hipStream_t)stream, w, g, m,
+                     v, n, lr, lr_dev, beta1, beta2, eps, t, t_dev);
+  return check_launch("adam_step");
+}
+
+extern "C" size_t cdml_lars_scratch_floats(void) { return 2 + 2 * (size_t)kLarsBlocks; }
+
+extern "C" int cdml_lars_step(float *w, const float *g, float *acc, int64_t n, float lr,
+                              const float *lr_dev, float momentum, float weight_decay, float eeta,
+                              float eps, float *scratch, cdml_stream_t stream) {
+  CDML_REQUIRE(w && g && acc && scratch && n > 0, CDML_E_BADARG, "lars_step: bad argument");
+  int blocks = grid_elems(n, 8);
+  if (blocks > kLarsBlocks) blocks = kLarsBlocks;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_lars_norm_partial, dim3(blocks), dim3(kThreads), 0, s, w, g, n, scratch);
+  hipLaunchKernelGGL(k_lars_norm_final, dim3(1), dim3(64), 0, s, scratch, blocks);
+  hipLaunchKernelGGL(k_lars_apply, dim3(grid_elems(n, 4)), dim3(kThreads), 0, s, w, g, acc, n, lr,
+                     lr_dev, momentum, weight_decay, eeta, eps, scratch);
+  return check_launch("lars_step");
+}

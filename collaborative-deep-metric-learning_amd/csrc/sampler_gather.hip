@@ -1,0 +1,322 @@
+// Triplet sampler + feature-row gather (+ fused input l2-normalise) for gfx950.
+//
+// Replaces the reference's host input pipe: MPTripletPipe.subprocess
+// (inputs.py:102-142: pair stream + negative draw), get_batch's numpy
+// fancy-index gather FEATURES[idx] (inputs.py:158), the reshape + feed_dict H2D
+// copy (train.py:313,318) and the tower's first op tf.nn.l2_normalize
+// (models.py:58).  The catalogue lives in HBM; nothing touches the host.
+//
+// Roofline: HBM.  Algorithmic bytes per gathered row = F*4 read + F*4 written.
+// One wave owns one row: 16 B/lane loads (1 KiB per wave-instruction), all of
+// a row's loads issued before the first use, wave-shuffle reduction for the
+// norm.  Rows start 128-B aligned when row_stride*4 is a multiple of 128.
+#include "common.h"
+
+namespace cdml {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWavesPerBlock = kThreads / kWave;
+
+// ---------------------------------------------------------------- table fill --
+__global__ void __launch_bounds__(kThreads)
+k_fill_table(float *__restrict__ table, int64_t row0, int64_t n_rows, int F,
+             int64_t row_stride, uint64_t seed) {
+  const int64_t q_per_row = row_stride >> 2;
+  const int64_t total = n_rows * q_per_row;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lr = i / q_per_row;
+    const int64_t q = i - lr * q_per_row;
+    const uint64_t r = (uint64_t)(row0 + lr);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t j = q * 4;
+    if (j < F) {
+      u32x4 w = philox4x32_10(u32x4{(uint32_t)q, (uint32_t)r, (uint32_t)(r >> 32), kTableTag}, k0, k1);
+      const float s = 5.9604644775390625e-08f;  // 2^-24
+      v.x = (float)(w.x >> 8) * s;
+      v.y = (j + 1 < F) ? (float)(w.y >> 8) * s : 0.f;
+      v.z = (j + 2 < F) ? (float)(w.z >> 8) * s : 0.f;
+      v.w = (j + 3 < F) ? (float)(w.w >> 8) * s : 0.f;
+    }
+    reinterpret_cast<float4 *>(table)[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------- sampler --
+__global__ void __launch_bounds__(kThreads)
+k_sample_uniform(const int32_t *__restrict__ pairs, int64_t n_pairs, uint32_t n_rows,
+                 uint64_t seed, uint64_t step_imm, const uint64_t *__restrict__ step_dev,
+                 int batch, int64_t slot0, int64_t batch_global, int32_t *__restrict__ idx_out) {
+  const uint64_t step = step_dev ? *step_dev : step_imm;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  const uint64_t slot = (uint64_t)(slot0 + i);
+  const uint64_t q = (step * (uint64_t)batch_global + slot) % (uint64_t)n_pairs;
+  const int32_t a = pairs[2 * q], p = pairs[2 * q + 1];
+  const int32_t n = sample_uniform_negative(seed, step, (uint32_t)slot, a, p, n_rows);
+  idx_out[3 * i + 0] = a;
+  idx_out[3 * i + 1] = p;
+  idx_out[3 * i + 2] = n;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_sample_inbatch(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t seed,
+                 uint64_t step_imm, const uint64_t *__restrict__ step_dev, int batch,
+                 int64_t slot0, int64_t batch_global, int32_t *__restrict__ rows_out,
+                 int32_t *__restrict__ shift_out) {
+  const uint64_t step = step_dev ? *step_dev : step_imm;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *shift_out = sample_inbatch_shift(seed, step, batch);
+  if (i >= batch) return;
+  const uint64_t slot = (uint64_t)(slot0 + i);
+  const uint64_t q = (step * (uint64_t)batch_global + slot) % (uint64_t)n_pairs;
+  rows_out[2 * i + 0] = pairs[2 * q];
+  rows_out[2 * i + 1] = pairs[2 * q + 1];
+}
+
+__global__ void k_step_advance(uint64_t *step_dev) { *step_dev += 1; }
+
+// -------------------------------------------------------------------- gather --
+// One wave gathers (and optionally l2-normalises) one row.  NCH = float4 chunks
+// per lane held in registers (covers F <= 256*NCH).
+template <int NCH>
+__device__ __forceinline__ void gather_one_row(const float *__restrict__ table, int64_t local_row,
+                                               int64_t row_stride, int F, int normalize,
+                                               float *__restrict__ dst, int64_t out_stride,
+                                               float *__restrict__ inv_out, int lane) {
+  const float4 *src = reinterpret_cast<const float4 *>(table + local_row * row_stride);
+  const int nq = (F + 3) >> 2;
+  float4 v[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int q = lane + kWave * c;
+    v[c] = (q < nq) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (F & 3) {  // mask the tail so the table's pad content never leaks in
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int j = 4 * (lane + kWave * c);
+      if (j + 1 >= F && j < F) v[c].y = 0.f;
+      if (j + 2 >= F && j < F) v[c].z = 0.f;
+      if (j + 3 >= F && j < F) v[c].w = 0.f;
+    }
+  }
+  float inv = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      ss += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+    ss = wave_sum(ss);
+    inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+  }
+  if (inv_out && lane == 0) *inv_out = inv;
+  float4 *d = reinterpret_cast<float4 *>(dst);
+  const int oq = (int)(out_stride >> 2);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int q = lane + kWave * c;
+    if (q < oq) d[q] = make_float4(v[c].x * inv, v[c].y * inv, v[c].z * inv, v[c].w * inv);
+  }
+  for (int q = lane + kWave * NCH; q < oq; q += kWave) d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ int64_t clamp_row(int32_t id, int64_t row0, int64_t n_rows,
+                                             int32_t *oob_flag) {
+  int64_t lr = (int64_t)id - row0;
+  if (lr < 0 || lr >= n_rows) {
+    if (oob_flag) atomicOr(oob_flag, 1);
+    lr = lr < 0 ? 0 : n_rows - 1;
+  }
+  return lr;
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(kThreads)
+k_gather_rows(const float *__restrict__ table, int64_t row0, int64_t n_rows, int64_t row_stride,
+              const int32_t *__restrict__ idx, int n_idx, int F, int normalize,
+              float *__restrict__ x_out, int64_t out_stride, float *__restrict__ inv_norm_out,
+              int32_t *__restrict__ oob_flag) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int r = blockIdx.x * kWavesPerBlock + wave; r < n_idx; r += gridDim.x * kWavesPerBlock) {
+    const int64_t lr = clamp_row(idx[r], row0, n_rows, oob_flag);
+    gather_one_row<NCH>(table, lr, row_stride, F, normalize, x_out + (int64_t)r * out_stride,
+                        out_stride, inv_norm_out ? inv_norm_out + r : nullptr, lane);
+  }
+}
+
+// Persistent fused sampler + gather.  A block walks chunks of kWavesPerBlock
+// triplets: one lane per triplet draws the ids and stages them in LDS, then
+// every wave gathers the rows of its triplet.  MODE 0 = uniform negatives
+// (3 rows/triplet), MODE 1 = in-batch negatives (2 rows/triplet).
+template <int MODE, int NCH>
+__global__ void __launch_bounds__(kThreads)
+k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t seed,
+                uint64_t step_imm, const uint64_t *__restrict__ step_dev, int batch,
+                int64_t slot0, int64_t batch_global, const float *__restrict__ table,
+                int64_t n_rows, int64_t row_stride, int F, int32_t *__restrict__ idx_out,
+                int32_t *__restrict__ shift_out, float *__restrict__ x_out, int64_t out_stride) {
+  constexpr int RPT = (MODE == 0) ? 3 : 2;  // rows per triplet
+  __shared__ int32_t s_ids[kWavesPerBlock][4];
+  const uint64_t step = step_dev ? *step_dev : step_imm;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0)
+    *shift_out = sample_inbatch_shift(seed, step, batch);
+  const int n_chunks = (batch + kWavesPerBlock - 1) / kWavesPerBlock;
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const int i = chunk * kWavesPerBlock + wave;  // triplet of this wave
+    if (lane == 0 && i < batch) {
+      const uint64_t slot = (uint64_t)(slot0 + i);
+      const uint64_t q = (step * (uint64_t)batch_global + slot) % (uint64_t)n_pairs;
+      const int32_t a = pairs[2 * q], p = pairs[2 * q + 1];
+      s_ids[wave][0] = a;
+      s_ids[wave][1] = p;
+      if (MODE == 0)
+        s_ids[wave][2] = sample_uniform_negative(seed, step, (uint32_t)slot, a, p, (uint32_t)n_rows);
+    }
+    __syncthreads();
+    if (i < batch) {
+      if (lane < RPT) idx_out[RPT * i + lane] = s_ids[wave][lane];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int64_t lr = clamp_row(s_ids[wave][k], 0, n_rows, nullptr);
+        const int64_t r = (int64_t)RPT * i + k;
+        gather_one_row<NCH>(table, lr, row_stride, F, 1, x_out + r * out_stride, out_stride,
+                            nullptr, lane);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int grid_for(int64_t work_items, int per_block) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  const int64_t cap = (int64_t)kNumCU * 8;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+}  // namespace cdml
+
+using namespace cdml;
+
+extern "C" int cdml_fill_uniform_table(float *table, int64_t row0, int64_t n_rows, int feature_size,
+                                       int64_t row_stride, uint64_t seed, cdml_stream_t stream) {
+  CDML_REQUIRE(table && n_rows > 0 && feature_size > 0 && row0 >= 0, CDML_E_BADARG,
+               "fill_uniform_table: bad argument");
+  CDML_REQUIRE(row_stride >= feature_size && (row_stride & 3) == 0 && aligned16(table), CDML_E_ALIGN,
+               "fill_uniform_table: row_stride must be >= F and a multiple of 4, base 16-B aligned");
+  const int64_t total = n_rows * (row_stride >> 2);
+  hipLaunchKernelGGL(k_fill_table, dim3(grid_for(total, kThreads)), dim3(kThreads), 0,
+                     (hipStream_t)stream, table, row0, n_rows, feature_size, row_stride, seed);
+  return check_launch("fill_uniform_table");
+}
+
+extern "C" int cdml_sample_uniform(const int32_t *pairs, int64_t n_pairs, int64_t n_rows,
+                                   uint64_t seed, uint64_t step, const uint64_t *step_dev,
+                                   int batch, int64_t slot0, int64_t batch_global,
+                                   int32_t *idx_out, cdml_stream_t stream) {
+  CDML_REQUIRE(pairs && idx_out && n_pairs > 0 && batch > 0 && slot0 >= 0, CDML_E_BADARG,
+               "sample_uniform: bad argument");
+  CDML_REQUIRE(n_rows >= 3 && n_rows <= 0x7FFFFFFFll, CDML_E_BADARG,
+               "sample_uniform: n_rows must be in [3, 2^31)");
+  CDML_REQUIRE(batch_global >= slot0 + batch, CDML_E_BADARG,
+               "sample_uniform: batch_global < slot0 + batch");
+  hipLaunchKernelGGL(k_sample_uniform, dim3((batch + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                     (hipStream_t)stream, pairs, n_pairs, (uint32_t)n_rows, seed, step, step_dev,
+                     batch, slot0, batch_global, idx_out);
+  return check_launch("sample_uniform");
+}
+
+extern "C" int cdml_sample_inbatch(const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                                   uint64_t step, const uint64_t *step_dev, int batch,
+                                   int64_t slot0, int64_t batch_global, int32_t *rows_out,
+                                   int32_t *shift_out, cdml_stream_t stream) {
+  CDML_REQUIRE(pairs && rows_out && shift_out && n_pairs > 0 && slot0 >= 0, CDML_E_BADARG,
+               "sample_inbatch: bad argument");
+  CDML_REQUIRE(batch >= 2, CDML_E_BADARG, "sample_inbatch: in-batch negatives need batch >= 2");
+  CDML_REQUIRE(batch_global >= slot0 + batch, CDML_E_BADARG,
+               "sample_inbatch: batch_global < slot0 + batch");
+  hipLaunchKernelGGL(k_sample_inbatch, dim3((batch + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                     (hipStream_t)stream, pairs, n_pairs, seed, step, step_dev, batch, slot0,
+                     batch_global, rows_out, shift_out);
+  return check_launch("sample_inbatch");
+}
+
+extern "C" int cdml_step_advance(uint64_t *step_dev, cdml_stream_t stream) {
+  CDML_REQUIRE(step_dev, CDML_E_BADARG, "step_advance: null pointer");
+  hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  return check_launch("step_advance");
+}
+
+static int check_gather_layout(const char *who, const float *table, int64_t row_stride, int F,
+                               const float *x_out, int64_t out_stride) {
+  CDML_REQUIRE(F > 0 && F <= 2048, CDML_E_UNSUPPORTED, "%s: feature size %d outside (0, 2048]", who, F);
+  CDML_REQUIRE(row_stride >= F && (row_stride & 3) == 0 && out_stride >= F && (out_stride & 3) == 0,
+               CDML_E_ALIGN, "%s: strides must be >= F and multiples of 4", who);
+  CDML_REQUIRE(aligned16(table) && aligned16(x_out), CDML_E_ALIGN, "%s: bases must be 16-B aligned", who);
+  return CDML_OK;
+}
+
+extern "C" int cdml_gather_rows(const float *table, int64_t row0, int64_t n_rows, int64_t row_stride,
+                                const int32_t *idx, int n_idx, int F, int normalize, float *x_out,
+                                int64_t out_stride, float *inv_norm_out, int32_t *oob_flag,
+                                cdml_stream_t stream) {
+  CDML_REQUIRE(table && idx && x_out && n_rows > 0 && n_idx > 0 && row0 >= 0, CDML_E_BADARG,
+               "gather_rows: bad argument");
+  int rc = check_gather_layout("gather_rows", table, row_stride, F, x_out, out_stride);
+  if (rc) return rc;
+  const int grid = grid_for(n_idx, kWavesPerBlock);
+  const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
+#define CDML_LAUNCH_GATHER(N)                                                                   \
+  hipLaunchKernelGGL(k_gather_rows<N>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, table, \
+                     row0, n_rows, row_stride, idx, n_idx, F, normalize, x_out, out_stride,     \
+                     inv_norm_out, oob_flag)
+  if (nch <= 2) CDML_LAUNCH_GATHER(2);
+  else if (nch <= 4) CDML_LAUNCH_GATHER(4);
+  else if (nch <= 6) CDML_LAUNCH_GATHER(6);
+  else CDML_LAUNCH_GATHER(8);
+#undef CDML_LAUNCH_GATHER
+  return check_launch("gather_rows");
+}
+
+extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                                  uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
+                                  int64_t batch_global, const float *table, int64_t n_rows,
+                                  int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
+                                  float *x_out, int64_t out_stride, cdml_stream_t stream) {
+  CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "sample_gather: mode must be 0 or 1");
+  CDML_REQUIRE(pairs && table && idx_out && x_out && n_pairs > 0 && slot0 >= 0, CDML_E_BADARG,
+               "sample_gather: bad argument");
+  CDML_REQUIRE(n_rows >= 3 && n_rows <= 0x7FFFFFFFll, CDML_E_BADARG,
+               "sample_gather: n_rows must be in [3, 2^31)");
+  CDML_REQUIRE(batch >= (mode == 1 ? 2 : 1), CDML_E_BADARG, "sample_gather: batch too small");
+  CDML_REQUIRE(mode == 0 || shift_out, CDML_E_BADARG, "sample_gather: shift_out required in mode 1");
+  CDML_REQUIRE(batch_global >= slot0 + batch, CDML_E_BADARG,
+               "sample_gather: batch_global < slot0 + batch");
+  int rc = check_gather_layout("sample_gather", table, row_stride, F, x_out, out_stride);
+  if (rc) return rc;
+  const int grid = grid_for(batch, kWavesPerBlock);
+  const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
+#define CDML_LAUNCH_SG(M, N)                                                                      \
+  hipLaunchKernelGGL((k_sample_gather<M, N>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
+                     pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global, table,     \
+                     n_rows, row_stride, F, idx_out, shift_out, x_out, out_stride)
+  if (mode == 0) {
+    if (nch <= 2) CDML_LAUNCH_SG(0, 2);
+    else if (nch <= 6) CDML_LAUNCH_SG(0, 6);
+    else CDML_LAUNCH_SG(0, 8);
+  } else {
+    if (nch <= 2) CDML_LAUNCH_SG(1, 2);
+    else if (nch <= 6) CDML_LAUNCH_SG(1, 6);
+    else CDML_LAUNCH_SG(1, 8);
+  }
+#undef CDML_LAUNCH_SG
+  return check_launch("sample_gather");
+}

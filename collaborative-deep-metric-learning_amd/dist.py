@@ -1,0 +1,112 @@
+"""Multi-GPU hooks: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference is single-GPU (train.py:341-342: CUDA_VISIBLE_DEVICES="0",
+"TODO Prepare distributed arguments here"); this is the build's data-parallel
+extension of the hot path:
+
+  * the catalogue is ROW-SHARDED: rank g owns global rows
+    [g*rows_per_rank, (g+1)*rows_per_rank);
+  * every rank samples its own slice of the global batch (the sampler is
+    counter-based, so no communication is needed to agree on triplets);
+  * ``RowExchange.gather``: all-to-all of requested row ids, owners gather +
+    l2-normalise the rows from their shard (HIP kernel), all-to-all of the rows
+    back -- the one real exchange step of the path;
+  * ``GradSync``: one all-reduce (average) of the flat 35 MB gradient buffer.
+
+Only torch.distributed plumbing lives here; the local gather is injected
+(``local_gather``) so the routing logic is testable on CPU with gloo.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def shard_bounds(n_rows_global, world, rank):
+    """Rows [lo, hi) owned by ``rank``: equal blocks of ceil(N/world) rows."""
+    per = (n_rows_global + world - 1) // world
+    lo = min(rank * per, n_rows_global)
+    return lo, min(lo + per, n_rows_global), per
+
+
+def _hip_local_gather(table, ids, out):
+    """Owner side: gather + l2-normalise local rows with the HIP kernel."""
+    ops.gather_rows(table.data, table.row0, ids, table.feature_size, out, normalize=True)
+    return out
+
+
+class RowExchange:
+    """Fetch (normalised) feature rows by GLOBAL id from a row-sharded table."""
+
+    def __init__(self, n_rows_global, group=None, local_gather=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_rows_global = int(n_rows_global)
+        self.per = shard_bounds(n_rows_global, self.world, self.rank)[2]
+        self.local_gather = local_gather or _hip_local_gather
+        self._buf = {}
+
+    def _scratch(self, name, shape, dtype, device):
+        t = self._buf.get(name)
+        if t is None or t.shape[0] < shape[0] or t.shape[1:] != tuple(shape[1:]) or t.device != device:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self._buf[name] = t
+        return t[:shape[0]]
+
+    def plan(self, ids):
+        """Route ids to owners: (send_ids sorted by owner, order, send_counts)."""
+        owner = torch.div(ids, self.per, rounding_mode="floor").to(torch.int64)
+        order = torch.argsort(owner, stable=True)
+        counts = torch.bincount(owner, minlength=self.world)
+        return ids[order].contiguous(), order, counts
+
+    def gather(self, table, ids, out):
+        """out[r] = l2norm(table_global[ids[r]]) for r < len(ids); out is [R, stride]."""
+        dev = ids.device
+        send_ids, order, send_counts = self.plan(ids)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()       # host sync: split sizes
+        n_req = int(sum(rc))
+        req_ids = self._scratch("req_ids", (max(n_req, 1),), torch.int32, dev)[:n_req]
+        dist.all_to_all_single(req_ids, send_ids, output_split_sizes=rc, input_split_sizes=sc,
+                               group=self.group)
+        stride = out.shape[1]
+        rows_out = self._scratch("rows_out", (max(n_req, 1), stride), torch.float32, out.device)[:n_req]
+        if n_req:
+            self.local_gather(table, req_ids, rows_out)
+        rows_in = self._scratch("rows_in", (ids.numel(), stride), torch.float32, out.device)
+        dist.all_to_all_single(rows_in, rows_out, output_split_sizes=sc, input_split_sizes=rc,
+                               group=self.group)
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel(), device=dev)
+        self.unpermute(rows_in, inv, out)
+        return out
+
+    def unpermute(self, rows_in, inv, out):
+        """out[r] = rows_in[inv[r]] -- a row gather of the receive buffer."""
+        if rows_in.is_cuda:
+            ops.gather_rows(rows_in, 0, inv.to(torch.int32), out.shape[1], out[:inv.numel()],
+                            normalize=False)
+        else:
+            out[:inv.numel()] = rows_in[inv]
+
+
+class GradSync:
+    """Average the flat gradient buffer over the data-parallel group."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.avg = dist.get_backend(group) == "nccl"
+
+    def __call__(self, flat_grad):
+        if self.world == 1:
+            return flat_grad
+        if self.avg:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            flat_grad.div_(self.world)
+        return flat_grad

@@ -1,0 +1,170 @@
+"""Tensor-level wrappers over the C ABI: pointer/stride plumbing only.
+
+Each function hands raw device pointers, sizes and the current torch stream to
+libcdml_hip.so.  Nothing here computes; a CPU tensor is an error.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import call, load_library
+
+LRELU_ALPHA = 0.2     # tf.nn.leaky_relu default (reference models.py:21)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=None):
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise ValueError("cdml ops need device tensors (there is no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"expected {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _mat(t, dtype=torch.float32):
+    """(pointer, leading dimension) of a 2-D row-major view."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("expected a 2-D tensor with unit inner stride")
+    return _p(t, dtype), t.stride(0)
+
+
+def version():
+    return load_library().cdml_version()
+
+
+# ------------------------------------------------------------------ data ------
+def fill_uniform_table(table, row0, feature_size, seed):
+    ptr, ld = _mat(table)
+    call("cdml_fill_uniform_table", ptr, row0, table.shape[0], feature_size, ld, seed, _stream())
+    return table
+
+
+def sample_uniform(pairs, n_rows, seed, step, batch, idx_out, slot0=0, batch_global=None,
+                   step_dev=None):
+    bg = batch if batch_global is None else batch_global
+    call("cdml_sample_uniform", _p(pairs, torch.int32), pairs.shape[0], n_rows, seed,
+         0 if step is None else step, _p(step_dev, torch.int64), batch, slot0, bg,
+         _p(idx_out, torch.int32), _stream())
+    return idx_out
+
+
+def sample_inbatch(pairs, seed, step, batch, rows_out, shift_out, slot0=0, batch_global=None,
+                   step_dev=None):
+    bg = batch if batch_global is None else batch_global
+    call("cdml_sample_inbatch", _p(pairs, torch.int32), pairs.shape[0], seed,
+         0 if step is None else step, _p(step_dev, torch.int64), batch, slot0, bg,
+         _p(rows_out, torch.int32), _p(shift_out, torch.int32), _stream())
+    return rows_out, shift_out
+
+
+def step_advance(step_dev):
+    call("cdml_step_advance", _p(step_dev, torch.int64), _stream())
+
+
+def gather_rows(table, row0, idx, feature_size, x_out, normalize=True, inv_norm_out=None,
+                oob_flag=None):
+    tp, tld = _mat(table)
+    xp, xld = _mat(x_out)
+    call("cdml_gather_rows", tp, row0, table.shape[0], tld, _p(idx, torch.int32), idx.numel(),
+         feature_size, 1 if normalize else 0, xp, xld, _p(inv_norm_out), _p(oob_flag, torch.int32),
+         _stream())
+    return x_out
+
+
+def sample_gather(mode, pairs, seed, step, batch, table, feature_size, idx_out, x_out,
+                  shift_out=None, slot0=0, batch_global=None, step_dev=None):
+    bg = batch if batch_global is None else batch_global
+    tp, tld = _mat(table)
+    xp, xld = _mat(x_out)
+    call("cdml_sample_gather", mode, _p(pairs, torch.int32), pairs.shape[0], seed,
+         0 if step is None else step, _p(step_dev, torch.int64), batch, slot0, bg, tp,
+         table.shape[0], tld, feature_size, _p(idx_out, torch.int32), _p(shift_out, torch.int32),
+         xp, xld, _stream())
+    return x_out
+
+
+# ----------------------------------------------------------------- tower ------
+def l2norm_fwd(x, n_cols, y, inv_out=None):
+    xp, xld = _mat(x)
+    yp, yld = _mat(y)
+    call("cdml_l2norm_fwd", xp, xld, x.shape[0], n_cols, yp, yld, _p(inv_out), _stream())
+    return y
+
+
+def l2norm_bwd(z, g, n_cols, dz, lrelu_alpha=-1.0):
+    zp, zld = _mat(z)
+    gp, gld = _mat(g)
+    dp, dld = _mat(dz)
+    call("cdml_l2norm_bwd", zp, zld, gp, gld, z.shape[0], n_cols, lrelu_alpha, dp, dld, _stream())
+    return dz
+
+
+def fc_lrelu_fwd(x, W, b, y, M, K, N, alpha=LRELU_ALPHA):
+    xp, xld = _mat(x)
+    wp, wld = _mat(W)
+    yp, yld = _mat(y)
+    call("cdml_fc_lrelu_fwd", xp, xld, wp, wld, _p(b, torch.float32), alpha, M, K, N, yp, yld,
+         _stream())
+    return y
+
+
+def fc_bwd_data(dy, W, x_post, dx, M, K, N, alpha=LRELU_ALPHA):
+    dyp, dyld = _mat(dy)
+    wp, wld = _mat(W)
+    dxp, dxld = _mat(dx)
+    if x_post is None:
+        xpp, xpld = C.c_void_p(0), 0
+    else:
+        xpp, xpld = _mat(x_post)
+    call("cdml_fc_bwd_data", dyp, dyld, wp, wld, xpp, xpld, alpha, M, K, N, dxp, dxld, _stream())
+    return dx
+
+
+def fc_bwd_weight_workspace(M, K, N):
+    return int(load_library().cdml_fc_bwd_weight_workspace(M, K, N))
+
+
+def fc_bwd_weight(x, dy, dW, db, workspace, M, K, N):
+    xp, xld = _mat(x)
+    dyp, dyld = _mat(dy)
+    wp, wld = _mat(dW)
+    call("cdml_fc_bwd_weight", xp, xld, dyp, dyld, M, K, N, wp, wld, _p(db, torch.float32),
+         _p(workspace), workspace.numel() * workspace.element_size(), _stream())
+    return dW, db
+
+
+# ------------------------------------------------------------------ loss ------
+def triplet_hinge(e, B, D, margin, pos, neg, hinge, stats=None, de=None):
+    ep, eld = _mat(e)
+    dep, deld = (C.c_void_p(0), 0) if de is None else _mat(de)
+    call("cdml_triplet_hinge", ep, eld, B, D, margin, _p(pos), _p(neg), _p(hinge), _p(stats), dep,
+         deld, _stream())
+
+
+def triplet_hinge_inbatch(e, rows, shift, B, D, margin, pos, neg, hinge, valid=None, stats=None,
+                          de=None):
+    ep, eld = _mat(e)
+    dep, deld = (C.c_void_p(0), 0) if de is None else _mat(de)
+    call("cdml_triplet_hinge_inbatch", ep, eld, _p(rows, torch.int32), _p(shift, torch.int32), B, D,
+         margin, _p(pos), _p(neg), _p(hinge), _p(valid, torch.uint8), _p(stats), dep, deld, _stream())
+
+
+# ------------------------------------------------------------- optimizers -----
+def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, t_dev=None):
+    call("cdml_adam_step", _p(w), _p(g), _p(m), _p(v), w.numel(), lr, _p(lr_dev), beta1, beta2, eps,
+         0 if t is None else t, _p(t_dev, torch.int64), _stream())
+
+
+def lars_scratch_floats():
+    return int(load_library().cdml_lars_scratch_floats())
+
+
+def lars_step(w, g, acc, lr, scratch, momentum=0.9, weight_decay=1e-4, eeta=1e-3, eps=0.0,
+              lr_dev=None):
+    call("cdml_lars_step", _p(w), _p(g), _p(acc), w.numel(), lr, _p(lr_dev), momentum, weight_decay,
+         eeta, eps, _p(scratch), _stream())

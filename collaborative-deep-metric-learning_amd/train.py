@@ -1,0 +1,199 @@
+"""Training step and loop of the hot path (reference train.py).
+
+``build_graph`` (train.py:74-174) assembled model + loss + optimizer into one TF
+graph executed by ``sess.run([train_op, global_step, loss])`` (train.py:317).
+Here ``TrainStep`` owns the device buffers and enqueues the same work as HIP
+kernels on one stream:
+
+    sample + gather + l2norm  ->  FC1  ->  FC2  ->  l2norm  ->  hinge loss + dE
+    ->  l2norm/lrelu bwd  ->  dW2,db2  ->  dH1  ->  dW1,db1
+    ->  [all-reduce grads]  ->  Adam | LARS  ->  step counter += 1
+
+Nothing in ``step()`` allocates or synchronises, so the whole step can be
+captured into a hipGraph (``use_graph=True``); the step counter and learning
+rate live in device memory so replays advance the sampler and Adam's bias
+correction.  ``Trainer`` mirrors the reference's loop (train.py:260-336).
+"""
+import logging
+import time
+
+import torch
+
+from . import engine, ops
+from .inputs import MODE_INBATCH, MODE_UNIFORM
+
+_MODES = {"uniform": MODE_UNIFORM, "inbatch": MODE_INBATCH}
+
+
+def exponential_decay(base_lr, global_step, decay_steps, decay_rate, staircase=True):
+    """tf.train.exponential_decay (train.py:108-113)."""
+    p = global_step / float(decay_steps)
+    if staircase:
+        p = float(int(p))
+    return base_lr * (decay_rate ** p)
+
+
+class TrainStep:
+    def __init__(self, table, pairs, batch_size, feature_size=None, output_size=256,
+                 hidden_size=5000, margin=0.8, mode="uniform", optimizer="adam",
+                 base_learning_rate=0.01, learning_rate_decay_examples=1000000,
+                 learning_rate_decay=0.96, seed=1234, weight_seed=42, device="cuda:0",
+                 exchange=None, grad_sync=None, slot0=0, batch_global=None, use_graph=False):
+        """table: FeatureTable (whole catalogue, or this rank's shard when
+        ``exchange`` is given); pairs: int32 [P,2] device tensor; ``exchange`` /
+        ``grad_sync``: the multi-GPU hooks of cdml_amd.dist (None on one GPU)."""
+        if mode not in _MODES:
+            raise ValueError("mode must be 'uniform' or 'inbatch'")
+        if optimizer not in ("adam", "lars"):
+            raise ValueError("optimizer must be 'adam' or 'lars'")
+        self.device = torch.device(device)
+        self.table, self.pairs = table, pairs
+        self.B = int(batch_size)
+        self.mode = mode
+        self.rows_per_triplet = 3 if mode == "uniform" else 2
+        self.R = self.B * self.rows_per_triplet
+        self.margin = float(margin)
+        self.seed = int(seed)
+        self.optimizer = optimizer
+        self.base_lr = float(base_learning_rate)
+        self.decay_steps = learning_rate_decay_examples
+        self.decay_rate = learning_rate_decay
+        self.exchange, self.grad_sync = exchange, grad_sync
+        self.slot0 = int(slot0)
+        self.batch_global = self.B if batch_global is None else int(batch_global)
+        F = table.feature_size if feature_size is None else feature_size
+        self.layout = engine.TowerLayout(F, hidden_size, output_size)
+        self.params = engine.VNetParams(self.layout, self.device, weight_seed)
+        self.ws = engine.TowerWorkspace(self.layout, self.R, self.device)
+        dev, i32, f32 = self.device, torch.int32, torch.float32
+        self.idx = torch.zeros(self.R, dtype=i32, device=dev)       # [B,3] or [2B] video ids
+        self.shift = torch.zeros(1, dtype=i32, device=dev)
+        self.pos = torch.zeros(self.B, dtype=f32, device=dev)
+        self.neg = torch.zeros(self.B, dtype=f32, device=dev)
+        self.hinge = torch.zeros(self.B, dtype=f32, device=dev)
+        self.valid = torch.ones(self.B, dtype=torch.uint8, device=dev)
+        self.stats = torch.zeros(4, dtype=f32, device=dev)          # loss, mean pos, mean neg, active
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.lr_dev = torch.full((1,), self.base_lr, dtype=f32, device=dev)
+        self._lr_host = self.base_lr
+        self.global_step = 0
+        n = self.layout.numel
+        if optimizer == "adam":
+            self.m = torch.zeros(n, dtype=f32, device=dev)
+            self.v = torch.zeros(n, dtype=f32, device=dev)
+        else:
+            self.acc = torch.zeros(n, dtype=f32, device=dev)
+            self.lars_scratch = torch.zeros(ops.lars_scratch_floats(), dtype=f32, device=dev)
+        self._graph = None
+        self.use_graph = bool(use_graph) and exchange is None and grad_sync is None
+
+    # ---------------------------------------------------------------- pieces --
+    def fetch(self):
+        """Sampler + gather (+ input l2norm): fills ws.x_hat and self.idx."""
+        m = _MODES[self.mode]
+        if self.exchange is None:
+            ops.sample_gather(m, self.pairs, self.seed, None, self.B, self.table.data,
+                              self.table.feature_size, self.idx, self.ws.x_hat,
+                              shift_out=self.shift, slot0=self.slot0,
+                              batch_global=self.batch_global, step_dev=self.step_dev)
+        else:
+            if m == MODE_UNIFORM:
+                ops.sample_uniform(self.pairs, self.table.n_rows_global, self.seed, None, self.B,
+                                   self.idx, slot0=self.slot0, batch_global=self.batch_global,
+                                   step_dev=self.step_dev)
+            else:
+                ops.sample_inbatch(self.pairs, self.seed, None, self.B, self.idx, self.shift,
+                                   slot0=self.slot0, batch_global=self.batch_global,
+                                   step_dev=self.step_dev)
+            self.exchange.gather(self.table, self.idx, self.ws.x_hat)
+
+    def forward_loss(self, with_grad=True):
+        engine.tower_forward(self.params, self.ws)
+        L = self.layout
+        de = self.ws.de if with_grad else None
+        if self.mode == "uniform":
+            ops.triplet_hinge(self.ws.e, self.B, L.Dp, self.margin, self.pos, self.neg, self.hinge,
+                              self.stats, de)
+        else:
+            ops.triplet_hinge_inbatch(self.ws.e, self.idx, self.shift, self.B, L.Dp, self.margin,
+                                      self.pos, self.neg, self.hinge, self.valid, self.stats, de)
+
+    def backward(self):
+        engine.tower_backward(self.params, self.ws)
+
+    def apply_gradients(self):
+        p = self.params
+        if self.optimizer == "adam":
+            ops.adam_step(p.flat, p.grad, self.m, self.v, 0.0, 1, lr_dev=self.lr_dev,
+                          t_dev=self.step_dev)
+        else:
+            for off, n in p.segments():       # LARS trust ratio is per variable
+                ops.lars_step(p.flat[off:off + n], p.grad[off:off + n], self.acc[off:off + n],
+                              0.0, self.lars_scratch, lr_dev=self.lr_dev)
+        ops.step_advance(self.step_dev)
+
+    def _enqueue(self):
+        self.fetch()
+        self.forward_loss()
+        self.backward()
+        if self.grad_sync is not None:
+            self.grad_sync(self.params.grad)
+        self.apply_gradients()
+
+    # ------------------------------------------------------------------ step --
+    def step(self):
+        """Enqueue one training step (no host sync).  Loss etc. land in
+        ``self.stats`` (device)."""
+        lr = exponential_decay(self.base_lr, self.global_step, self.decay_steps, self.decay_rate)
+        if lr != self._lr_host:                         # staircase: rare
+            self.lr_dev.fill_(lr)
+            self._lr_host = lr
+        if self.use_graph and self.global_step >= 1:     # step 0 runs eagerly (loads the kernels)
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        else:
+            self._enqueue()
+        self.global_step += 1
+
+    def _capture(self):
+        torch.cuda.synchronize(self.device)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                self._enqueue()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self._graph = g
+
+    def loss(self):
+        """Host value of the last step's mean hinge loss (synchronises)."""
+        return float(self.stats[0].item())
+
+
+class Trainer:
+    """Step loop with the reference's bookkeeping (train.py:260-336): runs until
+    the pair stream is exhausted, logs loss / fetch / train time every
+    ``show_step`` steps.  Evaluation-driven checkpointing and early stopping
+    (train.py:224-252) are the next-row N2 and not part of this class yet."""
+
+    def __init__(self, train_step, num_epochs, n_pairs, show_step=100, logger=None):
+        self.ts = train_step
+        self.num_batches = (n_pairs * num_epochs) // train_step.batch_global
+        self.show_step = max(1, int(show_step))
+        self.log = logger or logging.getLogger("cdml.train")
+        self.history = []
+
+    def run(self, max_steps=None):
+        n = self.num_batches if max_steps is None else min(self.num_batches, max_steps)
+        t0 = time.time()
+        for i in range(n):
+            self.ts.step()
+            if (i + 1) % self.show_step == 0 or i + 1 == n:
+                loss = self.ts.loss()
+                dt = time.time() - t0
+                self.history.append((i + 1, loss))
+                self.log.info("Step %d | Loss: %.8f | %.1f triplets/s", i + 1, loss,
+                              (i + 1) * self.ts.batch_global / dt)
+        return self.history

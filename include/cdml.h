@@ -1,0 +1,200 @@
+/* cdml.h -- C ABI of libcdml_hip.so: the MI355X (gfx950) triplet-embedding hot
+ * path of the CDML video recommender.
+ *
+ * This is the drop-in boundary for ONE path of the reference
+ * (geekieo/collaborative-deep-metric-learning, citations are file:line in it):
+ *   sampler + feature gather   inputs.py:102-166, parse_data.py:292-320
+ *   embedding tower (VNet)     models.py:19-62
+ *   triplet hinge loss         losses.py:20-49
+ *   backward + optimizer step  train.py:105-146
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no C++/torch types.  Every pointer is a
+ *     DEVICE pointer (HBM) unless its name ends in _host.
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library
+ *     allocates nothing and keeps no state between calls.
+ *   - every entry point only ENQUEUES work on `stream` (a hipStream_t passed as
+ *     void*); it never synchronises, so a sequence of calls can be captured into
+ *     a hipGraph.
+ *   - return value: CDML_OK or a negative cdml_status; cdml_last_error() gives
+ *     the message for the calling thread.  No exception or exit() crosses the
+ *     boundary (the reference swallows Python exceptions, train.py:331-332; the
+ *     Python facade raises instead).
+ *   - matrices are row-major fp32 with an explicit leading dimension (elements).
+ *     GEMM operands must have leading dimensions that are multiples of 4 and
+ *     16-byte aligned bases (CDML_E_ALIGN otherwise); padded columns must hold
+ *     zeros where noted.
+ *   - row order of a batch follows the reference: rows 3i,3i+1,3i+2 are the
+ *     anchor, positive, negative of triplet i (train.py:313,128).
+ */
+#ifndef CDML_H_
+#define CDML_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *cdml_stream_t; /* hipStream_t */
+
+enum cdml_status {
+  CDML_OK = 0,
+  CDML_E_BADARG = -1,      /* null pointer, non-positive size, bad enum */
+  CDML_E_HIP = -2,         /* a HIP runtime call / launch failed */
+  CDML_E_ALIGN = -3,       /* base pointer or leading dimension misaligned */
+  CDML_E_UNSUPPORTED = -4  /* shape outside what the kernels are built for */
+};
+
+/* ABI version (major*1000+minor) and the message of the last failure on this
+ * thread ("" if none). */
+int cdml_version(void);
+const char *cdml_last_error(void);
+
+/* ---- synthetic catalogue (bench/test data, imitation_data.py:41-53 shape) --
+ * table[r][j] for r in [row0,row0+n_rows), j < feature_size: U[0,1) on the fp32
+ * grid from Philox4x32-10 (ctr=(j>>2,row_lo,row_hi,TABLE_TAG), key=seed); columns
+ * feature_size..row_stride-1 are zeroed.  Global row id r is stored at local row
+ * r-row0. */
+int cdml_fill_uniform_table(float *table, int64_t row0, int64_t n_rows,
+                            int feature_size, int64_t row_stride, uint64_t seed,
+                            cdml_stream_t stream);
+
+/* ---- sampler: replaces MPTripletPipe.subprocess (inputs.py:102-142) and
+ * yield_negative_index / combine_cowatch_neg (parse_data.py:292-320) ----------
+ * pairs int32[n_pairs][2] co-watch (anchor,positive) video ids, read as one
+ * sequential stream with wrap-around: slot s of step t is pair
+ * (t*batch_global + s) mod n_pairs.  This call produces slots
+ * [slot0, slot0+batch).  If step_dev is non-NULL the step is read from device
+ * memory (graph replay); otherwise `step` is used.
+ * Uniform mode: negative ~ U{0..n_rows-1} from the counter-based stream
+ * specified in oracle/sampler.py, redrawn while it equals the anchor or the
+ * positive (inputs.py:125-127).  idx_out int32[batch][3] = (a,p,n). */
+int cdml_sample_uniform(const int32_t *pairs, int64_t n_pairs, int64_t n_rows,
+                        uint64_t seed, uint64_t step, const uint64_t *step_dev,
+                        int batch, int64_t slot0, int64_t batch_global,
+                        int32_t *idx_out, cdml_stream_t stream);
+
+/* In-batch mode (build-defined, no reference counterpart): rows_out
+ * int32[2*batch] = a0,p0,a1,p1,...; the negative of triplet i is the positive of
+ * triplet (i+shift) mod batch with shift = 1 + U{0..batch-2} drawn per step;
+ * shift_out int32[1]. */
+int cdml_sample_inbatch(const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                        uint64_t step, const uint64_t *step_dev, int batch,
+                        int64_t slot0, int64_t batch_global, int32_t *rows_out,
+                        int32_t *shift_out, cdml_stream_t stream);
+
+/* *step_dev += 1 (enqueue; lets a captured graph advance the sampler). */
+int cdml_step_advance(uint64_t *step_dev, cdml_stream_t stream);
+
+/* ---- feature gather: replaces FEATURES[np.asarray(idx)] (inputs.py:158), the
+ * reshape (train.py:313) and the feed_dict host->device copy (train.py:318),
+ * fused with the tower's input tf.nn.l2_normalize (models.py:58) -------------
+ * x_out[r][0:F] = table[idx[r]-row0][0:F] * (normalize ? rsqrt(max(sum sq,
+ * 1e-12)) : 1), columns F..out_stride-1 zeroed.  table rows have stride
+ * row_stride (>= F, multiple of 4; 16-B aligned base).  inv_norm_out may be
+ * NULL.  idx must lie in [row0, row0+n_rows) -- out-of-range ids are clamped
+ * and flagged in *oob_flag (int32, may be NULL). */
+int cdml_gather_rows(const float *table, int64_t row0, int64_t n_rows,
+                     int64_t row_stride, const int32_t *idx, int n_idx, int F,
+                     int normalize, float *x_out, int64_t out_stride,
+                     float *inv_norm_out, int32_t *oob_flag,
+                     cdml_stream_t stream);
+
+/* Persistent fused sampler+gather: samples slots [slot0,slot0+batch) exactly as
+ * cdml_sample_uniform (mode 0) / cdml_sample_inbatch (mode 1), stages each
+ * triplet's ids in LDS and gathers + normalises its rows in the same launch.
+ * idx_out: int32[batch][3] (mode 0) or int32[2*batch] (mode 1); x_out has
+ * 3*batch (mode 0) or 2*batch (mode 1) rows. */
+int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pairs,
+                       uint64_t seed, uint64_t step, const uint64_t *step_dev,
+                       int batch, int64_t slot0, int64_t batch_global,
+                       const float *table, int64_t n_rows, int64_t row_stride,
+                       int F, int32_t *idx_out, int32_t *shift_out,
+                       float *x_out, int64_t out_stride, cdml_stream_t stream);
+
+/* ---- tower pieces: VNet.create_model (models.py:46-62) ----------------------
+ * y = x * rsqrt(max(sum(x^2), 1e-12)) per row (tf.nn.l2_normalize, models.py:58,
+ * 61).  inv_out[M] may be NULL. */
+int cdml_l2norm_fwd(const float *x, int64_t ldx, int M, int N, float *y,
+                    int64_t ldy, float *inv_out, cdml_stream_t stream);
+
+/* dz = d/dz [ z*rsqrt(max(sum z^2,eps)) ] applied to g, optionally followed by
+ * the leaky-relu derivative of the layer that produced z (z is the
+ * post-activation; slope alpha where z <= 0).  lrelu_alpha < 0 disables it. */
+int cdml_l2norm_bwd(const float *z, int64_t ldz, const float *g, int64_t ldg,
+                    int M, int N, float lrelu_alpha, float *dz, int64_t lddz,
+                    cdml_stream_t stream);
+
+/* y[M][N] = leaky_relu(x[M][K] @ W[K][N] + b[N], alpha): slim.fully_connected
+ * with tf.nn.leaky_relu (models.py:19-30,59-60).  W is [in,out] like slim.
+ * K % 32 == 0 and N % 64 == 0 (pad with zeros); any M >= 1. */
+int cdml_fc_lrelu_fwd(const float *x, int64_t ldx, const float *W, int64_t ldw,
+                      const float *b, float alpha, int M, int K, int N,
+                      float *y, int64_t ldy, cdml_stream_t stream);
+
+/* dx[M][K] = (dy[M][N] @ W[K][N]^T) * lrelu'(x_post[M][K]) -- the data gradient
+ * of an FC layer chained with the leaky-relu derivative of the PREVIOUS layer
+ * (x_post = that layer's post-activation output = this layer's input).
+ * x_post NULL => no mask.  N % 32 == 0, K % 64 == 0. */
+int cdml_fc_bwd_data(const float *dy, int64_t lddy, const float *W, int64_t ldw,
+                     const float *x_post, int64_t ldxp, float alpha, int M,
+                     int K, int N, float *dx, int64_t lddx,
+                     cdml_stream_t stream);
+
+/* dW[K][N] = x[M][K]^T @ dy[M][N], db[N] = column sums of dy (db may be NULL).
+ * Deterministic split-K: workspace must hold cdml_fc_bwd_weight_workspace()
+ * bytes.  K % 64 == 0, N % 64 == 0; any M >= 1. */
+size_t cdml_fc_bwd_weight_workspace(int M, int K, int N);
+int cdml_fc_bwd_weight(const float *x, int64_t ldx, const float *dy,
+                       int64_t lddy, int M, int K, int N, float *dW,
+                       int64_t lddw, float *db, void *workspace,
+                       size_t workspace_bytes, cdml_stream_t stream);
+
+/* ---- loss: HingeLoss.calculate_loss (losses.py:20-49) fused with its
+ * gradient (train.py:141) --------------------------------------------------
+ * e[3B][ld] rows a,p,n per triplet.  pos/neg/hinge: float[B] (the reference's
+ * pos_dist / neg_dist / hinge_dist, shape [B,1]).  stats float[4] =
+ * {hinge_loss (mean), mean_pos_dist, mean_neg_dist, active fraction}.
+ * de (may be NULL) = d hinge_loss / d e, [3B][ldde]. */
+int cdml_triplet_hinge(const float *e, int64_t lde, int B, int D, float margin,
+                       float *pos, float *neg, float *hinge, float *stats,
+                       float *de, int64_t ldde, cdml_stream_t stream);
+
+/* In-batch variant: e[2B][ld] rows a_i,p_i; rows int32[2B] video ids;
+ * shift int32[1] (device).  Triplet i = (a_i, p_i, p_{(i+shift)%B}); it is
+ * masked (hinge 0, no gradient, still counted in the mean) when the negative's
+ * video id equals a_i's or p_i's.  valid_out uint8[B] may be NULL. */
+int cdml_triplet_hinge_inbatch(const float *e, int64_t lde, const int32_t *rows,
+                               const int32_t *shift, int B, int D, float margin,
+                               float *pos, float *neg, float *hinge,
+                               uint8_t *valid_out, float *stats, float *de,
+                               int64_t ldde, cdml_stream_t stream);
+
+/* ---- optimizers (train.py:108-125,146) --------------------------------------
+ * Adam, TensorFlow form (epsilon outside the bias correction):
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m=b1*m+(1-b1)*g; v=b2*v+(1-b2)*g*g;
+ *   w -= lr_t*m/(sqrt(v)+eps).            t = 1-based step.  n elements.
+ * lr_dev (nullable) overrides lr, and *t_dev (nullable) is ADDED to t, both read
+ * from device memory at execution time (t_dev = the sampler's 0-based step
+ * counter with t = 1), so a captured hipGraph follows the step counter and the
+ * staircase learning-rate schedule (train.py:108-113) without re-capture. */
+int cdml_adam_step(float *w, const float *g, float *m, float *v, int64_t n,
+                   float lr, const float *lr_dev, float beta1, float beta2,
+                   float eps, int64_t t, const uint64_t *t_dev,
+                   cdml_stream_t stream);
+
+/* LARS (tf.contrib.opt.LARSOptimizer, train.py:354), one variable of n
+ * elements: trust = eeta*|w|/(|g|+wd*|w|+eps) (1 if |w|==0 or |g|==0);
+ * acc = momentum*acc + lr*trust*(g+wd*w); w -= acc.
+ * scratch: cdml_lars_scratch_floats() floats (norm partials; deterministic). */
+size_t cdml_lars_scratch_floats(void);
+int cdml_lars_step(float *w, const float *g, float *acc, int64_t n, float lr,
+                   const float *lr_dev, float momentum, float weight_decay,
+                   float eeta, float eps, float *scratch, cdml_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDML_H_ */

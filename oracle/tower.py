@@ -210,16 +210,19 @@ def exponential_decay(base_lr, global_step, decay_steps, decay_rate,
 
 def adam_step(w, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8,
               dtype=np.float32):
-    """tf.train.AdamOptimizer update at (1-based) step t -- TF form, epsilon
-    OUTSIDE the bias correction:
-        lr_t = lr * sqrt(1-b2^t) / (1-b1^t)
-        m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; w <- w - lr_t m/(sqrt v + eps)
+    """tf.train.AdamOptimizer update at (1-based) step t -- the arithmetic of
+    TF 1.13's ApplyAdam functor, epsilon OUTSIDE the bias correction:
+        alpha = lr * sqrt(1-b2^t) / (1-b1^t)
+        m += (g - m)*(1-b1) ; v += (g*g - v)*(1-b2) ; w -= alpha*m/(sqrt(v)+eps)
+    with (1-b1), (1-b2) formed in ``dtype`` (in fp32 1-0.999 = 0.0010000467).
     Returns new (w, m, v).  PARITY UNPINNED (TF 1.13 source recalled)."""
     w, g, m, v = (np.asarray(a, dtype) for a in (w, g, m, v))
-    lr_t = dtype(lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
-    m = (dtype(beta1) * m + dtype(1.0 - beta1) * g).astype(dtype)
-    v = (dtype(beta2) * v + dtype(1.0 - beta2) * g * g).astype(dtype)
-    w = (w - lr_t * m / (np.sqrt(v) + dtype(eps))).astype(dtype)
+    alpha = dtype(lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
+    omb1 = dtype(1) - dtype(beta1)
+    omb2 = dtype(1) - dtype(beta2)
+    m = (m + (g - m) * omb1).astype(dtype)
+    v = (v + (g * g - v) * omb2).astype(dtype)
+    w = (w - (m * alpha) / (np.sqrt(v) + dtype(eps))).astype(dtype)
     return w, m, v
 
 

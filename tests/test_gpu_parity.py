@@ -1,0 +1,550 @@
+"""Parity of the HIP path (called through the C ABI) against the CPU oracle.
+
+Bars: bit-exact for sampled indices and the synthetic table; <= 1e-5 absolute
+(fp32) on embeddings and loss -- the tolerance BASELINE.json's north_star
+states; gradients / optimizer updates within 1e-5 of the fp64 oracle scaled to
+their magnitude.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sampler as osampler, synth as osynth, tower as otower
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def cd(gpu):
+    import cdml_amd
+    from cdml_amd import engine, inputs, losses, models, ops, train, utils
+    cdml_amd.load_library()
+
+    class NS:
+        pass
+    ns = NS()
+    ns.dev = gpu
+    ns.engine, ns.inputs, ns.losses, ns.models = engine, inputs, losses, models
+    ns.ops, ns.train, ns.utils, ns.pkg = ops, train, utils, cdml_amd
+    return ns
+
+
+def dt(a, dev, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).to(dev)
+
+
+def padded(a, rows, cols, dev):
+    out = torch.zeros((rows, cols), dtype=torch.float32, device=dev)
+    out[:a.shape[0], :a.shape[1]] = dt(a, dev)
+    return out
+
+
+def ru(x, m):
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------ table + sampler --
+def test_fill_table_bit_exact(cd):
+    for n, F, row0, seed in ((64, 1500, 0, 0), (33, 100, 1000, 7), (5, 7, 2 ** 33, 3)):
+        stride = ru(F, 64)
+        t = torch.full((n, stride), -1.0, device=cd.dev)
+        cd.ops.fill_uniform_table(t, row0, F, seed)
+        got = t.cpu().numpy()
+        np.testing.assert_array_equal(got[:, :F], osynth.features_philox(row0, n, F, seed))
+        assert np.all(got[:, F:] == 0)
+
+
+@pytest.mark.parametrize("n_rows,batch", [(10000, 128), (3, 64), (5, 1), (1000000, 4096)])
+def test_sampler_uniform_bit_exact(cd, n_rows, batch):
+    rng = np.random.RandomState(0)
+    pairs = rng.randint(0, n_rows, size=(1000, 2))
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]].astype(np.int32)
+    dp = dt(pairs, cd.dev, torch.int32)
+    out = torch.empty((batch, 3), dtype=torch.int32, device=cd.dev)
+    for step in (0, 1, 5, 2 ** 33 + 9):
+        cd.ops.sample_uniform(dp, n_rows, 1234, step, batch, out)
+        want = osampler.device_triplets_vec(pairs, n_rows, 1234, step, batch)
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+    # step read from device memory, rank slice of a global batch
+    step_dev = torch.tensor([3], dtype=torch.int64, device=cd.dev)
+    half = max(batch // 2, 1)
+    cd.ops.sample_uniform(dp, n_rows, 99, None, half, out[:half], slot0=half, batch_global=2 * half,
+                          step_dev=step_dev)
+    want = osampler.device_triplets_vec(pairs, n_rows, 99, 3, half, slot0=half, batch_global=2 * half)
+    np.testing.assert_array_equal(out[:half].cpu().numpy(), want)
+    cd.ops.step_advance(step_dev)
+    assert int(step_dev.item()) == 4
+
+
+def test_sampler_scalar_spec_small(cd):
+    pairs = np.array([[0, 1], [1, 2], [2, 0]], dtype=np.int32)
+    out = torch.empty((32, 3), dtype=torch.int32, device=cd.dev)
+    cd.ops.sample_uniform(dt(pairs, cd.dev, torch.int32), 3, 5, 2, 32, out)
+    np.testing.assert_array_equal(out.cpu().numpy(), osampler.device_triplets(pairs, 3, 5, 2, 32))
+
+
+def test_sampler_inbatch_bit_exact(cd):
+    pairs = osynth.cowatch_pairs(500, 100, 1)
+    dp = dt(pairs, cd.dev, torch.int32)
+    for B in (2, 16, 4096):
+        rows = torch.empty(2 * B, dtype=torch.int32, device=cd.dev)
+        shift = torch.empty(1, dtype=torch.int32, device=cd.dev)
+        for step in (0, 3, 2 ** 32 + 1):
+            cd.ops.sample_inbatch(dp, 77, step, B, rows, shift)
+            wrows, _, _, ws = osampler.device_inbatch(pairs, 77, step, B)
+            np.testing.assert_array_equal(rows.cpu().numpy(), wrows)
+            assert int(shift.item()) == ws
+
+
+# -------------------------------------------------------------------- gather --
+@pytest.mark.parametrize("F", [1500, 100, 6, 2048])
+def test_gather_rows(cd, F):
+    n = 300
+    feats = np.random.RandomState(1).random_sample((n, F)).astype(np.float32)
+    table = cd.engine.FeatureTable.from_numpy(feats, cd.dev)
+    idx = np.random.RandomState(2).randint(0, n, size=77).astype(np.int32)
+    didx = dt(idx, cd.dev, torch.int32)
+    stride = ru(F, 64)
+    out = torch.full((77, stride), 9.0, device=cd.dev)
+    inv = torch.empty(77, device=cd.dev)
+    cd.ops.gather_rows(table.data, 0, didx, F, out, normalize=True, inv_norm_out=inv)
+    want, winv = otower.l2_normalize(osampler.gather(feats, idx), np.float32)
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got[:, :F], want, atol=1e-6)
+    assert np.all(got[:, F:] == 0)
+    np.testing.assert_allclose(inv.cpu().numpy(), winv[:, 0], rtol=1e-6)
+    # raw gather is a bit-exact copy (inputs.py:158)
+    raw = torch.empty((77, ru(F, 4)), device=cd.dev)
+    cd.ops.gather_rows(table.data, 0, didx, F, raw, normalize=False)
+    np.testing.assert_array_equal(raw.cpu().numpy()[:, :F], feats[idx])
+
+
+def test_gather_shard_and_oob_flag(cd):
+    feats = np.random.RandomState(1).random_sample((50, 8)).astype(np.float32)
+    table = cd.engine.FeatureTable.from_numpy(feats, cd.dev, row0=100, n_rows_global=200)
+    flag = torch.zeros(1, dtype=torch.int32, device=cd.dev)
+    out = torch.empty((3, 8), device=cd.dev)
+    cd.ops.gather_rows(table.data, 100, dt([100, 149, 120], cd.dev, torch.int32), 8, out,
+                       normalize=False, oob_flag=flag)
+    np.testing.assert_array_equal(out.cpu().numpy(), feats[[0, 49, 20]])
+    assert int(flag.item()) == 0
+    cd.ops.gather_rows(table.data, 100, dt([99, 150, 120], cd.dev, torch.int32), 8, out,
+                       normalize=False, oob_flag=flag)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fused_sample_gather_equals_separate(cd, mode):
+    N, F, B = 2000, 1500, 130
+    table = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev)
+    pairs = dt(osynth.cowatch_pairs(N, 200, 0), cd.dev, torch.int32)
+    rpt = 3 if mode == 0 else 2
+    Fp = table.data.shape[1]
+    x1 = torch.empty((rpt * B, Fp), device=cd.dev)
+    x2 = torch.empty_like(x1)
+    i1 = torch.empty(rpt * B, dtype=torch.int32, device=cd.dev)
+    i2 = torch.empty_like(i1)
+    s1 = torch.zeros(1, dtype=torch.int32, device=cd.dev)
+    s2 = torch.zeros_like(s1)
+    cd.ops.sample_gather(mode, pairs, 5, 11, B, table.data, F, i1, x1, shift_out=s1)
+    if mode == 0:
+        cd.ops.sample_uniform(pairs, N, 5, 11, B, i2)
+    else:
+        cd.ops.sample_inbatch(pairs, 5, 11, B, i2, s2)
+    cd.ops.gather_rows(table.data, 0, i2, F, x2, normalize=True)
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
+    assert float((x1 - x2).abs().max()) < 1e-7          # same rows; fma contraction may differ per kernel
+    np.testing.assert_allclose(x1[:, :F].norm(dim=1).cpu().numpy(), 1.0, atol=1e-6)
+
+
+# --------------------------------------------------------------------- norms --
+def test_l2norm_fwd_bwd(cd):
+    rng = np.random.RandomState(0)
+    z = rng.randn(70, 256).astype(np.float32)
+    z[3] = 0                                   # clamped row: eps branch
+    z[4] = 1e-8
+    g = rng.randn(70, 256).astype(np.float32)
+    dz_, dg = dt(z, cd.dev), dt(g, cd.dev)
+    y = torch.empty_like(dz_)
+    inv = torch.empty(70, device=cd.dev)
+    cd.ops.l2norm_fwd(dz_, 256, y, inv)
+    wy, winv = otower.l2_normalize(z, np.float64)
+    np.testing.assert_allclose(y.cpu().numpy(), wy, atol=1e-6)
+    np.testing.assert_allclose(inv.cpu().numpy(), winv[:, 0], rtol=1e-6)
+    out = torch.empty_like(dz_)
+    cd.ops.l2norm_bwd(dz_, dg, 256, out, lrelu_alpha=-1.0)
+    want = otower.l2_normalize_backward(z.astype(np.float64), winv, g, np.float64)
+    scale = np.abs(want).max(axis=1, keepdims=True) + 1e-30
+    assert np.max(np.abs(out.cpu().numpy() - want) / scale) < 1e-5
+    cd.ops.l2norm_bwd(dz_, dg, 256, out, lrelu_alpha=0.2)
+    want2 = otower.leaky_relu_backward(z.astype(np.float64), want)
+    assert np.max(np.abs(out.cpu().numpy() - want2) / scale) < 1e-5
+
+
+# ---------------------------------------------------------------------- GEMM --
+FC_SHAPES = [(15, 64, 64), (130, 96, 192), (384, 1536, 5120), (257, 5120, 256), (64, 32, 128)]
+
+
+@pytest.mark.parametrize("M,K,N", FC_SHAPES)
+def test_fc_lrelu_fwd(cd, M, K, N):
+    rng = np.random.RandomState(M + K + N)
+    x = rng.randn(M, K) / np.sqrt(K)
+    W = rng.randn(K, N) * 0.5
+    b = rng.randn(N) * 0.1
+    y = torch.full((M, N), 7.0, device=cd.dev)
+    cd.ops.fc_lrelu_fwd(dt(x, cd.dev), dt(W, cd.dev), dt(b, cd.dev), y, M, K, N)
+    want = otower.fully_connected(x.astype(np.float32).astype(np.float64),
+                                  W.astype(np.float32).astype(np.float64),
+                                  b.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(y.cpu().numpy(), want, atol=TOL)
+
+
+def test_fc_fwd_identity_asymmetric(cd):
+    """A = I with an asymmetric B catches a transposed C/D register map."""
+    K = N = 128
+    Bm = np.arange(K * N, dtype=np.float64).reshape(K, N) % 251 - 100
+    y = torch.empty((K, N), device=cd.dev)
+    cd.ops.fc_lrelu_fwd(dt(np.eye(K), cd.dev), dt(Bm, cd.dev), dt(np.zeros(N), cd.dev), y, K, K, N,
+                        alpha=1.0)
+    np.testing.assert_array_equal(y.cpu().numpy(), Bm.astype(np.float32))
+
+
+@pytest.mark.parametrize("M,K,N", [(15, 64, 64), (130, 192, 96), (384, 5120, 256), (200, 128, 32)])
+def test_fc_bwd_data(cd, M, K, N):
+    rng = np.random.RandomState(M + K)
+    dy = rng.randn(M, N) / np.sqrt(N)
+    W = rng.randn(K, N) * 0.5
+    xp = rng.randn(M, K)
+    dx = torch.empty((M, K), device=cd.dev)
+    cd.ops.fc_bwd_data(dt(dy, cd.dev), dt(W, cd.dev), dt(xp, cd.dev), dx, M, K, N)
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    want = otower.leaky_relu_backward(f(xp), f(dy) @ f(W).T)
+    np.testing.assert_allclose(dx.cpu().numpy(), want, atol=TOL)
+    cd.ops.fc_bwd_data(dt(dy, cd.dev), dt(W, cd.dev), None, dx, M, K, N)
+    np.testing.assert_allclose(dx.cpu().numpy(), f(dy) @ f(W).T, atol=TOL)
+
+
+@pytest.mark.parametrize("M,K,N", [(15, 64, 64), (130, 192, 128), (384, 1536, 5120),
+                                   (3000, 5120, 256), (1000, 128, 64)])
+def test_fc_bwd_weight(cd, M, K, N):
+    rng = np.random.RandomState(M + N)
+    x = rng.randn(M, K) / np.sqrt(M)
+    dy = rng.randn(M, N)
+    nb = cd.ops.fc_bwd_weight_workspace(M, K, N)
+    assert nb > 0
+    ws = torch.empty(nb // 4, device=cd.dev)
+    dW = torch.empty((K, N), device=cd.dev)
+    db = torch.empty(N, device=cd.dev)
+    cd.ops.fc_bwd_weight(dt(x, cd.dev), dt(dy, cd.dev), dW, db, ws, M, K, N)
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    np.testing.assert_allclose(dW.cpu().numpy(), f(x).T @ f(dy), atol=2e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), f(dy).sum(0), atol=2e-5 * np.sqrt(M))
+    # deterministic: a second run is bit-identical
+    dW2 = torch.empty_like(dW)
+    cd.ops.fc_bwd_weight(dt(x, cd.dev), dt(dy, cd.dev), dW2, db, ws, M, K, N)
+    assert torch.equal(dW, dW2)
+
+
+# ---------------------------------------------------------------------- loss --
+@pytest.mark.parametrize("margin", [0.1, 0.8])
+def test_hinge_known_answer_facade(cd, golden_dir, margin):
+    k = json.load(open(os.path.join(golden_dir, "known_answers.json")))
+    x = np.zeros((5, 3, 4), np.float32)
+    x[:, :, :2] = np.array(k["loss_input"], np.float32)       # embed dim padded 2 -> 4 with zeros
+    loss_fn = cd.utils.find_class_by_name("HingeLoss", [cd.losses])()
+    out = loss_fn.calculate_loss(dt(x, cd.dev), margin=margin)
+    want = k[f"loss_margin_{margin}"]
+    assert tuple(out["pos_dist"].shape) == (5, 1) and tuple(out["anchors"].shape) == (5, 1, 4)
+    np.testing.assert_allclose(out["pos_dist"].cpu().numpy()[:, 0], k["loss_pos_dist"])
+    np.testing.assert_allclose(out["neg_dist"].cpu().numpy()[:, 0], k["loss_neg_dist"])
+    np.testing.assert_allclose(out["hinge_dist"].cpu().numpy()[:, 0], want["hinge_dist"], rtol=1e-6)
+    np.testing.assert_allclose(out["hinge_loss"].item(), want["hinge_loss"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("B,D", [(1, 4), (7, 256), (300, 256), (64, 32)])
+def test_hinge_fwd_bwd_vs_oracle(cd, B, D):
+    rng = np.random.RandomState(B)
+    e = otower.l2_normalize(rng.randn(3 * B, D), np.float64)[0]
+    de = torch.empty((3 * B, D), device=cd.dev)
+    pos, neg, hinge = (torch.empty(B, device=cd.dev) for _ in range(3))
+    stats = torch.empty(4, device=cd.dev)
+    cd.ops.triplet_hinge(dt(e, cd.dev), B, D, 0.8, pos, neg, hinge, stats, de)
+    e32 = e.astype(np.float32).astype(np.float64).reshape(B, 3, D)
+    w = otower.hinge_loss(e32, 0.8, np.float64)
+    np.testing.assert_allclose(pos.cpu().numpy(), w["pos_dist"][:, 0], atol=TOL)
+    np.testing.assert_allclose(hinge.cpu().numpy(), w["hinge_dist"][:, 0], atol=TOL)
+    np.testing.assert_allclose(stats[0].item(), w["hinge_loss"], atol=TOL)
+    np.testing.assert_allclose(stats[1].item(), w["pos_dist"].mean(), atol=TOL)
+    np.testing.assert_allclose(stats[2].item(), w["neg_dist"].mean(), atol=TOL)
+    wd = otower.hinge_loss_backward(e32, 0.8, np.float64).reshape(3 * B, D)
+    np.testing.assert_allclose(de.cpu().numpy(), wd, atol=TOL)
+
+
+def test_hinge_inbatch_vs_oracle(cd):
+    pairs = osynth.cowatch_pairs(40, 30, 2)            # tiny catalogue -> some invalid negatives
+    B, D = 64, 32
+    rng = np.random.RandomState(1)
+    e = otower.l2_normalize(rng.randn(2 * B, D), np.float64)[0].astype(np.float32)
+    n_invalid = 0
+    for step in range(4):
+        rows, tri, valid, s = osampler.device_inbatch(pairs, 3, step, B)
+        n_invalid += int((valid == 0).sum())
+        pos, neg, hinge = (torch.empty(B, device=cd.dev) for _ in range(3))
+        v = torch.empty(B, dtype=torch.uint8, device=cd.dev)
+        stats = torch.empty(4, device=cd.dev)
+        de = torch.empty((2 * B, D), device=cd.dev)
+        cd.ops.triplet_hinge_inbatch(dt(e, cd.dev), dt(rows, cd.dev, torch.int32),
+                                     dt([s], cd.dev, torch.int32), B, D, 0.8, pos, neg, hinge, v,
+                                     stats, de)
+        np.testing.assert_array_equal(v.cpu().numpy(), valid)
+        w = otower.hinge_loss_indexed(e.astype(np.float64), tri, valid.astype(bool), 0.8, np.float64)
+        np.testing.assert_allclose(hinge.cpu().numpy(), w["hinge_dist"], atol=TOL)
+        np.testing.assert_allclose(stats[0].item(), w["hinge_loss"], atol=TOL)
+        wd = otower.hinge_loss_indexed_backward(e.astype(np.float64), tri, valid.astype(bool), 0.8,
+                                                np.float64)
+        np.testing.assert_allclose(de.cpu().numpy(), wd, atol=TOL)
+    assert n_invalid > 0
+
+
+# ---------------------------------------------------------------- optimizers --
+def test_adam_vs_oracle(cd):
+    rng = np.random.RandomState(0)
+    n = 1003
+    w, g = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32) * 1e-3
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    dw, dm, dv = dt(w, cd.dev), dt(m, cd.dev), dt(v, cd.dev)
+    t_dev = torch.zeros(1, dtype=torch.int64, device=cd.dev)
+    lr_dev = torch.full((1,), 0.01, device=cd.dev)
+    for t in range(1, 4):
+        g = (g * 0.9 + 1e-4).astype(np.float32)
+        if t < 3:
+            cd.ops.adam_step(dw, dt(g, cd.dev), dm, dv, 0.01, t)
+        else:                                          # step and lr from device memory
+            t_dev.fill_(t - 1)
+            cd.ops.adam_step(dw, dt(g, cd.dev), dm, dv, 0.0, 1, lr_dev=lr_dev, t_dev=t_dev)
+        w, m, v = otower.adam_step(w, g, m, v, t, 0.01, dtype=np.float32)
+        np.testing.assert_allclose(dw.cpu().numpy(), w, atol=1e-6)
+        np.testing.assert_allclose(dm.cpu().numpy(), m, rtol=2e-6, atol=1e-12)
+        np.testing.assert_allclose(dv.cpu().numpy(), v, rtol=2e-6, atol=1e-15)
+
+
+def test_lars_vs_oracle(cd):
+    rng = np.random.RandomState(0)
+    n = 5000
+    w, g = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32) * 0.1
+    acc = np.zeros(n, np.float32)
+    dw, da = dt(w, cd.dev), dt(acc, cd.dev)
+    scratch = torch.zeros(cd.ops.lars_scratch_floats(), device=cd.dev)
+    for _ in range(3):
+        cd.ops.lars_step(dw, dt(g, cd.dev), da, 1.0, scratch)
+        w, acc = otower.lars_step(w, g, acc, 1.0, dtype=np.float64)
+        np.testing.assert_allclose(dw.cpu().numpy(), w, atol=1e-6)
+    z = torch.zeros(16, device=cd.dev)                 # |w| == 0 -> trust 1
+    cd.ops.lars_step(z, dt(np.ones(16), cd.dev), torch.zeros(16, device=cd.dev), 1.0, scratch)
+    np.testing.assert_allclose(z.cpu().numpy(), -1.0)
+
+
+# ------------------------------------------------------------ end-to-end step --
+def _oracle_step(feats, pairs, W, step, B, mode, seed, margin=0.8):
+    """Embeddings, loss and gradients of one reference step from weights W (fp64)."""
+    N = len(feats)
+    if mode == "uniform":
+        idx = osampler.device_triplets_vec(pairs, N, seed, step, B)
+        fwd, loss, grads = otower.train_step_grads(feats[idx.reshape(-1)], W, margin, np.float64)
+    else:
+        rows, tri, valid, _ = osampler.device_inbatch(pairs, seed, step, B)
+        fwd = otower.vnet_forward(feats[rows], *W, dtype=np.float64)
+        loss = otower.hinge_loss_indexed(fwd["l2_norm"], tri, valid.astype(bool), margin, np.float64)
+        dE = otower.hinge_loss_indexed_backward(fwd["l2_norm"], tri, valid.astype(bool), margin,
+                                                np.float64)
+        grads = otower.vnet_backward(fwd, W[2], dE, np.float64)
+    return fwd["l2_norm"], float(loss["hinge_loss"]), grads
+
+
+@pytest.mark.parametrize("mode,optimizer", [("uniform", "adam"), ("inbatch", "adam"),
+                                            ("uniform", "lars")])
+def test_train_steps_config0(cd, mode, optimizer):
+    """BASELINE config 0 shape: 10k x 1500 catalogue (imitation_data-shaped), 5000
+    hidden, 256-d, batch 128.  Every step is checked from the device's own
+    weights (Adam amplifies 1e-9 gradient noise near g = 0 into lr-sized update
+    differences, so free-running fp32 and fp64 trajectories are not comparable):
+    embeddings / loss / gradients against the fp64 oracle, and the optimizer
+    against the oracle's update applied to the device's gradients and slots."""
+    N, F, B, D = 10000, 1500, 128, 256
+    feats = osynth.features_numpy(N, F, seed=0).astype(np.float32)
+    pairs = osynth.cowatch_pairs(N, 3000, 0)
+    table = cd.engine.FeatureTable.from_numpy(feats, cd.dev)
+    lr = 0.01 if optimizer == "adam" else 1.0
+    ts = cd.train.TrainStep(table, dt(pairs, cd.dev, torch.int32), B, margin=0.8, mode=mode,
+                            optimizer=optimizer, base_learning_rate=lr, device=cd.dev)
+    f64 = feats.astype(np.float64)
+    host = lambda ts_: [t.detach().cpu().numpy().copy() for t in ts_]
+    names = ("dW1", "db1", "dW2", "db2")
+    for step in range(3):
+        W = host(ts.params.unpadded())
+        if optimizer == "adam":
+            slots = [host(ts.params._views(ts.m)), host(ts.params._views(ts.v))]
+        else:
+            slots = [host(ts.params._views(ts.acc))]
+        ts.step()
+        we, wl, wg = _oracle_step(f64, pairs, [w.astype(np.float64) for w in W], step, B, mode, 1234)
+        e = ts.ws.e[:, :D].cpu().numpy()
+        assert np.abs(e - we).max() < TOL, f"embeddings step {step}"
+        assert abs(ts.loss() - wl) < TOL, f"loss step {step}"
+        np.testing.assert_allclose(np.linalg.norm(e, axis=1), 1.0, atol=1e-5)
+        G = host(ts.params.unpadded(grads=True))
+        for got, k in zip(G, names):
+            scale = max(np.abs(wg[k]).max(), 1e-30)
+            assert np.abs(got - wg[k]).max() < TOL * max(scale, 1.0), f"{k} step {step}"
+            # embeddings of iid-uniform features nearly coincide, so the gradient is a sum of
+            # cancelling terms: fp32 accumulation noise is a few % of its (tiny) magnitude
+            assert np.abs(got - wg[k]).max() / scale < 5e-2, f"{k} (relative) step {step}"
+        L = ts.layout
+        sl = ((slice(0, L.F), slice(0, L.H)), (slice(0, L.H),), (slice(0, L.H), slice(0, L.D)),
+              (slice(0, L.D),))
+        for i, got in enumerate(host(ts.params.unpadded())):
+            if optimizer == "adam":
+                w, _, _ = otower.adam_step(W[i], G[i], slots[0][i][sl[i]], slots[1][i][sl[i]], step + 1,
+                                           lr, dtype=np.float32)
+            else:
+                w, _ = otower.lars_step(W[i], G[i], slots[0][i][sl[i]], lr, dtype=np.float32)
+            assert np.abs(got - w).max() < 1e-6, f"optimizer var {i} step {step}"
+    # padded storage stays exactly zero
+    L = ts.layout
+    assert float(ts.params.W1[L.F:].abs().max()) == 0 and float(ts.params.W1[:, L.H:].abs().max()) == 0
+    assert float(ts.params.b1[L.H:].abs().max()) == 0 and float(ts.params.W2[L.H:].abs().max()) == 0
+    assert int(ts.step_dev.item()) == 3
+
+
+def test_graph_replay_equals_eager(cd):
+    N, F, B = 4000, 200, 64
+    table = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev)
+    pairs = dt(osynth.cowatch_pairs(N, 500, 0), cd.dev, torch.int32)
+    kw = dict(hidden_size=300, output_size=64, mode="uniform", device=cd.dev)
+    a = cd.train.TrainStep(table, pairs, B, use_graph=False, **kw)
+    b = cd.train.TrainStep(table, pairs, B, use_graph=True, **kw)
+    for _ in range(4):
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.params.flat, b.params.flat)
+    assert torch.equal(a.idx, b.idx) and int(b.step_dev.item()) == 4
+
+
+# --------------------------------------------------------------------- facade --
+def test_facade_matches_train_step(cd):
+    """models.VNet / losses.HingeLoss / inputs.MPTripletPipe used the way
+    train.py:105-146 uses them give the fused step's numbers."""
+    N, F, B = 3000, 1500, 32
+    feats = osynth.features_numpy(N, F, seed=1).astype(np.float32)
+    pairs = osynth.cowatch_pairs(N, 400, 1)
+    pipe = cd.inputs.MPTripletPipe(pairs=pairs, table=feats, device=cd.dev, seed=1234)
+    assert pipe.cowatch_num == len(pairs)
+    pipe.create_pipe(num_epochs=1, batch_size=B)
+    batch = pipe.get_batch()
+    assert tuple(batch.shape) == (B, 3, F) and batch.dtype == torch.float32
+    idx = osampler.device_triplets_vec(pairs, N, 1234, 0, B)
+    np.testing.assert_array_equal(batch.cpu().numpy(), feats[idx])       # inputs.py:158
+
+    model = cd.utils.find_class_by_name("VNet", [cd.models])(device=cd.dev, seed=42)
+    loss_fn = cd.utils.find_class_by_name("HingeLoss", [cd.losses])()
+    result = model.create_model(batch.reshape(-1, F), 256)               # train.py:105,313
+    assert set(result) == {"layer_1", "layer_2", "l2_norm"}
+    assert tuple(result["layer_1"].shape) == (3 * B, 5000)
+    trip = result["l2_norm"].reshape(-1, 3, 256)                         # train.py:128
+    out = loss_fn.calculate_loss(trip, margin=0.8)
+    out["hinge_loss"].backward()
+
+    ts = cd.train.TrainStep(pipe.table, pipe.pairs, B, margin=0.8, mode="uniform", device=cd.dev)
+    ts.fetch(); ts.forward_loss(); ts.backward()
+    torch.cuda.synchronize()
+    # two kernel routes to the same numbers (fused gather+norm vs norm of a raw batch)
+    assert float((result["l2_norm"] - ts.ws.e[:, :256]).abs().max()) < 1e-6
+    assert abs(out["hinge_loss"].item() - ts.loss()) < 1e-6
+    assert float((model.params.flat.grad - ts.params.grad).abs().max()) < 1e-6
+    with pytest.raises(StopIteration):
+        cd.utils.find_class_by_name("VedeNet", [cd.models])              # train.py:43 default
+
+
+def test_pipe_exhaustion_and_replay(cd):
+    feats = np.random.RandomState(0).random_sample((20, 8)).astype(np.float32)
+    pairs = np.array([[i, (i + 1) % 20] for i in range(10)], dtype=np.int32)
+    pipe = cd.inputs.MPTripletPipe(pairs=pairs, table=feats, device=cd.dev)
+    pipe.create_pipe(num_epochs=3, batch_size=4)             # 30 pairs -> 7 whole batches
+    n = 0
+    while True:
+        b = pipe.get_batch()
+        if b is None:
+            break
+        n += 1
+        assert tuple(b.shape) == (4, 3, 8)
+    assert n == 7 and pipe.get_batch() is None
+    # replay mode: reference-identical triplets supplied by the caller
+    ref = osampler.reference_triplets(pairs[:4], 20, seed=1234)
+    b = pipe.get_batch(indices=ref)
+    np.testing.assert_array_equal(b.cpu().numpy(), feats[ref])
+    pipe.check_indices()
+    pipe.get_batch(indices=[[0, 1, 25]])
+    with pytest.raises(IndexError):
+        pipe.check_indices()
+
+
+def test_errors_are_raised_not_swallowed(cd):
+    y = torch.empty((8, 64), device=cd.dev)
+    x = torch.empty((8, 48), device=cd.dev)
+    W = torch.empty((48, 64), device=cd.dev)
+    b = torch.empty(64, device=cd.dev)
+    with pytest.raises(cd.pkg.CdmlError) as ei:
+        cd.ops.fc_lrelu_fwd(x, W, b, y, 8, 48, 64)           # K not a multiple of 32
+    assert ei.value.code == -4 and "multiple of 32" in str(ei.value)
+    with pytest.raises(cd.pkg.CdmlError):
+        cd.ops.fc_lrelu_fwd(x[:, 1:33], W[:32], b, y, 8, 32, 64)    # misaligned base
+    with pytest.raises(ValueError):
+        cd.ops.l2norm_fwd(torch.empty((4, 8)), 8, torch.empty((4, 8)))   # CPU tensors: no fallback
+    with pytest.raises(cd.pkg.CdmlError):
+        cd.ops.sample_inbatch(torch.zeros((4, 2), dtype=torch.int32, device=cd.dev), 1, 0, 1,
+                              torch.zeros(2, dtype=torch.int32, device=cd.dev),
+                              torch.zeros(1, dtype=torch.int32, device=cd.dev))
+
+
+# ------------------------------------------------ full-size properties (c1) ----
+def test_full_size_properties_config1(cd):
+    """BASELINE config 1 sizes (scaled catalogue: the properties do not depend on
+    row count): B=4096 in-batch step on a 200k x 1500 table."""
+    N, F, B = 200000, 1500, 4096
+    table = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev)
+    pairs_np = osynth.cowatch_pairs(N, 40000, 0)
+    ts = cd.train.TrainStep(table, dt(pairs_np, cd.dev, torch.int32), B, mode="inbatch", device=cd.dev)
+    ts.fetch(); ts.forward_loss(); ts.backward()
+    torch.cuda.synchronize()
+    rows = ts.idx.cpu().numpy()
+    q = np.arange(B) % len(pairs_np)
+    np.testing.assert_array_equal(rows.reshape(B, 2), pairs_np[q])           # bit-exact ids
+    xn = ts.ws.x_hat[:, :F].norm(dim=1)
+    assert float((xn - 1).abs().max()) < 1e-5                                 # unit rows in
+    en = ts.ws.e.norm(dim=1)
+    assert float((en - 1).abs().max()) < 1e-5                                 # unit rows out
+    # gathered rows are the table rows, normalised (spot check vs the oracle)
+    sel = np.array([0, 1, 4095, 8191])
+    raw = np.concatenate([osynth.features_philox(int(r), 1, F, 0) for r in rows[sel]])
+    want = otower.l2_normalize(raw, np.float32)[0]
+    np.testing.assert_allclose(ts.ws.x_hat[sel, :F].cpu().numpy(), want, atol=1e-6)
+    # loss/gradient consistency: dE rows sum to ~0 per triplet group and the
+    # weight gradient equals x_hat^T dz1 recomputed by torch on a column slab
+    assert torch.isfinite(ts.params.grad).all()
+    ref = ts.ws.x_hat.double().T @ ts.ws.dz1[:, :256].double()
+    assert float((ts.params.gW1[:, :256].double() - ref).abs().max()) < 1e-5
+    sub = otower.vnet_forward(ts.ws.x_hat[:64, :F].cpu().numpy().astype(np.float64),
+                              *[t.cpu().numpy().astype(np.float64) for t in ts.params.unpadded()],
+                              dtype=np.float64)
+    # x_hat is already unit norm, so re-normalising it is the identity to 1e-7
+    assert np.abs(ts.ws.e[:64].cpu().numpy() - sub["l2_norm"]).max() < TOL
+    # determinism: a second pass over the same step is bit-identical
+    g0 = ts.params.grad.clone()
+    ts.fetch(); ts.forward_loss(); ts.backward()
+    assert torch.equal(g0, ts.params.grad)

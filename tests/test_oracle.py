@@ -233,8 +233,10 @@ def test_adam_tf_form():
     m = np.zeros(2); v = np.zeros(2)
     w1, m1, v1 = tower.adam_step(w, g, m, v, 1, 0.01, dtype=np.float64)
     lr_t = 0.01 * np.sqrt(1 - 0.999) / (1 - 0.9)
-    np.testing.assert_allclose(m1, 0.1 * g)
-    np.testing.assert_allclose(v1, 0.001 * g * g)
+    np.testing.assert_allclose(m1, 0.1 * g, rtol=1e-12)
+    np.testing.assert_allclose(v1, 0.001 * g * g, rtol=1e-12)
+    _, _, v32 = tower.adam_step(w, g, m, v, 1, 0.01, dtype=np.float32)
+    np.testing.assert_allclose(v32, np.float32(1 - np.float32(0.999)) * np.float32(g) ** 2, rtol=1e-6)
     np.testing.assert_allclose(w1, w - lr_t * m1 / (np.sqrt(v1) + 1e-8))
     # differs from torch.optim.Adam's epsilon placement when g is tiny
     g2 = np.array([1e-9, 1e-9])
