@@ -76,6 +76,23 @@ class KernelTimer:
         return float(np.mean(v)) if v else None
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
+    (profiles/latest_pmc.csv: separate FETCH_SIZE / WRITE_SIZE passes of this
+    bench, KiB; FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "latest_pmc.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+    vals = {}
+    for r in csv.DictReader(open(path)):
+        if r["kernel"] == kernel:
+            vals[r["counter"]] = float(r["mean_per_launch"])
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def cpu_baseline(budget_s=12.0):
     """The oracle's restatement of one reference training step (numpy gather as
     inputs.py:158 + fp32 tower fwd/bwd + Adam), timed on the host cores."""
@@ -226,16 +243,26 @@ def main():
                        "hipgraph": bool(args.graph)},
             "loss": round(loss, 6),
         }
-        flops_gemm = 2.0 * R * F * H                        # algorithmic, unpadded
+        # dominant kernel by total time: the bwd-weight GEMM k_gemm_f32<false, false, 2, 2, 3>,
+        # launched twice per step (dW1: 2*R*F*H flop, dW2: 2*R*H*D flop); rocprof's per-kernel
+        # average is over both launches, so the roofline is too.  Algorithmic (unpadded) flop.
+        flops_gemm = 2.0 * R * F * H
         if timers_on:
-            cand = {k: kt.mean_ms(k) for k in ("fc1_fwd", "dW1")}
-            dom = max(cand, key=lambda k: cand[k] or 0)
-            t_ms = cand[dom]
-            ach = flops_gemm / (t_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
-                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                               "launch_ms": round(t_ms, 4), "flop_per_launch": flops_gemm}
+            t_ms = 0.5 * (kt.mean_ms("dW1") + kt.mean_ms("dW2"))
+            flop_launch = 0.5 * (2.0 * R * F * H + 2.0 * R * H * D)
+            ach = flop_launch / (t_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_f32<false, false, 2, 2, 3> (dW1+dW2 launches)",
+                               "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                               "traffic": pmc_traffic("k_gemm_f32<false, false, 2, 2, 3>"),
+                               "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch}
+            ach1 = flops_gemm / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
+            out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": "k_gemm_f32<true, false, 2, 2, 1>",
+                                       "achieved": round(ach1, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": round(ach1 / PEAK_F32_MFMA_TFLOPS, 4),
+                                       "traffic": pmc_traffic("k_gemm_f32<true, false, 2, 2, 1>"),
+                                       "launch_ms": round(kt.mean_ms("fc1_fwd"), 4),
+                                       "flop_per_launch": flops_gemm}
             kern = {}
             for k in ("fc1_fwd", "fc2_fwd", "dW1", "dW2", "fetch"):
                 if kt.mean_ms(k) is not None:
@@ -245,8 +272,9 @@ def main():
             if t_f and world == 1:
                 gbytes = 2.0 * R * F * 4                     # rows read + normalised rows written
                 g_ach = gbytes / (t_f * 1e-3) / 1e9
-                out["gather"] = {"bound": "hbm", "achieved": round(g_ach, 1), "peak": PEAK_HBM_GBS,
-                                 "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4),
+                out["gather"] = {"bound": "hbm", "kernel": "k_sample_gather", "achieved": round(g_ach, 1),
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4),
+                                 "traffic": pmc_traffic("k_sample_gather<1, 6>" if rpt == 2 else "k_sample_gather<0, 6>"),
                                  "bytes_per_launch": gbytes, "launch_ms": round(t_f, 4)}
         step_flops = R * (2.0 * F * H + 2.0 * H * D) + R * (2.0 * F * H + 4.0 * H * D)
         out["step_tflops"] = round(step_flops / (elapsed / args.steps) / 1e12, 2)
