@@ -156,6 +156,8 @@ def main():
         sys.exit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback)")
+    backend = os.environ.get("CDML_DIST_BACKEND", "nccl")     # "gloo": 1-GPU-box rehearsal of N>1
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -164,7 +166,10 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n_rows = args.rows or (1000000 if world == 1 else 10000000)
     B = args.batch
@@ -205,6 +210,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         ts.step()
     sync_all()
@@ -219,9 +229,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kt.on = False
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = reduce_max(elapsed)
     loss = ts.loss()
     assert np.isfinite(loss), "non-finite loss"
 

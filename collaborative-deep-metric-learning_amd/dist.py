@@ -29,6 +29,25 @@ def shard_bounds(n_rows_global, world, rank):
     return lo, min(lo + per, n_rows_global), per
 
 
+def _host_staged(group):
+    """gloo cannot move device tensors through all_to_all: a rehearsal run of the
+    N>1 path on a box without RCCL peers stages the collectives through host
+    memory.  With RCCL ("nccl") tensors go over xGMI directly."""
+    return dist.get_backend(group) != "nccl"
+
+
+def all_to_all(out, inp, out_splits=None, in_splits=None, group=None):
+    if inp.is_cuda and _host_staged(group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits,
+                               input_split_sizes=in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits,
+                               input_split_sizes=in_splits, group=group)
+    return out
+
+
 def _hip_local_gather(table, ids, out):
     """Owner side: gather + l2-normalise local rows with the HIP kernel."""
     ops.gather_rows(table.data, table.row0, ids, table.feature_size, out, normalize=True)
@@ -66,19 +85,17 @@ class RowExchange:
         dev = ids.device
         send_ids, order, send_counts = self.plan(ids)
         recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        all_to_all(recv_counts, send_counts, group=self.group)
         sc, rc = send_counts.tolist(), recv_counts.tolist()       # host sync: split sizes
         n_req = int(sum(rc))
         req_ids = self._scratch("req_ids", (max(n_req, 1),), torch.int32, dev)[:n_req]
-        dist.all_to_all_single(req_ids, send_ids, output_split_sizes=rc, input_split_sizes=sc,
-                               group=self.group)
+        all_to_all(req_ids, send_ids, rc, sc, self.group)
         stride = out.shape[1]
         rows_out = self._scratch("rows_out", (max(n_req, 1), stride), torch.float32, out.device)[:n_req]
         if n_req:
             self.local_gather(table, req_ids, rows_out)
         rows_in = self._scratch("rows_in", (ids.numel(), stride), torch.float32, out.device)
-        dist.all_to_all_single(rows_in, rows_out, output_split_sizes=sc, input_split_sizes=rc,
-                               group=self.group)
+        all_to_all(rows_in, rows_out, sc, rc, self.group)
         inv = torch.empty_like(order)
         inv[order] = torch.arange(order.numel(), device=dev)
         self.unpermute(rows_in, inv, out)
@@ -106,6 +123,10 @@ class GradSync:
             return flat_grad
         if self.avg:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=self.group)
+        elif flat_grad.is_cuda:                      # gloo rehearsal: stage through host
+            h = flat_grad.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            flat_grad.copy_(h.div_(self.world))
         else:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             flat_grad.div_(self.world)

@@ -1,0 +1,103 @@
+"""world_size-2 gloo (CPU) test of the multi-GPU plumbing in cdml_amd.dist: row
+routing over a row-sharded catalogue (all-to-all ids -> owner gather ->
+all-to-all rows -> unpermute) and the gradient average.  The owner-side gather
+is injected from the oracle here (the HIP kernel needs a GPU); everything else
+is the product code path the N>1 bench runs over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_rows, F, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cdml_amd import dist as cdist
+        from oracle import sampler as osampler, synth as osynth, tower as otower
+
+        full = osynth.features_philox(0, n_rows, F, seed=3)            # the global catalogue
+        lo, hi, per = cdist.shard_bounds(n_rows, world, rank)
+
+        class Shard:                                                   # stand-in for FeatureTable
+            data = torch.from_numpy(full[lo:hi].copy())
+            row0, feature_size = lo, F
+
+        def oracle_gather(table, ids, out):
+            rows = table.data.numpy()[ids.numpy() - table.row0]
+            out[:, :F] = torch.from_numpy(otower.l2_normalize(rows, np.float32)[0])
+            out[:, F:] = 0
+            return out
+
+        ex = cdist.RowExchange(n_rows, local_gather=oracle_gather)
+        assert ex.per == per
+        pairs = osynth.cowatch_pairs(n_rows, 60, 1)
+        B = 16
+        for step in range(3):
+            # this rank's slice of the global batch (counter-based sampler: no comms)
+            idx = osampler.device_triplets_vec(pairs, n_rows, 7, step, B, slot0=rank * B,
+                                               batch_global=world * B).reshape(-1)
+            ids = torch.from_numpy(idx.astype(np.int32))
+            out = torch.full((len(idx), F + 4), -1.0)
+            ex.gather(Shard, ids, out)
+            want = otower.l2_normalize(full[idx], np.float32)[0]
+            np.testing.assert_allclose(out[:, :F].numpy(), want, atol=1e-7)
+            assert float(out[:, F:].abs().max()) == 0
+        # routing plan: sorted by owner, counts per owner, stable
+        ids = torch.tensor([per + 1, 0, per, 3, 2 * per - 1], dtype=torch.int32).clamp(max=n_rows - 1)
+        send, order, counts = ex.plan(ids)
+        assert counts.tolist() == [2, 3] and send.tolist() == [0, 3, per + 1, per, min(2 * per - 1, n_rows - 1)]
+        # gradient average
+        sync = cdist.GradSync()
+        g = torch.full((10,), float(rank + 1))
+        sync(g)
+        np.testing.assert_allclose(g.numpy(), (1 + 2) / 2)
+        q.put((rank, "ok"))
+    except Exception as e:                                             # surface in the parent
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_exchange_and_grad_sync_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 101, 12, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_shard_bounds_cover_catalogue():
+    sys.path.insert(0, ROOT)
+    from cdml_amd import dist as cdist
+    for n, w in ((10000000, 8), (101, 2), (7, 8), (1000000, 1)):
+        spans = [cdist.shard_bounds(n, w, r)[:2] for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        per = cdist.shard_bounds(n, w, 0)[2]
+        for r in (0, n // 2, n - 1):
+            assert spans[r // per][0] <= r < spans[r // per][1]

@@ -1,0 +1,99 @@
+"""Data-parallel equivalence on the GPU box: two ranks (sharing the one card,
+collectives host-staged over gloo because RCCL needs one GPU per rank) with a
+row-sharded catalogue, the row exchange and the gradient average must reproduce
+the single-rank step on the global batch: same sampled triplets (bit-exact),
+same weights after the update (fp32 summation order differs only in the
+gradient average)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CFG = dict(n_rows=3000, F=200, H=300, D=64, B=32, steps=2)
+
+
+def _make(dev, rank, world, exchange=None, grad_sync=None):
+    from cdml_amd import dist as cdist, engine, train
+    from oracle import synth as osynth
+    c = CFG
+    pairs = torch.from_numpy(osynth.cowatch_pairs(c["n_rows"], 400, 0)).to(dev)
+    if world == 1:
+        table = engine.FeatureTable.synthetic(c["n_rows"], c["F"], 0, dev)
+        B, slot0 = 2 * c["B"], 0
+    else:
+        lo, hi, _ = cdist.shard_bounds(c["n_rows"], world, rank)
+        table = engine.FeatureTable.synthetic(hi - lo, c["F"], 0, dev, row0=lo, n_rows_global=c["n_rows"])
+        B, slot0 = c["B"], rank * c["B"]
+    return train.TrainStep(table, pairs, B, hidden_size=c["H"], output_size=c["D"], mode="uniform",
+                           device=dev, exchange=exchange, grad_sync=grad_sync, slot0=slot0,
+                           batch_global=2 * c["B"])
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cdml_amd import dist as cdist
+        dev = torch.device("cuda:0")
+        ts = _make(dev, rank, world, cdist.RowExchange(CFG["n_rows"]), cdist.GradSync())
+        idx, g0 = [], None
+        for _ in range(CFG["steps"]):
+            ts.step()
+            idx.append(ts.idx.cpu().numpy().copy())
+            if g0 is None:
+                g0 = ts.params.grad.cpu().numpy().copy()                # averaged gradient, step 0
+        torch.cuda.synchronize()
+        q.put((rank, "ok", np.stack(idx), ts.params.flat.cpu().numpy(), ts.loss(), g0))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None, None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_rank(gpu):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
+
+    single = _make(gpu, 0, 1)
+    idx, g0 = [], None
+    for _ in range(CFG["steps"]):
+        single.step()
+        idx.append(single.idx.cpu().numpy().copy())
+        if g0 is None:
+            g0 = single.params.grad.cpu().numpy().copy()
+    torch.cuda.synchronize()
+    # mean over the global batch == average of the two ranks' local means
+    assert np.abs(res[0][5] - g0).max() < 1e-6 and np.abs(res[1][5] - g0).max() < 1e-6
+    want_idx = np.stack(idx)                                           # [steps, 2B*3]
+    got_idx = np.concatenate([res[0][2], res[1][2]], axis=1)
+    np.testing.assert_array_equal(got_idx, want_idx)                   # same global triplets
+    w = single.params.flat.cpu().numpy()
+    np.testing.assert_array_equal(res[0][3], res[1][3])                # replicas stay identical
+    # Adam turns 1e-9 gradient-order noise near g=0 into visible update noise; compare loosely
+    # on weights and tightly on the loss of the last step
+    assert np.abs(res[0][3] - w).max() < 2.5e-2
+    assert np.mean(np.abs(res[0][3] - w) > 1e-4) < 0.02
+    assert abs(0.5 * (res[0][4] + res[1][4]) - single.loss()) < 1e-4
