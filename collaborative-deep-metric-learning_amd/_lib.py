@@ -19,7 +19,8 @@ class CdmlError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", _LIB_NAME)
+    """Path of the built library; CDML_LIB_PATH overrides it (kernel A/B builds)."""
+    return os.environ.get("CDML_LIB_PATH") or os.path.join(_HERE, "lib", _LIB_NAME)
 
 
 _p = C.c_void_p

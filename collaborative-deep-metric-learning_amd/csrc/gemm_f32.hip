@@ -25,10 +25,27 @@ namespace cdml {
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+// native vector: HIP's float4 is a struct, and struct copies through pointers become
+// memcpy-to-alloca (scratch) when the copy is conditional
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kThreads = 256;
 constexpr int BK = 32;
 constexpr int KPAD = 4;
+
+// tuning switches (A/B'd on MI355X with tools/gemm_variants.sh)
+#ifndef CDML_GEMM_FRAG_PREFETCH
+#define CDML_GEMM_FRAG_PREFETCH 2   // read k-group g+1's fragments while group g's MFMAs issue (2: bwd-weight only)
+#endif
+#ifndef CDML_GEMM_BRANCHLESS_LOADS
+#define CDML_GEMM_BRANCHLESS_LOADS 1  // clamp/select instead of exec-masked branches
+#endif
+#ifndef CDML_GEMM_STAGGER
+#define CDML_GEMM_STAGGER 0         // 1: delay blocks by (bid>>8)&1, 2: by (bid>>3)&1 (co-residents out of lockstep)
+#endif
+#ifndef CDML_GEMM_LDS_EPILOGUE
+#define CDML_GEMM_LDS_EPILOGUE 1    // C tile through LDS -> coalesced 16-B row stores
+#endif
 
 enum { EPI_STORE = 0, EPI_BIAS_LRELU = 1, EPI_LRELU_MASK = 2, EPI_SLAB_COLSUM = 3 };
 
@@ -68,8 +85,11 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int A_TILE = AKC ? BM * (BK + KPAD) : BK * BM;
   constexpr int B_TILE = BKC ? BN * (BK + KPAD) : BK * BN;
-  constexpr int A_REGS = BM / 32, B_REGS = BN / 32;  // float4 staging registers per thread
-  __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+  constexpr int A_REGS = BM / 32, B_REGS = BN / 32;  // f32x4 staging registers per thread
+  constexpr bool KPRED = !AKC && !BKC;               // only the bwd-weight GEMM has a ragged K
+  constexpr int STAGE = 2 * (A_TILE + B_TILE);
+  constexpr int SMEM = STAGE > BM * BN ? STAGE : BM * BN;  // the epilogue reuses it as the C tile
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -85,74 +105,143 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
   const int k_end = min(g.K, k_begin + g.k_per_split);
   const int n_ktiles = (k_end - k_begin + BK - 1) / BK;
 
-  float4 ra[A_REGS], rb[B_REGS];
-  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x4 ra[A_REGS], rb[B_REGS];
+  f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool do_colsum = (EPI == EPI_SLAB_COLSUM) && g.colsum && tm == 0;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Global -> registers.  No branches: out-of-range rows / k are clamped to a
+  // valid address.  Clamped rows are never stored; clamped k (ragged last K-tile
+  // of the bwd-weight GEMM) is zeroed LATER, in store_tile -- touching a loaded
+  // value here would put the vmcnt wait in front of the MFMAs.
   auto load_tile = [&](int kt) {
     const int k0 = k_begin + kt * BK;
-    if (AKC) {  // rows [m0, m0+BM) x k [k0, k0+32): 8 float4 per row
+    if (AKC) {  // rows [m0, m0+BM) x k [k0, k0+32): 8 f32x4 per row
 #pragma unroll
       for (int p = 0; p < A_REGS; ++p) {
+#if CDML_GEMM_BRANCHLESS_LOADS
+        const int row = min(m0 + p * 32 + (t >> 3), g.M - 1);
+        ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (int64_t)row * g.lda + k0 + (t & 7) * 4);
+#else
         const int row = m0 + p * 32 + (t >> 3);
         ra[p] = (row < g.M)
-                    ? *reinterpret_cast<const float4 *>(g.A + (int64_t)row * g.lda + k0 + (t & 7) * 4)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                    ? *reinterpret_cast<const f32x4 *>(g.A + (int64_t)row * g.lda + k0 + (t & 7) * 4)
+                    : zero4;
+#endif
       }
     } else {  // k rows [k0, k0+32) x cols [m0, m0+BM)
       constexpr int C4 = BM / 4, KR = kThreads / C4;
 #pragma unroll
       for (int p = 0; p < A_REGS; ++p) {
         const int k = k0 + p * KR + t / C4;
+#if CDML_GEMM_BRANCHLESS_LOADS
+        const int kc = KPRED ? min(k, k_end - 1) : k;
+        ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (int64_t)kc * g.lda + m0 + (t % C4) * 4);
+#else
         ra[p] = (k < k_end)
-                    ? *reinterpret_cast<const float4 *>(g.A + (int64_t)k * g.lda + m0 + (t % C4) * 4)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                    ? *reinterpret_cast<const f32x4 *>(g.A + (int64_t)k * g.lda + m0 + (t % C4) * 4)
+                    : zero4;
+#endif
       }
     }
     if (BKC) {
 #pragma unroll
       for (int p = 0; p < B_REGS; ++p) {
         const int row = n0 + p * 32 + (t >> 3);
-        rb[p] = *reinterpret_cast<const float4 *>(g.B + (int64_t)row * g.ldb + k0 + (t & 7) * 4);
+        rb[p] = *reinterpret_cast<const f32x4 *>(g.B + (int64_t)row * g.ldb + k0 + (t & 7) * 4);
       }
     } else {
       constexpr int C4 = BN / 4, KR = kThreads / C4;
 #pragma unroll
       for (int p = 0; p < B_REGS; ++p) {
         const int k = k0 + p * KR + t / C4;
+#if CDML_GEMM_BRANCHLESS_LOADS
+        const int kc = KPRED ? min(k, k_end - 1) : k;
+        rb[p] = *reinterpret_cast<const f32x4 *>(g.B + (int64_t)kc * g.ldb + n0 + (t % C4) * 4);
+#else
         rb[p] = (k < k_end)
-                    ? *reinterpret_cast<const float4 *>(g.B + (int64_t)k * g.ldb + n0 + (t % C4) * 4)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == EPI_SLAB_COLSUM && do_colsum) {
-          bsum.x += rb[p].x; bsum.y += rb[p].y; bsum.z += rb[p].z; bsum.w += rb[p].w;
-        }
+                    ? *reinterpret_cast<const f32x4 *>(g.B + (int64_t)k * g.ldb + n0 + (t % C4) * 4)
+                    : zero4;
+#endif
       }
     }
   };
 
-  auto store_tile = [&](int buf) {
+  // Registers -> LDS (tile kt); also where the ragged-K zeroing and the
+  // bias-gradient column sums of the bwd-weight GEMM happen.
+  auto store_tile = [&](int buf, int kt) {
     float *sA = smem + buf * (A_TILE + B_TILE);
     float *sB = sA + A_TILE;
+    if (KPRED) {
+      const int k0 = k_begin + kt * BK;
+#if CDML_GEMM_BRANCHLESS_LOADS
+      if (k0 + BK > k_end) {  // uniform: only the last K-tile of a split can be ragged
+        constexpr int CA = BM / 4, KRA = kThreads / CA, CB = BN / 4, KRB = kThreads / CB;
+#pragma unroll
+        for (int p = 0; p < A_REGS; ++p)
+          if (k0 + p * KRA + t / CA >= k_end) ra[p] = zero4;
+#pragma unroll
+        for (int p = 0; p < B_REGS; ++p)
+          if (k0 + p * KRB + t / CB >= k_end) rb[p] = zero4;
+      }
+#endif
+      if (EPI == EPI_SLAB_COLSUM && do_colsum) {
+#pragma unroll
+        for (int p = 0; p < B_REGS; ++p) {
+          bsum.x += rb[p].x; bsum.y += rb[p].y; bsum.z += rb[p].z; bsum.w += rb[p].w;
+        }
+      }
+    }
     if (AKC) {
 #pragma unroll
       for (int p = 0; p < A_REGS; ++p)
-        *reinterpret_cast<float4 *>(sA + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = ra[p];
+        *reinterpret_cast<f32x4 *>(sA + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = ra[p];
     } else {
       constexpr int C4 = BM / 4, KR = kThreads / C4;
 #pragma unroll
       for (int p = 0; p < A_REGS; ++p)
-        *reinterpret_cast<float4 *>(sA + (p * KR + t / C4) * BM + (t % C4) * 4) = ra[p];
+        *reinterpret_cast<f32x4 *>(sA + (p * KR + t / C4) * BM + (t % C4) * 4) = ra[p];
     }
     if (BKC) {
 #pragma unroll
       for (int p = 0; p < B_REGS; ++p)
-        *reinterpret_cast<float4 *>(sB + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = rb[p];
+        *reinterpret_cast<f32x4 *>(sB + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = rb[p];
     } else {
       constexpr int C4 = BN / 4, KR = kThreads / C4;
 #pragma unroll
       for (int p = 0; p < B_REGS; ++p)
-        *reinterpret_cast<float4 *>(sB + (p * KR + t / C4) * BN + (t % C4) * 4) = rb[p];
+        *reinterpret_cast<f32x4 *>(sB + (p * KR + t / C4) * BN + (t % C4) * 4) = rb[p];
     }
+  };
+
+  // LDS -> MFMA operand fragments of k-group grp (8 k values; lane-half h owns 4).
+  // Returned by value: arrays passed by reference into a lambda end up in scratch.
+  struct Frag { float a[TM][4]; float b[TN][4]; };
+  auto load_frags = [&](const float *sA, const float *sB, int grp) {
+    Frag f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      const int row = wm * 32 * TM + mi * 32 + l31;
+      if (AKC) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(sA + row * (BK + KPAD) + 8 * grp + 4 * h);
+        f.a[mi][0] = v.x; f.a[mi][1] = v.y; f.a[mi][2] = v.z; f.a[mi][3] = v.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f.a[mi][u] = sA[(8 * grp + 4 * h + u) * BM + row];
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int col = wn * 32 * TN + ni * 32 + l31;
+      if (BKC) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(sB + col * (BK + KPAD) + 8 * grp + 4 * h);
+        f.b[ni][0] = v.x; f.b[ni][1] = v.y; f.b[ni][2] = v.z; f.b[ni][3] = v.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f.b[ni][u] = sB[(8 * grp + 4 * h + u) * BN + col];
+      }
+    }
+    return f;
   };
 
   f32x16 acc[TM][TN];
@@ -163,9 +252,15 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+#if CDML_GEMM_STAGGER == 1
+  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(32);
+#elif CDML_GEMM_STAGGER == 2
+  if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_sleep(32);
+#endif
+
   if (n_ktiles > 0) {
     load_tile(0);
-    store_tile(0);
+    store_tile(0, 0);
   }
   __syncthreads();
 
@@ -175,84 +270,154 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
 
     const float *sA = smem + buf * (A_TILE + B_TILE);
     const float *sB = sA + A_TILE;
+#define CDML_MFMA_GROUP(F)                                                                   \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u)                                              \
+  _Pragma("unroll") for (int mi = 0; mi < TM; ++mi)                                          \
+  _Pragma("unroll") for (int ni = 0; ni < TN; ++ni)                                          \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32((F).a[mi][u], (F).b[ni][u], acc[mi][ni], 0, 0, 0)
+    // CDML_GEMM_FRAG_PREFETCH: 0 off, 1 every kernel, 2 only the bwd-weight GEMM (both
+    // operands k-strided: 2x the LDS read instructions; measured +5 % there, -2 % on fwd)
+    constexpr bool PF = (CDML_GEMM_FRAG_PREFETCH == 1) || (CDML_GEMM_FRAG_PREFETCH == 2 && KPRED);
+    if constexpr (PF) {
+    // fragments are double-buffered in registers: group g+1 is read from LDS while
+    // the 4*TM*TN MFMAs of group g issue.  The sched_barrier keeps the reads ahead
+    // (hipcc otherwise sinks each read to just before its use and stalls on lgkmcnt(0)).
+    static_assert(BK / 8 == 4, "unrolled for 4 k-groups");
+    Frag f0 = load_frags(sA, sB, 0);
+    Frag f1 = load_frags(sA, sB, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    CDML_MFMA_GROUP(f0);
+    f0 = load_frags(sA, sB, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    CDML_MFMA_GROUP(f1);
+    f1 = load_frags(sA, sB, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    CDML_MFMA_GROUP(f0);
+    CDML_MFMA_GROUP(f1);
+    } else {
 #pragma unroll
     for (int grp = 0; grp < BK / 8; ++grp) {
-      float a[TM][4], b[TN][4];
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) {
-        const int row = wm * 32 * TM + mi * 32 + l31;
-        if (AKC) {
-          const float4 v = *reinterpret_cast<const float4 *>(sA + row * (BK + KPAD) + 8 * grp + 4 * h);
-          a[mi][0] = v.x; a[mi][1] = v.y; a[mi][2] = v.z; a[mi][3] = v.w;
-        } else {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) a[mi][u] = sA[(8 * grp + 4 * h + u) * BM + row];
-        }
-      }
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni) {
-        const int col = wn * 32 * TN + ni * 32 + l31;
-        if (BKC) {
-          const float4 v = *reinterpret_cast<const float4 *>(sB + col * (BK + KPAD) + 8 * grp + 4 * h);
-          b[ni][0] = v.x; b[ni][1] = v.y; b[ni][2] = v.z; b[ni][3] = v.w;
-        } else {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) b[ni][u] = sB[(8 * grp + 4 * h + u) * BN + col];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][u], b[ni][u], acc[mi][ni], 0, 0, 0);
+      const Frag f = load_frags(sA, sB, grp);
+      CDML_MFMA_GROUP(f);
     }
+    }
+#undef CDML_MFMA_GROUP
 
-    if (kt + 1 < n_ktiles) store_tile(buf ^ 1);
+    if (kt + 1 < n_ktiles) store_tile(buf ^ 1, kt + 1);
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float *C = g.C + (EPI == EPI_SLAB_COLSUM ? (int64_t)split * g.slab_stride : 0);
+#if !CDML_GEMM_LDS_EPILOGUE
+  {  // direct epilogue: one dword per lane per store, two 128-B row segments per instruction
+    float *Cd = g.C + (EPI == EPI_SLAB_COLSUM ? (int64_t)split * g.slab_stride : 0);
 #pragma unroll
-  for (int mi = 0; mi < TM; ++mi) {
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      const int col = n0 + wn * 32 * TN + ni * 32 + l31;
-      float bias = 0.f;
-      if (EPI == EPI_BIAS_LRELU) bias = g.bias[col];
+      for (int ni = 0; ni < TN; ++ni) {
+        const int colx = n0 + wn * 32 * TN + ni * 32 + l31;
+        float bias = 0.f;
+        if (EPI == EPI_BIAS_LRELU) bias = g.bias[colx];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < g.M) {
+            float v = acc[mi][ni][r];
+            if (EPI == EPI_BIAS_LRELU) {
+              v += bias;
+              v = fmaxf(v, v * g.alpha);
+            } else if (EPI == EPI_LRELU_MASK) {
+              if (g.aux) v *= (g.aux[(int64_t)row * g.ldaux + colx] > 0.f) ? 1.f : g.alpha;
+            }
+            Cd[(int64_t)row * g.ldc + colx] = v;
+          }
+        }
+      }
+  }
+#else
+  // ---- epilogue.  Accumulators -> LDS C tile (C/D layout: col = lane&31,
+  // row = (r&3) + 8*(r>>2) + 4*(lane>>5)), then whole 16-B row segments per lane
+  // so global stores (and the aux/bias loads) are coalesced.
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < g.M) {
-          float v = acc[mi][ni][r];
-          if (EPI == EPI_BIAS_LRELU) {
-            v += bias;
-            v = fmaxf(v, v * g.alpha);
-          } else if (EPI == EPI_LRELU_MASK) {
-            if (g.aux) v *= (g.aux[(int64_t)row * g.ldaux + col] > 0.f) ? 1.f : g.alpha;
-          }
-          C[(int64_t)row * g.ldc + col] = v;
-        }
+        const int row = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        smem[row * BN + wn * 32 * TN + ni * 32 + l31] = acc[mi][ni][r];
+      }
+  __syncthreads();
+
+  float *C = g.C + (EPI == EPI_SLAB_COLSUM ? (int64_t)split * g.slab_stride : 0);
+  constexpr int C4 = BN / 4, ROWS_PER_PASS = kThreads / C4, PASSES = BM / ROWS_PER_PASS;
+  const int c4 = t % C4;
+  const int col = n0 + c4 * 4;
+  const int lr0 = t / C4;
+  const bool has_aux = (EPI == EPI_LRELU_MASK) && g.aux != nullptr;  // uniform
+  f32x4 bias4 = zero4;
+  if (EPI == EPI_BIAS_LRELU) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
+
+  auto finish = [&](f32x4 v, f32x4 m) {
+    if (EPI == EPI_BIAS_LRELU) {
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      v.x = fmaxf(v.x, v.x * g.alpha); v.y = fmaxf(v.y, v.y * g.alpha);
+      v.z = fmaxf(v.z, v.z * g.alpha); v.w = fmaxf(v.w, v.w * g.alpha);
+    } else if (EPI == EPI_LRELU_MASK) {
+      if (has_aux) {
+        v.x *= (m.x > 0.f) ? 1.f : g.alpha; v.y *= (m.y > 0.f) ? 1.f : g.alpha;
+        v.z *= (m.z > 0.f) ? 1.f : g.alpha; v.w *= (m.w > 0.f) ? 1.f : g.alpha;
+      }
+    }
+    return v;
+  };
+
+  if (m0 + BM <= g.M) {
+    // full tile (wave-uniform test): no per-lane branches, so every aux load and
+    // every store is in flight at once instead of one round trip per pass
+    f32x4 m[PASSES];
+    if (EPI == EPI_LRELU_MASK && has_aux) {
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p)
+        m[p] = *reinterpret_cast<const f32x4 *>(g.aux + (int64_t)(m0 + p * ROWS_PER_PASS + lr0) * g.ldaux + col);
+    }
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int lr = p * ROWS_PER_PASS + lr0;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(smem + lr * BN + c4 * 4);
+      *reinterpret_cast<f32x4 *>(C + (int64_t)(m0 + lr) * g.ldc + col) =
+          finish(v, (EPI == EPI_LRELU_MASK && has_aux) ? m[p] : zero4);
+    }
+  } else {
+    for (int p = 0; p < PASSES; ++p) {
+      const int lr = p * ROWS_PER_PASS + lr0;
+      const int row = m0 + lr;
+      if (row < g.M) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(smem + lr * BN + c4 * 4);
+        f32x4 mm = zero4;
+        if (EPI == EPI_LRELU_MASK && has_aux)
+          mm = *reinterpret_cast<const f32x4 *>(g.aux + (int64_t)row * g.ldaux + col);
+        *reinterpret_cast<f32x4 *>(C + (int64_t)row * g.ldc + col) = finish(v, mm);
       }
     }
   }
+
+#endif  // CDML_GEMM_LDS_EPILOGUE
 
   if (EPI == EPI_SLAB_COLSUM && do_colsum) {
     // threads with equal (t % C4) hold partial sums of the same 4 columns
-    constexpr int C4 = BN / 4, KR = kThreads / C4;
+    constexpr int C4 = BN / 4;
+    constexpr int KR = kThreads / C4;
     __syncthreads();
-    float4 *red = reinterpret_cast<float4 *>(smem);
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem);
     red[t] = bsum;
     __syncthreads();
     if (t < C4) {
-      float4 s = red[t];
+      f32x4 s = red[t];
       for (int j = 1; j < KR; ++j) {
-        const float4 v = red[t + j * C4];
+        const f32x4 v = red[t + j * C4];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
-      *reinterpret_cast<float4 *>(g.colsum + (int64_t)split * g.N + n0 + t * 4) = s;
+      *reinterpret_cast<f32x4 *>(g.colsum + (int64_t)split * g.N + n0 + t * 4) = s;
     }
   }
 }
@@ -412,9 +577,11 @@ extern "C" int cdml_fc_bwd_weight(const float *x, int64_t ldx, const float *dy, 
   const int splits = bwd_weight_splits(M, K, N);
   float *slabs = static_cast<float *>(workspace);
   float *colsum = slabs + (size_t)splits * K * N;
+  const bool direct = (splits == 1);  // no combine pass: the GEMM writes dW / db itself
   GemmArgs g{};  // dW[K][N] = x[M][K]^T @ dy[M][N] : output rows = K, contraction = M
-  g.A = x; g.lda = ldx; g.B = dy; g.ldb = lddy; g.C = slabs; g.ldc = N;
-  g.colsum = db ? colsum : nullptr; g.M = K; g.N = N; g.K = M;
+  g.A = x; g.lda = ldx; g.B = dy; g.ldb = lddy;
+  g.C = direct ? dW : slabs; g.ldc = direct ? lddw : N;
+  g.colsum = db ? (direct ? db : colsum) : nullptr; g.M = K; g.N = N; g.K = M;
   int kps = (M + splits - 1) / splits;
   kps = (kps + BK - 1) / BK * BK;
   g.k_per_split = kps;
@@ -422,6 +589,7 @@ extern "C" int cdml_fc_bwd_weight(const float *x, int64_t ldx, const float *dy, 
   int tm, tn;
   pick_tile_bwd_weight(K, N, tm, tn);
   if ((rc = launch_gemm<false, false, EPI_SLAB_COLSUM>(g, tm, tn, splits, (hipStream_t)stream))) return rc;
+  if (direct) return rc;
   const int64_t total4 = (int64_t)K * N / 4;
   int grid = (int)((total4 + kThreads - 1) / kThreads);
   if (grid > kNumCU * 8) grid = kNumCU * 8;

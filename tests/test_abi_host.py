@@ -90,3 +90,21 @@ def test_read_cowatch_files(tmp_path):
     got = inputs.read_cowatch_files(sorted(str(p) for p in tmp_path.glob("*.train")))
     np.testing.assert_array_equal(got, [[1, 2], [3, 4], [5, 6]])
     assert got.dtype == np.int32
+
+
+def test_no_kernel_uses_scratch():
+    """A kernel whose register arrays fall into scratch memory runs 1.5x slower and
+    looks fine otherwise (it happened: HIP's float4 struct copied through a
+    conditional pointer became a memcpy to a stack slot).  hipcc reports it."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "collaborative-deep-metric-learning_amd", "csrc")
+    for src in sorted(glob.glob(os.path.join(csrc, "*.hip"))):
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c",
+                              "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+                              "-o", "/dev/null", src], capture_output=True, text=True, cwd=csrc)
+        assert out.returncode == 0, out.stderr[-2000:]
+        scratch = re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)
+        spills = re.findall(r"VGPRs Spill: (\d+)", out.stderr)
+        assert scratch and all(int(x) == 0 for x in scratch), (src, scratch)
+        assert all(int(x) == 0 for x in spills), (src, spills)
