@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=None, help="catalogue rows (default: 1M, or 10M when --gpus > 1)")
-    ap.add_argument("--mode", default="inbatch", choices=["inbatch", "uniform"])
+    ap.add_argument("--mode", default="inbatch", choices=["inbatch", "uniform", "semihard"])
     ap.add_argument("--batch", type=int, default=BATCH, help="triplets per GPU per step")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -245,7 +245,8 @@ def main():
             "config": {"workload": "config1: %d videos x %d-d fp32 in HBM, %d hidden, %d-d embed, "
                                    "batch %d triplets/GPU, %s negatives, margin %.1f, Adam, full step "
                                    "(sample+gather+fwd+loss+bwd+opt)"
-                                   % (n_rows, F, H, D, B, "in-batch" if args.mode == "inbatch" else "uniform random", MARGIN),
+                                   % (n_rows, F, H, D, B, {"inbatch": "in-batch", "uniform": "uniform random",
+                                                              "semihard": "semi-hard mined"}[args.mode], MARGIN),
                        "global_batch": world * B, "rows_per_triplet": rpt,
                        "parallelism": "dp%d" % world + ("" if world == 1 else " row-sharded table, all-to-all rows + all-reduce grads"),
                        "hipgraph": bool(args.graph)},

@@ -179,6 +179,139 @@ k_triplet_hinge_inbatch(const float *__restrict__ e, int64_t lde, const int32_t 
   }
 }
 
+// ---------------------------------------------------- semi-hard mining (config 2) --
+// Build-defined (the reference only draws uniform negatives); spec in
+// oracle/tower.py semihard_select.  sqn[r] = |e_r|^2.
+__global__ void __launch_bounds__(kThreads)
+k_row_sumsq(const float *__restrict__ e, int64_t lde, int R, int D, float *__restrict__ sqn) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nq = D >> 2;
+  for (int r = blockIdx.x * kWavesPerBlock + wave; r < R; r += gridDim.x * kWavesPerBlock) {
+    float ss = 0.f;
+    for (int q = lane; q < nq; q += kWave) ss += sq4(ld4(e + (int64_t)r * lde, q));
+    ss = wave_sum(ss);
+    if (lane == 0) sqn[r] = ss;
+  }
+}
+
+struct Cand { float d; int c; };
+__device__ __forceinline__ bool closer(float d, int c, const Cand &b) {   // min, ties -> smaller index
+  return d < b.d || (d == b.d && c < b.c);
+}
+__device__ __forceinline__ bool farther(float d, int c, const Cand &b) {  // max, ties -> smaller index
+  return d > b.d || (d == b.d && c < b.c);
+}
+
+// One wave per anchor scans its row of S = E_a . E^T (dot products with every
+// embedded row): dist = sqn[a] + sqn[c] - 2 S; eligible = other videos.
+__global__ void __launch_bounds__(kThreads)
+k_semihard_select(const float *__restrict__ S, int64_t ldS, const float *__restrict__ sqn,
+                  const int32_t *__restrict__ rows, int B, int32_t *__restrict__ neg_row) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int R = 2 * B;
+  const float inf = __builtin_huge_valf();
+  for (int i = blockIdx.x * kWavesPerBlock + wave; i < B; i += gridDim.x * kWavesPerBlock) {
+    const float *Si = S + (int64_t)i * ldS;
+    const float sa = sqn[2 * i];
+    const int32_t va = rows[2 * i], vp = rows[2 * i + 1];
+    const float dp = sa + sqn[2 * i + 1] - 2.0f * Si[2 * i + 1];
+    Cand out{inf, 0x7fffffff}, in{-inf, 0x7fffffff};
+    for (int q = lane; q < (R >> 2); q += kWave) {
+      const float4 s4 = ld4(Si, q);
+      const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = 4 * q + u;
+        const int32_t vc = rows[c];
+        if (vc != va && vc != vp) {
+          const float d = sa + sqn[c] - 2.0f * sv[u];
+          if (d > dp) { if (closer(d, c, out)) out = Cand{d, c}; }
+          if (farther(d, c, in)) in = Cand{d, c};
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float od = __shfl_xor(out.d, off, 64); const int oc = __shfl_xor(out.c, off, 64);
+      if (closer(od, oc, out)) out = Cand{od, oc};
+      const float id = __shfl_xor(in.d, off, 64); const int ic = __shfl_xor(in.c, off, 64);
+      if (farther(id, ic, in)) in = Cand{id, ic};
+    }
+    if (lane == 0) neg_row[i] = (out.c != 0x7fffffff) ? out.c : (in.c != 0x7fffffff ? in.c : -1);
+  }
+}
+
+// Indexed triplets: anchor row 2i, positive 2i+1, negative neg_row[i] (any row of
+// e, or -1 = masked).  Forward: one wave per triplet; scale[i] = 2/B if active.
+__global__ void __launch_bounds__(kThreads)
+k_hinge_indexed_fwd(const float *__restrict__ e, int64_t lde, const int32_t *__restrict__ neg_row,
+                    int B, int D, float margin, float *__restrict__ pos_o, float *__restrict__ neg_o,
+                    float *__restrict__ hinge_o, float *__restrict__ scale) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nq = D >> 2;
+  const float two_over_b = 2.0f / (float)B;
+  for (int i = blockIdx.x * kWavesPerBlock + wave; i < B; i += gridDim.x * kWavesPerBlock) {
+    const int nr = neg_row[i];
+    const bool valid = nr >= 0;
+    const float *a = e + (int64_t)(2 * i) * lde, *p = a + lde;
+    const float *n = e + (int64_t)(valid ? nr : 2 * i) * lde;
+    float pos, neg;
+    dist_pair(a, p, n, nq, lane, pos, neg);
+    const float t = pos - neg + margin;
+    if (lane == 0) {
+      pos_o[i] = pos;
+      neg_o[i] = neg;
+      hinge_o[i] = valid ? fmaxf(t, 0.f) : 0.f;
+      scale[i] = (valid && t >= 0.f) ? two_over_b : 0.f;
+    }
+  }
+}
+
+// Backward: one wave per embedded row r sums, in ascending triplet order, its own
+// triplet's term and the terms of every triplet that mined r as its negative
+// (no atomics: bit-reproducible).
+__global__ void __launch_bounds__(kThreads)
+k_hinge_indexed_bwd(const float *__restrict__ e, int64_t lde, const int32_t *__restrict__ neg_row,
+                    const float *__restrict__ scale, int B, int D, float *__restrict__ de,
+                    int64_t ldde) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nq = D >> 2;
+  const int R = 2 * B;
+  for (int r = blockIdx.x * kWavesPerBlock + wave; r < R; r += gridDim.x * kWavesPerBlock) {
+    const int i = r >> 1;
+    const float si = scale[i];
+    const float *er = e + (int64_t)r * lde;
+    float *dr = de + (int64_t)r * ldde;
+    const float *a = e + (int64_t)(2 * i) * lde, *p = a + lde;
+    const int nr = neg_row[i];
+    const float *n = e + (int64_t)(nr >= 0 ? nr : 2 * i) * lde;
+    for (int q = lane; q < nq; q += kWave) {   // own triplet: anchor or positive role
+      const float4 va = ld4(a, q), vp = ld4(p, q), vn = ld4(n, q);
+      st4(dr, q, (r & 1) ? mul4(sub4(vp, va), si) : mul4(sub4(vn, vp), si));
+    }
+    for (int j0 = 0; j0 < B; j0 += kWave) {    // triplets that mined row r as negative
+      const int j = j0 + lane;
+      const bool hit = (j < B) && (neg_row[j] == r) && (scale[j] != 0.f);
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        const int jj = j0 + __builtin_ctzll(m);
+        m &= m - 1;
+        const float sj = scale[jj];
+        const float *aj = e + (int64_t)(2 * jj) * lde;
+        for (int q = lane; q < nq; q += kWave) {
+          const float4 g = mul4(sub4(ld4(aj, q), ld4(er, q)), sj);
+          const float4 cur = ld4(dr, q);
+          st4(dr, q, make_float4(cur.x + g.x, cur.y + g.y, cur.z + g.z, cur.w + g.w));
+        }
+      }
+    }
+  }
+}
+
 // stats[0..3] = mean hinge, mean pos, mean neg, fraction of triplets with hinge > 0.
 __global__ void __launch_bounds__(1024)
 k_loss_stats(const float *__restrict__ pos, const float *__restrict__ neg,
@@ -283,6 +416,44 @@ extern "C" int cdml_triplet_hinge_inbatch(const float *e, int64_t lde, const int
     hipLaunchKernelGGL(k_loss_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, pos, neg, hinge, B,
                        stats);
     rc = check_launch("triplet_hinge_inbatch stats");
+  }
+  return rc;
+}
+
+extern "C" int cdml_semihard_select(const float *S, int64_t ldS, const float *e, int64_t lde,
+                                    const int32_t *rows, int B, int D, float *sqn_scratch,
+                                    int32_t *neg_row_out, cdml_stream_t stream) {
+  CDML_REQUIRE(B >= 1 && D > 0 && rows && sqn_scratch && neg_row_out, CDML_E_BADARG,
+               "semihard_select: bad argument");
+  int rc;
+  if ((rc = check_rows("semihard_select e", e, lde, D))) return rc;
+  if ((rc = check_rows("semihard_select S", S, ldS, 2 * B))) return rc;
+  hipLaunchKernelGGL(k_row_sumsq, dim3(grid_rows(2 * B)), dim3(kThreads), 0, (hipStream_t)stream, e,
+                     lde, 2 * B, D, sqn_scratch);
+  hipLaunchKernelGGL(k_semihard_select, dim3(grid_rows(B)), dim3(kThreads), 0, (hipStream_t)stream, S,
+                     ldS, sqn_scratch, rows, B, neg_row_out);
+  return check_launch("semihard_select");
+}
+
+extern "C" int cdml_triplet_hinge_indexed(const float *e, int64_t lde, const int32_t *neg_row, int B,
+                                          int D, float margin, float *pos, float *neg, float *hinge,
+                                          float *stats, float *scale_scratch, float *de, int64_t ldde,
+                                          cdml_stream_t stream) {
+  CDML_REQUIRE(B >= 1 && D > 0 && neg_row && pos && neg && hinge && scale_scratch, CDML_E_BADARG,
+               "triplet_hinge_indexed: bad argument");
+  int rc;
+  if ((rc = check_rows("triplet_hinge_indexed", e, lde, D))) return rc;
+  if (de && (rc = check_rows("triplet_hinge_indexed", de, ldde, D))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_hinge_indexed_fwd, dim3(grid_rows(B)), dim3(kThreads), 0, s, e, lde, neg_row, B,
+                     D, margin, pos, neg, hinge, scale_scratch);
+  if (de)
+    hipLaunchKernelGGL(k_hinge_indexed_bwd, dim3(grid_rows(2 * B)), dim3(kThreads), 0, s, e, lde,
+                       neg_row, scale_scratch, B, D, de, ldde);
+  if ((rc = check_launch("triplet_hinge_indexed"))) return rc;
+  if (stats) {
+    hipLaunchKernelGGL(k_loss_stats, dim3(1), dim3(1024), 0, s, pos, neg, hinge, B, stats);
+    rc = check_launch("triplet_hinge_indexed stats");
   }
   return rc;
 }

@@ -18,6 +18,20 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWavesPerBlock = kThreads / kWave;
 
+#ifndef CDML_GATHER_NT
+#define CDML_GATHER_NT 0   // 1: non-temporal table loads (rows are read once per step)
+#endif
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float4 load_row_chunk(const float4 *p) {
+#if CDML_GATHER_NT
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+
 // ---------------------------------------------------------------- table fill --
 __global__ void __launch_bounds__(kThreads)
 k_fill_table(float *__restrict__ table, int64_t row0, int64_t n_rows, int F,
@@ -92,7 +106,7 @@ __device__ __forceinline__ void gather_one_row(const float *__restrict__ table, 
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int q = lane + kWave * c;
-    v[c] = (q < nq) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[c] = (q < nq) ? load_row_chunk(src + q) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (F & 3) {  // mask the tail so the table's pad content never leaks in
 #pragma unroll

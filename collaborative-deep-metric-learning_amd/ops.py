@@ -154,6 +154,21 @@ def triplet_hinge_inbatch(e, rows, shift, B, D, margin, pos, neg, hinge, valid=N
          margin, _p(pos), _p(neg), _p(hinge), _p(valid, torch.uint8), _p(stats), dep, deld, _stream())
 
 
+def semihard_select(S, e, rows, B, D, sqn_scratch, neg_row_out):
+    sp, sld = _mat(S)
+    ep, eld = _mat(e)
+    call("cdml_semihard_select", sp, sld, ep, eld, _p(rows, torch.int32), B, D, _p(sqn_scratch),
+         _p(neg_row_out, torch.int32), _stream())
+    return neg_row_out
+
+
+def triplet_hinge_indexed(e, neg_row, B, D, margin, pos, neg, hinge, scale_scratch, stats=None, de=None):
+    ep, eld = _mat(e)
+    dep, deld = (C.c_void_p(0), 0) if de is None else _mat(de)
+    call("cdml_triplet_hinge_indexed", ep, eld, _p(neg_row, torch.int32), B, D, margin, _p(pos), _p(neg),
+         _p(hinge), _p(stats), _p(scale_scratch), dep, deld, _stream())
+
+
 # ------------------------------------------------------------- optimizers -----
 def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, t_dev=None):
     call("cdml_adam_step", _p(w), _p(g), _p(m), _p(v), w.numel(), lr, _p(lr_dev), beta1, beta2, eps,

@@ -22,7 +22,9 @@ import torch
 from . import engine, ops
 from .inputs import MODE_INBATCH, MODE_UNIFORM
 
-_MODES = {"uniform": MODE_UNIFORM, "inbatch": MODE_INBATCH}
+# sampler mode per negative policy: "semihard" samples like "inbatch" (rows a_i, p_i)
+# and mines the negative among the embedded rows of the batch (BASELINE config 2)
+_MODES = {"uniform": MODE_UNIFORM, "inbatch": MODE_INBATCH, "semihard": MODE_INBATCH}
 
 
 def exponential_decay(base_lr, global_step, decay_steps, decay_rate, staircase=True):
@@ -43,7 +45,7 @@ class TrainStep:
         ``exchange`` is given); pairs: int32 [P,2] device tensor; ``exchange`` /
         ``grad_sync``: the multi-GPU hooks of cdml_amd.dist (None on one GPU)."""
         if mode not in _MODES:
-            raise ValueError("mode must be 'uniform' or 'inbatch'")
+            raise ValueError("mode must be 'uniform', 'inbatch' or 'semihard'")
         if optimizer not in ("adam", "lars"):
             raise ValueError("optimizer must be 'adam' or 'lars'")
         self.device = torch.device(device)
@@ -73,6 +75,13 @@ class TrainStep:
         self.hinge = torch.zeros(self.B, dtype=f32, device=dev)
         self.valid = torch.ones(self.B, dtype=torch.uint8, device=dev)
         self.stats = torch.zeros(4, dtype=f32, device=dev)          # loss, mean pos, mean neg, active
+        if mode == "semihard":
+            if self.B % 32:
+                raise ValueError("semi-hard mining needs a batch that is a multiple of 32")
+            self.S = torch.zeros((self.B, 2 * self.B), dtype=f32, device=dev)   # anchor x row dot products
+            self.sqn = torch.zeros(2 * self.B, dtype=f32, device=dev)
+            self.neg_row = torch.zeros(self.B, dtype=i32, device=dev)
+            self.scale = torch.zeros(self.B, dtype=f32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.lr_dev = torch.full((1,), self.base_lr, dtype=f32, device=dev)
         self._lr_host = self.base_lr
@@ -114,6 +123,13 @@ class TrainStep:
         if self.mode == "uniform":
             ops.triplet_hinge(self.ws.e, self.B, L.Dp, self.margin, self.pos, self.neg, self.hinge,
                               self.stats, de)
+        elif self.mode == "semihard":
+            e = self.ws.e
+            # S[i][c] = <anchor_i, row_c>: the data-gradient GEMM (x @ W^T) with no mask
+            ops.fc_bwd_data(e[0::2], e, None, self.S, self.B, 2 * self.B, L.Dp)
+            ops.semihard_select(self.S, e, self.idx, self.B, L.Dp, self.sqn, self.neg_row)
+            ops.triplet_hinge_indexed(e, self.neg_row, self.B, L.Dp, self.margin, self.pos, self.neg,
+                                      self.hinge, self.scale, self.stats, de)
         else:
             ops.triplet_hinge_inbatch(self.ws.e, self.idx, self.shift, self.B, L.Dp, self.margin,
                                       self.pos, self.neg, self.hinge, self.valid, self.stats, de)

@@ -172,6 +172,28 @@ int cdml_triplet_hinge_inbatch(const float *e, int64_t lde, const int32_t *rows,
                                uint8_t *valid_out, float *stats, float *de,
                                int64_t ldde, cdml_stream_t stream);
 
+/* ---- semi-hard negative mining (BASELINE config 2; build-defined, no reference
+ * counterpart -- spec: oracle/tower.py semihard_select) -----------------------
+ * e[2B][lde]: row 2i = anchor i, 2i+1 = positive i; rows int32[2B] video ids.
+ * S[B][ldS] = dot products of every anchor with every embedded row (one
+ * cdml_fc_bwd_data call: dy = anchors (ld 2*lde), W = e, no mask).
+ * neg_row_out[i] = the closest other-video row farther than the positive, else
+ * the farthest other-video row, else -1.  sqn_scratch: float[2B]. */
+int cdml_semihard_select(const float *S, int64_t ldS, const float *e,
+                         int64_t lde, const int32_t *rows, int B, int D,
+                         float *sqn_scratch, int32_t *neg_row_out,
+                         cdml_stream_t stream);
+
+/* Hinge loss + gradient over triplets (row 2i, row 2i+1, row neg_row[i]);
+ * neg_row[i] = -1 masks a triplet (hinge 0, still counted in the mean).  Rows
+ * mined by several anchors accumulate their gradients in ascending triplet
+ * order (deterministic).  scale_scratch: float[B]. */
+int cdml_triplet_hinge_indexed(const float *e, int64_t lde,
+                               const int32_t *neg_row, int B, int D, float margin,
+                               float *pos, float *neg, float *hinge, float *stats,
+                               float *scale_scratch, float *de, int64_t ldde,
+                               cdml_stream_t stream);
+
 /* ---- optimizers (train.py:108-125,146) --------------------------------------
  * Adam, TensorFlow form (epsilon outside the bias correction):
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m=b1*m+(1-b1)*g; v=b2*v+(1-b2)*g*g;

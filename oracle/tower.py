@@ -253,3 +253,45 @@ def xavier_uniform(rng, fan_in, fan_out, dtype=np.float32):
     """slim's default weights_initializer (xavier, uniform): U(+-sqrt(6/(in+out)))."""
     lim = np.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-lim, lim, size=(fan_in, fan_out)).astype(dtype)
+
+
+# ----------------------------------------------------------------------------
+# semi-hard negative mining (BASELINE config 2) -- build-defined, PARITY UNPINNED:
+# the reference only draws uniform random negatives.  Rule (the one of
+# tf.contrib.losses.metric_learning.triplet_semihard_loss, on squared distances):
+# for anchor i with positive distance d_p, over every OTHER embedded row c of the
+# batch whose video is neither the anchor's nor the positive's,
+#   pick the closest c with d(a,c) > d_p ("semi-hard / outside"),
+#   else (no such c) the farthest eligible c;  ties -> smallest row index;
+#   no eligible c at all -> -1 (triplet masked).
+# ----------------------------------------------------------------------------
+def semihard_select(E, rows, dtype=np.float64):
+    """E [2B,D] embeddings (row 2i anchor, 2i+1 positive), rows int[2B] video ids.
+    Returns (neg_row int32[B], dist float[B,2B]) with dist = squared distances of
+    each anchor to every row (the selection's input, for tolerance-aware checks)."""
+    E = np.asarray(E, dtype)
+    rows = np.asarray(rows)
+    B = len(rows) // 2
+    A = E[0::2]
+    sq = np.sum(E * E, axis=1)
+    dist = sq[0::2, None] + sq[None, :] - 2.0 * (A @ E.T)
+    d_p = dist[np.arange(B), 2 * np.arange(B) + 1]
+    eligible = (rows[None, :] != rows[0::2, None]) & (rows[None, :] != rows[1::2, None])
+    outside = eligible & (dist > d_p[:, None])
+    neg = np.full(B, -1, dtype=np.int32)
+    for i in range(B):
+        if outside[i].any():
+            d = np.where(outside[i], dist[i], np.inf)
+            neg[i] = int(np.argmin(d))
+        elif eligible[i].any():
+            d = np.where(eligible[i], dist[i], -np.inf)
+            neg[i] = int(np.argmax(d))
+    return neg, dist
+
+
+def semihard_triplets(neg_row):
+    """tri int32[B,3] row indices + valid mask for hinge_loss_indexed."""
+    B = len(neg_row)
+    valid = neg_row >= 0
+    tri = np.stack([2 * np.arange(B), 2 * np.arange(B) + 1, np.where(valid, neg_row, 0)], axis=1)
+    return tri.astype(np.int32), valid

@@ -547,3 +547,95 @@ def test_full_size_properties_config1(cd):
     g0 = ts.params.grad.clone()
     ts.fetch(); ts.forward_loss(); ts.backward()
     assert torch.equal(g0, ts.params.grad)
+
+
+# ------------------------------------------------ semi-hard mining (config 2) ----
+def test_semihard_select_and_indexed_loss(cd):
+    """Build-defined (no reference counterpart): spec = oracle.tower.semihard_select.
+    Selection is checked tolerance-aware: the device may break a < 2e-6 near-tie
+    differently, so its choice must be as good as the oracle's within that band."""
+    rng = np.random.RandomState(3)
+    B, D = 96, 64
+    for trial, n_videos in enumerate((500, 12)):           # 12 videos: many ineligible rows, some -1
+        E = otower.l2_normalize(rng.randn(2 * B, D) + (0.0 if trial else 2.0), np.float64)[0].astype(np.float32)
+        rows = rng.randint(0, n_videos, size=2 * B).astype(np.int32)
+        if trial:
+            rows[:8] = 0; rows[8:] = rng.randint(0, 2, size=2 * B - 8)   # anchors with nothing eligible
+        de_, dr = dt(E, cd.dev), dt(rows, cd.dev, torch.int32)
+        S = torch.empty((B, 2 * B), device=cd.dev)
+        cd.ops.fc_bwd_data(de_[0::2], de_, None, S, B, 2 * B, D)
+        np.testing.assert_allclose(S.cpu().numpy(), E[0::2].astype(np.float64) @ E.T.astype(np.float64), atol=1e-5)
+        neg_row = torch.empty(B, dtype=torch.int32, device=cd.dev)
+        cd.ops.semihard_select(S, de_, dr, B, D, torch.empty(2 * B, device=cd.dev), neg_row)
+        got = neg_row.cpu().numpy()
+        want, dist = otower.semihard_select(E.astype(np.float64), rows)
+        d_p = dist[np.arange(B), 2 * np.arange(B) + 1]
+        tol = 2e-6
+        for i in range(B):
+            if want[i] < 0:
+                assert got[i] == -1
+                continue
+            assert got[i] >= 0 and rows[got[i]] not in (rows[2 * i], rows[2 * i + 1])
+            elig = (rows != rows[2 * i]) & (rows != rows[2 * i + 1])
+            strict = elig & (dist[i] > d_p[i] + tol)  # clearly outside, whatever the rounding
+            if dist[i, got[i]] > d_p[i] - tol and (strict.any() or dist[i, want[i]] > d_p[i]):
+                # semi-hard branch: at least as close as the closest clearly-outside candidate
+                if strict.any():
+                    assert dist[i, got[i]] <= dist[i][strict].min() + tol
+            else:                                     # none outside: farthest eligible
+                assert dist[i, got[i]] >= dist[i][elig].max() - tol
+        assert (got == want).mean() > 0.95
+        if trial:
+            assert (want < 0).any()
+        # loss + gradient on the DEVICE's selection vs the oracle's indexed loss
+        tri, valid = otower.semihard_triplets(got)
+        pos, neg, hinge, scale = (torch.empty(B, device=cd.dev) for _ in range(4))
+        stats = torch.empty(4, device=cd.dev)
+        dE = torch.empty((2 * B, D), device=cd.dev)
+        cd.ops.triplet_hinge_indexed(de_, neg_row, B, D, 0.8, pos, neg, hinge, scale, stats, dE)
+        w = otower.hinge_loss_indexed(E.astype(np.float64), tri, valid, 0.8, np.float64)
+        np.testing.assert_allclose(hinge.cpu().numpy(), w["hinge_dist"], atol=TOL)
+        np.testing.assert_allclose(stats[0].item(), w["hinge_loss"], atol=TOL)
+        wd = otower.hinge_loss_indexed_backward(E.astype(np.float64), tri, valid, 0.8, np.float64)
+        np.testing.assert_allclose(dE.cpu().numpy(), wd, atol=TOL)
+        dE2 = torch.empty_like(dE)
+        cd.ops.triplet_hinge_indexed(de_, neg_row, B, D, 0.8, pos, neg, hinge, scale, stats, dE2)
+        assert torch.equal(dE, dE2)                   # deterministic accumulation
+
+
+def test_train_step_semihard_config2_shape(cd):
+    """BASELINE config 2 shape (batch 8192, all-pairs mining) on a 200k-row table:
+    the mined negatives satisfy the semi-hard rule under the fp64 oracle distances
+    of the device's own embeddings, and loss / gradients match the oracle."""
+    N, F, B = 200000, 1500, 8192
+    table = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev)
+    pairs_np = osynth.cowatch_pairs(N, 40000, 0)
+    ts = cd.train.TrainStep(table, dt(pairs_np, cd.dev, torch.int32), B, mode="semihard", device=cd.dev)
+    ts.fetch(); ts.forward_loss(); ts.backward()
+    torch.cuda.synchronize()
+    E = ts.ws.e.cpu().numpy().astype(np.float64)
+    rows = ts.idx.cpu().numpy()
+    got = ts.neg_row.cpu().numpy()
+    sel = np.random.RandomState(0).choice(B, 64, replace=False)
+    sq = np.sum(E * E, axis=1)
+    for i in sel:
+        dist = sq[2 * i] + sq - 2.0 * (E @ E[2 * i])
+        elig = (rows != rows[2 * i]) & (rows != rows[2 * i + 1])
+        d_p = dist[2 * i + 1]
+        tol = 2e-6                                # a candidate within tol of d_p may fall either side
+        strict = elig & (dist > d_p + tol)
+        assert elig[got[i]]
+        if dist[got[i]] > d_p - tol and (strict.any() or (elig & (dist > d_p)).any()):
+            if strict.any():
+                assert dist[got[i]] <= dist[strict].min() + tol
+        else:
+            assert dist[got[i]] >= dist[elig].max() - tol
+    tri, valid = otower.semihard_triplets(got)
+    w = otower.hinge_loss_indexed(E, tri, valid, 0.8, np.float64)
+    assert abs(ts.loss() - float(w["hinge_loss"])) < TOL
+    wd = otower.hinge_loss_indexed_backward(E, tri, valid, 0.8, np.float64)
+    assert np.abs(ts.ws.de.cpu().numpy() - wd).max() < TOL
+    assert torch.isfinite(ts.params.grad).all()
+    for _ in range(2):
+        ts.step()
+    assert np.isfinite(ts.loss())
