@@ -52,6 +52,7 @@ SIGNATURES = {
                                         _i64, _p]),
     "cdml_semihard_select": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _p, _p]),
     "cdml_triplet_hinge_indexed": (_i, [_p, _i64, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "cdml_pair_dist": (_i, [_p, _i64, _i, _p, _i, _i, _p, _p, _p, _p]),
     "cdml_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _i64, _p, _p]),
     "cdml_lars_scratch_floats": (_sz, []),
     "cdml_lars_step": (_i, [_p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p, _p]),

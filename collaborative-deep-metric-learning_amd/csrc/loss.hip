@@ -312,6 +312,28 @@ k_hinge_indexed_bwd(const float *__restrict__ e, int64_t lde, const int32_t *__r
   }
 }
 
+// Evaluation.mean_dist / mean_cos_dist (evaluate.py:57-90): per co-watch pair the
+// squared L2 distance and the dot product of the two embeddings.
+__global__ void __launch_bounds__(kThreads)
+k_pair_dist(const float *__restrict__ e, int64_t lde, const int32_t *__restrict__ pairs, int P, int D,
+            float *__restrict__ sqdist, float *__restrict__ dot) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nq = D >> 2;
+  for (int i = blockIdx.x * kWavesPerBlock + wave; i < P; i += gridDim.x * kWavesPerBlock) {
+    const float *a = e + (int64_t)pairs[2 * i] * lde, *b = e + (int64_t)pairs[2 * i + 1] * lde;
+    float sd = 0.f, sp = 0.f;
+    for (int q = lane; q < nq; q += kWave) {
+      const float4 va = ld4(a, q), vb = ld4(b, q);
+      sd += sq4(sub4(va, vb));
+      sp += dot4(va, vb);
+    }
+    sd = wave_sum(sd);
+    sp = wave_sum(sp);
+    if (lane == 0) { sqdist[i] = sd; dot[i] = sp; }
+  }
+}
+
 // stats[0..3] = mean hinge, mean pos, mean neg, fraction of triplets with hinge > 0.
 __global__ void __launch_bounds__(1024)
 k_loss_stats(const float *__restrict__ pos, const float *__restrict__ neg,
@@ -454,6 +476,22 @@ extern "C" int cdml_triplet_hinge_indexed(const float *e, int64_t lde, const int
   if (stats) {
     hipLaunchKernelGGL(k_loss_stats, dim3(1), dim3(1024), 0, s, pos, neg, hinge, B, stats);
     rc = check_launch("triplet_hinge_indexed stats");
+  }
+  return rc;
+}
+
+extern "C" int cdml_pair_dist(const float *e, int64_t lde, int n_rows, const int32_t *pairs, int P,
+                              int D, float *sqdist, float *dot, float *means, cdml_stream_t stream) {
+  CDML_REQUIRE(P >= 1 && D > 0 && n_rows > 0 && pairs && sqdist && dot, CDML_E_BADARG,
+               "pair_dist: bad argument");
+  int rc;
+  if ((rc = check_rows("pair_dist", e, lde, D))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_pair_dist, dim3(grid_rows(P)), dim3(kThreads), 0, s, e, lde, pairs, P, D, sqdist, dot);
+  if ((rc = check_launch("pair_dist"))) return rc;
+  if (means) {  // means[1] = mean squared distance, means[2] = mean dot product
+    hipLaunchKernelGGL(k_loss_stats, dim3(1), dim3(1024), 0, s, sqdist, dot, sqdist, P, means);
+    rc = check_launch("pair_dist means");
   }
   return rc;
 }

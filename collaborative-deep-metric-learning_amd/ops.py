@@ -169,6 +169,12 @@ def triplet_hinge_indexed(e, neg_row, B, D, margin, pos, neg, hinge, scale_scrat
          _p(hinge), _p(stats), _p(scale_scratch), dep, deld, _stream())
 
 
+def pair_dist(e, pairs, D, sqdist, dot, means=None):
+    ep, eld = _mat(e)
+    call("cdml_pair_dist", ep, eld, e.shape[0], _p(pairs, torch.int32), pairs.shape[0], D, _p(sqdist),
+         _p(dot), _p(means), _stream())
+
+
 # ------------------------------------------------------------- optimizers -----
 def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, t_dev=None):
     call("cdml_adam_step", _p(w), _p(g), _p(m), _p(v), w.numel(), lr, _p(lr_dev), beta1, beta2, eps,

@@ -15,6 +15,7 @@ rate live in device memory so replays advance the sampler and Adam's bias
 correction.  ``Trainer`` mirrors the reference's loop (train.py:260-336).
 """
 import logging
+import os
 import time
 
 import torch
@@ -187,29 +188,133 @@ class TrainStep:
         """Host value of the last step's mean hinge loss (synchronises)."""
         return float(self.stats[0].item())
 
+    # ------------------------------------------------------------ checkpoint --
+    def state_dict(self):
+        """Weights under their slim variable names (fully_connected{,_1}/{weights,
+        biases}), optimizer slots, step counter and sampler state."""
+        L = self.layout
+        slots = {"m": self.m, "v": self.v} if self.optimizer == "adam" else {"acc": self.acc}
+        return {"layout": (L.F, L.H, L.D), "variables": self.params.state_dict(),
+                "optimizer": self.optimizer, "slots": {k: t.detach().cpu().clone() for k, t in slots.items()},
+                "global_step": self.global_step, "seed": self.seed, "mode": self.mode,
+                "batch_size": self.B, "margin": self.margin}
+
+    def load_state_dict(self, state):
+        if tuple(state["layout"]) != (self.layout.F, self.layout.H, self.layout.D):
+            raise ValueError("checkpoint layout %s does not match the model" % (state["layout"],))
+        if state["optimizer"] != self.optimizer:
+            raise ValueError("checkpoint optimizer is %s" % state["optimizer"])
+        self.params.load(*[state["variables"][n] for n in engine.VNetParams.NAMES])
+        for k, t in state["slots"].items():
+            getattr(self, k).copy_(t.to(self.device))
+        self.global_step = int(state["global_step"])
+        self.step_dev.fill_(self.global_step)
+        self.seed = int(state["seed"])
+        self._graph = None
+
 
 class Trainer:
-    """Step loop with the reference's bookkeeping (train.py:260-336): runs until
-    the pair stream is exhausted, logs loss / fetch / train time every
-    ``show_step`` steps.  Evaluation-driven checkpointing and early stopping
-    (train.py:224-252) are the next-row N2 and not part of this class yet."""
+    """The reference's training loop and model-selection policy
+    (train.py:177-336) over ``TrainStep``:
 
-    def __init__(self, train_step, num_epochs, n_pairs, show_step=100, logger=None):
+      * runs until the pair stream is exhausted (``num_epochs`` passes, final
+        partial batch dropped) -- train.py:300-306;
+      * every ``eval_step`` steps embeds the held-out rows (``Prediction``) and
+        computes ``Evaluation.mean_dist`` -- train.py:224-231;
+      * before ``check_stop_step`` evaluations only reset the patience counter;
+        afterwards an improvement saves a checkpoint (best-only, one kept) --
+        train.py:232-241, 275;
+      * early stop when more than ``require_improve_num`` evaluations passed
+        without improvement past ``check_stop_step`` -- train.py:307-309;
+      * at the end of data the last model is saved if its eval_dist beats the
+        best -- train.py:301-305.
+
+    Unlike the reference (which always re-initialises, train.py:280) a
+    checkpoint also carries optimizer slots, step and sampler state, so
+    ``resume()`` continues a run exactly."""
+
+    def __init__(self, train_step, num_epochs, n_pairs, checkpoint_dir=None, eval_features=None,
+                 eval_cowatches=None, check_stop_epoch=3, best_eval_dist=1.0, eval_per_epoch=100,
+                 require_improve_num=10, logger=None):
+        from .evaluate import Evaluation
+        from .predict import Prediction
         self.ts = train_step
-        self.num_batches = (n_pairs * num_epochs) // train_step.batch_global
-        self.show_step = max(1, int(show_step))
+        B = train_step.batch_global
+        self.num_batches = (n_pairs * num_epochs) // B                  # inputs.py:110-122
+        self.check_stop_step = int(n_pairs / B * check_stop_epoch)      # train.py:285
+        self.step_per_epoch = max(1, int(n_pairs / B))                  # train.py:286
+        self.eval_step = max(1, int(n_pairs / B / eval_per_epoch))      # train.py:287
+        self.show_step = max(1, int(self.eval_step / 10))               # train.py:288
+        self.checkpoint_dir = checkpoint_dir
+        self.best_eval_dist = best_eval_dist
+        self.eval_dist = 0.0
+        self.total_eval_num = 0
+        self.last_improve_num = 0
+        self.require_improve_num = require_improve_num
         self.log = logger or logging.getLogger("cdml.train")
-        self.history = []
+        self.history, self.eval_history, self.saved = [], [], []
+        self.evaluater = None
+        if eval_cowatches is not None:
+            self.evaluater = Evaluation(eval_features, eval_cowatches, device=train_step.device)
+        self.predictor = Prediction(params=train_step.params)
+
+    # ---- checkpoints --------------------------------------------------------
+    def save(self, step):
+        if not self.checkpoint_dir:
+            return None
+        os.makedirs(self.checkpoint_dir, exist_ok=True)
+        path = os.path.join(self.checkpoint_dir, "model.ckpt-%d.pt" % step)
+        state = self.ts.state_dict()
+        state["trainer"] = {"best_eval_dist": self.best_eval_dist, "total_eval_num": self.total_eval_num,
+                            "last_improve_num": self.last_improve_num}
+        torch.save(state, path)
+        for old in self.saved:                                          # max_to_keep=1 (train.py:275)
+            if old != path and os.path.exists(old):
+                os.remove(old)
+        self.saved = [path]
+        return path
+
+    def resume(self, path):
+        state = torch.load(path, map_location="cpu")
+        self.ts.load_state_dict(state)
+        for k, v in state.get("trainer", {}).items():
+            setattr(self, k, v)
+
+    # ---- evaluation (train.py:224-252) ---------------------------------------
+    def _eval(self, global_step):
+        self.total_eval_num += 1
+        emb = self.predictor.run_features(self.evaluater.features, batch_size=10000)
+        self.eval_dist = self.evaluater.mean_dist(emb, self.evaluater.cowatches)
+        if global_step <= self.check_stop_step:
+            self.last_improve_num = self.total_eval_num                 # no early stop yet
+        elif self.eval_dist < self.best_eval_dist:
+            self.best_eval_dist = self.eval_dist
+            self.save(global_step)
+            self.last_improve_num = self.total_eval_num
+        self.eval_history.append((global_step, self.eval_dist, self.best_eval_dist))
+        self.log.info("Eval %d | step %d eval_dist %.6f best %.6f", self.total_eval_num, global_step,
+                      self.eval_dist, self.best_eval_dist)
 
     def run(self, max_steps=None):
         n = self.num_batches if max_steps is None else min(self.num_batches, max_steps)
         t0 = time.time()
-        for i in range(n):
+        stopped = "end of data"
+        while self.ts.global_step < n:
+            gs = self.ts.global_step
+            if (self.total_eval_num - self.last_improve_num > self.require_improve_num
+                    and gs > self.check_stop_step):
+                stopped = "early stop"
+                break
             self.ts.step()
-            if (i + 1) % self.show_step == 0 or i + 1 == n:
+            gs += 1
+            if gs % self.show_step == 0 or gs == n:
                 loss = self.ts.loss()
-                dt = time.time() - t0
-                self.history.append((i + 1, loss))
-                self.log.info("Step %d | Loss: %.8f | %.1f triplets/s", i + 1, loss,
-                              (i + 1) * self.ts.batch_global / dt)
+                self.history.append((gs, loss))
+                self.log.info("Epoch %d Step %d | Loss: %.8f | %.1f triplets/s", gs // self.step_per_epoch + 1,
+                              gs, loss, gs * self.ts.batch_global / (time.time() - t0))
+            if self.evaluater is not None and gs % self.eval_step == 0:
+                self._eval(gs)
+        if stopped == "end of data" and self.evaluater is not None and self.eval_dist < self.best_eval_dist:
+            self.save(self.ts.global_step)                              # train.py:301-305
+        self.stopped = stopped
         return self.history

@@ -194,6 +194,14 @@ int cdml_triplet_hinge_indexed(const float *e, int64_t lde,
                                float *scale_scratch, float *de, int64_t ldde,
                                cdml_stream_t stream);
 
+/* ---- evaluation metric: Evaluation.mean_dist / mean_cos_dist (evaluate.py:57-90)
+ * e[n_rows][lde] embeddings; pairs int32[P][2] row indices (must be < n_rows).
+ * sqdist[P] = sum (a-b)^2, dot[P] = sum a*b; means float[4] (may be NULL):
+ * means[1] = mean sqdist (= mean_dist), means[2] = mean dot (= mean_cos_dist). */
+int cdml_pair_dist(const float *e, int64_t lde, int n_rows, const int32_t *pairs,
+                   int P, int D, float *sqdist, float *dot, float *means,
+                   cdml_stream_t stream);
+
 /* ---- optimizers (train.py:108-125,146) --------------------------------------
  * Adam, TensorFlow form (epsilon outside the bias correction):
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m=b1*m+(1-b1)*g; v=b2*v+(1-b2)*g*g;

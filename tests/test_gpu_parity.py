@@ -639,3 +639,104 @@ def test_train_step_semihard_config2_shape(cd):
     for _ in range(2):
         ts.step()
     assert np.isfinite(ts.loss())
+
+
+# ------------------------------------------- next rows N1 / N2: predict, eval, trainer ----
+def test_evaluation_matches_reference_golden(cd, golden_dir):
+    """G3: inputs and outputs produced by the reference's own evaluate.Evaluation."""
+    from cdml_amd import evaluate
+    g = np.load(os.path.join(golden_dir, "evaluate_mean_dist.npz"))
+    ev = evaluate.Evaluation(g["features"], g["cowatches"].tolist(), device=cd.dev)
+    np.testing.assert_array_equal(ev.features, g["eval_features"])          # evaluate.py:34-55
+    np.testing.assert_array_equal(np.asarray(ev.cowatches), g["eval_cowatches"])
+    got = ev.mean_dist(g["embeddings"], ev.cowatches)
+    np.testing.assert_allclose(got, float(g["mean_dist"]), rtol=1e-6)       # evaluate.py:57-73
+    emb, cw = g["embeddings"].astype(np.float64), g["eval_cowatches"]
+    np.testing.assert_allclose(ev.mean_cos_dist(g["embeddings"], ev.cowatches),
+                               np.mean(np.sum(emb[cw[:, 0]] * emb[cw[:, 1]], axis=-1)), rtol=1e-5)
+    with pytest.raises(IndexError):
+        ev.mean_dist(g["embeddings"][:3], ev.cowatches)
+
+
+def test_prediction_run_features(cd, tmp_path):
+    from cdml_amd import predict
+    F, H, D, N = 200, 300, 64, 333
+    feats = np.random.RandomState(0).random_sample((N, F)).astype(np.float32)
+    params = cd.engine.VNetParams(cd.engine.TowerLayout(F, H, D), cd.dev, seed=1)
+    pred = predict.Prediction(params=params)
+    out = pred.run_features(feats, batch_size=128, output_dir=str(tmp_path), suffix="_t")   # 2 chunks + tail
+    W = [t.cpu().numpy().astype(np.float64) for t in params.unpadded()]
+    want = otower.vnet_forward(feats.astype(np.float64), *W, dtype=np.float64)["l2_norm"]
+    assert out.dtype == np.float32 and out.shape == (N, D)
+    np.testing.assert_allclose(out, want, atol=TOL)
+    np.testing.assert_array_equal(np.load(tmp_path / "output_t.npy"), out)                  # predict.py:87-91
+    table = cd.engine.FeatureTable.from_numpy(feats, cd.dev)                                # padded rows
+    np.testing.assert_allclose(pred.run_features(table, batch_size=1000), want, atol=TOL)
+    with pytest.raises(IOError):
+        predict.Prediction(ckpt=str(tmp_path / "missing.pt"))
+
+
+def _clustered(n_videos, F, n_clusters, seed):
+    rng = np.random.RandomState(seed)
+    centers = rng.random_sample((n_clusters, F))
+    cid = rng.randint(0, n_clusters, size=n_videos)
+    feats = (centers[cid] + 0.05 * rng.randn(n_videos, F)).clip(0, None).astype(np.float32)
+    a = rng.randint(0, n_videos, size=6000)
+    order = np.argsort(cid, kind="stable")
+    starts = np.searchsorted(cid[order], np.arange(n_clusters))
+    counts = np.bincount(cid, minlength=n_clusters)
+    p = order[starts[cid[a]] + rng.randint(0, 1 << 30, size=len(a)) % counts[cid[a]]]
+    pairs = np.stack([a, p], axis=1)
+    return feats, pairs[pairs[:, 0] != pairs[:, 1]].astype(np.int32)
+
+
+def test_trainer_learns_evaluates_checkpoints_and_resumes(cd, tmp_path):
+    """train.py:224-309 policy on a learnable synthetic set (co-watched videos share
+    a cluster): the loss and the held-out mean_dist go down, the best model is
+    checkpointed (one file kept), and a resumed run continues bit-exactly."""
+    feats, pairs = _clustered(2000, 64, 10, 0)
+    eval_pairs, train_pairs = pairs[:200], pairs[200:]
+    table = cd.engine.FeatureTable.from_numpy(feats, cd.dev)
+    kw = dict(hidden_size=128, output_size=32, margin=0.8, mode="uniform", optimizer="adam",
+              base_learning_rate=0.002, device=cd.dev)
+    B = 64
+    mk = lambda: cd.train.TrainStep(table, dt(train_pairs, cd.dev, torch.int32), B, **kw)
+    ts = mk()
+    tr = cd.train.Trainer(ts, num_epochs=2, n_pairs=len(train_pairs), checkpoint_dir=str(tmp_path),
+                          eval_features=feats, eval_cowatches=eval_pairs.tolist(), check_stop_epoch=0.2,
+                          best_eval_dist=10.0, eval_per_epoch=8, require_improve_num=100)
+    assert tr.num_batches == (len(train_pairs) * 2) // B
+    hist = tr.run()
+    assert tr.stopped == "end of data" and ts.global_step == tr.num_batches
+    assert hist[-1][1] < 0.6 * hist[0][1], hist                 # loss went down
+    ev = tr.eval_history
+    assert len(ev) >= 8 and ev[-1][1] < 0.8 * ev[0][1]          # held-out positive distance too
+    assert tr.best_eval_dist == min(e[1] for e in ev if e[0] > tr.check_stop_step)
+    files = sorted(os.listdir(tmp_path))
+    assert len(files) == 1 and files[0].startswith("model.ckpt-")           # max_to_keep=1
+    # resume: 5 steps + save + 5 steps  ==  10 steps straight
+    a, b = mk(), mk()
+    for _ in range(10):
+        a.step()
+    for _ in range(5):
+        b.step()
+    ck = tmp_path / "resume.pt"
+    torch.save(b.state_dict(), ck)
+    c = mk()
+    c.load_state_dict(torch.load(ck, map_location="cpu"))
+    for _ in range(5):
+        c.step()
+    torch.cuda.synchronize()
+    assert c.global_step == 10 and torch.equal(a.params.flat, c.params.flat)
+    assert torch.equal(a.m, c.m) and torch.equal(a.idx, c.idx)
+    # early stop: patience 0 after the check-stop step
+    ts2 = mk()
+    tr2 = cd.train.Trainer(ts2, num_epochs=50, n_pairs=len(train_pairs), eval_features=feats,
+                           eval_cowatches=eval_pairs.tolist(), check_stop_epoch=0.05,
+                           best_eval_dist=1e-9, eval_per_epoch=20, require_improve_num=1)
+    tr2.run()
+    assert tr2.stopped == "early stop" and ts2.global_step < tr2.num_batches
+    # a checkpoint feeds Prediction (predict.py:46-59)
+    from cdml_amd import predict
+    p = predict.Prediction(ckpt=os.path.join(tmp_path, files[0]), device=cd.dev)
+    assert p.run_features(feats[:10], 4).shape == (10, 32)
