@@ -43,6 +43,15 @@ constexpr int KPAD = 4;
 #ifndef CDML_GEMM_STAGGER
 #define CDML_GEMM_STAGGER 0         // 1: delay blocks by (bid>>8)&1, 2: by (bid>>3)&1 (co-residents out of lockstep)
 #endif
+#ifndef CDML_GEMM_GLDS
+#define CDML_GEMM_GLDS 1            // global->LDS by LDS-DMA (no VGPR staging, no ds_write)
+#endif
+#ifndef CDML_GEMM_PREFETCH_DIST
+#define CDML_GEMM_PREFETCH_DIST 2   // K-tiles the global loads run ahead of the MFMAs (1 or 2)
+#endif
+#ifndef CDML_GEMM_ABLATE
+#define CDML_GEMM_ABLATE 0          // timing-only builds (wrong results): 1 no global loads/LDS writes,
+#endif                              // 2 also no barrier, 3 also no LDS fragment reads
 #ifndef CDML_GEMM_LDS_EPILOGUE
 #define CDML_GEMM_LDS_EPILOGUE 1    // C tile through LDS -> coalesced 16-B row stores
 #endif
@@ -62,6 +71,39 @@ struct GemmArgs {
   int64_t slab_stride;           // elements between split outputs
   int tiles_m, tiles_n;
 };
+
+// ---- LDS-DMA primitives.  Issued through inline asm on purpose: with the
+// builtins hipcc cannot prove that the DMA into LDS buffer b^1 does not alias
+// the ds_reads of buffer b and drains the DMA (s_waitcnt vmcnt(0)) before the
+// first fragment read of every K-tile, i.e. in front of the MFMAs.  The asm
+// loads are invisible to its wait-count pass; the kernel waits for them itself
+// (dma_wait_all) right before the barrier that publishes the tile.
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+__device__ __forceinline__ uint32_t lds_offset(const float *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)p;
+}
+// 64 lanes x 16 B: global (per-lane address) -> LDS (m0 = wave-uniform base, + lane*16)
+__device__ __forceinline__ void dma_global_to_lds(const float *gptr, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(lds_base), "v"(gptr) : "memory", "m0");
+}
+// same through a buffer descriptor: lanes whose offset is outside the range read zeros
+__device__ __forceinline__ void dma_buffer_to_lds(i32x4 srd, uint32_t voff, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_base), "v"(voff), "s"(srd) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ i32x4 make_srd(const float *base, int64_t bytes) {
+  const uint64_t a = (uint64_t)(uintptr_t)base;
+  i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffff));  // stride 0
+  r.z = __builtin_amdgcn_readfirstlane((int)(bytes > 0 ? bytes : 0));
+  r.w = 0x00020000;
+  return r;
+}
 
 // XCD-aware bijective remap (blocks b and b+8 share an XCD) followed by a
 // grouped raster: 8 M-tiles x all N-tiles per group.
@@ -83,8 +125,14 @@ __device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int
 template <bool AKC, bool BKC, int TM, int TN, int EPI>
 __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int A_TILE = AKC ? BM * (BK + KPAD) : BK * BM;
-  constexpr int B_TILE = BKC ? BN * (BK + KPAD) : BK * BN;
+  constexpr bool GLDS = (CDML_GEMM_GLDS != 0);
+  // floats per row of a k-contiguous LDS tile: padded for register staging; with
+  // LDS-DMA the image must be lane-linear, so rows are 128 B and the 16-B chunks are
+  // XOR-swizzled by the row instead (chunk' = chunk ^ ((row >> 1) & 7): conflict-free
+  // ds_read_b128, applied on the DMA's per-lane SOURCE address and on the read).
+  constexpr int KROW = GLDS ? BK : BK + KPAD;
+  constexpr int A_TILE = AKC ? BM * KROW : BK * BM;
+  constexpr int B_TILE = BKC ? BN * KROW : BK * BN;
   constexpr int A_REGS = BM / 32, B_REGS = BN / 32;  // f32x4 staging registers per thread
   constexpr bool KPRED = !AKC && !BKC;               // only the bwd-weight GEMM has a ragged K
   constexpr int STAGE = 2 * (A_TILE + B_TILE);
@@ -105,7 +153,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
   const int k_end = min(g.K, k_begin + g.k_per_split);
   const int n_ktiles = (k_end - k_begin + BK - 1) / BK;
 
-  f32x4 ra[A_REGS], rb[B_REGS];
+  struct Stage { f32x4 a[A_REGS]; f32x4 b[B_REGS]; };  // one K-tile's staging registers
   f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool do_colsum = (EPI == EPI_SLAB_COLSUM) && g.colsum && tm == 0;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -115,16 +163,20 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
   // of the bwd-weight GEMM) is zeroed LATER, in store_tile -- touching a loaded
   // value here would put the vmcnt wait in front of the MFMAs.
   auto load_tile = [&](int kt) {
-    const int k0 = k_begin + kt * BK;
+    Stage st;
+    // a tile wholly past the end (the prefetch runs ahead) re-reads the split's first
+    // tile; k-strided rows of the ragged bwd-weight GEMM are clamped per row below
+    const int k0u = k_begin + kt * BK;
+    const int k0 = (KPRED || k0u < k_end) ? k0u : k_begin;
     if (AKC) {  // rows [m0, m0+BM) x k [k0, k0+32): 8 f32x4 per row
 #pragma unroll
       for (int p = 0; p < A_REGS; ++p) {
 #if CDML_GEMM_BRANCHLESS_LOADS
         const int row = min(m0 + p * 32 + (t >> 3), g.M - 1);
-        ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (int64_t)row * g.lda + k0 + (t & 7) * 4);
+        st.a[p] = *reinterpret_cast<const f32x4 *>(g.A + (int64_t)row * g.lda + k0 + (t & 7) * 4);
 #else
         const int row = m0 + p * 32 + (t >> 3);
-        ra[p] = (row < g.M)
+        st.a[p] = (row < g.M)
                     ? *reinterpret_cast<const f32x4 *>(g.A + (int64_t)row * g.lda + k0 + (t & 7) * 4)
                     : zero4;
 #endif
@@ -136,9 +188,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
         const int k = k0 + p * KR + t / C4;
 #if CDML_GEMM_BRANCHLESS_LOADS
         const int kc = KPRED ? min(k, k_end - 1) : k;
-        ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (int64_t)kc * g.lda + m0 + (t % C4) * 4);
+        st.a[p] = *reinterpret_cast<const f32x4 *>(g.A + (int64_t)kc * g.lda + m0 + (t % C4) * 4);
 #else
-        ra[p] = (k < k_end)
+        st.a[p] = (k < k_end)
                     ? *reinterpret_cast<const f32x4 *>(g.A + (int64_t)k * g.lda + m0 + (t % C4) * 4)
                     : zero4;
 #endif
@@ -148,7 +200,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
 #pragma unroll
       for (int p = 0; p < B_REGS; ++p) {
         const int row = n0 + p * 32 + (t >> 3);
-        rb[p] = *reinterpret_cast<const f32x4 *>(g.B + (int64_t)row * g.ldb + k0 + (t & 7) * 4);
+        st.b[p] = *reinterpret_cast<const f32x4 *>(g.B + (int64_t)row * g.ldb + k0 + (t & 7) * 4);
       }
     } else {
       constexpr int C4 = BN / 4, KR = kThreads / C4;
@@ -157,60 +209,66 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
         const int k = k0 + p * KR + t / C4;
 #if CDML_GEMM_BRANCHLESS_LOADS
         const int kc = KPRED ? min(k, k_end - 1) : k;
-        rb[p] = *reinterpret_cast<const f32x4 *>(g.B + (int64_t)kc * g.ldb + n0 + (t % C4) * 4);
+        st.b[p] = *reinterpret_cast<const f32x4 *>(g.B + (int64_t)kc * g.ldb + n0 + (t % C4) * 4);
 #else
-        rb[p] = (k < k_end)
+        st.b[p] = (k < k_end)
                     ? *reinterpret_cast<const f32x4 *>(g.B + (int64_t)k * g.ldb + n0 + (t % C4) * 4)
                     : zero4;
 #endif
       }
     }
+    return st;
   };
 
   // Registers -> LDS (tile kt); also where the ragged-K zeroing and the
   // bias-gradient column sums of the bwd-weight GEMM happen.
-  auto store_tile = [&](int buf, int kt) {
+  auto store_tile = [&](int buf, int kt, Stage st) {
     float *sA = smem + buf * (A_TILE + B_TILE);
     float *sB = sA + A_TILE;
-    if (KPRED) {
+    {
       const int k0 = k_begin + kt * BK;
 #if CDML_GEMM_BRANCHLESS_LOADS
-      if (k0 + BK > k_end) {  // uniform: only the last K-tile of a split can be ragged
+      if (k0 >= k_end) {  // uniform: a whole tile past the end (prefetch ran ahead) contributes zeros
+#pragma unroll
+        for (int p = 0; p < A_REGS; ++p) st.a[p] = zero4;
+#pragma unroll
+        for (int p = 0; p < B_REGS; ++p) st.b[p] = zero4;
+      } else if (KPRED && k0 + BK > k_end) {  // uniform: ragged last K-tile of a split
         constexpr int CA = BM / 4, KRA = kThreads / CA, CB = BN / 4, KRB = kThreads / CB;
 #pragma unroll
         for (int p = 0; p < A_REGS; ++p)
-          if (k0 + p * KRA + t / CA >= k_end) ra[p] = zero4;
+          if (k0 + p * KRA + t / CA >= k_end) st.a[p] = zero4;
 #pragma unroll
         for (int p = 0; p < B_REGS; ++p)
-          if (k0 + p * KRB + t / CB >= k_end) rb[p] = zero4;
+          if (k0 + p * KRB + t / CB >= k_end) st.b[p] = zero4;
       }
 #endif
-      if (EPI == EPI_SLAB_COLSUM && do_colsum) {
+      if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) {
 #pragma unroll
         for (int p = 0; p < B_REGS; ++p) {
-          bsum.x += rb[p].x; bsum.y += rb[p].y; bsum.z += rb[p].z; bsum.w += rb[p].w;
+          bsum.x += st.b[p].x; bsum.y += st.b[p].y; bsum.z += st.b[p].z; bsum.w += st.b[p].w;
         }
       }
     }
     if (AKC) {
 #pragma unroll
       for (int p = 0; p < A_REGS; ++p)
-        *reinterpret_cast<f32x4 *>(sA + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = ra[p];
+        *reinterpret_cast<f32x4 *>(sA + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = st.a[p];
     } else {
       constexpr int C4 = BM / 4, KR = kThreads / C4;
 #pragma unroll
       for (int p = 0; p < A_REGS; ++p)
-        *reinterpret_cast<f32x4 *>(sA + (p * KR + t / C4) * BM + (t % C4) * 4) = ra[p];
+        *reinterpret_cast<f32x4 *>(sA + (p * KR + t / C4) * BM + (t % C4) * 4) = st.a[p];
     }
     if (BKC) {
 #pragma unroll
       for (int p = 0; p < B_REGS; ++p)
-        *reinterpret_cast<f32x4 *>(sB + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = rb[p];
+        *reinterpret_cast<f32x4 *>(sB + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = st.b[p];
     } else {
       constexpr int C4 = BN / 4, KR = kThreads / C4;
 #pragma unroll
       for (int p = 0; p < B_REGS; ++p)
-        *reinterpret_cast<f32x4 *>(sB + (p * KR + t / C4) * BN + (t % C4) * 4) = rb[p];
+        *reinterpret_cast<f32x4 *>(sB + (p * KR + t / C4) * BN + (t % C4) * 4) = st.b[p];
     }
   };
 
@@ -223,7 +281,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
     for (int mi = 0; mi < TM; ++mi) {
       const int row = wm * 32 * TM + mi * 32 + l31;
       if (AKC) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(sA + row * (BK + KPAD) + 8 * grp + 4 * h);
+        const int off = GLDS ? row * BK + (((2 * grp + h) ^ ((row >> 1) & 7)) << 2)
+                             : row * (BK + KPAD) + 8 * grp + 4 * h;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(sA + off);
         f.a[mi][0] = v.x; f.a[mi][1] = v.y; f.a[mi][2] = v.z; f.a[mi][3] = v.w;
       } else {
 #pragma unroll
@@ -234,7 +294,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
     for (int ni = 0; ni < TN; ++ni) {
       const int col = wn * 32 * TN + ni * 32 + l31;
       if (BKC) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(sB + col * (BK + KPAD) + 8 * grp + 4 * h);
+        const int off = GLDS ? col * BK + (((2 * grp + h) ^ ((col >> 1) & 7)) << 2)
+                             : col * (BK + KPAD) + 8 * grp + 4 * h;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(sB + off);
         f.b[ni][0] = v.x; f.b[ni][1] = v.y; f.b[ni][2] = v.z; f.b[ni][3] = v.w;
       } else {
 #pragma unroll
@@ -258,16 +320,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
   if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_sleep(32);
 #endif
 
-  if (n_ktiles > 0) {
-    load_tile(0);
-    store_tile(0, 0);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < n_ktiles; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < n_ktiles) load_tile(kt + 1);  // global loads in flight under the MFMAs
-
+  // MFMAs of one K-tile held in LDS buffer `buf`
+  auto compute_tile = [&](int buf) {
     const float *sA = smem + buf * (A_TILE + B_TILE);
     const float *sB = sA + A_TILE;
 #define CDML_MFMA_GROUP(F)                                                                   \
@@ -279,33 +333,145 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
     // operands k-strided: 2x the LDS read instructions; measured +5 % there, -2 % on fwd)
     constexpr bool PF = (CDML_GEMM_FRAG_PREFETCH == 1) || (CDML_GEMM_FRAG_PREFETCH == 2 && KPRED);
     if constexpr (PF) {
-    // fragments are double-buffered in registers: group g+1 is read from LDS while
-    // the 4*TM*TN MFMAs of group g issue.  The sched_barrier keeps the reads ahead
-    // (hipcc otherwise sinks each read to just before its use and stalls on lgkmcnt(0)).
-    static_assert(BK / 8 == 4, "unrolled for 4 k-groups");
-    Frag f0 = load_frags(sA, sB, 0);
-    Frag f1 = load_frags(sA, sB, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    CDML_MFMA_GROUP(f0);
-    f0 = load_frags(sA, sB, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    CDML_MFMA_GROUP(f1);
-    f1 = load_frags(sA, sB, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    CDML_MFMA_GROUP(f0);
-    CDML_MFMA_GROUP(f1);
+      // fragments double-buffered in registers: group g+1 is read from LDS while the
+      // 4*TM*TN MFMAs of group g issue.  The sched_barrier keeps the reads ahead (hipcc
+      // otherwise sinks each read to just before its use and stalls on lgkmcnt(0)).
+      static_assert(BK / 8 == 4, "unrolled for 4 k-groups");
+      Frag f0 = load_frags(sA, sB, 0);
+      Frag f1 = load_frags(sA, sB, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      CDML_MFMA_GROUP(f0);
+      f0 = load_frags(sA, sB, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      CDML_MFMA_GROUP(f1);
+      f1 = load_frags(sA, sB, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      CDML_MFMA_GROUP(f0);
+      CDML_MFMA_GROUP(f1);
     } else {
 #pragma unroll
-    for (int grp = 0; grp < BK / 8; ++grp) {
-      const Frag f = load_frags(sA, sB, grp);
-      CDML_MFMA_GROUP(f);
-    }
+      for (int grp = 0; grp < BK / 8; ++grp) {
+#if CDML_GEMM_ABLATE >= 3
+        Frag f = load_frags(smem, smem + A_TILE, 0);
+        asm volatile("" : "+v"(f.a[0][0]), "+v"(f.b[0][0]));
+#else
+        const Frag f = load_frags(sA, sB, grp);
+#endif
+        CDML_MFMA_GROUP(f);
+      }
     }
 #undef CDML_MFMA_GROUP
+  };
 
-    if (kt + 1 < n_ktiles) store_tile(buf ^ 1, kt + 1);
-    __syncthreads();
+  // ---- LDS-DMA staging (GLDS): each wave-instruction moves 64 x 16 B = 1 KiB
+  // straight from global memory into LDS (destination = wave-uniform base +
+  // lane*16, source address per lane).  k-strided operands go through a buffer
+  // descriptor whose range ends at row k_end, so the ragged last K-tile of the
+  // bwd-weight GEMM reads zeros with no predication.
+  const i32x4 srd_a = (!AKC) ? make_srd(g.A + (int64_t)k_begin * g.lda, (int64_t)(k_end - k_begin) * g.lda * 4)
+                             : i32x4{0, 0, 0, 0};
+  const i32x4 srd_b = (!BKC) ? make_srd(g.B + (int64_t)k_begin * g.ldb, (int64_t)(k_end - k_begin) * g.ldb * 4)
+                             : i32x4{0, 0, 0, 0};
+  auto issue_tile = [&](int buf, int kt) {
+    const float *sA = smem + buf * (A_TILE + B_TILE);
+    const float *sB = sA + A_TILE;
+    const uint32_t la = __builtin_amdgcn_readfirstlane(lds_offset(sA) + wave * 1024);
+    const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_offset(sB) + wave * 1024);
+    const int k0 = k_begin + kt * BK;
+    if (AKC) {
+#pragma unroll
+      for (int j = 0; j < BM / 32; ++j) {      // piece = wave + 4j: 8 rows x 128 B
+        const int row = (wave + 4 * j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int grow = min(m0 + row, g.M - 1);
+        dma_global_to_lds(g.A + (int64_t)grow * g.lda + k0 + 4 * c, la + j * 4096);
+      }
+    } else {
+      constexpr int KPP = 256 / BM;            // k rows per 1-KiB piece
+#pragma unroll
+      for (int j = 0; j < BM / 32; ++j) {
+        const int f = lane * 4;
+        const int k = kt * BK + (wave + 4 * j) * KPP + f / BM;
+        dma_buffer_to_lds(srd_a, (uint32_t)(((int64_t)k * g.lda + m0 + f % BM) * 4), la + j * 4096);
+      }
+    }
+    if (BKC) {
+#pragma unroll
+      for (int j = 0; j < BN / 32; ++j) {
+        const int row = (wave + 4 * j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        dma_global_to_lds(g.B + (int64_t)(n0 + row) * g.ldb + k0 + 4 * c, lb + j * 4096);
+      }
+    } else {
+      constexpr int KPP = 256 / BN;
+#pragma unroll
+      for (int j = 0; j < BN / 32; ++j) {
+        const int f = lane * 4;
+        const int k = kt * BK + (wave + 4 * j) * KPP + f / BN;
+        dma_buffer_to_lds(srd_b, (uint32_t)(((int64_t)k * g.ldb + n0 + f % BN) * 4), lb + j * 4096);
+      }
+    }
+  };
+
+  // bias gradient of the bwd-weight GEMM: column sums of the dy tile now in LDS
+  auto colsum_tile = [&](int buf) {
+    const float *sB = smem + buf * (A_TILE + B_TILE) + A_TILE;
+    constexpr int CB = BN / 4, KRB = kThreads / CB;
+#pragma unroll
+    for (int j = 0; j < BK / KRB; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(sB + (j * KRB + t / CB) * BN + (t % CB) * 4);
+      bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+    }
+  };
+
+#if CDML_GEMM_GLDS
+  if (n_ktiles > 0) issue_tile(0, 0);
+  dma_wait_all();
+  __syncthreads();
+  for (int kt = 0; kt < n_ktiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < n_ktiles) issue_tile(buf ^ 1, kt + 1);  // lands in the other buffer under the MFMAs
+    if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) colsum_tile(buf);
+    compute_tile(buf);
+    dma_wait_all();    // this wave's pieces of tile kt+1 are in LDS ...
+    __syncthreads();   // ... and so are everybody else's; buffer `buf` is free again
   }
+#elif CDML_GEMM_PREFETCH_DIST == 2
+  // Global loads run TWO K-tiles ahead of the MFMAs (two staging register sets,
+  // loop unrolled by two so the set is static): a tile has two compute phases to
+  // arrive before its LDS write needs it.
+  // No conditional loads in the loop (a load under a branch makes hipcc wait for
+  // vmcnt(0) at the next LDS write): tiles past the end are loaded from a clamped
+  // address and zeroed in store_tile, and the tile count is rounded up to even.
+  const int n_even = (n_ktiles + 1) & ~1;
+  Stage s0 = load_tile(0), s1 = load_tile(1);
+  store_tile(0, 0, s0);
+  __syncthreads();
+  for (int kt = 0; kt < n_even; kt += 2) {
+    if (CDML_GEMM_ABLATE == 0) s0 = load_tile(kt + 2);
+    compute_tile(0);
+    if (CDML_GEMM_ABLATE == 0) store_tile(1, kt + 1, s1);
+    if (CDML_GEMM_ABLATE < 2) __syncthreads();
+    if (CDML_GEMM_ABLATE == 0) s1 = load_tile(kt + 3);
+    compute_tile(1);
+    if (CDML_GEMM_ABLATE == 0) store_tile(0, kt + 2, s0);
+    if (CDML_GEMM_ABLATE < 2) __syncthreads();
+  }
+#else
+  Stage s0;
+  if (n_ktiles > 0) {
+    s0 = load_tile(0);
+    store_tile(0, 0, s0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < n_ktiles; ++kt) {
+    const int buf = kt & 1;
+    if (CDML_GEMM_ABLATE == 0 && kt + 1 < n_ktiles) s0 = load_tile(kt + 1);  // in flight under the MFMAs
+    compute_tile(buf);
+    if (CDML_GEMM_ABLATE == 0 && kt + 1 < n_ktiles) store_tile(buf ^ 1, kt + 1, s0);
+    if (CDML_GEMM_ABLATE < 2) __syncthreads();
+  }
+#endif
 
 #if !CDML_GEMM_LDS_EPILOGUE
   {  // direct epilogue: one dword per lane per store, two 128-B row segments per instruction
