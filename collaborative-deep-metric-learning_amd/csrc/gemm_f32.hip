@@ -46,6 +46,9 @@ constexpr int KPAD = 4;
 #ifndef CDML_GEMM_GLDS
 #define CDML_GEMM_GLDS 1            // global->LDS by LDS-DMA (no VGPR staging, no ds_write)
 #endif
+#ifndef CDML_GEMM_DMA_INTERLEAVE
+#define CDML_GEMM_DMA_INTERLEAVE 0  // 1: issue the next tile's DMA pieces between MFMA quads (measured: -1 %)
+#endif
 #ifndef CDML_GEMM_PREFETCH_DIST
 #define CDML_GEMM_PREFETCH_DIST 2   // K-tiles the global loads run ahead of the MFMAs (1 or 2)
 #endif
@@ -424,15 +427,83 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
     }
   };
 
+  // One 1-KiB DMA piece of tile kt into buffer buf; idx < BM/32 -> A piece, else B.
+  auto issue_piece = [&](int buf, int kt, int idx) {
+    const float *sA = smem + buf * (A_TILE + B_TILE);
+    const float *sB = sA + A_TILE;
+    const int k0 = k_begin + kt * BK;
+    if (idx < BM / 32) {
+      const int j = idx;
+      const uint32_t la = __builtin_amdgcn_readfirstlane(lds_offset(sA) + wave * 1024 + j * 4096);
+      if (AKC) {
+        const int row = (wave + 4 * j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        dma_global_to_lds(g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + k0 + 4 * c, la);
+      } else {
+        constexpr int KPP = 256 / BM;
+        const int f = lane * 4;
+        const int k = kt * BK + (wave + 4 * j) * KPP + f / BM;
+        dma_buffer_to_lds(srd_a, (uint32_t)(((int64_t)k * g.lda + m0 + f % BM) * 4), la);
+      }
+    } else {
+      const int j = idx - BM / 32;
+      const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_offset(sB) + wave * 1024 + j * 4096);
+      if (BKC) {
+        const int row = (wave + 4 * j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        dma_global_to_lds(g.B + (int64_t)(n0 + row) * g.ldb + k0 + 4 * c, lb);
+      } else {
+        constexpr int KPP = 256 / BN;
+        const int f = lane * 4;
+        const int k = kt * BK + (wave + 4 * j) * KPP + f / BN;
+        dma_buffer_to_lds(srd_b, (uint32_t)(((int64_t)k * g.ldb + n0 + f % BN) * 4), lb);
+      }
+    }
+  };
+
+  // MFMAs of tile kt (buffer buf) with the DMA pieces of tile kt+1 issued BETWEEN the
+  // MFMA quads: an issued MFMA keeps the matrix pipe busy for 64 cycles, so a DMA
+  // issue (~60-100 cycles of this wave's issue slot) hides under it, whereas eight
+  // of them in front of the tile leave the wave's MFMA stream empty for ~700 cycles.
+  auto compute_issue = [&](int buf, int kt, bool more) {
+    const float *sA = smem + buf * (A_TILE + B_TILE);
+    const float *sB = sA + A_TILE;
+    constexpr int NP = BM / 32 + BN / 32;   // pieces per wave per K-tile
+    constexpr int STRIDE = 16 / NP;         // MFMA quads between two issues (NP = 8, 6 or 4)
+#pragma unroll
+    for (int grp = 0; grp < BK / 8; ++grp) {
+      const Frag f = load_frags(sA, sB, grp);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mi][u], f.b[ni][u], acc[mi][ni], 0, 0, 0);
+        const int slot = grp * 4 + u;
+        if (slot % STRIDE == 0 && slot / STRIDE < NP) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_piece(buf ^ 1, kt + 1, slot / STRIDE);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+
 #if CDML_GEMM_GLDS
   if (n_ktiles > 0) issue_tile(0, 0);
   dma_wait_all();
   __syncthreads();
   for (int kt = 0; kt < n_ktiles; ++kt) {
     const int buf = kt & 1;
+#if CDML_GEMM_DMA_INTERLEAVE
+    if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) colsum_tile(buf);
+    compute_issue(buf, kt, kt + 1 < n_ktiles);
+#else
     if (kt + 1 < n_ktiles) issue_tile(buf ^ 1, kt + 1);  // lands in the other buffer under the MFMAs
     if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) colsum_tile(buf);
     compute_tile(buf);
+#endif
     dma_wait_all();    // this wave's pieces of tile kt+1 are in LDS ...
     __syncthreads();   // ... and so are everybody else's; buffer `buf` is free again
   }
