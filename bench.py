@@ -176,7 +176,8 @@ def main():
     if world > 1:
         lo, hi, _ = cdist.shard_bounds(n_rows, world, rank)
         table = engine.FeatureTable.synthetic(hi - lo, F, seed=0, device=dev, row0=lo, n_rows_global=n_rows)
-        exchange, grad_sync = cdist.RowExchange(n_rows), cdist.GradSync()
+        # own communicator for the exchange so it never queues behind the gradient all-reduce
+        exchange, grad_sync = cdist.RowExchange(n_rows, group=dist.new_group()), cdist.GradSync()
     else:
         table = engine.FeatureTable.synthetic(n_rows, F, seed=0, device=dev)
         exchange = grad_sync = None

@@ -131,3 +131,44 @@ class GradSync:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             flat_grad.div_(self.world)
         return flat_grad
+
+
+class Prefetcher:
+    """Double-buffered run-ahead of the row exchange.
+
+    The sampler is counter-based, so the rows of step t+1 are known while step t
+    computes: ``launch`` enqueues sampling + exchange for one buffer on a side
+    stream (the host sync for the all-to-all split sizes then waits only for that
+    stream, not for the 2.7 ms of GEMMs queued on the compute stream), ``acquire``
+    makes the compute stream wait for a filled buffer and ``release`` tells the
+    side stream the buffer may be overwritten.  Give the exchange its own process
+    group (communicator): collectives of one group execute in issue order, and the
+    exchange of step t+1 must not queue behind the gradient all-reduce of step t."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        if self.cuda:
+            self.stream = torch.cuda.Stream(self.device)
+            self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self.free = [torch.cuda.Event(), torch.cuda.Event()]
+        self._released = [False, False]
+
+    def launch(self, b, fill_fn):
+        if not self.cuda:
+            fill_fn()
+            return
+        with torch.cuda.stream(self.stream):
+            if self._released[b]:
+                self.stream.wait_event(self.free[b])
+            fill_fn()
+            self.ready[b].record(self.stream)
+
+    def acquire(self, b):
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_event(self.ready[b])
+
+    def release(self, b):
+        if self.cuda:
+            self.free[b].record(torch.cuda.current_stream(self.device))
+            self._released[b] = True

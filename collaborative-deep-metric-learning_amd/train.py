@@ -41,7 +41,8 @@ class TrainStep:
                  hidden_size=5000, margin=0.8, mode="uniform", optimizer="adam",
                  base_learning_rate=0.01, learning_rate_decay_examples=1000000,
                  learning_rate_decay=0.96, seed=1234, weight_seed=42, device="cuda:0",
-                 exchange=None, grad_sync=None, slot0=0, batch_global=None, use_graph=False):
+                 exchange=None, grad_sync=None, slot0=0, batch_global=None, use_graph=False,
+                 prefetch=True):
         """table: FeatureTable (whole catalogue, or this rank's shard when
         ``exchange`` is given); pairs: int32 [P,2] device tensor; ``exchange`` /
         ``grad_sync``: the multi-GPU hooks of cdml_amd.dist (None on one GPU)."""
@@ -96,11 +97,39 @@ class TrainStep:
             self.lars_scratch = torch.zeros(ops.lars_scratch_floats(), dtype=f32, device=dev)
         self._graph = None
         self.use_graph = bool(use_graph) and exchange is None and grad_sync is None
+        # row-sharded catalogue: the exchange of step t+1 runs ahead on a side stream
+        # into the second x_hat / idx buffer while step t computes
+        self.prefetch = None
+        self._filled = -1
+        if exchange is not None and prefetch:
+            from .dist import Prefetcher
+            self.prefetch = Prefetcher(self.device)
+            self._x = [self.ws.x_hat, torch.zeros_like(self.ws.x_hat)]
+            self._idx = [self.idx, torch.zeros_like(self.idx)]
+            self._shift = [self.shift, torch.zeros_like(self.shift)]
 
     # ---------------------------------------------------------------- pieces --
+    def _fill(self, b, step):
+        """Sample step `step` (immediate, it runs ahead of the device counter) and
+        exchange its rows into buffer b."""
+        if _MODES[self.mode] == MODE_UNIFORM:
+            ops.sample_uniform(self.pairs, self.table.n_rows_global, self.seed, step, self.B,
+                               self._idx[b], slot0=self.slot0, batch_global=self.batch_global)
+        else:
+            ops.sample_inbatch(self.pairs, self.seed, step, self.B, self._idx[b], self._shift[b],
+                               slot0=self.slot0, batch_global=self.batch_global)
+        self.exchange.gather(self.table, self._idx[b], self._x[b])
+
     def fetch(self):
         """Sampler + gather (+ input l2norm): fills ws.x_hat and self.idx."""
         m = _MODES[self.mode]
+        if self.prefetch is not None:
+            t, b = self.global_step, self.global_step % 2
+            if t == 0 or self._filled != t:
+                self.prefetch.launch(b, lambda: self._fill(b, t))       # cold start / after a resume
+            self.prefetch.acquire(b)
+            self.ws.x_hat, self.idx, self.shift = self._x[b], self._idx[b], self._shift[b]
+            return
         if self.exchange is None:
             ops.sample_gather(m, self.pairs, self.seed, None, self.B, self.table.data,
                               self.table.feature_size, self.idx, self.ws.x_hat,
@@ -153,9 +182,15 @@ class TrainStep:
         self.fetch()
         self.forward_loss()
         self.backward()
+        if self.prefetch is not None:
+            t, b = self.global_step, self.global_step % 2
+            self.prefetch.release(b)                 # backward was the last reader of x_hat[b]
         if self.grad_sync is not None:
             self.grad_sync(self.params.grad)
         self.apply_gradients()
+        if self.prefetch is not None:                # next step's rows, under this step's GEMMs
+            self.prefetch.launch(1 - b, lambda: self._fill(1 - b, t + 1))
+            self._filled = t + 1
 
     # ------------------------------------------------------------------ step --
     def step(self):

@@ -45,7 +45,7 @@ def _worker(rank, world, port, q):
     try:
         from cdml_amd import dist as cdist
         dev = torch.device("cuda:0")
-        ts = _make(dev, rank, world, cdist.RowExchange(CFG["n_rows"]), cdist.GradSync())
+        ts = _make(dev, rank, world, cdist.RowExchange(CFG["n_rows"], group=dist.new_group()), cdist.GradSync())
         idx, g0 = [], None
         for _ in range(CFG["steps"]):
             ts.step()
