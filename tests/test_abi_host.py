@@ -108,3 +108,26 @@ def test_no_kernel_uses_scratch():
         spills = re.findall(r"VGPRs Spill: (\d+)", out.stderr)
         assert scratch and all(int(x) == 0 for x in scratch), (src, scratch)
         assert all(int(x) == 0 for x in spills), (src, spills)
+
+
+def test_dataset_directory_formats(tmp_path):
+    """Next-row N3: the reference's on-disk formats round-trip."""
+    from cdml_amd import inputs, online_data
+    rng = np.random.RandomState(0)
+    feats = rng.random_sample((50, 8)).astype(np.float32)
+    pairs = [[int(a), int(b)] for a, b in rng.randint(0, 50, size=(200, 2))]
+    d = str(tmp_path / "ds")
+    online_data.write_features(feats, {"g%d" % i: i for i in range(50)}, {i: "g%d" % i for i in range(50)}, d)
+    online_data.write_cowatches(pairs, d, split_num=4, eval_num=20, test_num=10)
+    ds = online_data.load_dataset(d)
+    np.testing.assert_array_equal(ds["features"], feats)
+    assert ds["eval_cowatches"] == pairs[:20] and ds["test_cowatches"] == pairs[20:30]
+    assert [os.path.basename(f) for f in ds["train_files"]] == ["xaa.train", "xab.train", "xac.train", "xad.train"]
+    got = inputs.read_cowatch_files(ds["train_files"])
+    np.testing.assert_array_equal(got, np.asarray(pairs[30:], dtype=np.int32))
+    assert ds["decode_map"]["7"] == "g7"
+    (tmp_path / "bad.eval").write_text("1,2\nx,y\n\n3,4\n")
+    assert online_data.load_cowatches(str(tmp_path / "bad.eval")) == [[1, 2], [3, 4]]
+    # 15 % rule of online_data.py:262-264
+    online_data.write_cowatches(pairs, str(tmp_path / "ds2"), split_num=1)
+    assert len(online_data.load_cowatches(str(tmp_path / "ds2" / "cowatches.eval"))) == 30

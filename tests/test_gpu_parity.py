@@ -740,3 +740,24 @@ def test_trainer_learns_evaluates_checkpoints_and_resumes(cd, tmp_path):
     from cdml_amd import predict
     p = predict.Prediction(ckpt=os.path.join(tmp_path, files[0]), device=cd.dev)
     assert p.run_features(feats[:10], 4).shape == (10, 32)
+
+
+def test_pipe_from_reference_format_directory(cd, tmp_path):
+    """N3: a dataset directory in the reference's on-disk formats drives the pipe the
+    way train.py:345 constructs it (file pattern + features.npy)."""
+    from cdml_amd import online_data
+    rng = np.random.RandomState(1)
+    feats = rng.random_sample((300, 16)).astype(np.float32)
+    pairs = rng.randint(0, 300, size=(500, 2))
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]].tolist()
+    d = str(tmp_path)
+    online_data.write_features(feats, save_dir=d)
+    online_data.write_cowatches(pairs, d, split_num=3, eval_num=40, test_num=40)
+    pipe = cd.inputs.MPTripletPipe(cowatch_file_patten=d + "/*.train", feature_file=d + "/features.npy",
+                                   wait_times=20, device=cd.dev)
+    train_pairs = np.asarray(pairs[80:], dtype=np.int32)
+    assert pipe.cowatch_num == len(train_pairs) and len(pipe.cowatch_files) == 3
+    pipe.create_pipe(num_epochs=1, batch_size=32)
+    b = pipe.get_batch()
+    idx = osampler.device_triplets_vec(train_pairs, 300, 1234, 0, 32)
+    np.testing.assert_array_equal(b.cpu().numpy(), feats[idx])
