@@ -53,6 +53,14 @@ SIGNATURES = {
     "cdml_semihard_select": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _p, _p]),
     "cdml_triplet_hinge_indexed": (_i, [_p, _i64, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "cdml_pair_dist": (_i, [_p, _i64, _i, _p, _i, _i, _p, _p, _p, _p]),
+    "cdml_gemm_bf16_workspace": (_sz, [_i, _i, _i]),
+    "cdml_gemm_bf16_nt": (_i, [_i, _p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _i64, _f, _p, _sz, _p]),
+    "cdml_transpose_to_bf16": (_i, [_i, _p, _i64, _i, _i, _p, _i64, _p]),
+    "cdml_cast_f32_bf16": (_i, [_p, _i64, _i, _i, _p, _i64, _p]),
+    "cdml_colsum_workspace_floats": (_sz, [_i, _i]),
+    "cdml_colsum": (_i, [_i, _p, _i64, _i, _i, _p, _p, _p]),
+    "cdml_fill_uniform_table_f16": (_i, [_p, _i64, _i64, _i, _i64, _u64, _p]),
+    "cdml_gather_rows_f16": (_i, [_p, _i64, _i64, _i64, _p, _i, _i, _p, _i64, _p, _p]),
     "cdml_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _i64, _p, _p]),
     "cdml_lars_scratch_floats": (_sz, []),
     "cdml_lars_step": (_i, [_p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p, _p]),

@@ -109,4 +109,22 @@ __device__ __forceinline__ int32_t sample_inbatch_shift(uint64_t seed, uint64_t 
   return 1 + (int32_t)(r < 0 ? 0 : r);
 }
 
+// XCD-aware bijective remap (blocks b and b+8 share an XCD) followed by a
+// grouped raster: 8 M-tiles x all N-tiles per group.
+__device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int tiles_n, int &tm,
+                                              int &tn) {
+  const int xcd = bid & 7, local = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  constexpr int GROUP_M = 8;
+  const int width = GROUP_M * tiles_n;
+  const int group = logical / width;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(tiles_m - first_m, GROUP_M);
+  const int in_group = logical - group * width;
+  tm = first_m + in_group % gsize;
+  tn = in_group / gsize;
+}
+
+
 }  // namespace cdml

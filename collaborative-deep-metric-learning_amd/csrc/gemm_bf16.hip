@@ -1,0 +1,483 @@
+// Reduced-precision variant of the tower for BASELINE config 4 ("fp16 features +
+// bf16 MFMA projection"): the same layers as gemm_f32.hip (models.py:59-60 and
+// their autodiff, train.py:141) with bf16 operands, fp32 accumulation
+// (v_mfma_f32_32x32x16_bf16) and fp32 master weights.  Build-defined precision --
+// the reference computes in fp32 -- so this path has its own, looser stated
+// tolerance (tests: 5e-3 on unit-norm embeddings) and is never the default.
+//
+// One GEMM form serves every layer: C[M][N] = A[M][K] . B[N][K]^T with BOTH
+// operands k-contiguous, which is what the bf16 MFMA fragment wants (8 consecutive
+// k per lane for A and for B).  Layers whose operands are k-strided in memory
+// (weight gradients: contraction over batch rows) get transposed bf16 copies from
+// k_transpose_bf16.  Roofline: MFMA (2.5 PFLOP/s dense bf16); tile 128x128x64,
+// 4 waves as 2x2, wave tile 64x64, register-staged double-buffered LDS with 144-B
+// rows (conflict-free ds_read_b128), split-K slabs for the skinny weight gradient.
+#include "common.h"
+
+namespace cdml {
+namespace {
+
+using bf16 = __bf16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kThreads = 256;
+constexpr int BM = 128, BN = 128, BKB = 64;
+constexpr int ROWB = BKB + 8;  // bf16 per LDS row: 144 B, banks 36r mod 64 -> conflict-free b128 reads
+
+enum { BE_BIAS_LRELU_BF16 = 0, BE_BIAS_LRELU_F32 = 1, BE_MASK_BF16 = 2, BE_F32 = 3 };
+
+struct BArgs {
+  const bf16 *A; int64_t lda;
+  const bf16 *B; int64_t ldb;
+  void *C; int64_t ldc;
+  const float *bias;
+  const bf16 *aux; int64_t ldaux;
+  float alpha;
+  int M, N, K;
+  int k_per_split;
+  int64_t slab_stride;
+  int tiles_m, tiles_n;
+};
+
+template <int EPI>
+__global__ void __launch_bounds__(kThreads, 2) k_gemm_bf16_nt(BArgs g) {
+  constexpr int A_TILE = BM * ROWB, B_TILE = BN * ROWB;          // bf16 elements
+  constexpr int STAGE_BYTES = (A_TILE + B_TILE) * 2;
+  constexpr int SMEM_BYTES = 2 * STAGE_BYTES > BM * BN * 4 ? 2 * STAGE_BYTES : BM * BN * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  bf16 *smem = reinterpret_cast<bf16 *>(smem_raw);
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int split = blockIdx.y;
+  const int k_begin = split * g.k_per_split;
+  const int k_end = min(g.K, k_begin + g.k_per_split);
+  const int n_ktiles = (k_end - k_begin + BKB - 1) / BKB;  // K and k_per_split are multiples of 64
+
+  struct Stage { bf16x8 a[4]; bf16x8 b[4]; };
+  auto load_tile = [&](int kt) {
+    Stage st;
+    const int k0 = k_begin + kt * BKB;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {  // 128 rows x 8 chunks of 16 B
+      const int row = p * 32 + (t >> 3), ch = t & 7;
+      st.a[p] = *reinterpret_cast<const bf16x8 *>(g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + k0 + ch * 8);
+      st.b[p] = *reinterpret_cast<const bf16x8 *>(g.B + (int64_t)(n0 + row) * g.ldb + k0 + ch * 8);
+    }
+    return st;
+  };
+  auto store_tile = [&](int buf, Stage st) {
+    bf16 *sA = smem + buf * (A_TILE + B_TILE);
+    bf16 *sB = sA + A_TILE;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = p * 32 + (t >> 3), ch = t & 7;
+      *reinterpret_cast<bf16x8 *>(sA + row * ROWB + ch * 8) = st.a[p];
+      *reinterpret_cast<bf16x8 *>(sB + row * ROWB + ch * 8) = st.b[p];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  Stage s0;
+  if (n_ktiles > 0) {
+    s0 = load_tile(0);
+    store_tile(0, s0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < n_ktiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < n_ktiles) s0 = load_tile(kt + 1);
+    const bf16 *sA = smem + buf * (A_TILE + B_TILE);
+    const bf16 *sB = sA + A_TILE;
+#pragma unroll
+    for (int kk = 0; kk < BKB / 16; ++kk) {  // lane (l31, h) holds k = 16*kk + 8*h + 0..7
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        a[mi] = *reinterpret_cast<const bf16x8 *>(sA + (wm * 64 + mi * 32 + l31) * ROWB + kk * 16 + 8 * h);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        b[ni] = *reinterpret_cast<const bf16x8 *>(sB + (wn * 64 + ni * 32 + l31) * ROWB + kk * 16 + 8 * h);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < n_ktiles) store_tile(buf ^ 1, s0);
+    __syncthreads();
+  }
+
+  // epilogue through an fp32 LDS C tile (C/D layout as in gemm_f32.hip)
+  float *sC = reinterpret_cast<float *>(smem_raw);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        sC[row * BN + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
+      }
+  __syncthreads();
+
+  const int c4 = t & 31, lr0 = t >> 5;  // 32 x 16-B segments per row, 8 rows per pass
+  const int col = n0 + c4 * 4;
+  f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
+  const bool has_aux = (EPI == BE_MASK_BF16) && g.aux != nullptr;
+#pragma unroll 4
+  for (int p = 0; p < BM / 8; ++p) {
+    const int lr = p * 8 + lr0;
+    const int row = m0 + lr;
+    if (row >= g.M) continue;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(sC + lr * BN + c4 * 4);
+    if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) {
+      v += bias4;
+      v.x = fmaxf(v.x, v.x * g.alpha); v.y = fmaxf(v.y, v.y * g.alpha);
+      v.z = fmaxf(v.z, v.z * g.alpha); v.w = fmaxf(v.w, v.w * g.alpha);
+    } else if (EPI == BE_MASK_BF16) {
+      if (has_aux) {
+        const bf16x4 m = *reinterpret_cast<const bf16x4 *>(g.aux + (int64_t)row * g.ldaux + col);
+        v.x *= ((float)m.x > 0.f) ? 1.f : g.alpha; v.y *= ((float)m.y > 0.f) ? 1.f : g.alpha;
+        v.z *= ((float)m.z > 0.f) ? 1.f : g.alpha; v.w *= ((float)m.w > 0.f) ? 1.f : g.alpha;
+      }
+    }
+    if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_MASK_BF16) {
+      bf16x4 o;
+      o.x = (bf16)v.x; o.y = (bf16)v.y; o.z = (bf16)v.z; o.w = (bf16)v.w;
+      *reinterpret_cast<bf16x4 *>(static_cast<bf16 *>(g.C) + (int64_t)row * g.ldc + col) = o;
+    } else {
+      float *C = static_cast<float *>(g.C) + (EPI == BE_F32 ? (int64_t)split * g.slab_stride : 0);
+      *reinterpret_cast<f32x4 *>(C + (int64_t)row * g.ldc + col) = v;
+    }
+  }
+}
+
+// out[c][r] = (bf16) in[r][c]; 64x64 tiles through LDS.  SRC = float or bf16.
+template <typename SRC>
+__global__ void __launch_bounds__(kThreads)
+k_transpose_bf16(const SRC *__restrict__ in, int64_t ldi, int rows, int cols, bf16 *__restrict__ out,
+                 int64_t ldo) {
+  __shared__ bf16 s[64][66];
+  const int t = threadIdx.x;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = t; i < 64 * 64; i += kThreads) {
+    const int r = i >> 6, c = i & 63;
+    const int gr = r0 + r, gc = c0 + c;
+    s[r][c] = (gr < rows && gc < cols) ? (bf16)(float)in[(int64_t)gr * ldi + gc] : (bf16)0.f;
+  }
+  __syncthreads();
+  for (int i = t; i < 64 * 64; i += kThreads) {
+    const int c = i >> 6, r = i & 63;
+    const int gr = r0 + r, gc = c0 + c;
+    if (gr < rows && gc < cols) out[(int64_t)gc * ldo + gr] = s[r][c];
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_cast_f32_bf16(const float *__restrict__ in, int64_t ldi, int rows, int cols, bf16 *__restrict__ out,
+                int64_t ldo) {
+  const int c4n = cols >> 2;
+  const int64_t total = (int64_t)rows * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(in + r * ldi + c);
+    bf16x4 o;
+    o.x = (bf16)v.x; o.y = (bf16)v.y; o.z = (bf16)v.z; o.w = (bf16)v.w;
+    *reinterpret_cast<bf16x4 *>(out + r * ldo + c) = o;
+  }
+}
+
+// column sums in two deterministic stages: partial[chunk][col] then the chunk sum
+template <typename SRC>
+__global__ void __launch_bounds__(kThreads)
+k_colsum_partial(const SRC *__restrict__ in, int64_t ld, int rows, int cols, int rows_per_chunk,
+                 float *__restrict__ partial) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  const int r_lo = blockIdx.y * rows_per_chunk, r_hi = min(rows, r_lo + rows_per_chunk);
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int r = r_lo; r < r_hi; ++r) s += (float)in[(int64_t)r * ld + c];
+  partial[(int64_t)blockIdx.y * cols + c] = s;
+}
+__global__ void __launch_bounds__(kThreads)
+k_colsum_final(const float *__restrict__ partial, int chunks, int cols, float *__restrict__ out) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * cols + c];
+  out[c] = s;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_sum_slabs_f32(const float *__restrict__ slabs, int64_t slab_stride, int splits, int rows, int N,
+                float *__restrict__ out, int64_t ldo) {
+  const int n4 = N >> 2;
+  const int64_t total = (int64_t)rows * n4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / n4;
+    const int c = (int)(i - r * n4);
+    f32x4 s = reinterpret_cast<const f32x4 *>(slabs)[i];
+    for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4 *>(slabs + (int64_t)z * slab_stride)[i];
+    reinterpret_cast<f32x4 *>(out + r * ldo)[c] = s;
+  }
+}
+
+// fp16 catalogue: Philox table (same stream as the fp32 one, rounded to half) and
+// the row gather: fp16 rows in, l2-normalised (fp32 arithmetic) bf16 rows out.
+__global__ void __launch_bounds__(kThreads)
+k_fill_table_f16(_Float16 *__restrict__ table, int64_t row0, int64_t n_rows, int F, int64_t row_stride,
+                 uint64_t seed) {
+  const int64_t q_per_row = row_stride >> 2;
+  const int64_t total = n_rows * q_per_row;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lr = i / q_per_row;
+    const int64_t q = i - lr * q_per_row;
+    const uint64_t r = (uint64_t)(row0 + lr);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t j = q * 4;
+    if (j < F) {
+      const u32x4 w = philox4x32_10(u32x4{(uint32_t)q, (uint32_t)r, (uint32_t)(r >> 32), kTableTag}, k0, k1);
+      const float s = 5.9604644775390625e-08f;
+      v[0] = (float)(w.x >> 8) * s;
+      if (j + 1 < F) v[1] = (float)(w.y >> 8) * s;
+      if (j + 2 < F) v[2] = (float)(w.z >> 8) * s;
+      if (j + 3 < F) v[3] = (float)(w.w >> 8) * s;
+    }
+    _Float16 *d = table + i * 4;
+    d[0] = (_Float16)v[0]; d[1] = (_Float16)v[1];
+    d[2] = (_Float16)v[2]; d[3] = (_Float16)v[3];
+  }
+}
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+template <int NCH>  // 16-B chunks (8 halfs) per lane
+__global__ void __launch_bounds__(kThreads)
+k_gather_rows_f16(const _Float16 *__restrict__ table, int64_t row0, int64_t n_rows, int64_t row_stride,
+                  const int32_t *__restrict__ idx, int n_idx, int F, bf16 *__restrict__ x_out,
+                  int64_t out_stride, int32_t *__restrict__ oob_flag) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nq = (F + 7) >> 3, oq = (int)(out_stride >> 3);
+  for (int r = blockIdx.x * 4 + wave; r < n_idx; r += gridDim.x * 4) {
+    int64_t lr = (int64_t)idx[r] - row0;
+    if (lr < 0 || lr >= n_rows) {
+      if (oob_flag) atomicOr(oob_flag, 1);
+      lr = lr < 0 ? 0 : n_rows - 1;
+    }
+    const half8 *src = reinterpret_cast<const half8 *>(table + lr * row_stride);
+    half8 v[NCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + 64 * c;
+      half8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < nq) x = src[q];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (8 * q + u >= F) x[u] = 0;           // never trust the pad
+        const float f = (float)x[u];
+        ss += f * f;
+      }
+      v[c] = x;
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    bf16x8 *d = reinterpret_cast<bf16x8 *>(x_out + (int64_t)r * out_stride);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + 64 * c;
+      if (q < oq) {
+        bf16x8 o;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = (bf16)((float)v[c][u] * inv);
+        d[q] = o;
+      }
+    }
+    for (int q = lane + 64 * NCH; q < oq; q += 64) d[q] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+}
+
+int bf16_splits(int M, int N, int K) {
+  const int64_t tiles = (int64_t)((M + BM - 1) / BM) * (N / BN);
+  int64_t splits = (480 + tiles - 1) / tiles;
+  const int64_t max_by_k = (K + 511) / 512;
+  if (splits > max_by_k) splits = max_by_k;
+  if (splits > 32) splits = 32;
+  return (int)(splits < 1 ? 1 : splits);
+}
+
+int grid1d(int64_t n, int per_thread) {
+  int64_t b = (n / per_thread + kThreads - 1) / kThreads;
+  if (b > kNumCU * 8) b = kNumCU * 8;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+}  // namespace cdml
+
+using namespace cdml;
+
+extern "C" size_t cdml_gemm_bf16_workspace(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || N % BN || K % BKB) return 0;
+  const int splits = bf16_splits(M, N, K);
+  return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda, const uint16_t *B,
+                                 int64_t ldb, int M, int N, int K, void *C, int64_t ldc,
+                                 const float *bias, const uint16_t *aux, int64_t ldaux, float alpha,
+                                 void *workspace, size_t workspace_bytes, cdml_stream_t stream) {
+  CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16_nt: bad argument");
+  CDML_REQUIRE(epilogue >= 0 && epilogue <= 3, CDML_E_BADARG, "gemm_bf16_nt: epilogue must be 0..3");
+  CDML_REQUIRE(N % BN == 0 && K % BKB == 0, CDML_E_UNSUPPORTED,
+               "gemm_bf16_nt: N must be a multiple of 128 and K of 64, got N=%d K=%d", N, K);
+  CDML_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && (lda & 7) == 0 && (ldb & 7) == 0 &&
+                   (ldc & 3) == 0 && lda >= K && ldb >= K && ldc >= N,
+               CDML_E_ALIGN, "gemm_bf16_nt: 16-B aligned bases, lda/ldb multiples of 8, ldc of 4");
+  CDML_REQUIRE(epilogue > 1 || bias, CDML_E_BADARG, "gemm_bf16_nt: bias required");
+  BArgs g{};
+  g.A = reinterpret_cast<const bf16 *>(A); g.lda = lda;
+  g.B = reinterpret_cast<const bf16 *>(B); g.ldb = ldb;
+  g.C = C; g.ldc = ldc; g.bias = bias;
+  g.aux = reinterpret_cast<const bf16 *>(aux); g.ldaux = ldaux; g.alpha = alpha;
+  g.M = M; g.N = N; g.K = K; g.k_per_split = K;
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = N / BN;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 block(kThreads);
+  int splits = 1;
+  if (epilogue == BE_F32) {
+    splits = bf16_splits(M, N, K);
+    if (splits > 1) {
+      const size_t need = (size_t)splits * M * N * sizeof(float);
+      CDML_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), CDML_E_BADARG,
+                   "gemm_bf16_nt: split-K workspace of %zu bytes required", need);
+      int kps = (K + splits - 1) / splits;
+      g.k_per_split = (kps + BKB - 1) / BKB * BKB;
+      g.slab_stride = (int64_t)M * N;
+      g.C = workspace; g.ldc = N;
+    }
+  }
+  const dim3 grid(g.tiles_m * g.tiles_n, splits);
+  switch (epilogue) {
+    case BE_BIAS_LRELU_BF16: hipLaunchKernelGGL((k_gemm_bf16_nt<BE_BIAS_LRELU_BF16>), grid, block, 0, s, g); break;
+    case BE_BIAS_LRELU_F32: hipLaunchKernelGGL((k_gemm_bf16_nt<BE_BIAS_LRELU_F32>), grid, block, 0, s, g); break;
+    case BE_MASK_BF16: hipLaunchKernelGGL((k_gemm_bf16_nt<BE_MASK_BF16>), grid, block, 0, s, g); break;
+    default: hipLaunchKernelGGL((k_gemm_bf16_nt<BE_F32>), grid, block, 0, s, g); break;
+  }
+  int rc = check_launch("gemm_bf16_nt");
+  if (rc || splits == 1) return rc;
+  hipLaunchKernelGGL(k_sum_slabs_f32, dim3(grid1d((int64_t)M * N / 4, 1)), block, 0, s,
+                     static_cast<const float *>(workspace), g.slab_stride, splits, M, N,
+                     static_cast<float *>(C), ldc);
+  return check_launch("gemm_bf16_nt combine");
+}
+
+extern "C" int cdml_transpose_to_bf16(int src_is_f32, const void *src, int64_t lds_, int rows, int cols,
+                                      uint16_t *dst, int64_t ldd, cdml_stream_t stream) {
+  CDML_REQUIRE(src && dst && rows > 0 && cols > 0 && lds_ >= cols && ldd >= rows, CDML_E_BADARG,
+               "transpose_to_bf16: bad argument");
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (src_is_f32)
+    hipLaunchKernelGGL((k_transpose_bf16<float>), grid, dim3(kThreads), 0, (hipStream_t)stream,
+                       static_cast<const float *>(src), lds_, rows, cols, reinterpret_cast<bf16 *>(dst), ldd);
+  else
+    hipLaunchKernelGGL((k_transpose_bf16<bf16>), grid, dim3(kThreads), 0, (hipStream_t)stream,
+                       static_cast<const bf16 *>(src), lds_, rows, cols, reinterpret_cast<bf16 *>(dst), ldd);
+  return check_launch("transpose_to_bf16");
+}
+
+extern "C" int cdml_cast_f32_bf16(const float *src, int64_t lds_, int rows, int cols, uint16_t *dst,
+                                  int64_t ldd, cdml_stream_t stream) {
+  CDML_REQUIRE(src && dst && rows > 0 && cols > 0, CDML_E_BADARG, "cast_f32_bf16: bad argument");
+  CDML_REQUIRE((cols & 3) == 0 && (lds_ & 3) == 0 && (ldd & 3) == 0 && aligned16(src) &&
+                   (reinterpret_cast<uintptr_t>(dst) & 7) == 0,
+               CDML_E_ALIGN, "cast_f32_bf16: widths and strides must be multiples of 4");
+  hipLaunchKernelGGL(k_cast_f32_bf16, dim3(grid1d((int64_t)rows * cols / 4, 1)), dim3(kThreads), 0,
+                     (hipStream_t)stream, src, lds_, rows, cols, reinterpret_cast<bf16 *>(dst), ldd);
+  return check_launch("cast_f32_bf16");
+}
+
+extern "C" size_t cdml_colsum_workspace_floats(int rows, int cols) {
+  const int chunks = rows >= 4096 ? 32 : (rows >= 256 ? 8 : 1);
+  return (size_t)chunks * cols;
+}
+
+extern "C" int cdml_colsum(int src_is_bf16, const void *src, int64_t ld, int rows, int cols, float *out,
+                           float *workspace, cdml_stream_t stream) {
+  CDML_REQUIRE(src && out && workspace && rows > 0 && cols > 0 && ld >= cols, CDML_E_BADARG,
+               "colsum: bad argument");
+  const int chunks = rows >= 4096 ? 32 : (rows >= 256 ? 8 : 1);
+  const int rpc = (rows + chunks - 1) / chunks;
+  const dim3 grid((cols + kThreads - 1) / kThreads, chunks);
+  hipStream_t s = (hipStream_t)stream;
+  if (src_is_bf16)
+    hipLaunchKernelGGL((k_colsum_partial<bf16>), grid, dim3(kThreads), 0, s, static_cast<const bf16 *>(src),
+                       ld, rows, cols, rpc, workspace);
+  else
+    hipLaunchKernelGGL((k_colsum_partial<float>), grid, dim3(kThreads), 0, s,
+                       static_cast<const float *>(src), ld, rows, cols, rpc, workspace);
+  hipLaunchKernelGGL(k_colsum_final, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads), 0, s, workspace,
+                     chunks, cols, out);
+  return check_launch("colsum");
+}
+
+extern "C" int cdml_fill_uniform_table_f16(uint16_t *table, int64_t row0, int64_t n_rows,
+                                           int feature_size, int64_t row_stride, uint64_t seed,
+                                           cdml_stream_t stream) {
+  CDML_REQUIRE(table && n_rows > 0 && feature_size > 0 && row0 >= 0, CDML_E_BADARG,
+               "fill_uniform_table_f16: bad argument");
+  CDML_REQUIRE(row_stride >= feature_size && (row_stride & 7) == 0 && aligned16(table), CDML_E_ALIGN,
+               "fill_uniform_table_f16: row_stride must be >= F and a multiple of 8");
+  hipLaunchKernelGGL(k_fill_table_f16, dim3(grid1d(n_rows * (row_stride >> 2), 1)), dim3(kThreads), 0,
+                     (hipStream_t)stream, reinterpret_cast<_Float16 *>(table), row0, n_rows, feature_size,
+                     row_stride, seed);
+  return check_launch("fill_uniform_table_f16");
+}
+
+extern "C" int cdml_gather_rows_f16(const uint16_t *table, int64_t row0, int64_t n_rows,
+                                    int64_t row_stride, const int32_t *idx, int n_idx, int F,
+                                    uint16_t *x_out_bf16, int64_t out_stride, int32_t *oob_flag,
+                                    cdml_stream_t stream) {
+  CDML_REQUIRE(table && idx && x_out_bf16 && n_rows > 0 && n_idx > 0 && row0 >= 0, CDML_E_BADARG,
+               "gather_rows_f16: bad argument");
+  CDML_REQUIRE(F > 0 && F <= 4096, CDML_E_UNSUPPORTED, "gather_rows_f16: feature size outside (0, 4096]");
+  CDML_REQUIRE(row_stride >= F && (row_stride & 7) == 0 && out_stride >= F && (out_stride & 7) == 0 &&
+                   aligned16(table) && aligned16(x_out_bf16),
+               CDML_E_ALIGN, "gather_rows_f16: strides must be >= F and multiples of 8, bases 16-B aligned");
+  int64_t blocks = ((int64_t)n_idx + 3) / 4;
+  if (blocks > kNumCU * 8) blocks = kNumCU * 8;
+  const int nch = ((F + 7) / 8 + 63) / 64;
+#define CDML_LAUNCH_GH(N)                                                                          \
+  hipLaunchKernelGGL(k_gather_rows_f16<N>, dim3((int)blocks), dim3(kThreads), 0, (hipStream_t)stream, \
+                     reinterpret_cast<const _Float16 *>(table), row0, n_rows, row_stride, idx, n_idx, F, \
+                     reinterpret_cast<bf16 *>(x_out_bf16), out_stride, oob_flag)
+  if (nch <= 1) CDML_LAUNCH_GH(1);
+  else if (nch <= 3) CDML_LAUNCH_GH(3);
+  else CDML_LAUNCH_GH(8);
+#undef CDML_LAUNCH_GH
+  return check_launch("gather_rows_f16");
+}

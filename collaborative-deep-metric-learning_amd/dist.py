@@ -49,8 +49,12 @@ def all_to_all(out, inp, out_splits=None, in_splits=None, group=None):
 
 
 def _hip_local_gather(table, ids, out):
-    """Owner side: gather + l2-normalise local rows with the HIP kernel."""
-    ops.gather_rows(table.data, table.row0, ids, table.feature_size, out, normalize=True)
+    """Owner side: gather + l2-normalise local rows with the HIP kernel (fp32 table ->
+    fp32 rows, fp16 table -> bf16 rows)."""
+    if table.data.dtype == torch.float16:
+        ops.gather_rows_f16(table.data, table.row0, ids, table.feature_size, out)
+    else:
+        ops.gather_rows(table.data, table.row0, ids, table.feature_size, out, normalize=True)
     return out
 
 
@@ -68,7 +72,8 @@ class RowExchange:
 
     def _scratch(self, name, shape, dtype, device):
         t = self._buf.get(name)
-        if t is None or t.shape[0] < shape[0] or t.shape[1:] != tuple(shape[1:]) or t.device != device:
+        if (t is None or t.shape[0] < shape[0] or t.shape[1:] != tuple(shape[1:]) or t.device != device
+                or t.dtype != dtype):
             t = torch.empty(shape, dtype=dtype, device=device)
             self._buf[name] = t
         return t[:shape[0]]
@@ -91,10 +96,10 @@ class RowExchange:
         req_ids = self._scratch("req_ids", (max(n_req, 1),), torch.int32, dev)[:n_req]
         all_to_all(req_ids, send_ids, rc, sc, self.group)
         stride = out.shape[1]
-        rows_out = self._scratch("rows_out", (max(n_req, 1), stride), torch.float32, out.device)[:n_req]
+        rows_out = self._scratch("rows_out", (max(n_req, 1), stride), out.dtype, out.device)[:n_req]
         if n_req:
             self.local_gather(table, req_ids, rows_out)
-        rows_in = self._scratch("rows_in", (ids.numel(), stride), torch.float32, out.device)
+        rows_in = self._scratch("rows_in", (ids.numel(), stride), out.dtype, out.device)
         all_to_all(rows_in, rows_out, sc, rc, self.group)
         inv = torch.empty_like(order)
         inv[order] = torch.arange(order.numel(), device=dev)
@@ -104,6 +109,8 @@ class RowExchange:
     def unpermute(self, rows_in, inv, out):
         """out[r] = rows_in[inv[r]] -- a row gather of the receive buffer."""
         if rows_in.is_cuda:
+            if rows_in.element_size() == 2:          # bf16 rows move as fp32 words (bitwise copy)
+                rows_in, out = rows_in.view(torch.float32), out.view(torch.float32)
             ops.gather_rows(rows_in, 0, inv.to(torch.int32), out.shape[1], out[:inv.numel()],
                             normalize=False)
         else:

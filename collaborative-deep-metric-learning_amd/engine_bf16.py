@@ -1,0 +1,110 @@
+"""Reduced-precision tower for BASELINE config 4: fp16 catalogue, bf16 MFMA
+projection, fp32 accumulation, fp32 master weights and optimizer.
+
+Build-defined precision (the reference computes in fp32): same layers and the
+same fp32 loss / normalisation kernels as ``engine``, but the four projection
+GEMMs and the data gradient run on ``v_mfma_f32_32x32x16_bf16`` through the one
+k-contiguous form ``C = A . B^T`` (``ops.gemm_bf16_nt``).  Operands that are
+k-strided in memory (the weight gradients contract over batch rows) are fed
+from transposed bf16 copies.  Tolerance stated in the tests: 5e-3 absolute on the
+unit-norm embeddings, 2e-2 on the loss.
+"""
+import torch
+
+from . import ops
+from .engine import FeatureTable, TowerLayout, round_up
+
+
+class FeatureTableF16(FeatureTable):
+    """fp16 catalogue shard [n_rows, row_stride] (3 KB rows at F=1500)."""
+
+    def __init__(self, data, feature_size, row0=0, n_rows_global=None):
+        if not data.is_cuda or data.dtype != torch.float16 or data.dim() != 2:
+            raise ValueError("FeatureTableF16 needs a 2-D fp16 device tensor")
+        self.data = data
+        self.feature_size = int(feature_size)
+        self.row0 = int(row0)
+        self.n_rows = data.shape[0]
+        self.n_rows_global = self.n_rows if n_rows_global is None else int(n_rows_global)
+
+    @classmethod
+    def from_numpy(cls, features, device, row0=0, n_rows_global=None):
+        import numpy as np
+        f = np.asarray(features, dtype=np.float16)
+        n, F = f.shape
+        data = torch.zeros((n, cls.padded_stride(F)), dtype=torch.float16, device=device)
+        data[:, :F] = torch.from_numpy(f).to(device)
+        return cls(data, F, row0, n_rows_global)
+
+    @classmethod
+    def synthetic(cls, n_rows, feature_size, seed, device, row0=0, n_rows_global=None):
+        data = torch.empty((n_rows, cls.padded_stride(feature_size)), dtype=torch.float16, device=device)
+        ops.fill_uniform_table_f16(data, row0, feature_size, seed)
+        return cls(data, feature_size, row0, n_rows_global)
+
+
+def layout_bf16(feature_size, hidden=5000, output_size=256):
+    """TowerLayout whose padded sizes satisfy the bf16 GEMM (N % 128, K % 64)."""
+    L = TowerLayout(feature_size, hidden, output_size)
+    if L.Dp % 128:
+        L.Dp = round_up(L.D, 128)
+        L.sizes = (L.Fp * L.Hp, L.Hp, L.Hp * L.Dp, L.Dp)
+        off = [0]
+        for n in L.sizes[:-1]:
+            off.append(off[-1] + n)
+        L.offsets = tuple(off)
+        L.numel = int(sum(L.sizes))
+    return L
+
+
+class TowerWorkspaceBF16:
+    def __init__(self, layout, n_rows, device):
+        L, R = layout, int(n_rows)
+        if R % 64:
+            raise ValueError("the bf16 path needs a row count that is a multiple of 64 (got %d)" % R)
+        self.layout, self.R = L, R
+        bf = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=device)
+        f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
+        self.x_hat, self.xT = bf(R, L.Fp), bf(L.Fp, R)
+        self.h1, self.h1T = bf(R, L.Hp), bf(L.Hp, R)
+        self.z, self.e, self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp)
+        self.dz2_bf, self.dz2T = bf(R, L.Dp), bf(L.Dp, R)
+        self.dz1, self.dz1T = bf(R, L.Hp), bf(L.Hp, R)
+        self.W1T, self.W2T, self.W2 = bf(L.Hp, L.Fp), bf(L.Dp, L.Hp), bf(L.Hp, L.Dp)
+        nb = max(ops.gemm_bf16_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_workspace(L.Fp, L.Hp, R), 16)
+        self.gemm_ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
+        self.colsum_ws = f32(max(ops.colsum_workspace_floats(R, L.Hp), ops.colsum_workspace_floats(R, L.Dp)))
+
+
+def refresh_weights(p, ws):
+    """bf16 operand copies of the fp32 master weights (after every optimizer step)."""
+    L = p.layout
+    ops.transpose_to_bf16(p.W1, ws.W1T, L.Fp, L.Hp)
+    ops.transpose_to_bf16(p.W2, ws.W2T, L.Hp, L.Dp)
+    ops.cast_f32_bf16(p.W2, ws.W2, L.Hp, L.Dp)
+
+
+def tower_forward(p, ws):
+    """x_hat (bf16, l2-normalised) -> h1 (bf16) -> z (fp32) -> e (fp32).  models.py:59-61."""
+    L, R = p.layout, ws.R
+    ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_BF16, ws.x_hat, ws.W1T, ws.h1, R, L.Hp, L.Fp, bias=p.b1)
+    ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_F32, ws.h1, ws.W2T, ws.z, R, L.Dp, L.Hp, bias=p.b2)
+    ops.l2norm_fwd(ws.z, L.Dp, ws.e)
+    return ws.e
+
+
+def tower_backward(p, ws):
+    """ws.de -> p.grad (fp32).  train.py:141; no dX."""
+    L, R = p.layout, ws.R
+    ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
+    ops.colsum(ws.dz2, R, L.Dp, p.gb2, ws.colsum_ws)
+    ops.cast_f32_bf16(ws.dz2, ws.dz2_bf, R, L.Dp)
+    ops.transpose_to_bf16(ws.dz2, ws.dz2T, R, L.Dp)
+    ops.transpose_to_bf16(ws.h1, ws.h1T, R, L.Hp)
+    ops.gemm_bf16_nt(ops.BE_F32, ws.h1T, ws.dz2T, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
+    ops.gemm_bf16_nt(ops.BE_MASK_BF16, ws.dz2_bf, ws.W2, ws.dz1, R, L.Hp, L.Dp, aux=ws.h1)
+    ops.colsum(ws.dz1, R, L.Hp, p.gb1, ws.colsum_ws)
+    ops.transpose_to_bf16(ws.dz1, ws.dz1T, R, L.Hp)
+    ops.transpose_to_bf16(ws.x_hat, ws.xT, R, L.Fp)
+    ops.gemm_bf16_nt(ops.BE_F32, ws.xT, ws.dz1T, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws)
+    return p.grad

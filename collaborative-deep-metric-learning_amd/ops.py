@@ -175,6 +175,67 @@ def pair_dist(e, pairs, D, sqdist, dot, means=None):
          _p(dot), _p(means), _stream())
 
 
+# ------------------------------------------- reduced precision (config 4) -----
+BE_BIAS_LRELU_BF16, BE_BIAS_LRELU_F32, BE_MASK_BF16, BE_F32 = 0, 1, 2, 3
+
+
+def _mat16(t):
+    if t.dim() != 2 or t.stride(1) != 1 or t.element_size() != 2:
+        raise ValueError("expected a 2-D 16-bit tensor with unit inner stride")
+    return _p(t), t.stride(0)
+
+
+def gemm_bf16_workspace(M, N, K):
+    return int(load_library().cdml_gemm_bf16_workspace(M, N, K))
+
+
+def gemm_bf16_nt(epilogue, A, B, C, M, N, K, bias=None, aux=None, alpha=LRELU_ALPHA, workspace=None):
+    ap, ald = _mat16(A)
+    bp, bld = _mat16(B)
+    if C.dim() != 2 or C.stride(1) != 1:
+        raise ValueError("C must be 2-D with unit inner stride")
+    xld = aux.stride(0) if aux is not None else 0
+    call("cdml_gemm_bf16_nt", epilogue, ap, ald, bp, bld, M, N, K, _p(C), C.stride(0), _p(bias),
+         _p(aux), xld, alpha, _p(workspace), 0 if workspace is None else workspace.numel() * workspace.element_size(),
+         _stream())
+    return C
+
+
+def transpose_to_bf16(src, dst, rows, cols):
+    call("cdml_transpose_to_bf16", 1 if src.dtype == torch.float32 else 0, _p(src), src.stride(0), rows, cols,
+         _p(dst, torch.bfloat16), dst.stride(0), _stream())
+    return dst
+
+
+def cast_f32_bf16(src, dst, rows, cols):
+    call("cdml_cast_f32_bf16", _p(src, torch.float32), src.stride(0), rows, cols, _p(dst, torch.bfloat16),
+         dst.stride(0), _stream())
+    return dst
+
+
+def colsum_workspace_floats(rows, cols):
+    return int(load_library().cdml_colsum_workspace_floats(rows, cols))
+
+
+def colsum(src, rows, cols, out, workspace):
+    call("cdml_colsum", 1 if src.dtype == torch.bfloat16 else 0, _p(src), src.stride(0), rows, cols,
+         _p(out, torch.float32), _p(workspace, torch.float32), _stream())
+    return out
+
+
+def fill_uniform_table_f16(table, row0, feature_size, seed):
+    call("cdml_fill_uniform_table_f16", _p(table, torch.float16), row0, table.shape[0], feature_size,
+         table.stride(0), seed, _stream())
+    return table
+
+
+def gather_rows_f16(table, row0, idx, feature_size, x_out, oob_flag=None):
+    call("cdml_gather_rows_f16", _p(table, torch.float16), row0, table.shape[0], table.stride(0),
+         _p(idx, torch.int32), idx.numel(), feature_size, _p(x_out, torch.bfloat16), x_out.stride(0),
+         _p(oob_flag, torch.int32), _stream())
+    return x_out
+
+
 # ------------------------------------------------------------- optimizers -----
 def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, t_dev=None):
     call("cdml_adam_step", _p(w), _p(g), _p(m), _p(v), w.numel(), lr, _p(lr_dev), beta1, beta2, eps,

@@ -20,7 +20,7 @@ import time
 
 import torch
 
-from . import engine, ops
+from . import engine, engine_bf16, ops
 from .inputs import MODE_INBATCH, MODE_UNIFORM
 
 # sampler mode per negative policy: "semihard" samples like "inbatch" (rows a_i, p_i)
@@ -42,7 +42,7 @@ class TrainStep:
                  base_learning_rate=0.01, learning_rate_decay_examples=1000000,
                  learning_rate_decay=0.96, seed=1234, weight_seed=42, device="cuda:0",
                  exchange=None, grad_sync=None, slot0=0, batch_global=None, use_graph=False,
-                 prefetch=True):
+                 prefetch=True, precision="f32"):
         """table: FeatureTable (whole catalogue, or this rank's shard when
         ``exchange`` is given); pairs: int32 [P,2] device tensor; ``exchange`` /
         ``grad_sync``: the multi-GPU hooks of cdml_amd.dist (None on one GPU)."""
@@ -66,9 +66,20 @@ class TrainStep:
         self.slot0 = int(slot0)
         self.batch_global = self.B if batch_global is None else int(batch_global)
         F = table.feature_size if feature_size is None else feature_size
-        self.layout = engine.TowerLayout(F, hidden_size, output_size)
-        self.params = engine.VNetParams(self.layout, self.device, weight_seed)
-        self.ws = engine.TowerWorkspace(self.layout, self.R, self.device)
+        if precision not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        self.bf16 = precision == "bf16"          # BASELINE config 4: fp16 table + bf16 MFMA
+        if self.bf16 != (table.data.dtype == torch.float16):
+            raise ValueError("precision 'bf16' goes with an fp16 FeatureTableF16, 'f32' with an fp32 table")
+        if self.bf16:
+            self.layout = engine_bf16.layout_bf16(F, hidden_size, output_size)
+            self.params = engine.VNetParams(self.layout, self.device, weight_seed)
+            self.ws = engine_bf16.TowerWorkspaceBF16(self.layout, self.R, self.device)
+            engine_bf16.refresh_weights(self.params, self.ws)
+        else:
+            self.layout = engine.TowerLayout(F, hidden_size, output_size)
+            self.params = engine.VNetParams(self.layout, self.device, weight_seed)
+            self.ws = engine.TowerWorkspace(self.layout, self.R, self.device)
         dev, i32, f32 = self.device, torch.int32, torch.float32
         self.idx = torch.zeros(self.R, dtype=i32, device=dev)       # [B,3] or [2B] video ids
         self.shift = torch.zeros(1, dtype=i32, device=dev)
@@ -130,6 +141,16 @@ class TrainStep:
             self.prefetch.acquire(b)
             self.ws.x_hat, self.idx, self.shift = self._x[b], self._idx[b], self._shift[b]
             return
+        if self.exchange is None and self.bf16:
+            if m == MODE_UNIFORM:
+                ops.sample_uniform(self.pairs, self.table.n_rows_global, self.seed, None, self.B, self.idx,
+                                   slot0=self.slot0, batch_global=self.batch_global, step_dev=self.step_dev)
+            else:
+                ops.sample_inbatch(self.pairs, self.seed, None, self.B, self.idx, self.shift,
+                                   slot0=self.slot0, batch_global=self.batch_global, step_dev=self.step_dev)
+            ops.gather_rows_f16(self.table.data, self.table.row0, self.idx, self.table.feature_size,
+                                self.ws.x_hat)
+            return
         if self.exchange is None:
             ops.sample_gather(m, self.pairs, self.seed, None, self.B, self.table.data,
                               self.table.feature_size, self.idx, self.ws.x_hat,
@@ -147,7 +168,10 @@ class TrainStep:
             self.exchange.gather(self.table, self.idx, self.ws.x_hat)
 
     def forward_loss(self, with_grad=True):
-        engine.tower_forward(self.params, self.ws)
+        if self.bf16:
+            engine_bf16.tower_forward(self.params, self.ws)
+        else:
+            engine.tower_forward(self.params, self.ws)
         L = self.layout
         de = self.ws.de if with_grad else None
         if self.mode == "uniform":
@@ -165,7 +189,10 @@ class TrainStep:
                                       self.pos, self.neg, self.hinge, self.valid, self.stats, de)
 
     def backward(self):
-        engine.tower_backward(self.params, self.ws)
+        if self.bf16:
+            engine_bf16.tower_backward(self.params, self.ws)
+        else:
+            engine.tower_backward(self.params, self.ws)
 
     def apply_gradients(self):
         p = self.params
@@ -176,6 +203,8 @@ class TrainStep:
             for off, n in p.segments():       # LARS trust ratio is per variable
                 ops.lars_step(p.flat[off:off + n], p.grad[off:off + n], self.acc[off:off + n],
                               0.0, self.lars_scratch, lr_dev=self.lr_dev)
+        if self.bf16:
+            engine_bf16.refresh_weights(p, self.ws)
         ops.step_advance(self.step_dev)
 
     def _enqueue(self):

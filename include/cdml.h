@@ -202,6 +202,48 @@ int cdml_pair_dist(const float *e, int64_t lde, int n_rows, const int32_t *pairs
                    int P, int D, float *sqdist, float *dot, float *means,
                    cdml_stream_t stream);
 
+/* ---- reduced-precision tower (BASELINE config 4: fp16 catalogue + bf16 MFMA
+ * projection; build-defined precision with its own tolerance, never the default).
+ * bf16 / fp16 buffers are passed as uint16_t*.  Same layers as the fp32 entry
+ * points (models.py:59-60, train.py:141), fp32 accumulation and master weights. --
+ * C[M][N] = epilogue(A[M][K] . B[N][K]^T), both operands k-contiguous bf16.
+ *   epilogue 0: C bf16 = lrelu(acc + bias[n], alpha)          (FC forward, hidden layer)
+ *            1: C f32  = lrelu(acc + bias[n], alpha)          (FC forward, output layer)
+ *            2: C bf16 = acc * (aux[m][n] > 0 ? 1 : alpha)    (data gradient * lrelu'; aux NULL = none)
+ *            3: C f32  = acc, deterministic split-K (workspace of cdml_gemm_bf16_workspace bytes)
+ * N % 128 == 0, K % 64 == 0, any M >= 1. */
+size_t cdml_gemm_bf16_workspace(int M, int N, int K);
+int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda,
+                      const uint16_t *B, int64_t ldb, int M, int N, int K, void *C,
+                      int64_t ldc, const float *bias, const uint16_t *aux,
+                      int64_t ldaux, float alpha, void *workspace,
+                      size_t workspace_bytes, cdml_stream_t stream);
+
+/* dst[c][r] = bf16(src[r][c]) (src fp32 or bf16): k-contiguous copies of weights
+ * and of activations for the weight-gradient GEMMs (contraction over batch rows). */
+int cdml_transpose_to_bf16(int src_is_f32, const void *src, int64_t ld_src,
+                           int rows, int cols, uint16_t *dst, int64_t ld_dst,
+                           cdml_stream_t stream);
+int cdml_cast_f32_bf16(const float *src, int64_t ld_src, int rows, int cols,
+                       uint16_t *dst, int64_t ld_dst, cdml_stream_t stream);
+
+/* out[c] = sum_r src[r][c] (bias gradients), two fixed-order stages;
+ * workspace: cdml_colsum_workspace_floats(rows, cols) floats. */
+size_t cdml_colsum_workspace_floats(int rows, int cols);
+int cdml_colsum(int src_is_bf16, const void *src, int64_t ld, int rows, int cols,
+                float *out, float *workspace, cdml_stream_t stream);
+
+/* fp16 catalogue: the Philox table of cdml_fill_uniform_table rounded to half, and
+ * the gather of inputs.py:158 + models.py:58 reading fp16 rows and writing
+ * l2-normalised (fp32 arithmetic) bf16 rows. */
+int cdml_fill_uniform_table_f16(uint16_t *table, int64_t row0, int64_t n_rows,
+                                int feature_size, int64_t row_stride,
+                                uint64_t seed, cdml_stream_t stream);
+int cdml_gather_rows_f16(const uint16_t *table, int64_t row0, int64_t n_rows,
+                         int64_t row_stride, const int32_t *idx, int n_idx, int F,
+                         uint16_t *x_out_bf16, int64_t out_stride,
+                         int32_t *oob_flag, cdml_stream_t stream);
+
 /* ---- optimizers (train.py:108-125,146) --------------------------------------
  * Adam, TensorFlow form (epsilon outside the bias correction):
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m=b1*m+(1-b1)*g; v=b2*v+(1-b2)*g*g;

@@ -1,0 +1,166 @@
+"""BASELINE config 4 path: fp16 catalogue + bf16 MFMA projection (build-defined
+precision; the reference computes in fp32).  Kernel-level checks are exact-ish
+(bf16 products are exact in fp32; only the summation order differs); the
+end-to-end tolerance this path claims is 5e-3 absolute on unit-norm embeddings
+and 2e-2 on the loss against the fp64 oracle run on the same fp16-rounded
+features and fp32 master weights."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sampler as osampler, synth as osynth, tower as otower
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cd(gpu):
+    import cdml_amd
+    from cdml_amd import engine, engine_bf16, ops, train
+
+    class NS:
+        pass
+    ns = NS()
+    ns.dev, ns.engine, ns.ebf, ns.ops, ns.train, ns.pkg = gpu, engine, engine_bf16, ops, train, cdml_amd
+    return ns
+
+
+def bf(x):
+    """Round to bf16 and come back (what the kernels see), as float64."""
+    return torch.as_tensor(np.asarray(x, np.float32)).bfloat16().float().numpy().astype(np.float64)
+
+
+def dbf(x, dev):
+    return torch.as_tensor(np.asarray(x, np.float32)).to(dev).bfloat16()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 192), (384, 5120, 1536), (77, 128, 5120)])
+def test_gemm_bf16_epilogues(cd, M, N, K):
+    rng = np.random.RandomState(M + N)
+    A, B = rng.randn(M, K) / np.sqrt(K), rng.randn(N, K)
+    bias, aux = rng.randn(N) * 0.1, rng.randn(M, N)
+    ref = bf(A) @ bf(B).T
+    dA, dB = dbf(A, cd.dev), dbf(B, cd.dev)
+    dbias = torch.as_tensor(bias, dtype=torch.float32).to(cd.dev)
+    lrelu = lambda v: np.maximum(v, 0.2 * v)
+    tol = dict(atol=2e-5 * np.sqrt(K / 64), rtol=0)
+    out = torch.empty((M, N), dtype=torch.float32, device=cd.dev)
+    cd.ops.gemm_bf16_nt(cd.ops.BE_BIAS_LRELU_F32, dA, dB, out, M, N, K, bias=dbias)
+    want = lrelu(ref + bias.astype(np.float32))
+    np.testing.assert_allclose(out.cpu().numpy(), want, **tol)
+    outb = torch.empty((M, N), dtype=torch.bfloat16, device=cd.dev)
+    cd.ops.gemm_bf16_nt(cd.ops.BE_BIAS_LRELU_BF16, dA, dB, outb, M, N, K, bias=dbias)
+    np.testing.assert_allclose(outb.float().cpu().numpy(), want, rtol=2 ** -8, atol=1e-4)
+    daux = dbf(aux, cd.dev)
+    cd.ops.gemm_bf16_nt(cd.ops.BE_MASK_BF16, dA, dB, outb, M, N, K, aux=daux)
+    want_m = ref * np.where(bf(aux) > 0, 1.0, 0.2)
+    np.testing.assert_allclose(outb.float().cpu().numpy(), want_m, rtol=2 ** -8, atol=1e-4)
+    ws = torch.empty(max(cd.ops.gemm_bf16_workspace(M, N, K), 16) // 4, device=cd.dev)
+    cd.ops.gemm_bf16_nt(cd.ops.BE_F32, dA, dB, out, M, N, K, workspace=ws)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, **tol)
+    out2 = torch.empty_like(out)
+    cd.ops.gemm_bf16_nt(cd.ops.BE_F32, dA, dB, out2, M, N, K, workspace=ws)
+    assert torch.equal(out, out2)                                  # deterministic split-K
+
+
+def test_gemm_bf16_identity_asymmetric_and_errors(cd):
+    K = N = 128
+    Bm = (np.arange(N * K).reshape(N, K) % 251 - 100).astype(np.float64)     # exact in bf16
+    out = torch.empty((K, N), dtype=torch.float32, device=cd.dev)
+    cd.ops.gemm_bf16_nt(cd.ops.BE_F32, dbf(np.eye(K), cd.dev), dbf(Bm, cd.dev), out, K, N, K)
+    np.testing.assert_array_equal(out.cpu().numpy(), Bm.T)                   # C = I . B^T
+    with pytest.raises(cd.pkg.CdmlError):
+        cd.ops.gemm_bf16_nt(cd.ops.BE_F32, dbf(np.eye(64), cd.dev), dbf(np.eye(64), cd.dev),
+                            torch.empty((64, 64), device=cd.dev), 64, 64, 64)      # N % 128
+
+
+def test_transpose_cast_colsum(cd):
+    rng = np.random.RandomState(0)
+    x = rng.randn(300, 200).astype(np.float32)
+    dx = torch.as_tensor(x).to(cd.dev)
+    t = torch.zeros((200, 304), dtype=torch.bfloat16, device=cd.dev)
+    cd.ops.transpose_to_bf16(dx, t, 300, 200)
+    np.testing.assert_array_equal(t[:, :300].float().cpu().numpy(), bf(x).T)
+    t2 = torch.zeros((300, 200), dtype=torch.bfloat16, device=cd.dev)
+    cd.ops.transpose_to_bf16(t[:, :300], t2, 200, 300)                     # bf16 source
+    np.testing.assert_array_equal(t2.float().cpu().numpy(), bf(x))
+    c = torch.zeros((300, 200), dtype=torch.bfloat16, device=cd.dev)
+    cd.ops.cast_f32_bf16(dx, c, 300, 200)
+    np.testing.assert_array_equal(c.float().cpu().numpy(), bf(x))
+    for src, ref in ((dx, x.astype(np.float64)), (c, bf(x))):
+        out = torch.empty(200, device=cd.dev)
+        ws = torch.empty(cd.ops.colsum_workspace_floats(300, 200), device=cd.dev)
+        cd.ops.colsum(src, 300, 200, out, ws)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.sum(0), atol=1e-4)
+
+
+def test_fp16_table_and_gather(cd):
+    N, F = 500, 1500
+    table = cd.ebf.FeatureTableF16.synthetic(N, F, 3, cd.dev)
+    want_tab = osynth.features_philox(0, N, F, 3).astype(np.float16)
+    np.testing.assert_array_equal(table.data[:, :F].cpu().numpy(), want_tab)
+    assert float(table.data[:, F:].abs().max()) == 0
+    idx = np.random.RandomState(0).randint(0, N, size=130).astype(np.int32)
+    x = torch.full((130, 1536), 7.0, dtype=torch.bfloat16, device=cd.dev)
+    cd.ops.gather_rows_f16(table.data, 0, torch.as_tensor(idx).to(cd.dev), F, x)
+    want = otower.l2_normalize(want_tab[idx].astype(np.float64), np.float64)[0]
+    np.testing.assert_allclose(x[:, :F].float().cpu().numpy(), want, rtol=2 ** -8, atol=1e-6)
+    assert float(x[:, F:].float().abs().max()) == 0
+
+
+@pytest.mark.parametrize("mode", ["uniform", "inbatch"])
+def test_train_step_bf16_config4_precision(cd, mode):
+    """fp16 table + bf16 MFMA step vs the fp64 oracle on the same fp16 features."""
+    N, F, B, D = 8000, 1500, 128, 256
+    feats16 = osynth.features_numpy(N, F, seed=0).astype(np.float16)
+    pairs = osynth.cowatch_pairs(N, 2500, 0)
+    table = cd.ebf.FeatureTableF16.from_numpy(feats16, cd.dev)
+    ts = cd.train.TrainStep(table, torch.as_tensor(pairs).to(cd.dev), B, mode=mode, precision="bf16",
+                            device=cd.dev)
+    W = [t.detach().cpu().numpy().astype(np.float64) for t in ts.params.unpadded()]
+    ts.fetch(); ts.forward_loss(); ts.backward()
+    torch.cuda.synchronize()
+    f64 = feats16.astype(np.float64)
+    if mode == "uniform":
+        idx = osampler.device_triplets_vec(pairs, N, 1234, 0, B)
+        np.testing.assert_array_equal(ts.idx.view(B, 3).cpu().numpy(), idx)
+        fwd, loss, grads = otower.train_step_grads(f64[idx.reshape(-1)], W, 0.8, np.float64)
+    else:
+        rows, tri, valid, _ = osampler.device_inbatch(pairs, 1234, 0, B)
+        fwd = otower.vnet_forward(f64[rows], *W, dtype=np.float64)
+        loss = otower.hinge_loss_indexed(fwd["l2_norm"], tri, valid.astype(bool), 0.8, np.float64)
+        dE = otower.hinge_loss_indexed_backward(fwd["l2_norm"], tri, valid.astype(bool), 0.8, np.float64)
+        grads = otower.vnet_backward(fwd, W[2], dE, np.float64)
+    e = ts.ws.e[:, :D].cpu().numpy()
+    assert np.abs(e - fwd["l2_norm"]).max() < 5e-3                       # stated tolerance of this path
+    assert abs(ts.loss() - float(loss["hinge_loss"])) < 2e-2
+    np.testing.assert_allclose(np.linalg.norm(e, axis=1), 1.0, atol=1e-5)  # normalisation itself is fp32
+    for got, k in zip(ts.params.unpadded(grads=True), ("dW1", "db1", "dW2", "db2")):
+        g, w = got.cpu().numpy().astype(np.float64).ravel(), grads[k].ravel()
+        cos = g @ w / (np.linalg.norm(g) * np.linalg.norm(w) + 1e-30)
+        assert cos > 0.98, (k, cos)
+    for _ in range(2):
+        ts.step()
+    assert np.isfinite(ts.loss())
+    with pytest.raises(ValueError):
+        cd.train.TrainStep(table, torch.as_tensor(pairs).to(cd.dev), B, precision="f32", device=cd.dev)
+
+
+def test_bf16_training_learns(cd):
+    rng = np.random.RandomState(0)
+    centers = rng.random_sample((10, 64))
+    cid = rng.randint(0, 10, size=2000)
+    feats = (centers[cid] + 0.05 * rng.randn(2000, 64)).clip(0, None).astype(np.float16)
+    a = rng.randint(0, 2000, size=6000)
+    p = np.array([rng.choice(np.flatnonzero(cid == cid[i])) for i in a])
+    pairs = np.stack([a, p], 1)
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]].astype(np.int32)
+    table = cd.ebf.FeatureTableF16.from_numpy(feats, cd.dev)
+    ts = cd.train.TrainStep(table, torch.as_tensor(pairs).to(cd.dev), 64, hidden_size=128, output_size=32,
+                            mode="uniform", base_learning_rate=0.002, precision="bf16", device=cd.dev)
+    losses = []
+    for _ in range(150):
+        ts.step()
+        if ts.global_step == 1 or ts.global_step % 25 == 0:
+            losses.append(ts.loss())
+    assert max(losses[2:]) < 0.5 * losses[0], losses        # from ~margin down, and it stays down
