@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--mode", default="inbatch", choices=["inbatch", "uniform", "semihard"])
     ap.add_argument("--batch", type=int, default=BATCH, help="triplets per GPU per step")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="bf16 = BASELINE config 4 path (fp16 table + bf16 MFMA); not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
@@ -162,7 +164,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    from cdml_amd import dist as cdist, engine, ops, train
+    from cdml_amd import dist as cdist, engine, engine_bf16, ops, train
+    Table = engine_bf16.FeatureTableF16 if args.precision == "bf16" else engine.FeatureTable
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -175,22 +178,22 @@ def main():
     B = args.batch
     if world > 1:
         lo, hi, _ = cdist.shard_bounds(n_rows, world, rank)
-        table = engine.FeatureTable.synthetic(hi - lo, F, seed=0, device=dev, row0=lo, n_rows_global=n_rows)
+        table = Table.synthetic(hi - lo, F, seed=0, device=dev, row0=lo, n_rows_global=n_rows)
         # own communicator for the exchange so it never queues behind the gradient all-reduce
         exchange, grad_sync = cdist.RowExchange(n_rows, group=dist.new_group()), cdist.GradSync()
     else:
-        table = engine.FeatureTable.synthetic(n_rows, F, seed=0, device=dev)
+        table = Table.synthetic(n_rows, F, seed=0, device=dev)
         exchange = grad_sync = None
     pairs = torch.from_numpy(synth_pairs(n_rows, max(n_rows // 3, 1000), seed=0)).to(dev)
 
     ts = train.TrainStep(table, pairs, B, output_size=D, hidden_size=H, margin=MARGIN, mode=args.mode,
                          optimizer="adam", base_learning_rate=0.01, seed=1234, weight_seed=42,
                          device=dev, exchange=exchange, grad_sync=grad_sync, slot0=rank * B,
-                         batch_global=world * B, use_graph=args.graph)
+                         batch_global=world * B, use_graph=args.graph, precision=args.precision)
 
     # per-kernel event timers on the launch stream (off during graph replay)
     kt = KernelTimer()
-    timers_on = not args.no_kernel_timers and not args.graph
+    timers_on = not args.no_kernel_timers and not args.graph and args.precision == "f32"
     if timers_on:
         real_fwd, real_bww = ops.fc_lrelu_fwd, ops.fc_bwd_weight
         L = ts.layout
@@ -242,7 +245,8 @@ def main():
             "metric": "triplets/sec", "value": round(world * B * args.steps / elapsed, 1),
             "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16 (fp16 table, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "config1: %d videos x %d-d fp32 in HBM, %d hidden, %d-d embed, "
                                    "batch %d triplets/GPU, %s negatives, margin %.1f, Adam, full step "
                                    "(sample+gather+fwd+loss+bwd+opt)"

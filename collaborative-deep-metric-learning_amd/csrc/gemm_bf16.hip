@@ -208,17 +208,33 @@ k_cast_f32_bf16(const float *__restrict__ in, int64_t ldi, int rows, int cols, b
   }
 }
 
-// column sums in two deterministic stages: partial[chunk][col] then the chunk sum
+// column sums in two deterministic stages: partial[chunk][col] then the chunk sum.
+// A block covers 128 columns x one row chunk: 32 four-column lanes x 8 row lanes,
+// each thread strides the rows by 8 with 4-wide loads, then the 8 row lanes are
+// combined through LDS in a fixed order.
+__device__ __forceinline__ f32x4 load4f(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ f32x4 load4f(const bf16 *p) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4 *>(p);
+  return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w};
+}
 template <typename SRC>
 __global__ void __launch_bounds__(kThreads)
 k_colsum_partial(const SRC *__restrict__ in, int64_t ld, int rows, int cols, int rows_per_chunk,
                  float *__restrict__ partial) {
-  const int c = blockIdx.x * kThreads + threadIdx.x;
+  __shared__ f32x4 red[8][32];
+  const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 128 + c4 * 4;
   const int r_lo = blockIdx.y * rows_per_chunk, r_hi = min(rows, r_lo + rows_per_chunk);
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int r = r_lo; r < r_hi; ++r) s += (float)in[(int64_t)r * ld + c];
-  partial[(int64_t)blockIdx.y * cols + c] = s;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c < cols)
+    for (int r = r_lo + rl; r < r_hi; r += 8) s += load4f(in + (int64_t)r * ld + c);
+  red[rl][c4] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+#pragma unroll
+    for (int j = 1; j < 8; ++j) s += red[j][c4];
+    *reinterpret_cast<f32x4 *>(partial + (int64_t)blockIdx.y * cols + c) = s;
+  }
 }
 __global__ void __launch_bounds__(kThreads)
 k_colsum_final(const float *__restrict__ partial, int chunks, int cols, float *__restrict__ out) {
@@ -421,18 +437,31 @@ extern "C" int cdml_cast_f32_bf16(const float *src, int64_t lds_, int rows, int 
   return check_launch("cast_f32_bf16");
 }
 
+// enough row chunks to fill the chip (~1024 blocks), at least 64 rows each, at most
+// 64 chunks so the final pass stays short
+static int colsum_chunks(int rows, int cols) {
+  const int gx = (cols + 127) / 128;
+  int chunks = (1024 + gx - 1) / gx;
+  const int max_chunks = (rows + 63) / 64;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks > 64) chunks = 64;
+  return chunks < 1 ? 1 : chunks;
+}
+
 extern "C" size_t cdml_colsum_workspace_floats(int rows, int cols) {
-  const int chunks = rows >= 4096 ? 32 : (rows >= 256 ? 8 : 1);
-  return (size_t)chunks * cols;
+  if (rows <= 0 || cols <= 0) return 0;
+  return (size_t)colsum_chunks(rows, cols) * cols;
 }
 
 extern "C" int cdml_colsum(int src_is_bf16, const void *src, int64_t ld, int rows, int cols, float *out,
                            float *workspace, cdml_stream_t stream) {
   CDML_REQUIRE(src && out && workspace && rows > 0 && cols > 0 && ld >= cols, CDML_E_BADARG,
                "colsum: bad argument");
-  const int chunks = rows >= 4096 ? 32 : (rows >= 256 ? 8 : 1);
+  CDML_REQUIRE((cols & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0, CDML_E_ALIGN,
+               "colsum: cols and ld must be multiples of 4, base 16-B aligned");
+  const int chunks = colsum_chunks(rows, cols);
   const int rpc = (rows + chunks - 1) / chunks;
-  const dim3 grid((cols + kThreads - 1) / kThreads, chunks);
+  const dim3 grid((cols + 127) / 128, chunks);
   hipStream_t s = (hipStream_t)stream;
   if (src_is_bf16)
     hipLaunchKernelGGL((k_colsum_partial<bf16>), grid, dim3(kThreads), 0, s, static_cast<const bf16 *>(src),
