@@ -125,6 +125,24 @@ class GradSync:
         self.world = dist.get_world_size(group)
         self.avg = dist.get_backend(group) == "nccl"
 
+    def start(self, flat_grad, lo, hi):
+        """Begin averaging flat_grad[lo:hi]; with RCCL the collective is asynchronous
+        (it runs on the communicator's stream behind everything enqueued so far and
+        overlaps whatever the compute stream does next).  Returns a handle for finish."""
+        seg = flat_grad[lo:hi]
+        if self.world == 1:
+            return None
+        if self.avg:
+            return dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        self(seg)                                    # gloo: synchronous, host-staged
+        return None
+
+    def finish(self, handles):
+        """Make the compute stream wait for the started collectives."""
+        for h in handles:
+            if h is not None:
+                h.wait()
+
     def __call__(self, flat_grad):
         if self.world == 1:
             return flat_grad

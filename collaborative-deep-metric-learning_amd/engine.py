@@ -161,13 +161,17 @@ def tower_forward(p, ws, n_rows=None):
     return ws.e
 
 
-def tower_backward(p, ws, n_rows=None):
+def tower_backward(p, ws, n_rows=None, after_w1=None):
     """ws.de (grad wrt e) -> p.grad (dW1, db1, dW2, db2).  No dX: the features are
-    inputs, not variables (train.py:265)."""
+    inputs, not variables (train.py:265).  The first layer's gradient (85 % of the
+    bytes) is produced BEFORE the second layer's so that ``after_w1`` -- the
+    data-parallel all-reduce of [dW1|db1] -- runs under the dW2 GEMM."""
     L = p.layout
     R = ws.R if n_rows is None else n_rows
     ops.l2norm_bwd(ws.z[:R], ws.de[:R], L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
-    ops.fc_bwd_weight(ws.h1, ws.dz2, p.gW2, p.gb2, ws.bw, R, L.Hp, L.Dp)
     ops.fc_bwd_data(ws.dz2, p.W2, ws.h1, ws.dz1, R, L.Hp, L.Dp)
     ops.fc_bwd_weight(ws.x_hat, ws.dz1, p.gW1, p.gb1, ws.bw, R, L.Fp, L.Hp)
+    if after_w1 is not None:
+        after_w1()
+    ops.fc_bwd_weight(ws.h1, ws.dz2, p.gW2, p.gb2, ws.bw, R, L.Hp, L.Dp)
     return p.grad

@@ -93,7 +93,7 @@ def tower_forward(p, ws):
     return ws.e
 
 
-def tower_backward(p, ws):
+def tower_backward(p, ws, after_w1=None):
     """ws.de -> p.grad (fp32).  train.py:141; no dX."""
     L, R = p.layout, ws.R
     ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
@@ -107,4 +107,6 @@ def tower_backward(p, ws):
     ops.transpose_to_bf16(ws.dz1, ws.dz1T, R, L.Hp)
     ops.transpose_to_bf16(ws.x_hat, ws.xT, R, L.Fp)
     ops.gemm_bf16_nt(ops.BE_F32, ws.xT, ws.dz1T, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws)
+    if after_w1 is not None:
+        after_w1()
     return p.grad
