@@ -334,6 +334,74 @@ k_pair_dist(const float *__restrict__ e, int64_t lde, const int32_t *__restrict_
   }
 }
 
+// ------------------------------------------- fusion towers (models.py:65-157) ----
+// Elementwise pieces between the FC layers of MultiplyNet / MlpNet / ResNet: the
+// multiply fusion tf.multiply(visual, doc) (models.py:90,117,148), ResNet's
+// residual sums (models.py:150-154), the leaky-relu derivative applied to a
+// gradient that reached an FC output through several consumers.  HBM-bound, 16-B
+// lane accesses over [M][N] views with leading dimensions.
+// mode 0: out = a*b          mode 1: out = a*b + a + b        mode 2: out = a + b
+__global__ void __launch_bounds__(kThreads)
+k_ew_combine(int mode, const float *__restrict__ a, int64_t lda, const float *__restrict__ b,
+             int64_t ldb, int M, int N, float *__restrict__ out, int64_t ldo) {
+  const int nq = N >> 2;
+  const int64_t total = (int64_t)M * nq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / nq;
+    const int q = (int)(i - r * nq);
+    const float4 x = ld4(a + r * lda, q), y = ld4(b + r * ldb, q);
+    float4 o;
+    if (mode == 0) o = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+    else if (mode == 1) o = make_float4(x.x * y.x + x.x + y.x, x.y * y.y + x.y + y.y, x.z * y.z + x.z + y.z,
+                                        x.w * y.w + x.w + y.w);
+    else o = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    st4(out + r * ldo, q, o);
+  }
+}
+
+// gradient of k_ew_combine modes 0/1 wrt both inputs, each followed by the
+// leaky-relu derivative of the FC layer that produced that input (a, b are
+// post-activations): da = g*(b + res) * lrelu'(a), db = g*(a + res) * lrelu'(b).
+__global__ void __launch_bounds__(kThreads)
+k_ew_fusion_bwd(int residual, const float *__restrict__ g, int64_t ldg, const float *__restrict__ a,
+                int64_t lda, const float *__restrict__ b, int64_t ldb, int M, int N, float alpha,
+                float *__restrict__ da, int64_t ldda, float *__restrict__ db, int64_t lddb) {
+  const int nq = N >> 2;
+  const int64_t total = (int64_t)M * nq;
+  const float res = residual ? 1.f : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / nq;
+    const int q = (int)(i - r * nq);
+    const float4 gg = ld4(g + r * ldg, q), x = ld4(a + r * lda, q), y = ld4(b + r * ldb, q);
+#define CDML_FB(c, OUTA, OUTB)                                   \
+  OUTA.c = gg.c * (y.c + res) * ((x.c > 0.f) ? 1.f : alpha);     \
+  OUTB.c = gg.c * (x.c + res) * ((y.c > 0.f) ? 1.f : alpha);
+    float4 oa, ob;
+    CDML_FB(x, oa, ob) CDML_FB(y, oa, ob) CDML_FB(z, oa, ob) CDML_FB(w, oa, ob)
+#undef CDML_FB
+    st4(da + r * ldda, q, oa);
+    st4(db + r * lddb, q, ob);
+  }
+}
+
+// dpre = g * lrelu'(y)  (y = post-activation)
+__global__ void __launch_bounds__(kThreads)
+k_lrelu_bwd(const float *__restrict__ g, int64_t ldg, const float *__restrict__ y, int64_t ldy, int M,
+            int N, float alpha, float *__restrict__ out, int64_t ldo) {
+  const int nq = N >> 2;
+  const int64_t total = (int64_t)M * nq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / nq;
+    const int q = (int)(i - r * nq);
+    const float4 gg = ld4(g + r * ldg, q), v = ld4(y + r * ldy, q);
+    st4(out + r * ldo, q, make_float4(gg.x * ((v.x > 0.f) ? 1.f : alpha), gg.y * ((v.y > 0.f) ? 1.f : alpha),
+                                      gg.z * ((v.z > 0.f) ? 1.f : alpha), gg.w * ((v.w > 0.f) ? 1.f : alpha)));
+  }
+}
+
 // stats[0..3] = mean hinge, mean pos, mean neg, fraction of triplets with hinge > 0.
 __global__ void __launch_bounds__(1024)
 k_loss_stats(const float *__restrict__ pos, const float *__restrict__ neg,
@@ -494,4 +562,49 @@ extern "C" int cdml_pair_dist(const float *e, int64_t lde, int n_rows, const int
     rc = check_launch("pair_dist means");
   }
   return rc;
+}
+
+static int ew_grid(int M, int N) {
+  int64_t b = ((int64_t)M * (N >> 2) + kThreads - 1) / kThreads;
+  if (b > kNumCU * 8) b = kNumCU * 8;
+  return (int)(b < 1 ? 1 : b);
+}
+
+extern "C" int cdml_ew_combine(int mode, const float *a, int64_t lda, const float *b, int64_t ldb, int M,
+                               int N, float *out, int64_t ldo, cdml_stream_t stream) {
+  CDML_REQUIRE(mode >= 0 && mode <= 2 && M > 0 && N > 0, CDML_E_BADARG, "ew_combine: bad argument");
+  int rc;
+  if ((rc = check_rows("ew_combine a", a, lda, N))) return rc;
+  if ((rc = check_rows("ew_combine b", b, ldb, N))) return rc;
+  if ((rc = check_rows("ew_combine out", out, ldo, N))) return rc;
+  hipLaunchKernelGGL(k_ew_combine, dim3(ew_grid(M, N)), dim3(kThreads), 0, (hipStream_t)stream, mode, a,
+                     lda, b, ldb, M, N, out, ldo);
+  return check_launch("ew_combine");
+}
+
+extern "C" int cdml_ew_fusion_bwd(int residual, const float *g, int64_t ldg, const float *a, int64_t lda,
+                                  const float *b, int64_t ldb, int M, int N, float alpha, float *da,
+                                  int64_t ldda, float *db, int64_t lddb, cdml_stream_t stream) {
+  CDML_REQUIRE(M > 0 && N > 0, CDML_E_BADARG, "ew_fusion_bwd: bad argument");
+  int rc;
+  if ((rc = check_rows("ew_fusion_bwd g", g, ldg, N))) return rc;
+  if ((rc = check_rows("ew_fusion_bwd a", a, lda, N))) return rc;
+  if ((rc = check_rows("ew_fusion_bwd b", b, ldb, N))) return rc;
+  if ((rc = check_rows("ew_fusion_bwd da", da, ldda, N))) return rc;
+  if ((rc = check_rows("ew_fusion_bwd db", db, lddb, N))) return rc;
+  hipLaunchKernelGGL(k_ew_fusion_bwd, dim3(ew_grid(M, N)), dim3(kThreads), 0, (hipStream_t)stream,
+                     residual, g, ldg, a, lda, b, ldb, M, N, alpha, da, ldda, db, lddb);
+  return check_launch("ew_fusion_bwd");
+}
+
+extern "C" int cdml_lrelu_bwd(const float *g, int64_t ldg, const float *y, int64_t ldy, int M, int N,
+                              float alpha, float *out, int64_t ldo, cdml_stream_t stream) {
+  CDML_REQUIRE(M > 0 && N > 0, CDML_E_BADARG, "lrelu_bwd: bad argument");
+  int rc;
+  if ((rc = check_rows("lrelu_bwd g", g, ldg, N))) return rc;
+  if ((rc = check_rows("lrelu_bwd y", y, ldy, N))) return rc;
+  if ((rc = check_rows("lrelu_bwd out", out, ldo, N))) return rc;
+  hipLaunchKernelGGL(k_lrelu_bwd, dim3(ew_grid(M, N)), dim3(kThreads), 0, (hipStream_t)stream, g, ldg, y,
+                     ldy, M, N, alpha, out, ldo);
+  return check_launch("lrelu_bwd");
 }

@@ -1,0 +1,217 @@
+"""Fusion towers of the reference (models.py:65-157) on the HIP kernels:
+MultiplyNet, MlpNet and ResNet -- visual (first 1500 columns) and doc features
+go through two FC branches, are fused by an elementwise product and, for
+MlpNet / ResNet, pass two more FC layers (with residual sums in ResNet).
+
+Every fully_connected is the fp32 MFMA GEMM of ``ops.fc_lrelu_fwd`` (bias_init
+0.1, leaky-relu 0.2 as in models.py:19-30); gradients use ``fc_bwd_weight`` /
+``fc_bwd_data``; the pieces between layers are the ``ew_*`` kernels.  Parameters
+live in one flat padded fp32 buffer like VNet's, so the same Adam/LARS launch and
+the same all-reduce apply.  DenseNet (broken in the reference: tf.shape used as a
+static dim, models.py:197-198) and ResNetV2 ("debugging") are not built.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .engine import round_up
+
+NETS = ("MultiplyNet", "MlpNet", "ResNet")
+VISUAL = 1500                       # models.py:80,107,138: model_input[:, :1500]
+
+
+class _Layer:
+    def __init__(self, name, fan_in, fan_out):
+        self.name, self.K, self.N = name, fan_in, fan_out
+        self.Kp = round_up(fan_in, 64)
+        self.Np = round_up(fan_out, 128 if fan_out >= 1024 else 64)
+
+
+class FusionParams:
+    def __init__(self, net, device, doc_size=128, visual_size=VISUAL, hidden_v=5000, hidden_d=400,
+                 output_size=256, mlp_hidden=600, seed=42, bias_init=0.1):
+        if net not in NETS:
+            raise ValueError("net must be one of %s" % (NETS,))
+        self.net, self.device = net, torch.device(device)
+        self.visual, self.doc, self.D = visual_size, doc_size, output_size
+        shapes = [("layer_visual_1", visual_size, hidden_v), ("layer_visual_2", hidden_v, output_size),
+                  ("layer_doc_1", doc_size, hidden_d), ("layer_doc_2", hidden_d, output_size)]
+        if net == "MlpNet":
+            shapes += [("layer_fusion_1", output_size, mlp_hidden), ("layer_fusion_2", mlp_hidden, output_size)]
+        elif net == "ResNet":
+            shapes += [("layer_fusion_1", output_size, output_size), ("layer_fusion_2", output_size, output_size)]
+        self.layers = {n: _Layer(n, fi, fo) for n, fi, fo in shapes}
+        # chain consistency: a layer's padded output width is the padded input width of its consumer
+        for a, b in (("layer_visual_1", "layer_visual_2"), ("layer_doc_1", "layer_doc_2"),
+                     ("layer_fusion_1", "layer_fusion_2")):
+            if a in self.layers:
+                self.layers[b].Kp = self.layers[a].Np
+        self.Dp = self.layers["layer_visual_2"].Np
+        for n in ("layer_doc_2", "layer_fusion_2"):
+            if n in self.layers:
+                self.layers[n].Np = self.Dp
+        if "layer_fusion_1" in self.layers:
+            self.layers["layer_fusion_1"].Kp = self.Dp
+            if net == "ResNet":
+                self.layers["layer_fusion_1"].Np = self.Dp
+                self.layers["layer_fusion_2"].Kp = self.Dp
+        off = 0
+        self._seg = {}
+        for n, L in self.layers.items():
+            self._seg[n] = (off, off + L.Kp * L.Np)
+            off += L.Kp * L.Np + L.Np
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.flat)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        for n, L in self.layers.items():
+            W, b = self.W(n), self.b(n)
+            lim = math.sqrt(6.0 / (L.K + L.N))                      # slim's Xavier-uniform default
+            W[:L.K, :L.N] = (torch.rand((L.K, L.N), device=device, generator=gen) * 2 - 1) * lim
+            b[:L.N] = bias_init
+
+    def _view(self, buf, n):
+        L = self.layers[n]
+        lo, mid = self._seg[n]
+        return buf[lo:mid].view(L.Kp, L.Np), buf[mid:mid + L.Np]
+
+    def W(self, n): return self._view(self.flat, n)[0]
+    def b(self, n): return self._view(self.flat, n)[1]
+    def gW(self, n): return self._view(self.grad, n)[0]
+    def gb(self, n): return self._view(self.grad, n)[1]
+
+    def load(self, P):
+        self.flat.zero_()
+        for n, (W, b) in P.items():
+            L = self.layers[n]
+            self.W(n)[:L.K, :L.N] = torch.as_tensor(np.asarray(W, np.float32)).to(self.device)
+            self.b(n)[:L.N] = torch.as_tensor(np.asarray(b, np.float32)).to(self.device)
+
+    def unpadded(self, grads=False):
+        out = {}
+        for n, L in self.layers.items():
+            W, b = self._view(self.grad if grads else self.flat, n)
+            out[n] = (W[:L.K, :L.N], b[:L.N])
+        return out
+
+
+class FusionTower:
+    """Activations + the forward / backward kernel sequences for R rows."""
+
+    def __init__(self, params, n_rows):
+        self.p, self.R = params, int(n_rows)
+        p, dev, R = params, params.device, self.R
+        z = lambda n: torch.zeros((R, n), dtype=torch.float32, device=dev)
+        Ls = p.layers
+        self.xv, self.xd = z(Ls["layer_visual_1"].Kp), z(Ls["layer_doc_1"].Kp)
+        self.act = {n: z(L.Np) for n, L in Ls.items()}             # post-activations of every FC
+        self.dpre = {n: z(L.Np) for n, L in Ls.items()}            # gradients wrt pre-activations
+        D = p.Dp
+        self.fu, self.r2, self.pre, self.e, self.de = z(D), z(D), z(D), z(D), z(D)
+        self.g0, self.g1, self.g2 = z(D), z(D), z(D)
+        self.din = {n: z(L.Kp) for n, L in Ls.items() if n in ("layer_fusion_1", "layer_fusion_2")}
+        nb = max(ops.fc_bwd_weight_workspace(R, L.Kp, L.Np) for L in Ls.values())
+        self.bw = torch.empty(max(nb, 16) // 4, dtype=torch.float32, device=dev)
+
+    def _fc(self, n, x):
+        L = self.p.layers[n]
+        return ops.fc_lrelu_fwd(x, self.p.W(n), self.p.b(n), self.act[n], self.R, L.Kp, L.Np)
+
+    def forward(self, x):
+        """x: raw features [R, >= visual+doc] (row-major, ld multiple of 4).  Returns e [R, Dp]."""
+        p, R, D = self.p, self.R, self.p.Dp
+        ops.l2norm_fwd(x[:, :p.visual], p.visual, self.xv)                       # models.py:81
+        ops.l2norm_fwd(x[:, p.visual:p.visual + p.doc], p.doc, self.xd)          # models.py:86
+        v2 = self._fc("layer_visual_2", self._fc("layer_visual_1", self.xv))
+        d2 = self._fc("layer_doc_2", self._fc("layer_doc_1", self.xd))
+        if p.net == "MultiplyNet":
+            ops.ew_combine(ops.EW_MUL, v2, d2, self.pre, R, D)                   # models.py:90
+        elif p.net == "MlpNet":
+            ops.ew_combine(ops.EW_MUL, v2, d2, self.fu, R, D)                    # models.py:117
+            self.pre = self._fc("layer_fusion_2", self._fc("layer_fusion_1", self.fu))   # alias, no copy
+        else:
+            ops.ew_combine(ops.EW_MUL_RES, v2, d2, self.fu, R, D)                # r1, models.py:148-150
+            f1 = self._fc("layer_fusion_1", self.fu)
+            ops.ew_combine(ops.EW_ADD, self.fu, f1, self.r2, R, D)               # models.py:152
+            f2 = self._fc("layer_fusion_2", self.r2)
+            ops.ew_combine(ops.EW_ADD, self.r2, f2, self.pre, R, D)              # models.py:154
+        ops.l2norm_fwd(self.pre, D, self.e)
+        return self.e
+
+    def _bwd_fc(self, n, x_in, d_pre, d_in=None, mask=None):
+        """dW,db of layer n from d_pre; optionally the gradient wrt its input
+        (times lrelu' of ``mask``, the post-activation of the producing layer)."""
+        p, L = self.p, self.p.layers[n]
+        ops.fc_bwd_weight(x_in, d_pre, p.gW(n), p.gb(n), self.bw, self.R, L.Kp, L.Np)
+        if d_in is not None:
+            ops.fc_bwd_data(d_pre, p.W(n), mask, d_in, self.R, L.Kp, L.Np)
+        return d_in
+
+    def backward(self, de=None):
+        """de (default self.de): gradient wrt e -> p.grad."""
+        p, R, D = self.p, self.R, self.p.Dp
+        de = self.de if de is None else de
+        A, dp = self.act, self.dpre
+        ops.l2norm_bwd(self.pre, de, D, self.g0, lrelu_alpha=-1.0)               # d wrt pre_norm
+        if p.net == "MultiplyNet":
+            dfu, res = self.g0, False
+        elif p.net == "MlpNet":
+            ops.lrelu_bwd(self.g0, A["layer_fusion_2"], dp["layer_fusion_2"], R, D)
+            d_f1 = self._bwd_fc("layer_fusion_2", A["layer_fusion_1"], dp["layer_fusion_2"],
+                                dp["layer_fusion_1"], mask=A["layer_fusion_1"])   # already d_pre of fusion_1
+            dfu = self._bwd_fc("layer_fusion_1", self.fu, d_f1, self.din["layer_fusion_1"])
+            res = False
+        else:
+            ops.lrelu_bwd(self.g0, A["layer_fusion_2"], dp["layer_fusion_2"], R, D)
+            self._bwd_fc("layer_fusion_2", self.r2, dp["layer_fusion_2"], self.din["layer_fusion_2"])
+            ops.ew_combine(ops.EW_ADD, self.g0, self.din["layer_fusion_2"], self.g1, R, D)      # d_r2
+            ops.lrelu_bwd(self.g1, A["layer_fusion_1"], dp["layer_fusion_1"], R, D)
+            self._bwd_fc("layer_fusion_1", self.fu, dp["layer_fusion_1"], self.din["layer_fusion_1"])
+            ops.ew_combine(ops.EW_ADD, self.g1, self.din["layer_fusion_1"], self.g2, R, D)      # d_r1
+            dfu, res = self.g2, True
+        ops.ew_fusion_bwd(res, dfu, A["layer_visual_2"], A["layer_doc_2"], dp["layer_visual_2"],
+                          dp["layer_doc_2"], R, D)
+        self._bwd_fc("layer_visual_2", A["layer_visual_1"], dp["layer_visual_2"], dp["layer_visual_1"],
+                     mask=A["layer_visual_1"])
+        self._bwd_fc("layer_visual_1", self.xv, dp["layer_visual_1"])
+        self._bwd_fc("layer_doc_2", A["layer_doc_1"], dp["layer_doc_2"], dp["layer_doc_1"], mask=A["layer_doc_1"])
+        self._bwd_fc("layer_doc_1", self.xd, dp["layer_doc_1"])
+        return p.grad
+
+
+class FusionTrainStep:
+    """sample -> raw gather -> fusion tower -> hinge loss -> backward -> Adam, all HIP
+    (the reference's step with ``FLAGS.model`` set to a fusion net and
+    ``feature_size`` 1628, online_data.py:38)."""
+
+    def __init__(self, net, table, pairs, batch_size, margin=0.8, base_learning_rate=0.01, seed=1234,
+                 weight_seed=42, device="cuda:0", **dims):
+        self.device = torch.device(device)
+        self.table, self.pairs, self.B, self.margin, self.seed = table, pairs, int(batch_size), margin, seed
+        doc = table.feature_size - dims.get("visual_size", VISUAL)
+        self.params = FusionParams(net, device, doc_size=doc, seed=weight_seed, **dims)
+        self.tower = FusionTower(self.params, 3 * self.B)
+        dev, f32 = self.device, torch.float32
+        self.idx = torch.zeros((self.B, 3), dtype=torch.int32, device=dev)
+        self.x = torch.zeros((3 * self.B, table.data.shape[1]), dtype=f32, device=dev)
+        self.pos, self.neg, self.hinge = (torch.zeros(self.B, dtype=f32, device=dev) for _ in range(3))
+        self.stats = torch.zeros(4, dtype=f32, device=dev)
+        self.m, self.v = torch.zeros_like(self.params.flat), torch.zeros_like(self.params.flat)
+        self.lr, self.global_step = base_learning_rate, 0
+
+    def step(self):
+        t = self.tower
+        ops.sample_uniform(self.pairs, self.table.n_rows_global, self.seed, self.global_step, self.B, self.idx)
+        ops.gather_rows(self.table.data, self.table.row0, self.idx.view(-1), self.table.feature_size, self.x,
+                        normalize=False)
+        t.forward(self.x)
+        ops.triplet_hinge(t.e, self.B, self.params.Dp, self.margin, self.pos, self.neg, self.hinge, self.stats, t.de)
+        t.backward()
+        self.global_step += 1
+        ops.adam_step(self.params.flat, self.params.grad, self.m, self.v, self.lr, self.global_step)
+
+    def loss(self):
+        return float(self.stats[0].item())

@@ -82,3 +82,73 @@ class VNet(BaseModel):
 
     def variables(self):
         return self.params.state_dict()
+
+
+# ---------------------------------------------------------------- fusion towers --
+class _FusionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model_input, flat, model):
+        tower = model._tower(model_input.shape[0])
+        x = model_input.contiguous()
+        e = tower.forward(x)
+        ctx.tower = tower
+        return e[:, :model.params.D].clone()
+
+    @staticmethod
+    def backward(ctx, g_out):
+        tower = ctx.tower
+        tower.de.zero_()
+        tower.de[:, :tower.p.D] = g_out
+        tower.backward()
+        return None, tower.p.grad, None
+
+
+class _FusionNet(BaseModel):
+    """Shared body of the fusion towers: input = visual (first 1500 columns) ++ doc
+    features (feature_size 1628 in production, online_data.py:38)."""
+
+    net = None
+    visual_size = 1500
+
+    def __init__(self, device="cuda:0", seed=42, **dims):
+        self.device, self.seed, self.dims = torch.device(device), seed, dims
+        self.params = None
+        self._t = None
+
+    def build(self, feature_size, output_size=256):
+        from . import fusion
+        visual = self.dims.get("visual_size", self.visual_size)
+        dims = dict(self.dims, visual_size=visual, doc_size=feature_size - visual, output_size=output_size)
+        self.params = fusion.FusionParams(self.net, self.device, seed=self.seed, **dims)
+        self.params.flat.requires_grad_(True)
+        return self
+
+    def _tower(self, n_rows):
+        from . import fusion
+        if self._t is None or self._t.R != n_rows:
+            self._t = fusion.FusionTower(self.params, n_rows)
+        return self._t
+
+    def create_model(self, model_input, output_size=256):
+        """model_input float32 [batch*3, feature_size] -> {"l2_norm": [batch*3, output_size]}."""
+        if self.params is None:
+            self.build(model_input.shape[1], output_size)
+        if model_input.shape[1] != self.params.visual + self.params.doc or output_size != self.params.D:
+            raise ValueError("model was built for another feature / output size")
+        return {"l2_norm": _FusionFunction.apply(model_input, self.params.flat, self)}
+
+
+class MultiplyNet(_FusionNet):
+    """Fusion by multiply (models.py:65-92)."""
+    net = "MultiplyNet"
+
+
+class MlpNet(_FusionNet):
+    """Multiply fusion followed by an MLP 600 -> 256 (models.py:93-122)."""
+    net = "MlpNet"
+
+
+class ResNet(_FusionNet):
+    """Multiply fusion with residual connections -- the tower the author reports to
+    work best (models.py:125-157)."""
+    net = "ResNet"

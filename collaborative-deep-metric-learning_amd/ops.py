@@ -175,6 +175,36 @@ def pair_dist(e, pairs, D, sqdist, dot, means=None):
          _p(dot), _p(means), _stream())
 
 
+# ------------------------------------------------- fusion towers (N4) ---------
+EW_MUL, EW_MUL_RES, EW_ADD = 0, 1, 2
+
+
+def ew_combine(mode, a, b, out, M, N):
+    ap, ald = _mat(a)
+    bp, bld = _mat(b)
+    op, old = _mat(out)
+    call("cdml_ew_combine", mode, ap, ald, bp, bld, M, N, op, old, _stream())
+    return out
+
+
+def ew_fusion_bwd(residual, g, a, b, da, db, M, N, alpha=LRELU_ALPHA):
+    gp, gld = _mat(g)
+    ap, ald = _mat(a)
+    bp, bld = _mat(b)
+    dap, dald = _mat(da)
+    dbp, dbld = _mat(db)
+    call("cdml_ew_fusion_bwd", 1 if residual else 0, gp, gld, ap, ald, bp, bld, M, N, alpha, dap, dald,
+         dbp, dbld, _stream())
+
+
+def lrelu_bwd(g, y, out, M, N, alpha=LRELU_ALPHA):
+    gp, gld = _mat(g)
+    yp, yld = _mat(y)
+    op, old = _mat(out)
+    call("cdml_lrelu_bwd", gp, gld, yp, yld, M, N, alpha, op, old, _stream())
+    return out
+
+
 # ------------------------------------------- reduced precision (config 4) -----
 BE_BIAS_LRELU_BF16, BE_BIAS_LRELU_F32, BE_MASK_BF16, BE_F32 = 0, 1, 2, 3
 

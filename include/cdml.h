@@ -244,6 +244,25 @@ int cdml_gather_rows_f16(const uint16_t *table, int64_t row0, int64_t n_rows,
                          uint16_t *x_out_bf16, int64_t out_stride,
                          int32_t *oob_flag, cdml_stream_t stream);
 
+/* ---- fusion towers MultiplyNet / MlpNet / ResNet (models.py:65-157): the
+ * elementwise pieces between their FC layers; [M][N] fp32 views, N % 4 == 0. ----
+ * mode 0: out = a*b (tf.multiply, models.py:90,117,148); 1: out = a*b + a + b
+ * (ResNet's first residual sum, models.py:150); 2: out = a + b (models.py:152,154). */
+int cdml_ew_combine(int mode, const float *a, int64_t lda, const float *b,
+                    int64_t ldb, int M, int N, float *out, int64_t ldo,
+                    cdml_stream_t stream);
+/* Gradient of modes 0 (residual=0) / 1 (residual=1) wrt a and b, each multiplied
+ * by the leaky-relu derivative of the FC layer that produced it (a, b are
+ * post-activations): da = g*(b+res)*lrelu'(a), db = g*(a+res)*lrelu'(b). */
+int cdml_ew_fusion_bwd(int residual, const float *g, int64_t ldg, const float *a,
+                       int64_t lda, const float *b, int64_t ldb, int M, int N,
+                       float alpha, float *da, int64_t ldda, float *db,
+                       int64_t lddb, cdml_stream_t stream);
+/* out = g * lrelu'(y), y = post-activation (LeakyReluGrad). */
+int cdml_lrelu_bwd(const float *g, int64_t ldg, const float *y, int64_t ldy, int M,
+                   int N, float alpha, float *out, int64_t ldo,
+                   cdml_stream_t stream);
+
 /* ---- optimizers (train.py:108-125,146) --------------------------------------
  * Adam, TensorFlow form (epsilon outside the bias correction):
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m=b1*m+(1-b1)*g; v=b2*v+(1-b2)*g*g;

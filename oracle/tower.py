@@ -295,3 +295,78 @@ def semihard_triplets(neg_row):
     valid = neg_row >= 0
     tri = np.stack([2 * np.arange(B), 2 * np.arange(B) + 1, np.where(valid, neg_row, 0)], axis=1)
     return tri.astype(np.int32), valid
+
+
+# ----------------------------------------------------------------------------
+# fusion towers (next-row N4): MultiplyNet / MlpNet / ResNet, models.py:65-157.
+# Input = visual (first 1500 columns) ++ doc features; every fully_connected has
+# leaky_relu and bias_init 0.1.  PARITY UNPINNED like VNet (TF 1.13 not available).
+# ----------------------------------------------------------------------------
+FUSION_LAYERS = {
+    "MultiplyNet": ("layer_visual_1", "layer_visual_2", "layer_doc_1", "layer_doc_2"),
+    "MlpNet": ("layer_visual_1", "layer_visual_2", "layer_doc_1", "layer_doc_2",
+               "layer_fusion_1", "layer_fusion_2"),
+    "ResNet": ("layer_visual_1", "layer_visual_2", "layer_doc_1", "layer_doc_2",
+               "layer_fusion_1", "layer_fusion_2"),
+}
+
+
+def fusion_layer_shapes(net, visual=1500, doc=128, hidden_v=5000, hidden_d=400, out=256, mlp_hidden=600):
+    """(fan_in, fan_out) per layer name (models.py:79-88,106-120,137-153)."""
+    s = {"layer_visual_1": (visual, hidden_v), "layer_visual_2": (hidden_v, out),
+         "layer_doc_1": (doc, hidden_d), "layer_doc_2": (hidden_d, out)}
+    if net == "MlpNet":
+        s["layer_fusion_1"], s["layer_fusion_2"] = (out, mlp_hidden), (mlp_hidden, out)
+    elif net == "ResNet":
+        s["layer_fusion_1"], s["layer_fusion_2"] = (out, out), (out, out)
+    return {k: s[k] for k in FUSION_LAYERS[net]}
+
+
+def fusion_forward(net, x, P, visual=1500, dtype=np.float64):
+    """P: name -> (W, b).  Returns dict of every intermediate + 'l2_norm'."""
+    x = np.asarray(x, dtype)
+    fc = lambda a, n: fully_connected(a, np.asarray(P[n][0], dtype), np.asarray(P[n][1], dtype)).astype(dtype)
+    t = {}
+    t["xv"], _ = l2_normalize(x[:, :visual], dtype)
+    t["xd"], _ = l2_normalize(x[:, visual:], dtype)
+    t["v1"] = fc(t["xv"], "layer_visual_1"); t["v2"] = fc(t["v1"], "layer_visual_2")
+    t["d1"] = fc(t["xd"], "layer_doc_1"); t["d2"] = fc(t["d1"], "layer_doc_2")
+    if net == "MultiplyNet":
+        t["pre_norm"] = t["v2"] * t["d2"]
+    elif net == "MlpNet":
+        t["fu"] = t["v2"] * t["d2"]
+        t["f1"] = fc(t["fu"], "layer_fusion_1"); t["f2"] = fc(t["f1"], "layer_fusion_2")
+        t["pre_norm"] = t["f2"]
+    else:
+        t["r1"] = t["v2"] * t["d2"] + t["v2"] + t["d2"]
+        t["f1"] = fc(t["r1"], "layer_fusion_1"); t["r2"] = t["r1"] + t["f1"]
+        t["f2"] = fc(t["r2"], "layer_fusion_2"); t["pre_norm"] = t["r2"] + t["f2"]
+    t["l2_norm"], t["inv"] = l2_normalize(t["pre_norm"], dtype)
+    return t
+
+
+def fusion_backward(net, t, P, dE, dtype=np.float64):
+    """Gradients name -> (dW, db) for dE = d loss / d l2_norm."""
+    W = {k: np.asarray(v[0], dtype) for k, v in P.items()}
+    g = {}
+
+    def fc_bwd(name, x_in, y_post, d_post):
+        d_pre = leaky_relu_backward(y_post, d_post)
+        g[name] = (x_in.T @ d_pre, d_pre.sum(0))
+        return d_pre @ W[name].T                     # wrt the layer's input (post-activation of its producer)
+
+    d = l2_normalize_backward(t["pre_norm"], t["inv"], np.asarray(dE, dtype), dtype)
+    if net == "MultiplyNet":
+        dfu, res = d, 0.0
+    elif net == "MlpNet":
+        d_f1 = fc_bwd("layer_fusion_2", t["f1"], t["f2"], d)
+        dfu, res = fc_bwd("layer_fusion_1", t["fu"], t["f1"], d_f1), 0.0
+    else:
+        d_r2 = d + fc_bwd("layer_fusion_2", t["r2"], t["f2"], d)
+        dfu, res = d_r2 + fc_bwd("layer_fusion_1", t["r1"], t["f1"], d_r2), 1.0
+    d_v2, d_d2 = dfu * (t["d2"] + res), dfu * (t["v2"] + res)
+    d_v1 = fc_bwd("layer_visual_2", t["v1"], t["v2"], d_v2)
+    fc_bwd("layer_visual_1", t["xv"], t["v1"], d_v1)
+    d_d1 = fc_bwd("layer_doc_2", t["d1"], t["d2"], d_d2)
+    fc_bwd("layer_doc_1", t["xd"], t["d1"], d_d1)
+    return g

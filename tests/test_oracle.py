@@ -263,3 +263,36 @@ def test_calc_var():
     t = np.random.RandomState(0).randn(5, 3, 4)
     want = np.mean((t - t.mean(axis=(0, 1))) ** 2)
     np.testing.assert_allclose(tower.calc_var(t, np.float64), want)
+
+
+# ----------------------------------------------------------- fusion towers (N4) ---
+@pytest.mark.parametrize("net", ["MultiplyNet", "MlpNet", "ResNet"])
+def test_fusion_towers_vs_torch_autograd(net):
+    rng = np.random.RandomState(0)
+    shapes = tower.fusion_layer_shapes(net, visual=20, doc=6, hidden_v=16, hidden_d=10, out=8, mlp_hidden=12)
+    P = {k: (tower.xavier_uniform(rng, fi, fo, np.float64), np.full(fo, 0.1)) for k, (fi, fo) in shapes.items()}
+    x = rng.random_sample((9, 26))
+    t = tower.fusion_forward(net, x, P, visual=20)
+    dE = rng.randn(9, 8)
+    g = tower.fusion_backward(net, t, P, dE)
+
+    tp = {k: (torch.tensor(w, requires_grad=True), torch.tensor(b, requires_grad=True)) for k, (w, b) in P.items()}
+    l2n = lambda a: a * torch.rsqrt(torch.clamp((a * a).sum(-1, keepdim=True), min=1e-12))
+    fc = lambda a, n: torch.maximum(0.2 * (a @ tp[n][0] + tp[n][1]), a @ tp[n][0] + tp[n][1])
+    xt = torch.tensor(x)
+    v2 = fc(fc(l2n(xt[:, :20]), "layer_visual_1"), "layer_visual_2")
+    d2 = fc(fc(l2n(xt[:, 20:]), "layer_doc_1"), "layer_doc_2")
+    if net == "MultiplyNet":
+        pre = v2 * d2
+    elif net == "MlpNet":
+        pre = fc(fc(v2 * d2, "layer_fusion_1"), "layer_fusion_2")
+    else:
+        r1 = v2 * d2 + v2 + d2
+        r2 = r1 + fc(r1, "layer_fusion_1")
+        pre = r2 + fc(r2, "layer_fusion_2")
+    out = l2n(pre)
+    (out * torch.tensor(dE)).sum().backward()
+    np.testing.assert_allclose(t["l2_norm"], out.detach().numpy(), atol=1e-13)
+    for k in P:
+        np.testing.assert_allclose(g[k][0], tp[k][0].grad.numpy(), atol=1e-12, err_msg=k)
+        np.testing.assert_allclose(g[k][1], tp[k][1].grad.numpy(), atol=1e-12, err_msg=k)
