@@ -180,7 +180,7 @@ def main():
         lo, hi, _ = cdist.shard_bounds(n_rows, world, rank)
         table = Table.synthetic(hi - lo, F, seed=0, device=dev, row0=lo, n_rows_global=n_rows)
         # own communicator for the exchange so it never queues behind the gradient all-reduce
-        exchange, grad_sync = cdist.RowExchange(n_rows, group=dist.new_group()), cdist.GradSync()
+        exchange, grad_sync = cdist.RowExchange(n_rows, group=dist.new_group()), cdist.GradSync(device=dev)
     else:
         table = Table.synthetic(n_rows, F, seed=0, device=dev)
         exchange = grad_sync = None

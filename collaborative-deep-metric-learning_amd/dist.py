@@ -120,10 +120,21 @@ class RowExchange:
 class GradSync:
     """Average the flat gradient buffer over the data-parallel group."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, device=None):
         self.group = group
         self.world = dist.get_world_size(group)
-        self.avg = dist.get_backend(group) == "nccl"
+        self.nccl = dist.get_backend(group) == "nccl"
+        self.avg = False
+        if self.nccl and self.world > 1:
+            # probe once whether the communicator implements ReduceOp.AVG (every rank
+            # runs the same probe, so the collective order stays identical)
+            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+            try:
+                t = torch.ones(1, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+                self.avg = abs(float(t.item()) - 1.0) < 1e-6
+            except Exception:
+                self.avg = False
 
     def start(self, flat_grad, lo, hi):
         """Begin averaging flat_grad[lo:hi]; with RCCL the collective is asynchronous
@@ -132,8 +143,9 @@ class GradSync:
         seg = flat_grad[lo:hi]
         if self.world == 1:
             return None
-        if self.avg:
-            return dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        if self.nccl:
+            op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+            return (dist.all_reduce(seg, op=op, group=self.group, async_op=True), seg)
         self(seg)                                    # gloo: synchronous, host-staged
         return None
 
@@ -141,13 +153,18 @@ class GradSync:
         """Make the compute stream wait for the started collectives."""
         for h in handles:
             if h is not None:
-                h.wait()
+                work, seg = h
+                work.wait()
+                if not self.avg:
+                    seg.div_(self.world)
 
     def __call__(self, flat_grad):
         if self.world == 1:
             return flat_grad
-        if self.avg:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=self.group)
+        if self.nccl:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, group=self.group)
+            if not self.avg:
+                flat_grad.div_(self.world)
         elif flat_grad.is_cuda:                      # gloo rehearsal: stage through host
             h = flat_grad.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -178,11 +195,17 @@ class Prefetcher:
             self.ready = [torch.cuda.Event(), torch.cuda.Event()]
             self.free = [torch.cuda.Event(), torch.cuda.Event()]
         self._released = [False, False]
+        self._cold = True
 
     def launch(self, b, fill_fn):
         if not self.cuda:
             fill_fn()
             return
+        if self._cold:
+            # first use: everything set up on the compute stream so far (table fill,
+            # uploads, weight init) must be visible to the side stream
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._cold = False
         with torch.cuda.stream(self.stream):
             if self._released[b]:
                 self.stream.wait_event(self.free[b])
