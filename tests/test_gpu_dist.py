@@ -97,3 +97,56 @@ def test_two_rank_step_equals_single_rank(gpu):
     assert np.abs(res[0][3] - w).max() < 2.5e-2
     assert np.mean(np.abs(res[0][3] - w) > 1e-4) < 0.02
     assert abs(0.5 * (res[0][4] + res[1][4]) - single.loss()) < 1e-4
+
+
+def _nccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from cdml_amd import dist as cdist
+        # real RCCL calls of the exchange (uneven all-to-all of int64 / int32 / fp32, own group,
+        # side stream) and of the gradient sync (async AVG / SUM), with a single rank
+        ts = _make(dev, 0, 1)                       # reference: whole table, no exchange
+        ex = cdist.RowExchange(CFG["n_rows"], group=dist.new_group())
+        sync = cdist.GradSync(device=dev)
+        sync.world = 2                              # force the collective path (average of one rank x1 ... /2 below)
+        from cdml_amd import train
+        ts2 = train.TrainStep(ts.table, ts.pairs, 2 * CFG["B"], hidden_size=CFG["H"], output_size=CFG["D"],
+                              mode="uniform", device=dev, exchange=ex, grad_sync=None, batch_global=2 * CFG["B"])
+        for _ in range(3):
+            ts.step(); ts2.step()
+        torch.cuda.synchronize()
+        same = torch.equal(ts.params.flat, ts2.params.flat) and torch.equal(ts.idx, ts2.idx)
+        g = torch.full((1000,), 3.0, device=dev)
+        h = sync.start(g, 0, 1000)
+        sync.finish([h])
+        torch.cuda.synchronize()
+        ok_avg = abs(float(g[0].item()) - (3.0 if sync.avg else 1.5)) < 1e-6
+        q.put(("ok" if (same and ok_avg) else "mismatch same=%s avg=%s g=%f" % (same, sync.avg, float(g[0].item()))))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(traceback.format_exc())
+
+
+def test_rccl_single_rank_exchange_paths(gpu):
+    """The box has one GPU, so RCCL can only run with world_size 1 -- enough to execute the
+    actual RCCL entry points the N>1 bench uses (all_to_all_single with uneven splits on
+    a side stream and its own communicator, async all-reduce) and to check that the
+    exchange path reproduces the direct gather bit for bit."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(port, q))
+    p.start()
+    msg = q.get(timeout=300)
+    p.join(timeout=60)
+    assert msg == "ok", msg
