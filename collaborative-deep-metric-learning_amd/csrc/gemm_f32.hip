@@ -12,13 +12,17 @@
 //   bwd data    dx = (dy @ W^T) * lrelu'    A k-contiguous, B k-contiguous
 //   bwd weight  dW = x^T @ dy (+ colsum dy) A k-strided,    B k-strided, split-K
 // Block = 4 waves (2x2), wave tile = (32*TM) x (32*TN) via TM*TN 32x32x2 MFMAs
-// per k-pair, BK = 32, register-staged double-buffered LDS (one barrier per
-// K-tile).  k-contiguous operands sit in LDS as [row][BK+4] and are read with
-// ds_read_b128 (4 k per lane; lane-half h takes k = 8g+4h+t for MFMA t, the
-// other operand uses the same k permutation); k-strided operands sit as
-// [k][cols] and are read with ds_read_b32.  Both patterns are bank-conflict
-// free.  Workgroups are dealt to XCDs in contiguous chunks of a grouped raster
-// so the tiles sharing an A/B panel hit the same L2.
+// per k-pair.  Two LDS stages of one K-tile (BKT = 32 or 16 deep) each, filled
+// by LDS-DMA (no VGPR staging, no ds_write), one barrier per K-tile.
+//   * k-contiguous operands: lane-linear rows of BKT floats whose 16-B chunks are
+//     XOR-swizzled by the row (on the DMA's per-lane source address and on the
+//     ds_read_b128) -> conflict-free; lane-half h takes k = 8g+4h+t for MFMA t
+//     and the other operand uses the same k permutation;
+//   * k-strided operands: [k][cols], read with ds_read_b32, fetched through a
+//     buffer descriptor that ends at the split's last row, so the ragged last
+//     K-tile of the weight gradient reads zeros with no predication.
+// Workgroups are dealt to XCDs in contiguous chunks of a grouped raster so the
+// tiles sharing an A/B panel hit the same L2.
 #include "common.h"
 
 namespace cdml {
@@ -28,38 +32,25 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // native vector: HIP's float4 is a struct, and struct copies through pointers become
 // memcpy-to-alloca (scratch) when the copy is conditional
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
 
 constexpr int kThreads = 256;
-constexpr int BK = 32;
-constexpr int KPAD = 4;
 
-// tuning switches (A/B'd on MI355X with tools/gemm_variants.sh)
+// tuning switches (A/B'd on MI355X with tools/gemm_variants.sh; see DESIGN.md)
 #ifndef CDML_GEMM_FRAG_PREFETCH
 #define CDML_GEMM_FRAG_PREFETCH 2   // read k-group g+1's fragments while group g's MFMAs issue (2: bwd-weight only)
 #endif
-#ifndef CDML_GEMM_BRANCHLESS_LOADS
-#define CDML_GEMM_BRANCHLESS_LOADS 1  // clamp/select instead of exec-masked branches
+#ifndef CDML_GEMM_BK
+#define CDML_GEMM_BK 32             // K-tile depth of the big-tile kernels (32 or 16)
 #endif
-#ifndef CDML_GEMM_STAGGER
-#define CDML_GEMM_STAGGER 0         // 1: delay blocks by (bid>>8)&1, 2: by (bid>>3)&1 (co-residents out of lockstep)
+#ifndef CDML_GEMM_STAGES
+#define CDML_GEMM_STAGES 2          // LDS stages of the big-tile kernels: 3 keeps the DMA two K-tiles ahead
 #endif
-#ifndef CDML_GEMM_GLDS
-#define CDML_GEMM_GLDS 1            // global->LDS by LDS-DMA (no VGPR staging, no ds_write)
-#endif
-#ifndef CDML_GEMM_DMA_INTERLEAVE
-#define CDML_GEMM_DMA_INTERLEAVE 0  // 1: issue the next tile's DMA pieces between MFMA quads (measured: -1 %)
-#endif
-#ifndef CDML_GEMM_PREFETCH_DIST
-#define CDML_GEMM_PREFETCH_DIST 2   // K-tiles the global loads run ahead of the MFMAs (1 or 2)
-#endif
-#ifndef CDML_GEMM_ABLATE
-#define CDML_GEMM_ABLATE 0          // timing-only builds (wrong results): 1 no global loads/LDS writes,
-#endif                              // 2 also no barrier, 3 also no LDS fragment reads
-#ifndef CDML_GEMM_LDS_EPILOGUE
-#define CDML_GEMM_LDS_EPILOGUE 1    // C tile through LDS -> coalesced 16-B row stores
+#ifndef CDML_GEMM_BLOCKS_PER_CU
+#define CDML_GEMM_BLOCKS_PER_CU 2   // launch-bounds occupancy request
 #endif
 
-enum { EPI_STORE = 0, EPI_BIAS_LRELU = 1, EPI_LRELU_MASK = 2, EPI_SLAB_COLSUM = 3 };
+enum { EPI_BIAS_LRELU = 1, EPI_LRELU_MASK = 2, EPI_SLAB_COLSUM = 3 };
 
 struct GemmArgs {
   const float *A; int64_t lda;
@@ -70,19 +61,17 @@ struct GemmArgs {
   float *colsum;                 // EPI_SLAB_COLSUM: [splits][N] (may be null)
   float alpha;
   int M, N, K;                   // output M x N, contraction K
-  int k_per_split;               // multiple of BK; blockIdx.y = split
+  int k_per_split;               // multiple of the K-tile; blockIdx.y = split
   int64_t slab_stride;           // elements between split outputs
   int tiles_m, tiles_n;
 };
 
 // ---- LDS-DMA primitives.  Issued through inline asm on purpose: with the
-// builtins hipcc cannot prove that the DMA into LDS buffer b^1 does not alias
-// the ds_reads of buffer b and drains the DMA (s_waitcnt vmcnt(0)) before the
+// builtins hipcc cannot prove that the DMA into LDS stage b^1 does not alias
+// the ds_reads of stage b and drains the DMA (s_waitcnt vmcnt(0)) before the
 // first fragment read of every K-tile, i.e. in front of the MFMAs.  The asm
 // loads are invisible to its wait-count pass; the kernel waits for them itself
 // (dma_wait_all) right before the barrier that publishes the tile.
-using i32x4 = __attribute__((ext_vector_type(4))) int;
-
 __device__ __forceinline__ uint32_t lds_offset(const float *p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)p;
 }
@@ -108,21 +97,21 @@ __device__ __forceinline__ i32x4 make_srd(const float *base, int64_t bytes) {
   return r;
 }
 
-template <bool AKC, bool BKC, int TM, int TN, int EPI>
-__global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
+// AKC/BKC: operand is k-contiguous in memory.  TM/TN: MFMA tiles per wave.
+// BKT: K-tile depth.  LEPI: stage the C tile through LDS for coalesced 16-B row
+// stores (pays when K is short); NBLK: blocks per CU asked of the register allocator.
+template <bool AKC, bool BKC, int TM, int TN, int EPI, int BKT, bool LEPI, int NBLK, int NSTG>
+__global__ void __launch_bounds__(kThreads, NBLK) k_gemm_f32(GemmArgs g) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr bool GLDS = (CDML_GEMM_GLDS != 0);
-  // floats per row of a k-contiguous LDS tile: padded for register staging; with
-  // LDS-DMA the image must be lane-linear, so rows are 128 B and the 16-B chunks are
-  // XOR-swizzled by the row instead (chunk' = chunk ^ ((row >> 1) & 7): conflict-free
-  // ds_read_b128, applied on the DMA's per-lane SOURCE address and on the read).
-  constexpr int KROW = GLDS ? BK : BK + KPAD;
-  constexpr int A_TILE = AKC ? BM * KROW : BK * BM;
-  constexpr int B_TILE = BKC ? BN * KROW : BK * BN;
-  constexpr int A_REGS = BM / 32, B_REGS = BN / 32;  // f32x4 staging registers per thread
-  constexpr bool KPRED = !AKC && !BKC;               // only the bwd-weight GEMM has a ragged K
-  constexpr int STAGE = 2 * (A_TILE + B_TILE);
-  constexpr int SMEM = STAGE > BM * BN ? STAGE : BM * BN;  // the epilogue reuses it as the C tile
+  constexpr int A_TILE = BM * BKT, B_TILE = BKT * BN;       // floats; no padding (lane-linear DMA image)
+  constexpr int STAGE = A_TILE + B_TILE;
+  constexpr int SMEM = (LEPI && BM * BN > NSTG * STAGE) ? BM * BN : NSTG * STAGE;
+  static_assert(NSTG == 2 || NSTG == 3, "LDS stages");
+  constexpr int CPR = BKT / 4;                               // 16-B chunks per k-contiguous row
+  constexpr int SWZ_SHIFT = (BKT == 32) ? 1 : 2;             // rows per 256-B bank row: 2 or 4
+  constexpr int RPP = 256 / BKT;                             // k-contiguous rows per 1-KiB DMA piece
+  constexpr bool KPRED = !AKC && !BKC;                       // only the bwd-weight GEMM has a ragged K
+  static_assert(BKT == 32 || BKT == 16, "K-tile depth");
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
   const int t = threadIdx.x;
@@ -137,124 +126,56 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
   const int split = blockIdx.y;
   const int k_begin = split * g.k_per_split;
   const int k_end = min(g.K, k_begin + g.k_per_split);
-  const int n_ktiles = (k_end - k_begin + BK - 1) / BK;
+  const int n_ktiles = (k_end - k_begin + BKT - 1) / BKT;
 
-  struct Stage { f32x4 a[A_REGS]; f32x4 b[B_REGS]; };  // one K-tile's staging registers
   f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool do_colsum = (EPI == EPI_SLAB_COLSUM) && g.colsum && tm == 0;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Global -> registers.  No branches: out-of-range rows / k are clamped to a
-  // valid address.  Clamped rows are never stored; clamped k (ragged last K-tile
-  // of the bwd-weight GEMM) is zeroed LATER, in store_tile -- touching a loaded
-  // value here would put the vmcnt wait in front of the MFMAs.
-  auto load_tile = [&](int kt) {
-    Stage st;
-    // a tile wholly past the end (the prefetch runs ahead) re-reads the split's first
-    // tile; k-strided rows of the ragged bwd-weight GEMM are clamped per row below
-    const int k0u = k_begin + kt * BK;
-    const int k0 = (KPRED || k0u < k_end) ? k0u : k_begin;
-    if (AKC) {  // rows [m0, m0+BM) x k [k0, k0+32): 8 f32x4 per row
-#pragma unroll
-      for (int p = 0; p < A_REGS; ++p) {
-#if CDML_GEMM_BRANCHLESS_LOADS
-        const int row = min(m0 + p * 32 + (t >> 3), g.M - 1);
-        st.a[p] = *reinterpret_cast<const f32x4 *>(g.A + (int64_t)row * g.lda + k0 + (t & 7) * 4);
-#else
-        const int row = m0 + p * 32 + (t >> 3);
-        st.a[p] = (row < g.M)
-                    ? *reinterpret_cast<const f32x4 *>(g.A + (int64_t)row * g.lda + k0 + (t & 7) * 4)
-                    : zero4;
-#endif
-      }
-    } else {  // k rows [k0, k0+32) x cols [m0, m0+BM)
-      constexpr int C4 = BM / 4, KR = kThreads / C4;
-#pragma unroll
-      for (int p = 0; p < A_REGS; ++p) {
-        const int k = k0 + p * KR + t / C4;
-#if CDML_GEMM_BRANCHLESS_LOADS
-        const int kc = KPRED ? min(k, k_end - 1) : k;
-        st.a[p] = *reinterpret_cast<const f32x4 *>(g.A + (int64_t)kc * g.lda + m0 + (t % C4) * 4);
-#else
-        st.a[p] = (k < k_end)
-                    ? *reinterpret_cast<const f32x4 *>(g.A + (int64_t)k * g.lda + m0 + (t % C4) * 4)
-                    : zero4;
-#endif
-      }
-    }
-    if (BKC) {
-#pragma unroll
-      for (int p = 0; p < B_REGS; ++p) {
-        const int row = n0 + p * 32 + (t >> 3);
-        st.b[p] = *reinterpret_cast<const f32x4 *>(g.B + (int64_t)row * g.ldb + k0 + (t & 7) * 4);
-      }
-    } else {
-      constexpr int C4 = BN / 4, KR = kThreads / C4;
-#pragma unroll
-      for (int p = 0; p < B_REGS; ++p) {
-        const int k = k0 + p * KR + t / C4;
-#if CDML_GEMM_BRANCHLESS_LOADS
-        const int kc = KPRED ? min(k, k_end - 1) : k;
-        st.b[p] = *reinterpret_cast<const f32x4 *>(g.B + (int64_t)kc * g.ldb + n0 + (t % C4) * 4);
-#else
-        st.b[p] = (k < k_end)
-                    ? *reinterpret_cast<const f32x4 *>(g.B + (int64_t)k * g.ldb + n0 + (t % C4) * 4)
-                    : zero4;
-#endif
-      }
-    }
-    return st;
-  };
+  const i32x4 srd_a = (!AKC) ? make_srd(g.A + (int64_t)k_begin * g.lda, (int64_t)(k_end - k_begin) * g.lda * 4)
+                             : i32x4{0, 0, 0, 0};
+  const i32x4 srd_b = (!BKC) ? make_srd(g.B + (int64_t)k_begin * g.ldb, (int64_t)(k_end - k_begin) * g.ldb * 4)
+                             : i32x4{0, 0, 0, 0};
 
-  // Registers -> LDS (tile kt); also where the ragged-K zeroing and the
-  // bias-gradient column sums of the bwd-weight GEMM happen.
-  auto store_tile = [&](int buf, int kt, Stage st) {
-    float *sA = smem + buf * (A_TILE + B_TILE);
-    float *sB = sA + A_TILE;
-    {
-      const int k0 = k_begin + kt * BK;
-#if CDML_GEMM_BRANCHLESS_LOADS
-      if (k0 >= k_end) {  // uniform: a whole tile past the end (prefetch ran ahead) contributes zeros
-#pragma unroll
-        for (int p = 0; p < A_REGS; ++p) st.a[p] = zero4;
-#pragma unroll
-        for (int p = 0; p < B_REGS; ++p) st.b[p] = zero4;
-      } else if (KPRED && k0 + BK > k_end) {  // uniform: ragged last K-tile of a split
-        constexpr int CA = BM / 4, KRA = kThreads / CA, CB = BN / 4, KRB = kThreads / CB;
-#pragma unroll
-        for (int p = 0; p < A_REGS; ++p)
-          if (k0 + p * KRA + t / CA >= k_end) st.a[p] = zero4;
-#pragma unroll
-        for (int p = 0; p < B_REGS; ++p)
-          if (k0 + p * KRB + t / CB >= k_end) st.b[p] = zero4;
-      }
-#endif
-      if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) {
-#pragma unroll
-        for (int p = 0; p < B_REGS; ++p) {
-          bsum.x += st.b[p].x; bsum.y += st.b[p].y; bsum.z += st.b[p].z; bsum.w += st.b[p].w;
-        }
-      }
-    }
+  // Each wave-instruction moves 64 x 16 B = 1 KiB ("piece") of tile kt into stage buf.
+  auto issue_tile = [&](int buf, int kt) {
+    const float *sA = smem + buf * STAGE;
+    const float *sB = sA + A_TILE;
+    const uint32_t la = __builtin_amdgcn_readfirstlane(lds_offset(sA) + wave * 1024);
+    const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_offset(sB) + wave * 1024);
+    const int k0 = k_begin + kt * BKT;
+    constexpr int PA = A_TILE / 256 / 4, PB = B_TILE / 256 / 4;   // pieces per wave
     if (AKC) {
 #pragma unroll
-      for (int p = 0; p < A_REGS; ++p)
-        *reinterpret_cast<f32x4 *>(sA + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = st.a[p];
+      for (int j = 0; j < PA; ++j) {                 // piece = wave + 4j: RPP rows of BKT floats
+        const int row = (wave + 4 * j) * RPP + lane / CPR;
+        const int c = (lane % CPR) ^ ((row >> SWZ_SHIFT) % CPR);
+        dma_global_to_lds(g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + k0 + 4 * c, la + j * 4096);
+      }
     } else {
-      constexpr int C4 = BM / 4, KR = kThreads / C4;
+      constexpr int KPP = 256 / BM;                  // k rows per piece
 #pragma unroll
-      for (int p = 0; p < A_REGS; ++p)
-        *reinterpret_cast<f32x4 *>(sA + (p * KR + t / C4) * BM + (t % C4) * 4) = st.a[p];
+      for (int j = 0; j < PA; ++j) {
+        const int f = lane * 4;
+        const int k = kt * BKT + (wave + 4 * j) * KPP + f / BM;
+        dma_buffer_to_lds(srd_a, (uint32_t)(((int64_t)k * g.lda + m0 + f % BM) * 4), la + j * 4096);
+      }
     }
     if (BKC) {
 #pragma unroll
-      for (int p = 0; p < B_REGS; ++p)
-        *reinterpret_cast<f32x4 *>(sB + (p * 32 + (t >> 3)) * (BK + KPAD) + (t & 7) * 4) = st.b[p];
+      for (int j = 0; j < PB; ++j) {
+        const int row = (wave + 4 * j) * RPP + lane / CPR;
+        const int c = (lane % CPR) ^ ((row >> SWZ_SHIFT) % CPR);
+        dma_global_to_lds(g.B + (int64_t)(n0 + row) * g.ldb + k0 + 4 * c, lb + j * 4096);
+      }
     } else {
-      constexpr int C4 = BN / 4, KR = kThreads / C4;
+      constexpr int KPP = 256 / BN;
 #pragma unroll
-      for (int p = 0; p < B_REGS; ++p)
-        *reinterpret_cast<f32x4 *>(sB + (p * KR + t / C4) * BN + (t % C4) * 4) = st.b[p];
+      for (int j = 0; j < PB; ++j) {
+        const int f = lane * 4;
+        const int k = kt * BKT + (wave + 4 * j) * KPP + f / BN;
+        dma_buffer_to_lds(srd_b, (uint32_t)(((int64_t)k * g.ldb + n0 + f % BN) * 4), lb + j * 4096);
+      }
     }
   };
 
@@ -267,8 +188,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
     for (int mi = 0; mi < TM; ++mi) {
       const int row = wm * 32 * TM + mi * 32 + l31;
       if (AKC) {
-        const int off = GLDS ? row * BK + (((2 * grp + h) ^ ((row >> 1) & 7)) << 2)
-                             : row * (BK + KPAD) + 8 * grp + 4 * h;
+        const int off = row * BKT + (((2 * grp + h) ^ ((row >> SWZ_SHIFT) % CPR)) << 2);
         const f32x4 v = *reinterpret_cast<const f32x4 *>(sA + off);
         f.a[mi][0] = v.x; f.a[mi][1] = v.y; f.a[mi][2] = v.z; f.a[mi][3] = v.w;
       } else {
@@ -280,8 +200,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
     for (int ni = 0; ni < TN; ++ni) {
       const int col = wn * 32 * TN + ni * 32 + l31;
       if (BKC) {
-        const int off = GLDS ? col * BK + (((2 * grp + h) ^ ((col >> 1) & 7)) << 2)
-                             : col * (BK + KPAD) + 8 * grp + 4 * h;
+        const int off = col * BKT + (((2 * grp + h) ^ ((col >> SWZ_SHIFT) % CPR)) << 2);
         const f32x4 v = *reinterpret_cast<const f32x4 *>(sB + off);
         f.b[ni][0] = v.x; f.b[ni][1] = v.y; f.b[ni][2] = v.z; f.b[ni][3] = v.w;
       } else {
@@ -300,15 +219,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-#if CDML_GEMM_STAGGER == 1
-  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(32);
-#elif CDML_GEMM_STAGGER == 2
-  if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_sleep(32);
-#endif
-
-  // MFMAs of one K-tile held in LDS buffer `buf`
+  // MFMAs of one K-tile held in LDS stage `buf`
   auto compute_tile = [&](int buf) {
-    const float *sA = smem + buf * (A_TILE + B_TILE);
+    const float *sA = smem + buf * STAGE;
     const float *sB = sA + A_TILE;
 #define CDML_MFMA_GROUP(F)                                                                   \
   _Pragma("unroll") for (int u = 0; u < 4; ++u)                                              \
@@ -317,12 +230,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
       acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32((F).a[mi][u], (F).b[ni][u], acc[mi][ni], 0, 0, 0)
     // CDML_GEMM_FRAG_PREFETCH: 0 off, 1 every kernel, 2 only the bwd-weight GEMM (both
     // operands k-strided: 2x the LDS read instructions; measured +5 % there, -2 % on fwd)
-    constexpr bool PF = (CDML_GEMM_FRAG_PREFETCH == 1) || (CDML_GEMM_FRAG_PREFETCH == 2 && KPRED);
+    constexpr bool PF = (BKT == 32) &&
+                        ((CDML_GEMM_FRAG_PREFETCH == 1) || (CDML_GEMM_FRAG_PREFETCH == 2 && KPRED));
     if constexpr (PF) {
       // fragments double-buffered in registers: group g+1 is read from LDS while the
       // 4*TM*TN MFMAs of group g issue.  The sched_barrier keeps the reads ahead (hipcc
       // otherwise sinks each read to just before its use and stalls on lgkmcnt(0)).
-      static_assert(BK / 8 == 4, "unrolled for 4 k-groups");
       Frag f0 = load_frags(sA, sB, 0);
       Frag f1 = load_frags(sA, sB, 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -336,207 +249,77 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
       CDML_MFMA_GROUP(f1);
     } else {
 #pragma unroll
-      for (int grp = 0; grp < BK / 8; ++grp) {
-#if CDML_GEMM_ABLATE >= 3
-        Frag f = load_frags(smem, smem + A_TILE, 0);
-        asm volatile("" : "+v"(f.a[0][0]), "+v"(f.b[0][0]));
-#else
+      for (int grp = 0; grp < BKT / 8; ++grp) {
         const Frag f = load_frags(sA, sB, grp);
-#endif
         CDML_MFMA_GROUP(f);
       }
     }
 #undef CDML_MFMA_GROUP
   };
 
-  // ---- LDS-DMA staging (GLDS): each wave-instruction moves 64 x 16 B = 1 KiB
-  // straight from global memory into LDS (destination = wave-uniform base +
-  // lane*16, source address per lane).  k-strided operands go through a buffer
-  // descriptor whose range ends at row k_end, so the ragged last K-tile of the
-  // bwd-weight GEMM reads zeros with no predication.
-  const i32x4 srd_a = (!AKC) ? make_srd(g.A + (int64_t)k_begin * g.lda, (int64_t)(k_end - k_begin) * g.lda * 4)
-                             : i32x4{0, 0, 0, 0};
-  const i32x4 srd_b = (!BKC) ? make_srd(g.B + (int64_t)k_begin * g.ldb, (int64_t)(k_end - k_begin) * g.ldb * 4)
-                             : i32x4{0, 0, 0, 0};
-  auto issue_tile = [&](int buf, int kt) {
-    const float *sA = smem + buf * (A_TILE + B_TILE);
-    const float *sB = sA + A_TILE;
-    const uint32_t la = __builtin_amdgcn_readfirstlane(lds_offset(sA) + wave * 1024);
-    const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_offset(sB) + wave * 1024);
-    const int k0 = k_begin + kt * BK;
-    if (AKC) {
-#pragma unroll
-      for (int j = 0; j < BM / 32; ++j) {      // piece = wave + 4j: 8 rows x 128 B
-        const int row = (wave + 4 * j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        const int grow = min(m0 + row, g.M - 1);
-        dma_global_to_lds(g.A + (int64_t)grow * g.lda + k0 + 4 * c, la + j * 4096);
-      }
-    } else {
-      constexpr int KPP = 256 / BM;            // k rows per 1-KiB piece
-#pragma unroll
-      for (int j = 0; j < BM / 32; ++j) {
-        const int f = lane * 4;
-        const int k = kt * BK + (wave + 4 * j) * KPP + f / BM;
-        dma_buffer_to_lds(srd_a, (uint32_t)(((int64_t)k * g.lda + m0 + f % BM) * 4), la + j * 4096);
-      }
-    }
-    if (BKC) {
-#pragma unroll
-      for (int j = 0; j < BN / 32; ++j) {
-        const int row = (wave + 4 * j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        dma_global_to_lds(g.B + (int64_t)(n0 + row) * g.ldb + k0 + 4 * c, lb + j * 4096);
-      }
-    } else {
-      constexpr int KPP = 256 / BN;
-#pragma unroll
-      for (int j = 0; j < BN / 32; ++j) {
-        const int f = lane * 4;
-        const int k = kt * BK + (wave + 4 * j) * KPP + f / BN;
-        dma_buffer_to_lds(srd_b, (uint32_t)(((int64_t)k * g.ldb + n0 + f % BN) * 4), lb + j * 4096);
-      }
-    }
-  };
-
   // bias gradient of the bwd-weight GEMM: column sums of the dy tile now in LDS
   auto colsum_tile = [&](int buf) {
-    const float *sB = smem + buf * (A_TILE + B_TILE) + A_TILE;
+    const float *sB = smem + buf * STAGE + A_TILE;
     constexpr int CB = BN / 4, KRB = kThreads / CB;
+    if constexpr (BKT >= KRB) {
 #pragma unroll
-    for (int j = 0; j < BK / KRB; ++j) {
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(sB + (j * KRB + t / CB) * BN + (t % CB) * 4);
-      bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-    }
-  };
-
-  // One 1-KiB DMA piece of tile kt into buffer buf; idx < BM/32 -> A piece, else B.
-  auto issue_piece = [&](int buf, int kt, int idx) {
-    const float *sA = smem + buf * (A_TILE + B_TILE);
-    const float *sB = sA + A_TILE;
-    const int k0 = k_begin + kt * BK;
-    if (idx < BM / 32) {
-      const int j = idx;
-      const uint32_t la = __builtin_amdgcn_readfirstlane(lds_offset(sA) + wave * 1024 + j * 4096);
-      if (AKC) {
-        const int row = (wave + 4 * j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        dma_global_to_lds(g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + k0 + 4 * c, la);
-      } else {
-        constexpr int KPP = 256 / BM;
-        const int f = lane * 4;
-        const int k = kt * BK + (wave + 4 * j) * KPP + f / BM;
-        dma_buffer_to_lds(srd_a, (uint32_t)(((int64_t)k * g.lda + m0 + f % BM) * 4), la);
-      }
+      for (int j = 0; j < BKT / KRB; ++j)
+        bsum += *reinterpret_cast<const f32x4 *>(sB + (j * KRB + t / CB) * BN + (t % CB) * 4);
     } else {
-      const int j = idx - BM / 32;
-      const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_offset(sB) + wave * 1024 + j * 4096);
-      if (BKC) {
-        const int row = (wave + 4 * j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        dma_global_to_lds(g.B + (int64_t)(n0 + row) * g.ldb + k0 + 4 * c, lb);
-      } else {
-        constexpr int KPP = 256 / BN;
-        const int f = lane * 4;
-        const int k = kt * BK + (wave + 4 * j) * KPP + f / BN;
-        dma_buffer_to_lds(srd_b, (uint32_t)(((int64_t)k * g.ldb + n0 + f % BN) * 4), lb);
-      }
+      if (t / CB < BKT) bsum += *reinterpret_cast<const f32x4 *>(sB + (t / CB) * BN + (t % CB) * 4);
     }
   };
 
-  // MFMAs of tile kt (buffer buf) with the DMA pieces of tile kt+1 issued BETWEEN the
-  // MFMA quads: an issued MFMA keeps the matrix pipe busy for 64 cycles, so a DMA
-  // issue (~60-100 cycles of this wave's issue slot) hides under it, whereas eight
-  // of them in front of the tile leave the wave's MFMA stream empty for ~700 cycles.
-  auto compute_issue = [&](int buf, int kt, bool more) {
-    const float *sA = smem + buf * (A_TILE + B_TILE);
-    const float *sB = sA + A_TILE;
-    constexpr int NP = BM / 32 + BN / 32;   // pieces per wave per K-tile
-    constexpr int STRIDE = 16 / NP;         // MFMA quads between two issues (NP = 8, 6 or 4)
-#pragma unroll
-    for (int grp = 0; grp < BK / 8; ++grp) {
-      const Frag f = load_frags(sA, sB, grp);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mi][u], f.b[ni][u], acc[mi][ni], 0, 0, 0);
-        const int slot = grp * 4 + u;
-        if (slot % STRIDE == 0 && slot / STRIDE < NP) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) issue_piece(buf ^ 1, kt + 1, slot / STRIDE);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+  if constexpr (NSTG == 2) {
+    if (n_ktiles > 0) issue_tile(0, 0);
+    dma_wait_all();
+    __syncthreads();
+    for (int kt = 0; kt < n_ktiles; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < n_ktiles) issue_tile(buf ^ 1, kt + 1);  // lands in the other stage under the MFMAs
+      if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) colsum_tile(buf);
+      compute_tile(buf);
+      dma_wait_all();    // this wave's pieces of tile kt+1 are in LDS ...
+      __syncthreads();   // ... and so are everybody else's; stage `buf` is free again
     }
-  };
+  } else {
+    // three stages: the DMA runs TWO K-tiles ahead, so a tile has two compute phases to
+    // arrive; the wait before the barrier leaves the newest tile's pieces in flight
+    // (counted vmcnt -- the kernel counts its own asm loads: P pieces per wave per tile)
+    constexpr int P = (A_TILE + B_TILE) / 256 / 4;
+    if (n_ktiles > 0) issue_tile(0, 0);
+    if (n_ktiles > 1) {
+      issue_tile(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory");
+    } else {
+      dma_wait_all();
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int kt = 0; kt < n_ktiles; ++kt) {
+      const int nxt2 = buf >= 1 ? buf - 1 : 2;             // (kt + 2) % 3
+      if (kt + 2 < n_ktiles) issue_tile(nxt2, kt + 2);
+      if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) colsum_tile(buf);
+      compute_tile(buf);
+      if (kt + 2 < n_ktiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory");
+      else dma_wait_all();
+      __syncthreads();
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+  }
 
-#if CDML_GEMM_GLDS
-  if (n_ktiles > 0) issue_tile(0, 0);
-  dma_wait_all();
-  __syncthreads();
-  for (int kt = 0; kt < n_ktiles; ++kt) {
-    const int buf = kt & 1;
-#if CDML_GEMM_DMA_INTERLEAVE
-    if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) colsum_tile(buf);
-    compute_issue(buf, kt, kt + 1 < n_ktiles);
-#else
-    if (kt + 1 < n_ktiles) issue_tile(buf ^ 1, kt + 1);  // lands in the other buffer under the MFMAs
-    if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) colsum_tile(buf);
-    compute_tile(buf);
-#endif
-    dma_wait_all();    // this wave's pieces of tile kt+1 are in LDS ...
-    __syncthreads();   // ... and so are everybody else's; buffer `buf` is free again
-  }
-#elif CDML_GEMM_PREFETCH_DIST == 2
-  // Global loads run TWO K-tiles ahead of the MFMAs (two staging register sets,
-  // loop unrolled by two so the set is static): a tile has two compute phases to
-  // arrive before its LDS write needs it.
-  // No conditional loads in the loop (a load under a branch makes hipcc wait for
-  // vmcnt(0) at the next LDS write): tiles past the end are loaded from a clamped
-  // address and zeroed in store_tile, and the tile count is rounded up to even.
-  const int n_even = (n_ktiles + 1) & ~1;
-  Stage s0 = load_tile(0), s1 = load_tile(1);
-  store_tile(0, 0, s0);
-  __syncthreads();
-  for (int kt = 0; kt < n_even; kt += 2) {
-    if (CDML_GEMM_ABLATE == 0) s0 = load_tile(kt + 2);
-    compute_tile(0);
-    if (CDML_GEMM_ABLATE == 0) store_tile(1, kt + 1, s1);
-    if (CDML_GEMM_ABLATE < 2) __syncthreads();
-    if (CDML_GEMM_ABLATE == 0) s1 = load_tile(kt + 3);
-    compute_tile(1);
-    if (CDML_GEMM_ABLATE == 0) store_tile(0, kt + 2, s0);
-    if (CDML_GEMM_ABLATE < 2) __syncthreads();
-  }
-#else
-  Stage s0;
-  if (n_ktiles > 0) {
-    s0 = load_tile(0);
-    store_tile(0, 0, s0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < n_ktiles; ++kt) {
-    const int buf = kt & 1;
-    if (CDML_GEMM_ABLATE == 0 && kt + 1 < n_ktiles) s0 = load_tile(kt + 1);  // in flight under the MFMAs
-    compute_tile(buf);
-    if (CDML_GEMM_ABLATE == 0 && kt + 1 < n_ktiles) store_tile(buf ^ 1, kt + 1, s0);
-    if (CDML_GEMM_ABLATE < 2) __syncthreads();
-  }
-#endif
-
-#if !CDML_GEMM_LDS_EPILOGUE
-  {  // direct epilogue: one dword per lane per store, two 128-B row segments per instruction
-    float *Cd = g.C + (EPI == EPI_SLAB_COLSUM ? (int64_t)split * g.slab_stride : 0);
+  float *C = g.C + (EPI == EPI_SLAB_COLSUM ? (int64_t)split * g.slab_stride : 0);
+  const bool has_aux = (EPI == EPI_LRELU_MASK) && g.aux != nullptr;  // uniform
+  if constexpr (!LEPI) {
+    // direct epilogue (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)):
+    // one dword per lane per store, two 128-B row segments per instruction
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
-        const int colx = n0 + wn * 32 * TN + ni * 32 + l31;
+        const int col = n0 + wn * 32 * TN + ni * 32 + l31;
         float bias = 0.f;
-        if (EPI == EPI_BIAS_LRELU) bias = g.bias[colx];
+        if (EPI == EPI_BIAS_LRELU) bias = g.bias[col];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -546,82 +329,77 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
               v += bias;
               v = fmaxf(v, v * g.alpha);
             } else if (EPI == EPI_LRELU_MASK) {
-              if (g.aux) v *= (g.aux[(int64_t)row * g.ldaux + colx] > 0.f) ? 1.f : g.alpha;
+              if (has_aux) v *= (g.aux[(int64_t)row * g.ldaux + col] > 0.f) ? 1.f : g.alpha;
             }
-            Cd[(int64_t)row * g.ldc + colx] = v;
+            C[(int64_t)row * g.ldc + col] = v;
           }
         }
       }
-  }
-#else
-  // ---- epilogue.  Accumulators -> LDS C tile (C/D layout: col = lane&31,
-  // row = (r&3) + 8*(r>>2) + 4*(lane>>5)), then whole 16-B row segments per lane
-  // so global stores (and the aux/bias loads) are coalesced.
-#pragma unroll
-  for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        smem[row * BN + wn * 32 * TN + ni * 32 + l31] = acc[mi][ni][r];
-      }
-  __syncthreads();
-
-  float *C = g.C + (EPI == EPI_SLAB_COLSUM ? (int64_t)split * g.slab_stride : 0);
-  constexpr int C4 = BN / 4, ROWS_PER_PASS = kThreads / C4, PASSES = BM / ROWS_PER_PASS;
-  const int c4 = t % C4;
-  const int col = n0 + c4 * 4;
-  const int lr0 = t / C4;
-  const bool has_aux = (EPI == EPI_LRELU_MASK) && g.aux != nullptr;  // uniform
-  f32x4 bias4 = zero4;
-  if (EPI == EPI_BIAS_LRELU) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
-
-  auto finish = [&](f32x4 v, f32x4 m) {
-    if (EPI == EPI_BIAS_LRELU) {
-      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-      v.x = fmaxf(v.x, v.x * g.alpha); v.y = fmaxf(v.y, v.y * g.alpha);
-      v.z = fmaxf(v.z, v.z * g.alpha); v.w = fmaxf(v.w, v.w * g.alpha);
-    } else if (EPI == EPI_LRELU_MASK) {
-      if (has_aux) {
-        v.x *= (m.x > 0.f) ? 1.f : g.alpha; v.y *= (m.y > 0.f) ? 1.f : g.alpha;
-        v.z *= (m.z > 0.f) ? 1.f : g.alpha; v.w *= (m.w > 0.f) ? 1.f : g.alpha;
-      }
-    }
-    return v;
-  };
-
-  if (m0 + BM <= g.M) {
-    // full tile (wave-uniform test): no per-lane branches, so every aux load and
-    // every store is in flight at once instead of one round trip per pass
-    f32x4 m[PASSES];
-    if (EPI == EPI_LRELU_MASK && has_aux) {
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p)
-        m[p] = *reinterpret_cast<const f32x4 *>(g.aux + (int64_t)(m0 + p * ROWS_PER_PASS + lr0) * g.ldaux + col);
-    }
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-      const int lr = p * ROWS_PER_PASS + lr0;
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(smem + lr * BN + c4 * 4);
-      *reinterpret_cast<f32x4 *>(C + (int64_t)(m0 + lr) * g.ldc + col) =
-          finish(v, (EPI == EPI_LRELU_MASK && has_aux) ? m[p] : zero4);
-    }
   } else {
-    for (int p = 0; p < PASSES; ++p) {
-      const int lr = p * ROWS_PER_PASS + lr0;
-      const int row = m0 + lr;
-      if (row < g.M) {
+    // accumulators -> LDS C tile, then whole 16-B row segments per lane so the global
+    // stores (and the aux / bias loads) are coalesced
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          smem[row * BN + wn * 32 * TN + ni * 32 + l31] = acc[mi][ni][r];
+        }
+    __syncthreads();
+
+    constexpr int C4 = BN / 4, ROWS_PER_PASS = kThreads / C4, PASSES = BM / ROWS_PER_PASS;
+    const int c4 = t % C4;
+    const int col = n0 + c4 * 4;
+    const int lr0 = t / C4;
+    f32x4 bias4 = zero4;
+    if (EPI == EPI_BIAS_LRELU) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
+
+    auto finish = [&](f32x4 v, f32x4 m) {
+      if (EPI == EPI_BIAS_LRELU) {
+        v += bias4;
+        v.x = fmaxf(v.x, v.x * g.alpha); v.y = fmaxf(v.y, v.y * g.alpha);
+        v.z = fmaxf(v.z, v.z * g.alpha); v.w = fmaxf(v.w, v.w * g.alpha);
+      } else if (EPI == EPI_LRELU_MASK) {
+        if (has_aux) {
+          v.x *= (m.x > 0.f) ? 1.f : g.alpha; v.y *= (m.y > 0.f) ? 1.f : g.alpha;
+          v.z *= (m.z > 0.f) ? 1.f : g.alpha; v.w *= (m.w > 0.f) ? 1.f : g.alpha;
+        }
+      }
+      return v;
+    };
+
+    if (m0 + BM <= g.M) {
+      // full tile (wave-uniform test): no per-lane branches, so every aux load and
+      // every store is in flight at once instead of one round trip per pass
+      f32x4 m[PASSES];
+      if (EPI == EPI_LRELU_MASK && has_aux) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p)
+          m[p] = *reinterpret_cast<const f32x4 *>(g.aux + (int64_t)(m0 + p * ROWS_PER_PASS + lr0) * g.ldaux + col);
+      }
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const int lr = p * ROWS_PER_PASS + lr0;
         const f32x4 v = *reinterpret_cast<const f32x4 *>(smem + lr * BN + c4 * 4);
-        f32x4 mm = zero4;
-        if (EPI == EPI_LRELU_MASK && has_aux)
-          mm = *reinterpret_cast<const f32x4 *>(g.aux + (int64_t)row * g.ldaux + col);
-        *reinterpret_cast<f32x4 *>(C + (int64_t)row * g.ldc + col) = finish(v, mm);
+        *reinterpret_cast<f32x4 *>(C + (int64_t)(m0 + lr) * g.ldc + col) =
+            finish(v, (EPI == EPI_LRELU_MASK && has_aux) ? m[p] : zero4);
+      }
+    } else {
+      for (int p = 0; p < PASSES; ++p) {
+        const int lr = p * ROWS_PER_PASS + lr0;
+        const int row = m0 + lr;
+        if (row < g.M) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(smem + lr * BN + c4 * 4);
+          f32x4 mm = zero4;
+          if (EPI == EPI_LRELU_MASK && has_aux)
+            mm = *reinterpret_cast<const f32x4 *>(g.aux + (int64_t)row * g.ldaux + col);
+          *reinterpret_cast<f32x4 *>(C + (int64_t)row * g.ldc + col) = finish(v, mm);
+        }
       }
     }
   }
-
-#endif  // CDML_GEMM_LDS_EPILOGUE
 
   if (EPI == EPI_SLAB_COLSUM && do_colsum) {
     // threads with equal (t % C4) hold partial sums of the same 4 columns
@@ -633,10 +411,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32(GemmArgs g) {
     __syncthreads();
     if (t < C4) {
       f32x4 s = red[t];
-      for (int j = 1; j < KR; ++j) {
-        const f32x4 v = red[t + j * C4];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
+      for (int j = 1; j < KR; ++j) s += red[t + j * C4];
       *reinterpret_cast<f32x4 *>(g.colsum + (int64_t)split * g.N + n0 + t * 4) = s;
     }
   }
@@ -648,12 +423,9 @@ k_sum_slabs(const float *__restrict__ slabs, int64_t slab_stride, int splits, in
             float *__restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
-    float4 s = reinterpret_cast<const float4 *>(slabs)[i];
-    for (int z = 1; z < splits; ++z) {
-      const float4 v = reinterpret_cast<const float4 *>(slabs + (int64_t)z * slab_stride)[i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    reinterpret_cast<float4 *>(out)[i] = s;
+    f32x4 s = reinterpret_cast<const f32x4 *>(slabs)[i];
+    for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4 *>(slabs + (int64_t)z * slab_stride)[i];
+    reinterpret_cast<f32x4 *>(out)[i] = s;
   }
 }
 
@@ -667,41 +439,49 @@ k_sum_slabs_2d(const float *__restrict__ slabs, int64_t slab_stride, int splits,
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / n4;
     const int c = (int)(i - r * n4);
-    float4 s = reinterpret_cast<const float4 *>(slabs)[i];
-    for (int z = 1; z < splits; ++z) {
-      const float4 v = reinterpret_cast<const float4 *>(slabs + (int64_t)z * slab_stride)[i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    reinterpret_cast<float4 *>(out + r * ldo)[c] = s;
+    f32x4 s = reinterpret_cast<const f32x4 *>(slabs)[i];
+    for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4 *>(slabs + (int64_t)z * slab_stride)[i];
+    reinterpret_cast<f32x4 *>(out + r * ldo)[c] = s;
   }
 }
 
+// LEPI per layout: the C tile goes through LDS only for the data-gradient GEMM,
+// whose contraction is short (K = 256: 8 K-tiles per output tile) so the epilogue
+// is a visible share of the tile; the long-K kernels keep the small LDS footprint
+// that lets more blocks share a CU.
 template <bool AKC, bool BKC, int EPI>
 int launch_gemm(GemmArgs g, int tm_sel, int tn_sel, int splits, hipStream_t s) {
   const dim3 block(kThreads);
+  constexpr bool NT = AKC && BKC;
+  // (the forward kernel also gains ~2 % from it while its two stages are 64 KB anyway)
+  constexpr bool LEPI = NT || (AKC && CDML_GEMM_BK == 32);
+  constexpr int BKT = NT ? 32 : CDML_GEMM_BK, NB = NT ? 2 : CDML_GEMM_BLOCKS_PER_CU;
+  constexpr int NS = NT ? 2 : CDML_GEMM_STAGES;
   if (tm_sel == 2 && tn_sel == 2) {
     g.tiles_m = (g.M + 127) / 128; g.tiles_n = g.N / 128;
-    hipLaunchKernelGGL((k_gemm_f32<AKC, BKC, 2, 2, EPI>), dim3(g.tiles_m * g.tiles_n, splits), block, 0, s, g);
+    hipLaunchKernelGGL((k_gemm_f32<AKC, BKC, 2, 2, EPI, BKT, LEPI, NB, NS>), dim3(g.tiles_m * g.tiles_n, splits),
+                       block, 0, s, g);
   } else if (tm_sel == 1 && tn_sel == 2) {
     g.tiles_m = (g.M + 63) / 64; g.tiles_n = g.N / 128;
-    hipLaunchKernelGGL((k_gemm_f32<AKC, BKC, 1, 2, EPI>), dim3(g.tiles_m * g.tiles_n, splits), block, 0, s, g);
+    hipLaunchKernelGGL((k_gemm_f32<AKC, BKC, 1, 2, EPI, 32, AKC, 2, 2>), dim3(g.tiles_m * g.tiles_n, splits),
+                       block, 0, s, g);
   } else {
     g.tiles_m = (g.M + 63) / 64; g.tiles_n = g.N / 64;
-    hipLaunchKernelGGL((k_gemm_f32<AKC, BKC, 1, 1, EPI>), dim3(g.tiles_m * g.tiles_n, splits), block, 0, s, g);
+    hipLaunchKernelGGL((k_gemm_f32<AKC, BKC, 1, 1, EPI, 32, AKC, 2, 2>), dim3(g.tiles_m * g.tiles_n, splits),
+                       block, 0, s, g);
   }
   return check_launch("gemm_f32");
 }
 
 // Pick the largest tile that still gives the chip enough workgroups
 // (256 CUs x 2 resident blocks).
-void pick_tile(int M, int N, bool m_must_divide, int &tm, int &tn) {
+void pick_tile(int M, int N, int &tm, int &tn) {
   const int64_t want = 384;
   auto tiles = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * (N / bn); };
-  const bool ok128m = !m_must_divide || (M % 128 == 0);
-  if (N % 128 == 0 && ok128m && tiles(128, 128) >= want) { tm = 2; tn = 2; return; }
+  if (N % 128 == 0 && tiles(128, 128) >= want) { tm = 2; tn = 2; return; }
   if (N % 128 == 0 && tiles(64, 128) >= want) { tm = 1; tn = 2; return; }
   if (tiles(64, 64) >= want || N % 128 != 0) { tm = 1; tn = 1; return; }
-  if (ok128m && tiles(128, 128) >= 192) { tm = 2; tn = 2; return; }
+  if (tiles(128, 128) >= 192) { tm = 2; tn = 2; return; }
   tm = 1; tn = (tiles(64, 128) >= 128) ? 2 : 1;
 }
 
@@ -748,11 +528,13 @@ extern "C" int cdml_fc_lrelu_fwd(const float *x, int64_t ldx, const float *W, in
   if ((rc = check_mat("fc_lrelu_fwd x", x, ldx, K))) return rc;
   if ((rc = check_mat("fc_lrelu_fwd W", W, ldw, N))) return rc;
   if ((rc = check_mat("fc_lrelu_fwd y", y, ldy, N))) return rc;
+  CDML_REQUIRE((int64_t)K * ldw * 4 < (1ll << 31), CDML_E_UNSUPPORTED,
+               "fc_lrelu_fwd: weight matrix exceeds the 2 GiB buffer-descriptor range");
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = y; g.ldc = ldy;
   g.bias = b; g.alpha = alpha; g.M = M; g.N = N; g.K = K; g.k_per_split = K;
   int tm, tn;
-  pick_tile(M, N, false, tm, tn);
+  pick_tile(M, N, tm, tn);
   return launch_gemm<true, false, EPI_BIAS_LRELU>(g, tm, tn, 1, (hipStream_t)stream);
 }
 
@@ -771,7 +553,7 @@ extern "C" int cdml_fc_bwd_data(const float *dy, int64_t lddy, const float *W, i
   g.A = dy; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dx; g.ldc = lddx;
   g.aux = x_post; g.ldaux = ldxp; g.alpha = alpha; g.M = M; g.N = K; g.K = N; g.k_per_split = N;
   int tm, tn;
-  pick_tile(M, K, false, tm, tn);
+  pick_tile(M, K, tm, tn);
   return launch_gemm<true, true, EPI_LRELU_MASK>(g, tm, tn, 1, (hipStream_t)stream);
 }
 
@@ -791,6 +573,8 @@ extern "C" int cdml_fc_bwd_weight(const float *x, int64_t ldx, const float *dy, 
   if ((rc = check_mat("fc_bwd_weight x", x, ldx, K))) return rc;
   if ((rc = check_mat("fc_bwd_weight dy", dy, lddy, N))) return rc;
   if ((rc = check_mat("fc_bwd_weight dW", dW, lddw, N))) return rc;
+  CDML_REQUIRE((int64_t)M * ldx * 4 < (1ll << 31) && (int64_t)M * lddy * 4 < (1ll << 31), CDML_E_UNSUPPORTED,
+               "fc_bwd_weight: an operand exceeds the 2 GiB buffer-descriptor range (M=%d)", M);
   const size_t need = cdml_fc_bwd_weight_workspace(M, K, N);
   CDML_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), CDML_E_BADARG,
                "fc_bwd_weight: workspace of %zu bytes (16-B aligned) required", need);
@@ -803,7 +587,7 @@ extern "C" int cdml_fc_bwd_weight(const float *x, int64_t ldx, const float *dy, 
   g.C = direct ? dW : slabs; g.ldc = direct ? lddw : N;
   g.colsum = db ? (direct ? db : colsum) : nullptr; g.M = K; g.N = N; g.K = M;
   int kps = (M + splits - 1) / splits;
-  kps = (kps + BK - 1) / BK * BK;
+  kps = (kps + 31) / 32 * 32;
   g.k_per_split = kps;
   g.slab_stride = (int64_t)K * N;
   int tm, tn;

@@ -3,7 +3,9 @@
 the buffers of one actual training step (normalised U[0,1) rows, Xavier weights,
 real activations and gradients).  MFMA clocks depend on operand values (DVFS), so
 dense random [-1,1] operands under-report what the step sees by up to 1.6x.
-usage: python tools/gemm_bench.py [B] [iters] [inbatch|uniform]"""
+usage: python tools/gemm_bench.py [B] [iters] [inbatch|uniform] [lib]
+"lib" adds the vendor library (torch.mm -> hipBLASLt/rocBLAS sgemm, fp32, no fused
+epilogue) on the same operands as a yardstick."""
 import os
 import sys
 
@@ -37,6 +39,17 @@ cases = [
     ("dH1      NT", 2.0 * R * H * D, lambda: ops.fc_bwd_data(ws.dz2, p.W2, ws.h1, ws.dz1, R, L.Hp, L.Dp)),
     ("dW1      TN", 2.0 * R * F * H, lambda: ops.fc_bwd_weight(ws.x_hat, ws.dz1, p.gW1, p.gb1, ws.bw, R, L.Fp, L.Hp)),
 ]
+if len(sys.argv) > 4 and sys.argv[4] == "lib":
+    torch.backends.cuda.matmul.allow_tf32 = False
+    xh, h1, dz1, dz2 = ws.x_hat[:R], ws.h1[:R], ws.dz1[:R], ws.dz2[:R]
+    o1, o2, o3, o4 = torch.empty_like(h1), torch.empty_like(ws.z[:R]), torch.empty_like(p.W2), torch.empty_like(p.W1)
+    cases += [
+        ("lib fc1  NN", 2.0 * R * F * H, lambda: torch.mm(xh, p.W1, out=o1)),
+        ("lib fc2  NN", 2.0 * R * H * D, lambda: torch.mm(h1, p.W2, out=o2)),
+        ("lib dW2  TN", 2.0 * R * H * D, lambda: torch.mm(h1.t(), dz2, out=o3)),
+        ("lib dH1  NT", 2.0 * R * H * D, lambda: torch.mm(dz2, p.W2.t(), out=o1)),
+        ("lib dW1  TN", 2.0 * R * F * H, lambda: torch.mm(xh.t(), dz1, out=o4)),
+    ]
 total_ms, total_fl = 0.0, 0.0
 for name, flops, fn in cases:
     for _ in range(3):
