@@ -1,0 +1,85 @@
+"""Exact k-nearest-neighbour export behind the reference's ``calc_knn`` signature
+(faiss_knn.py:82-131).
+
+The reference l2-normalises the embeddings, builds a faiss ``IndexHNSWFlat`` and
+returns ``D`` (squared L2 distances, ascending) and ``I`` (int64 ids; the query
+itself is its own first neighbour -- "51 = 50 neighbours + the query").  HNSW is an
+approximation of the exact answer; this module computes the exact one by brute
+force on the GPU: blocks of inner products from the fp32 MFMA GEMM
+(``ops.fc_bwd_data`` without a mask = ``Q @ Bᵀ``), folded into per-query
+candidate lists by ``ops.knn_merge``.  Ties are ordered by id.  ``M``,
+``efConstruction`` and ``efSearch`` are accepted for call compatibility and ignored.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+Q_BLOCK = 4096      # query rows per GEMM; 4096 x 8192 scores = 128 MiB stay in the 256 MiB Infinity Cache
+B_BLOCK = 8192
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def _device_matrix(a, device, row_multiple):
+    """[n, D] -> zero-padded fp32 device matrix [n_pad, Dp] (Dp % 32 == 0)."""
+    t = a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a, dtype=np.float32))
+    t = t.to(device=device, dtype=torch.float32)
+    n, D = t.shape
+    out = torch.zeros((_round_up(n, row_multiple), _round_up(D, 32)), dtype=torch.float32, device=device)
+    out[:n, :D] = t
+    return out
+
+
+def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK, b_block=B_BLOCK):
+    """Device tensors (D [nq,k] fp32 squared L2 ascending, I [nq,k] int64; -1 where
+    the catalogue has fewer than k rows)."""
+    cap = ops.knn_list_capacity()
+    if not 1 <= k <= cap:
+        raise ValueError("nearest_num must be in [1, %d]" % cap)
+    nb, D = base.shape
+    nq = queries.shape[0]
+    if queries.shape[1] != D:
+        raise ValueError("query / catalogue dimension mismatch")
+    b_block = _round_up(min(b_block, _round_up(nb, 64)), 64)
+    B = _device_matrix(base, device, b_block)
+    same = queries is base
+    Q = B if same else _device_matrix(queries, device, 1)
+    Dp = B.shape[1]
+    if l2_norm:                                              # faiss_knn.py:99-104
+        ops.l2norm_fwd(B[:nb], Dp, B)
+        if not same:
+            ops.l2norm_fwd(Q[:nq], Dp, Q)
+    b_sq = torch.zeros(B.shape[0], dtype=torch.float32, device=device)
+    ops.row_sqnorm(B[:nb], Dp, b_sq)
+    if same:
+        q_sq = b_sq
+    else:
+        q_sq = torch.zeros(nq, dtype=torch.float32, device=device)
+        ops.row_sqnorm(Q[:nq], Dp, q_sq)
+    best_d = torch.empty((nq, cap), dtype=torch.float32, device=device)
+    best_i = torch.empty((nq, cap), dtype=torch.int32, device=device)
+    q_block = min(q_block, nq)
+    scores = torch.empty((q_block, b_block), dtype=torch.float32, device=device)
+    for q0 in range(0, nq, q_block):
+        m = min(q_block, nq - q0)
+        for c0 in range(0, B.shape[0], b_block):
+            # scores[m, b_block] = Q[q0:q0+m] @ B[c0:c0+b_block]^T   (exact fp32 MFMA)
+            ops.fc_bwd_data(Q[q0:q0 + m], B[c0:c0 + b_block], None, scores, m, b_block, Dp)
+            ops.knn_merge(scores, m, b_block, c0, nb, q_sq[q0:q0 + m], b_sq[c0:c0 + b_block], k,
+                          best_d[q0:q0 + m], best_i[q0:q0 + m], first=(c0 == 0))
+    I = best_i[:, :k].to(torch.int64)
+    I[I == 0x7fffffff] = -1
+    return best_d[:, :k].contiguous(), I
+
+
+def calc_knn(embeddings, q_embeddings=None, nearest_num=51, l2_norm=True, M=80, efConstruction=64,
+             efSearch=32, device="cuda:0"):
+    """(D, I) ndarrays as faiss ``index.search(q, nearest_num)`` returns them
+    (faiss_knn.py:128).  Like the reference, queries default to the catalogue."""
+    emb = embeddings if torch.is_tensor(embeddings) else np.asarray(embeddings, dtype=np.float32)
+    q = emb if q_embeddings is None else q_embeddings
+    D, I = knn_search(emb, q, int(nearest_num), l2_norm=l2_norm, device=device)
+    return D.cpu().numpy(), I.cpu().numpy()

@@ -175,6 +175,23 @@ def pair_dist(e, pairs, D, sqdist, dot, means=None):
          _p(dot), _p(means), _stream())
 
 
+# ------------------------------------------------- exact kNN export (N4) ------
+def knn_list_capacity():
+    return int(load_library().cdml_knn_list_capacity())
+
+
+def row_sqnorm(x, D, out):
+    xp, xld = _mat(x)
+    call("cdml_row_sqnorm", xp, xld, x.shape[0], D, _p(out), _stream())
+    return out
+
+
+def knn_merge(scores, nq, nb, col0, n_valid, q_sq, b_sq, k, best_d, best_i, first):
+    sp, sld = _mat(scores)
+    call("cdml_knn_merge", sp, sld, nq, nb, col0, n_valid, _p(q_sq), _p(b_sq), k, _p(best_d),
+         _p(best_i, torch.int32), int(bool(first)), _stream())
+
+
 # ------------------------------------------------- fusion towers (N4) ---------
 EW_MUL, EW_MUL_RES, EW_ADD = 0, 1, 2
 

@@ -202,6 +202,24 @@ int cdml_pair_dist(const float *e, int64_t lde, int n_rows, const int32_t *pairs
                    int P, int D, float *sqdist, float *dot, float *means,
                    cdml_stream_t stream);
 
+/* ---- exact kNN export (faiss_knn.py:82-131 `calc_knn`: squared-L2 distances D
+ * and neighbour ids I over the l2-normalised embeddings, nearest first, the
+ * query itself included; the reference asks faiss HNSW, this is the brute-force
+ * answer HNSW approximates).  The inner products of a query block with a
+ * catalogue block come from cdml_fc_bwd_data(dy=queries, W=catalogue block,
+ * x_post=NULL); cdml_knn_merge folds one such [nq][nb] block into the running
+ * per-query lists best_d/best_i [nq][CDML_KNN_LIST] (sorted by (distance, id);
+ * unused entries = +inf / INT32_MAX): d = q_sq[r] + b_sq[c] - 2*score, id = col0+c,
+ * ids >= n_valid (padding rows of the catalogue) are skipped.  first != 0 starts
+ * the lists.  k <= CDML_KNN_LIST; nb, lds multiples of 4. */
+#define CDML_KNN_LIST 128
+int cdml_knn_list_capacity(void);
+int cdml_row_sqnorm(const float *x, int64_t ldx, int n_rows, int D, float *out,
+                    cdml_stream_t stream);
+int cdml_knn_merge(const float *scores, int64_t lds, int nq, int nb, int col0,
+                   int n_valid, const float *q_sq, const float *b_sq, int k,
+                   float *best_d, int32_t *best_i, int first, cdml_stream_t stream);
+
 /* ---- reduced-precision tower (BASELINE config 4: fp16 catalogue + bf16 MFMA
  * projection; build-defined precision with its own tolerance, never the default).
  * bf16 / fp16 buffers are passed as uint16_t*.  Same layers as the fp32 entry

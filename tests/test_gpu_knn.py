@@ -1,0 +1,71 @@
+"""kNN export (faiss_knn.py:82-131) -- HIP brute force through the
+C ABI against the fp64 exact search of oracle/knn.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn as oknn
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5    # squared-L2 distance of unit vectors, fp32 MFMA vs fp64
+
+
+def check(D, I, Dref, Iref, dfull):
+    k = Dref.shape[1]
+    finite = np.isfinite(Dref)
+    assert np.array_equal(I[~finite], Iref[~finite])          # -1 where the catalogue runs out
+    assert np.abs(D[finite] - Dref[finite]).max() <= TOL
+    with np.errstate(invalid="ignore"):
+        assert (np.diff(D, axis=1)[finite[:, 1:]] >= 0).all() # ascending
+    for r in range(D.shape[0]):
+        if np.array_equal(I[r], Iref[r]):
+            continue
+        # ids may differ only where the exact distances are within the tolerance of each other
+        n = int(finite[r].sum())
+        assert len(set(I[r, :n])) == n
+        assert np.abs(dfull[r, I[r, :n]] - Dref[r, :n]).max() <= 2 * TOL
+
+
+def embeddings(n, D, seed):
+    rng = np.random.RandomState(seed)
+    return rng.randn(n, D).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,D,k", [(1000, 256, 51), (333, 48, 128), (20, 256, 51), (64, 32, 1)])
+def test_self_knn_matches_exact_search(n, D, k):
+    from cdml_amd import knn
+    e = embeddings(n, D, 0)
+    Dg, Ig = knn.calc_knn(e.copy(), nearest_num=k)
+    Dr, Ir, dfull = oknn.calc_knn_exact(e, nearest_num=k)
+    assert Dg.dtype == np.float32 and Ig.dtype == np.int64 and Dg.shape == (n, k)
+    check(Dg, Ig, Dr, Ir, dfull)
+    assert (Ig[:, 0] == np.arange(n)).all()                    # the query is its own nearest neighbour
+
+
+def test_separate_queries_many_blocks_and_ties():
+    from cdml_amd import knn
+    base = embeddings(20000, 256, 1)
+    base[5000:5016] = base[17]                                  # exact duplicates: ties ordered by id
+    q = np.concatenate([embeddings(300, 256, 2), base[17:18]])
+    D, I = knn.knn_search(torch.from_numpy(base), torch.from_numpy(q), 81, q_block=128, b_block=4096)
+    Dr, Ir, dfull = oknn.calc_knn_exact(base, q, 81)
+    check(D.cpu().numpy(), I.cpu().numpy(), Dr, Ir, dfull)
+    got = I[-1, :17].cpu().numpy()
+    assert sorted(got.tolist()) == [17] + list(range(5000, 5016))
+
+
+def test_unnormalised_distances():
+    from cdml_amd import knn
+    base, q = embeddings(500, 64, 3), embeddings(40, 64, 4)
+    D, I = knn.calc_knn(base, q, nearest_num=10, l2_norm=False)
+    Dr, Ir, dfull = oknn.calc_knn_exact(base, q, 10, l2_norm=False)
+    finite = np.isfinite(Dr)
+    assert np.abs(D - Dr)[finite].max() <= 1e-4 * Dr.max()     # |x|^2 ~ 64: relative tolerance
+    assert (I == Ir).mean() > 0.99
+
+
+def test_bad_k_is_refused():
+    from cdml_amd import knn
+    with pytest.raises(ValueError):
+        knn.calc_knn(embeddings(10, 32, 0), nearest_num=129)
