@@ -1,0 +1,32 @@
+// Shared between gemm_bf16.hip (128x128 kernel, transposes, dispatch) and
+// gemm_bf16_256.hip (256x256 ping-pong kernel).
+#pragma once
+#include "common.h"
+
+namespace cdml {
+
+using bf16 = __bf16;
+
+enum { BE_BIAS_LRELU_BF16 = 0, BE_BIAS_LRELU_F32 = 1, BE_MASK_BF16 = 2, BE_F32 = 3 };
+
+struct BArgs {
+  const bf16 *A; int64_t lda;
+  const bf16 *B; int64_t ldb;
+  void *C; int64_t ldc;
+  const float *bias;
+  const bf16 *aux; int64_t ldaux;
+  float alpha;
+  int M, N, K;
+  int k_per_split;
+  int64_t slab_stride;
+  int tiles_m, tiles_n;
+};
+
+// 256x256x64 kernel: true if the shape can use it (N % 256 == 0, K per split a
+// multiple of 128, operands inside the 2 GiB buffer-descriptor window).
+bool gemm_bf16_256_usable(int M, int N, int K, int64_t lda, int64_t ldb);
+int gemm_bf16_256_splits(int M, int N, int K);
+// g.tiles_m / g.tiles_n / g.k_per_split / g.C (slabs when splits > 1) set by the caller
+int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t stream);
+
+}  // namespace cdml

@@ -12,12 +12,14 @@
 // k_transpose_bf16.  Roofline: MFMA (2.5 PFLOP/s dense bf16); tile 128x128x64,
 // 4 waves as 2x2, wave tile 64x64, register-staged double-buffered LDS with 144-B
 // rows (conflict-free ds_read_b128), split-K slabs for the skinny weight gradient.
-#include "common.h"
+// Large products go to the 256x256 ping-pong kernel of gemm_bf16_256.hip; this one
+// keeps the shapes that kernel does not take (N % 256, K % 128, few tiles).
+#include <stdlib.h>
+#include "gemm_bf16.h"
 
 namespace cdml {
 namespace {
 
-using bf16 = __bf16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -26,21 +28,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kThreads = 256;
 constexpr int BM = 128, BN = 128, BKB = 64;
 constexpr int ROWB = BKB + 8;  // bf16 per LDS row: 144 B, banks 36r mod 64 -> conflict-free b128 reads
-
-enum { BE_BIAS_LRELU_BF16 = 0, BE_BIAS_LRELU_F32 = 1, BE_MASK_BF16 = 2, BE_F32 = 3 };
-
-struct BArgs {
-  const bf16 *A; int64_t lda;
-  const bf16 *B; int64_t ldb;
-  void *C; int64_t ldc;
-  const float *bias;
-  const bf16 *aux; int64_t ldaux;
-  float alpha;
-  int M, N, K;
-  int k_per_split;
-  int64_t slab_stride;
-  int tiles_m, tiles_n;
-};
 
 template <int EPI>
 __global__ void __launch_bounds__(kThreads, 2) k_gemm_bf16_nt(BArgs g) {
@@ -357,9 +344,23 @@ int grid1d(int64_t n, int per_thread) {
 
 using namespace cdml;
 
+// 0 = choose by shape, 128 / 256 = force that kernel where it applies (A/B runs)
+static int forced_tile() {
+  const char *e = getenv("CDML_BF16_TILE");     // read per call: tests flip it
+  return e ? atoi(e) : 0;
+}
+
+static bool use_256(int epilogue, int M, int N, int K, int64_t lda, int64_t ldb) {
+  if (forced_tile() == 128 || !gemm_bf16_256_usable(M, N, K, lda, ldb)) return false;
+  if (forced_tile() == 256) return true;
+  const int64_t tiles = (int64_t)((M + 255) / 256) * (N / 256);
+  return K >= 256 && (epilogue == BE_F32 ? tiles * gemm_bf16_256_splits(M, N, K) >= 128 : tiles >= 192);
+}
+
 extern "C" size_t cdml_gemm_bf16_workspace(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0 || N % BN || K % BKB) return 0;
-  const int splits = bf16_splits(M, N, K);
+  int splits = bf16_splits(M, N, K);             // enough for whichever kernel is dispatched
+  if (gemm_bf16_256_usable(M, N, K, K, K)) splits = max(splits, gemm_bf16_256_splits(M, N, K));
   return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
@@ -384,19 +385,26 @@ extern "C" int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda, c
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = N / BN;
   hipStream_t s = (hipStream_t)stream;
   const dim3 block(kThreads);
+  const bool big = use_256(epilogue, M, N, K, lda, ldb);
   int splits = 1;
   if (epilogue == BE_F32) {
-    splits = bf16_splits(M, N, K);
+    splits = big ? gemm_bf16_256_splits(M, N, K) : bf16_splits(M, N, K);
     if (splits > 1) {
       const size_t need = (size_t)splits * M * N * sizeof(float);
       CDML_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), CDML_E_BADARG,
                    "gemm_bf16_nt: split-K workspace of %zu bytes required", need);
+      const int kq = big ? 2 * BKB : BKB;        // the 256 kernel walks K-tiles in pairs
       int kps = (K + splits - 1) / splits;
-      g.k_per_split = (kps + BKB - 1) / BKB * BKB;
+      g.k_per_split = (kps + kq - 1) / kq * kq;
       g.slab_stride = (int64_t)M * N;
       g.C = workspace; g.ldc = N;
     }
   }
+  int rc;
+  if (big) {
+    g.tiles_m = (M + 255) / 256; g.tiles_n = N / 256;
+    rc = launch_gemm_bf16_256(g, epilogue, splits, s);
+  } else {
   const dim3 grid(g.tiles_m * g.tiles_n, splits);
   switch (epilogue) {
     case BE_BIAS_LRELU_BF16: hipLaunchKernelGGL((k_gemm_bf16_nt<BE_BIAS_LRELU_BF16>), grid, block, 0, s, g); break;
@@ -404,7 +412,8 @@ extern "C" int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda, c
     case BE_MASK_BF16: hipLaunchKernelGGL((k_gemm_bf16_nt<BE_MASK_BF16>), grid, block, 0, s, g); break;
     default: hipLaunchKernelGGL((k_gemm_bf16_nt<BE_F32>), grid, block, 0, s, g); break;
   }
-  int rc = check_launch("gemm_bf16_nt");
+  rc = check_launch("gemm_bf16_nt");
+  }
   if (rc || splits == 1) return rc;
   hipLaunchKernelGGL(k_sum_slabs_f32, dim3(grid1d((int64_t)M * N / 4, 1)), block, 0, s,
                      static_cast<const float *>(workspace), g.slab_stride, splits, M, N,

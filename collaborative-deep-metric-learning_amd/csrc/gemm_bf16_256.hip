@@ -1,0 +1,398 @@
+// bf16 projection GEMM, large-tile form: C[M][N] = epilogue(A[M][K] . B[N][K]^T),
+// both operands k-contiguous bf16, fp32 accumulation (v_mfma_f32_32x32x16_bf16).
+// Same layers and epilogues as k_gemm_bf16_nt (models.py:59-60, train.py:141 at
+// BASELINE config 4's precision); this kernel is the one the big products run on.
+//
+// Structure (one block per CU, 512 threads, 128 KiB LDS):
+//   * tile 256x256x64; 8 waves = 2 row groups x 4 column strips, wave tile 128x64
+//     (8 accumulators of 32x32);
+//   * operands reach LDS by LDS-DMA (buffer_load_dwordx4 ... lds) in full 128-B
+//     rows; a K-tile is four 16-KiB "half images" -- A-h0 / A-h1 hold the first /
+//     second 64 rows of each row group, B-h0 / B-h1 the first / second 32 columns of
+//     each strip -- so that an image is read in exactly ONE phase of the K-tile and
+//     can be refilled for tile t+2 while tile t is still being multiplied;
+//   * a K-tile is four phases, one output quadrant (64x32 per wave, full K=64, 8
+//     MFMAs) each: Q00 needs A-h0,B-h0 (12 ds_read_b128), Q01 needs B-h1 (4), Q11
+//     needs A-h1 (8), Q10 reuses registers (0).  Each phase = [fragment reads + one
+//     half-image DMA] barrier [8 MFMAs] barrier;
+//   * the two row groups run one barrier apart (ping-pong): while one group's waves
+//     issue MFMAs the other group's waves, on the same SIMDs, issue their LDS reads
+//     and DMA, so the matrix pipe always has a wave feeding it;
+//   * the DMA is never drained inside the loop: each half image is waited for (counted
+//     s_waitcnt vmcnt(10), five newer half images stay in flight) in the phase before
+//     the one that reads it, 5-6 phases after it was issued.
+//
+// Hazards, in phases of a K-tile t living in LDS buffer t&1 (group 1 runs one
+// barrier behind group 0; every phase has two barriers):
+//   RAW  tile t+1's images were issued in phases 2,3,4 of tile t-1 (B-h0, A-h0, B-h1)
+//        and phase 1 of tile t (A-h1) and are first read in phases 1,1,2,3 of tile
+//        t+1; every wave retires its own pieces in the phase before that read (phase 4
+//        of tile t, phases 1 and 2 of tile t+1) BEFORE that phase's first barrier, so
+//        the read comes two barriers later for either group.
+//   WAR  B-h0 is read in phase 1 and those reads are retired (lgkmcnt(8): LDS reads
+//        return in order and the B reads are issued first) before phase 1's first
+//        barrier, so it is refilled in phase 2; A-h0 (read phase 1, retired after the
+//        barrier) in phase 3; B-h1 (read phase 2) in phase 4; A-h1 (read phase 3) in
+//        phase 1 of the next tile: always >= 2 barriers after the lagging group's
+//        reads retired.
+#include "gemm_bf16.h"
+
+namespace cdml {
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+constexpr int kT = 512;
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int IMG = 16384;       // one half image: 128 rows x 128 B
+constexpr int BUF = 4 * IMG;     // A-h0 | B-h0 | A-h1 | B-h1
+constexpr int SMEM = 2 * BUF;    // 128 KiB
+
+__device__ __forceinline__ uint32_t lds_off(const void *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+// 64 lanes x 16 B through a buffer descriptor into LDS at m0 + lane*16; lanes whose
+// offset is outside the descriptor's range deliver zeros.  Inline asm: invisible to
+// hipcc's wait-count pass, the kernel counts these loads itself.
+__device__ __forceinline__ void dma(i32x4 srd, uint32_t voff, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_base), "v"(voff), "s"(srd) : "memory", "m0");
+}
+__device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
+  const uint64_t a = (uint64_t)(uintptr_t)base;
+  i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffff));  // stride 0
+  r.z = __builtin_amdgcn_readfirstlane((int)(bytes > 0 ? bytes : 0));
+  r.w = 0x00020000;
+  return r;
+}
+
+// Every half image is waited for one phase before the phase that reads it, which
+// always leaves the five newest images (10 wave-instructions) in flight.
+#ifndef CDML_BF16_PHASES
+#define CDML_BF16_PHASES 2       // phases per K-tile: 4 (quadrants) or 2 (half tiles)
+#endif
+#ifndef CDML_BF16_INFLIGHT
+#define CDML_BF16_INFLIGHT 10
+#endif
+#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CDML_BF16_INFLIGHT) : "memory")
+
+#define CDML_BARRIER()                         \
+  do {                                         \
+    __builtin_amdgcn_sched_barrier(0);         \
+    asm volatile("s_barrier" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);         \
+  } while (0)
+
+template <int EPI>
+__global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2, wc = wave & 3;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, tm, tn);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int split = blockIdx.y;
+  const int k_begin = split * g.k_per_split;
+  const int k_end = min(g.K, k_begin + g.k_per_split);
+  const int n_ktiles = k_end > k_begin ? (k_end - k_begin) / TK : 0;   // even (host)
+
+  const i32x4 srd_a = make_srd(g.A, (int64_t)g.M * g.lda * 2);
+  const i32x4 srd_b = make_srd(g.B, (int64_t)g.N * g.ldb * 2);
+
+  // ---- DMA lane constants: piece pc = wave*2+i covers image rows pc*8 .. pc*8+7 ----
+  uint32_t va[2], vb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 8 + (lane >> 3);
+    const int sc = (lane & 7) ^ ((r >> 1) & 7);              // swizzle on the SOURCE chunk
+    const int row_a = (r >> 6) * 128 + (r & 63);             // A-h0 (A-h1: + 64 rows)
+    const int col_b = (r >> 5) * 64 + (r & 31);              // B-h0 (B-h1: + 32 columns)
+    va[i] = (uint32_t)(((int64_t)(m0 + row_a) * g.lda + sc * 8) * 2);
+    vb[i] = (uint32_t)(((int64_t)(n0 + col_b) * g.ldb + sc * 8) * 2);
+  }
+  const uint32_t d_a = (uint32_t)(64 * g.lda * 2), d_b = (uint32_t)(32 * g.ldb * 2);
+  const uint32_t lds_piece = __builtin_amdgcn_readfirstlane(lds_off(smem) + wave * 2048);
+
+  // img 0 = A, 1 = B; hh = half; tile beyond the split's range -> every lane out of range (zeros)
+  auto stage = [&](int img, int hh, int tile, int buf) {
+    const uint32_t kb = tile < n_ktiles ? (uint32_t)((k_begin + tile * TK) * 2) : 0x80000000u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t voff = (img == 0 ? va[i] + hh * d_a : vb[i] + hh * d_b) + kb;
+      dma(img == 0 ? srd_a : srd_b, voff, lds_piece + i * 1024 + buf * BUF + (hh * 2 + img) * IMG);
+    }
+  };
+
+  // ---- fragment reads: lane (l31, h) holds k = 16*ks + 8*h .. +7 of image row l31 ----
+  const int x = (l31 >> 1) & 7;
+  const unsigned char *a_rd = smem + (grp * 64 + l31) * 128;
+  const unsigned char *b_rd = smem + IMG + (wc * 32 + l31) * 128;
+  int sw[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) sw[ks] = ((2 * ks + h) ^ x) * 16;
+  auto read_a = [&](int buf, int hh, int mi, int ks) {
+    return *reinterpret_cast<const bf16x8 *>(a_rd + buf * BUF + hh * 2 * IMG + mi * 4096 + sw[ks]);
+  };
+  auto read_b = [&](int buf, int hh, int ks) {
+    return *reinterpret_cast<const bf16x8 *>(b_rd + buf * BUF + hh * 2 * IMG + sw[ks]);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bf16x8 fa[2][4], fb0[4], fb1[4];
+
+  auto do_tile = [&](const int buf, const int tile) {
+    // ---- phase 1: Q00 = A-h0 x B-h0 ----
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb0[ks] = read_b(buf, 0, ks);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = read_a(buf, 0, mi, ks);
+    stage(0, 1, tile + 1, buf ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four B-h0 reads have returned
+    DMA_WAIT();                                          // B-h1 of this tile (read next phase)
+    CDML_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb0[ks], acc[mi][0], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    CDML_BARRIER();
+    // ---- phase 2: Q01 = A-h0 x B-h1 ----
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb1[ks] = read_b(buf, 1, ks);
+    stage(1, 0, tile + 2, buf);
+    DMA_WAIT();                                          // A-h1 of this tile (read next phase)
+    CDML_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb1[ks], acc[mi][1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    CDML_BARRIER();
+    // ---- phase 3: Q11 = A-h1 x B-h1 ----
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = read_a(buf, 1, mi, ks);
+    stage(0, 0, tile + 2, buf);
+    CDML_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        acc[2 + mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb1[ks], acc[2 + mi][1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    CDML_BARRIER();
+    // ---- phase 4: Q10 = A-h1 x B-h0 (registers only) ----
+    stage(1, 1, tile + 2, buf);
+    DMA_WAIT();                                          // B-h0 and A-h0 of tile+1 (read next phase)
+    CDML_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        acc[2 + mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb0[ks], acc[2 + mi][0], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    CDML_BARRIER();
+  };
+
+  // Two-phase form of the K-tile (CDML_BF16_PHASES == 2): phase A = Q00 + Q01 (16 fragment
+  // reads, 16 MFMAs), phase B = Q11 + Q10 (8 reads, 16 MFMAs): half the barriers, and the
+  // read parts have a 512-cycle MFMA part of the other group to hide under.  Fragment reads
+  // are retired (lgkmcnt(0)) BEFORE the phase's first barrier, so an image is dead one
+  // barrier after the lagging group read it:
+  //   phase A of tile T issues A-h0, A-h1 of tile T+1 (other buffer; last read in tile T-1);
+  //   phase B of tile T issues B-h0, B-h1 of tile T+2 (this buffer; read in phase A of T);
+  //   phase B waits vmcnt(6): B-h0, B-h1, A-h0 of T+1 landed (read in phase A of T+1);
+  //   phase A waits vmcnt(8): A-h1 of T landed (read in phase B of T).
+  auto do_tile2 = [&](const int buf, const int tile) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb0[ks] = read_b(buf, 0, ks);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb1[ks] = read_b(buf, 1, ks);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = read_a(buf, 0, mi, ks);
+    stage(0, 0, tile + 1, buf ^ 1);
+    stage(0, 1, tile + 1, buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CDML_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb0[ks], acc[mi][0], 0, 0, 0);
+        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb1[ks], acc[mi][1], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    CDML_BARRIER();
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = read_a(buf, 1, mi, ks);
+    stage(1, 0, tile + 2, buf);
+    stage(1, 1, tile + 2, buf);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CDML_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        acc[2 + mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb0[ks], acc[2 + mi][0], 0, 0, 0);
+        acc[2 + mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb1[ks], acc[2 + mi][1], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    CDML_BARRIER();
+  };
+
+  // prologue: the steady state at the first phase of tile 0
+#if CDML_BF16_PHASES == 4
+  stage(1, 0, 0, 0); stage(0, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 1, 0, 0);
+  stage(1, 0, 1, 1); stage(0, 0, 1, 1); stage(1, 1, 1, 1);
+  DMA_WAIT();
+  CDML_BARRIER();
+  if (grp == 1) CDML_BARRIER();                          // group 1 runs one barrier behind
+  for (int tile = 0; tile < n_ktiles; tile += 2) {
+    do_tile(0, tile);
+    do_tile(1, tile + 1);
+  }
+#else
+  stage(1, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 0, 0, 0); stage(0, 1, 0, 0);
+  stage(1, 0, 1, 1); stage(1, 1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  CDML_BARRIER();
+  if (grp == 1) CDML_BARRIER();                          // group 1 runs one barrier behind
+  for (int tile = 0; tile < n_ktiles; tile += 2) {
+    do_tile2(0, tile);
+    do_tile2(1, tile + 1);
+  }
+#endif
+  if (grp == 0) CDML_BARRIER();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the out-of-range tail DMAs still write zeros
+  CDML_BARRIER();
+
+  // ---- epilogue: per wave, 32x64 strips through its private 16 KiB of LDS ----
+  float *sC = reinterpret_cast<float *>(smem + wave * 16384);
+  const int c4 = lane & 15;
+  const int gcol = n0 + wc * 64 + c4 * 4;
+  f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + gcol);
+  const bool has_aux = (EPI == BE_MASK_BF16) && g.aux != nullptr;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    float *strip = sC + (rt & 1) * 2048;                 // alternate halves: no wait for the readers
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        strip[row * 64 + ct * 32 + l31] = acc[rt][ct][r];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int lr = p * 4 + (lane >> 4);
+      const int row = m0 + grp * 128 + rt * 32 + lr;
+      f32x4 v = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + c4 * 4);
+      if (row >= g.M) continue;
+      if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) {
+        v += bias4;
+        v.x = fmaxf(v.x, v.x * g.alpha); v.y = fmaxf(v.y, v.y * g.alpha);
+        v.z = fmaxf(v.z, v.z * g.alpha); v.w = fmaxf(v.w, v.w * g.alpha);
+      } else if (EPI == BE_MASK_BF16) {
+        if (has_aux) {
+          const bf16x4 m = *reinterpret_cast<const bf16x4 *>(g.aux + (int64_t)row * g.ldaux + gcol);
+          v.x *= ((float)m.x > 0.f) ? 1.f : g.alpha; v.y *= ((float)m.y > 0.f) ? 1.f : g.alpha;
+          v.z *= ((float)m.z > 0.f) ? 1.f : g.alpha; v.w *= ((float)m.w > 0.f) ? 1.f : g.alpha;
+        }
+      }
+      if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_MASK_BF16) {
+        bf16x4 o;
+        o.x = (bf16)v.x; o.y = (bf16)v.y; o.z = (bf16)v.z; o.w = (bf16)v.w;
+        *reinterpret_cast<bf16x4 *>(static_cast<bf16 *>(g.C) + (int64_t)row * g.ldc + gcol) = o;
+      } else {
+        float *C = static_cast<float *>(g.C) + (EPI == BE_F32 ? (int64_t)split * g.slab_stride : 0);
+        *reinterpret_cast<f32x4 *>(C + (int64_t)row * g.ldc + gcol) = v;
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch(const BArgs &g, int splits, hipStream_t s) {
+  static bool configured = false;   // raising the dynamic-LDS limit is idempotent; a race only repeats it
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16_256: cannot reserve %d B of LDS: %s", SMEM,
+                                     hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL((k_gemm_bf16_256<EPI>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), SMEM, s, g);
+  return check_launch("gemm_bf16_256");
+}
+
+}  // namespace
+
+bool gemm_bf16_256_usable(int M, int N, int K, int64_t lda, int64_t ldb) {
+  if (N % TN || K % (2 * TK) || M < 1) return false;
+  const int64_t lim = (int64_t)1 << 31;
+  return ((int64_t)M + TM) * lda * 2 < lim && (int64_t)N * ldb * 2 < lim;
+}
+
+// split-K for the skinny weight gradients: fill one round of 256 CUs as evenly as
+// possible with the fewest slabs
+int gemm_bf16_256_splits(int M, int N, int K) {
+  const int64_t tiles = (int64_t)((M + TM - 1) / TM) * (N / TN);
+  const int max_by_k = K / 1024 > 0 ? K / 1024 : 1;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int s = 1; s <= 16 && s <= max_by_k; ++s) {
+    const int64_t blocks = tiles * s;
+    const double eff = (double)blocks / (double)(((blocks + kNumCU - 1) / kNumCU) * kNumCU);
+    if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+  }
+  return best;
+}
+
+int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t s) {
+  switch (epilogue) {
+    case BE_BIAS_LRELU_BF16: return launch<BE_BIAS_LRELU_BF16>(g, splits, s);
+    case BE_BIAS_LRELU_F32: return launch<BE_BIAS_LRELU_F32>(g, splits, s);
+    case BE_MASK_BF16: return launch<BE_MASK_BF16>(g, splits, s);
+    default: return launch<BE_F32>(g, splits, s);
+  }
+}
+
+}  // namespace cdml

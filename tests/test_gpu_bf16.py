@@ -34,8 +34,14 @@ def dbf(x, dev):
     return torch.as_tensor(np.asarray(x, np.float32)).to(dev).bfloat16()
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 192), (384, 5120, 1536), (77, 128, 5120)])
-def test_gemm_bf16_epilogues(cd, M, N, K):
+@pytest.mark.parametrize("M,N,K,tile", [(128, 128, 64, 0), (200, 256, 192, 0), (384, 5120, 1536, 128),
+                                        (77, 128, 5120, 0),
+                                        # the 256x256 ping-pong kernel: minimal, ragged M, long K, many tiles
+                                        (256, 256, 128, 256), (700, 512, 384, 256), (1000, 1024, 1536, 256),
+                                        (77, 256, 5120, 256), (3100, 4096, 512, 0)])
+def test_gemm_bf16_epilogues(cd, M, N, K, tile, monkeypatch):
+    if tile:
+        monkeypatch.setenv("CDML_BF16_TILE", str(tile))
     rng = np.random.RandomState(M + N)
     A, B = rng.randn(M, K) / np.sqrt(K), rng.randn(N, K)
     bias, aux = rng.randn(N) * 0.1, rng.randn(M, N)

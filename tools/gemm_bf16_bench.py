@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""bf16 projection GEMMs at the config-4 shapes (R rows per GPU), 128x128 kernel vs
+the 256x256 ping-pong kernel (CDML_BF16_TILE).  Operands: N(0,1)/sqrt(K) and N(0,1)
+(dense random -- the pessimistic case for MFMA clocks).
+usage: python tools/gemm_bf16_bench.py [R] [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cdml_amd import ops  # noqa: E402
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 24576
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device("cuda:0")
+F, H, D = 1536, 5120, 256
+cases = [("fc1  R x H x F", ops.BE_BIAS_LRELU_BF16, R, H, F), ("fc2  R x D x H", ops.BE_BIAS_LRELU_F32, R, D, H),
+         ("dH1  R x H x D", ops.BE_MASK_BF16, R, H, D), ("dW1  F x H x R", ops.BE_F32, F, H, R),
+         ("dW2  H x D x R", ops.BE_F32, H, D, R)]
+for name, epi, M, N, K in cases:
+    A = (torch.randn(M, K, device=dev) / K ** 0.5).bfloat16()
+    B = torch.randn(N, K, device=dev).bfloat16()
+    bias = torch.zeros(N, device=dev)
+    out = torch.empty((M, N), device=dev, dtype=torch.float32 if epi in (ops.BE_BIAS_LRELU_F32, ops.BE_F32) else torch.bfloat16)
+    ws = torch.empty(max(ops.gemm_bf16_workspace(M, N, K), 16) // 4, device=dev)
+    res = {}
+    for tile in ("128", "256"):
+        os.environ["CDML_BF16_TILE"] = tile
+        fn = lambda: ops.gemm_bf16_nt(epi, A, B, out, M, N, K, bias=bias, workspace=ws)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / iters
+        res[tile] = (ms, out.float().abs().sum().item())
+    fl = 2.0 * M * N * K
+    print("%-16s 128: %7.4f ms %7.1f TF (%.3f) | 256: %7.4f ms %7.1f TF (%.3f) | checksum rel diff %.2e"
+          % (name, res["128"][0], fl / res["128"][0] / 1e9, fl / res["128"][0] / 1e9 / 2500,
+             res["256"][0], fl / res["256"][0] / 1e9, fl / res["256"][0] / 1e9 / 2500,
+             abs(res["128"][1] - res["256"][1]) / max(res["128"][1], 1e-9)))
