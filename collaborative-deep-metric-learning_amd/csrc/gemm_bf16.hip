@@ -421,6 +421,50 @@ extern "C" int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda, c
   return check_launch("gemm_bf16_nt combine");
 }
 
+extern "C" int cdml_gemm_bf16_tn_supported(int M, int N, int K, int64_t lda, int64_t ldb) {
+  return gemm_bf16_tn_usable(M, N, K, lda, ldb) ? 1 : 0;
+}
+
+extern "C" size_t cdml_gemm_bf16_tn_workspace(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int splits = gemm_bf16_256_splits(M, N, K);
+  return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int cdml_gemm_bf16_tn(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t ldb, int M,
+                                 int N, int K, float *C, int64_t ldc, void *workspace,
+                                 size_t workspace_bytes, cdml_stream_t stream) {
+  CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16_tn: bad argument");
+  CDML_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && (lda & 7) == 0 && (ldb & 7) == 0 &&
+                   (ldc & 3) == 0 && lda >= M && ldb >= N && ldc >= N,
+               CDML_E_ALIGN, "gemm_bf16_tn: 16-B aligned bases, lda/ldb multiples of 8, ldc of 4");
+  CDML_REQUIRE(gemm_bf16_tn_usable(M, N, K, lda, ldb), CDML_E_UNSUPPORTED,
+               "gemm_bf16_tn: needs M, N multiples of 256 and K of 128 (got M=%d N=%d K=%d); use "
+               "cdml_transpose_to_bf16 + cdml_gemm_bf16_nt for other shapes", M, N, K);
+  BArgs g{};
+  g.A = reinterpret_cast<const bf16 *>(A); g.lda = lda;
+  g.B = reinterpret_cast<const bf16 *>(B); g.ldb = ldb;
+  g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.k_per_split = K;
+  g.tiles_m = M / 256; g.tiles_n = N / 256;
+  const int splits = gemm_bf16_256_splits(M, N, K);
+  hipStream_t s = (hipStream_t)stream;
+  if (splits > 1) {
+    const size_t need = (size_t)splits * M * N * sizeof(float);
+    CDML_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), CDML_E_BADARG,
+                 "gemm_bf16_tn: split-K workspace of %zu bytes required", need);
+    const int kps = (K + splits - 1) / splits;
+    g.k_per_split = (kps + 127) / 128 * 128;
+    g.slab_stride = (int64_t)M * N;
+    g.C = workspace; g.ldc = N;
+  }
+  int rc = launch_gemm_bf16_tn(g, splits, s);
+  if (rc || splits == 1) return rc;
+  hipLaunchKernelGGL(k_sum_slabs_f32, dim3(grid1d((int64_t)M * N / 4, 1)), dim3(kThreads), 0, s,
+                     static_cast<const float *>(workspace), g.slab_stride, splits, M, N, C, ldc);
+  return check_launch("gemm_bf16_tn combine");
+}
+
 extern "C" int cdml_transpose_to_bf16(int src_is_f32, const void *src, int64_t lds_, int rows, int cols,
                                       uint16_t *dst, int64_t ldd, cdml_stream_t stream) {
   CDML_REQUIRE(src && dst && rows > 0 && cols > 0 && lds_ >= cols && ldd >= rows, CDML_E_BADARG,

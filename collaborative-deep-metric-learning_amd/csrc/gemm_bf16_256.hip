@@ -47,7 +47,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
 constexpr int kT = 512;
-constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int kTileM = 256, kTileN = 256, kTileK = 64;
 constexpr int IMG = 16384;       // one half image: 128 rows x 128 B
 constexpr int BUF = 4 * IMG;     // A-h0 | B-h0 | A-h1 | B-h1
 constexpr int SMEM = 2 * BUF;    // 128 KiB
@@ -89,8 +89,18 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
     __builtin_amdgcn_sched_barrier(0);         \
   } while (0)
 
-template <int EPI>
+// TN = false: A[M][K], B[N][K] (k-contiguous rows; fragments by ds_read_b128).
+// TN = true : A[K][M], B[K][N] (the weight gradients x^T.dy: the contraction runs over
+//   the batch rows, so operand rows are k).  Half images are [64 k][128 columns] with
+//   256-B rows, A-h0/A-h1 = columns 0-127 / 128-255 of the tile (a row group owns 64 of
+//   each), B likewise (a strip owns 32 of each); chunk swizzle
+//   ch ^ (((row&3)<<2) | ((row>>2)&3)) on the DMA source; fragments come out of LDS
+//   already transposed through ds_read_b64_tr_b16 (two per 32x16 fragment), so no
+//   transposed copy of the activations is ever made.
+template <bool TN, int EPI>
 __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
+  static_assert(!TN || EPI == BE_F32, "the k-strided form only serves the weight gradients");
+  static_assert(!TN || CDML_BF16_PHASES == 2, "the quadrant schedule counts ds_read_b128 returns");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const int t = threadIdx.x;
@@ -101,32 +111,41 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
 
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, tm, tn);
-  const int m0 = tm * TM, n0 = tn * TN;
+  const int m0 = tm * kTileM, n0 = tn * kTileN;
   const int split = blockIdx.y;
   const int k_begin = split * g.k_per_split;
   const int k_end = min(g.K, k_begin + g.k_per_split);
-  const int n_ktiles = k_end > k_begin ? (k_end - k_begin) / TK : 0;   // even (host)
+  const int n_ktiles = k_end > k_begin ? (k_end - k_begin) / kTileK : 0;   // even (host)
 
-  const i32x4 srd_a = make_srd(g.A, (int64_t)g.M * g.lda * 2);
-  const i32x4 srd_b = make_srd(g.B, (int64_t)g.N * g.ldb * 2);
+  const i32x4 srd_a = make_srd(g.A, (int64_t)(TN ? g.K : g.M) * g.lda * 2);
+  const i32x4 srd_b = make_srd(g.B, (int64_t)(TN ? g.K : g.N) * g.ldb * 2);
 
-  // ---- DMA lane constants: piece pc = wave*2+i covers image rows pc*8 .. pc*8+7 ----
+  // ---- DMA lane constants.  NT: piece pc = wave*2+i covers image rows pc*8 .. pc*8+7
+  //      (128-B rows); TN: k-rows pc*4 .. pc*4+3 (256-B rows) ----
   uint32_t va[2], vb[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int r = (wave * 2 + i) * 8 + (lane >> 3);
-    const int sc = (lane & 7) ^ ((r >> 1) & 7);              // swizzle on the SOURCE chunk
-    const int row_a = (r >> 6) * 128 + (r & 63);             // A-h0 (A-h1: + 64 rows)
-    const int col_b = (r >> 5) * 64 + (r & 31);              // B-h0 (B-h1: + 32 columns)
-    va[i] = (uint32_t)(((int64_t)(m0 + row_a) * g.lda + sc * 8) * 2);
-    vb[i] = (uint32_t)(((int64_t)(n0 + col_b) * g.ldb + sc * 8) * 2);
+    if constexpr (!TN) {
+      const int r = (wave * 2 + i) * 8 + (lane >> 3);
+      const int sc = (lane & 7) ^ ((r >> 1) & 7);            // swizzle on the SOURCE chunk
+      const int row_a = (r >> 6) * 128 + (r & 63);           // A-h0 (A-h1: + 64 rows)
+      const int col_b = (r >> 5) * 64 + (r & 31);            // B-h0 (B-h1: + 32 columns)
+      va[i] = (uint32_t)(((int64_t)(m0 + row_a) * g.lda + sc * 8) * 2);
+      vb[i] = (uint32_t)(((int64_t)(n0 + col_b) * g.ldb + sc * 8) * 2);
+    } else {
+      const int r = (wave * 2 + i) * 4 + (lane >> 4);
+      const int sc = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
+      va[i] = (uint32_t)(((int64_t)r * g.lda + m0 + sc * 8) * 2);   // A-h1: + 128 columns
+      vb[i] = (uint32_t)(((int64_t)r * g.ldb + n0 + sc * 8) * 2);
+    }
   }
-  const uint32_t d_a = (uint32_t)(64 * g.lda * 2), d_b = (uint32_t)(32 * g.ldb * 2);
+  const uint32_t d_a = TN ? 256u : (uint32_t)(64 * g.lda * 2), d_b = TN ? 256u : (uint32_t)(32 * g.ldb * 2);
   const uint32_t lds_piece = __builtin_amdgcn_readfirstlane(lds_off(smem) + wave * 2048);
 
   // img 0 = A, 1 = B; hh = half; tile beyond the split's range -> every lane out of range (zeros)
   auto stage = [&](int img, int hh, int tile, int buf) {
-    const uint32_t kb = tile < n_ktiles ? (uint32_t)((k_begin + tile * TK) * 2) : 0x80000000u;
+    const int64_t k_elems = (int64_t)(k_begin + tile * kTileK) * (TN ? (img == 0 ? g.lda : g.ldb) : 1);
+    const uint32_t kb = tile < n_ktiles ? (uint32_t)(k_elems * 2) : 0x80000000u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const uint32_t voff = (img == 0 ? va[i] + hh * d_a : vb[i] + hh * d_b) + kb;
@@ -141,11 +160,40 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   int sw[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) sw[ks] = ((2 * ks + h) ^ x) * 16;
+  // TN: lane 4q+p of a 16-lane group addresses row r0+q, columns 4p..4p+3 of a 4x16 block and
+  // receives column (lane & 15) of its 4 rows; a fragment = rows 8h..8h+3 and 8h+4..8h+7 of
+  // k-step ks for the 32 columns lane&31 (cdna guide T10, image (b))
+  const int tq = (lane >> 2) & 3, tp = lane & 3, tmb = (lane >> 4) & 1;
+  auto tr_off = [&](int c0, int sh) {
+    const int row = 8 * h + 4 * sh + tq;
+    const int swz = (tq << 2) | ((2 * h + sh) & 3);
+    return 256 * row + 16 * ((c0 + tmb * 2 + (tp >> 1)) ^ swz) + 8 * (tp & 1);
+  };
+  int ta[2][2], tb[2];
+#pragma unroll
+  for (int sh = 0; sh < 2; ++sh) {
+    ta[0][sh] = tr_off(grp * 8, sh);
+    ta[1][sh] = tr_off(grp * 8 + 4, sh);
+    tb[sh] = tr_off(wc * 4, sh);
+  }
+  auto tr_read = [&](const unsigned char *img, int off0, int off1) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) bf16x4 *)(img + off0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) bf16x4 *)(img + off1));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
   auto read_a = [&](int buf, int hh, int mi, int ks) {
-    return *reinterpret_cast<const bf16x8 *>(a_rd + buf * BUF + hh * 2 * IMG + mi * 4096 + sw[ks]);
+    if constexpr (!TN)
+      return *reinterpret_cast<const bf16x8 *>(a_rd + buf * BUF + hh * 2 * IMG + mi * 4096 + sw[ks]);
+    else
+      return tr_read(smem + buf * BUF + hh * 2 * IMG + ks * 4096, ta[mi][0], ta[mi][1]);
   };
   auto read_b = [&](int buf, int hh, int ks) {
-    return *reinterpret_cast<const bf16x8 *>(b_rd + buf * BUF + hh * 2 * IMG + sw[ks]);
+    if constexpr (!TN)
+      return *reinterpret_cast<const bf16x8 *>(b_rd + buf * BUF + hh * 2 * IMG + sw[ks]);
+    else
+      return tr_read(smem + buf * BUF + IMG + hh * 2 * IMG + ks * 4096, tb[0], tb[1]);
   };
 
   f32x16 acc[4][2];
@@ -304,7 +352,8 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   // ---- epilogue: per wave, 32x64 strips through its private 16 KiB of LDS ----
   float *sC = reinterpret_cast<float *>(smem + wave * 16384);
   const int c4 = lane & 15;
-  const int gcol = n0 + wc * 64 + c4 * 4;
+  // NT: the strip's 64 columns are contiguous; TN: 32 of each column half
+  const int gcol = TN ? n0 + (c4 >> 3) * 128 + wc * 32 + (c4 & 7) * 4 : n0 + wc * 64 + c4 * 4;
   f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
   if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + gcol);
   const bool has_aux = (EPI == BE_MASK_BF16) && g.aux != nullptr;
@@ -323,7 +372,7 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int lr = p * 4 + (lane >> 4);
-      const int row = m0 + grp * 128 + rt * 32 + lr;
+      const int row = TN ? m0 + (rt >> 1) * 128 + grp * 64 + (rt & 1) * 32 + lr : m0 + grp * 128 + rt * 32 + lr;
       f32x4 v = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + c4 * 4);
       if (row >= g.M) continue;
       if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) {
@@ -349,32 +398,32 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   }
 }
 
-template <int EPI>
+template <bool TN, int EPI>
 int launch(const BArgs &g, int splits, hipStream_t s) {
   static bool configured = false;   // raising the dynamic-LDS limit is idempotent; a race only repeats it
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16_256: cannot reserve %d B of LDS: %s", SMEM,
                                      hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL((k_gemm_bf16_256<EPI>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), SMEM, s, g);
+  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), SMEM, s, g);
   return check_launch("gemm_bf16_256");
 }
 
 }  // namespace
 
 bool gemm_bf16_256_usable(int M, int N, int K, int64_t lda, int64_t ldb) {
-  if (N % TN || K % (2 * TK) || M < 1) return false;
+  if (N % kTileN || K % (2 * kTileK) || M < 1) return false;
   const int64_t lim = (int64_t)1 << 31;
-  return ((int64_t)M + TM) * lda * 2 < lim && (int64_t)N * ldb * 2 < lim;
+  return ((int64_t)M + kTileM) * lda * 2 < lim && (int64_t)N * ldb * 2 < lim;
 }
 
 // split-K for the skinny weight gradients: fill one round of 256 CUs as evenly as
 // possible with the fewest slabs
 int gemm_bf16_256_splits(int M, int N, int K) {
-  const int64_t tiles = (int64_t)((M + TM - 1) / TM) * (N / TN);
+  const int64_t tiles = (int64_t)((M + kTileM - 1) / kTileM) * (N / kTileN);
   const int max_by_k = K / 1024 > 0 ? K / 1024 : 1;
   int best = 1;
   double best_eff = 0.0;
@@ -388,11 +437,19 @@ int gemm_bf16_256_splits(int M, int N, int K) {
 
 int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t s) {
   switch (epilogue) {
-    case BE_BIAS_LRELU_BF16: return launch<BE_BIAS_LRELU_BF16>(g, splits, s);
-    case BE_BIAS_LRELU_F32: return launch<BE_BIAS_LRELU_F32>(g, splits, s);
-    case BE_MASK_BF16: return launch<BE_MASK_BF16>(g, splits, s);
-    default: return launch<BE_F32>(g, splits, s);
+    case BE_BIAS_LRELU_BF16: return launch<false, BE_BIAS_LRELU_BF16>(g, splits, s);
+    case BE_BIAS_LRELU_F32: return launch<false, BE_BIAS_LRELU_F32>(g, splits, s);
+    case BE_MASK_BF16: return launch<false, BE_MASK_BF16>(g, splits, s);
+    default: return launch<false, BE_F32>(g, splits, s);
   }
 }
+
+bool gemm_bf16_tn_usable(int M, int N, int K, int64_t lda, int64_t ldb) {
+  if (M % kTileM || N % kTileN || K % (2 * kTileK) || K < 2 * kTileK) return false;
+  const int64_t lim = (int64_t)1 << 31;
+  return (int64_t)K * lda * 2 < lim && (int64_t)K * ldb * 2 < lim;
+}
+
+int launch_gemm_bf16_tn(const BArgs &g, int splits, hipStream_t s) { return launch<true, BE_F32>(g, splits, s); }
 
 }  // namespace cdml

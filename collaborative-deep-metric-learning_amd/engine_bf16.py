@@ -65,13 +65,20 @@ class TowerWorkspaceBF16:
         self.layout, self.R = L, R
         bf = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=device)
         f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
-        self.x_hat, self.xT = bf(R, L.Fp), bf(L.Fp, R)
-        self.h1, self.h1T = bf(R, L.Hp), bf(L.Hp, R)
+        # weight gradients straight from the activations as stored (k-strided GEMM with
+        # transposed LDS reads) when the shapes allow; otherwise transposed bf16 copies
+        self.tn1 = ops.gemm_bf16_tn_supported(L.Fp, L.Hp, R, L.Fp, L.Hp)
+        self.tn2 = ops.gemm_bf16_tn_supported(L.Hp, L.Dp, R, L.Hp, L.Dp)
+        self.x_hat, self.h1, self.dz1 = bf(R, L.Fp), bf(R, L.Hp), bf(R, L.Hp)
         self.z, self.e, self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp)
-        self.dz2_bf, self.dz2T = bf(R, L.Dp), bf(L.Dp, R)
-        self.dz1, self.dz1T = bf(R, L.Hp), bf(L.Hp, R)
+        self.dz2_bf = bf(R, L.Dp)
+        if not self.tn1:
+            self.xT, self.dz1T = bf(L.Fp, R), bf(L.Hp, R)
+        if not self.tn2:
+            self.h1T, self.dz2T = bf(L.Hp, R), bf(L.Dp, R)
         self.W1T, self.W2T, self.W2 = bf(L.Hp, L.Fp), bf(L.Dp, L.Hp), bf(L.Hp, L.Dp)
-        nb = max(ops.gemm_bf16_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_workspace(L.Fp, L.Hp, R), 16)
+        nb = max(ops.gemm_bf16_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_workspace(L.Fp, L.Hp, R),
+                 ops.gemm_bf16_tn_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_tn_workspace(L.Fp, L.Hp, R), 16)
         self.gemm_ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
         self.colsum_ws = f32(max(ops.colsum_workspace_floats(R, L.Hp), ops.colsum_workspace_floats(R, L.Dp)))
 
@@ -99,14 +106,20 @@ def tower_backward(p, ws, after_w1=None):
     ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
     ops.colsum(ws.dz2, R, L.Dp, p.gb2, ws.colsum_ws)
     ops.cast_f32_bf16(ws.dz2, ws.dz2_bf, R, L.Dp)
-    ops.transpose_to_bf16(ws.dz2, ws.dz2T, R, L.Dp)
-    ops.transpose_to_bf16(ws.h1, ws.h1T, R, L.Hp)
-    ops.gemm_bf16_nt(ops.BE_F32, ws.h1T, ws.dz2T, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
+    if ws.tn2:
+        ops.gemm_bf16_tn(ws.h1, ws.dz2_bf, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
+    else:
+        ops.transpose_to_bf16(ws.dz2, ws.dz2T, R, L.Dp)
+        ops.transpose_to_bf16(ws.h1, ws.h1T, R, L.Hp)
+        ops.gemm_bf16_nt(ops.BE_F32, ws.h1T, ws.dz2T, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
     ops.gemm_bf16_nt(ops.BE_MASK_BF16, ws.dz2_bf, ws.W2, ws.dz1, R, L.Hp, L.Dp, aux=ws.h1)
     ops.colsum(ws.dz1, R, L.Hp, p.gb1, ws.colsum_ws)
-    ops.transpose_to_bf16(ws.dz1, ws.dz1T, R, L.Hp)
-    ops.transpose_to_bf16(ws.x_hat, ws.xT, R, L.Fp)
-    ops.gemm_bf16_nt(ops.BE_F32, ws.xT, ws.dz1T, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws)
+    if ws.tn1:
+        ops.gemm_bf16_tn(ws.x_hat, ws.dz1, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws)
+    else:
+        ops.transpose_to_bf16(ws.dz1, ws.dz1T, R, L.Hp)
+        ops.transpose_to_bf16(ws.x_hat, ws.xT, R, L.Fp)
+        ops.gemm_bf16_nt(ops.BE_F32, ws.xT, ws.dz1T, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws)
     if after_w1 is not None:
         after_w1()
     return p.grad

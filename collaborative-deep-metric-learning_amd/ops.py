@@ -248,6 +248,24 @@ def gemm_bf16_nt(epilogue, A, B, C, M, N, K, bias=None, aux=None, alpha=LRELU_AL
     return C
 
 
+def gemm_bf16_tn_supported(M, N, K, lda, ldb):
+    return bool(load_library().cdml_gemm_bf16_tn_supported(M, N, K, lda, ldb))
+
+
+def gemm_bf16_tn_workspace(M, N, K):
+    return int(load_library().cdml_gemm_bf16_tn_workspace(M, N, K))
+
+
+def gemm_bf16_tn(A, B, C, M, N, K, workspace=None):
+    """C[M][N] f32 = sum_k A[k][M] * B[k][N]: the weight gradient from the activations as stored."""
+    ap, ald = _mat16(A)
+    bp, bld = _mat16(B)
+    cp, cld = _mat(C)
+    call("cdml_gemm_bf16_tn", ap, ald, bp, bld, M, N, K, cp, cld, _p(workspace),
+         0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())
+    return C
+
+
 def transpose_to_bf16(src, dst, rows, cols):
     call("cdml_transpose_to_bf16", 1 if src.dtype == torch.float32 else 0, _p(src), src.stride(0), rows, cols,
          _p(dst, torch.bfloat16), dst.stride(0), _stream())

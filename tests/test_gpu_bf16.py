@@ -69,6 +69,38 @@ def test_gemm_bf16_epilogues(cd, M, N, K, tile, monkeypatch):
     assert torch.equal(out, out2)                                  # deterministic split-K
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1280), (1536, 5120, 2048), (5120, 256, 3072)])
+def test_gemm_bf16_tn_weight_gradient_form(cd, M, N, K):
+    """C = A^T . B from k-strided operands (transposed LDS reads, no transposed copies)."""
+    rng = np.random.RandomState(M + K)
+    A, B = rng.randn(K, M) / np.sqrt(K), rng.randn(K, N)
+    # make a wrong k-permutation or a swapped fragment half visible: scale rows of k
+    A *= (1.0 + (np.arange(K) % 7)[:, None] * 0.25)
+    ref = bf(A).T @ bf(B)
+    dA, dB = dbf(A, cd.dev), dbf(B, cd.dev)
+    assert cd.ops.gemm_bf16_tn_supported(M, N, K, M, N)
+    ws = torch.empty(max(cd.ops.gemm_bf16_tn_workspace(M, N, K), 16) // 4, device=cd.dev)
+    out = torch.empty((M, N), dtype=torch.float32, device=cd.dev)
+    cd.ops.gemm_bf16_tn(dA, dB, out, M, N, K, workspace=ws)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-4 * np.sqrt(K / 64), rtol=0)
+    out2 = torch.empty_like(out)
+    cd.ops.gemm_bf16_tn(dA, dB, out2, M, N, K, workspace=ws)
+    assert torch.equal(out, out2)
+    # strided operands (views into wider buffers), as the tower uses them
+    wideA = torch.zeros((K, M + 64), dtype=torch.bfloat16, device=cd.dev)
+    wideA[:, :M] = dA
+    cd.ops.gemm_bf16_tn(wideA[:, :M], dB, out2, M, N, K, workspace=ws)
+    assert torch.equal(out, out2)
+
+
+def test_gemm_bf16_tn_refuses_other_shapes(cd):
+    assert not cd.ops.gemm_bf16_tn_supported(192, 256, 128, 192, 256)
+    a = torch.zeros((128, 192), dtype=torch.bfloat16, device=cd.dev)
+    b = torch.zeros((128, 256), dtype=torch.bfloat16, device=cd.dev)
+    with pytest.raises(cd.pkg.CdmlError):
+        cd.ops.gemm_bf16_tn(a, b, torch.empty((192, 256), device=cd.dev), 192, 256, 128)
+
+
 def test_gemm_bf16_identity_asymmetric_and_errors(cd):
     K = N = 128
     Bm = (np.arange(N * K).reshape(N, K) % 251 - 100).astype(np.float64)     # exact in bf16

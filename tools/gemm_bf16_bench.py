@@ -44,3 +44,34 @@ for name, epi, M, N, K in cases:
           % (name, res["128"][0], fl / res["128"][0] / 1e9, fl / res["128"][0] / 1e9 / 2500,
              res["256"][0], fl / res["256"][0] / 1e9, fl / res["256"][0] / 1e9 / 2500,
              abs(res["128"][1] - res["256"][1]) / max(res["128"][1], 1e-9)))
+
+# weight gradients from k-strided operands (no transposed copies) vs transposes + NT
+os.environ["CDML_BF16_TILE"] = "0"
+for name, M, N, K in (("dW1 tn F x H x R", F, H, R), ("dW2 tn H x D x R", H, D, R)):
+    if not ops.gemm_bf16_tn_supported(M, N, K, M, N):
+        continue
+    A = (torch.randn(K, M, device=dev) / K ** 0.5).bfloat16()
+    B = torch.randn(K, N, device=dev).bfloat16()
+    AT, BT = torch.empty((M, K), device=dev, dtype=torch.bfloat16), torch.empty((N, K), device=dev, dtype=torch.bfloat16)
+    out, out2 = torch.empty((M, N), device=dev), torch.empty((M, N), device=dev)
+    ws = torch.empty(max(ops.gemm_bf16_tn_workspace(M, N, K), ops.gemm_bf16_workspace(M, N, K), 16) // 4, device=dev)
+
+    def via_transposes():
+        ops.transpose_to_bf16(A, AT, K, M)
+        ops.transpose_to_bf16(B, BT, K, N)
+        ops.gemm_bf16_nt(ops.BE_F32, AT, BT, out2, M, N, K, workspace=ws)
+    res = []
+    for fn in (lambda: ops.gemm_bf16_tn(A, B, out, M, N, K, workspace=ws), via_transposes):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        res.append(s.elapsed_time(e) / iters)
+    fl = 2.0 * M * N * K
+    print("%-16s tn: %7.4f ms %7.1f TF (%.3f) | transposes+nt: %7.4f ms | max abs diff %.2e"
+          % (name, res[0], fl / res[0] / 1e9, fl / res[0] / 1e9 / 2500, res[1], (out - out2).abs().max().item()))
