@@ -20,6 +20,7 @@ struct BArgs {
   int k_per_split;
   int64_t slab_stride;
   int tiles_m, tiles_n;
+  float *colsum_partial;   // k-strided form only: [splits*tiles_m*2][N] column sums of B (nullable)
 };
 
 // 256x256x64 kernel: true if the shape can use it (N % 256 == 0, K per split a

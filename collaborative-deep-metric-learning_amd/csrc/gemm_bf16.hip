@@ -428,11 +428,13 @@ extern "C" int cdml_gemm_bf16_tn_supported(int M, int N, int K, int64_t lda, int
 extern "C" size_t cdml_gemm_bf16_tn_workspace(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int splits = gemm_bf16_256_splits(M, N, K);
-  return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+  const size_t slabs = splits > 1 ? (size_t)splits * M * N : 0;
+  const size_t partials = (size_t)splits * ((M + 255) / 256) * 2 * N;    // column sums of B
+  return (slabs + partials) * sizeof(float);
 }
 
 extern "C" int cdml_gemm_bf16_tn(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t ldb, int M,
-                                 int N, int K, float *C, int64_t ldc, void *workspace,
+                                 int N, int K, float *C, int64_t ldc, float *colsum, void *workspace,
                                  size_t workspace_bytes, cdml_stream_t stream) {
   CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16_tn: bad argument");
   CDML_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && (lda & 7) == 0 && (ldb & 7) == 0 &&
@@ -449,20 +451,31 @@ extern "C" int cdml_gemm_bf16_tn(const uint16_t *A, int64_t lda, const uint16_t 
   g.tiles_m = M / 256; g.tiles_n = N / 256;
   const int splits = gemm_bf16_256_splits(M, N, K);
   hipStream_t s = (hipStream_t)stream;
+  const size_t slab_floats = splits > 1 ? (size_t)splits * M * N : 0;
+  const int chunks = splits * g.tiles_m * 2;
+  const size_t need = (slab_floats + (colsum ? (size_t)chunks * N : 0)) * sizeof(float);
+  CDML_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && aligned16(workspace)), CDML_E_BADARG,
+               "gemm_bf16_tn: workspace of %zu bytes required", need);
   if (splits > 1) {
-    const size_t need = (size_t)splits * M * N * sizeof(float);
-    CDML_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), CDML_E_BADARG,
-                 "gemm_bf16_tn: split-K workspace of %zu bytes required", need);
     const int kps = (K + splits - 1) / splits;
     g.k_per_split = (kps + 127) / 128 * 128;
     g.slab_stride = (int64_t)M * N;
     g.C = workspace; g.ldc = N;
   }
+  if (colsum) g.colsum_partial = static_cast<float *>(workspace) + slab_floats;
   int rc = launch_gemm_bf16_tn(g, splits, s);
-  if (rc || splits == 1) return rc;
-  hipLaunchKernelGGL(k_sum_slabs_f32, dim3(grid1d((int64_t)M * N / 4, 1)), dim3(kThreads), 0, s,
-                     static_cast<const float *>(workspace), g.slab_stride, splits, M, N, C, ldc);
-  return check_launch("gemm_bf16_tn combine");
+  if (rc) return rc;
+  if (splits > 1) {
+    hipLaunchKernelGGL(k_sum_slabs_f32, dim3(grid1d((int64_t)M * N / 4, 1)), dim3(kThreads), 0, s,
+                       static_cast<const float *>(workspace), g.slab_stride, splits, M, N, C, ldc);
+    if ((rc = check_launch("gemm_bf16_tn combine"))) return rc;
+  }
+  if (colsum) {
+    hipLaunchKernelGGL(k_colsum_final, dim3((N + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
+                       g.colsum_partial, chunks, N, colsum);
+    rc = check_launch("gemm_bf16_tn bias gradient");
+  }
+  return rc;
 }
 
 extern "C" int cdml_transpose_to_bf16(int src_is_f32, const void *src, int64_t lds_, int rows, int cols,

@@ -269,6 +269,20 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
     CDML_BARRIER();
   };
 
+  // Bias gradient riding along (k-strided form): db[n] = sum_k B[k][n].  The tiles_m blocks and
+  // two row groups that share a B tile split its K-tiles between them (tile t belongs to
+  // (tm, grp) = (t % (2*tiles_m)) >> 1, & 1); the owner adds its fragments' 8 k-values per lane
+  // in the read part of the phase, where the wave only waits anyway.
+  float cs[2] = {0.f, 0.f};
+  const bool cs_on = TN && g.colsum_partial != nullptr;
+  const int cs_owner = 2 * tm + grp, cs_period = 2 * g.tiles_m;
+  auto frag_sum = [&](const bf16x8 &f) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)f[e];
+    return s;
+  };
+
   // Two-phase form of the K-tile (CDML_BF16_PHASES == 2): phase A = Q00 + Q01 (16 fragment
   // reads, 16 MFMAs), phase B = Q11 + Q10 (8 reads, 16 MFMAs): half the barriers, and the
   // read parts have a 512-cycle MFMA part of the other group to hide under.  Fragment reads
@@ -291,6 +305,13 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
     stage(0, 1, tile + 1, buf ^ 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (TN && cs_on && (tile % cs_period) == cs_owner) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        cs[0] += frag_sum(fb0[ks]);
+        cs[1] += frag_sum(fb1[ks]);
+      }
+    }
     CDML_BARRIER();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -349,6 +370,15 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the out-of-range tail DMAs still write zeros
   CDML_BARRIER();
 
+  if (TN && cs_on) {   // lanes l31 / l31+32 hold the two k-halves of column l31
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float v = cs[ct] + __shfl_xor(cs[ct], 32, 64);
+      if (h == 0)
+        g.colsum_partial[(int64_t)((split * g.tiles_m + tm) * 2 + grp) * g.N + n0 + ct * 128 + wc * 32 + l31] = v;
+    }
+  }
+
   // ---- epilogue: per wave, 32x64 strips through its private 16 KiB of LDS ----
   float *sC = reinterpret_cast<float *>(smem + wave * 16384);
   const int c4 = lane & 15;
@@ -357,6 +387,20 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
   if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + gcol);
   const bool has_aux = (EPI == BE_MASK_BF16) && g.aux != nullptr;
+  auto out_row = [&](int rt, int p) {
+    const int lr = p * 4 + (lane >> 4);
+    return TN ? m0 + (rt >> 1) * 128 + grp * 64 + (rt & 1) * 32 + lr : m0 + grp * 128 + rt * 32 + lr;
+  };
+  // all 32 mask loads of the wave go out together (rows clamped, not branched around: a load
+  // under a branch is waited for on the spot, 32 dependent round trips per tile)
+  bf16x4 mk[4][8];
+  if (EPI == BE_MASK_BF16 && has_aux) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int p = 0; p < 8; ++p)
+        mk[rt][p] = *reinterpret_cast<const bf16x4 *>(g.aux + (int64_t)min(out_row(rt, p), g.M - 1) * g.ldaux + gcol);
+  }
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
     float *strip = sC + (rt & 1) * 2048;                 // alternate halves: no wait for the readers
@@ -372,20 +416,20 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int lr = p * 4 + (lane >> 4);
-      const int row = TN ? m0 + (rt >> 1) * 128 + grp * 64 + (rt & 1) * 32 + lr : m0 + grp * 128 + rt * 32 + lr;
+      const int row = out_row(rt, p);
       f32x4 v = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + c4 * 4);
-      if (row >= g.M) continue;
       if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) {
         v += bias4;
         v.x = fmaxf(v.x, v.x * g.alpha); v.y = fmaxf(v.y, v.y * g.alpha);
         v.z = fmaxf(v.z, v.z * g.alpha); v.w = fmaxf(v.w, v.w * g.alpha);
       } else if (EPI == BE_MASK_BF16) {
         if (has_aux) {
-          const bf16x4 m = *reinterpret_cast<const bf16x4 *>(g.aux + (int64_t)row * g.ldaux + gcol);
+          const bf16x4 m = mk[rt][p];
           v.x *= ((float)m.x > 0.f) ? 1.f : g.alpha; v.y *= ((float)m.y > 0.f) ? 1.f : g.alpha;
           v.z *= ((float)m.z > 0.f) ? 1.f : g.alpha; v.w *= ((float)m.w > 0.f) ? 1.f : g.alpha;
         }
       }
+      if (row >= g.M) continue;                            // stores only below this line
       if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_MASK_BF16) {
         bf16x4 o;
         o.x = (bf16)v.x; o.y = (bf16)v.y; o.z = (bf16)v.z; o.w = (bf16)v.w;

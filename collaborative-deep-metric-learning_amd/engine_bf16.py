@@ -104,7 +104,7 @@ def tower_backward(p, ws, after_w1=None):
     """ws.de -> p.grad (fp32).  train.py:141; no dX."""
     L, R = p.layout, ws.R
     ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
-    ops.colsum(ws.dz2, R, L.Dp, p.gb2, ws.colsum_ws)
+    ops.colsum(ws.dz2, R, L.Dp, p.gb2, ws.colsum_ws)       # fp32 dz2: db2 keeps full precision
     ops.cast_f32_bf16(ws.dz2, ws.dz2_bf, R, L.Dp)
     if ws.tn2:
         ops.gemm_bf16_tn(ws.h1, ws.dz2_bf, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
@@ -113,10 +113,10 @@ def tower_backward(p, ws, after_w1=None):
         ops.transpose_to_bf16(ws.h1, ws.h1T, R, L.Hp)
         ops.gemm_bf16_nt(ops.BE_F32, ws.h1T, ws.dz2T, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
     ops.gemm_bf16_nt(ops.BE_MASK_BF16, ws.dz2_bf, ws.W2, ws.dz1, R, L.Hp, L.Dp, aux=ws.h1)
-    ops.colsum(ws.dz1, R, L.Hp, p.gb1, ws.colsum_ws)
-    if ws.tn1:
-        ops.gemm_bf16_tn(ws.x_hat, ws.dz1, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws)
+    if ws.tn1:   # db1 = column sums of dz1, taken from the LDS tiles of the same GEMM
+        ops.gemm_bf16_tn(ws.x_hat, ws.dz1, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws, colsum=p.gb1)
     else:
+        ops.colsum(ws.dz1, R, L.Hp, p.gb1, ws.colsum_ws)
         ops.transpose_to_bf16(ws.dz1, ws.dz1T, R, L.Hp)
         ops.transpose_to_bf16(ws.x_hat, ws.xT, R, L.Fp)
         ops.gemm_bf16_nt(ops.BE_F32, ws.xT, ws.dz1T, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws)

@@ -256,12 +256,13 @@ def gemm_bf16_tn_workspace(M, N, K):
     return int(load_library().cdml_gemm_bf16_tn_workspace(M, N, K))
 
 
-def gemm_bf16_tn(A, B, C, M, N, K, workspace=None):
-    """C[M][N] f32 = sum_k A[k][M] * B[k][N]: the weight gradient from the activations as stored."""
+def gemm_bf16_tn(A, B, C, M, N, K, workspace=None, colsum=None):
+    """C[M][N] f32 = sum_k A[k][M] * B[k][N]: the weight gradient from the activations as
+    stored; colsum[n] = sum_k B[k][n] (the bias gradient) on request."""
     ap, ald = _mat16(A)
     bp, bld = _mat16(B)
     cp, cld = _mat(C)
-    call("cdml_gemm_bf16_tn", ap, ald, bp, bld, M, N, K, cp, cld, _p(workspace),
+    call("cdml_gemm_bf16_tn", ap, ald, bp, bld, M, N, K, cp, cld, _p(colsum, torch.float32), _p(workspace),
          0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())
     return C
 

@@ -241,13 +241,14 @@ int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda,
  * (dW = x^T . dy with x [rows][M], dy [rows][N] bf16 as the forward/backward wrote
  * them: no transposed copies).  Needs M, N % 256 == 0 and K % 128 == 0
  * (cdml_gemm_bf16_tn_supported); other shapes: cdml_transpose_to_bf16 +
- * cdml_gemm_bf16_nt.  Deterministic split-K through `workspace`
- * (cdml_gemm_bf16_tn_workspace bytes). */
+ * cdml_gemm_bf16_nt.  colsum (nullable): colsum[n] = sum_k B[k][n], the bias
+ * gradient, accumulated from the same LDS tiles.  Deterministic split-K and
+ * column-sum partials through `workspace` (cdml_gemm_bf16_tn_workspace bytes). */
 int cdml_gemm_bf16_tn_supported(int M, int N, int K, int64_t lda, int64_t ldb);
 size_t cdml_gemm_bf16_tn_workspace(int M, int N, int K);
 int cdml_gemm_bf16_tn(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t ldb,
-                      int M, int N, int K, float *C, int64_t ldc, void *workspace,
-                      size_t workspace_bytes, cdml_stream_t stream);
+                      int M, int N, int K, float *C, int64_t ldc, float *colsum,
+                      void *workspace, size_t workspace_bytes, cdml_stream_t stream);
 
 /* dst[c][r] = bf16(src[r][c]) (src fp32 or bf16): k-contiguous copies of weights
  * and of activations for the weight-gradient GEMMs (contraction over batch rows). */

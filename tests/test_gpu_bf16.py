@@ -84,8 +84,10 @@ def test_gemm_bf16_tn_weight_gradient_form(cd, M, N, K):
     cd.ops.gemm_bf16_tn(dA, dB, out, M, N, K, workspace=ws)
     np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-4 * np.sqrt(K / 64), rtol=0)
     out2 = torch.empty_like(out)
-    cd.ops.gemm_bf16_tn(dA, dB, out2, M, N, K, workspace=ws)
+    cs = torch.full((N,), 7.0, dtype=torch.float32, device=cd.dev)
+    cd.ops.gemm_bf16_tn(dA, dB, out2, M, N, K, workspace=ws, colsum=cs)      # + bias gradient
     assert torch.equal(out, out2)
+    np.testing.assert_allclose(cs.cpu().numpy(), bf(B).sum(0), atol=2e-4 * np.sqrt(K), rtol=0)
     # strided operands (views into wider buffers), as the tower uses them
     wideA = torch.zeros((K, M + 64), dtype=torch.bfloat16, device=cd.dev)
     wideA[:, :M] = dA
