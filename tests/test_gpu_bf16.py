@@ -95,6 +95,36 @@ def test_gemm_bf16_tn_weight_gradient_form(cd, M, N, K):
     assert torch.equal(out, out2)
 
 
+def test_gemm_bf16_256_race_screen(cd, monkeypatch):
+    """The ping-pong kernel orders its LDS-DMA against the fragment reads by counted waits and
+    barriers only; a misplaced wait shows up as rare wrong tiles.  Many launches, full chip,
+    operands changing under the same buffers, every result compared bit for bit."""
+    monkeypatch.setenv("CDML_BF16_TILE", "256")
+    M, N, K = 4096, 4096, 1024                      # 256 tiles: one per CU, 16 K-tiles each
+    g = torch.Generator(device=cd.dev)
+    g.manual_seed(5)
+    A = (torch.randn(M, K, device=cd.dev, generator=g) / 32).bfloat16()
+    B = torch.randn(N, K, device=cd.dev, generator=g).bfloat16()
+    bias = torch.zeros(N, device=cd.dev)
+    out = torch.empty((M, N), dtype=torch.float32, device=cd.dev)
+    cd.ops.gemm_bf16_nt(cd.ops.BE_BIAS_LRELU_F32, A, B, out, M, N, K, bias=bias)
+    ref = (A.float() @ B.float().T)
+    ref = torch.maximum(ref, 0.2 * ref)
+    assert (out - ref).abs().max().item() < 2e-3
+    first = out.clone()
+    for _ in range(60):
+        cd.ops.gemm_bf16_nt(cd.ops.BE_BIAS_LRELU_F32, A, B, out, M, N, K, bias=bias)
+        assert torch.equal(out, first)
+    At, Bt = A.t().contiguous(), B.t().contiguous()  # [K][M], [K][N]
+    ws = torch.empty(max(cd.ops.gemm_bf16_tn_workspace(M, N, K), 16) // 4, device=cd.dev)
+    cd.ops.gemm_bf16_tn(At, Bt, out, M, N, K, workspace=ws)
+    assert (out - A.float() @ B.float().T).abs().max().item() < 2e-3
+    first = out.clone()
+    for _ in range(60):
+        cd.ops.gemm_bf16_tn(At, Bt, out, M, N, K, workspace=ws)
+        assert torch.equal(out, first)
+
+
 def test_gemm_bf16_tn_refuses_other_shapes(cd):
     assert not cd.ops.gemm_bf16_tn_supported(192, 256, 128, 192, 256)
     a = torch.zeros((128, 192), dtype=torch.bfloat16, device=cd.dev)
