@@ -292,6 +292,17 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   //   phase B of tile T issues B-h0, B-h1 of tile T+2 (this buffer; read in phase A of T);
   //   phase B waits vmcnt(6): B-h0, B-h1, A-h0 of T+1 landed (read in phase A of T+1);
   //   phase A waits vmcnt(8): A-h1 of T landed (read in phase B of T).
+  // Fragments as in/out operands of an empty asm: hipcc has to have them in registers here,
+  // so the LDS reads are waited for BEFORE the barrier that follows (it would otherwise sink
+  // the waits into the MFMA part, and the images are refilled one barrier after their reads).
+  auto pin_a = [&]() {
+    asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
+                      "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]));
+  };
+  auto pin_b = [&]() {
+    asm volatile("" : "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]), "+v"(fb0[3]),
+                      "+v"(fb1[0]), "+v"(fb1[1]), "+v"(fb1[2]), "+v"(fb1[3]));
+  };
   auto do_tile2 = [&](const int buf, const int tile) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fb0[ks] = read_b(buf, 0, ks);
@@ -304,7 +315,8 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
     stage(0, 0, tile + 1, buf ^ 1);
     stage(0, 1, tile + 1, buf ^ 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    pin_b();
+    pin_a();
     if (TN && cs_on && (tile % cs_period) == cs_owner) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -330,7 +342,7 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
     stage(1, 0, tile + 2, buf);
     stage(1, 1, tile + 2, buf);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    pin_a();
     CDML_BARRIER();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll

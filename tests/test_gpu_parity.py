@@ -188,6 +188,54 @@ def test_l2norm_fwd_bwd(cd):
 
 # ---------------------------------------------------------------------- GEMM --
 FC_SHAPES = [(15, 64, 64), (130, 96, 192), (384, 1536, 5120), (257, 5120, 256), (64, 32, 128)]
+# the 128x256 ping-pong kernel (CDML_F32_TILE=256 takes it wherever the shape allows):
+# minimal, ragged rows, long K, several column tiles
+PP_FWD = [(128, 64, 256), (300, 128, 256), (1000, 1536, 512), (77, 5120, 256), (384, 1536, 5120)]
+
+
+@pytest.fixture
+def pp(monkeypatch):
+    monkeypatch.setenv("CDML_F32_TILE", "256")
+
+
+@pytest.mark.parametrize("M,K,N", PP_FWD)
+def test_fc_lrelu_fwd_pingpong(cd, pp, M, K, N):
+    test_fc_lrelu_fwd(cd, M, K, N)
+
+
+@pytest.mark.parametrize("M,K,N", [(128, 256, 64), (300, 512, 128), (1000, 1024, 256), (77, 5120, 256)])
+def test_fc_bwd_data_pingpong(cd, pp, M, K, N):
+    test_fc_bwd_data(cd, M, K, N)
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 128, 256), (777, 256, 512), (3000, 5120, 256), (1001, 1536, 1024),
+                                   (8192, 128, 256)])
+def test_fc_bwd_weight_pingpong(cd, pp, M, K, N):
+    test_fc_bwd_weight(cd, M, K, N)
+
+
+def test_fc_pingpong_race_screen(cd, pp):
+    """Counted-wait / barrier ordering of the ping-pong kernel: many launches on the whole
+    chip, every result compared bit for bit with the first."""
+    M, K, N = 4096, 512, 2048
+    g = torch.Generator(device=cd.dev)
+    g.manual_seed(3)
+    x = torch.randn(M, K, device=cd.dev, generator=g) / 16
+    W = torch.randn(K, N, device=cd.dev, generator=g)
+    dy = torch.randn(M, N, device=cd.dev, generator=g)
+    b = torch.zeros(N, device=cd.dev)
+    y = torch.empty((M, N), device=cd.dev)
+    cd.ops.fc_lrelu_fwd(x, W, b, y, M, K, N)
+    first = y.clone()
+    ws = torch.empty(cd.ops.fc_bwd_weight_workspace(M, K, N) // 4, device=cd.dev)
+    dW, db = torch.empty((K, N), device=cd.dev), torch.empty(N, device=cd.dev)
+    cd.ops.fc_bwd_weight(x, dy, dW, db, ws, M, K, N)
+    dW0 = dW.clone()
+    for _ in range(40):
+        cd.ops.fc_lrelu_fwd(x, W, b, y, M, K, N)
+        assert torch.equal(y, first)
+        cd.ops.fc_bwd_weight(x, dy, dW, db, ws, M, K, N)
+        assert torch.equal(dW, dW0)
 
 
 @pytest.mark.parametrize("M,K,N", FC_SHAPES)
