@@ -8,7 +8,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // mode bit0: MFMA waves active, bit1: LDS waves active, bit2: barriers between chunks (ping-pong)
-template <int MODE, int BF16>
+template <int MODE, int BF16, int VALU = 0>
 __global__ void __launch_bounds__(512) k_probe(const float *in, float *out, int iters) {
   __shared__ f32x4 lds[4096];   // 64 KB
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, grp = wave >> 2;
@@ -30,7 +30,13 @@ __global__ void __launch_bounds__(512) k_probe(const float *in, float *out, int 
     }
   };
   const int base = (lane * 7 + wave * 13) & 1023;
-  auto lds_chunk = [&]() {      // 24 ds_read_b128 into 24 registers, no VALU work, then wait for all
+  auto lds_chunk = [&]() {      // 24 ds_read_b128 into 24 registers, then wait for all
+    if (VALU) {                 // ... or folded into a sum: 4 VALU adds per read beside the partner's MFMAs
+#pragma unroll
+      for (int i = 0; i < 24; ++i) sum += lds[base + i * 64];
+      asm volatile("" : "+v"(sum));
+      return;
+    }
     f32x4 r[24];
 #pragma unroll
     for (int i = 0; i < 24; ++i) r[i] = lds[base + i * 64];
@@ -53,13 +59,13 @@ __global__ void __launch_bounds__(512) k_probe(const float *in, float *out, int 
   out[blockIdx.x * 512 + t] = s;
 }
 
-template <int MODE, int BF16>
+template <int MODE, int BF16, int VALU = 0>
 void run(const char *tag, const float *in, float *out, int iters) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((k_probe<MODE, BF16>), dim3(256), dim3(512), 0, 0, in, out, iters);
+  hipLaunchKernelGGL((k_probe<MODE, BF16, VALU>), dim3(256), dim3(512), 0, 0, in, out, iters);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((k_probe<MODE, BF16>), dim3(256), dim3(512), 0, 0, in, out, iters);
+  hipLaunchKernelGGL((k_probe<MODE, BF16, VALU>), dim3(256), dim3(512), 0, 0, in, out, iters);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   // MFMA work per iteration: with barriers both groups do one chunk each (all 8 waves), without only group 0 does two
@@ -82,6 +88,8 @@ int main() {
   run<5, 0>("MFMA only, ping-pong barriers", in, out, it);
   run<6, 0>("LDS only, ping-pong barriers", in, out, it);
   run<7, 0>("both, ping-pong barriers", in, out, it);
+  run<6, 0, 1>("LDS + 4 adds/read only, ping-pong barriers", in, out, it);
+  run<7, 0, 1>("both, LDS + 4 adds/read, ping-pong barriers", in, out, it);
   printf("bf16 32x32x16 (chunk = 16 MFMAs = 512 cycles)\n");
   run<1, 1>("MFMA waves only, no barriers", in, out, it);
   run<3, 1>("both, no barriers (free-running)", in, out, it);
