@@ -71,9 +71,23 @@ class KernelTimer:
             return r
         return timed
 
+    def calibrate(self):
+        """Time an empty start/end pair: what the pair itself adds on this stream (a few us;
+        matters for the 20 us gather, not for the 1 ms GEMMs).  Subtracted from every mean."""
+        pairs = []
+        for _ in range(20):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            e.record()
+            pairs.append((s, e))
+        torch.cuda.synchronize()
+        self.overhead_ms = float(np.median([s.elapsed_time(e) for s, e in pairs]))
+
+    overhead_ms = 0.0
+
     def mean_ms(self, name):
         v = [s.elapsed_time(e) for s, e in self.ev.get(name, [])]
-        return float(np.mean(v)) if v else None
+        return max(float(np.mean(v)) - self.overhead_ms, 1e-6) if v else None
 
 
 def pmc_traffic(kernel):
@@ -233,6 +247,8 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     kt.on = False
+    if timers_on:
+        kt.calibrate()
     if world > 1:
         elapsed = reduce_max(elapsed)
     loss = ts.loss()
@@ -282,6 +298,7 @@ def main():
             for k in ("fc1_fwd", "fc2_fwd", "dW1", "dW2", "fetch"):
                 if kt.mean_ms(k) is not None:
                     kern[k + "_ms"] = round(kt.mean_ms(k), 4)
+            kern["event_pair_overhead_ms"] = round(kt.overhead_ms, 5)   # already subtracted above
             out["kernels"] = kern
             t_f = kt.mean_ms("fetch")
             if t_f and world == 1:

@@ -162,10 +162,13 @@ k_gather_rows(const float *__restrict__ table, int64_t row0, int64_t n_rows, int
   }
 }
 
-// Persistent fused sampler + gather.  A block walks chunks of kWavesPerBlock
-// triplets: one lane per triplet draws the ids and stages them in LDS, then
-// every wave gathers the rows of its triplet.  MODE 0 = uniform negatives
-// (3 rows/triplet), MODE 1 = in-batch negatives (2 rows/triplet).
+// Persistent fused sampler + gather.  One wave per ROW of the batch: the wave re-derives the
+// ids of its triplet (scalar loads of the pair; the Philox negative only on the wave that
+// gathers it), loads its row (NCH x 1 KiB in flight), normalises and stores it.  A triplet's
+// rows go to different waves so that a batch of 4096 triplets still puts 8-12 k independent
+// ids -> row chains on the chip (the kernel is 20 us long: chain latency, not bandwidth, is
+// what it has to hide).  MODE 0 = uniform negatives (3 rows/triplet), MODE 1 = in-batch
+// negatives (2 rows/triplet).
 template <int MODE, int NCH>
 __global__ void __launch_bounds__(kThreads)
 k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t seed,
@@ -174,36 +177,27 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
                 int64_t n_rows, int64_t row_stride, int F, int32_t *__restrict__ idx_out,
                 int32_t *__restrict__ shift_out, float *__restrict__ x_out, int64_t out_stride) {
   constexpr int RPT = (MODE == 0) ? 3 : 2;  // rows per triplet
-  __shared__ int32_t s_ids[kWavesPerBlock][4];
   const uint64_t step = step_dev ? *step_dev : step_imm;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0)
     *shift_out = sample_inbatch_shift(seed, step, batch);
-  const int n_chunks = (batch + kWavesPerBlock - 1) / kWavesPerBlock;
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    const int i = chunk * kWavesPerBlock + wave;  // triplet of this wave
-    if (lane == 0 && i < batch) {
-      const uint64_t slot = (uint64_t)(slot0 + i);
-      const uint64_t q = (step * (uint64_t)batch_global + slot) % (uint64_t)n_pairs;
-      const int32_t a = pairs[2 * q], p = pairs[2 * q + 1];
-      s_ids[wave][0] = a;
-      s_ids[wave][1] = p;
-      if (MODE == 0)
-        s_ids[wave][2] = sample_uniform_negative(seed, step, (uint32_t)slot, a, p, (uint32_t)n_rows);
+  const int64_t total_rows = (int64_t)RPT * batch;
+  for (int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave; r < total_rows;
+       r += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int i = (int)(r / RPT), k = (int)(r - (int64_t)i * RPT);   // wave-uniform
+    const uint64_t slot = (uint64_t)(slot0 + i);
+    const uint64_t q = (step * (uint64_t)batch_global + slot) % (uint64_t)n_pairs;
+    const int32_t a = pairs[2 * q], p = pairs[2 * q + 1];
+    int32_t id = k == 0 ? a : p;
+    if (MODE == 0 && k == 2) {
+      int32_t n = 0;
+      if (lane == 0) n = sample_uniform_negative(seed, step, (uint32_t)slot, a, p, (uint32_t)n_rows);
+      id = __builtin_amdgcn_readfirstlane(n);
     }
-    __syncthreads();
-    if (i < batch) {
-      if (lane < RPT) idx_out[RPT * i + lane] = s_ids[wave][lane];
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) {
-        const int64_t lr = clamp_row(s_ids[wave][k], 0, n_rows, nullptr);
-        const int64_t r = (int64_t)RPT * i + k;
-        gather_one_row<NCH>(table, lr, row_stride, F, 1, x_out + r * out_stride, out_stride,
-                            nullptr, lane);
-      }
-    }
-    __syncthreads();
+    if (lane == 0) idx_out[r] = id;
+    gather_one_row<NCH>(table, clamp_row(id, 0, n_rows, nullptr), row_stride, F, 1,
+                        x_out + r * out_stride, out_stride, nullptr, lane);
   }
 }
 
@@ -316,7 +310,7 @@ extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pair
                "sample_gather: batch_global < slot0 + batch");
   int rc = check_gather_layout("sample_gather", table, row_stride, F, x_out, out_stride);
   if (rc) return rc;
-  const int grid = grid_for(batch, kWavesPerBlock);
+  const int grid = grid_for((int64_t)batch * (mode == 0 ? 3 : 2), kWavesPerBlock);
   const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
 #define CDML_LAUNCH_SG(M, N)                                                                      \
   hipLaunchKernelGGL((k_sample_gather<M, N>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
