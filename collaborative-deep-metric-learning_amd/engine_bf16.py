@@ -101,17 +101,12 @@ def tower_forward(p, ws):
 
 
 def tower_backward(p, ws, after_w1=None):
-    """ws.de -> p.grad (fp32).  train.py:141; no dX."""
+    """ws.de -> p.grad (fp32).  train.py:141; no dX.  As in the fp32 engine the first layer's
+    gradient (85 % of the bytes) is produced BEFORE the second layer's, so that ``after_w1`` --
+    the data-parallel all-reduce of [dW1|db1] -- runs under the dW2 GEMM and the db2 sums."""
     L, R = p.layout, ws.R
     ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
-    ops.colsum(ws.dz2, R, L.Dp, p.gb2, ws.colsum_ws)       # fp32 dz2: db2 keeps full precision
     ops.cast_f32_bf16(ws.dz2, ws.dz2_bf, R, L.Dp)
-    if ws.tn2:
-        ops.gemm_bf16_tn(ws.h1, ws.dz2_bf, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
-    else:
-        ops.transpose_to_bf16(ws.dz2, ws.dz2T, R, L.Dp)
-        ops.transpose_to_bf16(ws.h1, ws.h1T, R, L.Hp)
-        ops.gemm_bf16_nt(ops.BE_F32, ws.h1T, ws.dz2T, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
     ops.gemm_bf16_nt(ops.BE_MASK_BF16, ws.dz2_bf, ws.W2, ws.dz1, R, L.Hp, L.Dp, aux=ws.h1)
     if ws.tn1:   # db1 = column sums of dz1, taken from the LDS tiles of the same GEMM
         ops.gemm_bf16_tn(ws.x_hat, ws.dz1, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws, colsum=p.gb1)
@@ -122,4 +117,11 @@ def tower_backward(p, ws, after_w1=None):
         ops.gemm_bf16_nt(ops.BE_F32, ws.xT, ws.dz1T, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws)
     if after_w1 is not None:
         after_w1()
+    ops.colsum(ws.dz2, R, L.Dp, p.gb2, ws.colsum_ws)       # fp32 dz2: db2 keeps full precision
+    if ws.tn2:
+        ops.gemm_bf16_tn(ws.h1, ws.dz2_bf, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
+    else:
+        ops.transpose_to_bf16(ws.dz2, ws.dz2T, R, L.Dp)
+        ops.transpose_to_bf16(ws.h1, ws.h1T, R, L.Hp)
+        ops.gemm_bf16_nt(ops.BE_F32, ws.h1T, ws.dz2T, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
     return p.grad
