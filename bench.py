@@ -258,17 +258,23 @@ def main():
         rpt = ts.rows_per_triplet
         R = B * rpt
         ms = elapsed / args.steps * 1e3
+        if args.precision == "bf16":
+            cfg_name = "config4" + (" (1 GPU)" if world == 1 else "")
+        elif world > 1:
+            cfg_name = "config3 (weak-scaled)"
+        else:
+            cfg_name = {"inbatch": "config1", "semihard": "config2", "uniform": "config1 size, reference negative rule"}[args.mode]
         out = {
             "metric": "triplets/sec", "value": round(world * B * args.steps / elapsed, 1),
             "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16 (fp16 table, f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": ("config1" if world == 1 else "config3 (weak-scaled)") + ": %d videos x %d-d fp32 in HBM, %d hidden, %d-d embed, "
-                                   "batch %d triplets/GPU, %s negatives, margin %.1f, Adam, full step "
-                                   "(sample+gather+fwd+loss+bwd+opt)"
-                                   % (n_rows, F, H, D, B, {"inbatch": "in-batch", "uniform": "uniform random",
-                                                              "semihard": "semi-hard mined"}[args.mode], MARGIN),
+            "config": {"workload": "%s: %d videos x %d-d %s in HBM, %d hidden, %d-d embed, batch %d triplets/GPU, "
+                                   "%s negatives, margin %.1f, Adam, full step (sample+gather+fwd+loss+bwd+opt)"
+                                   % (cfg_name, n_rows, F, "fp16" if args.precision == "bf16" else "fp32", H, D, B,
+                                      {"inbatch": "in-batch", "uniform": "uniform random",
+                                       "semihard": "semi-hard mined"}[args.mode], MARGIN),
                        "global_batch": world * B, "rows_per_triplet": rpt,
                        "parallelism": "dp%d" % world + ("" if world == 1 else " row-sharded table, all-to-all rows + all-reduce grads"),
                        "hipgraph": bool(args.graph)},
