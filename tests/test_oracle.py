@@ -296,3 +296,24 @@ def test_fusion_towers_vs_torch_autograd(net):
     for k in P:
         np.testing.assert_allclose(g[k][0], tp[k][0].grad.numpy(), atol=1e-12, err_msg=k)
         np.testing.assert_allclose(g[k][1], tp[k][1].grad.numpy(), atol=1e-12, err_msg=k)
+
+
+def test_knn_oracle_known_geometry():
+    """oracle/knn.py on a configuration with a known answer: points on a circle -- the
+    neighbours of a point are itself, then its ring neighbours in order of angular distance."""
+    from oracle import knn as oknn
+    n = 24
+    ang = 2 * np.pi * np.arange(n) / n
+    pts = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32) * 3.0    # not unit length: l2_norm fixes it
+    D, I, _ = oknn.calc_knn_exact(pts, nearest_num=5)
+    assert (I[:, 0] == np.arange(n)).all() and np.allclose(D[:, 0], 0.0, atol=1e-12)
+    for r in range(n):
+        assert set(I[r, 1:3]) == {(r - 1) % n, (r + 1) % n}
+        assert set(I[r, 3:5]) == {(r - 2) % n, (r + 2) % n}
+    chord = 2 - 2 * np.cos(2 * np.pi / n)                                       # squared chord of unit circle
+    assert np.allclose(D[:, 1:3], chord, atol=1e-6)
+    dup = np.concatenate([pts, pts[5:6], pts[5:6]])                             # exact ties: ordered by id
+    _, Id, _ = oknn.calc_knn_exact(dup, nearest_num=3)
+    assert list(Id[5]) == [5, n, n + 1] and list(Id[n + 1]) == [5, n, n + 1]
+    D2, I2, _ = oknn.calc_knn_exact(pts[:3], nearest_num=5)                     # fewer rows than k
+    assert (I2[:, 3:] == -1).all() and np.isinf(D2[:, 3:]).all()
