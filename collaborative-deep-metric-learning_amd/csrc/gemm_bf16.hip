@@ -247,6 +247,26 @@ k_sum_slabs_f32(const float *__restrict__ slabs, int64_t slab_stride, int splits
   }
 }
 
+// out = lrelu(sum_z slab[z] + bias): the split-K form of the narrow output layer (N = 256
+// gives the big kernel too few tiles; two K-halves fill the chip and this pass finishes it)
+__global__ void __launch_bounds__(kThreads)
+k_sum_slabs_bias_lrelu(const float *__restrict__ slabs, int64_t slab_stride, int splits, int rows, int N,
+                       const float *__restrict__ bias, float alpha, float *__restrict__ out, int64_t ldo) {
+  const int n4 = N >> 2;
+  const int64_t total = (int64_t)rows * n4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / n4;
+    const int c = (int)(i - r * n4);
+    f32x4 s = reinterpret_cast<const f32x4 *>(slabs)[i];
+    for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4 *>(slabs + (int64_t)z * slab_stride)[i];
+    s += reinterpret_cast<const f32x4 *>(bias)[c];
+    s.x = fmaxf(s.x, s.x * alpha); s.y = fmaxf(s.y, s.y * alpha);
+    s.z = fmaxf(s.z, s.z * alpha); s.w = fmaxf(s.w, s.w * alpha);
+    reinterpret_cast<f32x4 *>(out + r * ldo)[c] = s;
+  }
+}
+
 // fp16 catalogue: Philox table (same stream as the fp32 one, rounded to half) and
 // the row gather: fp16 rows in, l2-normalised (fp32 arithmetic) bf16 rows out.
 __global__ void __launch_bounds__(kThreads)
@@ -357,10 +377,24 @@ static bool use_256(int epilogue, int M, int N, int K, int64_t lda, int64_t ldb)
   return K >= 256 && (epilogue == BE_F32 ? tiles * gemm_bf16_256_splits(M, N, K) >= 128 : tiles >= 192);
 }
 
+// Narrow fp32-output forward layer (epilogue 1) on the 256x256 kernel: split K until most of
+// the chip has a block; the bias + leaky-relu then move to the slab combine.  1 = do not split.
+static int fwd_f32_splits(int M, int N, int K, int64_t lda, int64_t ldb) {
+  if (forced_tile() == 128 || !gemm_bf16_256_usable(M, N, K, lda, ldb)) return 1;
+  const int64_t tiles = (int64_t)((M + 255) / 256) * (N / 256);
+  if (tiles >= 192) return 1;
+  int s = (int)((170 + tiles - 1) / tiles);
+  const int max_by_k = K / 512;
+  if (s > max_by_k) s = max_by_k;
+  if (s > 8) s = 8;
+  return s < 2 ? 1 : s;
+}
+
 extern "C" size_t cdml_gemm_bf16_workspace(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0 || N % BN || K % BKB) return 0;
-  int splits = bf16_splits(M, N, K);             // enough for whichever kernel is dispatched
-  if (gemm_bf16_256_usable(M, N, K, K, K)) splits = max(splits, gemm_bf16_256_splits(M, N, K));
+  int splits = bf16_splits(M, N, K);             // enough for whichever kernel / epilogue is dispatched
+  if (gemm_bf16_256_usable(M, N, K, K, K))
+    splits = max(splits, max(gemm_bf16_256_splits(M, N, K), fwd_f32_splits(M, N, K, K, K)));
   return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
@@ -385,6 +419,22 @@ extern "C" int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda, c
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = N / BN;
   hipStream_t s = (hipStream_t)stream;
   const dim3 block(kThreads);
+  if (epilogue == BE_BIAS_LRELU_F32) {
+    const int fs = fwd_f32_splits(M, N, K, lda, ldb);
+    const size_t need = (size_t)fs * M * N * sizeof(float);
+    if (fs > 1 && workspace && workspace_bytes >= need && aligned16(workspace)) {   // else: one-pass kernels below
+      g.k_per_split = ((K + fs - 1) / fs + 2 * BKB - 1) / (2 * BKB) * (2 * BKB);
+      g.slab_stride = (int64_t)M * N;
+      g.C = workspace; g.ldc = N;
+      g.tiles_m = (M + 255) / 256; g.tiles_n = N / 256;
+      int rc = launch_gemm_bf16_256(g, BE_F32, fs, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_sum_slabs_bias_lrelu, dim3(grid1d((int64_t)M * N / 4, 1)), block, 0, s,
+                         static_cast<const float *>(workspace), g.slab_stride, fs, M, N, bias, alpha,
+                         static_cast<float *>(C), ldc);
+      return check_launch("gemm_bf16_nt combine + bias + lrelu");
+    }
+  }
   const bool big = use_256(epilogue, M, N, K, lda, ldb);
   int splits = 1;
   if (epilogue == BE_F32) {

@@ -78,6 +78,7 @@ class TowerWorkspaceBF16:
             self.h1T, self.dz2T = bf(L.Hp, R), bf(L.Dp, R)
         self.W1T, self.W2T, self.W2 = bf(L.Hp, L.Fp), bf(L.Dp, L.Hp), bf(L.Hp, L.Dp)
         nb = max(ops.gemm_bf16_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_workspace(L.Fp, L.Hp, R),
+                 ops.gemm_bf16_workspace(R, L.Dp, L.Hp),
                  ops.gemm_bf16_tn_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_tn_workspace(L.Fp, L.Hp, R), 16)
         self.gemm_ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
         self.colsum_ws = f32(max(ops.colsum_workspace_floats(R, L.Hp), ops.colsum_workspace_floats(R, L.Dp)))
@@ -95,7 +96,7 @@ def tower_forward(p, ws):
     """x_hat (bf16, l2-normalised) -> h1 (bf16) -> z (fp32) -> e (fp32).  models.py:59-61."""
     L, R = p.layout, ws.R
     ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_BF16, ws.x_hat, ws.W1T, ws.h1, R, L.Hp, L.Fp, bias=p.b1)
-    ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_F32, ws.h1, ws.W2T, ws.z, R, L.Dp, L.Hp, bias=p.b2)
+    ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_F32, ws.h1, ws.W2T, ws.z, R, L.Dp, L.Hp, bias=p.b2, workspace=ws.gemm_ws)
     ops.l2norm_fwd(ws.z, L.Dp, ws.e)
     return ws.e
 

@@ -38,7 +38,7 @@ def dbf(x, dev):
                                         (77, 128, 5120, 0),
                                         # the 256x256 ping-pong kernel: minimal, ragged M, long K, many tiles
                                         (256, 256, 128, 256), (700, 512, 384, 256), (1000, 1024, 1536, 256),
-                                        (77, 256, 5120, 256), (3100, 4096, 512, 0)])
+                                        (77, 256, 5120, 256), (3100, 4096, 512, 0), (2000, 256, 5120, 0)])
 def test_gemm_bf16_epilogues(cd, M, N, K, tile, monkeypatch):
     if tile:
         monkeypatch.setenv("CDML_BF16_TILE", str(tile))
@@ -64,6 +64,10 @@ def test_gemm_bf16_epilogues(cd, M, N, K, tile, monkeypatch):
     ws = torch.empty(max(cd.ops.gemm_bf16_workspace(M, N, K), 16) // 4, device=cd.dev)
     cd.ops.gemm_bf16_nt(cd.ops.BE_F32, dA, dB, out, M, N, K, workspace=ws)
     np.testing.assert_allclose(out.cpu().numpy(), ref, **tol)
+    # epilogue 1 with a workspace: split-K + combine(bias, lrelu) where the layer is narrow
+    out1 = torch.empty_like(out)
+    cd.ops.gemm_bf16_nt(cd.ops.BE_BIAS_LRELU_F32, dA, dB, out1, M, N, K, bias=dbias, workspace=ws)
+    np.testing.assert_allclose(out1.cpu().numpy(), want, **tol)
     out2 = torch.empty_like(out)
     cd.ops.gemm_bf16_nt(cd.ops.BE_F32, dA, dB, out2, M, N, K, workspace=ws)
     assert torch.equal(out, out2)                                  # deterministic split-K
