@@ -111,11 +111,24 @@ __device__ __forceinline__ int32_t sample_inbatch_shift(uint64_t seed, uint64_t 
 
 // XCD-aware bijective remap (blocks b and b+8 share an XCD) followed by a
 // grouped raster: 8 M-tiles x all N-tiles per group.
-__device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int tiles_n, int &tm,
-                                              int &tn) {
+__device__ __forceinline__ int logical_block(int bid, int nwg) {
   const int xcd = bid & 7, local = bid >> 3;
   const int q = nwg >> 3, r = nwg & 7;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+// Row-major raster after the same XCD remap: consecutive blocks of an XCD walk ALONG an output
+// row, so what the chip writes (and reads beside it) at any moment is long contiguous runs.
+// For products with a short contraction, where the output stream is the cost.
+__device__ __forceinline__ void tile_of_block_rowmajor(int bid, int nwg, int tiles_n, int &tm, int &tn) {
+  const int logical = logical_block(bid, nwg);
+  tm = logical / tiles_n;
+  tn = logical - tm * tiles_n;
+}
+
+__device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int tiles_n, int &tm,
+                                              int &tn) {
+  const int logical = logical_block(bid, nwg);
   constexpr int GROUP_M = 8;
   const int width = GROUP_M * tiles_n;
   const int group = logical / width;

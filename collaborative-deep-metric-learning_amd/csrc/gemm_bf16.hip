@@ -130,11 +130,18 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_bf16_nt(BArgs g) {
   f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
   if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
   const bool has_aux = (EPI == BE_MASK_BF16) && g.aux != nullptr;
-#pragma unroll 4
+  // the 16 mask loads of a thread go out together (rows clamped): a load under the row branch
+  // is waited for on the spot, 16 dependent round trips per tile
+  bf16x4 mk[BM / 8];
+  if (EPI == BE_MASK_BF16 && has_aux) {
+#pragma unroll
+    for (int p = 0; p < BM / 8; ++p)
+      mk[p] = *reinterpret_cast<const bf16x4 *>(g.aux + (int64_t)min(m0 + p * 8 + lr0, g.M - 1) * g.ldaux + col);
+  }
+#pragma unroll
   for (int p = 0; p < BM / 8; ++p) {
     const int lr = p * 8 + lr0;
     const int row = m0 + lr;
-    if (row >= g.M) continue;
     f32x4 v = *reinterpret_cast<const f32x4 *>(sC + lr * BN + c4 * 4);
     if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) {
       v += bias4;
@@ -142,11 +149,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_bf16_nt(BArgs g) {
       v.z = fmaxf(v.z, v.z * g.alpha); v.w = fmaxf(v.w, v.w * g.alpha);
     } else if (EPI == BE_MASK_BF16) {
       if (has_aux) {
-        const bf16x4 m = *reinterpret_cast<const bf16x4 *>(g.aux + (int64_t)row * g.ldaux + col);
+        const bf16x4 m = mk[p];
         v.x *= ((float)m.x > 0.f) ? 1.f : g.alpha; v.y *= ((float)m.y > 0.f) ? 1.f : g.alpha;
         v.z *= ((float)m.z > 0.f) ? 1.f : g.alpha; v.w *= ((float)m.w > 0.f) ? 1.f : g.alpha;
       }
     }
+    if (row >= g.M) continue;                                // stores only below this line
     if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_MASK_BF16) {
       bf16x4 o;
       o.x = (bf16)v.x; o.y = (bf16)v.y; o.z = (bf16)v.z; o.w = (bf16)v.w;

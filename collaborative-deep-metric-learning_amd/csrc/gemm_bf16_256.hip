@@ -110,7 +110,8 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   const int l31 = lane & 31, h = lane >> 5;
 
   int tm, tn;
-  tile_of_block(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, tm, tn);
+  if (g.K <= 512) tile_of_block_rowmajor(blockIdx.x, gridDim.x, g.tiles_n, tm, tn);   // output-bound
+  else tile_of_block(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, tm, tn);
   const int m0 = tm * kTileM, n0 = tn * kTileN;
   const int split = blockIdx.y;
   const int k_begin = split * g.k_per_split;

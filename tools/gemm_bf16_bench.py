@@ -22,12 +22,13 @@ for name, epi, M, N, K in cases:
     A = (torch.randn(M, K, device=dev) / K ** 0.5).bfloat16()
     B = torch.randn(N, K, device=dev).bfloat16()
     bias = torch.zeros(N, device=dev)
+    aux = torch.randn(M, N, device=dev).bfloat16() if epi == ops.BE_MASK_BF16 else None   # the lrelu mask (h1)
     out = torch.empty((M, N), device=dev, dtype=torch.float32 if epi in (ops.BE_BIAS_LRELU_F32, ops.BE_F32) else torch.bfloat16)
     ws = torch.empty(max(ops.gemm_bf16_workspace(M, N, K), 16) // 4, device=dev)
     res = {}
     for tile in ("128", "256"):
         os.environ["CDML_BF16_TILE"] = tile
-        fn = lambda: ops.gemm_bf16_nt(epi, A, B, out, M, N, K, bias=bias, workspace=ws)
+        fn = lambda: ops.gemm_bf16_nt(epi, A, B, out, M, N, K, bias=bias, aux=aux, workspace=ws)
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
