@@ -220,6 +220,23 @@ def test_train_step_bf16_config4_precision(cd, mode):
         cd.train.TrainStep(table, torch.as_tensor(pairs).to(cd.dev), B, precision="f32", device=cd.dev)
 
 
+def test_bf16_graph_replay_equals_eager(cd):
+    """Config 4 asks for a hipGraph-captured step: replay must give the eager step's bits
+    (device-side step counter and learning rate, no allocation on the step path)."""
+    N, F, B = 6000, 1500, 128
+    table = cd.ebf.FeatureTableF16.synthetic(N, F, 0, cd.dev)
+    pairs = torch.as_tensor(osynth.cowatch_pairs(N, 800, 0)).to(cd.dev)
+    kw = dict(mode="uniform", precision="bf16", device=cd.dev)
+    a = cd.train.TrainStep(table, pairs, B, use_graph=False, **kw)
+    b = cd.train.TrainStep(table, pairs, B, use_graph=True, **kw)
+    for _ in range(4):
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.params.flat, b.params.flat)
+    assert torch.equal(a.idx, b.idx) and int(b.step_dev.item()) == 4
+
+
 def test_bf16_training_learns(cd):
     rng = np.random.RandomState(0)
     centers = rng.random_sample((10, 64))
