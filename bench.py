@@ -89,6 +89,9 @@ class KernelTimer:
         v = [s.elapsed_time(e) for s, e in self.ev.get(name, [])]
         return max(float(np.mean(v)) - self.overhead_ms, 1e-6) if v else None
 
+    def count(self, name):
+        return len(self.ev.get(name, []))
+
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
@@ -218,7 +221,7 @@ def main():
             return kt.wrap(name, real_fwd)(x, W, b, y, M, K, N, *a, **k)
 
         def bww(x, dy, dW, db, ws, M, K, N):
-            name = "dW1" if K == L.Fp else "dW2"
+            name = "dW1" if N == L.Hp else "dW2"         # by layer (data-parallel runs do dW1 in row blocks)
             return kt.wrap(name, real_bww)(x, dy, dW, db, ws, M, K, N)
         ops.fc_lrelu_fwd, ops.fc_bwd_weight = fwd, bww
         ts.fetch = kt.wrap("fetch", ts.fetch)
@@ -284,15 +287,18 @@ def main():
         # launched twice per step (dW1: 2*R*F*H flop, dW2: 2*R*H*D flop); rocprof's per-kernel
         # average is over both launches, so the roofline is too.  Algorithmic (unpadded) flop.
         flops_gemm = 2.0 * R * F * H
-        if timers_on:
-            t_ms = 0.5 * (kt.mean_ms("dW1") + kt.mean_ms("dW2"))
-            flop_launch = 0.5 * (2.0 * R * F * H + 2.0 * R * H * D)
+        if timers_on and kt.count("dW1") and kt.count("dW2") and kt.count("fc1_fwd"):
+            # mean over ALL launches of the kernel in the timed steps, like rocprof's average
+            n_launch = kt.count("dW1") + kt.count("dW2")
+            t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
+            flop_launch = args.steps * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
             ach = flop_launch / (t_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_f32<false, false, 2, 2, 3, ...> (dW1+dW2 launches)",
                                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                               "traffic": pmc_traffic("k_gemm_f32<false, false, 2, 2, 3,"),
-                               "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch}
+                               "traffic": pmc_traffic("k_gemm_f32<false, false, 2, 2, 3,") if world == 1 else None,
+                               "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch,
+                               "launches_per_step": n_launch / args.steps}
             ach1 = flops_gemm / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
             out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": "k_gemm_f32<true, false, 2, 2, 1, ...>",
                                        "achieved": round(ach1, 2), "peak": PEAK_F32_MFMA_TFLOPS,

@@ -146,7 +146,9 @@ class TowerWorkspace:
             self.dz2 = z(n_rows, L.Dp)
             self.dz1 = z(n_rows, L.Hp)
             nbytes = max(ops.fc_bwd_weight_workspace(n_rows, L.Hp, L.Dp),
-                         ops.fc_bwd_weight_workspace(n_rows, L.Fp, L.Hp))
+                         ops.fc_bwd_weight_workspace(n_rows, L.Fp, L.Hp),
+                         # dW1 in two row blocks (data-parallel runs, tower_backward w1_chunks=2)
+                         ops.fc_bwd_weight_workspace(n_rows, L.Fp // 2, L.Hp) if L.Fp % 256 == 0 else 0)
             self.bw = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
@@ -161,16 +163,32 @@ def tower_forward(p, ws, n_rows=None):
     return ws.e
 
 
-def tower_backward(p, ws, n_rows=None, after_w1=None):
+def tower_backward(p, ws, n_rows=None, after_w1=None, w1_chunks=1, after_w1_chunk=None):
     """ws.de (grad wrt e) -> p.grad (dW1, db1, dW2, db2).  No dX: the features are
     inputs, not variables (train.py:265).  The first layer's gradient (85 % of the
     bytes) is produced BEFORE the second layer's so that ``after_w1`` -- the
-    data-parallel all-reduce of [dW1|db1] -- runs under the dW2 GEMM."""
+    data-parallel all-reduce of [dW1|db1] -- runs under the dW2 GEMM.
+
+    ``w1_chunks`` > 1 with ``after_w1_chunk(lo, hi)``: dW1 is produced in row blocks of W1
+    (contiguous ranges [lo, hi) of the flat gradient; the last one ends after db1) and the
+    callback fires after each, so the all-reduce of block c runs under the GEMM of block
+    c+1 and only the last, smaller one is left for the dW2 GEMM to cover."""
     L = p.layout
     R = ws.R if n_rows is None else n_rows
     ops.l2norm_bwd(ws.z[:R], ws.de[:R], L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
     ops.fc_bwd_data(ws.dz2, p.W2, ws.h1, ws.dz1, R, L.Hp, L.Dp)
-    ops.fc_bwd_weight(ws.x_hat, ws.dz1, p.gW1, p.gb1, ws.bw, R, L.Fp, L.Hp)
+    rows = L.Fp // w1_chunks if w1_chunks > 1 else 0
+    if after_w1_chunk is not None and w1_chunks > 1 and rows % 128 == 0 and rows * w1_chunks == L.Fp:
+        for c in range(w1_chunks):
+            lo, hi = c * rows, (c + 1) * rows
+            last = c == w1_chunks - 1
+            ops.fc_bwd_weight(ws.x_hat[:, lo:hi], ws.dz1, p.gW1[lo:hi], p.gb1 if last else None, ws.bw,
+                              R, rows, L.Hp)
+            after_w1_chunk(lo * L.Hp, hi * L.Hp + (L.Hp if last else 0))
+    else:
+        ops.fc_bwd_weight(ws.x_hat, ws.dz1, p.gW1, p.gb1, ws.bw, R, L.Fp, L.Hp)
+        if after_w1_chunk is not None:
+            after_w1_chunk(0, L.Fp * L.Hp + L.Hp)
     if after_w1 is not None:
         after_w1()
     ops.fc_bwd_weight(ws.h1, ws.dz2, p.gW2, p.gb2, ws.bw, R, L.Hp, L.Dp)

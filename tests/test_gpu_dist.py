@@ -160,3 +160,27 @@ def test_rccl_single_rank_exchange_paths(gpu):
     msg = q.get(timeout=300)
     p.join(timeout=60)
     assert msg == "ok", msg
+
+
+def test_bench_two_rank_rehearsal(gpu):
+    """bench.py through its N>1 code path (torch.distributed.run, two ranks sharing the card,
+    gloo-staged collectives): one JSON line from rank 0 with the whole-job numbers."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, CDML_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "40000", "--batch", "256"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 512 and out["value"] > 0
+    assert out["roofline"]["launches_per_step"] == 3.0      # dW1 in two row blocks + dW2
+    assert np.isfinite(out["loss"])
