@@ -79,7 +79,8 @@ class TowerWorkspaceBF16:
         self.W1T, self.W2T, self.W2 = bf(L.Hp, L.Fp), bf(L.Dp, L.Hp), bf(L.Hp, L.Dp)
         nb = max(ops.gemm_bf16_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_workspace(L.Fp, L.Hp, R),
                  ops.gemm_bf16_workspace(R, L.Dp, L.Hp),
-                 ops.gemm_bf16_tn_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_tn_workspace(L.Fp, L.Hp, R), 16)
+                 ops.gemm_bf16_tn_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_tn_workspace(L.Fp, L.Hp, R),
+                 ops.gemm_bf16_tn_workspace(L.Fp // 2, L.Hp, R), 16)      # dW1 in two row blocks (data-parallel)
         self.gemm_ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
         self.colsum_ws = f32(max(ops.colsum_workspace_floats(R, L.Hp), ops.colsum_workspace_floats(R, L.Dp)))
 
@@ -101,21 +102,36 @@ def tower_forward(p, ws):
     return ws.e
 
 
-def tower_backward(p, ws, after_w1=None):
+def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
     """ws.de -> p.grad (fp32).  train.py:141; no dX.  As in the fp32 engine the first layer's
     gradient (85 % of the bytes) is produced BEFORE the second layer's, so that ``after_w1`` --
-    the data-parallel all-reduce of [dW1|db1] -- runs under the dW2 GEMM and the db2 sums."""
+    the data-parallel all-reduce of [dW1|db1] -- runs under the dW2 GEMM and the db2 sums;
+    with ``w1_chunks`` > 1 dW1 comes in row blocks of W1 and ``after_w1_chunk(lo, hi)`` fires
+    after each (flat-gradient ranges; the last one ends after db1), as in engine.tower_backward."""
     L, R = p.layout, ws.R
     ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
     ops.cast_f32_bf16(ws.dz2, ws.dz2_bf, R, L.Dp)
     ops.gemm_bf16_nt(ops.BE_MASK_BF16, ws.dz2_bf, ws.W2, ws.dz1, R, L.Hp, L.Dp, aux=ws.h1)
-    if ws.tn1:   # db1 = column sums of dz1, taken from the LDS tiles of the same GEMM
-        ops.gemm_bf16_tn(ws.x_hat, ws.dz1, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws, colsum=p.gb1)
+    rows = L.Fp // w1_chunks if w1_chunks > 1 else 0
+    chunked = (after_w1_chunk is not None and w1_chunks > 1 and rows * w1_chunks == L.Fp and ws.tn1
+               and ops.gemm_bf16_tn_supported(rows, L.Hp, R, L.Fp, L.Hp))
+    if chunked:
+        for c in range(w1_chunks):
+            lo, hi = c * rows, (c + 1) * rows
+            last = c == w1_chunks - 1
+            ops.gemm_bf16_tn(ws.x_hat[:, lo:hi], ws.dz1, p.gW1[lo:hi], rows, L.Hp, R, workspace=ws.gemm_ws,
+                             colsum=p.gb1 if last else None)
+            after_w1_chunk(lo * L.Hp, hi * L.Hp + (L.Hp if last else 0))
     else:
-        ops.colsum(ws.dz1, R, L.Hp, p.gb1, ws.colsum_ws)
-        ops.transpose_to_bf16(ws.dz1, ws.dz1T, R, L.Hp)
-        ops.transpose_to_bf16(ws.x_hat, ws.xT, R, L.Fp)
-        ops.gemm_bf16_nt(ops.BE_F32, ws.xT, ws.dz1T, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws)
+        if ws.tn1:   # db1 = column sums of dz1, taken from the LDS tiles of the same GEMM
+            ops.gemm_bf16_tn(ws.x_hat, ws.dz1, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws, colsum=p.gb1)
+        else:
+            ops.colsum(ws.dz1, R, L.Hp, p.gb1, ws.colsum_ws)
+            ops.transpose_to_bf16(ws.dz1, ws.dz1T, R, L.Hp)
+            ops.transpose_to_bf16(ws.x_hat, ws.xT, R, L.Fp)
+            ops.gemm_bf16_nt(ops.BE_F32, ws.xT, ws.dz1T, p.gW1, L.Fp, L.Hp, R, workspace=ws.gemm_ws)
+        if after_w1_chunk is not None:
+            after_w1_chunk(0, L.Fp * L.Hp + L.Hp)
     if after_w1 is not None:
         after_w1()
     ops.colsum(ws.dz2, R, L.Dp, p.gb2, ws.colsum_ws)       # fp32 dz2: db2 keeps full precision

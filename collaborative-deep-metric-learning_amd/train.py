@@ -213,18 +213,14 @@ class TrainStep:
         if self.grad_sync is None:
             self.backward()
         else:
-            # buckets: [dW1|db1] (85 % of the bytes) is all-reduced while later GEMMs run --
-            # fp32: in two row blocks, the first under the second block's GEMM, the second
-            # under the dW2 GEMM; bf16: in one piece under the dW2 GEMM -- and [dW2|db2] right
-            # after its GEMM; the optimizer waits for all of them
+            # buckets: [dW1|db1] (85 % of the bytes) is all-reduced while later GEMMs run, in two
+            # row blocks -- the first under the second block's GEMM, the second under the dW2
+            # GEMM -- and [dW2|db2] right after its GEMM; the optimizer waits for all of them
             n1 = self.layout.offsets[2]
             handles = []
-            if self.bf16:
-                self.backward(after_w1=lambda: handles.append(self.grad_sync.start(self.params.grad, 0, n1)))
-            else:
-                engine.tower_backward(
-                    self.params, self.ws, w1_chunks=2,
-                    after_w1_chunk=lambda lo, hi: handles.append(self.grad_sync.start(self.params.grad, lo, hi)))
+            (engine_bf16 if self.bf16 else engine).tower_backward(
+                self.params, self.ws, w1_chunks=2,
+                after_w1_chunk=lambda lo, hi: handles.append(self.grad_sync.start(self.params.grad, lo, hi)))
             handles.append(self.grad_sync.start(self.params.grad, n1, self.layout.numel))
             self.grad_sync.finish(handles)
         if self.prefetch is not None:

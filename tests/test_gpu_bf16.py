@@ -220,6 +220,31 @@ def test_train_step_bf16_config4_precision(cd, mode):
         cd.train.TrainStep(table, torch.as_tensor(pairs).to(cd.dev), B, precision="f32", device=cd.dev)
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_backward_in_row_blocks_equals_one_piece(cd, precision):
+    """Data-parallel runs produce dW1 in two row blocks of W1 so that each block's all-reduce can
+    start early: same gradient (up to the split-K summation order), and the callback ranges tile
+    [W1|b1] of the flat gradient exactly."""
+    N, F, B = 6000, 1500, 128
+    if precision == "bf16":
+        table, eng = cd.ebf.FeatureTableF16.synthetic(N, F, 0, cd.dev), cd.ebf
+    else:
+        table, eng = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev), cd.engine
+    pairs = torch.as_tensor(osynth.cowatch_pairs(N, 800, 0)).to(cd.dev)
+    ts = cd.train.TrainStep(table, pairs, B, mode="uniform", precision=precision, device=cd.dev)
+    ts.fetch(); ts.forward_loss()
+    ts.backward()
+    g_one = ts.params.grad.clone()
+    ts.params.grad.zero_()
+    ranges = []
+    eng.tower_backward(ts.params, ts.ws, w1_chunks=2, after_w1_chunk=lambda lo, hi: ranges.append((lo, hi)))
+    torch.cuda.synchronize()
+    L = ts.layout
+    assert ranges == [(0, L.Fp // 2 * L.Hp), (L.Fp // 2 * L.Hp, L.Fp * L.Hp + L.Hp)]
+    scale = g_one.abs().max().item()
+    assert (ts.params.grad - g_one).abs().max().item() <= 2e-6 * max(scale, 1.0) + 1e-9
+
+
 def test_bf16_graph_replay_equals_eager(cd):
     """Config 4 asks for a hipGraph-captured step: replay must give the eager step's bits
     (device-side step counter and learning rate, no allocation on the step path)."""
