@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="bf16 = BASELINE config 4 path (fp16 table + bf16 MFMA); not the headline metric")
+    ap.add_argument("--train-table", action="store_true",
+                    help="also train the catalogue rows (lazy Adam; build-defined, not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
@@ -207,7 +209,8 @@ def main():
     ts = train.TrainStep(table, pairs, B, output_size=D, hidden_size=H, margin=MARGIN, mode=args.mode,
                          optimizer="adam", base_learning_rate=0.01, seed=1234, weight_seed=42,
                          device=dev, exchange=exchange, grad_sync=grad_sync, slot0=rank * B,
-                         batch_global=world * B, use_graph=args.graph, precision=args.precision)
+                         batch_global=world * B, use_graph=args.graph, precision=args.precision,
+                         train_table=args.train_table)
 
     # per-kernel event timers on the launch stream (off during graph replay)
     kt = KernelTimer()
@@ -280,7 +283,7 @@ def main():
                                        "semihard": "semi-hard mined"}[args.mode], MARGIN),
                        "global_batch": world * B, "rows_per_triplet": rpt,
                        "parallelism": "dp%d" % world + ("" if world == 1 else " row-sharded table, all-to-all rows + all-reduce grads"),
-                       "hipgraph": bool(args.graph)},
+                       "hipgraph": bool(args.graph), "trainable_table": bool(args.train_table)},
             "loss": round(loss, 6),
         }
         # dominant kernel by total time: the bwd-weight GEMM k_gemm_f32<false, false, 2, 2, 3>,

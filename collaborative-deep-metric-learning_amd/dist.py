@@ -104,7 +104,23 @@ class RowExchange:
         inv = torch.empty_like(order)
         inv[order] = torch.arange(order.numel(), device=dev)
         self.unpermute(rows_in, inv, out)
+        # kept for scatter_back(): the same routing carries row gradients to their owners
+        self.last_plan = (order, sc, rc, req_ids.clone() if n_req else req_ids)
         return out
+
+    def scatter_back(self, rows):
+        """The reverse trip of the last ``gather``: rows[r] (e.g. the gradient of the r-th
+        requested row) goes to the rank that owns ids[r].  Returns (ids, rows) as the owner
+        sees them: every request it served, in the order it served them (source rank, then the
+        requester's order) -- duplicates included."""
+        order, sc, rc, req_ids = self.last_plan
+        stride = rows.shape[1]
+        send = self._scratch("back_send", (order.numel(), stride), rows.dtype, rows.device)
+        self.unpermute(rows, order, send)                    # send[j] = rows[order[j]]
+        n_req = int(sum(rc))
+        recv = self._scratch("back_recv", (max(n_req, 1), stride), rows.dtype, rows.device)[:n_req]
+        all_to_all(recv, send, rc, sc, self.group)
+        return req_ids, recv
 
     def unpermute(self, rows_in, inv, out):
         """out[r] = rows_in[inv[r]] -- a row gather of the receive buffer."""

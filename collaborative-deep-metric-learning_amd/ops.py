@@ -308,6 +308,21 @@ def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, 
          0 if t is None else t, _p(t_dev, torch.int64), _stream())
 
 
+def table_adam_rows(table, row0, F, idx, grad_xhat, m_table, v_table, head, nxt, lr, t, beta1=0.9, beta2=0.999,
+                    eps=1e-8, lr_dev=None, t_dev=None):
+    """Lazy-Adam update of the catalogue rows a batch touched (see include/cdml.h)."""
+    tp, tld = _mat(table)
+    gp, gld = _mat(grad_xhat)
+    if m_table.shape != table.shape or v_table.shape != table.shape or m_table.stride(0) != tld \
+            or v_table.stride(0) != tld:
+        raise ValueError("m/v tables must have the table's shape and stride")
+    if head.numel() < table.shape[0] or nxt.numel() < idx.numel():
+        raise ValueError("head needs one int32 per table row, next one per gathered row")
+    call("cdml_table_adam_rows", tp, row0, table.shape[0], tld, F, _p(idx, torch.int32), idx.numel(), gp, gld,
+         _p(m_table), _p(v_table), _p(head, torch.int32), _p(nxt, torch.int32), lr, _p(lr_dev), beta1, beta2,
+         eps, 0 if t is None else t, _p(t_dev, torch.int64), _stream())
+
+
 def lars_scratch_floats():
     return int(load_library().cdml_lars_scratch_floats())
 

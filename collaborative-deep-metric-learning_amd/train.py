@@ -42,10 +42,12 @@ class TrainStep:
                  base_learning_rate=0.01, learning_rate_decay_examples=1000000,
                  learning_rate_decay=0.96, seed=1234, weight_seed=42, device="cuda:0",
                  exchange=None, grad_sync=None, slot0=0, batch_global=None, use_graph=False,
-                 prefetch=True, precision="f32"):
+                 prefetch=True, precision="f32", train_table=False):
         """table: FeatureTable (whole catalogue, or this rank's shard when
         ``exchange`` is given); pairs: int32 [P,2] device tensor; ``exchange`` /
-        ``grad_sync``: the multi-GPU hooks of cdml_amd.dist (None on one GPU)."""
+        ``grad_sync``: the multi-GPU hooks of cdml_amd.dist (None on one GPU).
+        ``train_table``: also train the catalogue rows (lazy Adam, states stored beside the
+        shard; build-defined -- the reference keeps the features frozen, train.py:265)."""
         if mode not in _MODES:
             raise ValueError("mode must be 'uniform', 'inbatch' or 'semihard'")
         if optimizer not in ("adam", "lars"):
@@ -106,6 +108,16 @@ class TrainStep:
         else:
             self.acc = torch.zeros(n, dtype=f32, device=dev)
             self.lars_scratch = torch.zeros(ops.lars_scratch_floats(), dtype=f32, device=dev)
+        self.train_table = bool(train_table)
+        if self.train_table:
+            if self.bf16 or optimizer != "adam":
+                raise ValueError("train_table goes with the fp32 path and the Adam optimizer")
+            self.tab_m = torch.zeros_like(table.data)
+            self.tab_v = torch.zeros_like(table.data)
+            self.tab_head = torch.full((table.n_rows,), -1, dtype=i32, device=dev)
+            self.tab_next = torch.zeros(self.R, dtype=i32, device=dev)
+            self.dxh = torch.zeros((self.R, self.layout.Fp), dtype=f32, device=dev)
+            prefetch = False      # a prefetched batch would read rows from before this step's update
         self._graph = None
         self.use_graph = bool(use_graph) and exchange is None and grad_sync is None
         # row-sharded catalogue: the exchange of step t+1 runs ahead on a side stream
@@ -194,6 +206,22 @@ class TrainStep:
         else:
             engine.tower_backward(self.params, self.ws, after_w1=after_w1)
 
+    def update_table(self):
+        """dLoss/d x_hat = dz1 . W1^T for the gathered rows, then the lazy-Adam update of the
+        catalogue rows they came from (on their owners when the table is sharded).  Runs
+        before the dense update: it needs this step's W1 and step counter."""
+        L, p, t = self.layout, self.params, self.table
+        ops.fc_bwd_data(self.ws.dz1, p.W1, None, self.dxh, self.R, L.Fp, L.Hp)
+        idx, rows = self.idx, self.dxh
+        if self.exchange is not None:
+            idx, rows = self.exchange.scatter_back(self.dxh)
+            if idx.numel() == 0:
+                return
+            if self.tab_next.numel() < idx.numel():
+                self.tab_next = torch.zeros(idx.numel(), dtype=torch.int32, device=self.device)
+        ops.table_adam_rows(t.data, t.row0, t.feature_size, idx, rows, self.tab_m, self.tab_v,
+                            self.tab_head, self.tab_next, 0.0, 1, lr_dev=self.lr_dev, t_dev=self.step_dev)
+
     def apply_gradients(self):
         p = self.params
         if self.optimizer == "adam":
@@ -226,6 +254,8 @@ class TrainStep:
         if self.prefetch is not None:
             t, b = self.global_step, self.global_step % 2
             self.prefetch.release(b)                 # backward was the last reader of x_hat[b]
+        if self.train_table:
+            self.update_table()
         self.apply_gradients()
         if self.prefetch is not None:                # next step's rows, under this step's GEMMs
             self.prefetch.launch(1 - b, lambda: self._fill(1 - b, t + 1))
@@ -268,10 +298,14 @@ class TrainStep:
         biases}), optimizer slots, step counter and sampler state."""
         L = self.layout
         slots = {"m": self.m, "v": self.v} if self.optimizer == "adam" else {"acc": self.acc}
-        return {"layout": (L.F, L.H, L.D), "variables": self.params.state_dict(),
-                "optimizer": self.optimizer, "slots": {k: t.detach().cpu().clone() for k, t in slots.items()},
-                "global_step": self.global_step, "seed": self.seed, "mode": self.mode,
-                "batch_size": self.B, "margin": self.margin}
+        state = {"layout": (L.F, L.H, L.D), "variables": self.params.state_dict(),
+                 "optimizer": self.optimizer, "slots": {k: t.detach().cpu().clone() for k, t in slots.items()},
+                 "global_step": self.global_step, "seed": self.seed, "mode": self.mode,
+                 "batch_size": self.B, "margin": self.margin}
+        if self.train_table:                             # this rank's shard and its Adam states
+            state["table"] = {"row0": self.table.row0, "rows": self.table.data.detach().cpu().clone(),
+                              "m": self.tab_m.detach().cpu().clone(), "v": self.tab_v.detach().cpu().clone()}
+        return state
 
     def load_state_dict(self, state):
         if tuple(state["layout"]) != (self.layout.F, self.layout.H, self.layout.D):
@@ -281,6 +315,12 @@ class TrainStep:
         self.params.load(*[state["variables"][n] for n in engine.VNetParams.NAMES])
         for k, t in state["slots"].items():
             getattr(self, k).copy_(t.to(self.device))
+        if self.train_table and "table" in state:
+            if int(state["table"]["row0"]) != self.table.row0 or state["table"]["rows"].shape != self.table.data.shape:
+                raise ValueError("checkpointed table shard does not match this rank's shard")
+            self.table.data.copy_(state["table"]["rows"].to(self.device))
+            self.tab_m.copy_(state["table"]["m"].to(self.device))
+            self.tab_v.copy_(state["table"]["v"].to(self.device))
         self.global_step = int(state["global_step"])
         self.step_dev.fill_(self.global_step)
         self.seed = int(state["seed"])

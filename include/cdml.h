@@ -309,6 +309,23 @@ int cdml_adam_step(float *w, const float *g, float *m, float *v, int64_t n,
                    float eps, int64_t t, const uint64_t *t_dev,
                    cdml_stream_t stream);
 
+/* Trainable catalogue rows (north_star: "the catalogue feature table and its Adam states
+ * shard row-wise"; the reference keeps the features frozen, train.py:265, so this is
+ * build-defined and off by default; spec oracle/table.py).  grad_xhat[r] = dLoss/d x_hat of
+ * the r-th gathered row (= cdml_fc_bwd_data(dz1, W1, NULL)), idx[r] its GLOBAL row id; rows
+ * outside [row0, row0+n_rows) are skipped (other shards').  Per touched row, once: the
+ * gradients of all batch rows that gathered it are summed in ascending r (deterministic),
+ * taken through the l2norm backward of models.py:58 with the raw row, and a lazy-Adam update
+ * (the arithmetic of cdml_adam_step; m/v/x of untouched rows are not read) is applied to
+ * table, m_table, v_table (same shape and stride).  head: int32[n_rows] scratch that must be
+ * all -1 on entry and is -1 again on exit; next: int32[n_idx] scratch. */
+int cdml_table_adam_rows(float *table, int64_t row0, int64_t n_rows, int64_t row_stride,
+                         int F, const int32_t *idx, int n_idx, const float *grad_xhat,
+                         int64_t ldg, float *m_table, float *v_table, int32_t *head,
+                         int32_t *next, float lr, const float *lr_dev, float beta1,
+                         float beta2, float eps, int64_t t, const uint64_t *t_dev,
+                         cdml_stream_t stream);
+
 /* LARS (tf.contrib.opt.LARSOptimizer, train.py:354), one variable of n
  * elements: trust = eeta*|w|/(|g|+wd*|w|+eps) (1 if |w|==0 or |g|==0);
  * acc = momentum*acc + lr*trust*(g+wd*w); w -= acc.

@@ -60,6 +60,20 @@ def _worker(rank, world, port, n_rows, F, q):
             want = otower.l2_normalize(full[idx], np.float32)[0]
             np.testing.assert_allclose(out[:, :F].numpy(), want, atol=1e-7)
             assert float(out[:, F:].abs().max()) == 0
+            # the reverse trip (row gradients to their owners): tag every requested row with
+            # (requesting rank, position, id); the owner must see exactly the requests it served
+            tag = torch.zeros((len(idx), 4))
+            tag[:, 0], tag[:, 1], tag[:, 2] = rank, torch.arange(len(idx)), torch.from_numpy(idx.astype(np.float32))
+            got_ids, got_rows = ex.scatter_back(tag)
+            assert got_ids.numel() == got_rows.shape[0]
+            assert ((got_ids >= lo) & (got_ids < hi)).all()                    # only rows this rank owns
+            np.testing.assert_array_equal(got_rows[:, 2].numpy(), got_ids.numpy().astype(np.float32))
+            mine = got_rows[got_rows[:, 0] == rank]                            # own requests come back in order
+            own = np.nonzero((idx >= lo) & (idx < hi))[0]
+            np.testing.assert_array_equal(mine[:, 1].numpy(), own.astype(np.float32))
+            n_total = torch.tensor([got_ids.numel()])
+            dist.all_reduce(n_total)
+            assert int(n_total) == world * len(idx)                            # nothing lost, nothing doubled
         # routing plan: sorted by owner, counts per owner, stable
         ids = torch.tensor([per + 1, 0, per, 3, 2 * per - 1], dtype=torch.int32).clamp(max=n_rows - 1)
         send, order, counts = ex.plan(ids)

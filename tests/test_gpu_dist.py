@@ -20,6 +20,8 @@ CFG = dict(n_rows=3000, F=200, H=300, D=64, B=32, steps=2, precision="f32")
 # config-4 precision on the same path: fp16 shards, bf16 rows over the wire, bf16 MFMA
 # (the bf16 tower wants a multiple of 64 rows: 64 triplets x 3 per rank)
 CFG_BF16 = dict(CFG, B=64, precision="bf16")
+# trainable catalogue rows: row gradients travel back to the owners (RowExchange.scatter_back)
+CFG_TABLE = dict(CFG, train_table=True)
 
 
 def _make(dev, rank, world, exchange=None, grad_sync=None, c=None):
@@ -37,7 +39,8 @@ def _make(dev, rank, world, exchange=None, grad_sync=None, c=None):
         B, slot0 = c["B"], rank * c["B"]
     return train.TrainStep(table, pairs, B, hidden_size=c["H"], output_size=c["D"], mode="uniform",
                            device=dev, exchange=exchange, grad_sync=grad_sync, slot0=slot0,
-                           batch_global=2 * c["B"], precision=c["precision"])
+                           batch_global=2 * c["B"], precision=c["precision"],
+                           train_table=c.get("train_table", False))
 
 
 def _worker(rank, world, port, q, CFG=CFG):
@@ -58,15 +61,16 @@ def _worker(rank, world, port, q, CFG=CFG):
             if g0 is None:
                 g0 = ts.params.grad.cpu().numpy().copy()                # averaged gradient, step 0
         torch.cuda.synchronize()
-        q.put((rank, "ok", np.stack(idx), ts.params.flat.cpu().numpy(), ts.loss(), g0))
+        shard = ts.table.data.cpu().numpy() if CFG.get("train_table") else None
+        q.put((rank, "ok", np.stack(idx), ts.params.flat.cpu().numpy(), ts.loss(), g0, shard))
     except Exception:
         import traceback
-        q.put((rank, traceback.format_exc(), None, None, None, None))
+        q.put((rank, traceback.format_exc(), None, None, None, None, None))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("CFG", [CFG, CFG_BF16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_TABLE], ids=["f32", "bf16", "trainable-table"])
 def test_two_rank_step_equals_single_rank(gpu, CFG):
     bf16 = CFG["precision"] == "bf16"
     s = socket.socket()
@@ -107,6 +111,15 @@ def test_two_rank_step_equals_single_rank(gpu, CFG):
     assert np.abs(res[0][3] - w).max() < 2.5e-2
     assert np.mean(np.abs(res[0][3] - w) > 1e-4) < 0.02
     assert abs(0.5 * (res[0][4] + res[1][4]) - single.loss()) < (2e-3 if bf16 else 1e-4)
+    if CFG.get("train_table"):
+        # each rank holds its rows of the single-rank table after the same updates (same Adam
+        # caveat as for the weights: sign flips of gradients that are fp32 noise)
+        whole = single.table.data.cpu().numpy()
+        got = np.concatenate([res[0][6], res[1][6]])
+        assert got.shape == whole.shape
+        assert np.mean(np.abs(got - whole) > 1e-4) < 0.02 and np.abs(got - whole).max() < 2.5e-2
+        fresh = _make(gpu, 0, 1, c=CFG).table.data.cpu().numpy()
+        assert np.abs(got - fresh).max() > 5e-3                       # and they did move
 
 
 def _nccl_worker(port, q):

@@ -317,3 +317,24 @@ def test_knn_oracle_known_geometry():
     assert list(Id[5]) == [5, n, n + 1] and list(Id[n + 1]) == [5, n, n + 1]
     D2, I2, _ = oknn.calc_knn_exact(pts[:3], nearest_num=5)                     # fewer rows than k
     assert (I2[:, 3:] == -1).all() and np.isinf(D2[:, 3:]).all()
+
+
+def test_table_oracle_l2norm_backward_and_duplicates():
+    """oracle/table.py: the row gradient is the l2-normalisation backward of the summed
+    duplicates (finite differences), and only touched rows move."""
+    from oracle import table as otable
+    rng = np.random.RandomState(0)
+    tab = rng.rand(6, 9)
+    G = rng.randn(5, 9)
+    idx = np.array([2, 4, 2, 9, 2])                       # row 2 three times, row 9 belongs to another shard
+    # one Adam step from zero slots moves w by lr * dx / (|dx| + eps'): recover the sign pattern, and the
+    # magnitude through m = (1 - beta1) * dx
+    new, m, v = otable.table_adam_rows(tab, np.zeros_like(tab), np.zeros_like(tab), idx, G, 1, 0.01)
+    g2 = G[0] + G[2] + G[4]
+    f = lambda x: float((x / np.sqrt(x @ x)) @ g2)        # loss whose d/dx_hat is g2
+    num = np.array([(f(tab[2] + 1e-6 * e) - f(tab[2] - 1e-6 * e)) / 2e-6 for e in np.eye(9)])
+    np.testing.assert_allclose(m[2] / (1 - 0.9), num, atol=1e-6)
+    np.testing.assert_allclose(new[2], tab[2] - 0.01 * np.sign(num), atol=1e-6)   # first Adam step = lr * sign
+    assert np.array_equal(new[[0, 1, 3, 5]], tab[[0, 1, 3, 5]]) and not np.array_equal(new[4], tab[4])
+    shard, _, _ = otable.table_adam_rows(tab[3:], np.zeros((3, 9)), np.zeros((3, 9)), idx, G, 1, 0.01, row0=3)
+    np.testing.assert_array_equal(shard, new[3:])         # a shard sees only its own rows
