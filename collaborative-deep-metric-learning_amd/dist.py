@@ -58,6 +58,13 @@ def _hip_local_gather(table, ids, out):
     return out
 
 
+def raw_local_gather(table, ids, out):
+    """Owner side for the fusion towers: rows as stored (they normalise the visual and the
+    document part separately, models.py:86-88)."""
+    ops.gather_rows(table.data, table.row0, ids, table.feature_size, out, normalize=False)
+    return out
+
+
 class RowExchange:
     """Fetch (normalised) feature rows by GLOBAL id from a row-sharded table."""
 

@@ -188,8 +188,15 @@ class FusionTrainStep:
     ``feature_size`` 1628, online_data.py:38)."""
 
     def __init__(self, net, table, pairs, batch_size, margin=0.8, base_learning_rate=0.01, seed=1234,
-                 weight_seed=42, device="cuda:0", **dims):
+                 weight_seed=42, device="cuda:0", exchange=None, grad_sync=None, slot0=0, batch_global=None,
+                 **dims):
+        """``exchange`` (a dist.RowExchange built with ``local_gather=dist.raw_local_gather``) and
+        ``grad_sync``: the data-parallel hooks, as for train.TrainStep -- row-sharded table, this
+        rank's slice [slot0, slot0+B) of the global batch, averaged gradients."""
         self.device = torch.device(device)
+        self.exchange, self.grad_sync = exchange, grad_sync
+        self.slot0 = int(slot0)
+        self.batch_global = int(batch_size) if batch_global is None else int(batch_global)
         self.table, self.pairs, self.B, self.margin, self.seed = table, pairs, int(batch_size), margin, seed
         doc = table.feature_size - dims.get("visual_size", VISUAL)
         self.params = FusionParams(net, device, doc_size=doc, seed=weight_seed, **dims)
@@ -204,12 +211,18 @@ class FusionTrainStep:
 
     def step(self):
         t = self.tower
-        ops.sample_uniform(self.pairs, self.table.n_rows_global, self.seed, self.global_step, self.B, self.idx)
-        ops.gather_rows(self.table.data, self.table.row0, self.idx.view(-1), self.table.feature_size, self.x,
-                        normalize=False)
+        ops.sample_uniform(self.pairs, self.table.n_rows_global, self.seed, self.global_step, self.B, self.idx,
+                           slot0=self.slot0, batch_global=self.batch_global)
+        if self.exchange is None:
+            ops.gather_rows(self.table.data, self.table.row0, self.idx.view(-1), self.table.feature_size, self.x,
+                            normalize=False)
+        else:
+            self.exchange.gather(self.table, self.idx.view(-1), self.x)
         t.forward(self.x)
         ops.triplet_hinge(t.e, self.B, self.params.Dp, self.margin, self.pos, self.neg, self.hinge, self.stats, t.de)
         t.backward()
+        if self.grad_sync is not None:
+            self.grad_sync(self.params.grad)
         self.global_step += 1
         ops.adam_step(self.params.flat, self.params.grad, self.m, self.v, self.lr, self.global_step)
 

@@ -197,3 +197,76 @@ def test_bench_two_rank_rehearsal(gpu):
     assert out["config"]["global_batch"] == 512 and out["value"] > 0
     assert out["roofline"]["launches_per_step"] == 3.0      # dW1 in two row blocks + dW2
     assert np.isfinite(out["loss"])
+
+
+# ---- fusion towers (ResNet, the reference's production model) over a row-sharded table ----
+FUS = dict(n_rows=1200, vis=64, doc=16, B=32, steps=2)
+
+
+def _make_fusion(dev, rank, world, exchange=None, grad_sync=None):
+    from cdml_amd import dist as cdist, engine, fusion
+    from oracle import synth as osynth
+    c = FUS
+    F = c["vis"] + c["doc"]
+    pairs = torch.from_numpy(osynth.cowatch_pairs(c["n_rows"], 200, 0)).to(dev)
+    if world == 1:
+        table, B, slot0 = engine.FeatureTable.synthetic(c["n_rows"], F, 0, dev), 2 * c["B"], 0
+    else:
+        lo, hi, _ = cdist.shard_bounds(c["n_rows"], world, rank)
+        table = engine.FeatureTable.synthetic(hi - lo, F, 0, dev, row0=lo, n_rows_global=c["n_rows"])
+        B, slot0 = c["B"], rank * c["B"]
+    return fusion.FusionTrainStep("ResNet", table, pairs, B, device=dev, exchange=exchange, grad_sync=grad_sync,
+                                  slot0=slot0, batch_global=2 * c["B"], visual_size=c["vis"], hidden_v=128,
+                                  hidden_d=32, output_size=32)
+
+
+def _worker_fusion(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cdml_amd import dist as cdist
+        dev = torch.device("cuda:0")
+        ex = cdist.RowExchange(FUS["n_rows"], group=dist.new_group(), local_gather=cdist.raw_local_gather)
+        ts = _make_fusion(dev, rank, world, ex, cdist.GradSync())
+        idx = []
+        for _ in range(FUS["steps"]):
+            ts.step()
+            idx.append(ts.idx.cpu().numpy().copy())
+        torch.cuda.synchronize()
+        q.put((rank, "ok", np.stack(idx), ts.params.flat.cpu().numpy(), ts.loss()))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_fusion_step_equals_single_rank(gpu):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_fusion, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
+    single = _make_fusion(gpu, 0, 1)
+    idx = []
+    for _ in range(FUS["steps"]):
+        single.step()
+        idx.append(single.idx.cpu().numpy().copy())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(np.concatenate([res[0][2], res[1][2]], axis=1), np.stack(idx))
+    np.testing.assert_array_equal(res[0][3], res[1][3])                # replicas stay identical
+    w = single.params.flat.cpu().numpy()
+    assert np.abs(res[0][3] - w).max() < 2.5e-2 and np.mean(np.abs(res[0][3] - w) > 1e-4) < 0.02
+    assert abs(0.5 * (res[0][4] + res[1][4]) - single.loss()) < 1e-4
