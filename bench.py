@@ -154,8 +154,8 @@ def cpu_baseline(budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=None, help="catalogue rows (default: 1M, or 10M when --gpus > 1)")
     ap.add_argument("--mode", default="inbatch", choices=["inbatch", "uniform", "semihard"])
     ap.add_argument("--batch", type=int, default=BATCH, help="triplets per GPU per step")
@@ -325,7 +325,11 @@ def main():
                 out["gather"] = {"bound": "hbm", "kernel": "k_sample_gather", "achieved": round(g_ach, 1),
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4),
                                  "traffic": pmc_traffic("k_sample_gather<1, 6>" if rpt == 2 else "k_sample_gather<0, 6>"),
-                                 "bytes_per_launch": gbytes, "launch_ms": round(t_f, 4)}
+                                 "bytes_per_launch": gbytes, "launch_ms": round(t_f, 4),
+                                 # a 20-us kernel between two events: the pair's own cost (measured
+                                 # on an empty pair, +-2 us run to run) is subtracted above; rocprofv3's
+                                 # per-kernel average in profiles/ is the steadier figure
+                                 "launch_ms_with_event_pair": round(t_f + kt.overhead_ms, 4)}
         step_flops = R * (2.0 * F * H + 2.0 * H * D) + R * (2.0 * F * H + 4.0 * H * D)
         out["step_tflops"] = round(step_flops / (elapsed / args.steps) / 1e12, 2)
         if world == 1 and not args.no_cpu_baseline:
