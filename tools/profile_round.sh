@@ -9,9 +9,9 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $ROOT/bench.py --steps 20 --warmup 3 > $ROOT/gpurun_out/${TAG}_bench.json
+python3 $ROOT/bench.py > $ROOT/gpurun_out/${TAG}_bench.json
 echo "[profile] plain bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --steps 20 --warmup 3 \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --steps 60 --warmup 5 \
     --no-cpu-baseline > $ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $ROOT/gpurun_out/${TAG}_kernel_stats.csv
 echo "[profile] kernel stats done"
