@@ -48,7 +48,7 @@ def synth_pairs(n_videos, n_users, seed):
     last[np.cumsum(lens) - 1] = True
     keep = ~last[:-1] & (vids[:-1] != vids[1:])
     pairs = np.stack([vids[:-1][keep], vids[1:][keep]], axis=1)
-    rng.shuffle(pairs)
+    pairs = pairs[rng.permutation(len(pairs))]      # one global shuffle (parse_data.py:206), vectorised
     return pairs.astype(np.int32)
 
 
@@ -205,7 +205,9 @@ def main():
     else:
         table = Table.synthetic(n_rows, F, seed=0, device=dev)
         exchange = grad_sync = None
-    pairs = torch.from_numpy(synth_pairs(n_rows, max(n_rows // 3, 1000), seed=0)).to(dev)
+    # users: a third of the catalogue, capped -- the run consumes < 1 M pairs per rank, and every
+    # rank builds the same list on its host while the others wait
+    pairs = torch.from_numpy(synth_pairs(n_rows, max(min(n_rows // 3, 600000), 1000), seed=0)).to(dev)
 
     ts = train.TrainStep(table, pairs, B, output_size=D, hidden_size=H, margin=MARGIN, mode=args.mode,
                          optimizer="adam", base_learning_rate=0.01, seed=1234, weight_seed=42,
