@@ -22,6 +22,9 @@ CFG = dict(n_rows=3000, F=200, H=300, D=64, B=32, steps=2, precision="f32")
 CFG_BF16 = dict(CFG, B=64, precision="bf16")
 # trainable catalogue rows: row gradients travel back to the owners (RowExchange.scatter_back)
 CFG_TABLE = dict(CFG, train_table=True)
+# four ranks on the card: uneven shards (3000 = 4 x 750 here, 3001 rows -> 751/751/751/748), every
+# pair of ranks exchanging rows, the 1/4 gradient average
+CFG_W4 = dict(CFG, world=4, n_rows=3001, B=16)
 
 
 def _make(dev, rank, world, exchange=None, grad_sync=None, c=None):
@@ -30,16 +33,17 @@ def _make(dev, rank, world, exchange=None, grad_sync=None, c=None):
     c = c or CFG
     Table = engine_bf16.FeatureTableF16 if c["precision"] == "bf16" else engine.FeatureTable
     pairs = torch.from_numpy(osynth.cowatch_pairs(c["n_rows"], 400, 0)).to(dev)
+    W = c.get("world", 2)
     if world == 1:
         table = Table.synthetic(c["n_rows"], c["F"], 0, dev)
-        B, slot0 = 2 * c["B"], 0
+        B, slot0 = W * c["B"], 0
     else:
         lo, hi, _ = cdist.shard_bounds(c["n_rows"], world, rank)
         table = Table.synthetic(hi - lo, c["F"], 0, dev, row0=lo, n_rows_global=c["n_rows"])
         B, slot0 = c["B"], rank * c["B"]
     return train.TrainStep(table, pairs, B, hidden_size=c["H"], output_size=c["D"], mode="uniform",
                            device=dev, exchange=exchange, grad_sync=grad_sync, slot0=slot0,
-                           batch_global=2 * c["B"], precision=c["precision"],
+                           batch_global=W * c["B"], precision=c["precision"],
                            train_table=c.get("train_table", False))
 
 
@@ -70,7 +74,7 @@ def _worker(rank, world, port, q, CFG=CFG):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_TABLE], ids=["f32", "bf16", "trainable-table"])
+@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_TABLE, CFG_W4], ids=["f32", "bf16", "trainable-table", "4-ranks"])
 def test_two_rank_step_equals_single_rank(gpu, CFG):
     bf16 = CFG["precision"] == "bf16"
     s = socket.socket()
@@ -79,7 +83,8 @@ def test_two_rank_step_equals_single_rank(gpu, CFG):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, CFG)) for r in range(2)]
+    W = CFG.get("world", 2)
+    procs = [ctx.Process(target=_worker, args=(r, W, port, q, CFG)) for r in range(W)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
@@ -100,22 +105,23 @@ def test_two_rank_step_equals_single_rank(gpu, CFG):
     # (bf16: the ranks round their activations exactly as the single rank does -- same rows, same
     # kernels -- but the k-split of the weight gradient follows the local row count)
     gtol = 2e-5 if bf16 else 1e-6
-    assert np.abs(res[0][5] - g0).max() < gtol and np.abs(res[1][5] - g0).max() < gtol
-    want_idx = np.stack(idx)                                           # [steps, 2B*3]
-    got_idx = np.concatenate([res[0][2], res[1][2]], axis=1)
+    assert all(np.abs(r[5] - g0).max() < gtol for r in res)
+    want_idx = np.stack(idx)                                           # [steps, W*B*3]
+    got_idx = np.concatenate([r[2] for r in res], axis=1)
     np.testing.assert_array_equal(got_idx, want_idx)                   # same global triplets
     w = single.params.flat.cpu().numpy()
-    np.testing.assert_array_equal(res[0][3], res[1][3])                # replicas stay identical
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0][3], r[3])                 # replicas stay identical
     # Adam turns 1e-9 gradient-order noise near g=0 into visible update noise; compare loosely
     # on weights and tightly on the loss of the last step
     assert np.abs(res[0][3] - w).max() < 2.5e-2
     assert np.mean(np.abs(res[0][3] - w) > 1e-4) < 0.02
-    assert abs(0.5 * (res[0][4] + res[1][4]) - single.loss()) < (2e-3 if bf16 else 1e-4)
+    assert abs(np.mean([r[4] for r in res]) - single.loss()) < (2e-3 if bf16 else 1e-4)
     if CFG.get("train_table"):
         # each rank holds its rows of the single-rank table after the same updates (same Adam
         # caveat as for the weights: sign flips of gradients that are fp32 noise)
         whole = single.table.data.cpu().numpy()
-        got = np.concatenate([res[0][6], res[1][6]])
+        got = np.concatenate([r[6] for r in res])
         assert got.shape == whole.shape
         assert np.mean(np.abs(got - whole) > 1e-4) < 0.02 and np.abs(got - whole).max() < 2.5e-2
         fresh = _make(gpu, 0, 1, c=CFG).table.data.cpu().numpy()
