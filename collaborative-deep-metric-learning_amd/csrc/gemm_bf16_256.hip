@@ -11,30 +11,31 @@
 //     second 64 rows of each row group, B-h0 / B-h1 the first / second 32 columns of
 //     each strip -- so that an image is read in exactly ONE phase of the K-tile and
 //     can be refilled for tile t+2 while tile t is still being multiplied;
-//   * a K-tile is four phases, one output quadrant (64x32 per wave, full K=64, 8
-//     MFMAs) each: Q00 needs A-h0,B-h0 (12 ds_read_b128), Q01 needs B-h1 (4), Q11
-//     needs A-h1 (8), Q10 reuses registers (0).  Each phase = [fragment reads + one
-//     half-image DMA] barrier [8 MFMAs] barrier;
+//   * a K-tile is two phases of 16 MFMAs per wave: phase A multiplies the wave's first 64
+//     rows by both column halves (reads A-h0, B-h0, B-h1: 16 ds_read_b128), phase B its second
+//     64 rows (reads A-h1: 8; the B fragments stay in registers).  Each phase =
+//     [fragment reads + two half-image DMAs + counted wait]  barrier  [16 MFMAs]  barrier,
+//     and every fragment of a phase is in registers before its first barrier;
 //   * the two row groups run one barrier apart (ping-pong): while one group's waves
 //     issue MFMAs the other group's waves, on the same SIMDs, issue their LDS reads
 //     and DMA, so the matrix pipe always has a wave feeding it;
-//   * the DMA is never drained inside the loop: each half image is waited for (counted
-//     s_waitcnt vmcnt(10), five newer half images stay in flight) in the phase before
-//     the one that reads it, 5-6 phases after it was issued.
+//   * the DMA is never drained inside the loop (counted s_waitcnt vmcnt(8) / vmcnt(6): three
+//     to four half images stay in flight across every barrier).
+//   (A four-phase, quadrant-per-phase schedule with five half images in flight was measured at
+//   the same throughput and removed.)
 //
-// Hazards, in phases of a K-tile t living in LDS buffer t&1 (group 1 runs one
-// barrier behind group 0; every phase has two barriers):
-//   RAW  tile t+1's images were issued in phases 2,3,4 of tile t-1 (B-h0, A-h0, B-h1)
-//        and phase 1 of tile t (A-h1) and are first read in phases 1,1,2,3 of tile
-//        t+1; every wave retires its own pieces in the phase before that read (phase 4
-//        of tile t, phases 1 and 2 of tile t+1) BEFORE that phase's first barrier, so
-//        the read comes two barriers later for either group.
-//   WAR  B-h0 is read in phase 1 and those reads are retired (lgkmcnt(8): LDS reads
-//        return in order and the B reads are issued first) before phase 1's first
-//        barrier, so it is refilled in phase 2; A-h0 (read phase 1, retired after the
-//        barrier) in phase 3; B-h1 (read phase 2) in phase 4; A-h1 (read phase 3) in
-//        phase 1 of the next tile: always >= 2 barriers after the lagging group's
-//        reads retired.
+// DMA schedule and hazards (tile T lives in LDS buffer T&1; group 1 runs one barrier behind
+// group 0; every phase has two barriers; LDS reads are retired BEFORE a phase's first barrier):
+//   phase A(T) issues A-h0, A-h1 of tile T+1 -> other buffer; their last readers were phases
+//              A(T-1) / B(T-1): at least one barrier back for the lagging group, and reads are
+//              retired before a barrier is entered;
+//   phase B(T) issues B-h0, B-h1 of tile T+2 -> this buffer; read in phase A(T), whose reads
+//              the lagging group retired before ITS first barrier, one barrier back;
+//   phase A(T) waits vmcnt(8): everything but the four newest half images has landed, i.e.
+//              A-h1(T), read in phase B(T);
+//   phase B(T) waits vmcnt(6): B-h0, B-h1, A-h0 of T+1 have landed, read in phase A(T+1).
+//   A wave waits for its OWN pieces before a barrier; the read of the image comes two barriers
+//   later, after every wave of both groups has passed its wait.
 #include "gemm_bf16.h"
 
 namespace cdml {
@@ -74,14 +75,6 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
 
 // Every half image is waited for one phase before the phase that reads it, which
 // always leaves the five newest images (10 wave-instructions) in flight.
-#ifndef CDML_BF16_PHASES
-#define CDML_BF16_PHASES 2       // phases per K-tile: 4 (quadrants) or 2 (half tiles)
-#endif
-#ifndef CDML_BF16_INFLIGHT
-#define CDML_BF16_INFLIGHT 10
-#endif
-#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CDML_BF16_INFLIGHT) : "memory")
-
 #define CDML_BARRIER()                         \
   do {                                         \
     __builtin_amdgcn_sched_barrier(0);         \
@@ -100,7 +93,6 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
 template <bool TN, int EPI>
 __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   static_assert(!TN || EPI == BE_F32, "the k-strided form only serves the weight gradients");
-  static_assert(!TN || CDML_BF16_PHASES == 2, "the quadrant schedule counts ds_read_b128 returns");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const int t = threadIdx.x;
@@ -206,70 +198,6 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   bf16x8 fa[2][4], fb0[4], fb1[4];
 
-  auto do_tile = [&](const int buf, const int tile) {
-    // ---- phase 1: Q00 = A-h0 x B-h0 ----
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb0[ks] = read_b(buf, 0, ks);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = read_a(buf, 0, mi, ks);
-    stage(0, 1, tile + 1, buf ^ 1);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four B-h0 reads have returned
-    DMA_WAIT();                                          // B-h1 of this tile (read next phase)
-    CDML_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb0[ks], acc[mi][0], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    CDML_BARRIER();
-    // ---- phase 2: Q01 = A-h0 x B-h1 ----
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb1[ks] = read_b(buf, 1, ks);
-    stage(1, 0, tile + 2, buf);
-    DMA_WAIT();                                          // A-h1 of this tile (read next phase)
-    CDML_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb1[ks], acc[mi][1], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    CDML_BARRIER();
-    // ---- phase 3: Q11 = A-h1 x B-h1 ----
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = read_a(buf, 1, mi, ks);
-    stage(0, 0, tile + 2, buf);
-    CDML_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        acc[2 + mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb1[ks], acc[2 + mi][1], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    CDML_BARRIER();
-    // ---- phase 4: Q10 = A-h1 x B-h0 (registers only) ----
-    stage(1, 1, tile + 2, buf);
-    DMA_WAIT();                                          // B-h0 and A-h0 of tile+1 (read next phase)
-    CDML_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        acc[2 + mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fb0[ks], acc[2 + mi][0], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    CDML_BARRIER();
-  };
-
   // Bias gradient riding along (k-strided form): db[n] = sum_k B[k][n].  The tiles_m blocks and
   // two row groups that share a B tile split its K-tiles between them (tile t belongs to
   // (tm, grp) = (t % (2*tiles_m)) >> 1, & 1); the owner adds its fragments' 8 k-values per lane
@@ -284,7 +212,7 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
     return s;
   };
 
-  // Two-phase form of the K-tile (CDML_BF16_PHASES == 2): phase A = Q00 + Q01 (16 fragment
+  // The K-tile in two phases: phase A = Q00 + Q01 (16 fragment
   // reads, 16 MFMAs), phase B = Q11 + Q10 (8 reads, 16 MFMAs): half the barriers, and the
   // read parts have a 512-cycle MFMA part of the other group to hide under.  Fragment reads
   // are retired (lgkmcnt(0)) BEFORE the phase's first barrier, so an image is dead one
@@ -358,17 +286,6 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   };
 
   // prologue: the steady state at the first phase of tile 0
-#if CDML_BF16_PHASES == 4
-  stage(1, 0, 0, 0); stage(0, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 1, 0, 0);
-  stage(1, 0, 1, 1); stage(0, 0, 1, 1); stage(1, 1, 1, 1);
-  DMA_WAIT();
-  CDML_BARRIER();
-  if (grp == 1) CDML_BARRIER();                          // group 1 runs one barrier behind
-  for (int tile = 0; tile < n_ktiles; tile += 2) {
-    do_tile(0, tile);
-    do_tile(1, tile + 1);
-  }
-#else
   stage(1, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 0, 0, 0); stage(0, 1, 0, 0);
   stage(1, 0, 1, 1); stage(1, 1, 1, 1);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -378,7 +295,7 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
     do_tile2(0, tile);
     do_tile2(1, tile + 1);
   }
-#endif
+
   if (grp == 0) CDML_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the out-of-range tail DMAs still write zeros
   CDML_BARRIER();
