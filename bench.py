@@ -201,7 +201,12 @@ def main():
         lo, hi, _ = cdist.shard_bounds(n_rows, world, rank)
         table = Table.synthetic(hi - lo, F, seed=0, device=dev, row0=lo, n_rows_global=n_rows)
         # own communicator for the exchange so it never queues behind the gradient all-reduce
-        exchange, grad_sync = cdist.RowExchange(n_rows, group=dist.new_group()), cdist.GradSync(device=dev)
+        ex_group = dist.new_group()
+        exchange, grad_sync = cdist.RowExchange(n_rows, group=ex_group), cdist.GradSync(device=dev)
+        # bring both communicators up here (RCCL builds them on first use), not inside a step
+        warm = torch.zeros(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(warm)
+        dist.all_reduce(warm, group=ex_group)
     else:
         table = Table.synthetic(n_rows, F, seed=0, device=dev)
         exchange = grad_sync = None
