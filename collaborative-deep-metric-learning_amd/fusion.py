@@ -7,8 +7,11 @@ Every fully_connected is the fp32 MFMA GEMM of ``ops.fc_lrelu_fwd`` (bias_init
 0.1, leaky-relu 0.2 as in models.py:19-30); gradients use ``fc_bwd_weight`` /
 ``fc_bwd_data``; the pieces between layers are the ``ew_*`` kernels.  Parameters
 live in one flat padded fp32 buffer like VNet's, so the same Adam/LARS launch and
-the same all-reduce apply.  DenseNet (broken in the reference: tf.shape used as a
-static dim, models.py:197-198) and ResNetV2 ("debugging") are not built.
+the same all-reduce apply.  ResNetV2 (models.py:205-243) adds a shallow one-layer branch
+beside each deep branch; its four cross products and residual sum collapse to
+(v12+v21)*(d12+d21) + (v12+v21) + (d12+d21), i.e. ResNet's first residual sum on the branch
+SUMS, so it runs on the same kernels.  DenseNet (broken in the reference: tf.shape used as
+a static dim, models.py:197-198) is not built.
 """
 import math
 
@@ -18,7 +21,7 @@ import torch
 from . import ops
 from .engine import round_up
 
-NETS = ("MultiplyNet", "MlpNet", "ResNet")
+NETS = ("MultiplyNet", "MlpNet", "ResNet", "ResNetV2")
 VISUAL = 1500                       # models.py:80,107,138: model_input[:, :1500]
 
 
@@ -38,23 +41,30 @@ class FusionParams:
         self.visual, self.doc, self.D = visual_size, doc_size, output_size
         shapes = [("layer_visual_1", visual_size, hidden_v), ("layer_visual_2", hidden_v, output_size),
                   ("layer_doc_1", doc_size, hidden_d), ("layer_doc_2", hidden_d, output_size)]
-        if net == "MlpNet":
+        if net == "ResNetV2":
+            shapes = [("layer_visual_1_1", visual_size, hidden_v), ("layer_visual_1_2", hidden_v, output_size),
+                      ("layer_visual_2_1", visual_size, output_size), ("layer_doc_1_1", doc_size, hidden_d),
+                      ("layer_doc_1_2", hidden_d, output_size), ("layer_doc_2_1", doc_size, output_size),
+                      ("layer_fusion_1", output_size, output_size), ("layer_fusion_2", output_size, output_size)]
+        elif net == "MlpNet":
             shapes += [("layer_fusion_1", output_size, mlp_hidden), ("layer_fusion_2", mlp_hidden, output_size)]
         elif net == "ResNet":
             shapes += [("layer_fusion_1", output_size, output_size), ("layer_fusion_2", output_size, output_size)]
         self.layers = {n: _Layer(n, fi, fo) for n, fi, fo in shapes}
         # chain consistency: a layer's padded output width is the padded input width of its consumer
         for a, b in (("layer_visual_1", "layer_visual_2"), ("layer_doc_1", "layer_doc_2"),
-                     ("layer_fusion_1", "layer_fusion_2")):
+                     ("layer_fusion_1", "layer_fusion_2"), ("layer_visual_1_1", "layer_visual_1_2"),
+                     ("layer_doc_1_1", "layer_doc_1_2")):
             if a in self.layers:
                 self.layers[b].Kp = self.layers[a].Np
-        self.Dp = self.layers["layer_visual_2"].Np
-        for n in ("layer_doc_2", "layer_fusion_2"):
+        v2 = "layer_visual_1_2" if net == "ResNetV2" else "layer_visual_2"
+        self.Dp = self.layers[v2].Np
+        for n in ("layer_doc_2", "layer_fusion_2", "layer_visual_2_1", "layer_doc_1_2", "layer_doc_2_1"):
             if n in self.layers:
                 self.layers[n].Np = self.Dp
         if "layer_fusion_1" in self.layers:
             self.layers["layer_fusion_1"].Kp = self.Dp
-            if net == "ResNet":
+            if net in ("ResNet", "ResNetV2"):
                 self.layers["layer_fusion_1"].Np = self.Dp
                 self.layers["layer_fusion_2"].Kp = self.Dp
         off = 0
@@ -106,12 +116,16 @@ class FusionTower:
         p, dev, R = params, params.device, self.R
         z = lambda n: torch.zeros((R, n), dtype=torch.float32, device=dev)
         Ls = p.layers
-        self.xv, self.xd = z(Ls["layer_visual_1"].Kp), z(Ls["layer_doc_1"].Kp)
+        first_v = "layer_visual_1_1" if p.net == "ResNetV2" else "layer_visual_1"
+        first_d = "layer_doc_1_1" if p.net == "ResNetV2" else "layer_doc_1"
+        self.xv, self.xd = z(Ls[first_v].Kp), z(Ls[first_d].Kp)
         self.act = {n: z(L.Np) for n, L in Ls.items()}             # post-activations of every FC
         self.dpre = {n: z(L.Np) for n, L in Ls.items()}            # gradients wrt pre-activations
         D = p.Dp
         self.fu, self.r2, self.pre, self.e, self.de = z(D), z(D), z(D), z(D), z(D)
         self.g0, self.g1, self.g2 = z(D), z(D), z(D)
+        if p.net == "ResNetV2":
+            self.vs, self.ds, self.dvs, self.dds = z(D), z(D), z(D), z(D)   # branch sums and their gradients
         self.din = {n: z(L.Kp) for n, L in Ls.items() if n in ("layer_fusion_1", "layer_fusion_2")}
         nb = max(ops.fc_bwd_weight_workspace(R, L.Kp, L.Np) for L in Ls.values())
         self.bw = torch.empty(max(nb, 16) // 4, dtype=torch.float32, device=dev)
@@ -125,6 +139,20 @@ class FusionTower:
         p, R, D = self.p, self.R, self.p.Dp
         ops.l2norm_fwd(x[:, :p.visual], p.visual, self.xv)                       # models.py:81
         ops.l2norm_fwd(x[:, p.visual:p.visual + p.doc], p.doc, self.xd)          # models.py:86
+        if p.net == "ResNetV2":
+            v12 = self._fc("layer_visual_1_2", self._fc("layer_visual_1_1", self.xv))   # models.py:222-223
+            v21 = self._fc("layer_visual_2_1", self.xv)                                 # models.py:224
+            d12 = self._fc("layer_doc_1_2", self._fc("layer_doc_1_1", self.xd))         # models.py:228-229
+            d21 = self._fc("layer_doc_2_1", self.xd)                                    # models.py:230
+            ops.ew_combine(ops.EW_ADD, v12, v21, self.vs, R, D)
+            ops.ew_combine(ops.EW_ADD, d12, d21, self.ds, R, D)
+            ops.ew_combine(ops.EW_MUL_RES, self.vs, self.ds, self.fu, R, D)             # layer_res_1, :232-237
+            f1 = self._fc("layer_fusion_1", self.fu)
+            ops.ew_combine(ops.EW_ADD, self.fu, f1, self.r2, R, D)                      # :239
+            f2 = self._fc("layer_fusion_2", self.r2)
+            ops.ew_combine(ops.EW_ADD, self.r2, f2, self.pre, R, D)                     # :241
+            ops.l2norm_fwd(self.pre, D, self.e)
+            return self.e
         v2 = self._fc("layer_visual_2", self._fc("layer_visual_1", self.xv))
         d2 = self._fc("layer_doc_2", self._fc("layer_doc_1", self.xd))
         if p.net == "MultiplyNet":
@@ -164,7 +192,7 @@ class FusionTower:
                                 dp["layer_fusion_1"], mask=A["layer_fusion_1"])   # already d_pre of fusion_1
             dfu = self._bwd_fc("layer_fusion_1", self.fu, d_f1, self.din["layer_fusion_1"])
             res = False
-        else:
+        else:                                                                    # ResNet and ResNetV2
             ops.lrelu_bwd(self.g0, A["layer_fusion_2"], dp["layer_fusion_2"], R, D)
             self._bwd_fc("layer_fusion_2", self.r2, dp["layer_fusion_2"], self.din["layer_fusion_2"])
             ops.ew_combine(ops.EW_ADD, self.g0, self.din["layer_fusion_2"], self.g1, R, D)      # d_r2
@@ -172,6 +200,18 @@ class FusionTower:
             self._bwd_fc("layer_fusion_1", self.fu, dp["layer_fusion_1"], self.din["layer_fusion_1"])
             ops.ew_combine(ops.EW_ADD, self.g1, self.din["layer_fusion_1"], self.g2, R, D)      # d_r1
             dfu, res = self.g2, True
+        if p.net == "ResNetV2":
+            # d wrt the branch sums (no activation derivative: alpha 1), then each branch's own lrelu'
+            ops.ew_fusion_bwd(True, dfu, self.vs, self.ds, self.dvs, self.dds, R, D, alpha=1.0)
+            for deep, first, shallow, x_in, dsum in (
+                    ("layer_visual_1_2", "layer_visual_1_1", "layer_visual_2_1", self.xv, self.dvs),
+                    ("layer_doc_1_2", "layer_doc_1_1", "layer_doc_2_1", self.xd, self.dds)):
+                ops.lrelu_bwd(dsum, A[deep], dp[deep], R, D)
+                self._bwd_fc(deep, A[first], dp[deep], dp[first], mask=A[first])
+                self._bwd_fc(first, x_in, dp[first])
+                ops.lrelu_bwd(dsum, A[shallow], dp[shallow], R, D)
+                self._bwd_fc(shallow, x_in, dp[shallow])
+            return p.grad
         ops.ew_fusion_bwd(res, dfu, A["layer_visual_2"], A["layer_doc_2"], dp["layer_visual_2"],
                           dp["layer_doc_2"], R, D)
         self._bwd_fc("layer_visual_2", A["layer_visual_1"], dp["layer_visual_2"], dp["layer_visual_1"],

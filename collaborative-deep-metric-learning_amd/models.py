@@ -152,3 +152,9 @@ class ResNet(_FusionNet):
     """Multiply fusion with residual connections -- the tower the author reports to
     work best (models.py:125-157)."""
     net = "ResNet"
+
+
+class ResNetV2(_FusionNet):
+    """The wider ResNet: a deep and a shallow branch per modality, four cross products,
+    the same residual head (models.py:205-243)."""
+    net = "ResNetV2"

@@ -308,6 +308,9 @@ FUSION_LAYERS = {
                "layer_fusion_1", "layer_fusion_2"),
     "ResNet": ("layer_visual_1", "layer_visual_2", "layer_doc_1", "layer_doc_2",
                "layer_fusion_1", "layer_fusion_2"),
+    # models.py:205-243: a deep and a shallow branch per modality, four cross products
+    "ResNetV2": ("layer_visual_1_1", "layer_visual_1_2", "layer_visual_2_1", "layer_doc_1_1",
+                 "layer_doc_1_2", "layer_doc_2_1", "layer_fusion_1", "layer_fusion_2"),
 }
 
 
@@ -319,6 +322,11 @@ def fusion_layer_shapes(net, visual=1500, doc=128, hidden_v=5000, hidden_d=400, 
         s["layer_fusion_1"], s["layer_fusion_2"] = (out, mlp_hidden), (mlp_hidden, out)
     elif net == "ResNet":
         s["layer_fusion_1"], s["layer_fusion_2"] = (out, out), (out, out)
+    elif net == "ResNetV2":
+        s = {"layer_visual_1_1": (visual, hidden_v), "layer_visual_1_2": (hidden_v, out),
+             "layer_visual_2_1": (visual, out), "layer_doc_1_1": (doc, hidden_d),
+             "layer_doc_1_2": (hidden_d, out), "layer_doc_2_1": (doc, out),
+             "layer_fusion_1": (out, out), "layer_fusion_2": (out, out)}
     return {k: s[k] for k in FUSION_LAYERS[net]}
 
 
@@ -329,6 +337,19 @@ def fusion_forward(net, x, P, visual=1500, dtype=np.float64):
     t = {}
     t["xv"], _ = l2_normalize(x[:, :visual], dtype)
     t["xd"], _ = l2_normalize(x[:, visual:], dtype)
+    if net == "ResNetV2":
+        # models.py:219-238.  f1+f2+f3+f4 = (v12+v21)*(d12+d21), so layer_res_1 is ResNet's
+        # a*b + a + b with a, b the SUMS of the deep and the shallow branch
+        t["v11"] = fc(t["xv"], "layer_visual_1_1"); t["v12"] = fc(t["v11"], "layer_visual_1_2")
+        t["v21"] = fc(t["xv"], "layer_visual_2_1")
+        t["d11"] = fc(t["xd"], "layer_doc_1_1"); t["d12"] = fc(t["d11"], "layer_doc_1_2")
+        t["d21"] = fc(t["xd"], "layer_doc_2_1")
+        t["r1"] = (t["v12"] * t["d12"] + t["v12"] * t["d21"] + t["v21"] * t["d12"] + t["v21"] * t["d21"]
+                   + t["v12"] + t["v21"] + t["d12"] + t["d21"])
+        t["f1"] = fc(t["r1"], "layer_fusion_1"); t["r2"] = t["r1"] + t["f1"]
+        t["f2"] = fc(t["r2"], "layer_fusion_2"); t["pre_norm"] = t["r2"] + t["f2"]
+        t["l2_norm"], t["inv"] = l2_normalize(t["pre_norm"], dtype)
+        return t
     t["v1"] = fc(t["xv"], "layer_visual_1"); t["v2"] = fc(t["v1"], "layer_visual_2")
     t["d1"] = fc(t["xd"], "layer_doc_1"); t["d2"] = fc(t["d1"], "layer_doc_2")
     if net == "MultiplyNet":
@@ -356,6 +377,16 @@ def fusion_backward(net, t, P, dE, dtype=np.float64):
         return d_pre @ W[name].T                     # wrt the layer's input (post-activation of its producer)
 
     d = l2_normalize_backward(t["pre_norm"], t["inv"], np.asarray(dE, dtype), dtype)
+    if net == "ResNetV2":
+        d_r2 = d + fc_bwd("layer_fusion_2", t["r2"], t["f2"], d)
+        d_r1 = d_r2 + fc_bwd("layer_fusion_1", t["r1"], t["f1"], d_r2)
+        d_v = d_r1 * (t["d12"] + t["d21"] + 1.0)              # wrt v12 and wrt v21 alike
+        d_d = d_r1 * (t["v12"] + t["v21"] + 1.0)
+        fc_bwd("layer_visual_1_1", t["xv"], t["v11"], fc_bwd("layer_visual_1_2", t["v11"], t["v12"], d_v))
+        fc_bwd("layer_visual_2_1", t["xv"], t["v21"], d_v)
+        fc_bwd("layer_doc_1_1", t["xd"], t["d11"], fc_bwd("layer_doc_1_2", t["d11"], t["d12"], d_d))
+        fc_bwd("layer_doc_2_1", t["xd"], t["d21"], d_d)
+        return g
     if net == "MultiplyNet":
         dfu, res = d, 0.0
     elif net == "MlpNet":

@@ -40,7 +40,7 @@ def test_elementwise_kernels(cd):
     np.testing.assert_allclose(out.cpu().numpy(), g * np.where(a > 0, 1, 0.2), rtol=1e-6)
 
 
-@pytest.mark.parametrize("net", ["MultiplyNet", "MlpNet", "ResNet"])
+@pytest.mark.parametrize("net", ["MultiplyNet", "MlpNet", "ResNet", "ResNetV2"])
 def test_fusion_tower_vs_oracle_production_shape(cd, net):
     """feature_size 1628 = 1500 visual ++ 128 doc (online_data.py:38), hidden 5000 / 400."""
     R, F = 96, 1628
@@ -51,7 +51,8 @@ def test_fusion_tower_vs_oracle_production_shape(cd, net):
     P = {k: (w.detach().cpu().numpy().astype(np.float64), b.detach().cpu().numpy().astype(np.float64))
          for k, (w, b) in model.params.unpadded().items()}
     assert set(P) == set(otower.FUSION_LAYERS[net])
-    assert float(model.params.b("layer_doc_1")[:400].min()) == pytest.approx(0.1)       # bias_init=0.1
+    first_doc = "layer_doc_1_1" if net == "ResNetV2" else "layer_doc_1"
+    assert float(model.params.b(first_doc)[:400].detach().min()) == pytest.approx(0.1)   # bias_init=0.1
     t = otower.fusion_forward(net, x.astype(np.float64), P)
     assert tuple(out.shape) == (R, 256)
     assert np.abs(out.detach().cpu().numpy() - t["l2_norm"]).max() < TOL

@@ -266,7 +266,7 @@ def test_calc_var():
 
 
 # ----------------------------------------------------------- fusion towers (N4) ---
-@pytest.mark.parametrize("net", ["MultiplyNet", "MlpNet", "ResNet"])
+@pytest.mark.parametrize("net", ["MultiplyNet", "MlpNet", "ResNet", "ResNetV2"])
 def test_fusion_towers_vs_torch_autograd(net):
     rng = np.random.RandomState(0)
     shapes = tower.fusion_layer_shapes(net, visual=20, doc=6, hidden_v=16, hidden_d=10, out=8, mlp_hidden=12)
@@ -280,9 +280,20 @@ def test_fusion_towers_vs_torch_autograd(net):
     l2n = lambda a: a * torch.rsqrt(torch.clamp((a * a).sum(-1, keepdim=True), min=1e-12))
     fc = lambda a, n: torch.maximum(0.2 * (a @ tp[n][0] + tp[n][1]), a @ tp[n][0] + tp[n][1])
     xt = torch.tensor(x)
-    v2 = fc(fc(l2n(xt[:, :20]), "layer_visual_1"), "layer_visual_2")
-    d2 = fc(fc(l2n(xt[:, 20:]), "layer_doc_1"), "layer_doc_2")
-    if net == "MultiplyNet":
+    if net == "ResNetV2":                                  # written out as models.py:219-238 writes it
+        xv, xd = l2n(xt[:, :20]), l2n(xt[:, 20:])
+        v12, v21 = fc(fc(xv, "layer_visual_1_1"), "layer_visual_1_2"), fc(xv, "layer_visual_2_1")
+        d12, d21 = fc(fc(xd, "layer_doc_1_1"), "layer_doc_1_2"), fc(xd, "layer_doc_2_1")
+        r1 = v12 * d12 + v12 * d21 + v21 * d12 + v21 * d21 + v12 + v21 + d12 + d21
+        r2 = r1 + fc(r1, "layer_fusion_1")
+        pre = r2 + fc(r2, "layer_fusion_2")
+        v2 = d2 = None
+    else:
+        v2 = fc(fc(l2n(xt[:, :20]), "layer_visual_1"), "layer_visual_2")
+        d2 = fc(fc(l2n(xt[:, 20:]), "layer_doc_1"), "layer_doc_2")
+    if net == "ResNetV2":
+        pass
+    elif net == "MultiplyNet":
         pre = v2 * d2
     elif net == "MlpNet":
         pre = fc(fc(v2 * d2, "layer_fusion_1"), "layer_fusion_2")
