@@ -47,6 +47,59 @@ def read_cowatch_files(files):
     return np.concatenate(parts).astype(np.int32)
 
 
+class TripletPipe(BasePipe):
+    """In-memory pipe over precomputed triplet features (inputs.py:32-59: a tf.data
+    ``from_tensor_slices(...).repeat(num_epochs).batch(batch_size).shuffle(buffer_size)``
+    one-shot iterator; imitation_data.gen_triplets feeds it in the reference's tests).
+    Same order of transformations: elements repeat ``num_epochs`` times (``None`` = forever),
+    are cut into batches (a batch may straddle two passes, the last one may be short) and the
+    BATCHES are shuffled through a ``buffer_size`` reservoir.  The triplets live on the device;
+    ``get_next()`` returns device tensors [b, 3, F] and raises ``StopIteration`` at the end
+    (tf: OutOfRangeError)."""
+
+    def __init__(self, triplets, device="cuda:0", seed=0):
+        t = triplets if torch.is_tensor(triplets) else torch.as_tensor(np.asarray(triplets, dtype=np.float32))
+        if t.dim() != 3 or t.shape[1] != 3:
+            raise ValueError("triplets must be [N, 3, feature_size]")
+        self.triplets = t.to(device=device, dtype=torch.float32)
+        self.seed = seed
+
+    def create_pipe(self, batch_size=10, num_epochs=None, num_readers=1, buffer_size=1000):
+        return _TripletIterator(self.triplets, int(batch_size), num_epochs, int(buffer_size), self.seed)
+
+
+class _TripletIterator:
+    def __init__(self, triplets, batch_size, num_epochs, buffer_size, seed):
+        self.t, self.B, self.n = triplets, batch_size, triplets.shape[0]
+        self.total = None if num_epochs is None else self.n * int(num_epochs)
+        self.pos = 0                                   # next element of the repeated stream
+        self.buf, self.cap = [], max(buffer_size, 1)
+        self.rng = np.random.RandomState(seed)
+
+    def _next_batch(self):
+        if self.n == 0 or (self.total is not None and self.pos >= self.total):
+            return None
+        hi = self.pos + self.B if self.total is None else min(self.pos + self.B, self.total)
+        idx = torch.arange(self.pos, hi, device=self.t.device) % self.n
+        self.pos = hi
+        return self.t[idx]
+
+    def get_next(self):
+        while len(self.buf) < self.cap:                # tf.data shuffle: fill the buffer, draw one at random
+            b = self._next_batch()
+            if b is None:
+                break
+            self.buf.append(b)
+        if not self.buf:
+            raise StopIteration
+        return self.buf.pop(self.rng.randint(len(self.buf)))
+
+    __next__ = get_next
+
+    def __iter__(self):
+        return self
+
+
 class MPTripletPipe(BasePipe):
     def __init__(self, cowatch_file_patten=None, feature_file=None, wait_times=30,
                  device="cuda:0", seed=1234, pairs=None, table=None):

@@ -541,6 +541,26 @@ def test_pipe_exhaustion_and_replay(cd):
         pipe.check_indices()
 
 
+def test_memory_triplet_pipe(cd):
+    """inputs.TripletPipe: repeat -> batch -> shuffle(batches) like the reference's tf.data pipe."""
+    from cdml_amd import inputs
+    trip = np.arange(7 * 3 * 4, dtype=np.float32).reshape(7, 3, 4)
+    it = inputs.TripletPipe(trip, device=cd.dev).create_pipe(batch_size=3, num_epochs=2, buffer_size=1)
+    got = [b.cpu().numpy() for b in it]                       # buffer 1: stream order
+    assert [len(b) for b in got] == [3, 3, 3, 3, 2]           # 14 elements, a batch straddles the passes
+    np.testing.assert_array_equal(np.concatenate(got), np.concatenate([trip, trip]))
+    it = inputs.TripletPipe(trip, device=cd.dev, seed=1).create_pipe(batch_size=2, num_epochs=3, buffer_size=4)
+    shuf = [b.cpu().numpy() for b in it]
+    assert sorted(len(b) for b in shuf) == [1] + [2] * 10
+    key = lambda bs: sorted(tuple(x.ravel()) for b in bs for x in b)
+    assert key(shuf) == key([trip, trip, trip])               # same multiset of elements
+    assert any(not np.array_equal(a, b) for a, b in zip(shuf, [np.concatenate([trip] * 3)[i:i + 2] for i in range(0, 21, 2)]))
+    with pytest.raises(StopIteration):
+        it.get_next()
+    forever = inputs.TripletPipe(trip, device=cd.dev).create_pipe(batch_size=5, num_epochs=None, buffer_size=2)
+    assert all(forever.get_next().shape == (5, 3, 4) for _ in range(10))
+
+
 def test_errors_are_raised_not_swallowed(cd):
     y = torch.empty((8, 64), device=cd.dev)
     x = torch.empty((8, 48), device=cd.dev)
