@@ -131,3 +131,30 @@ def test_dataset_directory_formats(tmp_path):
     # 15 % rule of online_data.py:262-264
     online_data.write_cowatches(pairs, str(tmp_path / "ds2"), split_num=1)
     assert len(online_data.load_cowatches(str(tmp_path / "ds2" / "cowatches.eval"))) == 30
+
+
+def test_imitation_data_matches_reference_fixture(golden_dir):
+    """cdml_amd.imitation_data.gen_features under np.random.seed == the array the reference's
+    generator produced (fixture G2), and the other generators keep its shapes and rules."""
+    import random
+    from cdml_amd import imitation_data as im
+    g = np.load(os.path.join(golden_dir, "imitation_features_seed0.npz"))
+    key = [k for k in g.files if g[k].ndim == 2][0]
+    ref = g[key]
+    np.random.seed(0)
+    np.testing.assert_array_equal(im.gen_features(*ref.shape), ref)
+    np.random.seed(1)
+    t = im.gen_triplets(5, 12)
+    assert t.shape == (5, 3, 12) and t.dtype == np.float64 and 0 <= t.min() and t.max() < 1
+    random.seed(2)
+    np.random.seed(2)
+    w = im.gen_all_watched_guids(np.arange(50), 20, low=2, high=6)
+    assert len(w) == 20 and all(2 <= len(x) <= 6 and set(x) <= set(range(50)) for x in w)
+    ids = im.gen_unique_id_array(5, 30, 10)
+    assert len(set(ids.tolist())) == 10 and ids.min() >= 5 and ids.max() <= 30
+    with pytest.raises(ValueError):
+        im.gen_unique_id_array(0, 3, 9)
+    d = im.arrays_to_dict(["a", "b"], np.eye(2))
+    assert list(d) == ["a", "b"] and d["b"][1] == 1
+    p = im.cowatch_pairs(1000, 100, seed=3)
+    assert p.dtype == np.int32 and p.shape[1] == 2 and (p[:, 0] != p[:, 1]).all() and p.max() < 1000
