@@ -53,6 +53,9 @@ SIGNATURES = {
     "cdml_semihard_select": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _p, _p]),
     "cdml_triplet_hinge_indexed": (_i, [_p, _i64, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "cdml_pair_dist": (_i, [_p, _i64, _i, _p, _i, _i, _p, _p, _p, _p]),
+    "cdml_cowatch_workspace": (_sz, [_i64]),
+    "cdml_cowatch_graph": (_i, [_p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "cdml_cowatch_select": (_i, [_p, _i64, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "cdml_knn_list_capacity": (_i, []),
     "cdml_row_sqnorm": (_i, [_p, _i64, _i, _i, _p, _p]),
     "cdml_knn_merge": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),

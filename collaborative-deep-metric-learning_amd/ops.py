@@ -175,6 +175,37 @@ def pair_dist(e, pairs, D, sqdist, dot, means=None):
          _p(dot), _p(means), _stream())
 
 
+# ------------------------------------------------- co-watch graph (N3) --------
+def _cowatch_ws(P, device):
+    nbytes = int(load_library().cdml_cowatch_workspace(P))
+    return torch.empty(nbytes + 256, dtype=torch.uint8, device=device)   # torch allocations are 256-B aligned
+
+
+def cowatch_graph(pairs):
+    P = pairs.shape[0]
+    dev = pairs.device
+    ws = _cowatch_ws(P, dev)
+    edges = torch.empty((P, 2), dtype=torch.int32, device=dev)
+    counts = torch.empty(P, dtype=torch.int32, device=dev)
+    n_edges = torch.zeros(1, dtype=torch.int64, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    call("cdml_cowatch_graph", _p(pairs, torch.int32), P, _p(edges), _p(counts), _p(n_edges), _p(flag), _p(ws),
+         ws.numel(), _stream())
+    return edges, counts, n_edges, flag
+
+
+def cowatch_select(pairs, threshold, unique):
+    P = pairs.shape[0]
+    dev = pairs.device
+    ws = _cowatch_ws(P, dev)
+    out = torch.empty((P, 2), dtype=torch.int32, device=dev)
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    call("cdml_cowatch_select", _p(pairs, torch.int32), P, threshold, 1 if unique else 0, _p(out), _p(n), _p(flag),
+         _p(ws), ws.numel(), _stream())
+    return out, n, flag
+
+
 # ------------------------------------------------- exact kNN export (N4) ------
 def knn_list_capacity():
     return int(load_library().cdml_knn_list_capacity())

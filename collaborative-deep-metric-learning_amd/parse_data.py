@@ -1,0 +1,63 @@
+"""Co-watch mining of the reference's ETL on the device (parse_data.py:181-289).
+
+The reference walks Python lists and a dict keyed by ``"a,b"`` strings; here the pair list is an
+int32 [P,2] device tensor and the graph statistics come from one sort + run-length encode
+(``csrc/cowatch.hip``).  Results are the reference's, as sets / sequences of integer pairs:
+
+  get_all_cowatch(all_watched_guids)   consecutive pairs of every watch history, shuffled once
+                                       (parse_data.py:181-209; host, numpy)
+  cowatch_graph(pairs)                 distinct undirected edges + multiplicities
+                                       (get_cowatch_graph, :221-254; raises on a self pair)
+  select_cowatch(pairs, threshold, unique=False)
+                                       pairs whose edge was seen >= threshold times (:256-289);
+                                       unique=True: each such edge once -- as (min, max) in
+                                       ascending order where the reference shuffles
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def get_all_cowatch(all_watched_guids, seed=None):
+    """int32 [P,2]: (w[i], w[i+1]) for every history w, shuffled (np.random, or ``seed``)."""
+    parts = [np.stack([np.asarray(w[:-1]), np.asarray(w[1:])], 1) for w in all_watched_guids if len(w) > 1]
+    if not parts:
+        return np.zeros((0, 2), dtype=np.int32)
+    cow = np.concatenate(parts).astype(np.int32)
+    (np.random if seed is None else np.random.RandomState(seed)).shuffle(cow)
+    return cow
+
+
+def _device_pairs(pairs, device):
+    t = pairs if torch.is_tensor(pairs) else torch.as_tensor(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
+    return t.to(device=device, dtype=torch.int32).contiguous()
+
+
+def _check_self_pairs(flag):
+    if int(flag.item()):
+        # parse_data.py:244-246: "cowatch 存在相邻重复元素，结果不合规"
+        raise RuntimeError("get_cowatch_graph: a co-watch pair repeats one video (a == p); "
+                           "remove adjacent duplicates from the watch histories first")
+
+
+def cowatch_graph(pairs, device="cuda:0"):
+    """(edges int32 [U,2] with a < b in ascending order, counts int32 [U]) device tensors."""
+    p = _device_pairs(pairs, device)
+    P = p.shape[0]
+    if P == 0:
+        return p.new_zeros((0, 2)), p.new_zeros((0,))
+    edges, counts, n_edges, flag = ops.cowatch_graph(p)
+    _check_self_pairs(flag)
+    U = int(n_edges.item())
+    return edges[:U], counts[:U]
+
+
+def select_cowatch(pairs, threshold, unique=False, device="cuda:0"):
+    """int32 [S,2] device tensor (see module docstring)."""
+    p = _device_pairs(pairs, device)
+    if p.shape[0] == 0:
+        return p
+    out, n, flag = ops.cowatch_select(p, int(threshold), bool(unique))
+    _check_self_pairs(flag)
+    return out[:int(n.item())]

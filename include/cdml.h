@@ -202,6 +202,25 @@ int cdml_pair_dist(const float *e, int64_t lde, int n_rows, const int32_t *pairs
                    int P, int D, float *sqdist, float *dot, float *means,
                    cdml_stream_t stream);
 
+/* ---- co-watch graph statistics of the ETL (parse_data.py:221-289).
+ * pairs: int32 [n_pairs][2] row ids (8-B aligned).  self_pair_flag: device int32 the caller
+ * zeroes; set to 1 if some pair has a == p (get_cowatch_graph raises RuntimeError there,
+ * parse_data.py:244-246 -- the host side raises).  Counts (n_edges_out, out_count) are written
+ * to DEVICE int64s.  workspace: cdml_cowatch_workspace(n_pairs) bytes, 256-B aligned.
+ *   cdml_cowatch_graph : the distinct UNDIRECTED edges (min, max) in ascending order into
+ *     edges_out [<= n_pairs][2] with their multiplicities in counts_out (get_cowatch_graph).
+ *   cdml_cowatch_select: unique == 0 -> every pair whose edge was seen >= threshold times, all
+ *     occurrences, input order kept (select_cowatch's default; threshold <= 1 keeps everything);
+ *     unique != 0 -> each qualifying edge once as (min, max) in ascending edge order (the
+ *     reference orients and orders these at random). */
+size_t cdml_cowatch_workspace(int64_t n_pairs);
+int cdml_cowatch_graph(const int32_t *pairs, int64_t n_pairs, int32_t *edges_out,
+                       int32_t *counts_out, int64_t *n_edges_out, int32_t *self_pair_flag,
+                       void *workspace, size_t workspace_bytes, cdml_stream_t stream);
+int cdml_cowatch_select(const int32_t *pairs, int64_t n_pairs, int threshold, int unique,
+                        int32_t *out_pairs, int64_t *out_count, int32_t *self_pair_flag,
+                        void *workspace, size_t workspace_bytes, cdml_stream_t stream);
+
 /* ---- exact kNN export (faiss_knn.py:82-131 `calc_knn`: squared-L2 distances D
  * and neighbour ids I over the l2-normalised embeddings, nearest first, the
  * query itself included; the reference asks faiss HNSW, this is the brute-force

@@ -103,6 +103,28 @@ def main():
         "get_all_cowatch_len": len(cow),
         "get_all_cowatch_sorted": sorted([list(map(int, c)) for c in cow]),
     }
+    # G6 -- co-watch graph and selection (next-row N3): the reference's own get_cowatch_graph /
+    # select_cowatch on seeded watch histories (adjacent duplicates removed, as the ETL does
+    # before pairing, online_data.py:114-116)
+    r = np.random.RandomState(7)
+    histories = []
+    for _ in range(400):
+        w = r.randint(0, 60, size=r.randint(2, 12)).tolist()
+        histories.append([int(v) for i, v in enumerate(w) if i == 0 or v != w[i - 1]])
+    np.random.seed(7)
+    cowatches = [[int(a), int(b)] for a, b in parse_data.get_all_cowatch(histories)]
+    graph, cowatches = parse_data.get_cowatch_graph(cowatches)
+    edges = sorted(tuple(map(int, e.split(","))) for e in graph)
+    counts = [graph["%d,%d" % e] for e in edges]
+    sel = {t: parse_data.select_cowatch(graph, t, cowatches) for t in (1, 2, 3, 5)}
+    np.random.seed(8)
+    uniq3 = parse_data.select_cowatch(graph, 3, unique=True)
+    np.savez(os.path.join(OUT, "cowatch_graph_seed7.npz"),
+             cowatches=np.asarray(cowatches, dtype=np.int64), edges=np.asarray(edges, dtype=np.int64),
+             counts=np.asarray(counts, dtype=np.int64),
+             **{"select_t%d" % t: np.asarray(v, dtype=np.int64).reshape(-1, 2) for t, v in sel.items()},
+             unique_t3_sorted=np.asarray(sorted(tuple(sorted(map(int, c))) for c in uniq3), dtype=np.int64))
+
     with open(os.path.join(OUT, "known_answers.json"), "w") as f:
         json.dump(kat, f, indent=1)
     print("golden fixtures written to", OUT)

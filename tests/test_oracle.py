@@ -349,3 +349,19 @@ def test_table_oracle_l2norm_backward_and_duplicates():
     assert np.array_equal(new[[0, 1, 3, 5]], tab[[0, 1, 3, 5]]) and not np.array_equal(new[4], tab[4])
     shard, _, _ = otable.table_adam_rows(tab[3:], np.zeros((3, 9)), np.zeros((3, 9)), idx, G, 1, 0.01, row0=3)
     np.testing.assert_array_equal(shard, new[3:])         # a shard sees only its own rows
+
+
+def test_etl_oracle_matches_reference_cowatch_graph(golden_dir):
+    """oracle/etl.py against the outputs of the reference's get_cowatch_graph / select_cowatch
+    (fixture G6, tests/golden/make_golden.py)."""
+    from oracle import etl
+    g = np.load(os.path.join(golden_dir, "cowatch_graph_seed7.npz"))
+    edges, counts = etl.cowatch_graph(g["cowatches"])
+    np.testing.assert_array_equal(edges, g["edges"])
+    np.testing.assert_array_equal(counts, g["counts"])
+    for t in (1, 2, 3, 5):
+        np.testing.assert_array_equal(etl.select_cowatch(g["cowatches"], t), g["select_t%d" % t])
+    np.testing.assert_array_equal(etl.select_cowatch(g["cowatches"], 3, unique=True), g["unique_t3_sorted"])
+    assert len(g["select_t1"]) == len(g["cowatches"]) > len(g["select_t2"]) > len(g["select_t5"]) > 0
+    with pytest.raises(RuntimeError):
+        etl.cowatch_graph([[1, 2], [3, 3]])
