@@ -58,10 +58,13 @@ class TripletPipe(BasePipe):
     (tf: OutOfRangeError)."""
 
     def __init__(self, triplets, device="cuda:0", seed=0):
-        t = triplets if torch.is_tensor(triplets) else torch.as_tensor(np.asarray(triplets, dtype=np.float32))
-        if t.dim() != 3 or t.shape[1] != 3:
-            raise ValueError("triplets must be [N, 3, feature_size]")
-        self.triplets = t.to(device=device, dtype=torch.float32)
+        t = triplets if torch.is_tensor(triplets) else torch.as_tensor(np.asarray(triplets))
+        if t.dim() == 2 and t.shape[1] == 3:             # row-id triplets (tests/test_inputs.py feeds guids;
+            self.triplets = t.to(device=device, dtype=torch.int32)    # parse_data.lookup turns a batch into features)
+        elif t.dim() == 3 and t.shape[1] == 3:
+            self.triplets = t.to(device=device, dtype=torch.float32)
+        else:
+            raise ValueError("triplets must be [N, 3] row ids or [N, 3, feature_size] features")
         self.seed = seed
 
     def create_pipe(self, batch_size=10, num_epochs=None, num_readers=1, buffer_size=1000):

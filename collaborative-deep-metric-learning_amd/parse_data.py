@@ -29,6 +29,22 @@ def get_all_cowatch(all_watched_guids, seed=None):
     return cow
 
 
+def lookup(batch_triplets, features):
+    """Row-id triplets [b,3] -> feature triplets [b,3,F] (parse_data.py:353-376; the reference
+    walks a guid -> ndarray dict, here ``features`` is an engine.FeatureTable or a [N,F] device
+    tensor and the rows are gathered by the HIP kernel).  Ids outside the table raise -- the
+    reference logs and silently drops the triplet."""
+    from .engine import FeatureTable
+    table = features if isinstance(features, FeatureTable) else FeatureTable(features, features.shape[1])
+    idx = batch_triplets.reshape(-1).to(device=table.data.device, dtype=torch.int32)
+    out = torch.empty((idx.numel(), table.data.shape[1]), dtype=torch.float32, device=table.data.device)
+    oob = torch.zeros(1, dtype=torch.int32, device=table.data.device)
+    ops.gather_rows(table.data, table.row0, idx, table.feature_size, out, normalize=False, oob_flag=oob)
+    if int(oob.item()):
+        raise IndexError("lookup: a row id is outside the feature table")
+    return out[:, :table.feature_size].reshape(batch_triplets.shape[0], 3, table.feature_size)
+
+
 def _device_pairs(pairs, device):
     t = pairs if torch.is_tensor(pairs) else torch.as_tensor(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
     return t.to(device=device, dtype=torch.int32).contiguous()

@@ -559,6 +559,17 @@ def test_memory_triplet_pipe(cd):
         it.get_next()
     forever = inputs.TripletPipe(trip, device=cd.dev).create_pipe(batch_size=5, num_epochs=None, buffer_size=2)
     assert all(forever.get_next().shape == (5, 3, 4) for _ in range(10))
+    # the reference's own use (tests/test_inputs.py): row-id triplets through the pipe, then lookup
+    from cdml_amd import parse_data
+    table = cd.engine.FeatureTable.synthetic(50, 96, 0, cd.dev)
+    ids = np.random.RandomState(0).randint(0, 50, size=(9, 3))
+    batch = inputs.TripletPipe(ids, device=cd.dev).create_pipe(batch_size=2, num_epochs=None, buffer_size=1).get_next()
+    assert batch.shape == (2, 3) and np.array_equal(batch.cpu().numpy(), ids[:2])
+    feats = parse_data.lookup(batch, table)
+    assert feats.shape == (2, 3, 96)
+    np.testing.assert_array_equal(feats.cpu().numpy(), table.data[ids[:2].reshape(-1), :96].cpu().numpy().reshape(2, 3, 96))
+    with pytest.raises(IndexError):
+        parse_data.lookup(torch.tensor([[0, 1, 50]]), table)
 
 
 def test_errors_are_raised_not_swallowed(cd):
