@@ -245,6 +245,36 @@ def test_backward_in_row_blocks_equals_one_piece(cd, precision):
     assert (ts.params.grad - g_one).abs().max().item() <= 2e-6 * max(scale, 1.0) + 1e-9
 
 
+def test_full_size_properties_config4(cd):
+    """BASELINE config 4's per-GPU shape (B = 8192 uniform triplets -> 24 576 rows; scaled
+    catalogue) through size-independent properties: bit-exact ids, unit-norm rows in and out at the
+    path's tolerance, the weight gradient = x_hat^T dz1 recomputed by torch from the SAME bf16
+    operands, the bias gradient = column sums, bit-identical repetition."""
+    N, F, B = 200000, 1500, 8192
+    table = cd.ebf.FeatureTableF16.synthetic(N, F, 0, cd.dev)
+    pairs_np = osynth.cowatch_pairs(N, 40000, 0)
+    ts = cd.train.TrainStep(table, torch.as_tensor(pairs_np).to(cd.dev), B, mode="uniform", precision="bf16",
+                            device=cd.dev)
+    ts.fetch(); ts.forward_loss(); ts.backward()
+    torch.cuda.synchronize()
+    idx = osampler.device_triplets_vec(pairs_np, N, 1234, 0, B)
+    np.testing.assert_array_equal(ts.idx.view(B, 3).cpu().numpy(), idx)
+    xn = ts.ws.x_hat[:, :F].float().norm(dim=1)
+    assert float((xn - 1).abs().max()) < 4e-3                         # bf16 rows: 2^-9 relative per element
+    en = ts.ws.e.norm(dim=1)
+    assert float((en - 1).abs().max()) < 1e-5                         # the output normalisation is fp32
+    assert torch.isfinite(ts.params.grad).all() and abs(ts.loss() - 0.8) < 0.2
+    L = ts.layout
+    ref = ts.ws.x_hat.double().T @ ts.ws.dz1[:, :256].double()        # same bf16 operands, fp64 sum
+    scale = float(ref.abs().max())
+    assert float((ts.params.gW1[:, :256].double() - ref).abs().max()) < 1e-5 * max(scale, 1e-3) + 1e-7
+    db1 = ts.ws.dz1.double().sum(0)
+    assert float((ts.params.gb1.double() - db1).abs().max()) < 1e-5 * max(float(db1.abs().max()), 1e-3) + 1e-7
+    g0 = ts.params.grad.clone()
+    ts.fetch(); ts.forward_loss(); ts.backward()
+    assert torch.equal(g0, ts.params.grad)
+
+
 def test_bf16_graph_replay_equals_eager(cd):
     """Config 4 asks for a hipGraph-captured step: replay must give the eager step's bits
     (device-side step counter and learning rate, no allocation on the step path)."""
