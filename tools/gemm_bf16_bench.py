@@ -76,3 +76,24 @@ for name, M, N, K in (("dW1 tn F x H x R", F, H, R), ("dW2 tn H x D x R", H, D, 
     fl = 2.0 * M * N * K
     print("%-16s tn: %7.4f ms %7.1f TF (%.3f) | transposes+nt: %7.4f ms | max abs diff %.2e"
           % (name, res[0], fl / res[0] / 1e9, fl / res[0] / 1e9 / 2500, res[1], (out - out2).abs().max().item()))
+
+# the vendor library (torch.mm -> hipBLASLt, bf16 in / bf16 out, no fused epilogue) on the same shapes
+if len(sys.argv) > 3 and sys.argv[3] == "lib":
+    for name, M, N, K, tb in (("lib fc1  NT", R, H, F, True), ("lib dW1  TN", F, H, R, False), ("lib fc2  NT", R, D, H, True)):
+        if tb:
+            A = (torch.randn(M, K, device=dev) / K ** 0.5).bfloat16(); B = torch.randn(N, K, device=dev).bfloat16()
+            fn = lambda: torch.mm(A, B.t())
+        else:
+            A = (torch.randn(K, M, device=dev) / K ** 0.5).bfloat16(); B = torch.randn(K, N, device=dev).bfloat16()
+            fn = lambda: torch.mm(A.t(), B)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / iters
+        print("%-16s %7.4f ms %7.1f TF (%.3f of 2500)" % (name, ms, 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / ms / 1e9 / 2500))
