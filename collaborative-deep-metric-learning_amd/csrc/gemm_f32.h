@@ -1,5 +1,4 @@
-// Shared between gemm_f32.hip (128x128 / 64x128 / 64x64 kernels, entry points,
-// dispatch) and gemm_f32_pp.hip (128x256 ping-pong kernel).
+// Argument block of the fp32 MFMA GEMM kernels (gemm_f32.hip).
 #pragma once
 #include "common.h"
 
@@ -20,13 +19,5 @@ struct GemmArgs {
   int64_t slab_stride;           // elements between split outputs
   int tiles_m, tiles_n;
 };
-
-// ---- 128x256x32 ping-pong kernel (gemm_f32_pp.hip) ----
-// form 0 = NN (A[M][K], B[K][N]; FC forward), 1 = NT (A[M][K], B[N][K]; data gradient),
-// 2 = TN (A[K][M], B[K][N]; weight gradient)
-bool gemm_f32_pp_usable(int form, int M, int N, int K, int64_t lda, int64_t ldb);
-int gemm_f32_pp_splits(int M, int N, int K);          // TN only
-int gemm_f32_pp_colsum_chunks(int M, int splits);     // TN: partial rows the kernel writes to g.colsum
-int launch_gemm_f32_pp(int form, GemmArgs g, int splits, hipStream_t stream);
 
 }  // namespace cdml

@@ -23,7 +23,6 @@
 //     K-tile of the weight gradient reads zeros with no predication.
 // Workgroups are dealt to XCDs in contiguous chunks of a grouped raster so the
 // tiles sharing an A/B panel hit the same L2.
-#include <stdlib.h>
 #include "gemm_f32.h"
 
 namespace cdml {
@@ -470,16 +469,6 @@ void pick_tile(int M, int N, int &tm, int &tn) {
   tm = 1; tn = (tiles(64, 128) >= 128) ? 2 : 1;
 }
 
-// The 128x256 ping-pong kernel (gemm_f32_pp.hip) is an opt-in experiment: CDML_F32_TILE=256
-// takes it wherever the shape allows (tests, A/B runs; read per call).  Measured on the
-// config-1 shapes it ties this file's kernels on the forward product (0.77-0.80 of peak both)
-// and loses on the k-strided weight gradient (0.60 vs 0.78), so nothing selects it by default.
-bool use_pp(int form, int M, int N, int K, int64_t lda, int64_t ldb, int splits) {
-  const char *e = getenv("CDML_F32_TILE");
-  (void)splits;
-  return e && atoi(e) == 256 && gemm_f32_pp_usable(form, M, N, K, lda, ldb);
-}
-
 int check_mat(const char *who, const void *p, int64_t ld, int64_t min_ld) {
   CDML_REQUIRE(p, CDML_E_BADARG, "%s: null pointer", who);
   CDML_REQUIRE(aligned16(p) && (ld & 3) == 0 && ld >= min_ld, CDML_E_ALIGN,
@@ -528,7 +517,6 @@ extern "C" int cdml_fc_lrelu_fwd(const float *x, int64_t ldx, const float *W, in
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = y; g.ldc = ldy;
   g.bias = b; g.alpha = alpha; g.M = M; g.N = N; g.K = K; g.k_per_split = K;
-  if (use_pp(0, M, N, K, ldx, ldw, 1)) return launch_gemm_f32_pp(0, g, 1, (hipStream_t)stream);
   int tm, tn;
   pick_tile(M, N, tm, tn);
   return launch_gemm<true, false, EPI_BIAS_LRELU>(g, tm, tn, 1, (hipStream_t)stream);
@@ -548,7 +536,6 @@ extern "C" int cdml_fc_bwd_data(const float *dy, int64_t lddy, const float *W, i
   GemmArgs g{};  // dx[M][K] = dy[M][N] @ W[K][N]^T : output cols = K, contraction = N
   g.A = dy; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dx; g.ldc = lddx;
   g.aux = x_post; g.ldaux = ldxp; g.alpha = alpha; g.M = M; g.N = K; g.K = N; g.k_per_split = N;
-  if (use_pp(1, M, K, N, lddy, ldw, 1)) return launch_gemm_f32_pp(1, g, 1, (hipStream_t)stream);
   int tm, tn;
   pick_tile(M, K, tm, tn);
   return launch_gemm<true, true, EPI_LRELU_MASK>(g, tm, tn, 1, (hipStream_t)stream);
@@ -557,12 +544,7 @@ extern "C" int cdml_fc_bwd_data(const float *dy, int64_t lddy, const float *W, i
 extern "C" size_t cdml_fc_bwd_weight_workspace(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0 || K % 64 || N % 64) return 0;
   const int splits = bwd_weight_splits(M, K, N);   // enough for whichever kernel is dispatched
-  size_t slabs = splits > 1 ? (size_t)splits * K * N : 0, chunks = (size_t)splits;
-  if (gemm_f32_pp_usable(2, K, N, M, K, N)) {
-    const int sp = gemm_f32_pp_splits(K, N, M);
-    slabs = max(slabs, sp > 1 ? (size_t)sp * K * N : (size_t)0);
-    chunks = max(chunks, (size_t)gemm_f32_pp_colsum_chunks(K, sp));
-  }
+  const size_t slabs = splits > 1 ? (size_t)splits * K * N : 0, chunks = (size_t)splits;
   return (slabs + chunks * N) * sizeof(float);
 }
 
@@ -581,44 +563,30 @@ extern "C" int cdml_fc_bwd_weight(const float *x, int64_t ldx, const float *dy, 
   const size_t need = cdml_fc_bwd_weight_workspace(M, K, N);
   CDML_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), CDML_E_BADARG,
                "fc_bwd_weight: workspace of %zu bytes (16-B aligned) required", need);
-  const int pp_splits = gemm_f32_pp_usable(2, K, N, M, ldx, lddy) ? gemm_f32_pp_splits(K, N, M) : 1;
-  const bool pp = use_pp(2, K, N, M, ldx, lddy, pp_splits);
-  const int splits = pp ? pp_splits : bwd_weight_splits(M, K, N);
+  const int splits = bwd_weight_splits(M, K, N);
   float *slabs = static_cast<float *>(workspace);
   float *colsum = slabs + (splits > 1 ? (size_t)splits * K * N : (size_t)0);
-  // no combine pass for one split: the GEMM writes dW itself (and the 128-tile kernel db too;
-  // the ping-pong kernel always leaves partial column sums: its blocks share the bias gradient)
+  // no combine pass for one split: the GEMM writes dW (and db) itself
   const bool direct = (splits == 1);
   GemmArgs g{};  // dW[K][N] = x[M][K]^T @ dy[M][N] : output rows = K, contraction = M
   g.A = x; g.lda = ldx; g.B = dy; g.ldb = lddy;
   g.C = direct ? dW : slabs; g.ldc = direct ? lddw : N;
-  g.colsum = db ? ((direct && !pp) ? db : colsum) : nullptr; g.M = K; g.N = N; g.K = M;
+  g.colsum = db ? (direct ? db : colsum) : nullptr; g.M = K; g.N = N; g.K = M;
   int kps = (M + splits - 1) / splits;
   kps = (kps + 63) / 64 * 64;
   g.k_per_split = kps;
   g.slab_stride = (int64_t)K * N;
-  if (pp) {
-    if ((rc = launch_gemm_f32_pp(2, g, splits, (hipStream_t)stream))) return rc;
-    if (db) {
-      hipLaunchKernelGGL(k_sum_slabs, dim3((N / 4 + kThreads - 1) / kThreads), dim3(kThreads), 0,
-                         (hipStream_t)stream, colsum, (int64_t)N, gemm_f32_pp_colsum_chunks(K, splits),
-                         (int64_t)(N / 4), db);
-      if ((rc = check_launch("fc_bwd_weight bias combine"))) return rc;
-    }
-    if (direct) return rc;
-  } else {
-    int tm, tn;
-    pick_tile_bwd_weight(K, N, tm, tn);
-    if ((rc = launch_gemm<false, false, EPI_SLAB_COLSUM>(g, tm, tn, splits, (hipStream_t)stream))) return rc;
-    if (direct) return rc;
-  }
+  int tm, tn;
+  pick_tile_bwd_weight(K, N, tm, tn);
+  if ((rc = launch_gemm<false, false, EPI_SLAB_COLSUM>(g, tm, tn, splits, (hipStream_t)stream))) return rc;
+  if (direct) return rc;
   const int64_t total4 = (int64_t)K * N / 4;
   int grid = (int)((total4 + kThreads - 1) / kThreads);
   if (grid > kNumCU * 8) grid = kNumCU * 8;
   hipLaunchKernelGGL(k_sum_slabs_2d, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, slabs,
                      g.slab_stride, splits, K, N, dW, lddw);
   if ((rc = check_launch("fc_bwd_weight combine"))) return rc;
-  if (db && !pp) {
+  if (db) {
     hipLaunchKernelGGL(k_sum_slabs, dim3((N / 4 + kThreads - 1) / kThreads), dim3(kThreads), 0,
                        (hipStream_t)stream, colsum, (int64_t)N, splits, (int64_t)(N / 4), db);
     rc = check_launch("fc_bwd_weight bias combine");

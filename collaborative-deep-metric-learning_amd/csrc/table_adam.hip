@@ -37,8 +37,9 @@ __global__ void __launch_bounds__(kThreads)
 k_rows_adam(float *__restrict__ table, int64_t row0, int64_t n_rows, int64_t row_stride, int F,
             const int32_t *__restrict__ idx, int n_idx, const float *__restrict__ G, int64_t ldg,
             float *__restrict__ m_tab, float *__restrict__ v_tab, int32_t *__restrict__ head,
-            const int32_t *__restrict__ next, float lr_imm, const float *__restrict__ lr_dev, float b1,
-            float b2, float eps, int64_t t_imm, const uint64_t *__restrict__ t_dev) {
+            const int32_t *__restrict__ next, float grad_scale, float lr_imm,
+            const float *__restrict__ lr_dev, float b1, float b2, float eps, int64_t t_imm,
+            const uint64_t *__restrict__ t_dev) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_idx) return;
@@ -66,6 +67,10 @@ k_rows_adam(float *__restrict__ table, int64_t row0, int64_t n_rows, int64_t row
       }
     }
     last = best;
+  }
+  if (grad_scale != 1.0f) {   // data-parallel runs: 1/world, the mean over the GLOBAL batch
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { g[c].x *= grad_scale; g[c].y *= grad_scale; g[c].z *= grad_scale; g[c].w *= grad_scale; }
   }
   // l2norm backward from the raw row
   float4 *xrow = reinterpret_cast<float4 *>(table + lr * row_stride);
@@ -121,7 +126,7 @@ using namespace cdml;
 extern "C" int cdml_table_adam_rows(float *table, int64_t row0, int64_t n_rows, int64_t row_stride,
                                     int F, const int32_t *idx, int n_idx, const float *grad_xhat,
                                     int64_t ldg, float *m_table, float *v_table, int32_t *head,
-                                    int32_t *next, float lr, const float *lr_dev, float beta1,
+                                    int32_t *next, float grad_scale, float lr, const float *lr_dev, float beta1,
                                     float beta2, float eps, int64_t t, const uint64_t *t_dev,
                                     cdml_stream_t stream) {
   CDML_REQUIRE(table && idx && grad_xhat && m_table && v_table && head && next, CDML_E_BADARG,
@@ -141,7 +146,7 @@ extern "C" int cdml_table_adam_rows(float *table, int64_t row0, int64_t n_rows, 
   if (rc) return rc;
 #define CDML_LAUNCH_RA(N)                                                                              \
   hipLaunchKernelGGL((k_rows_adam<N>), dim3((n_idx + 3) / 4), dim3(kThreads), 0, s, table, row0, n_rows, \
-                     row_stride, F, idx, n_idx, grad_xhat, ldg, m_table, v_table, head, next, lr, lr_dev, \
+                     row_stride, F, idx, n_idx, grad_xhat, ldg, m_table, v_table, head, next, grad_scale, lr, lr_dev, \
                      beta1, beta2, eps, t, t_dev)
   if (nch <= 2) CDML_LAUNCH_RA(2);
   else if (nch <= 6) CDML_LAUNCH_RA(6);

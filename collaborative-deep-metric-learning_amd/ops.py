@@ -13,6 +13,7 @@ LRELU_ALPHA = 0.2     # tf.nn.leaky_relu default (reference models.py:21)
 
 
 def _stream():
+    # the caller selects the device (TrainStep asserts it); the stream is that device's current one
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -340,7 +341,7 @@ def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, 
 
 
 def table_adam_rows(table, row0, F, idx, grad_xhat, m_table, v_table, head, nxt, lr, t, beta1=0.9, beta2=0.999,
-                    eps=1e-8, lr_dev=None, t_dev=None):
+                    eps=1e-8, lr_dev=None, t_dev=None, grad_scale=1.0):
     """Lazy-Adam update of the catalogue rows a batch touched (see include/cdml.h)."""
     tp, tld = _mat(table)
     gp, gld = _mat(grad_xhat)
@@ -350,7 +351,7 @@ def table_adam_rows(table, row0, F, idx, grad_xhat, m_table, v_table, head, nxt,
     if head.numel() < table.shape[0] or nxt.numel() < idx.numel():
         raise ValueError("head needs one int32 per table row, next one per gathered row")
     call("cdml_table_adam_rows", tp, row0, table.shape[0], tld, F, _p(idx, torch.int32), idx.numel(), gp, gld,
-         _p(m_table), _p(v_table), _p(head, torch.int32), _p(nxt, torch.int32), lr, _p(lr_dev), beta1, beta2,
+         _p(m_table), _p(v_table), _p(head, torch.int32), _p(nxt, torch.int32), grad_scale, lr, _p(lr_dev), beta1, beta2,
          eps, 0 if t is None else t, _p(t_dev, torch.int64), _stream())
 
 

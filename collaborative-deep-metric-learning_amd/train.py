@@ -53,7 +53,20 @@ class TrainStep:
         if optimizer not in ("adam", "lars"):
             raise ValueError("optimizer must be 'adam' or 'lars'")
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is not None \
+                and torch.cuda.current_device() != self.device.index:
+            # the ops launch on the CURRENT device's stream: a step built for another device
+            # would run its kernels on the wrong stream with that device's pointers
+            raise ValueError("TrainStep(device=%s) needs torch.cuda.set_device(%d) first (current device %d)"
+                             % (self.device, self.device.index, torch.cuda.current_device()))
         self.table, self.pairs = table, pairs
+        # the reference raises IndexError on an id outside the table (inputs.py:158); the fused
+        # kernel clamps, so the ids are checked once here instead of per step
+        if pairs.numel():
+            lo, hi = int(pairs.min().item()), int(pairs.max().item())
+            if lo < 0 or hi >= table.n_rows_global:
+                raise IndexError("co-watch pair ids span [%d, %d] but the catalogue has %d rows"
+                                 % (lo, hi, table.n_rows_global))
         self.B = int(batch_size)
         self.mode = mode
         self.rows_per_triplet = 3 if mode == "uniform" else 2
@@ -118,8 +131,15 @@ class TrainStep:
             self.tab_next = torch.zeros(self.R, dtype=i32, device=dev)
             self.dxh = torch.zeros((self.R, self.layout.Fp), dtype=f32, device=dev)
             prefetch = False      # a prefetched batch would read rows from before this step's update
+            if grad_sync is not None and exchange is None:
+                raise ValueError("train_table with grad_sync needs a row-sharded table (exchange): "
+                                 "replicated trainable tables would diverge between ranks")
         self._graph = None
+        self._warmed = False
         self.use_graph = bool(use_graph) and exchange is None and grad_sync is None
+        if use_graph and not self.use_graph:
+            logging.getLogger("cdml.train").warning(
+                "use_graph ignored: the data-parallel step (exchange / grad_sync) runs eagerly")
         # row-sharded catalogue: the exchange of step t+1 runs ahead on a side stream
         # into the second x_hat / idx buffer while step t computes
         self.prefetch = None
@@ -219,8 +239,12 @@ class TrainStep:
                 return
             if self.tab_next.numel() < idx.numel():
                 self.tab_next = torch.zeros(idx.numel(), dtype=torch.int32, device=self.device)
+        # dxh carries the mean over THIS rank's batch; the dense gradients are averaged over
+        # ranks, so the row gradients (summed on the owner) take the same 1/world
+        world = self.grad_sync.world if self.grad_sync is not None else 1
         ops.table_adam_rows(t.data, t.row0, t.feature_size, idx, rows, self.tab_m, self.tab_v,
-                            self.tab_head, self.tab_next, 0.0, 1, lr_dev=self.lr_dev, t_dev=self.step_dev)
+                            self.tab_head, self.tab_next, 0.0, 1, lr_dev=self.lr_dev, t_dev=self.step_dev,
+                            grad_scale=1.0 / world)
 
     def apply_gradients(self):
         p = self.params
@@ -269,12 +293,13 @@ class TrainStep:
         if lr != self._lr_host:                         # staircase: rare
             self.lr_dev.fill_(lr)
             self._lr_host = lr
-        if self.use_graph and self.global_step >= 1:     # step 0 runs eagerly (loads the kernels)
-            if self._graph is None:
+        if self.use_graph and self._warmed:              # the first step of a process runs eagerly
+            if self._graph is None:                      # (it loads the kernels), also after a resume
                 self._capture()
             self._graph.replay()
         else:
             self._enqueue()
+            self._warmed = True
         self.global_step += 1
 
     def _capture(self):
@@ -321,10 +346,13 @@ class TrainStep:
             self.table.data.copy_(state["table"]["rows"].to(self.device))
             self.tab_m.copy_(state["table"]["m"].to(self.device))
             self.tab_v.copy_(state["table"]["v"].to(self.device))
+        if self.bf16:                                    # the GEMMs read the bf16 copies, not the masters
+            engine_bf16.refresh_weights(self.params, self.ws)
         self.global_step = int(state["global_step"])
         self.step_dev.fill_(self.global_step)
         self.seed = int(state["seed"])
         self._graph = None
+        self._filled = -1
 
 
 class Trainer:
@@ -376,8 +404,17 @@ class Trainer:
     def save(self, step):
         if not self.checkpoint_dir:
             return None
+        # data-parallel runs: the dense state is replicated -> rank 0 writes it; a trainable
+        # table is sharded -> every rank writes its own shard file
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        sharded = self.ts.train_table and self.ts.exchange is not None
+        if rank != 0 and not sharded:
+            return None
         os.makedirs(self.checkpoint_dir, exist_ok=True)
-        path = os.path.join(self.checkpoint_dir, "model.ckpt-%d.pt" % step)
+        name = "model.ckpt-%d.rank%d.pt" % (step, rank) if sharded else "model.ckpt-%d.pt" % step
+        path = os.path.join(self.checkpoint_dir, name)
         state = self.ts.state_dict()
         state["trainer"] = {"best_eval_dist": self.best_eval_dist, "total_eval_num": self.total_eval_num,
                             "last_improve_num": self.last_improve_num}

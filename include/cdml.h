@@ -337,13 +337,15 @@ int cdml_adam_step(float *w, const float *g, float *m, float *v, int64_t n,
  * taken through the l2norm backward of models.py:58 with the raw row, and a lazy-Adam update
  * (the arithmetic of cdml_adam_step; m/v/x of untouched rows are not read) is applied to
  * table, m_table, v_table (same shape and stride).  head: int32[n_rows] scratch that must be
- * all -1 on entry and is -1 again on exit; next: int32[n_idx] scratch. */
+ * all -1 on entry and is -1 again on exit; next: int32[n_idx] scratch.  grad_scale
+ * multiplies the summed row gradient (1/world in a data-parallel run, where every rank's
+ * grad_xhat carries the mean over its LOCAL batch and the dense gradients are averaged). */
 int cdml_table_adam_rows(float *table, int64_t row0, int64_t n_rows, int64_t row_stride,
                          int F, const int32_t *idx, int n_idx, const float *grad_xhat,
                          int64_t ldg, float *m_table, float *v_table, int32_t *head,
-                         int32_t *next, float lr, const float *lr_dev, float beta1,
-                         float beta2, float eps, int64_t t, const uint64_t *t_dev,
-                         cdml_stream_t stream);
+                         int32_t *next, float grad_scale, float lr, const float *lr_dev,
+                         float beta1, float beta2, float eps, int64_t t,
+                         const uint64_t *t_dev, cdml_stream_t stream);
 
 /* LARS (tf.contrib.opt.LARSOptimizer, train.py:354), one variable of n
  * elements: trust = eeta*|w|/(|g|+wd*|w|+eps) (1 if |w|==0 or |g|==0);

@@ -58,18 +58,20 @@ def _worker(rank, world, port, q, CFG=CFG):
         dev = torch.device("cuda:0")
         ts = _make(dev, rank, world, cdist.RowExchange(CFG["n_rows"], group=dist.new_group()), cdist.GradSync(),
                    c=CFG)
-        idx, g0 = [], None
+        idx, g0, tab_m0 = [], None, None
         for _ in range(CFG["steps"]):
             ts.step()
             idx.append(ts.idx.cpu().numpy().copy())
             if g0 is None:
                 g0 = ts.params.grad.cpu().numpy().copy()                # averaged gradient, step 0
+                if CFG.get("train_table"):                               # (1-b1) x row gradient: shows its SCALE
+                    tab_m0 = ts.tab_m.cpu().numpy().copy()
         torch.cuda.synchronize()
         shard = ts.table.data.cpu().numpy() if CFG.get("train_table") else None
-        q.put((rank, "ok", np.stack(idx), ts.params.flat.cpu().numpy(), ts.loss(), g0, shard))
+        q.put((rank, "ok", np.stack(idx), ts.params.flat.cpu().numpy(), ts.loss(), g0, shard, tab_m0))
     except Exception:
         import traceback
-        q.put((rank, traceback.format_exc(), None, None, None, None, None))
+        q.put((rank, traceback.format_exc(), None, None, None, None, None, None))
     finally:
         dist.destroy_process_group()
 
@@ -94,12 +96,14 @@ def test_two_rank_step_equals_single_rank(gpu, CFG):
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
 
     single = _make(gpu, 0, 1, c=CFG)
-    idx, g0 = [], None
+    idx, g0, tab_m0 = [], None, None
     for _ in range(CFG["steps"]):
         single.step()
         idx.append(single.idx.cpu().numpy().copy())
         if g0 is None:
             g0 = single.params.grad.cpu().numpy().copy()
+            if CFG.get("train_table"):
+                tab_m0 = single.tab_m.cpu().numpy().copy()
     torch.cuda.synchronize()
     # mean over the global batch == average of the two ranks' local means
     # (bf16: the ranks round their activations exactly as the single rank does -- same rows, same
@@ -124,6 +128,11 @@ def test_two_rank_step_equals_single_rank(gpu, CFG):
         got = np.concatenate([r[6] for r in res])
         assert got.shape == whole.shape
         assert np.mean(np.abs(got - whole) > 1e-4) < 0.02 and np.abs(got - whole).max() < 2.5e-2
+        # the row gradients themselves (Adam's first-moment slot after step 0 = 0.1 x gradient):
+        # the mean over the GLOBAL batch, i.e. the owners scale the summed local means by 1/world
+        got_m = np.concatenate([r[7] for r in res])
+        scale = np.abs(tab_m0).max()
+        assert scale > 0 and np.abs(got_m - tab_m0).max() < 1e-3 * scale
         fresh = _make(gpu, 0, 1, c=CFG).table.data.cpu().numpy()
         assert np.abs(got - fresh).max() > 5e-3                       # and they did move
 

@@ -188,34 +188,10 @@ def test_l2norm_fwd_bwd(cd):
 
 # ---------------------------------------------------------------------- GEMM --
 FC_SHAPES = [(15, 64, 64), (130, 96, 192), (384, 1536, 5120), (257, 5120, 256), (64, 32, 128)]
-# the 128x256 ping-pong kernel (CDML_F32_TILE=256 takes it wherever the shape allows):
-# minimal, ragged rows, long K, several column tiles
-PP_FWD = [(128, 64, 256), (300, 128, 256), (1000, 1536, 512), (77, 5120, 256), (384, 1536, 5120)]
 
 
-@pytest.fixture
-def pp(monkeypatch):
-    monkeypatch.setenv("CDML_F32_TILE", "256")
-
-
-@pytest.mark.parametrize("M,K,N", PP_FWD)
-def test_fc_lrelu_fwd_pingpong(cd, pp, M, K, N):
-    test_fc_lrelu_fwd(cd, M, K, N)
-
-
-@pytest.mark.parametrize("M,K,N", [(128, 256, 64), (300, 512, 128), (1000, 1024, 256), (77, 5120, 256)])
-def test_fc_bwd_data_pingpong(cd, pp, M, K, N):
-    test_fc_bwd_data(cd, M, K, N)
-
-
-@pytest.mark.parametrize("M,K,N", [(64, 128, 256), (777, 256, 512), (3000, 5120, 256), (1001, 1536, 1024),
-                                   (8192, 128, 256)])
-def test_fc_bwd_weight_pingpong(cd, pp, M, K, N):
-    test_fc_bwd_weight(cd, M, K, N)
-
-
-def test_fc_pingpong_race_screen(cd, pp):
-    """Counted-wait / barrier ordering of the ping-pong kernel: many launches on the whole
+def test_fc_race_screen(cd):
+    """DMA-wait / barrier ordering of the LDS-DMA staged kernels: many launches on the whole
     chip, every result compared bit for bit with the first."""
     M, K, N = 4096, 512, 2048
     g = torch.Generator(device=cd.dev)

@@ -57,6 +57,16 @@ def test_table_adam_rows_vs_oracle(cd, F, stride):
     d2, m2, v2 = t(tab.copy()), t(m0.copy()), t(v0.copy())
     cd.ops.table_adam_rows(d2, row0, F, t(idx), t(G), m2, v2, head, nxt, 0.01, 1, t_dev=step)
     assert torch.equal(d2, d_tab) and torch.equal(m2, d_m) and torch.equal(v2, d_v)
+    # grad_scale (1/world in a data-parallel run): the m slot is linear in the gradient, so it
+    # shows the scale that Adam's m/sqrt(v) ratio would hide in the rows themselves
+    d3, m3, v3 = t(tab.copy()), t(m0.copy()), t(v0.copy())
+    cd.ops.table_adam_rows(d3, row0, F, t(idx), t(G), m3, v3, head, nxt, 0.01, 1, t_dev=step, grad_scale=0.25)
+    w3, wm3, wv3 = otable.table_adam_rows(tab[:, :F], m0[:, :F], v0[:, :F], idx, 0.25 * G[:, :F].astype(np.float64),
+                                          5, 0.01, row0=row0)
+    np.testing.assert_allclose(m3.cpu().numpy()[:, :F], wm3, atol=1e-7)
+    np.testing.assert_allclose(v3.cpu().numpy()[:, :F], wv3, atol=1e-9)
+    np.testing.assert_allclose(d3.cpu().numpy()[:, :F], w3, atol=2e-6)
+    assert not np.allclose(m3.cpu().numpy()[touched, :F], got_m[touched, :F], atol=1e-7)
 
 
 def test_train_step_with_trainable_table(cd):
