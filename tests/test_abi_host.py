@@ -46,7 +46,8 @@ def test_argument_errors_need_no_gpu(built):
     rc = lib.cdml_fc_lrelu_fwd(C.c_void_p(16), 48, C.c_void_p(16), 64, C.c_void_p(16), 0.2, 8, 48, 64,
                                C.c_void_p(16), 64, None)
     assert rc == -4 and b"multiple of 32" in lib.cdml_last_error()
-    assert lib.cdml_fc_bwd_weight_workspace(8192, 1536, 5120) >= 1536 * 5120 * 4
+    assert lib.cdml_fc_bwd_weight_workspace(8192, 1536, 5120) >= 5120 * 4       # one split: bias partials only
+    assert lib.cdml_fc_bwd_weight_workspace(8192, 5120, 256) >= 2 * 5120 * 256 * 4   # split-K slabs
     assert lib.cdml_fc_bwd_weight_workspace(8, 48, 64) == 0
     with pytest.raises(built.CdmlError):
         built.call("cdml_step_advance", None, None)
