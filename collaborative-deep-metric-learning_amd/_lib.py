@@ -40,7 +40,7 @@ SIGNATURES = {
     "cdml_step_advance": (_i, [_p, _p]),
     "cdml_gather_rows": (_i, [_p, _i64, _i64, _i64, _p, _i, _i, _i, _p, _i64, _p, _p, _p]),
     "cdml_sample_gather": (_i, [_i, _p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _i64, _i64, _i,
-                                _p, _p, _p, _i64, _p]),
+                                _p, _p, _p, _i64, _i, _i64, _i64, _p]),
     "cdml_l2norm_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p]),
     "cdml_l2norm_bwd": (_i, [_p, _i64, _p, _i64, _i, _i, _f, _p, _i64, _p]),
     "cdml_fc_lrelu_fwd": (_i, [_p, _i64, _p, _i64, _p, _f, _i, _i, _i, _p, _i64, _p]),
@@ -50,6 +50,9 @@ SIGNATURES = {
     "cdml_triplet_hinge": (_i, [_p, _i64, _i, _i, _f, _p, _p, _p, _p, _p, _i64, _p]),
     "cdml_triplet_hinge_inbatch": (_i, [_p, _i64, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p,
                                         _i64, _p]),
+    "cdml_vnet_tail_workspace": (_sz, [_i, _i]),
+    "cdml_vnet_tail": (_i, [_i, _p, _i64, _p, _p, _i, _i, _f, _f, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64,
+                            _p, _p, _p, _p]),
     "cdml_semihard_select": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _p, _p]),
     "cdml_triplet_hinge_indexed": (_i, [_p, _i64, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "cdml_pair_dist": (_i, [_p, _i64, _i, _p, _i, _i, _p, _p, _p, _p]),
@@ -73,7 +76,7 @@ SIGNATURES = {
     "cdml_ew_combine": (_i, [_i, _p, _i64, _p, _i64, _i, _i, _p, _i64, _p]),
     "cdml_ew_fusion_bwd": (_i, [_i, _p, _i64, _p, _i64, _p, _i64, _i, _i, _f, _p, _i64, _p, _i64, _p]),
     "cdml_lrelu_bwd": (_i, [_p, _i64, _p, _i64, _i, _i, _f, _p, _i64, _p]),
-    "cdml_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _i64, _p, _p]),
+    "cdml_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _i64, _p, _i, _p, _p]),
     "cdml_table_adam_rows": (_i, [_p, _i64, _i64, _i64, _i, _p, _i, _p, _i64, _p, _p, _p, _p, _f, _f, _p, _f, _f, _f,
                                   _i64, _p, _p]),
     "cdml_lars_scratch_floats": (_sz, []),

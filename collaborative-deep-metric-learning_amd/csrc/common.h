@@ -36,6 +36,43 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- "am I the last block of this grid to get here" ------------------------------------
+// For kernels whose last finisher folds a tiny grid-wide reduction (loss statistics, step
+// counter) into the same launch instead of paying another launch for it.  Two-level tickets
+// (groups of 32 blocks, then one top word) keep every word at <= 64 arrivals.  tickets:
+// uint32[kTicketWords], zero before the first launch; the last arrivers reset them, so one
+// buffer serves every later launch of the same kernel on the same stream.
+// Memory order (MI355X_MICROARCH.md, inter-workgroup visibility): every wave drains its own
+// stores, the block's lane 0 releases at agent scope BEFORE the relaxed atomic, and the last
+// block acquires at agent scope AFTER it, then the block barrier publishes that to its waves.
+constexpr int kTicketWords = 80;          // 1 top + up to 64 groups (grids <= 2048 blocks) + slack
+__device__ __forceinline__ bool grid_last_block(uint32_t *tickets) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned nb = gridDim.x, g = blockIdx.x >> 5, ngroups = (nb + 31) >> 5;
+    const unsigned gsize = min(32u, nb - (g << 5));
+    int last = 0;
+    if (__hip_atomic_fetch_add(&tickets[1 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+      __hip_atomic_store(&tickets[1 + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) {
+        __hip_atomic_store(&tickets[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
+    }
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
 // Philox4x32-10 (Salmon et al., Random123); spec + known answers: oracle/sampler.py
 struct u32x4 { uint32_t x, y, z, w; };
 

@@ -179,6 +179,249 @@ k_triplet_hinge_inbatch(const float *__restrict__ e, int64_t lde, const int32_t 
   }
 }
 
+// ------------------------------------------------------------ fused tower tail ----
+// tf.nn.l2_normalize of the output layer (models.py:61) -> HingeLoss.calculate_loss
+// (losses.py:32-38) -> its gradient -> l2-normalise backward -> leaky-relu' of the output
+// layer (train.py:141), in ONE launch instead of three + the statistics pass: one wave per
+// triplet slot keeps the rows of z it needs in registers (NCH float4 per lane per row).  The
+// arithmetic is that of k_l2norm_fwd / dist_pair / k_triplet_hinge{,_inbatch} / k_l2norm_bwd,
+// operation for operation, so both routes give the same bits.  The last block to finish
+// (grid_last_block) reduces the per-triplet values to the step's scalars in a fixed order:
+// stats[0..3] = mean hinge, mean pos, mean neg, active fraction; stats[4] = calc_var of the
+// [B,3,D] triplet tensor (train.py:67-71) when var_ws is given.
+// MODE 0: rows 3i, 3i+1, 3i+2 = anchor, positive, negative.  MODE 1 (in-batch negatives): slot i
+// owns rows 2i (a_i), 2i+1 (p_i); its negative is p_j, j = (i+shift) mod B, and p_i is also the
+// negative of slot k = (i-shift) mod B, so the wave of slot i recomputes triplet k's activity
+// and writes both of its rows' complete gradients (no atomics, fixed order).
+template <int NCH>
+struct TailRow {
+  float4 v[NCH];
+  float ss, inv;
+  __device__ __forceinline__ void load(const float *zr, int nq, int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      v[c] = (q < nq) ? ld4(zr, q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += sq4(v[c]);
+    }
+    ss = wave_sum(s);
+    inv = 1.0f / sqrtf(fmaxf(ss, kL2Eps));
+  }
+  __device__ __forceinline__ float4 e(int c) const { return mul4(v[c], inv); }
+};
+
+template <int NCH>
+__device__ __forceinline__ void tail_dist(const TailRow<NCH> &a, const TailRow<NCH> &p, const TailRow<NCH> &n,
+                                          float &pos, float &neg) {
+  float sp = 0.f, sn = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const float4 va = a.e(c);
+    sp += sq4(sub4(va, p.e(c)));
+    sn += sq4(sub4(va, n.e(c)));
+  }
+  pos = wave_sum(sp);
+  neg = wave_sum(sn);
+}
+
+// dz = inv * (g - z*c) * lrelu'(z), c = inv^2 <z,g>  (k_l2norm_bwd); also stores e
+template <int NCH>
+__device__ __forceinline__ void tail_store_row(const TailRow<NCH> &r, const float4 (&g)[NCH], float alpha,
+                                               float *er, float *dr, uint16_t *br, int nq, int lane) {
+  float zg = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) zg += dot4(r.v[c], g[c]);
+  zg = wave_sum(zg);
+  const float inv = r.inv;
+  const float cc = (r.ss > kL2Eps) ? inv * inv * zg : 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int q = lane + kWave * c;
+    if (q >= nq) continue;
+    const float4 a = r.v[c], b = g[c];
+    float4 d = make_float4(inv * (b.x - a.x * cc), inv * (b.y - a.y * cc), inv * (b.z - a.z * cc),
+                           inv * (b.w - a.w * cc));
+    if (alpha >= 0.f) {
+      d.x *= (a.x > 0.f) ? 1.f : alpha;
+      d.y *= (a.y > 0.f) ? 1.f : alpha;
+      d.z *= (a.z > 0.f) ? 1.f : alpha;
+      d.w *= (a.w > 0.f) ? 1.f : alpha;
+    }
+    st4(er, q, r.e(c));
+    st4(dr, q, d);
+    if (br) {   // bf16 copy (round to nearest even) for the reduced-precision GEMMs
+      auto rn = [](float x) -> uint32_t {
+        const uint32_t u = __float_as_uint(x);
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+      };
+      uint2 w;
+      w.x = rn(d.x) | (rn(d.y) << 16);
+      w.y = rn(d.z) | (rn(d.w) << 16);
+      reinterpret_cast<uint2 *>(br)[q] = w;
+    }
+  }
+}
+
+template <int MODE, int NCH>
+__global__ void __launch_bounds__(kThreads)
+k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict__ rows,
+            const int32_t *__restrict__ shift_p, int B, int D, float margin, float alpha,
+            float *__restrict__ e, int64_t lde, float *__restrict__ pos_o, float *__restrict__ neg_o,
+            float *__restrict__ hinge_o, uint8_t *__restrict__ valid_o, float *__restrict__ dz2,
+            int64_t lddz, uint16_t *__restrict__ dz2_bf, int64_t ldbf, float *__restrict__ var_ws,
+            float *__restrict__ stats, uint32_t *__restrict__ tickets) {
+  __shared__ __attribute__((aligned(16))) float s_red[kWavesPerBlock][8];
+  extern __shared__ __attribute__((aligned(16))) float s_col[];                 // [kWavesPerBlock][D] when var_ws
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nq = D >> 2;
+  const int shift = (MODE == 1) ? *shift_p : 0;
+  const float two_over_b = 2.0f / (float)B;
+  float4 csum[NCH];
+  float tsq = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) csum[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = blockIdx.x * kWavesPerBlock + wave; i < B; i += gridDim.x * kWavesPerBlock) {
+    TailRow<NCH> A, P, N;
+    float4 ga[NCH], gp[NCH];
+    int64_t ra, rp;
+    bool valid_i = true;
+    float pos, neg;
+    if (MODE == 0) {
+      ra = 3 * (int64_t)i; rp = ra + 1;
+      A.load(z + ra * ldz, nq, lane);
+      P.load(z + rp * ldz, nq, lane);
+      N.load(z + (ra + 2) * ldz, nq, lane);
+      tail_dist<NCH>(A, P, N, pos, neg);
+      const float t = pos - neg + margin;
+      const float s = (t >= 0.f) ? two_over_b : 0.f;       // MaximumGrad: inclusive at 0
+      float4 gn[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const float4 va = A.e(c), vp = P.e(c), vn = N.e(c);
+        ga[c] = mul4(sub4(vn, vp), s);
+        gp[c] = mul4(sub4(vp, va), s);
+        gn[c] = mul4(sub4(va, vn), s);
+      }
+      if (lane == 0) { pos_o[i] = pos; neg_o[i] = neg; hinge_o[i] = fmaxf(t, 0.f); }
+      tail_store_row<NCH>(N, gn, alpha, e + (ra + 2) * lde, dz2 + (ra + 2) * lddz,
+                          dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane);
+    } else {
+      const int j = (i + shift) % B;
+      const int k = (i - shift % B + B) % B;
+      ra = 2 * (int64_t)i; rp = ra + 1;
+      const int32_t va_id = rows[2 * i], vp_id = rows[2 * i + 1], vn_id = rows[2 * j + 1];
+      valid_i = (vn_id != va_id) && (vn_id != vp_id);
+      const bool valid_k = (vp_id != rows[2 * k]) && (vp_id != rows[2 * k + 1]);
+      TailRow<NCH> AK, PK;
+      A.load(z + ra * ldz, nq, lane);
+      P.load(z + rp * ldz, nq, lane);
+      N.load(z + (int64_t)(2 * j + 1) * ldz, nq, lane);
+      AK.load(z + (int64_t)(2 * k) * ldz, nq, lane);
+      PK.load(z + (int64_t)(2 * k + 1) * ldz, nq, lane);
+      tail_dist<NCH>(A, P, N, pos, neg);
+      float posk, negk;
+      tail_dist<NCH>(AK, PK, P, posk, negk);               // triplet k = (a_k, p_k, p_i)
+      const float t = pos - neg + margin;
+      const float si = (valid_i && t >= 0.f) ? two_over_b : 0.f;
+      const float sk = (valid_k && (posk - negk + margin) >= 0.f) ? two_over_b : 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const float4 va = A.e(c), vp = P.e(c), vn = N.e(c), vak = AK.e(c);
+        ga[c] = mul4(sub4(vn, vp), si);
+        const float4 g1 = mul4(sub4(vp, va), si);          // as positive of triplet i
+        const float4 g2 = mul4(sub4(vak, vp), sk);         // as negative of triplet k
+        gp[c] = make_float4(g1.x + g2.x, g1.y + g2.y, g1.z + g2.z, g1.w + g2.w);
+      }
+      if (lane == 0) {
+        pos_o[i] = pos; neg_o[i] = neg;
+        hinge_o[i] = valid_i ? fmaxf(t, 0.f) : 0.f;
+        if (valid_o) valid_o[i] = valid_i ? 1 : 0;
+      }
+    }
+    tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane);
+    tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane);
+    if (var_ws) {       // column sums and sum of squares of the [B,3,D] triplet tensor
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const float4 va = A.e(c), vp = P.e(c), vn = N.e(c);
+        csum[c].x += va.x + vp.x + vn.x; csum[c].y += va.y + vp.y + vn.y;
+        csum[c].z += va.z + vp.z + vn.z; csum[c].w += va.w + vp.w + vn.w;
+        tsq += sq4(va) + sq4(vp) + sq4(vn);
+      }
+    }
+  }
+  const int nb = gridDim.x;
+  if (var_ws) {         // block partial: var_ws[block][D + 4]
+    float *mine = s_col + wave * D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      if (q < nq) st4(mine, q, csum[c]);
+    }
+    tsq = wave_sum(tsq);
+    if (lane == 0) s_red[wave][0] = tsq;
+    __syncthreads();
+    float *out = var_ws + (int64_t)blockIdx.x * (D + 4);
+    for (int d = threadIdx.x; d < D; d += kThreads) {
+      float v = 0.f;
+      for (int w = 0; w < kWavesPerBlock; ++w) v += s_col[w * D + d];
+      out[d] = v;
+    }
+    if (threadIdx.x == 0) {
+      float v = 0.f;
+      for (int w = 0; w < kWavesPerBlock; ++w) v += s_red[w][0];
+      out[D] = v;
+    }
+  }
+  if (!stats) return;
+  if (!grid_last_block(tickets)) return;
+  // ---- the last block: the step's scalars, fixed summation order ----
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < B; i += kThreads) {
+    const float h = hinge_o[i];
+    acc[0] += h;
+    acc[1] += pos_o[i];
+    acc[2] += neg_o[i];
+    acc[3] += (h > 0.f) ? 1.f : 0.f;
+  }
+  double vsum = 0.0;
+  if (var_ws) {         // var = [sum t^2 - n_rows * sum_d mean_d^2] / (n_rows * D), n_rows = 3B
+    const double n_rows = 3.0 * (double)B;
+    for (int d = threadIdx.x; d < D; d += kThreads) {
+      double col = 0.0;
+      for (int b = 0; b < nb; ++b) col += (double)var_ws[(int64_t)b * (D + 4) + d];
+      const double mean = col / n_rows;
+      vsum -= n_rows * mean * mean;
+    }
+    for (int b = threadIdx.x; b < nb; b += kThreads) vsum += (double)var_ws[(int64_t)b * (D + 4) + D];
+  }
+  __syncthreads();      // s_red is reused below
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float v = wave_sum(acc[c]);
+    if (lane == 0) s_red[wave][c] = v;
+  }
+  {
+    double v = vsum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) reinterpret_cast<double *>(&s_red[wave][4])[0] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = 0.f;
+    for (int w = 0; w < kWavesPerBlock; ++w) v += s_red[w][threadIdx.x];
+    stats[threadIdx.x] = v / (float)B;
+  }
+  if (threadIdx.x == 4 && var_ws) {
+    double v = 0.0;
+    for (int w = 0; w < kWavesPerBlock; ++w) v += reinterpret_cast<const double *>(&s_red[w][4])[0];
+    stats[4] = (float)(v / (3.0 * (double)B * (double)D));
+  }
+}
+
 // ---------------------------------------------------- semi-hard mining (config 2) --
 // Build-defined (the reference only draws uniform negatives); spec in
 // oracle/tower.py semihard_select.  sqn[r] = |e_r|^2.
@@ -508,6 +751,48 @@ extern "C" int cdml_triplet_hinge_inbatch(const float *e, int64_t lde, const int
     rc = check_launch("triplet_hinge_inbatch stats");
   }
   return rc;
+}
+
+constexpr int kTailVarBlocks = 256;   // grid cap when the variance is wanted (last block sums the partials)
+
+extern "C" size_t cdml_vnet_tail_workspace(int B, int D) {
+  if (B <= 0 || D <= 0) return 0;
+  return (size_t)kTailVarBlocks * (size_t)(D + 4) * sizeof(float);
+}
+
+extern "C" int cdml_vnet_tail(int mode, const float *z, int64_t ldz, const int32_t *rows,
+                              const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
+                              float *e, int64_t lde, float *pos, float *neg, float *hinge,
+                              uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_bf16,
+                              int64_t ldbf, float *stats, float *var_ws, uint32_t *tickets,
+                              cdml_stream_t stream) {
+  CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "vnet_tail: mode must be 0 (a,p,n rows) or 1 (in-batch)");
+  CDML_REQUIRE(B >= (mode == 1 ? 2 : 1) && D > 0 && pos && neg && hinge, CDML_E_BADARG, "vnet_tail: bad argument");
+  CDML_REQUIRE(mode == 0 || (rows && shift), CDML_E_BADARG, "vnet_tail: in-batch mode needs rows and shift");
+  CDML_REQUIRE(!stats || tickets, CDML_E_BADARG, "vnet_tail: stats needs the ticket words");
+  CDML_REQUIRE(!var_ws || stats, CDML_E_BADARG, "vnet_tail: the variance is written to stats[4]");
+  CDML_REQUIRE(D <= 1024, CDML_E_UNSUPPORTED, "vnet_tail: embedding size %d > 1024", D);
+  int rc;
+  if ((rc = check_rows("vnet_tail z", z, ldz, D))) return rc;
+  if ((rc = check_rows("vnet_tail e", e, lde, D))) return rc;
+  if ((rc = check_rows("vnet_tail dz2", dz2, lddz2, D))) return rc;
+  CDML_REQUIRE(!dz2_bf16 || (ldbf >= D && (ldbf & 3) == 0 && (reinterpret_cast<uintptr_t>(dz2_bf16) & 7) == 0),
+               CDML_E_ALIGN, "vnet_tail: bf16 copy needs an 8-B aligned base and a leading dimension multiple of 4");
+  int grid = grid_rows(B);
+  if (var_ws && grid > kTailVarBlocks) grid = kTailVarBlocks;
+  const size_t lds = var_ws ? (size_t)kWavesPerBlock * D * sizeof(float) : 0;
+  const int nch = ((D >> 2) + kWave - 1) / kWave;
+#define CDML_LAUNCH_TAIL(M, N)                                                                       \
+  hipLaunchKernelGGL((k_vnet_tail<M, N>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, z, ldz, \
+                     rows, shift, B, D, margin, lrelu_alpha, e, lde, pos, neg, hinge, valid_out, dz2,  \
+                     lddz2, dz2_bf16, ldbf, var_ws, stats, tickets)
+  if (mode == 0) {
+    if (nch <= 1) CDML_LAUNCH_TAIL(0, 1); else if (nch <= 2) CDML_LAUNCH_TAIL(0, 2); else CDML_LAUNCH_TAIL(0, 4);
+  } else {
+    if (nch <= 1) CDML_LAUNCH_TAIL(1, 1); else if (nch <= 2) CDML_LAUNCH_TAIL(1, 2); else CDML_LAUNCH_TAIL(1, 4);
+  }
+#undef CDML_LAUNCH_TAIL
+  return check_launch("vnet_tail");
 }
 
 extern "C" int cdml_semihard_select(const float *S, int64_t ldS, const float *e, int64_t lde,

@@ -31,7 +31,8 @@ constexpr int kLarsBlocks = 1024;
 __global__ void __launch_bounds__(kThreads)
 k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
        float *__restrict__ v, int64_t n, float lr_imm, const float *__restrict__ lr_dev, float b1,
-       float b2, float eps, int64_t t_imm, const uint64_t *__restrict__ t_dev) {
+       float b2, float eps, int64_t t_imm, uint64_t *__restrict__ t_dev, int advance,
+       uint32_t *__restrict__ tickets) {
   __shared__ float s_lr_t;
   if (threadIdx.x == 0) {
     const double t = (double)t_imm + (t_dev ? (double)(*t_dev) : 0.0);
@@ -66,6 +67,9 @@ k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m
     v[i] = vi;
     w[i] = w[i] - (mi * lr_t) / (sqrtf(vi) + eps);
   }
+  // global_step += 1 (train.py:146 apply_gradients(global_step=...)) by the last block to
+  // finish: every block has read *t_dev by then, and no other kernel runs beside this one
+  if (advance && grid_last_block(tickets) && threadIdx.x == 0) *t_dev += 1;
 }
 
 // scratch layout: [0]=|w|^2, [1]=|g|^2, then kLarsBlocks x 2 block partials
@@ -131,18 +135,21 @@ int grid_elems(int64_t n, int per_thread) {
 
 using namespace cdml;
 
-extern "C" int cdml_version(void) { return 1000; }
+extern "C" int cdml_version(void) { return 2000; }
 extern "C" const char *cdml_last_error(void) { return err_buf(); }
 
 extern "C" int cdml_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float lr,
                               const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
-                              const uint64_t *t_dev, cdml_stream_t stream) {
+                              uint64_t *t_dev, int advance_step, uint32_t *tickets,
+                              cdml_stream_t stream) {
   CDML_REQUIRE(w && g && m && v && n > 0, CDML_E_BADARG, "adam_step: bad argument");
+  CDML_REQUIRE(!advance_step || (t_dev && tickets), CDML_E_BADARG,
+               "adam_step: advance_step needs the device step counter and the ticket words");
   CDML_REQUIRE(t >= (t_dev ? 0 : 1), CDML_E_BADARG, "adam_step: step t is 1-based");
   CDML_REQUIRE(aligned16(w) && aligned16(g) && aligned16(m) && aligned16(v), CDML_E_ALIGN,
                "adam_step: buffers must be 16-B aligned");
   hipLaunchKernelGGL(k_adam, dim3(grid_elems(n, 4)), dim3(kThreads), 0, (hipStream_t)stream, w, g, m,
-                     v, n, lr, lr_dev, beta1, beta2, eps, t, t_dev);
+                     v, n, lr, lr_dev, beta1, beta2, eps, t, t_dev, advance_step, tickets);
   return check_launch("adam_step");
 }
 

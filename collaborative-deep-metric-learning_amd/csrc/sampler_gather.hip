@@ -162,42 +162,132 @@ k_gather_rows(const float *__restrict__ table, int64_t row0, int64_t n_rows, int
   }
 }
 
-// Persistent fused sampler + gather.  One wave per ROW of the batch: the wave re-derives the
-// ids of its triplet (scalar loads of the pair; the Philox negative only on the wave that
-// gathers it), loads its row (NCH x 1 KiB in flight), normalises and stores it.  A triplet's
-// rows go to different waves so that a batch of 4096 triplets still puts 8-12 k independent
-// ids -> row chains on the chip (the kernel is 20 us long: chain latency, not bandwidth, is
-// what it has to hide).  MODE 0 = uniform negatives (3 rows/triplet), MODE 1 = in-batch
-// negatives (2 rows/triplet).
+// Persistent fused sampler + gather + input l2-normalise, one launch for n_steps consecutive
+// training steps (the sampler is counter-based, so the triplets of step t+1 are known at step
+// t; two or more steps per launch amortise the launch ramp and the ids -> row latency chain of
+// a kernel that is otherwise only ~16 us of HBM traffic long).
+//   * the launch's rows (n_steps x RPT x batch; RPT = 3 uniform, 2 in-batch) are cut into
+//     chunks of kChunkRows; a block walks chunks c, c + grid, ...;
+//   * the ids of a chunk are produced once by the block's first lanes -- pair stream position,
+//     pair load, the Philox negative where the row is one -- and STAGED IN LDS (also written to
+//     idx_out); the ids of the NEXT chunk are computed while this chunk's row loads are in
+//     flight (two LDS buffers);
+//   * every wave then owns kRowsPerWave = 2 rows of the chunk: both rows' loads (NCH x 1 KiB
+//     each, 16 B per lane = whole 128-B lines) are issued before the first use, then the
+//     wave-shuffle norm and the stores.
+// MODE 0 = uniform negatives, MODE 1 = in-batch negatives.
+constexpr int kRowsPerWave = 2;
+constexpr int kChunkRows = kRowsPerWave * kWavesPerBlock;
+
+template <int NCH>
+struct RowRegs { float4 v[NCH]; };
+
+template <int NCH>
+__device__ __forceinline__ void row_issue(RowRegs<NCH> &R, const float *__restrict__ table, int64_t local_row,
+                                          int64_t row_stride, int nq, int lane) {
+  const float4 *src = reinterpret_cast<const float4 *>(table + local_row * row_stride);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int q = lane + kWave * c;
+    R.v[c] = (q < nq) ? load_row_chunk(src + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// same arithmetic as gather_one_row (normalize = 1), on rows already in registers
+template <int NCH>
+__device__ __forceinline__ void row_finish(RowRegs<NCH> &R, int F, float *__restrict__ dst, int64_t out_stride,
+                                           int lane) {
+  if (F & 3) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int j = 4 * (lane + kWave * c);
+      if (j + 1 >= F && j < F) R.v[c].y = 0.f;
+      if (j + 2 >= F && j < F) R.v[c].z = 0.f;
+      if (j + 3 >= F && j < F) R.v[c].w = 0.f;
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    ss += R.v[c].x * R.v[c].x + R.v[c].y * R.v[c].y + R.v[c].z * R.v[c].z + R.v[c].w * R.v[c].w;
+  ss = wave_sum(ss);
+  const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+  float4 *d = reinterpret_cast<float4 *>(dst);
+  const int oq = (int)(out_stride >> 2);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int q = lane + kWave * c;
+    if (q < oq) d[q] = make_float4(R.v[c].x * inv, R.v[c].y * inv, R.v[c].z * inv, R.v[c].w * inv);
+  }
+  for (int q = lane + kWave * NCH; q < oq; q += kWave) d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 template <int MODE, int NCH>
 __global__ void __launch_bounds__(kThreads)
 k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t seed,
                 uint64_t step_imm, const uint64_t *__restrict__ step_dev, int batch,
                 int64_t slot0, int64_t batch_global, const float *__restrict__ table,
                 int64_t n_rows, int64_t row_stride, int F, int32_t *__restrict__ idx_out,
-                int32_t *__restrict__ shift_out, float *__restrict__ x_out, int64_t out_stride) {
+                int32_t *__restrict__ shift_out, float *__restrict__ x_out, int64_t out_stride,
+                int n_steps, int64_t x_step_stride, int64_t idx_step_stride) {
   constexpr int RPT = (MODE == 0) ? 3 : 2;  // rows per triplet
-  const uint64_t step = step_dev ? *step_dev : step_imm;
+  __shared__ int32_t s_id[2][kChunkRows];
+  const uint64_t step0 = step_dev ? *step_dev : step_imm;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0)
-    *shift_out = sample_inbatch_shift(seed, step, batch);
-  const int64_t total_rows = (int64_t)RPT * batch;
-  for (int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave; r < total_rows;
-       r += (int64_t)gridDim.x * kWavesPerBlock) {
-    const int i = (int)(r / RPT), k = (int)(r - (int64_t)i * RPT);   // wave-uniform
-    const uint64_t slot = (uint64_t)(slot0 + i);
-    const uint64_t q = (step * (uint64_t)batch_global + slot) % (uint64_t)n_pairs;
-    const int32_t a = pairs[2 * q], p = pairs[2 * q + 1];
-    int32_t id = k == 0 ? a : p;
-    if (MODE == 0 && k == 2) {
-      int32_t n = 0;
-      if (lane == 0) n = sample_uniform_negative(seed, step, (uint32_t)slot, a, p, (uint32_t)n_rows);
-      id = __builtin_amdgcn_readfirstlane(n);
+  const int64_t rows_per_step = (int64_t)RPT * batch;
+  const int64_t total_rows = rows_per_step * n_steps;
+  const int64_t n_chunks = (total_rows + kChunkRows - 1) / kChunkRows;
+  const int nq = (F + 3) >> 2;
+
+  // ids of chunk c -> LDS buffer b (threads 0..kChunkRows-1), and to idx_out / shift_out
+  auto stage_ids = [&](int64_t c, int b) {
+    if (threadIdx.x < kChunkRows) {
+      const int64_t g = c * kChunkRows + threadIdx.x;
+      int32_t id = 0;
+      if (g < total_rows) {
+        const int s = (int)(g / rows_per_step);
+        const int r = (int)(g - (int64_t)s * rows_per_step);
+        const int i = r / RPT, k = r - i * RPT;
+        const uint64_t step = step0 + (uint64_t)s;
+        const uint64_t slot = (uint64_t)(slot0 + i);
+        const uint64_t q = (step * (uint64_t)batch_global + slot) % (uint64_t)n_pairs;
+        if (MODE == 0 && k == 2) {
+          id = sample_uniform_negative(seed, step, (uint32_t)slot, pairs[2 * q], pairs[2 * q + 1], (uint32_t)n_rows);
+        } else {
+          id = pairs[2 * q + (k ? 1 : 0)];
+        }
+        idx_out[(int64_t)s * idx_step_stride + r] = id;
+        if (MODE == 1 && r == 0) shift_out[s] = sample_inbatch_shift(seed, step, batch);
+      }
+      s_id[b][threadIdx.x] = id;
     }
-    if (lane == 0) idx_out[r] = id;
-    gather_one_row<NCH>(table, clamp_row(id, 0, n_rows, nullptr), row_stride, F, 1,
-                        x_out + r * out_stride, out_stride, nullptr, lane);
+  };
+
+  int64_t c = blockIdx.x;
+  if (c >= n_chunks) return;
+  stage_ids(c, 0);
+  __syncthreads();
+  int b = 0;
+  for (; c < n_chunks; c += gridDim.x, b ^= 1) {
+    const int64_t g0 = c * kChunkRows + wave * kRowsPerWave;
+    RowRegs<NCH> R[kRowsPerWave];
+#pragma unroll
+    for (int u = 0; u < kRowsPerWave; ++u) {
+      const int32_t id = __builtin_amdgcn_readfirstlane(s_id[b][wave * kRowsPerWave + u]);
+      if (g0 + u < total_rows) row_issue<NCH>(R[u], table, clamp_row(id, 0, n_rows, nullptr), row_stride, nq, lane);
+    }
+    const int64_t cn = c + gridDim.x;
+    if (cn < n_chunks) stage_ids(cn, b ^ 1);       // under the row loads in flight
+#pragma unroll
+    for (int u = 0; u < kRowsPerWave; ++u) {
+      const int64_t g = g0 + u;
+      if (g < total_rows) {
+        const int64_t s = g / rows_per_step, r = g - s * rows_per_step;
+        row_finish<NCH>(R[u], F, x_out + s * x_step_stride + r * out_stride, out_stride, lane);
+      }
+    }
+    __syncthreads();                               // ids of the next chunk are staged; this buffer is free
   }
 }
 
@@ -298,8 +388,13 @@ extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pair
                                   uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
                                   int64_t batch_global, const float *table, int64_t n_rows,
                                   int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
-                                  float *x_out, int64_t out_stride, cdml_stream_t stream) {
+                                  float *x_out, int64_t out_stride, int n_steps, int64_t x_step_stride,
+                                  int64_t idx_step_stride, cdml_stream_t stream) {
   CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "sample_gather: mode must be 0 or 1");
+  CDML_REQUIRE(n_steps >= 1 && n_steps <= 64, CDML_E_BADARG, "sample_gather: n_steps must be in [1, 64]");
+  CDML_REQUIRE(n_steps == 1 || (x_step_stride >= (int64_t)batch * (mode == 0 ? 3 : 2) * out_stride &&
+                                (x_step_stride & 3) == 0 && idx_step_stride >= (int64_t)batch * (mode == 0 ? 3 : 2)),
+               CDML_E_BADARG, "sample_gather: per-step strides too small for the batch");
   CDML_REQUIRE(pairs && table && idx_out && x_out && n_pairs > 0 && slot0 >= 0, CDML_E_BADARG,
                "sample_gather: bad argument");
   CDML_REQUIRE(n_rows >= 3 && n_rows <= 0x7FFFFFFFll, CDML_E_BADARG,
@@ -310,12 +405,13 @@ extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pair
                "sample_gather: batch_global < slot0 + batch");
   int rc = check_gather_layout("sample_gather", table, row_stride, F, x_out, out_stride);
   if (rc) return rc;
-  const int grid = grid_for((int64_t)batch * (mode == 0 ? 3 : 2), kWavesPerBlock);
+  const int grid = grid_for((int64_t)batch * (mode == 0 ? 3 : 2) * n_steps, kChunkRows);
   const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
 #define CDML_LAUNCH_SG(M, N)                                                                      \
   hipLaunchKernelGGL((k_sample_gather<M, N>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
                      pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global, table,     \
-                     n_rows, row_stride, F, idx_out, shift_out, x_out, out_stride)
+                     n_rows, row_stride, F, idx_out, shift_out, x_out, out_stride, n_steps,       \
+                     x_step_stride, idx_step_stride)
   if (mode == 0) {
     if (nch <= 2) CDML_LAUNCH_SG(0, 2);
     else if (nch <= 6) CDML_LAUNCH_SG(0, 6);

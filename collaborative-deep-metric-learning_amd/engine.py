@@ -152,14 +152,21 @@ class TowerWorkspace:
             self.bw = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
-def tower_forward(p, ws, n_rows=None):
+def tower_forward(p, ws, n_rows=None, normalize=True):
     """x_hat (already l2-normalised, models.py:58) -> h1 -> z -> e.
-    models.py:59-61."""
+    models.py:59-61.  ``normalize=False`` stops at z: the training step's fused tail
+    (ops.vnet_tail) normalises, takes the loss and starts the backward pass in one launch.
+
+    The contractions run over round_up(F, 32) and round_up(H, 32), not over the padded leading
+    dimensions (columns F.. of x_hat and H.. of h1 are zero): 47 instead of 48 K-tiles for
+    F = 1500, 157 instead of 160 for H = 5000."""
     L = p.layout
     R = ws.R if n_rows is None else n_rows
-    ops.fc_lrelu_fwd(ws.x_hat, p.W1, p.b1, ws.h1, R, L.Fp, L.Hp)
-    ops.fc_lrelu_fwd(ws.h1, p.W2, p.b2, ws.z, R, L.Hp, L.Dp)
-    ops.l2norm_fwd(ws.z[:R], L.Dp, ws.e)
+    ops.fc_lrelu_fwd(ws.x_hat, p.W1, p.b1, ws.h1, R, round_up(L.F, 32), L.Hp)
+    ops.fc_lrelu_fwd(ws.h1, p.W2, p.b2, ws.z, R, round_up(L.H, 32), L.Dp)
+    ws.tail_done = False
+    if normalize:
+        ops.l2norm_fwd(ws.z[:R], L.Dp, ws.e)
     return ws.e
 
 
@@ -175,7 +182,8 @@ def tower_backward(p, ws, n_rows=None, after_w1=None, w1_chunks=1, after_w1_chun
     c+1 and only the last, smaller one is left for the dW2 GEMM to cover."""
     L = p.layout
     R = ws.R if n_rows is None else n_rows
-    ops.l2norm_bwd(ws.z[:R], ws.de[:R], L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
+    if not getattr(ws, "tail_done", False):          # the fused tail has already produced dz2
+        ops.l2norm_bwd(ws.z[:R], ws.de[:R], L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
     ops.fc_bwd_data(ws.dz2, p.W2, ws.h1, ws.dz1, R, L.Hp, L.Dp)
     rows = L.Fp // w1_chunks if w1_chunks > 1 else 0
     if after_w1_chunk is not None and w1_chunks > 1 and rows % 128 == 0 and rows * w1_chunks == L.Fp:

@@ -93,12 +93,15 @@ def refresh_weights(p, ws):
     ops.cast_f32_bf16(p.W2, ws.W2, L.Hp, L.Dp)
 
 
-def tower_forward(p, ws):
-    """x_hat (bf16, l2-normalised) -> h1 (bf16) -> z (fp32) -> e (fp32).  models.py:59-61."""
+def tower_forward(p, ws, normalize=True):
+    """x_hat (bf16, l2-normalised) -> h1 (bf16) -> z (fp32) -> e (fp32).  models.py:59-61.
+    ``normalize=False``: stop at z (the fused tail of the training step takes over)."""
     L, R = p.layout, ws.R
     ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_BF16, ws.x_hat, ws.W1T, ws.h1, R, L.Hp, L.Fp, bias=p.b1)
     ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_F32, ws.h1, ws.W2T, ws.z, R, L.Dp, L.Hp, bias=p.b2, workspace=ws.gemm_ws)
-    ops.l2norm_fwd(ws.z, L.Dp, ws.e)
+    ws.tail_done = False
+    if normalize:
+        ops.l2norm_fwd(ws.z, L.Dp, ws.e)
     return ws.e
 
 
@@ -109,8 +112,9 @@ def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
     with ``w1_chunks`` > 1 dW1 comes in row blocks of W1 and ``after_w1_chunk(lo, hi)`` fires
     after each (flat-gradient ranges; the last one ends after db1), as in engine.tower_backward."""
     L, R = p.layout, ws.R
-    ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
-    ops.cast_f32_bf16(ws.dz2, ws.dz2_bf, R, L.Dp)
+    if not getattr(ws, "tail_done", False):          # the fused tail writes dz2 and its bf16 copy
+        ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
+        ops.cast_f32_bf16(ws.dz2, ws.dz2_bf, R, L.Dp)
     ops.gemm_bf16_nt(ops.BE_MASK_BF16, ws.dz2_bf, ws.W2, ws.dz1, R, L.Hp, L.Dp, aux=ws.h1)
     rows = L.Fp // w1_chunks if w1_chunks > 1 else 0
     chunked = (after_w1_chunk is not None and w1_chunks > 1 and rows * w1_chunks == L.Fp and ws.tn1

@@ -78,14 +78,23 @@ def gather_rows(table, row0, idx, feature_size, x_out, normalize=True, inv_norm_
 
 
 def sample_gather(mode, pairs, seed, step, batch, table, feature_size, idx_out, x_out,
-                  shift_out=None, slot0=0, batch_global=None, step_dev=None):
+                  shift_out=None, slot0=0, batch_global=None, step_dev=None, n_steps=1):
+    """n_steps > 1: x_out is [n_steps, rows, stride], idx_out [n_steps, rows], shift_out [n_steps]
+    (steps step, step+1, ... in one launch)."""
     bg = batch if batch_global is None else batch_global
     tp, tld = _mat(table)
-    xp, xld = _mat(x_out)
+    if n_steps > 1:
+        if x_out.dim() != 3 or idx_out.dim() != 2 or x_out.shape[0] != n_steps or idx_out.shape[0] != n_steps:
+            raise ValueError("n_steps > 1 needs x_out [n_steps, rows, stride] and idx_out [n_steps, rows]")
+        xp, xld = _mat(x_out[0])
+        xss, iss = x_out.stride(0), idx_out.stride(0)
+    else:
+        xp, xld = _mat(x_out)
+        xss = iss = 0
     call("cdml_sample_gather", mode, _p(pairs, torch.int32), pairs.shape[0], seed,
          0 if step is None else step, _p(step_dev, torch.int64), batch, slot0, bg, tp,
          table.shape[0], tld, feature_size, _p(idx_out, torch.int32), _p(shift_out, torch.int32),
-         xp, xld, _stream())
+         xp, xld, n_steps, xss, iss, _stream())
     return x_out
 
 
@@ -153,6 +162,31 @@ def triplet_hinge_inbatch(e, rows, shift, B, D, margin, pos, neg, hinge, valid=N
     dep, deld = (C.c_void_p(0), 0) if de is None else _mat(de)
     call("cdml_triplet_hinge_inbatch", ep, eld, _p(rows, torch.int32), _p(shift, torch.int32), B, D,
          margin, _p(pos), _p(neg), _p(hinge), _p(valid, torch.uint8), _p(stats), dep, deld, _stream())
+
+
+TICKET_WORDS = 80     # CDML_TICKET_WORDS (include/cdml.h)
+
+
+def new_tickets(device):
+    """Zeroed ticket words for the kernels whose last block folds a grid-wide reduction."""
+    return torch.zeros(TICKET_WORDS, dtype=torch.int32, device=device)
+
+
+def vnet_tail_workspace_floats(B, D):
+    return int(load_library().cdml_vnet_tail_workspace(B, D)) // 4
+
+
+def vnet_tail(mode, z, rows, shift, B, D, margin, e, pos, neg, hinge, dz2, valid=None, stats=None,
+              tickets=None, dz2_bf16=None, var_ws=None, alpha=LRELU_ALPHA):
+    """l2norm -> hinge loss -> its gradient -> l2norm backward -> lrelu' in one launch
+    (mode 0: rows a,p,n per triplet; 1: in-batch negatives)."""
+    zp, zld = _mat(z)
+    ep, eld = _mat(e)
+    dp, dld = _mat(dz2)
+    bp, bld = (C.c_void_p(0), 0) if dz2_bf16 is None else _mat16(dz2_bf16)
+    call("cdml_vnet_tail", mode, zp, zld, _p(rows, torch.int32), _p(shift, torch.int32), B, D, margin, alpha,
+         ep, eld, _p(pos), _p(neg), _p(hinge), _p(valid, torch.uint8), dp, dld, bp, bld, _p(stats), _p(var_ws),
+         _p(tickets, torch.int32), _stream())
 
 
 def semihard_select(S, e, rows, B, D, sqn_scratch, neg_row_out):
@@ -335,9 +369,12 @@ def gather_rows_f16(table, row0, idx, feature_size, x_out, oob_flag=None):
 
 
 # ------------------------------------------------------------- optimizers -----
-def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, t_dev=None):
+def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, t_dev=None,
+              advance_tickets=None):
+    """advance_tickets (ops.new_tickets): also do global_step += 1 on *t_dev in the same launch."""
     call("cdml_adam_step", _p(w), _p(g), _p(m), _p(v), w.numel(), lr, _p(lr_dev), beta1, beta2, eps,
-         0 if t is None else t, _p(t_dev, torch.int64), _stream())
+         0 if t is None else t, _p(t_dev, torch.int64), 0 if advance_tickets is None else 1,
+         _p(advance_tickets, torch.int32), _stream())
 
 
 def table_adam_rows(table, row0, F, idx, grad_xhat, m_table, v_table, head, nxt, lr, t, beta1=0.9, beta2=0.999,

@@ -42,12 +42,15 @@ class TrainStep:
                  base_learning_rate=0.01, learning_rate_decay_examples=1000000,
                  learning_rate_decay=0.96, seed=1234, weight_seed=42, device="cuda:0",
                  exchange=None, grad_sync=None, slot0=0, batch_global=None, use_graph=False,
-                 prefetch=True, precision="f32", train_table=False):
+                 prefetch=True, precision="f32", train_table=False, gather_ahead=2):
         """table: FeatureTable (whole catalogue, or this rank's shard when
         ``exchange`` is given); pairs: int32 [P,2] device tensor; ``exchange`` /
         ``grad_sync``: the multi-GPU hooks of cdml_amd.dist (None on one GPU).
         ``train_table``: also train the catalogue rows (lazy Adam, states stored beside the
-        shard; build-defined -- the reference keeps the features frozen, train.py:265)."""
+        shard; build-defined -- the reference keeps the features frozen, train.py:265).
+        ``gather_ahead``: steps fetched per launch of the fused sampler+gather (single-GPU fp32
+        path): the sampler is counter-based, so one launch samples and gathers the rows of
+        this step and the next gather_ahead-1 into their own buffers."""
         if mode not in _MODES:
             raise ValueError("mode must be 'uniform', 'inbatch' or 'semihard'")
         if optimizer not in ("adam", "lars"):
@@ -102,7 +105,10 @@ class TrainStep:
         self.neg = torch.zeros(self.B, dtype=f32, device=dev)
         self.hinge = torch.zeros(self.B, dtype=f32, device=dev)
         self.valid = torch.ones(self.B, dtype=torch.uint8, device=dev)
-        self.stats = torch.zeros(4, dtype=f32, device=dev)          # loss, mean pos, mean neg, active
+        self.stats = torch.zeros(8, dtype=f32, device=dev)   # loss, mean pos, mean neg, active, variance
+        self.tail_tickets = ops.new_tickets(dev)             # fused tail: last block writes the stats
+        self.adam_tickets = ops.new_tickets(dev)             # Adam: last block advances the step counter
+        self.var_ws = None                                   # set by enable_variance()
         if mode == "semihard":
             if self.B % 32:
                 raise ValueError("semi-hard mining needs a batch that is a multiple of 32")
@@ -134,7 +140,19 @@ class TrainStep:
             if grad_sync is not None and exchange is None:
                 raise ValueError("train_table with grad_sync needs a row-sharded table (exchange): "
                                  "replicated trainable tables would diverge between ranks")
-        self._graph = None
+        # several steps' rows per gather launch (the frozen catalogue cannot change in between;
+        # a trainable one can, and the sharded path has its own prefetcher)
+        self.gather_ahead = max(1, int(gather_ahead))
+        if self.bf16 or exchange is not None or self.train_table:
+            self.gather_ahead = 1
+        self._ahead_base = None
+        if self.gather_ahead > 1:
+            K = self.gather_ahead
+            self._xa = torch.zeros((K,) + tuple(self.ws.x_hat.shape), dtype=f32, device=dev)
+            self._idxa = torch.zeros((K, self.R), dtype=i32, device=dev)
+            self._shifta = torch.zeros(K, dtype=i32, device=dev)
+            self._select_ahead(0)
+        self._graphs = {}
         self._warmed = False
         self.use_graph = bool(use_graph) and exchange is None and grad_sync is None
         if use_graph and not self.use_graph:
@@ -163,9 +181,30 @@ class TrainStep:
                                slot0=self.slot0, batch_global=self.batch_global)
         self.exchange.gather(self.table, self._idx[b], self._x[b])
 
+    def _ahead_offset(self):
+        """Position of the current step inside the block of steps the last gather launch
+        fetched; 0 = this step launches the gather."""
+        t, b = self.global_step, self._ahead_base
+        if self.gather_ahead == 1 or b is None or not (b <= t < b + self.gather_ahead):
+            return 0
+        return t - b
+
+    def _select_ahead(self, off):
+        self.ws.x_hat, self.idx, self.shift = self._xa[off], self._idxa[off], self._shifta[off:off + 1]
+
     def fetch(self):
         """Sampler + gather (+ input l2norm): fills ws.x_hat and self.idx."""
         m = _MODES[self.mode]
+        if self.gather_ahead > 1:
+            off = self._ahead_offset()
+            if off == 0:
+                ops.sample_gather(m, self.pairs, self.seed, None, self.B, self.table.data,
+                                  self.table.feature_size, self._idxa, self._xa, shift_out=self._shifta,
+                                  slot0=self.slot0, batch_global=self.batch_global, step_dev=self.step_dev,
+                                  n_steps=self.gather_ahead)
+                self._ahead_base = self.global_step
+            self._select_ahead(off)
+            return
         if self.prefetch is not None:
             t, b = self.global_step, self.global_step % 2
             if t == 0 or self._filled != t:
@@ -199,12 +238,35 @@ class TrainStep:
                                    step_dev=self.step_dev)
             self.exchange.gather(self.table, self.idx, self.ws.x_hat)
 
-    def forward_loss(self, with_grad=True):
-        if self.bf16:
-            engine_bf16.tower_forward(self.params, self.ws)
-        else:
-            engine.tower_forward(self.params, self.ws)
+    def enable_variance(self, on=True):
+        """Also compute build_graph's ``variance`` summary (calc_var, train.py:67-71,151) each
+        step: stats[4]."""
         L = self.layout
+        self.var_ws = (torch.zeros(ops.vnet_tail_workspace_floats(self.B, L.Dp), dtype=torch.float32,
+                                   device=self.device) if on else None)
+        self._graphs = {}
+
+    def variance(self):
+        if self.var_ws is None:
+            raise RuntimeError("call enable_variance() before the step")
+        return float(self.stats[4].item())
+
+    def forward_loss(self, with_grad=True):
+        # uniform / in-batch negatives: one launch normalises z, takes the loss and starts the
+        # backward pass (semi-hard mining needs every embedded row first: separate kernels)
+        fused = with_grad and self.mode != "semihard"
+        if self.bf16:
+            engine_bf16.tower_forward(self.params, self.ws, normalize=not fused)
+        else:
+            engine.tower_forward(self.params, self.ws, normalize=not fused)
+        L = self.layout
+        if fused:
+            ops.vnet_tail(0 if self.mode == "uniform" else 1, self.ws.z, self.idx, self.shift, self.B, L.Dp,
+                          self.margin, self.ws.e, self.pos, self.neg, self.hinge, self.ws.dz2, valid=self.valid,
+                          stats=self.stats, tickets=self.tail_tickets,
+                          dz2_bf16=self.ws.dz2_bf if self.bf16 else None, var_ws=self.var_ws)
+            self.ws.tail_done = True
+            return
         de = self.ws.de if with_grad else None
         if self.mode == "uniform":
             ops.triplet_hinge(self.ws.e, self.B, L.Dp, self.margin, self.pos, self.neg, self.hinge,
@@ -249,15 +311,18 @@ class TrainStep:
     def apply_gradients(self):
         p = self.params
         if self.optimizer == "adam":
+            # the step counter advances inside the same launch unless something after it (the
+            # bf16 weight refresh is fine, LARS is not on this branch) still reads it
             ops.adam_step(p.flat, p.grad, self.m, self.v, 0.0, 1, lr_dev=self.lr_dev,
-                          t_dev=self.step_dev)
+                          t_dev=self.step_dev, advance_tickets=self.adam_tickets)
         else:
             for off, n in p.segments():       # LARS trust ratio is per variable
                 ops.lars_step(p.flat[off:off + n], p.grad[off:off + n], self.acc[off:off + n],
                               0.0, self.lars_scratch, lr_dev=self.lr_dev)
         if self.bf16:
             engine_bf16.refresh_weights(p, self.ws)
-        ops.step_advance(self.step_dev)
+        if self.optimizer != "adam":
+            ops.step_advance(self.step_dev)
 
     def _enqueue(self):
         self.fetch()
@@ -294,9 +359,14 @@ class TrainStep:
             self.lr_dev.fill_(lr)
             self._lr_host = lr
         if self.use_graph and self._warmed:              # the first step of a process runs eagerly
-            if self._graph is None:                      # (it loads the kernels), also after a resume
-                self._capture()
-            self._graph.replay()
+            off = self._ahead_offset()                   # (it loads the kernels), also after a resume
+            if off not in self._graphs:                  # one graph per position in the gather block
+                self._graphs[off] = self._capture()      # (capturing records, it does not run)
+            if self.gather_ahead > 1:
+                if off == 0:
+                    self._ahead_base = self.global_step
+                self._select_ahead(off)
+            self._graphs[off].replay()
         else:
             self._enqueue()
             self._warmed = True
@@ -311,7 +381,7 @@ class TrainStep:
             with torch.cuda.graph(g, stream=side):
                 self._enqueue()
         torch.cuda.current_stream(self.device).wait_stream(side)
-        self._graph = g
+        return g
 
     def loss(self):
         """Host value of the last step's mean hinge loss (synchronises)."""
@@ -351,7 +421,8 @@ class TrainStep:
         self.global_step = int(state["global_step"])
         self.step_dev.fill_(self.global_step)
         self.seed = int(state["seed"])
-        self._graph = None
+        self._graphs = {}
+        self._ahead_base = None
         self._filled = -1
 
 

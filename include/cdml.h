@@ -102,17 +102,23 @@ int cdml_gather_rows(const float *table, int64_t row0, int64_t n_rows,
                      float *inv_norm_out, int32_t *oob_flag,
                      cdml_stream_t stream);
 
-/* Persistent fused sampler+gather: samples slots [slot0,slot0+batch) exactly as
- * cdml_sample_uniform (mode 0) / cdml_sample_inbatch (mode 1), stages each
- * triplet's ids in LDS and gathers + normalises its rows in the same launch.
- * idx_out: int32[batch][3] (mode 0) or int32[2*batch] (mode 1); x_out has
- * 3*batch (mode 0) or 2*batch (mode 1) rows. */
+/* Persistent fused sampler+gather for n_steps consecutive training steps (step, step+1, ...;
+ * the sampler is counter-based, so later steps' triplets are known now and one launch can
+ * fetch several steps' rows): samples slots [slot0,slot0+batch) of every step exactly as
+ * cdml_sample_uniform (mode 0) / cdml_sample_inbatch (mode 1).  A block walks chunks of 8
+ * rows; the chunk's ids are computed once, staged in LDS (and written to idx_out) while the
+ * previous chunk's row loads are in flight; each wave gathers + l2-normalises two rows at a
+ * time with whole-128-B-line loads.  Step s writes idx_out + s*idx_step_stride (int32[batch][3]
+ * in mode 0, int32[2*batch] in mode 1), shift_out[s] (mode 1) and x_out + s*x_step_stride
+ * (3*batch or 2*batch rows of out_stride floats).  n_steps = 1: the strides are unused. */
 int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pairs,
                        uint64_t seed, uint64_t step, const uint64_t *step_dev,
                        int batch, int64_t slot0, int64_t batch_global,
                        const float *table, int64_t n_rows, int64_t row_stride,
                        int F, int32_t *idx_out, int32_t *shift_out,
-                       float *x_out, int64_t out_stride, cdml_stream_t stream);
+                       float *x_out, int64_t out_stride, int n_steps,
+                       int64_t x_step_stride, int64_t idx_step_stride,
+                       cdml_stream_t stream);
 
 /* ---- tower pieces: VNet.create_model (models.py:46-62) ----------------------
  * y = x * rsqrt(max(sum(x^2), 1e-12)) per row (tf.nn.l2_normalize, models.py:58,
@@ -171,6 +177,28 @@ int cdml_triplet_hinge_inbatch(const float *e, int64_t lde, const int32_t *rows,
                                float *pos, float *neg, float *hinge,
                                uint8_t *valid_out, float *stats, float *de,
                                int64_t ldde, cdml_stream_t stream);
+
+/* Fused tail of the tower for the training step: tf.nn.l2_normalize of the output layer
+ * (models.py:61) -> HingeLoss.calculate_loss (losses.py:32-38) -> d loss / d e -> l2-normalise
+ * backward -> leaky-relu' of the output layer (train.py:141), one launch, one wave per triplet
+ * slot (= cdml_l2norm_fwd + cdml_triplet_hinge{,_inbatch} + cdml_l2norm_bwd, same bits).
+ *   mode 0: z[3B][ldz] rows a,p,n per triplet (rows/shift unused).
+ *   mode 1: z[2B][ldz] rows a_i,p_i, in-batch negatives as cdml_triplet_hinge_inbatch.
+ * Outputs: e (unit rows, "l2_norm"), pos/neg/hinge float[B], valid_out uint8[B] (mode 1,
+ * nullable), dz2 = d loss / d (pre-activation of the output layer), optionally also as bf16
+ * (dz2_bf16 nullable, round-to-nearest-even).  stats (nullable) float[8]: [0..3] as
+ * cdml_triplet_hinge, written by the last block to finish -- needs tickets =
+ * uint32[CDML_TICKET_WORDS], zero before the first call (the kernel leaves them zero).
+ * var_ws (nullable, cdml_vnet_tail_workspace bytes): stats[4] = calc_var (train.py:67-71) of
+ * the [B,3,D] triplet tensor: mean over everything of (t - mean over [batch, role])^2. */
+#define CDML_TICKET_WORDS 80
+size_t cdml_vnet_tail_workspace(int B, int D);
+int cdml_vnet_tail(int mode, const float *z, int64_t ldz, const int32_t *rows,
+                   const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
+                   float *e, int64_t lde, float *pos, float *neg, float *hinge,
+                   uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_bf16,
+                   int64_t ldbf, float *stats, float *var_ws, uint32_t *tickets,
+                   cdml_stream_t stream);
 
 /* ---- semi-hard negative mining (BASELINE config 2; build-defined, no reference
  * counterpart -- spec: oracle/tower.py semihard_select) -----------------------
@@ -322,11 +350,14 @@ int cdml_lrelu_bwd(const float *g, int64_t ldg, const float *y, int64_t ldy, int
  * lr_dev (nullable) overrides lr, and *t_dev (nullable) is ADDED to t, both read
  * from device memory at execution time (t_dev = the sampler's 0-based step
  * counter with t = 1), so a captured hipGraph follows the step counter and the
- * staircase learning-rate schedule (train.py:108-113) without re-capture. */
+ * staircase learning-rate schedule (train.py:108-113) without re-capture.
+ * advance_step != 0: the last block to finish stores *t_dev + 1 -- the global_step
+ * increment of apply_gradients (train.py:146) without a launch of its own; needs t_dev and
+ * tickets = uint32[CDML_TICKET_WORDS], zero before the first call (left zero). */
 int cdml_adam_step(float *w, const float *g, float *m, float *v, int64_t n,
                    float lr, const float *lr_dev, float beta1, float beta2,
-                   float eps, int64_t t, const uint64_t *t_dev,
-                   cdml_stream_t stream);
+                   float eps, int64_t t, uint64_t *t_dev, int advance_step,
+                   uint32_t *tickets, cdml_stream_t stream);
 
 /* Trainable catalogue rows (north_star: "the catalogue feature table and its Adam states
  * shard row-wise"; the reference keeps the features frozen, train.py:265, so this is

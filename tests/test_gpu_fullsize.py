@@ -218,14 +218,24 @@ def _config3_worker(port, q):
         ts2 = train.TrainStep(table, pairs, B, mode="inbatch", device=dev)
         ts2.table = engine.FeatureTable(table.data, F, row0=0, n_rows_global=per)   # local ids
         ts2.pairs = pairs - row0
-        for _ in range(2):
-            ts.step(); ts2.step()
-        torch.cuda.synchronize()
         msgs = []
+        for it in range(2):
+            ts.step(); ts2.step()
+            if it == 0:
+                # the data-parallel step produces dW1 in two row blocks (other split-K order): the
+                # gradient agrees to fp32 summation noise, not bit for bit
+                gd = float((ts.params.grad - ts2.params.grad).abs().max())
+                if gd > 1e-6:
+                    msgs.append("gradients differ: %g" % gd)
+                if not torch.equal(ts.ws.x_hat, ts2.ws.x_hat):
+                    msgs.append("exchanged rows differ from directly gathered rows")
+        torch.cuda.synchronize()
         if not torch.equal(ts.idx - row0, ts2.idx):
             msgs.append("ids differ")
-        if not torch.equal(ts.params.flat, ts2.params.flat):
-            msgs.append("weights differ: %g" % float((ts.params.flat - ts2.params.flat).abs().max()))
+        # Adam turns gradient noise near g = 0 into lr-sized update noise (iid catalogue): loose bar
+        wd = (ts.params.flat - ts2.params.flat).abs()
+        if float(wd.max()) > 2.5e-2 or float((wd > 1e-4).float().mean()) > 0.02:
+            msgs.append("weights differ: max %g" % float(wd.max()))
         rows = ts.idx.cpu().numpy()
         want_rows = osampler.device_inbatch(pairs_np, 1234, 1, B)[0]
         if not np.array_equal(rows, want_rows):

@@ -335,7 +335,99 @@ def test_hinge_inbatch_vs_oracle(cd):
     assert n_invalid > 0
 
 
+@pytest.mark.parametrize("mode,B,D", [("uniform", 70, 256), ("inbatch", 64, 256), ("uniform", 33, 64),
+                                      ("inbatch", 4096, 256), ("uniform", 4096, 256), ("inbatch", 50, 512),
+                                      ("uniform", 9, 1024)])
+def test_vnet_tail_fused_equals_separate_kernels_and_oracle(cd, mode, B, D):
+    """The fused tail (l2norm -> hinge -> dE -> l2norm backward -> lrelu') gives the bits of the
+    separate kernels, the oracle's values (fp64, 1e-5), the statistics and -- on request --
+    build_graph's variance summary (train.py:67-71,151)."""
+    rng = np.random.RandomState(B + D)
+    rpt = 3 if mode == "uniform" else 2
+    R = rpt * B
+    z = (rng.randn(R, D) * 0.3 + 0.05).astype(np.float32)
+    z[1] *= 1e-8                                            # a row below the 1e-12 clamp
+    dz = dt(z, cd.dev)
+    n_vid = 40 if B < 100 else 3000
+    pairs = osynth.cowatch_pairs(n_vid, max(30, B // 8), 2)
+    step = 1
+    f = lambda *s: torch.full(s, -7.0, device=cd.dev)
+    if mode == "uniform":
+        rows = shift = None
+        tri = np.arange(R).reshape(B, 3)
+        valid = np.ones(B, bool)
+    else:
+        rows_np, tri, valid, sh = osampler.device_inbatch(pairs, 3, step, B)
+        valid = valid.astype(bool)
+        rows, shift = dt(rows_np, cd.dev, torch.int32), dt([sh], cd.dev, torch.int32)
+    # separate kernels
+    e0, de0, dz0 = f(R, D), f(R, D), f(R, D)
+    p0, n0, h0, st0 = f(B), f(B), f(B), f(4)
+    cd.ops.l2norm_fwd(dz, D, e0)
+    if mode == "uniform":
+        cd.ops.triplet_hinge(e0, B, D, 0.8, p0, n0, h0, st0, de0)
+    else:
+        cd.ops.triplet_hinge_inbatch(e0, rows, shift, B, D, 0.8, p0, n0, h0, None, st0, de0)
+    cd.ops.l2norm_bwd(dz, de0, D, dz0, lrelu_alpha=0.2)
+    # fused, twice (the tickets must be clean again after the first launch)
+    tickets = cd.ops.new_tickets(cd.dev)
+    var_ws = torch.zeros(cd.ops.vnet_tail_workspace_floats(B, D), device=cd.dev)
+    for rep in range(2):
+        e1, dz1 = f(R, D), f(R, D)
+        p1, n1, h1, st1 = f(B), f(B), f(B), f(8)
+        v1 = torch.full((B,), 9, dtype=torch.uint8, device=cd.dev)
+        bf = torch.zeros((R, D), dtype=torch.bfloat16, device=cd.dev)
+        cd.ops.vnet_tail(0 if mode == "uniform" else 1, dz, rows, shift, B, D, 0.8, e1, p1, n1, h1, dz1, valid=v1,
+                         stats=st1, tickets=tickets, dz2_bf16=bf, var_ws=var_ws if rep else None)
+        torch.cuda.synchronize()
+        assert torch.equal(e1, e0) and torch.equal(dz1, dz0)
+        assert torch.equal(p1, p0) and torch.equal(n1, n0) and torch.equal(h1, h0)
+        assert torch.equal(bf, dz0.bfloat16())                               # round-to-nearest-even copy
+        np.testing.assert_allclose(st1[:4].cpu().numpy(), st0.cpu().numpy(), rtol=2e-6, atol=1e-7)
+        assert int(tickets.abs().sum().item()) == 0
+        if mode == "inbatch":
+            np.testing.assert_array_equal(v1.cpu().numpy().astype(bool), valid)
+    # oracle (fp64 on the fp32 inputs)
+    e64, inv = otower.l2_normalize(z.astype(np.float64), np.float64)
+    np.testing.assert_allclose(e1.cpu().numpy(), e64, atol=TOL)
+    w = otower.hinge_loss_indexed(e64, tri, valid, 0.8, np.float64)
+    np.testing.assert_allclose(st1[0].item(), w["hinge_loss"], atol=TOL)
+    np.testing.assert_allclose(h1.cpu().numpy(), w["hinge_dist"], atol=TOL)
+    t = w["pos_dist"] - w["neg_dist"] + 0.8
+    if np.abs(t).min() > 1e-5:                                               # nobody sits on the hinge
+        dE = otower.hinge_loss_indexed_backward(e64, tri, valid, 0.8, np.float64)
+        want = otower.leaky_relu_backward(z.astype(np.float64),
+                                          otower.l2_normalize_backward(z.astype(np.float64), inv, dE, np.float64))
+        scale = max(np.abs(want).max(), 1e-30)
+        assert np.abs(dz1.cpu().numpy() - want).max() < 1e-5 * max(scale, 1.0)
+    var = otower.calc_var(e64[tri], np.float64)
+    np.testing.assert_allclose(st1[4].item(), var, rtol=1e-5, atol=1e-8)
+
+
 # ---------------------------------------------------------------- optimizers --
+def test_adam_advances_step_counter_in_the_same_launch(cd):
+    """apply_gradients(global_step=...) (train.py:146): with advance_tickets the last block of
+    the Adam launch stores step + 1; every block still used the OLD step for the bias correction."""
+    rng = np.random.RandomState(5)
+    n = 9 * 1000 * 1000                                    # > 2048 blocks x 256 x 4: all grid blocks busy
+    w0 = torch.as_tensor(rng.randn(n).astype(np.float32)).to(cd.dev)
+    g = torch.as_tensor((rng.randn(n) * 1e-3).astype(np.float32)).to(cd.dev)
+    tick = cd.ops.new_tickets(cd.dev)
+    res = []
+    for adv in (False, True):
+        w, m, v = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0)
+        t_dev = torch.full((1,), 6, dtype=torch.int64, device=cd.dev)
+        for _ in range(3):
+            cd.ops.adam_step(w, g, m, v, 0.01, 1, t_dev=t_dev, advance_tickets=tick if adv else None)
+            if not adv:
+                cd.ops.step_advance(t_dev)
+        torch.cuda.synchronize()
+        assert int(t_dev.item()) == 9 and int(tick.abs().sum().item()) == 0
+        res.append((w, m, v))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_adam_vs_oracle(cd):
     rng = np.random.RandomState(0)
     n = 1003
