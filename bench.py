@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
-"""Headline benchmark: triplets/s of the full training step (sample + gather +
-tower fwd + hinge loss + backward + Adam) on synthetic imitation_data-shaped
-input, BASELINE.json config 1 at N=1:
-
-    1 x MI355X, 1M videos x 1500-d fp32 in HBM, 5000 hidden, 256-d embedding,
-    batch 4096 triplets, in-batch negatives, margin 0.8, Adam.
+"""Headline benchmark: triplets/s of the full training step (sample + gather + tower fwd +
+hinge loss + backward + Adam) on synthetic imitation_data-shaped input.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling --
-every rank keeps batch 4096; the catalogue becomes config 3's 10M rows,
-row-sharded, with an RCCL all-to-all of sampled rows and an all-reduce of the
-gradients per step.
+Workloads (BASELINE.json `configs`, 0-based):
+  N = 1 (default)   config 1: 1 M videos x 1500-d fp32 in HBM, 5000 hidden, 256-d embedding,
+                    batch 4096 triplets, in-batch negatives, margin 0.8, Adam.
+  N > 1             config 3: 10 M videos row-sharded over the ranks, batch 8192 triplets per
+                    GPU (65 536 global at N = 8), RCCL all-to-all of sampled rows + all-reduce of
+                    the gradients.  Weak scaling (per-GPU work fixed).
+  --precision bf16  config 4: fp16 table + bf16 MFMA, uniform (global) negatives, batch 8192 per
+                    GPU on the 10 M catalogue; --graph replays the step from a hipGraph.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the
-1500x5000 projection GEMMs, MFMA-bound), timed live with events on the launch
-stream over the timed steps; `gather` reports the HBM side the metric also
-names; `cpu_baseline` is the CPU oracle (numpy restatement of the reference
-step) timed on this box's host cores on a bounded sample.
+Prints ONE JSON line (rank 0).  Beside the contract's fields:
+  roofline       the dominant kernel (weight-gradient GEMM), timed live with events on the
+                 launch stream inside the timed region; `traffic` from the committed PMC summary
+  gather         the HBM-bound fused sampler+gather: 10 launches per event pair (a pair around
+                 one 20-40 us launch costs 10-25 % of it), same arguments as the timed steps
+  cpu_baseline   BASELINE.md section 4: the CPU restatement of the reference step (oracle/
+                 tower_torch.py) on config 0's 10k x 1500 table, B = 128 and 1024, 1 and all
+                 threads, fetch / train split, on this box's host cores
+  like_for_like  (N = 1) the per-GPU workload of the N > 1 line on ONE GPU holding the whole
+                 10 M-row catalogue, so that 8-vs-1 compares one workload
+  data_learnable (N = 1) the same step on a learnable catalogue (co-watched videos share a
+                 cluster): the iid imitation_data features collapse the embeddings
+  comm           (N > 1) what the compute stream waits for: all-reduce and row exchange
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -33,13 +42,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F, H, D = 1500, 5000, 256
-BATCH = 4096
 MARGIN = 0.8
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: matrix FP32 (spec)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: BF16 MFMA dense (spec)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
-def synth_pairs(n_videos, n_users, seed):
+def synth_pairs(n_videos, n_users, seed, lo=0):
     """imitation_data.py:56-85-shaped co-watch pairs (own generator, product side)."""
     rng = np.random.RandomState(seed)
     lens = rng.randint(2, 31, size=n_users)
@@ -49,7 +58,7 @@ def synth_pairs(n_videos, n_users, seed):
     keep = ~last[:-1] & (vids[:-1] != vids[1:])
     pairs = np.stack([vids[:-1][keep], vids[1:][keep]], axis=1)
     pairs = pairs[rng.permutation(len(pairs))]      # one global shuffle (parse_data.py:206), vectorised
-    return pairs.astype(np.int32)
+    return (pairs + lo).astype(np.int32)
 
 
 class KernelTimer:
@@ -67,14 +76,13 @@ class KernelTimer:
             s.record()
             r = fn(*a, **k)
             e.record()
-            self.ev.setdefault(name, []).append((s, e))
+            self.ev.setdefault(name(*a, **k) if callable(name) else name, []).append((s, e))
             return r
         return timed
 
     def calibrate(self):
-        """Time an empty start/end pair: an upper bound of what the pair itself adds to a measured
-        launch (a few us: it matters for the 20 us gather, not for the 1 ms GEMMs).  Reported, not
-        subtracted -- subtracting it over-corrects (rocprofv3's per-kernel averages say so)."""
+        """An empty start/end pair: what the pair itself adds to a measured launch (reported,
+        not subtracted)."""
         pairs = []
         for _ in range(20):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -95,9 +103,9 @@ class KernelTimer:
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
-    (profiles/latest_pmc.csv: separate FETCH_SIZE / WRITE_SIZE passes of this
-    bench, KiB; FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary
+    (profiles/latest_pmc.csv: separate FETCH_SIZE / WRITE_SIZE passes of this bench, KiB;
+    FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
     path = os.path.join(ROOT, "profiles", "latest_pmc.csv")
     if not os.path.exists(path):
         return None
@@ -112,44 +120,76 @@ def pmc_traffic(kernel):
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
-def cpu_baseline(budget_s=12.0):
-    """The oracle's restatement of one reference training step (numpy gather as
-    inputs.py:158 + fp32 tower fwd/bwd + Adam), timed on the host cores."""
-    from oracle import sampler as osampler, tower as otower
+def cpu_model():
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    n_rows, B = 50000, 256
-    rng = np.random.RandomState(0)
-    table = rng.random_sample((n_rows, F)).astype(np.float32)
-    pairs = synth_pairs(n_rows, 5000, 0)
-    W = [otower.xavier_uniform(rng, F, H), np.zeros(H, np.float32),
-         otower.xavier_uniform(rng, H, D), np.zeros(D, np.float32)]
-    m = [np.zeros_like(w) for w in W]
-    v = [np.zeros_like(w) for w in W]
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
-    def one_step(step):
-        rows, tri, valid, _ = osampler.device_inbatch(pairs, 1234, step, B)
-        x = osampler.gather(table, rows)
-        fwd = otower.vnet_forward(x, *W, dtype=np.float32)
-        otower.hinge_loss_indexed(fwd["l2_norm"], tri, valid.astype(bool), MARGIN, np.float32)
-        dE = otower.hinge_loss_indexed_backward(fwd["l2_norm"], tri, valid.astype(bool), MARGIN, np.float32)
-        g = otower.vnet_backward(fwd, W[2], dE, np.float32)
-        for i, k in enumerate(("dW1", "db1", "dW2", "db2")):
-            W[i], m[i], v[i] = otower.adam_step(W[i], g[k], m[i], v[i], step + 1, 0.01)
 
-    one_step(0)
-    t0, n = time.time(), 0
-    while time.time() - t0 < budget_s:
-        one_step(n + 1)
-        n += 1
-    dt = time.time() - t0
-    return {"value": round(n * B / dt, 1), "unit": "triplets/s", "cores": int(threads), "kind": "port",
-            "sample": "%d oracle steps (numpy fp32 restatement of the reference step incl. gather "
-                      "and Adam) of %d in-batch triplets on a %dx%d host table, %.1f s"
-                      % (n, B, n_rows, F, dt)}
+def cpu_baseline(full=False):
+    """the CPU restatement of the reference step (numpy fancy-index gather
+    as inputs.py:158 + torch-CPU fp32 tower / hinge loss / backward / TF-form Adam,
+    oracle/tower_torch.py) on config 0's inputs -- 10 000 x 1500 table of round(U[0,1), 8)
+    (imitation_data.py:41-53, np.random.seed(0)), imitation_data-shaped pairs, the reference's
+    uniform-negative rule -- at B = 128 (config 0) and B = 1024 (the reference's production
+    batch, train.py:360), with 1 thread and with all threads, fetch vs train split like
+    train.py:314-323, median over the timed steps.  Bounded: each of the four runs stops at 50
+    timed steps or at its share of ~25 s, whichever comes first (--cpu-baseline-full: 50 steps
+    everywhere)."""
+    from oracle import synth as osynth, tower_torch
+    table = osynth.features_numpy(10000, F, seed=0).astype(np.float32)
+    pairs = osynth.cowatch_pairs(10000, 3000, 0)
+    all_threads = os.cpu_count() or 1
+    prev = torch.get_num_threads()
+    runs = []
+    for threads, B, budget, warm in ((all_threads, 128, 3.0, 5), (all_threads, 1024, 6.0, 3),
+                                     (1, 128, 8.0, 2), (1, 1024, 8.0, 1)):
+        torch.set_num_threads(threads)
+        st = tower_torch.CpuStep(table, pairs, B, hidden=H, out=D, margin=MARGIN, lr=0.01)
+        tf, tt, n = tower_torch.time_steps(st, 50, 1e9 if full else budget, 10 if full else warm)
+        runs.append({"batch": B, "threads": threads, "timed_steps": n, "fetch_ms": round(tf * 1e3, 3),
+                     "train_ms": round(tt * 1e3, 3), "triplets_per_s": round(B / (tf + tt), 1)})
+    torch.set_num_threads(prev)
+    head = runs[1]                                   # production batch on all threads
+    return {"value": head["triplets_per_s"], "unit": "triplets/s", "cores": all_threads, "kind": "port",
+            "cpu": cpu_model(),
+            "sample": "CPU restatement of the TF1 path (oracle/tower_torch.py: numpy gather + torch-CPU fp32 "
+                      "tower/loss/backward/Adam), config-0 table 10000x1500, uniform negatives; value = B=1024 on "
+                      "%d threads, median of %d timed steps (fetch %.1f ms + train %.1f ms); all four runs in `runs`"
+                      % (all_threads, head["timed_steps"], head["fetch_ms"], head["train_ms"]),
+            "runs": runs}
+
+
+def learnable_catalogue(n_rows, dev, n_clusters=2000, seed=0):
+    """tools/train_demo.py's catalogue: co-watched videos share a cluster, so there is something
+    to learn (loss 0.8 -> ~0) and the embeddings do not collapse."""
+    from cdml_amd import engine
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    centers = torch.rand(n_clusters, F, device=dev, generator=g)
+    cluster = torch.randint(0, n_clusters, (n_rows,), device=dev, generator=g)
+    table = engine.FeatureTable(torch.zeros((n_rows, engine.FeatureTable.padded_stride(F)), device=dev), F)
+    table.data[:, :F] = (centers[cluster] + 0.35 * torch.randn(n_rows, F, device=dev, generator=g)).clamp_(0.0, 1.0)
+    order = torch.argsort(cluster)
+    a, b = order[:-1], order[1:]
+    same = cluster[a] == cluster[b]
+    pairs = torch.stack([a[same], b[same]], 1).to(torch.int32)
+    return table, pairs[torch.randperm(pairs.shape[0], device=dev, generator=g)].contiguous()
+
+
+def timed_steps(ts, steps, warmup, dev):
+    for _ in range(warmup):
+        ts.step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts.step()
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0
 
 
 def main():
@@ -157,16 +197,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--rows", type=int, default=None, help="catalogue rows (default: 1M, or 10M when --gpus > 1)")
-    ap.add_argument("--mode", default="inbatch", choices=["inbatch", "uniform", "semihard"])
-    ap.add_argument("--batch", type=int, default=BATCH, help="triplets per GPU per step")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU)")
+    ap.add_argument("--rows", type=int, default=None, help="catalogue rows (default: 1M at N=1 fp32, else 10M)")
+    ap.add_argument("--mode", default=None, choices=["inbatch", "uniform", "semihard"])
+    ap.add_argument("--batch", type=int, default=None, help="triplets per GPU per step (default 4096 for config 1, else 8192)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="bf16 = BASELINE config 4 path (fp16 table + bf16 MFMA); not the headline metric")
     ap.add_argument("--train-table", action="store_true",
                     help="also train the catalogue rows (lazy Adam; build-defined, not the headline metric)")
+    ap.add_argument("--gather-ahead", type=int, default=2, help="steps fetched per sampler+gather launch (1 GPU, fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="50 timed CPU steps in all four runs (minutes)")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip like_for_like and data_learnable")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,163 +229,264 @@ def main():
 
     import torch.distributed as dist
     from cdml_amd import dist as cdist, engine, engine_bf16, ops, train
-    Table = engine_bf16.FeatureTableF16 if args.precision == "bf16" else engine.FeatureTable
+    bf16 = args.precision == "bf16"
+    Table = engine_bf16.FeatureTableF16 if bf16 else engine.FeatureTable
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a finite timeout: a stuck collective ends the run with a non-zero exit instead of hanging
+        tmo = datetime.timedelta(seconds=int(os.environ.get("CDML_DIST_TIMEOUT_S", "180")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
-    n_rows = args.rows or (1000000 if world == 1 else 10000000)
-    B = args.batch
-    if world > 1:
-        lo, hi, _ = cdist.shard_bounds(n_rows, world, rank)
-        table = Table.synthetic(hi - lo, F, seed=0, device=dev, row0=lo, n_rows_global=n_rows)
-        # own communicator for the exchange so it never queues behind the gradient all-reduce
-        ex_group = dist.new_group()
-        exchange, grad_sync = cdist.RowExchange(n_rows, group=ex_group), cdist.GradSync(device=dev)
-        # bring both communicators up here (RCCL builds them on first use), not inside a step
-        warm = torch.zeros(1, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(warm)
-        dist.all_reduce(warm, group=ex_group)
-    else:
-        table = Table.synthetic(n_rows, F, seed=0, device=dev)
-        exchange = grad_sync = None
-    # users: a third of the catalogue, capped -- the run consumes < 1 M pairs per rank, and every
-    # rank builds the same list on its host while the others wait
-    pairs = torch.from_numpy(synth_pairs(n_rows, max(min(n_rows // 3, 600000), 1000), seed=0)).to(dev)
+    config1 = world == 1 and not bf16
+    n_rows = args.rows or (1000000 if config1 else 10000000)
+    B = args.batch or (4096 if config1 else 8192)
+    mode = args.mode or ("uniform" if bf16 else "inbatch")
+    phase = "setup"
+    try:
+        if world > 1:
+            lo, hi, _ = cdist.shard_bounds(n_rows, world, rank)
+            table = Table.synthetic(hi - lo, F, seed=0, device=dev, row0=lo, n_rows_global=n_rows)
+            # own communicator for the exchange so it never queues behind the gradient all-reduce
+            ex_group = dist.new_group()
+            exchange, grad_sync = cdist.RowExchange(n_rows, group=ex_group), cdist.GradSync(device=dev)
+            # bring both communicators up here (RCCL builds them on first use), not inside a step
+            phase = "communicator warm-up"
+            warm = torch.zeros(1, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(warm)
+            dist.all_reduce(warm, group=ex_group)
+        else:
+            table = Table.synthetic(n_rows, F, seed=0, device=dev)
+            exchange = grad_sync = None
+        # users: a third of the catalogue, capped -- the run consumes < 1 M pairs per rank, and every
+        # rank builds the same list on its host while the others wait
+        pairs = torch.from_numpy(synth_pairs(n_rows, max(min(n_rows // 3, 600000), 1000), seed=0)).to(dev)
 
-    ts = train.TrainStep(table, pairs, B, output_size=D, hidden_size=H, margin=MARGIN, mode=args.mode,
-                         optimizer="adam", base_learning_rate=0.01, seed=1234, weight_seed=42,
-                         device=dev, exchange=exchange, grad_sync=grad_sync, slot0=rank * B,
-                         batch_global=world * B, use_graph=args.graph, precision=args.precision,
-                         train_table=args.train_table)
-
-    # per-kernel event timers on the launch stream (off during graph replay)
-    kt = KernelTimer()
-    timers_on = not args.no_kernel_timers and not args.graph and args.precision == "f32"
-    if timers_on:
-        real_fwd, real_bww = ops.fc_lrelu_fwd, ops.fc_bwd_weight
+        ts = train.TrainStep(table, pairs, B, output_size=D, hidden_size=H, margin=MARGIN, mode=mode,
+                             optimizer="adam", base_learning_rate=0.01, seed=1234, weight_seed=42,
+                             device=dev, exchange=exchange, grad_sync=grad_sync, slot0=rank * B,
+                             batch_global=world * B, use_graph=args.graph, precision=args.precision,
+                             train_table=args.train_table, gather_ahead=args.gather_ahead)
         L = ts.layout
 
-        def fwd(x, W, b, y, M, K, N, *a, **k):
-            name = "fc1_fwd" if K == L.Fp else "fc2_fwd"
-            return kt.wrap(name, real_fwd)(x, W, b, y, M, K, N, *a, **k)
+        # per-kernel event timers on the launch stream (off during graph replay)
+        kt = KernelTimer()
+        timers_on = not args.no_kernel_timers and not ts.use_graph
+        real = {}
+        if timers_on:
+            def patch(name, label):
+                real[name] = getattr(ops, name)
+                setattr(ops, name, kt.wrap(label, real[name]))
+            if bf16:
+                # gemm_bf16_nt(epilogue, A, B, C, M, N, K, ...): FC1 has N = Hp, K = Fp; FC2 N = Dp; dH1 K = Dp
+                patch("gemm_bf16_nt", lambda e, A, Bm, C, M, N, K, **k:
+                      "fc1_fwd" if (N == L.Hp and K == L.Fp) else ("fc2_fwd" if N == L.Dp else "dH1"))
+                # gemm_bf16_tn(A, B, C, M, N, K, ...): dW1 has N = Hp
+                patch("gemm_bf16_tn", lambda A, Bm, C, M, N, K, **k: "dW1" if N == L.Hp else "dW2")
+            else:
+                patch("fc_lrelu_fwd", lambda x, W, b, y, M, K, N, *a, **k: "fc1_fwd" if N == L.Hp else "fc2_fwd")
+                patch("fc_bwd_weight", lambda x, dy, dW, db, ws, M, K, N: "dW1" if N == L.Hp else "dW2")
+                patch("fc_bwd_data", "dH1")
+            patch("adam_step", "adam")
+            patch("vnet_tail", "tail")
+        comm = {}
+        if world > 1:                                   # what the compute stream waits for
+            real_finish = grad_sync.finish
+            grad_sync.finish = kt.wrap("allreduce_wait", real_finish)
+            if ts.prefetch is not None:
+                ts.prefetch.acquire = kt.wrap("exchange_wait", ts.prefetch.acquire)
 
-        def bww(x, dy, dW, db, ws, M, K, N):
-            name = "dW1" if N == L.Hp else "dW2"         # by layer (data-parallel runs do dW1 in row blocks)
-            return kt.wrap(name, real_bww)(x, dy, dW, db, ws, M, K, N)
-        ops.fc_lrelu_fwd, ops.fc_bwd_weight = fwd, bww
-        ts.fetch = kt.wrap("fetch", ts.fetch)
+        def sync_all():
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
 
-    def sync_all():
+        def reduce_max(x):
+            t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        phase = "warm-up steps"
+        for _ in range(args.warmup):
+            ts.step()
+        sync_all()
+        phase = "timed steps"
+        # kernel timers on every 4th timed step: an event pair costs the stream a few us, a dozen
+        # pairs a step are ~1 % of it; the sampled launches are still launches of the timed region
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            kt.on = timers_on and (i % 4 == 0)
+            ts.step()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
-
-    def reduce_max(x):
-        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    for _ in range(args.warmup):
-        ts.step()
-    sync_all()
-    # kernel timers on every 4th timed step: an event pair costs the stream a few us, ten pairs a
-    # step are ~1 % of it; the sampled launches are still launches of the timed region
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        kt.on = timers_on and (i % 4 == 0)
-        ts.step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    kt.on = False
-    if timers_on:
-        kt.calibrate()
-    if world > 1:
-        elapsed = reduce_max(elapsed)
-    loss = ts.loss()
-    assert np.isfinite(loss), "non-finite loss"
+        elapsed = time.perf_counter() - t0
+        kt.on = False
+        for name, fn in real.items():
+            setattr(ops, name, fn)
+        if timers_on:
+            kt.calibrate()
+        if world > 1:
+            phase = "max over ranks"
+            elapsed = reduce_max(elapsed)
+        loss = ts.loss()
+        assert np.isfinite(loss), "non-finite loss"
+        if exchange is not None:
+            exchange.check_overflow()
+    except Exception as e:                               # noqa: BLE001 -- name the phase, exit non-zero
+        sys.stderr.write("[bench rank %d] failed during %s: %r\n" % (rank, phase, e))
+        raise
 
     if rank == 0:
         rpt = ts.rows_per_triplet
         R = B * rpt
         ms = elapsed / args.steps * 1e3
-        if args.precision == "bf16":
-            cfg_name = "config4" + (" (1 GPU)" if world == 1 else "")
+        if bf16:
+            cfg_name = "config4" + (" per-GPU shape on 1 GPU" if world == 1 else "")
         elif world > 1:
-            cfg_name = "config3 (weak-scaled)"
+            cfg_name = "config3"
         else:
-            cfg_name = {"inbatch": "config1", "semihard": "config2", "uniform": "config1 size, reference negative rule"}[args.mode]
+            cfg_name = {"inbatch": "config1", "semihard": "config2", "uniform": "config1 size, reference negative rule"}[mode]
         out = {
             "metric": "triplets/sec", "value": round(world * B * args.steps / elapsed, 1),
             "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16 (fp16 table, f32 accumulate)",
+            "vs_baseline": None, "dtype": "f32" if not bf16 else "bf16 (fp16 table, f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "%s: %d videos x %d-d %s in HBM, %d hidden, %d-d embed, batch %d triplets/GPU, "
-                                   "%s negatives, margin %.1f, Adam, full step (sample+gather+fwd+loss+bwd+opt)"
-                                   % (cfg_name, n_rows, F, "fp16" if args.precision == "bf16" else "fp32", H, D, B,
-                                      {"inbatch": "in-batch", "uniform": "uniform random",
-                                       "semihard": "semi-hard mined"}[args.mode], MARGIN),
+            "config": {"workload": "%s: %d videos x %d-d %s in HBM%s, %d hidden, %d-d embed, batch %d triplets/GPU "
+                                   "(%d global), %s negatives, margin %.1f, Adam, full step (sample+gather+fwd+loss+bwd+opt)"
+                                   % (cfg_name, n_rows, F, "fp16" if bf16 else "fp32",
+                                      "" if world == 1 else " row-sharded over %d GPUs" % world, H, D, B, world * B,
+                                      {"inbatch": "in-batch", "uniform": "uniform random", "semihard": "semi-hard mined"}[mode],
+                                      MARGIN),
                        "global_batch": world * B, "rows_per_triplet": rpt,
                        "parallelism": "dp%d" % world + ("" if world == 1 else " row-sharded table, all-to-all rows + all-reduce grads"),
-                       "hipgraph": bool(args.graph), "trainable_table": bool(args.train_table)},
+                       "hipgraph": bool(ts.use_graph), "trainable_table": bool(args.train_table),
+                       "gather_steps_per_launch": ts.gather_ahead},
             "loss": round(loss, 6),
         }
-        # dominant kernel by total time: the bwd-weight GEMM k_gemm_f32<false, false, 2, 2, 3>,
-        # launched twice per step (dW1: 2*R*F*H flop, dW2: 2*R*H*D flop); rocprof's per-kernel
-        # average is over both launches, so the roofline is too.  Algorithmic (unpadded) flop.
+        # dominant kernel by total time: the weight-gradient GEMM (dW1: 2*R*F*H flop, dW2: 2*R*H*D
+        # flop, one kernel symbol); rocprof's per-kernel average is over all its launches, so the
+        # roofline is too.  Algorithmic (unpadded) flop.
         flops_gemm = 2.0 * R * F * H
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+        kname = "k_gemm_bf16_256<true, 3>" if bf16 else "k_gemm_f32<false, false, 2, 2, 3,"
         if timers_on and kt.count("dW1") and kt.count("dW2") and kt.count("fc1_fwd"):
-            # mean over ALL launches of the kernel in the timed steps, like rocprof's average
             n_launch = kt.count("dW1") + kt.count("dW2")
             t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
-            timed_steps = (args.steps + 3) // 4
-            flop_launch = timed_steps * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
+            sampled = (args.steps + 3) // 4
+            flop_launch = sampled * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
             ach = flop_launch / (t_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_f32<false, false, 2, 2, 3, ...> (dW1+dW2 launches)",
-                               "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                               "traffic": pmc_traffic("k_gemm_f32<false, false, 2, 2, 3,") if world == 1 else None,
+            out["roofline"] = {"bound": "mfma", "kernel": kname + " ...> (dW1+dW2 launches)" if not bf16 else kname + " (dW1+dW2 launches)",
+                               "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4),
+                               "traffic": pmc_traffic(kname) if world == 1 else None,
                                "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch,
-                               "launches_per_step": n_launch / timed_steps, "timed_steps": timed_steps}
+                               "launches_per_step": n_launch / sampled, "timed_steps": sampled}
             ach1 = flops_gemm / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
-            out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": "k_gemm_f32<true, false, 2, 2, 1, ...>",
-                                       "achieved": round(ach1, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                                       "unit": "TFLOP/s", "frac": round(ach1 / PEAK_F32_MFMA_TFLOPS, 4),
-                                       "traffic": pmc_traffic("k_gemm_f32<true, false, 2, 2, 1,"),
-                                       "launch_ms": round(kt.mean_ms("fc1_fwd"), 4),
-                                       "flop_per_launch": flops_gemm}
+            k1 = "k_gemm_bf16_256<false, 0>" if bf16 else "k_gemm_f32<true, false, 2, 2, 1,"
+            out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": k1 + ("" if bf16 else " ...>"),
+                                       "achieved": round(ach1, 2), "peak": peak, "unit": "TFLOP/s",
+                                       "frac": round(ach1 / peak, 4), "traffic": pmc_traffic(k1) if world == 1 else None,
+                                       "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": flops_gemm}
             kern = {}
-            for k in ("fc1_fwd", "fc2_fwd", "dW1", "dW2", "fetch"):
+            for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW1", "dW2", "adam"):
                 if kt.mean_ms(k) is not None:
                     kern[k + "_ms"] = round(kt.mean_ms(k), 4)
             kern["empty_event_pair_ms"] = round(kt.overhead_ms, 5)      # included in the figures above
             out["kernels"] = kern
-            t_f = kt.mean_ms("fetch")
-            if t_f and world == 1:
-                gbytes = 2.0 * R * F * 4                     # rows read + normalised rows written
-                g_ach = gbytes / (t_f * 1e-3) / 1e9
-                out["gather"] = {"bound": "hbm", "kernel": "k_sample_gather", "achieved": round(g_ach, 1),
-                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4),
-                                 "traffic": pmc_traffic("k_sample_gather<1, 6>" if rpt == 2 else "k_sample_gather<0, 6>"),
-                                 "bytes_per_launch": gbytes, "launch_ms": round(t_f, 4),
-                                 # a 20-us kernel between two events: the launch time above includes
-                                 # the pair's own cost (at most kernels.empty_event_pair_ms), so this
-                                 # GB/s is a lower bound; rocprofv3's per-kernel average in profiles/
-                                 # is the steadier figure
-                                 "note": "event-pair cost included; see profiles/*kernel_stats.csv"}
+        # the HBM-bound kernel the metric also names: the fused sampler+gather (fp32, 1 GPU) or
+        # the fp16 row gather (config 4), 10 back-to-back launches per event pair
+        if world == 1 and not args.train_table:
+            reps, per = 5, 10
+            if bf16:
+                gk, n_st = "k_gather_rows_f16", 1
+                gbytes = R * F * (2 + 2.0)                  # fp16 rows read + bf16 normalised rows written
+
+                def launch():
+                    ops.gather_rows_f16(ts.table.data, ts.table.row0, ts.idx, F, ts.ws.x_hat)
+            else:
+                n_st = ts.gather_ahead
+                gk = "k_sample_gather<%d, 6>" % (1 if rpt == 2 else 0)
+                gbytes = n_st * 2.0 * R * F * 4             # rows read + normalised rows written
+                base = ts._ahead_base if n_st > 1 else ts.global_step - 1
+                m = train._MODES[mode]
+
+                def launch():                               # re-fetches the block of steps already in the buffers
+                    if n_st > 1:
+                        ops.sample_gather(m, ts.pairs, ts.seed, base, B, ts.table.data, F, ts._idxa, ts._xa,
+                                          shift_out=ts._shifta, n_steps=n_st)
+                    else:
+                        ops.sample_gather(m, ts.pairs, ts.seed, base, B, ts.table.data, F, ts.idx, ts.ws.x_hat,
+                                          shift_out=ts.shift)
+            for _ in range(3):
+                launch()
+            evs = []
+            for _ in range(reps):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(per):
+                    launch()
+                e.record()
+                evs.append((s, e))
+            torch.cuda.synchronize(dev)
+            t_g = float(np.median([s.elapsed_time(e) for s, e in evs])) / per
+            g_ach = gbytes / (t_g * 1e-3) / 1e9
+            out["gather"] = {"bound": "hbm", "kernel": gk, "achieved": round(g_ach, 1), "peak": PEAK_HBM_GBS,
+                             "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(gk),
+                             "bytes_per_launch": gbytes, "launch_ms": round(t_g, 4), "steps_per_launch": n_st,
+                             "method": "%d back-to-back launches per event pair (inter-launch gaps included), median of %d"
+                                       % (per, reps)}
+        if world > 1:
+            ar, exw = kt.mean_ms("allreduce_wait"), kt.mean_ms("exchange_wait")
+            out["comm"] = {"allreduce_exposed_ms": None if ar is None else round(ar, 4),
+                           "exchange_exposed_ms": None if exw is None else round(exw, 4),
+                           "exchange_bytes": exchange.bytes_per_step(ts.R, ts.ws.x_hat),
+                           "allreduce_bytes": int(ts.layout.numel * 4),
+                           "note": "event pairs around GradSync.finish / Prefetcher.acquire on the compute stream "
+                                   "(every 4th timed step): what the step waits for, not the collectives' own duration"}
         step_flops = R * (2.0 * F * H + 2.0 * H * D) + R * (2.0 * F * H + 4.0 * H * D)
         out["step_tflops"] = round(step_flops / (elapsed / args.steps) / 1e12, 2)
+
+        if config1 and mode == "inbatch" and not args.no_extras and not args.train_table:
+            del ts, table, pairs
+            torch.cuda.empty_cache()
+            n_s, n_w = min(args.steps, 30), min(max(args.warmup, 3), 5)
+            # (b) the N > 1 line's per-GPU workload, whole 10 M-row catalogue on this one GPU
+            t10 = Table.synthetic(10000000, F, seed=0, device=dev)
+            p10 = torch.from_numpy(synth_pairs(10000000, 600000, seed=0)).to(dev)
+            ts10 = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
+                                   optimizer="adam", base_learning_rate=0.01, device=dev, gather_ahead=args.gather_ahead)
+            el = timed_steps(ts10, n_s, n_w, dev)
+            out["like_for_like"] = {"workload": "config3 per-GPU batch on ONE GPU: 10000000 videos x 1500-d fp32 (61 GB) in "
+                                                "HBM, batch 8192 triplets, in-batch negatives (the N>1 lines run this per GPU "
+                                                "on a row-sharded catalogue)",
+                                    "value": round(8192 * n_s / el, 1), "unit": "triplets/s",
+                                    "ms_per_step": round(el / n_s * 1e3, 4), "steps": n_s, "warmup": n_w}
+            del ts10, t10, p10
+            torch.cuda.empty_cache()
+            # (c) the headline step on a learnable catalogue
+            tl, pl = learnable_catalogue(200000, dev)
+            tsl = train.TrainStep(tl, pl, B, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
+                                  optimizer="adam", base_learning_rate=2e-4, device=dev, gather_ahead=args.gather_ahead)
+            tsl.step()
+            l0 = tsl.loss()
+            n_l = max(n_s, 60)
+            el = timed_steps(tsl, n_l, n_w, dev)
+            out["data_learnable"] = {"workload": "config1 step (batch %d in-batch) on a learnable 200000 x 1500 catalogue "
+                                                 "(co-watched videos share one of 2000 clusters), Adam 2e-4" % B,
+                                     "value": round(B * n_l / el, 1), "unit": "triplets/s",
+                                     "ms_per_step": round(el / n_l * 1e3, 4), "steps": n_l,
+                                     "loss_first_step": round(l0, 4), "loss_last_step": round(tsl.loss(), 4)}
+            del tsl, tl, pl
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -314,6 +314,7 @@ k_gather_rows_f16(const _Float16 *__restrict__ table, int64_t row0, int64_t n_ro
   const int wave = threadIdx.x >> 6;
   const int nq = (F + 7) >> 3, oq = (int)(out_stride >> 3);
   for (int r = blockIdx.x * 4 + wave; r < n_idx; r += gridDim.x * 4) {
+    if (idx[r] == -1) continue;                  // padding slot of a fixed-capacity exchange
     int64_t lr = (int64_t)idx[r] - row0;
     if (lr < 0 || lr >= n_rows) {
       if (oob_flag) atomicOr(oob_flag, 1);

@@ -156,7 +156,9 @@ k_gather_rows(const float *__restrict__ table, int64_t row0, int64_t n_rows, int
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int r = blockIdx.x * kWavesPerBlock + wave; r < n_idx; r += gridDim.x * kWavesPerBlock) {
-    const int64_t lr = clamp_row(idx[r], row0, n_rows, oob_flag);
+    const int32_t id = idx[r];
+    if (id == -1) continue;                    // padding slot of a fixed-capacity exchange: untouched
+    const int64_t lr = clamp_row(id, row0, n_rows, oob_flag);
     gather_one_row<NCH>(table, lr, row_stride, F, normalize, x_out + (int64_t)r * out_stride,
                         out_stride, inv_norm_out ? inv_norm_out + r : nullptr, lane);
   }
@@ -288,6 +290,82 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
       }
     }
     __syncthreads();                               // ids of the next chunk are staged; this buffer is free
+  }
+}
+
+// ------------------------------------------------ row exchange: routing (multi-GPU) --
+// Row-sharded catalogue, fixed-capacity all-to-all (cdml_amd/dist.py): every rank sends each
+// peer exactly `cap` id slots and gets `cap` row slots back, so nothing on the step path depends
+// on a host-side count (enqueue-only, hipGraph-capturable).  k_route_rows puts request r of this
+// rank (global id ids[r], owner = id / rows_per_shard) into the owner's segment of the send
+// buffer in ASCENDING r (deterministic: the owner of a trainable table sums duplicate rows in the
+// order it was asked), pads the rest with -1 and records the slot for the way back.  One block:
+// R is a few 10^4 ids and the kernel sits on the prefetch stream, off the critical path.
+constexpr int kRouteThreads = 1024;
+constexpr int kRouteMaxWorld = 64;
+
+__global__ void __launch_bounds__(kRouteThreads)
+k_route_rows(const int32_t *__restrict__ ids, int n, int64_t rows_per_shard, int world, int cap,
+             int32_t *__restrict__ send_ids, int32_t *__restrict__ slot, int32_t *__restrict__ overflow) {
+  __shared__ int s_cnt[kRouteMaxWorld];
+  __shared__ int s_wave[kRouteThreads / kWave][kRouteMaxWorld];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  for (int i = tid; i < world * cap; i += kRouteThreads) send_ids[i] = -1;
+  if (tid < world) s_cnt[tid] = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += kRouteThreads) {
+    const int r = base + tid;
+    int id = 0, o = -1;
+    if (r < n) {
+      id = ids[r];
+      const int64_t q = (int64_t)id / rows_per_shard;
+      if (id < 0 || q >= world) { atomicOr(overflow, 2); o = -1; }     // not a catalogue row
+      else o = (int)q;
+    }
+    int my_rank = 0;
+    for (int ow = 0; ow < world; ++ow) {
+      const unsigned long long m = __ballot(o == ow);
+      if (o == ow) my_rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wave[wave][ow] = __popcll(m);
+    }
+    __syncthreads();
+    if (o >= 0) {
+      int pos = s_cnt[o] + my_rank;
+      for (int w = 0; w < wave; ++w) pos += s_wave[w][o];
+      if (pos < cap) {
+        send_ids[o * cap + pos] = id;
+        slot[r] = o * cap + pos;
+      } else {
+        slot[r] = -1;                                                  // the row is not fetched: fatal, flagged
+        atomicOr(overflow, 1);
+      }
+    } else if (r < n) {
+      slot[r] = -1;
+    }
+    __syncthreads();
+    if (tid < world) {
+      int c = s_cnt[tid];
+      for (int w = 0; w < kRouteThreads / kWave; ++w) c += s_wave[w][tid];
+      s_cnt[tid] = c;
+    }
+    __syncthreads();
+  }
+}
+
+// dst[slot[r]] = src[r] for r < n (slot -1: dropped): the reverse trip of the exchange (row
+// gradients to their owners).  One wave per row, 16-B lanes.
+__global__ void __launch_bounds__(kThreads)
+k_scatter_rows(const float *__restrict__ src, int64_t lds, const int32_t *__restrict__ slot, int n, int width,
+               float *__restrict__ dst, int64_t ldd) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nq = width >> 2;
+  for (int r = blockIdx.x * kWavesPerBlock + wave; r < n; r += gridDim.x * kWavesPerBlock) {
+    const int t = slot[r];
+    if (t < 0) continue;
+    const float4 *a = reinterpret_cast<const float4 *>(src + (int64_t)r * lds);
+    float4 *d = reinterpret_cast<float4 *>(dst + (int64_t)t * ldd);
+    for (int q = lane; q < nq; q += kWave) d[q] = a[q];
   }
 }
 
@@ -423,4 +501,27 @@ extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pair
   }
 #undef CDML_LAUNCH_SG
   return check_launch("sample_gather");
+}
+
+extern "C" int cdml_route_rows(const int32_t *ids, int n, int64_t rows_per_shard, int world, int capacity,
+                               int32_t *send_ids, int32_t *slot_out, int32_t *overflow_flag,
+                               cdml_stream_t stream) {
+  CDML_REQUIRE(ids && send_ids && slot_out && overflow_flag && n > 0 && rows_per_shard > 0 && capacity > 0,
+               CDML_E_BADARG, "route_rows: bad argument");
+  CDML_REQUIRE(world >= 1 && world <= kRouteMaxWorld, CDML_E_UNSUPPORTED, "route_rows: world size %d outside [1, %d]",
+               world, kRouteMaxWorld);
+  hipLaunchKernelGGL(k_route_rows, dim3(1), dim3(kRouteThreads), 0, (hipStream_t)stream, ids, n, rows_per_shard,
+                     world, capacity, send_ids, slot_out, overflow_flag);
+  return check_launch("route_rows");
+}
+
+extern "C" int cdml_scatter_rows(const float *src, int64_t ld_src, const int32_t *slot, int n, int width,
+                                 float *dst, int64_t ld_dst, cdml_stream_t stream) {
+  CDML_REQUIRE(src && slot && dst && n > 0 && width > 0, CDML_E_BADARG, "scatter_rows: bad argument");
+  CDML_REQUIRE((width & 3) == 0 && ld_src >= width && ld_dst >= width && (ld_src & 3) == 0 && (ld_dst & 3) == 0 &&
+                   aligned16(src) && aligned16(dst),
+               CDML_E_ALIGN, "scatter_rows: width and leading dimensions multiples of 4, 16-B aligned bases");
+  hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(n, kWavesPerBlock)), dim3(kThreads), 0, (hipStream_t)stream, src,
+                     ld_src, slot, n, width, dst, ld_dst);
+  return check_launch("scatter_rows");
 }

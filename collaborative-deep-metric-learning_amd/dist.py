@@ -8,14 +8,21 @@ extension of the hot path:
     [g*rows_per_rank, (g+1)*rows_per_rank);
   * every rank samples its own slice of the global batch (the sampler is
     counter-based, so no communication is needed to agree on triplets);
-  * ``RowExchange.gather``: all-to-all of requested row ids, owners gather +
-    l2-normalise the rows from their shard (HIP kernel), all-to-all of the rows
-    back -- the one real exchange step of the path;
-  * ``GradSync``: one all-reduce (average) of the flat 35 MB gradient buffer.
+  * ``RowExchange.gather``: FIXED-CAPACITY all-to-all.  A HIP kernel routes the R
+    requested ids into per-owner segments of ``capacity`` slots (unused slots -1),
+    one all-to-all with equal splits carries the ids, the owners gather +
+    l2-normalise the rows of their shard (HIP kernel; -1 slots skipped), a second
+    equal-split all-to-all carries the rows back and a HIP gather puts them in
+    request order.  No host-side counts anywhere: the step is enqueue-only and the
+    same every step (hipGraph-capturable); a segment that overflows raises a device
+    flag that ``check_overflow`` reads off the critical path;
+  * ``GradSync``: bucketed all-reduce (average) of the flat 35 MB gradient buffer.
 
 Only torch.distributed plumbing lives here; the local gather is injected
 (``local_gather``) so the routing logic is testable on CPU with gloo.
 """
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -36,21 +43,20 @@ def _host_staged(group):
     return dist.get_backend(group) != "nccl"
 
 
-def all_to_all(out, inp, out_splits=None, in_splits=None, group=None):
+def all_to_all(out, inp, group=None):
+    """Equal-split all-to-all of the leading dimension."""
     if inp.is_cuda and _host_staged(group):
         o = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits,
-                               input_split_sizes=in_splits, group=group)
+        dist.all_to_all_single(o, inp.cpu(), group=group)
         out.copy_(o)
     else:
-        dist.all_to_all_single(out, inp, output_split_sizes=out_splits,
-                               input_split_sizes=in_splits, group=group)
+        dist.all_to_all_single(out, inp, group=group)
     return out
 
 
 def _hip_local_gather(table, ids, out):
     """Owner side: gather + l2-normalise local rows with the HIP kernel (fp32 table ->
-    fp32 rows, fp16 table -> bf16 rows)."""
+    fp32 rows, fp16 table -> bf16 rows); id -1 = padding slot, left untouched."""
     if table.data.dtype == torch.float16:
         ops.gather_rows_f16(table.data, table.row0, ids, table.feature_size, out)
     else:
@@ -65,79 +71,129 @@ def raw_local_gather(table, ids, out):
     return out
 
 
+def exchange_capacity(n_requests, world, factor=1.25):
+    """Slots per peer: the mean share with ``factor`` headroom plus six standard deviations of
+    a uniform draw (small batches), a multiple of 8, never more than all requests."""
+    if world == 1:
+        return int(n_requests)
+    mean = n_requests / world
+    cap = int(math.ceil(mean * factor + 6.0 * math.sqrt(mean))) + 8
+    return min(int(n_requests), (cap + 7) // 8 * 8)
+
+
 class RowExchange:
     """Fetch (normalised) feature rows by GLOBAL id from a row-sharded table."""
 
-    def __init__(self, n_rows_global, group=None, local_gather=None):
+    def __init__(self, n_rows_global, group=None, local_gather=None, capacity_factor=1.25):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.n_rows_global = int(n_rows_global)
         self.per = shard_bounds(n_rows_global, self.world, self.rank)[2]
         self.local_gather = local_gather or _hip_local_gather
+        self.capacity_factor = float(capacity_factor)
         self._buf = {}
+        self.overflow = None
+        self.last = None
 
     def _scratch(self, name, shape, dtype, device):
         t = self._buf.get(name)
-        if (t is None or t.shape[0] < shape[0] or t.shape[1:] != tuple(shape[1:]) or t.device != device
-                or t.dtype != dtype):
-            t = torch.empty(shape, dtype=dtype, device=device)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != device or t.dtype != dtype:
+            t = torch.zeros(shape, dtype=dtype, device=device)
             self._buf[name] = t
-        return t[:shape[0]]
+        return t
 
-    def plan(self, ids):
-        """Route ids to owners: (send_ids sorted by owner, order, send_counts)."""
-        owner = torch.div(ids, self.per, rounding_mode="floor").to(torch.int64)
-        order = torch.argsort(owner, stable=True)
-        counts = torch.bincount(owner, minlength=self.world)
-        return ids[order].contiguous(), order, counts
+    def capacity(self, n_requests):
+        return exchange_capacity(n_requests, self.world, self.capacity_factor)
+
+    def route(self, ids, cap):
+        """(send_ids int32[world*cap] with -1 padding, slot int32[R]): request r sits in slot
+        owner*cap + k, k counting the owner's requests in ascending r."""
+        dev, R = ids.device, ids.numel()
+        if self.overflow is None or self.overflow.device != dev:
+            self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        send_ids = self._scratch("send_ids", (self.world * cap,), torch.int32, dev)
+        slot = self._scratch("slot", (R,), torch.int32, dev)
+        if ids.is_cuda:
+            ops.route_rows(ids, self.per, self.world, cap, send_ids, slot, self.overflow)
+        else:                                   # CPU tensors: the gloo unit test of this plumbing
+            owner = torch.div(ids, self.per, rounding_mode="floor").to(torch.int64)
+            bad = (ids < 0) | (owner >= self.world)
+            if bool(bad.any()):
+                self.overflow |= 2
+            owner = owner.clamp(0, self.world - 1)
+            onehot = torch.nn.functional.one_hot(owner, self.world)
+            pos = (onehot.cumsum(0) - onehot).gather(1, owner[:, None])[:, 0]
+            ok = (pos < cap) & ~bad
+            if bool((~ok & ~bad).any()):
+                self.overflow |= 1
+            send_ids.fill_(-1)
+            s = (owner * cap + pos).to(torch.int32)
+            send_ids[s[ok].long()] = ids[ok]
+            slot.copy_(torch.where(ok, s, torch.full_like(s, -1)))
+        return send_ids, slot
 
     def gather(self, table, ids, out):
         """out[r] = l2norm(table_global[ids[r]]) for r < len(ids); out is [R, stride]."""
-        dev = ids.device
-        send_ids, order, send_counts = self.plan(ids)
-        recv_counts = torch.empty_like(send_counts)
-        all_to_all(recv_counts, send_counts, group=self.group)
-        sc, rc = send_counts.tolist(), recv_counts.tolist()       # host sync: split sizes
-        n_req = int(sum(rc))
-        req_ids = self._scratch("req_ids", (max(n_req, 1),), torch.int32, dev)[:n_req]
-        all_to_all(req_ids, send_ids, rc, sc, self.group)
+        dev, R = ids.device, ids.numel()
+        cap = self.capacity(R)
+        send_ids, slot = self.route(ids, cap)
+        n_slots = self.world * cap
+        recv_ids = self._scratch("recv_ids", (n_slots,), torch.int32, dev)
+        all_to_all(recv_ids, send_ids, self.group)
         stride = out.shape[1]
-        rows_out = self._scratch("rows_out", (max(n_req, 1), stride), out.dtype, out.device)[:n_req]
-        if n_req:
-            self.local_gather(table, req_ids, rows_out)
-        rows_in = self._scratch("rows_in", (ids.numel(), stride), out.dtype, out.device)
-        all_to_all(rows_in, rows_out, sc, rc, self.group)
-        inv = torch.empty_like(order)
-        inv[order] = torch.arange(order.numel(), device=dev)
-        self.unpermute(rows_in, inv, out)
+        rows_out = self._scratch("rows_out", (n_slots, stride), out.dtype, out.device)
+        self.local_gather(table, recv_ids, rows_out)
+        rows_in = self._scratch("rows_in", (n_slots, stride), out.dtype, out.device)
+        all_to_all(rows_in, rows_out, self.group)
+        self.unpermute(rows_in, slot, out)
         # kept for scatter_back(): the same routing carries row gradients to their owners
-        self.last_plan = (order, sc, rc, req_ids.clone() if n_req else req_ids)
+        self.last = (slot, recv_ids, cap)
         return out
 
     def scatter_back(self, rows):
         """The reverse trip of the last ``gather``: rows[r] (e.g. the gradient of the r-th
         requested row) goes to the rank that owns ids[r].  Returns (ids, rows) as the owner
-        sees them: every request it served, in the order it served them (source rank, then the
-        requester's order) -- duplicates included."""
-        order, sc, rc, req_ids = self.last_plan
-        stride = rows.shape[1]
-        send = self._scratch("back_send", (order.numel(), stride), rows.dtype, rows.device)
-        self.unpermute(rows, order, send)                    # send[j] = rows[order[j]]
-        n_req = int(sum(rc))
-        recv = self._scratch("back_recv", (max(n_req, 1), stride), rows.dtype, rows.device)[:n_req]
-        all_to_all(recv, send, rc, sc, self.group)
-        return req_ids, recv
+        sees them: world*capacity slots in the order it was asked (source rank, then the
+        requester's order; duplicates included), unused slots carrying id -1."""
+        slot, recv_ids, cap = self.last
+        n_slots, stride = self.world * cap, rows.shape[1]
+        send = self._scratch("back_send", (n_slots, stride), rows.dtype, rows.device)
+        if rows.is_cuda:
+            ops.scatter_rows(rows, slot, send, stride)
+        else:
+            ok = slot >= 0
+            send[slot[ok].long()] = rows[ok]
+        recv = self._scratch("back_recv", (n_slots, stride), rows.dtype, rows.device)
+        all_to_all(recv, send, self.group)
+        return recv_ids, recv
 
-    def unpermute(self, rows_in, inv, out):
-        """out[r] = rows_in[inv[r]] -- a row gather of the receive buffer."""
+    def unpermute(self, rows_in, slot, out):
+        """out[r] = rows_in[slot[r]] -- a row gather of the receive buffer."""
         if rows_in.is_cuda:
             if rows_in.element_size() == 2:          # bf16 rows move as fp32 words (bitwise copy)
                 rows_in, out = rows_in.view(torch.float32), out.view(torch.float32)
-            ops.gather_rows(rows_in, 0, inv.to(torch.int32), out.shape[1], out[:inv.numel()],
-                            normalize=False)
+            ops.gather_rows(rows_in, 0, slot, out.shape[1], out[:slot.numel()], normalize=False)
         else:
-            out[:inv.numel()] = rows_in[inv]
+            ok = slot >= 0
+            out[:slot.numel()][ok] = rows_in[slot[ok].long()]
+
+    def check_overflow(self):
+        """Host check of the device-side flag (a sync: call it off the critical path -- the
+        trainer does at its logging cadence, bench.py after the timed region)."""
+        if self.overflow is None:
+            return
+        f = int(self.overflow.item())
+        if f & 2:
+            raise IndexError("row exchange: a requested id lies outside the %d-row catalogue" % self.n_rows_global)
+        if f & 1:
+            raise RuntimeError("row exchange: a peer segment overflowed (requests are skewed towards one shard); "
+                               "raise RowExchange(capacity_factor=%.2f)" % self.capacity_factor)
+
+    def bytes_per_step(self, n_requests, x):
+        """Bytes this rank sends per step (ids out + rows back), padding included."""
+        n_slots = self.world * self.capacity(n_requests)
+        return int(n_slots * 4 + n_slots * x.shape[1] * x.element_size())
 
 
 class GradSync:
@@ -203,12 +259,17 @@ class Prefetcher:
 
     The sampler is counter-based, so the rows of step t+1 are known while step t
     computes: ``launch`` enqueues sampling + exchange for one buffer on a side
-    stream (the host sync for the all-to-all split sizes then waits only for that
-    stream, not for the 2.7 ms of GEMMs queued on the compute stream), ``acquire``
-    makes the compute stream wait for a filled buffer and ``release`` tells the
-    side stream the buffer may be overwritten.  Give the exchange its own process
-    group (communicator): collectives of one group execute in issue order, and the
-    exchange of step t+1 must not queue behind the gradient all-reduce of step t."""
+    stream (the transfer hides under step t's GEMMs), ``acquire`` makes the compute
+    stream wait for a filled buffer and ``release`` tells the side stream the buffer
+    may be overwritten.  Give the exchange its own process group (communicator):
+    collectives of one group execute in issue order, and the exchange of step t+1
+    must not queue behind the gradient all-reduce of step t.
+
+    Inside a hipGraph capture the side stream is FORKED from the capturing stream and
+    joined again before the capture ends (``join``): the graph of step t then contains the
+    exchange of step t+1 as a parallel branch, and consecutive replays are ordered by the
+    stream, so the event hand-over between steps is not needed (and could not be captured:
+    its events belong to earlier launches)."""
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -219,15 +280,26 @@ class Prefetcher:
             self.free = [torch.cuda.Event(), torch.cuda.Event()]
         self._released = [False, False]
         self._cold = True
+        self._forked = False
+
+    def _capturing(self):
+        return self.cuda and torch.cuda.is_current_stream_capturing()
 
     def launch(self, b, fill_fn):
         if not self.cuda:
             fill_fn()
             return
+        cur = torch.cuda.current_stream(self.device)
+        if self._capturing():
+            self.stream.wait_stream(cur)             # fork: the branch starts behind what is captured so far
+            with torch.cuda.stream(self.stream):
+                fill_fn()
+            self._forked = True
+            return
         if self._cold:
             # first use: everything set up on the compute stream so far (table fill,
             # uploads, weight init) must be visible to the side stream
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self.stream.wait_stream(cur)
             self._cold = False
         with torch.cuda.stream(self.stream):
             if self._released[b]:
@@ -236,10 +308,22 @@ class Prefetcher:
             self.ready[b].record(self.stream)
 
     def acquire(self, b):
-        if self.cuda:
+        if self.cuda and not self._capturing():
             torch.cuda.current_stream(self.device).wait_event(self.ready[b])
 
     def release(self, b):
-        if self.cuda:
+        if self.cuda and not self._capturing():
             self.free[b].record(torch.cuda.current_stream(self.device))
             self._released[b] = True
+
+    def join(self):
+        """End of a captured step: the forked branch rejoins the capturing stream."""
+        if self._forked:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self._forked = False
+
+    def drain(self):
+        """Make the compute stream wait for everything the side stream has been given (before
+        switching between eager steps and graph replays)."""
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)

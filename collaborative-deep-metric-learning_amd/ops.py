@@ -98,6 +98,18 @@ def sample_gather(mode, pairs, seed, step, batch, table, feature_size, idx_out, 
     return x_out
 
 
+def route_rows(ids, rows_per_shard, world, capacity, send_ids, slot_out, overflow_flag):
+    call("cdml_route_rows", _p(ids, torch.int32), ids.numel(), rows_per_shard, world, capacity,
+         _p(send_ids, torch.int32), _p(slot_out, torch.int32), _p(overflow_flag, torch.int32), _stream())
+
+
+def scatter_rows(src, slot, dst, width):
+    sp, sld = _mat(src)
+    dp, dld = _mat(dst)
+    call("cdml_scatter_rows", sp, sld, _p(slot, torch.int32), slot.numel(), width, dp, dld, _stream())
+    return dst
+
+
 # ----------------------------------------------------------------- tower ------
 def l2norm_fwd(x, n_cols, y, inv_out=None):
     xp, xld = _mat(x)

@@ -154,10 +154,12 @@ class TrainStep:
             self._select_ahead(0)
         self._graphs = {}
         self._warmed = False
-        self.use_graph = bool(use_graph) and exchange is None and grad_sync is None
-        if use_graph and not self.use_graph:
-            logging.getLogger("cdml.train").warning(
-                "use_graph ignored: the data-parallel step (exchange / grad_sync) runs eagerly")
+        # the data-parallel step is enqueue-only too (fixed-capacity exchange, no host counts), so
+        # it captures like the single-GPU one: one graph per prefetch buffer
+        self.use_graph = bool(use_graph)
+        if self.use_graph and self.train_table and exchange is not None:
+            self.use_graph = False                       # scatter_back sizes its scratch on the fly
+            logging.getLogger("cdml.train").warning("use_graph ignored: trainable sharded table runs eagerly")
         # row-sharded catalogue: the exchange of step t+1 runs ahead on a side stream
         # into the second x_hat / idx buffer while step t computes
         self.prefetch = None
@@ -349,6 +351,7 @@ class TrainStep:
         if self.prefetch is not None:                # next step's rows, under this step's GEMMs
             self.prefetch.launch(1 - b, lambda: self._fill(1 - b, t + 1))
             self._filled = t + 1
+            self.prefetch.join()                     # (inside a graph capture: the branch rejoins)
 
     # ------------------------------------------------------------------ step --
     def step(self):
@@ -359,15 +362,29 @@ class TrainStep:
             self.lr_dev.fill_(lr)
             self._lr_host = lr
         if self.use_graph and self._warmed:              # the first step of a process runs eagerly
-            off = self._ahead_offset()                   # (it loads the kernels), also after a resume
-            if off not in self._graphs:                  # one graph per position in the gather block
-                self._graphs[off] = self._capture()      # (capturing records, it does not run)
-            if self.gather_ahead > 1:
-                if off == 0:
-                    self._ahead_base = self.global_step
-                self._select_ahead(off)
-            self._graphs[off].replay()
+            t = self.global_step                         # (it loads the kernels), also after a resume
+            if self.prefetch is not None:
+                # one graph per prefetch buffer; the rows of step t were fetched by step t-1 (an
+                # eager step handed them over through an event, a replay through stream order)
+                key = t % 2
+                if self._filled != t:
+                    raise RuntimeError("graph replay needs the previous step's prefetch (step %d)" % t)
+                self.prefetch.acquire(key)
+            else:
+                key = self._ahead_offset()               # one graph per position in the gather block
+            if key not in self._graphs:
+                self._graphs[key] = self._capture()      # (capturing records, it does not run)
+            if self.prefetch is not None:
+                self.ws.x_hat, self.idx, self.shift = self._x[key], self._idx[key], self._shift[key]
+                self._filled = t + 1
+            elif self.gather_ahead > 1:
+                if key == 0:
+                    self._ahead_base = t
+                self._select_ahead(key)
+            self._graphs[key].replay()
         else:
+            if self.prefetch is not None and self._graphs:
+                self.prefetch.drain()
             self._enqueue()
             self._warmed = True
         self.global_step += 1

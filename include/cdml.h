@@ -95,12 +95,29 @@ int cdml_step_advance(uint64_t *step_dev, cdml_stream_t stream);
  * 1e-12)) : 1), columns F..out_stride-1 zeroed.  table rows have stride
  * row_stride (>= F, multiple of 4; 16-B aligned base).  inv_norm_out may be
  * NULL.  idx must lie in [row0, row0+n_rows) -- out-of-range ids are clamped
- * and flagged in *oob_flag (int32, may be NULL). */
+ * and flagged in *oob_flag (int32, may be NULL); idx == -1 marks a padding slot
+ * (fixed-capacity exchange): that output row is left untouched, nothing flagged. */
 int cdml_gather_rows(const float *table, int64_t row0, int64_t n_rows,
                      int64_t row_stride, const int32_t *idx, int n_idx, int F,
                      int normalize, float *x_out, int64_t out_stride,
                      float *inv_norm_out, int32_t *oob_flag,
                      cdml_stream_t stream);
+
+/* Row exchange over a row-sharded catalogue (multi-GPU; the reference is single-GPU,
+ * train.py:341-342 -- this fills its "distributed arguments" TODO).  Fixed capacity: every
+ * rank sends each peer `capacity` id slots and receives `capacity` row slots, so the step path
+ * needs no host-side counts (enqueue-only, hipGraph-capturable).
+ * cdml_route_rows: request r (global id ids[r], owner = id / rows_per_shard) goes to slot
+ * owner*capacity + k of send_ids (int32[world*capacity], unused slots = -1), k counting the
+ * owner's requests in ascending r; slot_out[r] = that slot (-1 if the owner's segment is full).
+ * *overflow_flag |= 1 on a full segment, |= 2 on an id outside the catalogue (check it off the
+ * critical path; a flagged step fetched wrong rows).
+ * cdml_scatter_rows: dst[slot[r]] = src[r] (slot -1 dropped): the way back, for row gradients. */
+int cdml_route_rows(const int32_t *ids, int n, int64_t rows_per_shard, int world,
+                    int capacity, int32_t *send_ids, int32_t *slot_out,
+                    int32_t *overflow_flag, cdml_stream_t stream);
+int cdml_scatter_rows(const float *src, int64_t ld_src, const int32_t *slot, int n,
+                      int width, float *dst, int64_t ld_dst, cdml_stream_t stream);
 
 /* Persistent fused sampler+gather for n_steps consecutive training steps (step, step+1, ...;
  * the sampler is counter-based, so later steps' triplets are known now and one launch can

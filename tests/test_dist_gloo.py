@@ -41,9 +41,10 @@ def _worker(rank, world, port, n_rows, F, q):
             row0, feature_size = lo, F
 
         def oracle_gather(table, ids, out):
-            rows = table.data.numpy()[ids.numpy() - table.row0]
-            out[:, :F] = torch.from_numpy(otower.l2_normalize(rows, np.float32)[0])
-            out[:, F:] = 0
+            used = ids.numpy() >= 0                                    # id -1 = padding slot: untouched
+            rows = table.data.numpy()[ids.numpy()[used] - table.row0]
+            out[torch.from_numpy(used), :F] = torch.from_numpy(otower.l2_normalize(rows, np.float32)[0])
+            out[torch.from_numpy(used), F:] = 0
             return out
 
         ex = cdist.RowExchange(n_rows, local_gather=oracle_gather)
@@ -65,7 +66,9 @@ def _worker(rank, world, port, n_rows, F, q):
             tag = torch.zeros((len(idx), 4))
             tag[:, 0], tag[:, 1], tag[:, 2] = rank, torch.arange(len(idx)), torch.from_numpy(idx.astype(np.float32))
             got_ids, got_rows = ex.scatter_back(tag)
-            assert got_ids.numel() == got_rows.shape[0]
+            assert got_ids.numel() == got_rows.shape[0] == world * ex.capacity(len(idx))
+            used = got_ids >= 0                                                # unused slots carry id -1
+            got_ids, got_rows = got_ids[used], got_rows[used]
             assert ((got_ids >= lo) & (got_ids < hi)).all()                    # only rows this rank owns
             np.testing.assert_array_equal(got_rows[:, 2].numpy(), got_ids.numpy().astype(np.float32))
             mine = got_rows[got_rows[:, 0] == rank]                            # own requests come back in order
@@ -74,10 +77,20 @@ def _worker(rank, world, port, n_rows, F, q):
             n_total = torch.tensor([got_ids.numel()])
             dist.all_reduce(n_total)
             assert int(n_total) == world * len(idx)                            # nothing lost, nothing doubled
-        # routing plan: sorted by owner, counts per owner, stable
+        ex.check_overflow()
+        # routing: per-owner segments of `cap` slots, requests in ascending order, -1 padding
         ids = torch.tensor([per + 1, 0, per, 3, 2 * per - 1], dtype=torch.int32).clamp(max=n_rows - 1)
-        send, order, counts = ex.plan(ids)
-        assert counts.tolist() == [2, 3] and send.tolist() == [0, 3, per + 1, per, min(2 * per - 1, n_rows - 1)]
+        send, slot = ex.route(ids, 4)
+        assert send.tolist() == [0, 3, -1, -1, per + 1, per, min(2 * per - 1, n_rows - 1), -1]
+        assert slot.tolist() == [4, 0, 5, 1, 6]
+        # a segment that is too small raises the flag (and only then)
+        ex.check_overflow()
+        send, slot = ex.route(ids, 2)
+        assert slot.tolist() == [2, 0, 3, 1, -1]
+        with pytest.raises(RuntimeError):
+            ex.check_overflow()
+        ex.overflow.zero_()
+        assert cdist.exchange_capacity(16384, 8) == 2840 and cdist.exchange_capacity(100, 1) == 100
         # gradient average
         sync = cdist.GradSync()
         g = torch.full((10,), float(rank + 1))

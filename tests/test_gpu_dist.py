@@ -165,7 +165,30 @@ def _nccl_worker(port, q):
         sync.finish([h])
         torch.cuda.synchronize()
         ok_avg = abs(float(g[0].item()) - (3.0 if sync.avg else 1.5)) < 1e-6
-        q.put(("ok" if (same and ok_avg) else "mismatch same=%s avg=%s g=%f" % (same, sync.avg, float(g[0].item()))))
+        ex.check_overflow()
+        # the data-parallel step captured into hipGraphs (one per prefetch buffer): RCCL all-to-all
+        # on the forked prefetch stream + async all-reduce inside the capture == the eager step
+        graph_msg = "ok"
+        try:
+            sync1 = cdist.GradSync(device=dev)
+            mk = lambda g_: train.TrainStep(ts.table, ts.pairs, 2 * CFG["B"], hidden_size=CFG["H"],
+                                            output_size=CFG["D"], mode="uniform", device=dev,
+                                            exchange=cdist.RowExchange(CFG["n_rows"], group=dist.new_group()),
+                                            grad_sync=sync1, batch_global=2 * CFG["B"], use_graph=g_)
+            e1, g1 = mk(False), mk(True)
+            for _ in range(6):
+                e1.step(); g1.step()
+            torch.cuda.synchronize()
+            if len(g1._graphs) != 2:
+                graph_msg = "expected 2 captured graphs, got %d" % len(g1._graphs)
+            elif not (torch.equal(e1.params.flat, g1.params.flat) and torch.equal(e1.idx, g1.idx)
+                      and int(g1.step_dev.item()) == 6):
+                graph_msg = "graph replay differs from eager: %g" % float((e1.params.flat - g1.params.flat).abs().max())
+        except Exception:
+            import traceback
+            graph_msg = "graph capture of the data-parallel step failed: " + traceback.format_exc()[-1500:]
+        ok = same and ok_avg and graph_msg == "ok"
+        q.put("ok" if ok else "mismatch same=%s avg=%s g=%f graph=%s" % (same, sync.avg, float(g[0].item()), graph_msg))
         dist.destroy_process_group()
     except Exception:
         import traceback

@@ -138,6 +138,76 @@ def test_gather_shard_and_oob_flag(cd):
     assert int(flag.item()) == 1
 
 
+def test_route_and_scatter_rows(cd):
+    """Fixed-capacity routing of the row exchange: per-owner segments filled in ascending request
+    order, -1 padding, overflow / bad-id flags; the scatter is the inverse of the gather by slot;
+    gather_rows leaves -1 slots untouched."""
+    rng = np.random.RandomState(0)
+    for world, n, per, cap in ((8, 24576, 1250000, 4184), (2, 96, 1500, 96), (3, 5000, 700, 1800), (1, 300, 10 ** 6, 300)):
+        ids = rng.randint(0, per * world, size=n).astype(np.int32)
+        send = torch.zeros(world * cap, dtype=torch.int32, device=cd.dev)
+        slot = torch.zeros(n, dtype=torch.int32, device=cd.dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=cd.dev)
+        cd.ops.route_rows(dt(ids, cd.dev, torch.int32), per, world, cap, send, slot, flag)
+        owner = ids // per
+        want_send = np.full(world * cap, -1, np.int32)
+        want_slot = np.zeros(n, np.int32)
+        cnt = np.zeros(world, np.int64)
+        for r in range(n):
+            want_slot[r] = owner[r] * cap + cnt[owner[r]]
+            want_send[want_slot[r]] = ids[r]
+            cnt[owner[r]] += 1
+        assert cnt.max() <= cap and int(flag.item()) == 0
+        np.testing.assert_array_equal(send.cpu().numpy(), want_send)
+        np.testing.assert_array_equal(slot.cpu().numpy(), want_slot)
+        # rows travel by slot and come back by slot
+        rows = torch.as_tensor(rng.randn(n, 64).astype(np.float32)).to(cd.dev)
+        buf = torch.full((world * cap, 64), -5.0, device=cd.dev)
+        cd.ops.scatter_rows(rows, slot, buf, 64)
+        back = torch.full((n, 64), 9.0, device=cd.dev)
+        cd.ops.gather_rows(buf, 0, slot, 64, back, normalize=False)
+        assert torch.equal(back, rows)
+        pad = torch.as_tensor(want_send == -1).to(cd.dev)
+        assert bool((buf[pad] == -5.0).all())                       # padding slots untouched
+        out = torch.full((world * cap, 64), 3.0, device=cd.dev)
+        tbl = torch.as_tensor(rng.randn(per * world if per * world < 10000 else 10000, 64).astype(np.float32)).to(cd.dev)
+        cd.ops.gather_rows(tbl, 0, torch.clamp(send, max=tbl.shape[0] - 1), 64, out, normalize=False)
+        assert bool((out[pad] == 3.0).all())                        # gather skips id -1
+    # a full segment and an id outside the catalogue raise the flag bits
+    ids = dt(np.array([0, 1, 2, 3, 4, 2500], np.int32), cd.dev, torch.int32)
+    send = torch.zeros(8, dtype=torch.int32, device=cd.dev)
+    slot = torch.zeros(6, dtype=torch.int32, device=cd.dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=cd.dev)
+    cd.ops.route_rows(ids, 1000, 2, 4, send, slot, flag)
+    assert int(flag.item()) == 3 and slot.cpu().tolist() == [0, 1, 2, 3, -1, -1]
+
+
+@pytest.mark.parametrize("n_steps", [2, 3])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sample_gather_several_steps_per_launch(cd, mode, n_steps):
+    """One launch for steps t..t+n-1 == n single-step launches (ids, shift and rows, bit for bit)."""
+    N, F, B = 3000, 1500, 133
+    table = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev)
+    pairs = dt(osynth.cowatch_pairs(N, 300, 0), cd.dev, torch.int32)
+    rpt = 3 if mode == 0 else 2
+    R = B * rpt
+    x = torch.full((n_steps, R, 1536), -1.0, device=cd.dev)
+    idx = torch.full((n_steps, R), -1, dtype=torch.int32, device=cd.dev)
+    shift = torch.full((n_steps,), -1, dtype=torch.int32, device=cd.dev)
+    step_dev = torch.tensor([7], dtype=torch.int64, device=cd.dev)
+    cd.ops.sample_gather(mode, pairs, 1234, None, B, table.data, F, idx, x, shift_out=shift, slot0=5,
+                         batch_global=B + 9, step_dev=step_dev, n_steps=n_steps)
+    for s in range(n_steps):
+        x1 = torch.full((R, 1536), -1.0, device=cd.dev)
+        i1 = torch.full((R,), -1, dtype=torch.int32, device=cd.dev)
+        s1 = torch.full((1,), -1, dtype=torch.int32, device=cd.dev)
+        cd.ops.sample_gather(mode, pairs, 1234, 7 + s, B, table.data, F, i1, x1, shift_out=s1, slot0=5,
+                             batch_global=B + 9)
+        assert torch.equal(i1, idx[s]) and torch.equal(x1, x[s])
+        if mode == 1:
+            assert int(s1.item()) == int(shift[s].item())
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_fused_sample_gather_equals_separate(cd, mode):
     N, F, B = 2000, 1500, 130

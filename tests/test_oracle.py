@@ -365,3 +365,31 @@ def test_etl_oracle_matches_reference_cowatch_graph(golden_dir):
     assert len(g["select_t1"]) == len(g["cowatches"]) > len(g["select_t2"]) > len(g["select_t5"]) > 0
     with pytest.raises(RuntimeError):
         etl.cowatch_graph([[1, 2], [3, 3]])
+
+
+def test_torch_cpu_step_equals_numpy_oracle():
+    """oracle/tower_torch.py (the CPU baseline that bench.py times) is the same step as
+    oracle/tower.py: embeddings, loss, gradients and the TF-form Adam update."""
+    from oracle import tower_torch
+    rng = np.random.RandomState(0)
+    N, F, H, D, B = 300, 40, 50, 16, 8
+    table = rng.random_sample((N, F)).astype(np.float32)
+    pairs = synth.cowatch_pairs(N, 40, 0)
+    st = tower_torch.CpuStep(table, pairs, B, hidden=H, out=D, margin=0.8, lr=0.01)
+    W = [w.detach().numpy().copy() for w in st.W]
+    idx = st.sample()
+    assert idx.shape == (B, 3) and np.array_equal(idx[:, :2], pairs[:B])
+    assert np.all(idx[:, 2] != idx[:, 0]) and np.all(idx[:, 2] != idx[:, 1])      # the reference's rule
+    x = st.fetch(idx)
+    np.testing.assert_array_equal(x.numpy(), sampler.gather(table, idx).reshape(-1, F))
+    e, loss, grads = st.train(x)
+    fwd, wl, wg = tower.train_step_grads(x.numpy().astype(np.float64), [w.astype(np.float64) for w in W], 0.8,
+                                          np.float64)
+    np.testing.assert_allclose(e.detach().numpy(), fwd["l2_norm"], atol=1e-6)
+    assert abs(loss - float(wl["hinge_loss"])) < 1e-6
+    for g, k, w0, w1 in zip(grads, ("dW1", "db1", "dW2", "db2"), W, st.W):
+        np.testing.assert_allclose(g.numpy(), wg[k], atol=1e-6)
+        want, _, _ = tower.adam_step(w0, g.numpy(), 0 * w0, 0 * w0, 1, 0.01, dtype=np.float32)
+        np.testing.assert_allclose(w1.detach().numpy(), want, atol=1e-6)
+    tf, tt, n = tower_torch.time_steps(st, 4, 0.5, 1)
+    assert n >= 3 and tf > 0 and tt > 0
