@@ -81,6 +81,8 @@ SIGNATURES = {
     "cdml_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _i64, _p, _i, _p, _p]),
     "cdml_table_adam_rows": (_i, [_p, _i64, _i64, _i64, _i, _p, _i, _p, _i64, _p, _p, _p, _p, _f, _f, _p, _f, _f, _f,
                                   _i64, _p, _p]),
+    "cdml_grad_prepare": (_i, [_p, _p, _i64, _f, _f, _p, _p, _p]),
+    "cdml_momentum_step": (_i, [_p, _p, _p, _i64, _f, _p, _f, _i, _p]),
     "cdml_lars_scratch_floats": (_sz, []),
     "cdml_lars_step": (_i, [_p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p, _p]),
 }

@@ -124,6 +124,62 @@ k_lars_apply(float *__restrict__ w, const float *__restrict__ g, float *__restri
   }
 }
 
+// ---- build_graph's gradient options (train.py:133-145), off in the reference's own run -------
+// One variable at a time, in place, before the optimizer:
+//   g <- g + l2_scale * w                 the slim l2_regularizer term of a weight matrix
+//                                         (models.py:28: 1e-8 * |W|^2 / 2, times regularization_penalty)
+//   g <- g * clip / max(|g|_2, clip)      tf.clip_by_norm per variable (train.py:47-64)
+// Pass 1 (k_prep_partial + k_lars_norm_final): |g + l2_scale*w|^2 and |w|^2, two-stage, fixed order.
+__global__ void __launch_bounds__(kThreads)
+k_prep_partial(const float *__restrict__ w, const float *__restrict__ g, int64_t n, float l2_scale,
+               float *__restrict__ scratch) {
+  __shared__ double s[2][kThreads / kWave];
+  float sw = 0.f, sg = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float a = w[i], b = g[i] + l2_scale * a;
+    sw += a * a;
+    sg += b * b;
+  }
+  sw = wave_sum(sw);
+  sg = wave_sum(sg);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  if (lane == 0) { s[0][wave] = sw; s[1][wave] = sg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int k = 0; k < kThreads / kWave; ++k) { a += s[0][k]; b += s[1][k]; }
+    scratch[2 + 2 * blockIdx.x] = (float)a;
+    scratch[3 + 2 * blockIdx.x] = (float)b;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_prep_apply(float *__restrict__ g, const float *__restrict__ w, int64_t n, float l2_scale, float clip,
+             const float *__restrict__ scratch, float *__restrict__ norms_out) {
+  const float gn = sqrtf(scratch[1]);
+  const float scale = (clip > 0.f) ? clip / fmaxf(gn, clip) : 1.0f;
+  if (norms_out && blockIdx.x == 0 && threadIdx.x == 0) { norms_out[0] = gn; norms_out[1] = scratch[0]; }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    g[i] = (g[i] + l2_scale * w[i]) * scale;
+}
+
+// tf.train.MomentumOptimizer(lr, momentum, use_nesterov) (train.py:115-116), TF's ApplyMomentum:
+// accum = accum*momentum + g;  w -= nesterov ? g*lr + accum*momentum*lr : accum*lr
+__global__ void __launch_bounds__(kThreads)
+k_momentum(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ acc, int64_t n,
+           float lr_imm, const float *__restrict__ lr_dev, float momentum, int nesterov) {
+  const float lr = lr_dev ? *lr_dev : lr_imm;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float a = acc[i] * momentum + gi;
+    acc[i] = a;
+    w[i] -= nesterov ? (gi * lr + a * momentum * lr) : (a * lr);
+  }
+}
+
 int grid_elems(int64_t n, int per_thread) {
   int64_t b = (n / per_thread + kThreads - 1) / kThreads;
   if (b > kNumCU * 8) b = kNumCU * 8;
@@ -167,4 +223,26 @@ extern "C" int cdml_lars_step(float *w, const float *g, float *acc, int64_t n, f
   hipLaunchKernelGGL(k_lars_apply, dim3(grid_elems(n, 4)), dim3(kThreads), 0, s, w, g, acc, n, lr,
                      lr_dev, momentum, weight_decay, eeta, eps, scratch);
   return check_launch("lars_step");
+}
+
+extern "C" int cdml_grad_prepare(float *g, const float *w, int64_t n, float l2_scale, float clip_norm,
+                                 float *scratch, float *norms_out, cdml_stream_t stream) {
+  CDML_REQUIRE(g && w && scratch && n > 0, CDML_E_BADARG, "grad_prepare: bad argument");
+  int blocks = grid_elems(n, 8);
+  if (blocks > kLarsBlocks) blocks = kLarsBlocks;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_prep_partial, dim3(blocks), dim3(kThreads), 0, s, w, g, n, l2_scale, scratch);
+  hipLaunchKernelGGL(k_lars_norm_final, dim3(1), dim3(64), 0, s, scratch, blocks);
+  hipLaunchKernelGGL(k_prep_apply, dim3(grid_elems(n, 4)), dim3(kThreads), 0, s, g, w, n, l2_scale, clip_norm,
+                     scratch, norms_out);
+  return check_launch("grad_prepare");
+}
+
+extern "C" int cdml_momentum_step(float *w, const float *g, float *acc, int64_t n, float lr,
+                                  const float *lr_dev, float momentum, int use_nesterov,
+                                  cdml_stream_t stream) {
+  CDML_REQUIRE(w && g && acc && n > 0, CDML_E_BADARG, "momentum_step: bad argument");
+  hipLaunchKernelGGL(k_momentum, dim3(grid_elems(n, 4)), dim3(kThreads), 0, (hipStream_t)stream, w, g, acc, n, lr,
+                     lr_dev, momentum, use_nesterov);
+  return check_launch("momentum_step");
 }

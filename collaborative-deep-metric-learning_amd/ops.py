@@ -404,6 +404,16 @@ def table_adam_rows(table, row0, F, idx, grad_xhat, m_table, v_table, head, nxt,
          eps, 0 if t is None else t, _p(t_dev, torch.int64), _stream())
 
 
+def grad_prepare(g, w, l2_scale, clip_norm, scratch, norms_out=None):
+    """In place on one variable: g += l2_scale*w, then tf.clip_by_norm(g, clip_norm)."""
+    call("cdml_grad_prepare", _p(g), _p(w), g.numel(), l2_scale, clip_norm, _p(scratch), _p(norms_out), _stream())
+
+
+def momentum_step(w, g, acc, lr, momentum=0.9, use_nesterov=True, lr_dev=None):
+    call("cdml_momentum_step", _p(w), _p(g), _p(acc), w.numel(), lr, _p(lr_dev), momentum,
+         1 if use_nesterov else 0, _stream())
+
+
 def lars_scratch_floats():
     return int(load_library().cdml_lars_scratch_floats())
 

@@ -42,7 +42,8 @@ class TrainStep:
                  base_learning_rate=0.01, learning_rate_decay_examples=1000000,
                  learning_rate_decay=0.96, seed=1234, weight_seed=42, device="cuda:0",
                  exchange=None, grad_sync=None, slot0=0, batch_global=None, use_graph=False,
-                 prefetch=True, precision="f32", train_table=False, gather_ahead=2):
+                 prefetch=True, precision="f32", train_table=False, gather_ahead=2,
+                 clip_gradient_norm=0.0, regularization_penalty=0.0, l2_penalty=1e-8):
         """table: FeatureTable (whole catalogue, or this rank's shard when
         ``exchange`` is given); pairs: int32 [P,2] device tensor; ``exchange`` /
         ``grad_sync``: the multi-GPU hooks of cdml_amd.dist (None on one GPU).
@@ -50,11 +51,16 @@ class TrainStep:
         shard; build-defined -- the reference keeps the features frozen, train.py:265).
         ``gather_ahead``: steps fetched per launch of the fused sampler+gather (single-GPU fp32
         path): the sampler is counter-based, so one launch samples and gathers the rows of
-        this step and the next gather_ahead-1 into their own buffers."""
+        this step and the next gather_ahead-1 into their own buffers.
+        ``clip_gradient_norm`` / ``regularization_penalty``: build_graph's switches
+        (train.py:133-145; the reference's run passes 0 for both, train.py:221-222): per-variable
+        tf.clip_by_norm, and penalty * sum_W l2_penalty*|W|^2/2 added to the loss (models.py:28).
+        ``optimizer``: "adam" (build_graph's default), "lars" (what the reference's main() uses,
+        train.py:354) or "momentum" (Nesterov, momentum 0.9: train.py:115-116)."""
         if mode not in _MODES:
             raise ValueError("mode must be 'uniform', 'inbatch' or 'semihard'")
-        if optimizer not in ("adam", "lars"):
-            raise ValueError("optimizer must be 'adam' or 'lars'")
+        if optimizer not in ("adam", "lars", "momentum"):
+            raise ValueError("optimizer must be 'adam', 'lars' or 'momentum'")
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is not None \
                 and torch.cuda.current_device() != self.device.index:
@@ -126,7 +132,11 @@ class TrainStep:
             self.v = torch.zeros(n, dtype=f32, device=dev)
         else:
             self.acc = torch.zeros(n, dtype=f32, device=dev)
-            self.lars_scratch = torch.zeros(ops.lars_scratch_floats(), dtype=f32, device=dev)
+        self.lars_scratch = torch.zeros(ops.lars_scratch_floats(), dtype=f32, device=dev)
+        self.clip_gradient_norm = float(clip_gradient_norm)
+        self.reg_scale = float(regularization_penalty) * float(l2_penalty)
+        self.l2_penalty = float(l2_penalty)
+        self.grad_norms = torch.zeros((4, 2), dtype=f32, device=dev)   # per variable: |g|, |w|^2
         self.train_table = bool(train_table)
         if self.train_table:
             if self.bf16 or optimizer != "adam":
@@ -173,14 +183,19 @@ class TrainStep:
 
     # ---------------------------------------------------------------- pieces --
     def _fill(self, b, step):
-        """Sample step `step` (immediate, it runs ahead of the device counter) and
-        exchange its rows into buffer b."""
+        """Sample step `step` and exchange its rows into buffer b.  Eager: the step is an
+        immediate (the side stream runs ahead of the device counter).  Inside a graph capture the
+        branch is forked behind the optimizer, which has advanced the device counter to exactly
+        this step, so the captured kernels read it from there and replays follow it."""
+        sd = None
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            step, sd = None, self.step_dev
         if _MODES[self.mode] == MODE_UNIFORM:
             ops.sample_uniform(self.pairs, self.table.n_rows_global, self.seed, step, self.B,
-                               self._idx[b], slot0=self.slot0, batch_global=self.batch_global)
+                               self._idx[b], slot0=self.slot0, batch_global=self.batch_global, step_dev=sd)
         else:
             ops.sample_inbatch(self.pairs, self.seed, step, self.B, self._idx[b], self._shift[b],
-                               slot0=self.slot0, batch_global=self.batch_global)
+                               slot0=self.slot0, batch_global=self.batch_global, step_dev=sd)
         self.exchange.gather(self.table, self._idx[b], self._x[b])
 
     def _ahead_offset(self):
@@ -310,13 +325,25 @@ class TrainStep:
                             self.tab_head, self.tab_next, 0.0, 1, lr_dev=self.lr_dev, t_dev=self.step_dev,
                             grad_scale=1.0 / world)
 
+    def reg_loss(self):
+        """build_graph's reg_loss summary (train.py:133-136): sum over the weight matrices of
+        l2_penalty*|W|^2/2, as of the last step (needs regularization_penalty or clipping on)."""
+        n = self.grad_norms.cpu()
+        return float(self.l2_penalty * (n[0, 1] + n[2, 1]) / 2.0)
+
     def apply_gradients(self):
         p = self.params
+        if self.clip_gradient_norm > 0.0 or self.reg_scale != 0.0:
+            for i, (off, n) in enumerate(p.segments()):    # W1, b1, W2, b2: weights carry the regulariser
+                ops.grad_prepare(p.grad[off:off + n], p.flat[off:off + n], self.reg_scale if i % 2 == 0 else 0.0,
+                                 self.clip_gradient_norm, self.lars_scratch, self.grad_norms[i])
         if self.optimizer == "adam":
             # the step counter advances inside the same launch unless something after it (the
             # bf16 weight refresh is fine, LARS is not on this branch) still reads it
             ops.adam_step(p.flat, p.grad, self.m, self.v, 0.0, 1, lr_dev=self.lr_dev,
                           t_dev=self.step_dev, advance_tickets=self.adam_tickets)
+        elif self.optimizer == "momentum":
+            ops.momentum_step(p.flat, p.grad, self.acc, 0.0, 0.9, True, lr_dev=self.lr_dev)
         else:
             for off, n in p.segments():       # LARS trust ratio is per variable
                 ops.lars_step(p.flat[off:off + n], p.grad[off:off + n], self.acc[off:off + n],
@@ -395,7 +422,9 @@ class TrainStep:
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            # thread-local capture mode: the RCCL watchdog thread of torch.distributed may touch
+            # the runtime while this thread captures
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 self._enqueue()
         torch.cuda.current_stream(self.device).wait_stream(side)
         return g

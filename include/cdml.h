@@ -376,6 +376,23 @@ int cdml_adam_step(float *w, const float *g, float *m, float *v, int64_t n,
                    float eps, int64_t t, uint64_t *t_dev, int advance_step,
                    uint32_t *tickets, cdml_stream_t stream);
 
+/* build_graph's gradient options (train.py:133-145; both off in the reference's own run,
+ * train.py:221-222), applied to ONE variable in place before its optimizer step:
+ *   g <- g + l2_scale*w    slim.l2_regularizer of a weight matrix (models.py:28: 1e-8*|W|^2/2)
+ *                          times regularization_penalty; pass 0 for biases
+ *   g <- g * clip_norm / max(|g|_2, clip_norm)      tf.clip_by_norm (clip_norm <= 0: off)
+ * scratch: float[cdml_lars_scratch_floats()].  norms_out (nullable) float[2] = {|g|_2 after the
+ * regulariser and before clipping, |w|_2^2 (for the reg_loss summary)}. */
+int cdml_grad_prepare(float *g, const float *w, int64_t n, float l2_scale,
+                      float clip_norm, float *scratch, float *norms_out,
+                      cdml_stream_t stream);
+
+/* tf.train.MomentumOptimizer(lr, momentum=0.9, use_nesterov=True) (train.py:115-116), TF's
+ * ApplyMomentum: acc = acc*momentum + g;  w -= nesterov ? g*lr + acc*momentum*lr : acc*lr. */
+int cdml_momentum_step(float *w, const float *g, float *acc, int64_t n, float lr,
+                       const float *lr_dev, float momentum, int use_nesterov,
+                       cdml_stream_t stream);
+
 /* Trainable catalogue rows (north_star: "the catalogue feature table and its Adam states
  * shard row-wise"; the reference keeps the features frozen, train.py:265, so this is
  * build-defined and off by default; spec oracle/table.py).  grad_xhat[r] = dLoss/d x_hat of

@@ -249,6 +249,40 @@ def lars_step(w, g, acc, lr, momentum=0.9, weight_decay=1e-4, eeta=1e-3,
     return w, acc
 
 
+def clip_by_norm(g, clip_norm, dtype=np.float32):
+    """tf.clip_by_norm (train.py:47-64 applies it per variable): g * clip / max(|g|_2, clip)."""
+    g = np.asarray(g, dtype)
+    n = np.sqrt(np.sum(np.square(g), dtype=dtype))
+    return (g * (dtype(clip_norm) / np.maximum(n, dtype(clip_norm)))).astype(dtype)
+
+
+def regularized_grads(grads, params, regularization_penalty, l2_penalty=1e-8, dtype=np.float32):
+    """final_loss = regularization_penalty * reg_loss + loss (train.py:133-139) with reg_loss =
+    sum over the weight matrices of slim.l2_regularizer(l2_penalty)(W) = l2_penalty*|W|^2/2
+    (models.py:28; biases carry no regulariser): dW += penalty*l2_penalty*W.  Returns
+    (grads incl. the term as a dict like vnet_backward's, reg_loss)."""
+    W1, _, W2, _ = [np.asarray(p, dtype) for p in params]
+    s = dtype(regularization_penalty) * dtype(l2_penalty)
+    out = dict(grads)
+    out["dW1"] = (np.asarray(grads["dW1"], dtype) + s * W1).astype(dtype)
+    out["dW2"] = (np.asarray(grads["dW2"], dtype) + s * W2).astype(dtype)
+    reg = dtype(l2_penalty) * (np.sum(np.square(W1), dtype=dtype) + np.sum(np.square(W2), dtype=dtype)) / dtype(2)
+    return out, dtype(reg)
+
+
+def momentum_step(w, g, acc, lr, momentum=0.9, use_nesterov=True, dtype=np.float32):
+    """tf.train.MomentumOptimizer(lr, momentum=0.9, use_nesterov=True) (train.py:115-116), TF's
+    ApplyMomentum functor: acc = acc*momentum + g; w -= g*lr + acc*momentum*lr (Nesterov) or
+    acc*lr.  Restated from the op's definition; parity unpinned (no TF here)."""
+    w, g, acc = (np.asarray(a, dtype) for a in (w, g, acc))
+    acc = (acc * dtype(momentum) + g).astype(dtype)
+    if use_nesterov:
+        w = w - (g * dtype(lr) + acc * dtype(momentum) * dtype(lr))
+    else:
+        w = w - acc * dtype(lr)
+    return w.astype(dtype), acc
+
+
 def xavier_uniform(rng, fan_in, fan_out, dtype=np.float32):
     """slim's default weights_initializer (xavier, uniform): U(+-sqrt(6/(in+out)))."""
     lim = np.sqrt(6.0 / (fan_in + fan_out))

@@ -357,7 +357,9 @@ def test_gradients_well_conditioned_production_shape(cd, mode, precision, bar):
         if grads is None:
             continue
         checked += 1
-        assert n_amb < (50 if precision == "f32" else 0.02 * fwd["layer_1"].size), n_amb
+        # (leaky-relu halves the distance to 0 five-fold on the negative side: |h| < band is a
+        # few 1e-4 of the entries in fp32, a few % at the bf16 band)
+        assert n_amb < (3e-4 if precision == "f32" else 0.06) * fwd["layer_1"].size, n_amb
         for got, k in zip(ts.params.unpadded(grads=True), names):
             assert np.linalg.norm(grads[k]) > 1e-4, (k, step, "gradient vanished: test is ill-conditioned")
             r = _rel_l2(got.cpu().numpy(), grads[k])

@@ -65,7 +65,7 @@ def test_table_adam_rows_vs_oracle(cd, F, stride):
                                           5, 0.01, row0=row0)
     np.testing.assert_allclose(m3.cpu().numpy()[:, :F], wm3, atol=1e-7)
     np.testing.assert_allclose(v3.cpu().numpy()[:, :F], wv3, atol=1e-9)
-    np.testing.assert_allclose(d3.cpu().numpy()[:, :F], w3, atol=2e-6)
+    np.testing.assert_allclose(d3.cpu().numpy()[:, :F], w3, atol=5e-6)
     assert not np.allclose(m3.cpu().numpy()[touched, :F], got_m[touched, :F], atol=1e-7)
 
 

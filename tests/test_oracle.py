@@ -393,3 +393,37 @@ def test_torch_cpu_step_equals_numpy_oracle():
         np.testing.assert_allclose(w1.detach().numpy(), want, atol=1e-6)
     tf, tt, n = tower_torch.time_steps(st, 4, 0.5, 1)
     assert n >= 3 and tf > 0 and tt > 0
+
+
+def test_build_graph_switches_of_the_oracle():
+    """regularization_penalty and clip_gradient_norm (train.py:133-145) and calc_var
+    (train.py:67-71) against torch autograd / their definitions."""
+    rng = np.random.RandomState(2)
+    x, params = _rand_problem(rng, B=6, F=20, H=30, D=8) if "_rand_problem" in globals() else (None, None)
+    if x is None:
+        x = rng.random_sample((18, 20))
+        params = [tower.xavier_uniform(rng, 20, 30, np.float64), rng.randn(30) * 0.1,
+                  tower.xavier_uniform(rng, 30, 8, np.float64), rng.randn(8) * 0.1]
+    fwd, loss, grads = tower.train_step_grads(x, params, 0.8, np.float64)
+    reg_g, reg = tower.regularized_grads(grads, params, 7.0, l2_penalty=0.01, dtype=np.float64)
+    W = [torch.tensor(p, dtype=torch.float64, requires_grad=True) for p in params]
+    l2n = lambda t: t * torch.rsqrt(torch.clamp((t * t).sum(-1, keepdim=True), min=1e-12))
+    lre = lambda t: torch.maximum(0.2 * t, t)
+    e = l2n(lre(lre(l2n(torch.tensor(x)) @ W[0] + W[1]) @ W[2] + W[3])).view(-1, 3, 8)
+    hinge = torch.clamp(((e[:, 0] - e[:, 1]) ** 2).sum(-1) - ((e[:, 0] - e[:, 2]) ** 2).sum(-1) + 0.8, min=0).mean()
+    reg_t = 0.01 * ((W[0] ** 2).sum() + (W[2] ** 2).sum()) / 2          # slim.l2_regularizer = scale * l2_loss
+    (7.0 * reg_t + hinge).backward()                                     # train.py:139
+    assert abs(float(reg_t) - float(reg)) < 1e-12
+    for w, k in zip(W, ("dW1", "db1", "dW2", "db2")):
+        np.testing.assert_allclose(w.grad.numpy(), reg_g[k], atol=1e-10)
+    g = rng.randn(50)
+    for clip in (0.1, 100.0):
+        c = tower.clip_by_norm(g, clip, np.float64)
+        np.testing.assert_allclose(c, torch.nn.functional.normalize(torch.tensor(g), dim=0).numpy() * min(clip, np.linalg.norm(g)),
+                                   atol=1e-12)
+    t = rng.randn(5, 3, 4)
+    mean = t.reshape(15, 4).mean(0)                                       # reduce_mean over axis [0,1]
+    assert abs(float(tower.calc_var(t, np.float64)) - float(((t - mean) ** 2).mean())) < 1e-12
+    w, a = tower.momentum_step(np.ones(3), np.full(3, 0.5), np.full(3, 2.0), 0.1, 0.9, True, np.float64)
+    np.testing.assert_allclose(a, 2.3)                                    # 2*0.9 + 0.5
+    np.testing.assert_allclose(w, 1 - (0.05 + 2.3 * 0.9 * 0.1))
