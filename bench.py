@@ -120,6 +120,23 @@ def pmc_traffic(kernel):
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask and the cgroup CPU quota (a GPU
+    box hands one job a share of the host; 256 torch threads on a 16-core share crawl)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -143,7 +160,7 @@ def cpu_baseline(full=False):
     from oracle import synth as osynth, tower_torch
     table = osynth.features_numpy(10000, F, seed=0).astype(np.float32)
     pairs = osynth.cowatch_pairs(10000, 3000, 0)
-    all_threads = os.cpu_count() or 1
+    all_threads = usable_cores()
     prev = torch.get_num_threads()
     runs = []
     for threads, B, budget, warm in ((all_threads, 128, 3.0, 5), (all_threads, 1024, 6.0, 3),
@@ -156,7 +173,7 @@ def cpu_baseline(full=False):
     torch.set_num_threads(prev)
     head = runs[1]                                   # production batch on all threads
     return {"value": head["triplets_per_s"], "unit": "triplets/s", "cores": all_threads, "kind": "port",
-            "cpu": cpu_model(),
+            "cpu": cpu_model(), "host_cpu_count": os.cpu_count(),
             "sample": "CPU restatement of the TF1 path (oracle/tower_torch.py: numpy gather + torch-CPU fp32 "
                       "tower/loss/backward/Adam), config-0 table 10000x1500, uniform negatives; value = B=1024 on "
                       "%d threads, median of %d timed steps (fetch %.1f ms + train %.1f ms); all four runs in `runs`"
@@ -289,6 +306,7 @@ def main():
             else:
                 patch("fc_lrelu_fwd", lambda x, W, b, y, M, K, N, *a, **k: "fc1_fwd" if N == L.Hp else "fc2_fwd")
                 patch("fc_bwd_weight", lambda x, dy, dW, db, ws, M, K, N: "dW1" if N == L.Hp else "dW2")
+                patch("fc_bwd_weight2", "dW")             # single GPU: both products in one stream-K launch
                 patch("fc_bwd_data", "dH1")
             patch("adam_step", "adam")
             patch("vnet_tail", "tail")
@@ -376,13 +394,19 @@ def main():
         flops_gemm = 2.0 * R * F * H
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
         kname = "k_gemm_bf16_256<true, 3>" if bf16 else "k_gemm_f32<false, false, 2, 2, 3,"
-        if timers_on and kt.count("dW1") and kt.count("dW2") and kt.count("fc1_fwd"):
-            n_launch = kt.count("dW1") + kt.count("dW2")
-            t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
+        have_dw = kt.count("dW") or (kt.count("dW1") and kt.count("dW2"))
+        if timers_on and have_dw and kt.count("fc1_fwd"):
             sampled = (args.steps + 3) // 4
+            if kt.count("dW"):                          # stream-K: dW1 and dW2 (+ the fix-up pass) in one call
+                n_launch, t_ms = kt.count("dW"), kt.mean_ms("dW")
+                kname, klabel = "k_gemm_f32_sk", "k_gemm_f32_sk (dW1+dW2 in one stream-K launch, fix-up pass included)"
+            else:
+                n_launch = kt.count("dW1") + kt.count("dW2")
+                t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
+                klabel = kname + (" ...> (dW1+dW2 launches)" if not bf16 else " (dW1+dW2 launches)")
             flop_launch = sampled * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
             ach = flop_launch / (t_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": kname + " ...> (dW1+dW2 launches)" if not bf16 else kname + " (dW1+dW2 launches)",
+            out["roofline"] = {"bound": "mfma", "kernel": klabel,
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4),
                                "traffic": pmc_traffic(kname) if world == 1 else None,
@@ -395,7 +419,7 @@ def main():
                                        "frac": round(ach1 / peak, 4), "traffic": pmc_traffic(k1) if world == 1 else None,
                                        "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": flops_gemm}
             kern = {}
-            for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW1", "dW2", "adam"):
+            for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "adam"):
                 if kt.mean_ms(k) is not None:
                     kern[k + "_ms"] = round(kt.mean_ms(k), 4)
             kern["empty_event_pair_ms"] = round(kt.overhead_ms, 5)      # included in the figures above

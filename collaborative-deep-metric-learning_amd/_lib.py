@@ -49,6 +49,9 @@ SIGNATURES = {
     "cdml_fc_bwd_data": (_i, [_p, _i64, _p, _i64, _p, _i64, _f, _i, _i, _i, _p, _i64, _p]),
     "cdml_fc_bwd_weight_workspace": (_sz, [_i, _i, _i]),
     "cdml_fc_bwd_weight": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _sz, _p]),
+    "cdml_fc_bwd_weight2_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "cdml_fc_bwd_weight2": (_i, [_p, _i64, _p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p, _i64, _i, _i, _p, _i64, _p,
+                                 _i, _p, _sz, _p]),
     "cdml_triplet_hinge": (_i, [_p, _i64, _i, _i, _f, _p, _p, _p, _p, _p, _i64, _p]),
     "cdml_triplet_hinge_inbatch": (_i, [_p, _i64, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p,
                                         _i64, _p]),

@@ -42,17 +42,24 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (groups of 32 blocks, then one top word) keep every word at <= 64 arrivals.  tickets:
 // uint32[kTicketWords], zero before the first launch; the last arrivers reset them, so one
 // buffer serves every later launch of the same kernel on the same stream.
-// Memory order (MI355X_MICROARCH.md, inter-workgroup visibility): every wave drains its own
-// stores, the block's lane 0 releases at agent scope BEFORE the relaxed atomic, and the last
-// block acquires at agent scope AFTER it, then the block barrier publishes that to its waves.
+// NO FENCES here (an agent-scope release per block is an L2 write-back per block: it cost the
+// 2048-block Adam launch 100 us).  Whatever the last block reads from the others must therefore
+// travel write-through: stored with st_sc1 (every storing wave drains its stores, the block
+// barrier comes before lane 0's ticket -- both done here) and loaded with ld_sc1, which bypasses
+// this CU's L1 and the XCD's non-coherent L2 lines (MI355X_MICROARCH.md, inter-workgroup
+// visibility: "sc1 stores and loads both sides").
 constexpr int kTicketWords = 80;          // 1 top + up to 64 groups (grids <= 2048 blocks) + slack
+__device__ __forceinline__ void st_sc1(float *p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ bool grid_last_block(uint32_t *tickets) {
   __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's (write-through) stores have landed
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned nb = gridDim.x, g = blockIdx.x >> 5, ngroups = (nb + 31) >> 5;
     const unsigned gsize = min(32u, nb - (g << 5));
     int last = 0;
@@ -62,10 +69,6 @@ __device__ __forceinline__ bool grid_last_block(uint32_t *tickets) {
         __hip_atomic_store(&tickets[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = 1;
       }
-    }
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     s_last = last;
   }

@@ -429,6 +429,228 @@ k_sum_slabs_2d(const float *__restrict__ slabs, int64_t slab_stride, int splits,
   }
 }
 
+// ------------------------------------------------------ stream-K weight gradients ----
+// Both weight gradients of the tower in ONE launch, stream-K over their joint iteration space.
+// At the step's shapes dW1 is 12 x 40 = 480 tiles of 128 x 128 and dW2 40 x 2 = 80, every tile
+// R/32 K-tiles deep: as two launches on 512 block slots (256 CUs x 2) that is one round at
+// 480/512 occupancy and then a split-K round for dW2 -- 1.19 tile-times.  Here the 560 x (R/32)
+// tile-iterations are dealt evenly to the 512 resident blocks (280 each at R = 8192): 1.09
+// tile-times, no idle CU.  A block's share is a run of consecutive iterations in tile-major
+// order, so it covers at most the tail of one tile, whole tiles, and the head of another;
+// whole tiles are written in place (with their bias-gradient column sums), parts go to the
+// block's two slab slots -- [0] a part that starts inside a tile, [1] a part that starts a tile
+// but does not finish it -- and k_gemm_f32_sk_fixup adds a tile's parts in block order
+// (deterministic, no atomics).  Kernel body = k_gemm_f32<false,false,2,2,EPI_SLAB_COLSUM,32,...>
+// (k-strided operands through buffer descriptors, LDS-DMA, register-prefetched fragments).
+struct SkProblem {
+  const float *A; int64_t lda;     // x     [K][M]  (k-strided)
+  const float *B; int64_t ldb;     // dy    [K][N]
+  float *C; int64_t ldc;           // dW    [M][N]
+  float *colsum;                   // db    [N] or null
+  int tiles_m, tiles_n, tile0;
+};
+struct SkArgs {
+  SkProblem p[2];
+  int n_problems, K, n_kt, total_tiles, ipb;
+  float *slabs;                    // [grid][2][128*128]
+  float *cs_slabs;                 // [grid][2][128]
+};
+
+__device__ __forceinline__ void sk_tile(const SkArgs &g, int T, int &pi, int &tm, int &tn) {
+  pi = (g.n_problems > 1 && T >= g.p[1].tile0) ? 1 : 0;
+  const int tiles_m = pi ? g.p[1].tiles_m : g.p[0].tiles_m, tiles_n = pi ? g.p[1].tiles_n : g.p[0].tiles_n;
+  const int lt = T - (pi ? g.p[1].tile0 : g.p[0].tile0);
+  constexpr int GROUP_M = 8;
+  const int width = GROUP_M * tiles_n;
+  const int group = lt / width;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(tiles_m - first_m, GROUP_M);
+  const int in_group = lt - group * width;
+  tm = first_m + in_group % gsize;
+  tn = in_group / gsize;
+}
+
+__global__ void __launch_bounds__(kThreads, 2) k_gemm_f32_sk(SkArgs g) {
+  constexpr int TM = 2, TN = 2, BKT = 32, BM = 128, BN = 128;
+  constexpr int A_TILE = BM * BKT, B_TILE = BKT * BN, STAGE = A_TILE + B_TILE;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int lb = logical_block(blockIdx.x, gridDim.x);
+  const int64_t total_iters = (int64_t)g.total_tiles * g.n_kt;
+  int64_t it = (int64_t)lb * g.ipb;
+  const int64_t it_end = min(it + (int64_t)g.ipb, total_iters);
+
+  while (it < it_end) {
+    const int T = (int)(it / g.n_kt);
+    const int kt0 = (int)(it - (int64_t)T * g.n_kt);
+    const int kt1 = (int)min((int64_t)g.n_kt, kt0 + (it_end - it));
+    it += kt1 - kt0;
+    int pi, tm, tn;
+    sk_tile(g, T, pi, tm, tn);
+    const float *pA = pi ? g.p[1].A : g.p[0].A, *pB = pi ? g.p[1].B : g.p[0].B;
+    const int64_t lda = pi ? g.p[1].lda : g.p[0].lda, ldb = pi ? g.p[1].ldb : g.p[0].ldb;
+    float *pcs = pi ? g.p[1].colsum : g.p[0].colsum;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int k_begin = kt0 * BKT, k_end = min(g.K, kt1 * BKT);
+    const int n_ktiles = kt1 - kt0;
+    const bool whole = (kt0 == 0) && (kt1 == g.n_kt);
+    const bool do_colsum = pcs != nullptr && tm == 0;
+
+    const i32x4 srd_a = make_srd(pA + (int64_t)k_begin * lda, (int64_t)(k_end - k_begin) * lda * 4);
+    const i32x4 srd_b = make_srd(pB + (int64_t)k_begin * ldb, (int64_t)(k_end - k_begin) * ldb * 4);
+
+    auto issue_tile = [&](int buf, int kt) {
+      const float *sA = smem + buf * STAGE;
+      const float *sB = sA + A_TILE;
+      const uint32_t la = __builtin_amdgcn_readfirstlane(lds_offset(sA) + wave * 1024);
+      const uint32_t lbo = __builtin_amdgcn_readfirstlane(lds_offset(sB) + wave * 1024);
+      constexpr int PA = A_TILE / 256 / 4, PB = B_TILE / 256 / 4, KPP = 256 / BM;
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        const int f = lane * 4;
+        const int k = kt * BKT + (wave + 4 * j) * KPP + f / BM;
+        dma_buffer_to_lds(srd_a, (uint32_t)(((int64_t)k * lda + m0 + f % BM) * 4), la + j * 4096);
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const int f = lane * 4;
+        const int k = kt * BKT + (wave + 4 * j) * KPP + f / BN;
+        dma_buffer_to_lds(srd_b, (uint32_t)(((int64_t)k * ldb + n0 + f % BN) * 4), lbo + j * 4096);
+      }
+    };
+
+    struct Frag { float a[TM][4]; float b[TN][4]; };
+    auto load_frags = [&](const float *sA, const float *sB, int grp) {
+      Frag f;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int row = wm * 32 * TM + mi * 32 + l31;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f.a[mi][u] = sA[(8 * grp + 4 * h + u) * BM + row];
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int col = wn * 32 * TN + ni * 32 + l31;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f.b[ni][u] = sB[(8 * grp + 4 * h + u) * BN + col];
+      }
+      return f;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define CDML_SK_MFMA(F)                                                                      \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u)                                              \
+  _Pragma("unroll") for (int mi = 0; mi < TM; ++mi)                                          \
+  _Pragma("unroll") for (int ni = 0; ni < TN; ++ni)                                          \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32((F).a[mi][u], (F).b[ni][u], acc[mi][ni], 0, 0, 0)
+    if (n_ktiles > 0) issue_tile(0, 0);
+    dma_wait_all();
+    __syncthreads();
+    for (int kt = 0; kt < n_ktiles; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < n_ktiles) issue_tile(buf ^ 1, kt + 1);
+      const float *sA = smem + buf * STAGE;
+      const float *sB = sA + A_TILE;
+      if (do_colsum) {
+        constexpr int CB = BN / 4, KRB = kThreads / CB;          // 32 column quads x 8 k-rows per pass
+#pragma unroll
+        for (int j = 0; j < BKT / KRB; ++j)
+          bsum += *reinterpret_cast<const f32x4 *>(sB + (j * KRB + t / CB) * BN + (t % CB) * 4);
+      }
+      Frag f0 = load_frags(sA, sB, 0);
+      Frag f1 = load_frags(sA, sB, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      CDML_SK_MFMA(f0);
+      f0 = load_frags(sA, sB, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      CDML_SK_MFMA(f1);
+      f1 = load_frags(sA, sB, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      CDML_SK_MFMA(f0);
+      CDML_SK_MFMA(f1);
+      dma_wait_all();
+      __syncthreads();
+    }
+#undef CDML_SK_MFMA
+
+    // epilogue: a whole tile goes to dW, a part to the block's slab slot
+    const int which = (kt0 == 0) ? 1 : 0;
+    float *C = whole ? (pi ? g.p[1].C : g.p[0].C) + (int64_t)m0 * (pi ? g.p[1].ldc : g.p[0].ldc) + n0
+                     : g.slabs + ((int64_t)lb * 2 + which) * (BM * BN);
+    const int64_t ldc = whole ? (pi ? g.p[1].ldc : g.p[0].ldc) : BN;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int col = wn * 32 * TN + ni * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          C[(int64_t)row * ldc + col] = acc[mi][ni][r];
+        }
+      }
+    if (do_colsum) {       // threads with equal (t % 32) hold partial sums of the same 4 columns
+      constexpr int C4 = BN / 4, KR = kThreads / C4;
+      f32x4 *red = reinterpret_cast<f32x4 *>(smem);
+      red[t] = bsum;
+      __syncthreads();
+      if (t < C4) {
+        f32x4 sum = red[t];
+        for (int j = 1; j < KR; ++j) sum += red[t + j * C4];
+        float *dst = whole ? pcs + n0 : g.cs_slabs + ((int64_t)lb * 2 + which) * BN;
+        *reinterpret_cast<f32x4 *>(dst + t * 4) = sum;
+      }
+      __syncthreads();     // the staging buffers are reused by the next segment
+    }
+  }
+}
+
+// One block per output tile: a tile that was computed in parts is the sum of its parts, added in
+// block order (block b0 holds the part that starts the tile in its slot 1, every later block its
+// part in slot 0).  Whole tiles are already in place.
+__global__ void __launch_bounds__(kThreads) k_gemm_f32_sk_fixup(SkArgs g) {
+  const int T = blockIdx.x, t = threadIdx.x;
+  const int64_t first = (int64_t)T * g.n_kt;
+  const int b0 = (int)(first / g.ipb), b1 = (int)((first + g.n_kt - 1) / g.ipb);
+  if (b0 == b1) return;
+  int pi, tm, tn;
+  sk_tile(g, T, pi, tm, tn);
+  float *C = (pi ? g.p[1].C : g.p[0].C);
+  const int64_t ldc = pi ? g.p[1].ldc : g.p[0].ldc;
+  float *pcs = pi ? g.p[1].colsum : g.p[0].colsum;
+  const int m0 = tm * 128, n0 = tn * 128;
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int idx = t + kThreads * j;
+    const int row = idx >> 5, c4 = idx & 31;
+    f32x4 sum = *reinterpret_cast<const f32x4 *>(g.slabs + ((int64_t)b0 * 2 + 1) * 16384 + row * 128 + c4 * 4);
+    for (int b = b0 + 1; b <= b1; ++b)
+      sum += *reinterpret_cast<const f32x4 *>(g.slabs + ((int64_t)b * 2) * 16384 + row * 128 + c4 * 4);
+    *reinterpret_cast<f32x4 *>(C + (int64_t)(m0 + row) * ldc + n0 + c4 * 4) = sum;
+  }
+  if (pcs && tm == 0 && t < 32) {
+    f32x4 sum = *reinterpret_cast<const f32x4 *>(g.cs_slabs + ((int64_t)b0 * 2 + 1) * 128 + t * 4);
+    for (int b = b0 + 1; b <= b1; ++b)
+      sum += *reinterpret_cast<const f32x4 *>(g.cs_slabs + ((int64_t)b * 2) * 128 + t * 4);
+    *reinterpret_cast<f32x4 *>(pcs + n0 + t * 4) = sum;
+  }
+}
+
+constexpr int kSkGrid = 2 * kNumCU;     // every block resident at once: 2 per CU
+
 // LEPI per layout: the C tile goes through LDS only for the data-gradient GEMM,
 // whose contraction is short (K = 256: 8 K-tiles per output tile) so the epilogue
 // is a visible share of the tile; the long-K kernels keep the small LDS footprint
@@ -592,4 +814,55 @@ extern "C" int cdml_fc_bwd_weight(const float *x, int64_t ldx, const float *dy, 
     rc = check_launch("fc_bwd_weight bias combine");
   }
   return rc;
+}
+
+// ---- both weight gradients in one stream-K launch -------------------------------------------
+static bool sk_usable(int M, int K1, int N1, int64_t ldx1, int64_t lddy1, int K2, int N2, int64_t ldx2, int64_t lddy2) {
+  if (M < 256 || K1 % 128 || N1 % 128 || K2 % 128 || N2 % 128) return false;
+  const int64_t lim = (int64_t)1 << 31;
+  if ((int64_t)M * ldx1 * 4 >= lim || (int64_t)M * lddy1 * 4 >= lim || (int64_t)M * ldx2 * 4 >= lim ||
+      (int64_t)M * lddy2 * 4 >= lim) return false;
+  const int64_t tiles = (int64_t)(K1 / 128) * (N1 / 128) + (int64_t)(K2 / 128) * (N2 / 128);
+  return tiles >= kSkGrid / 2;            // fewer tiles: the split-K kernels are the better fit
+}
+
+extern "C" size_t cdml_fc_bwd_weight2_workspace(int M, int K1, int N1, int K2, int N2) {
+  if (!sk_usable(M, K1, N1, K1, N1, K2, N2, K2, N2)) return 0;
+  return (size_t)kSkGrid * 2 * (128 * 128 + 128) * sizeof(float);
+}
+
+extern "C" int cdml_fc_bwd_weight2(const float *x1, int64_t ldx1, const float *dy1, int64_t lddy1, int K1, int N1,
+                                   float *dW1, int64_t lddw1, float *db1, const float *x2, int64_t ldx2,
+                                   const float *dy2, int64_t lddy2, int K2, int N2, float *dW2, int64_t lddw2,
+                                   float *db2, int M, void *workspace, size_t workspace_bytes,
+                                   cdml_stream_t stream) {
+  CDML_REQUIRE(M > 0 && K1 > 0 && N1 > 0 && K2 > 0 && N2 > 0, CDML_E_BADARG, "fc_bwd_weight2: bad argument");
+  int rc;
+  if ((rc = check_mat("fc_bwd_weight2 x1", x1, ldx1, K1))) return rc;
+  if ((rc = check_mat("fc_bwd_weight2 dy1", dy1, lddy1, N1))) return rc;
+  if ((rc = check_mat("fc_bwd_weight2 dW1", dW1, lddw1, N1))) return rc;
+  if ((rc = check_mat("fc_bwd_weight2 x2", x2, ldx2, K2))) return rc;
+  if ((rc = check_mat("fc_bwd_weight2 dy2", dy2, lddy2, N2))) return rc;
+  if ((rc = check_mat("fc_bwd_weight2 dW2", dW2, lddw2, N2))) return rc;
+  CDML_REQUIRE(sk_usable(M, K1, N1, ldx1, lddy1, K2, N2, ldx2, lddy2), CDML_E_UNSUPPORTED,
+               "fc_bwd_weight2: needs K and N multiples of 128, M >= 256, operands below 2 GiB and >= %d tiles "
+               "(use cdml_fc_bwd_weight per layer)", kSkGrid / 2);
+  const size_t need = cdml_fc_bwd_weight2_workspace(M, K1, N1, K2, N2);
+  CDML_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), CDML_E_BADARG,
+               "fc_bwd_weight2: workspace of %zu bytes (16-B aligned) required", need);
+  SkArgs g{};
+  g.p[0] = SkProblem{x1, ldx1, dy1, lddy1, dW1, lddw1, db1, K1 / 128, N1 / 128, 0};
+  g.p[1] = SkProblem{x2, ldx2, dy2, lddy2, dW2, lddw2, db2, K2 / 128, N2 / 128, (K1 / 128) * (N1 / 128)};
+  g.n_problems = 2;
+  g.K = M;
+  g.n_kt = (M + 31) / 32;
+  g.total_tiles = g.p[1].tile0 + (K2 / 128) * (N2 / 128);
+  const int64_t total = (int64_t)g.total_tiles * g.n_kt;
+  g.ipb = (int)((total + kSkGrid - 1) / kSkGrid);
+  g.slabs = static_cast<float *>(workspace);
+  g.cs_slabs = g.slabs + (size_t)kSkGrid * 2 * 128 * 128;
+  hipLaunchKernelGGL(k_gemm_f32_sk, dim3(kSkGrid), dim3(kThreads), 0, (hipStream_t)stream, g);
+  if ((rc = check_launch("fc_bwd_weight2"))) return rc;
+  hipLaunchKernelGGL(k_gemm_f32_sk_fixup, dim3(g.total_tiles), dim3(kThreads), 0, (hipStream_t)stream, g);
+  return check_launch("fc_bwd_weight2 fix-up");
 }

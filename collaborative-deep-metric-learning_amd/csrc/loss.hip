@@ -280,6 +280,7 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
   const float two_over_b = 2.0f / (float)B;
   float4 csum[NCH];
   float tsq = 0.f;
+  float st_h = 0.f, st_p = 0.f, st_n = 0.f, st_a = 0.f;    // this wave's triplets: sums for the step's scalars
 #pragma unroll
   for (int c = 0; c < NCH; ++c) csum[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = blockIdx.x * kWavesPerBlock + wave; i < B; i += gridDim.x * kWavesPerBlock) {
@@ -305,6 +306,7 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
         gn[c] = mul4(sub4(va, vn), s);
       }
       if (lane == 0) { pos_o[i] = pos; neg_o[i] = neg; hinge_o[i] = fmaxf(t, 0.f); }
+      st_h += fmaxf(t, 0.f); st_p += pos; st_n += neg; st_a += (t > 0.f) ? 1.f : 0.f;
       tail_store_row<NCH>(N, gn, alpha, e + (ra + 2) * lde, dz2 + (ra + 2) * lddz,
                           dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane);
     } else {
@@ -339,6 +341,8 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
         hinge_o[i] = valid_i ? fmaxf(t, 0.f) : 0.f;
         if (valid_o) valid_o[i] = valid_i ? 1 : 0;
       }
+      const float hv = valid_i ? fmaxf(t, 0.f) : 0.f;
+      st_h += hv; st_p += pos; st_n += neg; st_a += (hv > 0.f) ? 1.f : 0.f;
     }
     tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane);
     tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane);
@@ -352,8 +356,14 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       }
     }
   }
+  if (!stats) return;
+  // ---- block partials, written through (st_sc1), then the ticket ----
+  // part[block] = {sum hinge, sum pos, sum neg, active count} (+ with var_ws: D column sums of the
+  // [B,3,D] triplet tensor and its sum of squares); waves in order, blocks in order: deterministic
   const int nb = gridDim.x;
-  if (var_ws) {         // block partial: var_ws[block][D + 4]
+  float *part = reinterpret_cast<float *>(tickets + kTicketWords) + (int64_t)blockIdx.x * 4;
+  if (lane == 0) { s_red[wave][0] = st_h; s_red[wave][1] = st_p; s_red[wave][2] = st_n; s_red[wave][3] = st_a; }
+  if (var_ws) {
     float *mine = s_col + wave * D;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -361,41 +371,45 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       if (q < nq) st4(mine, q, csum[c]);
     }
     tsq = wave_sum(tsq);
-    if (lane == 0) s_red[wave][0] = tsq;
-    __syncthreads();
+    if (lane == 0) s_red[wave][4] = tsq;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = 0.f;
+    for (int w = 0; w < kWavesPerBlock; ++w) v += s_red[w][threadIdx.x];
+    st_sc1(part + threadIdx.x, v);
+  }
+  if (var_ws) {
     float *out = var_ws + (int64_t)blockIdx.x * (D + 4);
     for (int d = threadIdx.x; d < D; d += kThreads) {
       float v = 0.f;
       for (int w = 0; w < kWavesPerBlock; ++w) v += s_col[w * D + d];
-      out[d] = v;
+      st_sc1(out + d, v);
     }
     if (threadIdx.x == 0) {
       float v = 0.f;
-      for (int w = 0; w < kWavesPerBlock; ++w) v += s_red[w][0];
-      out[D] = v;
+      for (int w = 0; w < kWavesPerBlock; ++w) v += s_red[w][4];
+      st_sc1(out + D, v);
     }
   }
-  if (!stats) return;
   if (!grid_last_block(tickets)) return;
-  // ---- the last block: the step's scalars, fixed summation order ----
+  // ---- the last block: the step's scalars ----
+  const float *parts = reinterpret_cast<const float *>(tickets + kTicketWords);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < B; i += kThreads) {
-    const float h = hinge_o[i];
-    acc[0] += h;
-    acc[1] += pos_o[i];
-    acc[2] += neg_o[i];
-    acc[3] += (h > 0.f) ? 1.f : 0.f;
+  for (int b = threadIdx.x; b < nb; b += kThreads) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] += ld_sc1(parts + (int64_t)b * 4 + c);
   }
   double vsum = 0.0;
   if (var_ws) {         // var = [sum t^2 - n_rows * sum_d mean_d^2] / (n_rows * D), n_rows = 3B
     const double n_rows = 3.0 * (double)B;
     for (int d = threadIdx.x; d < D; d += kThreads) {
       double col = 0.0;
-      for (int b = 0; b < nb; ++b) col += (double)var_ws[(int64_t)b * (D + 4) + d];
+      for (int b = 0; b < nb; ++b) col += (double)ld_sc1(var_ws + (int64_t)b * (D + 4) + d);
       const double mean = col / n_rows;
       vsum -= n_rows * mean * mean;
     }
-    for (int b = threadIdx.x; b < nb; b += kThreads) vsum += (double)var_ws[(int64_t)b * (D + 4) + D];
+    for (int b = threadIdx.x; b < nb; b += kThreads) vsum += (double)ld_sc1(var_ws + (int64_t)b * (D + 4) + D);
   }
   __syncthreads();      // s_red is reused below
 #pragma unroll

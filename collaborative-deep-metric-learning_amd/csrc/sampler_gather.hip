@@ -18,6 +18,9 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWavesPerBlock = kThreads / kWave;
 
+#ifndef CDML_GATHER_NT_STORE
+#define CDML_GATHER_NT_STORE 0   // 1: non-temporal stores of the gathered rows
+#endif
 #ifndef CDML_GATHER_NT
 #define CDML_GATHER_NT 0   // 1: non-temporal table loads (rows are read once per step)
 #endif
@@ -178,7 +181,10 @@ k_gather_rows(const float *__restrict__ table, int64_t row0, int64_t n_rows, int
 //     each, 16 B per lane = whole 128-B lines) are issued before the first use, then the
 //     wave-shuffle norm and the stores.
 // MODE 0 = uniform negatives, MODE 1 = in-batch negatives.
-constexpr int kRowsPerWave = 2;
+#ifndef CDML_GATHER_ROWS_PER_WAVE
+#define CDML_GATHER_ROWS_PER_WAVE 2   // rows a wave keeps in flight (A/B'd: tools/gather_variants.sh)
+#endif
+constexpr int kRowsPerWave = CDML_GATHER_ROWS_PER_WAVE;
 constexpr int kChunkRows = kRowsPerWave * kWavesPerBlock;
 
 template <int NCH>
@@ -219,7 +225,14 @@ __device__ __forceinline__ void row_finish(RowRegs<NCH> &R, int F, float *__rest
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int q = lane + kWave * c;
-    if (q < oq) d[q] = make_float4(R.v[c].x * inv, R.v[c].y * inv, R.v[c].z * inv, R.v[c].w * inv);
+    if (q < oq) {
+#if CDML_GATHER_NT_STORE
+      const f32x4 o = f32x4{R.v[c].x * inv, R.v[c].y * inv, R.v[c].z * inv, R.v[c].w * inv};
+      __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(d + q));
+#else
+      d[q] = make_float4(R.v[c].x * inv, R.v[c].y * inv, R.v[c].z * inv, R.v[c].w * inv);
+#endif
+    }
   }
   for (int q = lane + kWave * NCH; q < oq; q += kWave) d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 }

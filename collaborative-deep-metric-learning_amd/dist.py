@@ -84,8 +84,11 @@ def exchange_capacity(n_requests, world, factor=1.25):
 class RowExchange:
     """Fetch (normalised) feature rows by GLOBAL id from a row-sharded table."""
 
-    def __init__(self, n_rows_global, group=None, local_gather=None, capacity_factor=1.25):
+    def __init__(self, n_rows_global, group=None, local_gather=None, capacity_factor=1.25, skip_self=True):
+        """``skip_self``: with a single rank every request is local, so the two all-to-alls are
+        skipped (False keeps them: the RCCL entry points then run even at world size 1)."""
         self.group = group
+        self.skip_self = bool(skip_self)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.n_rows_global = int(n_rows_global)
@@ -139,13 +142,16 @@ class RowExchange:
         cap = self.capacity(R)
         send_ids, slot = self.route(ids, cap)
         n_slots = self.world * cap
-        recv_ids = self._scratch("recv_ids", (n_slots,), torch.int32, dev)
-        all_to_all(recv_ids, send_ids, self.group)
+        local_only = self.world == 1 and self.skip_self
+        recv_ids = send_ids if local_only else self._scratch("recv_ids", (n_slots,), torch.int32, dev)
+        if not local_only:
+            all_to_all(recv_ids, send_ids, self.group)
         stride = out.shape[1]
         rows_out = self._scratch("rows_out", (n_slots, stride), out.dtype, out.device)
         self.local_gather(table, recv_ids, rows_out)
-        rows_in = self._scratch("rows_in", (n_slots, stride), out.dtype, out.device)
-        all_to_all(rows_in, rows_out, self.group)
+        rows_in = rows_out if local_only else self._scratch("rows_in", (n_slots, stride), out.dtype, out.device)
+        if not local_only:
+            all_to_all(rows_in, rows_out, self.group)
         self.unpermute(rows_in, slot, out)
         # kept for scatter_back(): the same routing carries row gradients to their owners
         self.last = (slot, recv_ids, cap)
@@ -164,6 +170,8 @@ class RowExchange:
         else:
             ok = slot >= 0
             send[slot[ok].long()] = rows[ok]
+        if self.world == 1 and self.skip_self:
+            return recv_ids, send
         recv = self._scratch("back_recv", (n_slots, stride), rows.dtype, rows.device)
         all_to_all(recv, send, self.group)
         return recv_ids, recv

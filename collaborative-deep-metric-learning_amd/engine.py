@@ -15,6 +15,7 @@ zero gradients -> zero Adam/LARS update), so the padded problem computes the
 reference's numbers exactly.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -145,7 +146,9 @@ class TowerWorkspace:
             self.de = z(n_rows, L.Dp)
             self.dz2 = z(n_rows, L.Dp)
             self.dz1 = z(n_rows, L.Hp)
-            nbytes = max(ops.fc_bwd_weight_workspace(n_rows, L.Hp, L.Dp),
+            # both weight gradients in one stream-K launch when the shapes allow (0 = they do not)
+            self.sk_bytes = ops.fc_bwd_weight2_workspace(n_rows, L.Fp, L.Hp, L.Hp, L.Dp)
+            nbytes = max(self.sk_bytes, ops.fc_bwd_weight_workspace(n_rows, L.Hp, L.Dp),
                          ops.fc_bwd_weight_workspace(n_rows, L.Fp, L.Hp),
                          # dW1 in two row blocks (data-parallel runs, tower_backward w1_chunks=2)
                          ops.fc_bwd_weight_workspace(n_rows, L.Fp // 2, L.Hp) if L.Fp % 256 == 0 else 0)
@@ -186,6 +189,12 @@ def tower_backward(p, ws, n_rows=None, after_w1=None, w1_chunks=1, after_w1_chun
         ops.l2norm_bwd(ws.z[:R], ws.de[:R], L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
     ops.fc_bwd_data(ws.dz2, p.W2, ws.h1, ws.dz1, R, L.Hp, L.Dp)
     rows = L.Fp // w1_chunks if w1_chunks > 1 else 0
+    if (after_w1 is None and after_w1_chunk is None and getattr(ws, "sk_bytes", 0) and R == ws.R
+            and not os.environ.get("CDML_NO_STREAMK")):
+        # single GPU: nothing waits for dW1 alone, so both products share one stream-K launch
+        ops.fc_bwd_weight2(ws.x_hat, ws.dz1, p.gW1, p.gb1, L.Fp, L.Hp, ws.h1, ws.dz2, p.gW2, p.gb2, L.Hp, L.Dp,
+                           R, ws.bw)
+        return p.grad
     if after_w1_chunk is not None and w1_chunks > 1 and rows % 128 == 0 and rows * w1_chunks == L.Fp:
         for c in range(w1_chunks):
             lo, hi = c * rows, (c + 1) * rows

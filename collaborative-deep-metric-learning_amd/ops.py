@@ -160,6 +160,24 @@ def fc_bwd_weight(x, dy, dW, db, workspace, M, K, N):
     return dW, db
 
 
+def fc_bwd_weight2_workspace(M, K1, N1, K2, N2):
+    """0 = shapes the stream-K launch does not take (use fc_bwd_weight per layer)."""
+    return int(load_library().cdml_fc_bwd_weight2_workspace(M, K1, N1, K2, N2))
+
+
+def fc_bwd_weight2(x1, dy1, dW1, db1, K1, N1, x2, dy2, dW2, db2, K2, N2, M, workspace):
+    """Both weight gradients (and bias gradients) of the two-layer tower in one stream-K launch."""
+    a1, lda1 = _mat(x1)
+    b1, ldb1 = _mat(dy1)
+    c1, ldc1 = _mat(dW1)
+    a2, lda2 = _mat(x2)
+    b2, ldb2 = _mat(dy2)
+    c2, ldc2 = _mat(dW2)
+    call("cdml_fc_bwd_weight2", a1, lda1, b1, ldb1, K1, N1, c1, ldc1, _p(db1, torch.float32), a2, lda2, b2, ldb2,
+         K2, N2, c2, ldc2, _p(db2, torch.float32), M, _p(workspace), workspace.numel() * workspace.element_size(),
+         _stream())
+
+
 # ------------------------------------------------------------------ loss ------
 def triplet_hinge(e, B, D, margin, pos, neg, hinge, stats=None, de=None):
     ep, eld = _mat(e)
@@ -176,7 +194,7 @@ def triplet_hinge_inbatch(e, rows, shift, B, D, margin, pos, neg, hinge, valid=N
          margin, _p(pos), _p(neg), _p(hinge), _p(valid, torch.uint8), _p(stats), dep, deld, _stream())
 
 
-TICKET_WORDS = 80     # CDML_TICKET_WORDS (include/cdml.h)
+TICKET_WORDS = 8320   # CDML_TICKET_WORDS (include/cdml.h): 80 tickets + per-block partial sums
 
 
 def new_tickets(device):

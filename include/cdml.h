@@ -175,6 +175,22 @@ int cdml_fc_bwd_weight(const float *x, int64_t ldx, const float *dy,
                        int64_t lddw, float *db, void *workspace,
                        size_t workspace_bytes, cdml_stream_t stream);
 
+/* Both weight gradients of the two-layer tower in ONE launch (train.py:141):
+ *   dW1[K1][N1] = x1[M][K1]^T . dy1[M][N1],  db1[N1] = column sums of dy1   (nullable)
+ *   dW2[K2][N2] = x2[M][K2]^T . dy2[M][N2],  db2[N2] likewise
+ * as a stream-K product: the tile-iterations of both outputs are dealt evenly to 2 blocks per
+ * CU, so no CU idles while another still has a whole tile to do (480 + 80 tiles on 512 slots
+ * at the step's shapes); tiles computed in parts are summed in a fixed order by a second small
+ * launch (deterministic, no atomics).  K1, N1, K2, N2 multiples of 128, M >= 256; otherwise
+ * CDML_E_UNSUPPORTED and cdml_fc_bwd_weight2_workspace returns 0: call cdml_fc_bwd_weight per
+ * layer.  workspace: cdml_fc_bwd_weight2_workspace bytes, 16-B aligned. */
+size_t cdml_fc_bwd_weight2_workspace(int M, int K1, int N1, int K2, int N2);
+int cdml_fc_bwd_weight2(const float *x1, int64_t ldx1, const float *dy1, int64_t lddy1,
+                        int K1, int N1, float *dW1, int64_t lddw1, float *db1,
+                        const float *x2, int64_t ldx2, const float *dy2, int64_t lddy2,
+                        int K2, int N2, float *dW2, int64_t lddw2, float *db2, int M,
+                        void *workspace, size_t workspace_bytes, cdml_stream_t stream);
+
 /* ---- loss: HingeLoss.calculate_loss (losses.py:20-49) fused with its
  * gradient (train.py:141) --------------------------------------------------
  * e[3B][ld] rows a,p,n per triplet.  pos/neg/hinge: float[B] (the reference's
@@ -205,10 +221,10 @@ int cdml_triplet_hinge_inbatch(const float *e, int64_t lde, const int32_t *rows,
  * nullable), dz2 = d loss / d (pre-activation of the output layer), optionally also as bf16
  * (dz2_bf16 nullable, round-to-nearest-even).  stats (nullable) float[8]: [0..3] as
  * cdml_triplet_hinge, written by the last block to finish -- needs tickets =
- * uint32[CDML_TICKET_WORDS], zero before the first call (the kernel leaves them zero).
+ * uint32[CDML_TICKET_WORDS], zero before the first call (the kernel leaves the tickets zero).
  * var_ws (nullable, cdml_vnet_tail_workspace bytes): stats[4] = calc_var (train.py:67-71) of
  * the [B,3,D] triplet tensor: mean over everything of (t - mean over [batch, role])^2. */
-#define CDML_TICKET_WORDS 80
+#define CDML_TICKET_WORDS 8320   /* 80 ticket words (kept zero) + 4 floats of partial sums per block */
 size_t cdml_vnet_tail_workspace(int B, int D);
 int cdml_vnet_tail(int mode, const float *z, int64_t ldz, const int32_t *rows,
                    const int32_t *shift, int B, int D, float margin, float lrelu_alpha,

@@ -150,7 +150,7 @@ def _nccl_worker(port, q):
         # real RCCL calls of the exchange (uneven all-to-all of int64 / int32 / fp32, own group,
         # side stream) and of the gradient sync (async AVG / SUM), with a single rank
         ts = _make(dev, 0, 1)                       # reference: whole table, no exchange
-        ex = cdist.RowExchange(CFG["n_rows"], group=dist.new_group())
+        ex = cdist.RowExchange(CFG["n_rows"], group=dist.new_group(), skip_self=False)
         sync = cdist.GradSync(device=dev)
         sync.world = 2                              # force the collective path (average of one rank x1 ... /2 below)
         from cdml_amd import train
@@ -181,8 +181,11 @@ def _say(msg):
 
 
 def _nccl_graph_worker(port, q):
-    """The data-parallel step captured into hipGraphs (one per prefetch buffer): RCCL all-to-all
-    on the forked prefetch stream + async all-reduce inside the capture must equal the eager step."""
+    """The data-parallel step (row routing, owner gather, un-permute on the forked prefetch stream;
+    GradSync hooks in place) captured into hipGraphs, one per prefetch buffer, must equal the eager
+    step.  World size 1: the exchange skips its two all-to-alls (every request is local), so no
+    RCCL call sits inside the capture -- a captured all_to_all_single never came back on this
+    stack (torch 2.10 / RCCL 2.26), which is why TrainStep keeps world > 1 eager by default."""
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"

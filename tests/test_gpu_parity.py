@@ -260,6 +260,39 @@ def test_l2norm_fwd_bwd(cd):
 FC_SHAPES = [(15, 64, 64), (130, 96, 192), (384, 1536, 5120), (257, 5120, 256), (64, 32, 128)]
 
 
+@pytest.mark.parametrize("M,K1,N1,K2,N2", [(777, 1024, 4096, 4096, 128), (8192, 1536, 5120, 5120, 256),
+                                            (4100, 1536, 5120, 5120, 256), (256, 2048, 2048, 128, 128)])
+def test_fc_bwd_weight2_stream_k(cd, M, K1, N1, K2, N2):
+    """Both weight gradients in one stream-K launch == the per-layer launches (fp32 summation
+    order aside) == x^T dy in fp64; bias gradients ride along; repeatable bit for bit."""
+    g = torch.Generator(device=cd.dev)
+    g.manual_seed(M)
+    x1 = torch.randn(M, K1, device=cd.dev, generator=g) / 8
+    dy1 = torch.randn(M, N1, device=cd.dev, generator=g) / 8
+    x2 = torch.randn(M, K2, device=cd.dev, generator=g) / 8
+    dy2 = torch.randn(M, N2, device=cd.dev, generator=g) / 8
+    nb = cd.ops.fc_bwd_weight2_workspace(M, K1, N1, K2, N2)
+    assert nb > 0
+    ws = torch.empty(nb // 4, device=cd.dev)
+    f = lambda *s: torch.full(s, 7.0, device=cd.dev)
+    dW1, db1, dW2, db2 = f(K1, N1), f(N1), f(K2, N2), f(N2)
+    cd.ops.fc_bwd_weight2(x1, dy1, dW1, db1, K1, N1, x2, dy2, dW2, db2, K2, N2, M, ws)
+    for x, dy, dW, db in ((x1, dy1, dW1, db1), (x2, dy2, dW2, db2)):
+        ref = (x.double().T @ dy.double())
+        scale = float(ref.abs().max())
+        assert float((dW.double() - ref).abs().max()) < 2e-6 * scale * max(1.0, np.sqrt(M / 256))
+        rb = dy.double().sum(0)
+        assert float((db.double() - rb).abs().max()) < 2e-6 * float(rb.abs().max()) * max(1.0, np.sqrt(M / 256)) + 1e-6
+    first = [t.clone() for t in (dW1, db1, dW2, db2)]
+    for _ in range(3):
+        cd.ops.fc_bwd_weight2(x1, dy1, dW1, db1, K1, N1, x2, dy2, dW2, db2, K2, N2, M, ws)
+    assert all(torch.equal(a, b) for a, b in zip(first, (dW1, db1, dW2, db2)))
+    # no bias gradients wanted
+    cd.ops.fc_bwd_weight2(x1, dy1, dW1, None, K1, N1, x2, dy2, dW2, None, K2, N2, M, ws)
+    assert torch.equal(dW1, first[0]) and torch.equal(dW2, first[2])
+    assert cd.ops.fc_bwd_weight2_workspace(M, 192, 256, 256, 128) == 0          # not multiples of 128 / too few tiles
+
+
 def test_fc_race_screen(cd):
     """DMA-wait / barrier ordering of the LDS-DMA staged kernels: many launches on the whole
     chip, every result compared bit for bit with the first."""
@@ -457,7 +490,7 @@ def test_vnet_tail_fused_equals_separate_kernels_and_oracle(cd, mode, B, D):
         assert close(p1, p0, 1e-6) and close(n1, n0, 1e-6) and close(h1, h0, 1e-6)
         assert torch.equal(bf, dz1.bfloat16())                               # round-to-nearest-even copy
         np.testing.assert_allclose(st1[:4].cpu().numpy(), st0.cpu().numpy(), rtol=2e-6, atol=1e-7)
-        assert int(tickets.abs().sum().item()) == 0
+        assert int(tickets[:80].abs().sum().item()) == 0
         if mode == "inbatch":
             np.testing.assert_array_equal(v1.cpu().numpy().astype(bool), valid)
     # oracle (fp64 on the fp32 inputs)
@@ -495,7 +528,7 @@ def test_adam_advances_step_counter_in_the_same_launch(cd):
             if not adv:
                 cd.ops.step_advance(t_dev)
         torch.cuda.synchronize()
-        assert int(t_dev.item()) == 9 and int(tick.abs().sum().item()) == 0
+        assert int(t_dev.item()) == 9 and int(tick[:80].abs().sum().item()) == 0
         res.append((w, m, v))
     for a, b in zip(*res):
         assert torch.equal(a, b)
