@@ -222,7 +222,7 @@ def main():
                     help="bf16 = BASELINE config 4 path (fp16 table + bf16 MFMA); not the headline metric")
     ap.add_argument("--train-table", action="store_true",
                     help="also train the catalogue rows (lazy Adam; build-defined, not the headline metric)")
-    ap.add_argument("--gather-ahead", type=int, default=2, help="steps fetched per sampler+gather launch (1 GPU, fp32)")
+    ap.add_argument("--gather-ahead", type=int, default=4, help="steps fetched per sampler+gather launch (1 GPU, fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="50 timed CPU steps in all four runs (minutes)")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -432,22 +432,27 @@ def main():
                 gk, n_st = "k_gather_rows_f16", 1
                 gbytes = R * F * (2 + 2.0)                  # fp16 rows read + bf16 normalised rows written
 
-                def launch():
-                    ops.gather_rows_f16(ts.table.data, ts.table.row0, ts.idx, F, ts.ws.x_hat)
+                probe_idx = [torch.randint(0, ts.table.n_rows, (R,), dtype=torch.int32, device=dev) for _ in range(8)]
+                nxt = [0]
+
+                def launch():                               # other rows every launch (see the fp32 probe)
+                    ops.gather_rows_f16(ts.table.data, ts.table.row0, probe_idx[nxt[0] % 8], F, ts.ws.x_hat)
+                    nxt[0] += 1
             else:
                 n_st = ts.gather_ahead
                 gk = "k_sample_gather<%d, 6>" % (1 if rpt == 2 else 0)
                 gbytes = n_st * 2.0 * R * F * 4             # rows read + normalised rows written
-                base = ts._ahead_base if n_st > 1 else ts.global_step - 1
                 m = train._MODES[mode]
+                nxt = [ts.global_step + 1000]               # fresh steps every launch: re-reading the same rows
+                                                            # would be served from the 256 MB Infinity Cache
 
-                def launch():                               # re-fetches the block of steps already in the buffers
+                def launch():                               # (training on `ts` is over: its buffers are scratch now)
                     if n_st > 1:
-                        ops.sample_gather(m, ts.pairs, ts.seed, base, B, ts.table.data, F, ts._idxa, ts._xa,
-                                          shift_out=ts._shifta, n_steps=n_st)
+                        ts._gather_block(0, nxt[0])
                     else:
-                        ops.sample_gather(m, ts.pairs, ts.seed, base, B, ts.table.data, F, ts.idx, ts.ws.x_hat,
+                        ops.sample_gather(m, ts.pairs, ts.seed, nxt[0], B, ts.table.data, F, ts.idx, ts.ws.x_hat,
                                           shift_out=ts.shift)
+                    nxt[0] += n_st
             for _ in range(3):
                 launch()
             evs = []

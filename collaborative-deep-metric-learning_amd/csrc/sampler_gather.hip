@@ -22,7 +22,8 @@ constexpr int kWavesPerBlock = kThreads / kWave;
 #define CDML_GATHER_NT_STORE 0   // 1: non-temporal stores of the gathered rows
 #endif
 #ifndef CDML_GATHER_NT
-#define CDML_GATHER_NT 0   // 1: non-temporal table loads (rows are read once per step)
+#define CDML_GATHER_NT 1   // non-temporal table loads: a row is read once, keep it out of L2 / Infinity Cache
+                           // (A/B on MI355X, 32 768 rows per launch: 5.3 -> 6.2 TB/s; profiles/r02_gather_variants.txt)
 #endif
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 

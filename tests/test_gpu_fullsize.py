@@ -362,7 +362,7 @@ def test_gradients_well_conditioned_production_shape(cd, mode, precision, bar):
         e = ts.ws.e[:, :D].cpu().numpy()
         assert np.abs(e - fwd["l2_norm"]).max() < (1e-5 if precision == "f32" else 5e-3)
         assert abs(ts.loss() - loss) < (1e-5 if precision == "f32" else 2e-2)
-        assert n_amb_t <= (1 if precision == "f32" else 12), n_amb_t
+        assert n_amb_t <= (1 if precision == "f32" else 40), n_amb_t
         checked += 1
         # (leaky-relu halves the distance to 0 five-fold on the negative side: |h| < band is a
         # few 1e-4 of the entries in fp32, a few % at the bf16 band)

@@ -12,19 +12,19 @@ cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py > $ROOT/gpurun_out/${TAG}_bench.json
 echo "[profile] plain bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --steps 60 --warmup 5 \
-    --no-cpu-baseline > $ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err
+    --no-cpu-baseline --no-extras > $ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $ROOT/gpurun_out/${TAG}_kernel_stats.csv
 echo "[profile] kernel stats done"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- python3 $ROOT/bench.py --steps 4 --warmup 0 \
-      --no-cpu-baseline --no-kernel-timers > /dev/null 2> $OUT/pmc_$C.err
+      --no-cpu-baseline --no-extras --no-kernel-timers > /dev/null 2> $OUT/pmc_$C.err
   echo "[profile] pmc $C done"
 done
 python3 $ROOT/tools/pmc_summary.py $ROOT/gpurun_out/${TAG}_pmc_fetch_write.csv \
     FETCH_SIZE=$(find $OUT/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) \
     WRITE_SIZE=$(find $OUT/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) > /dev/null
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_busy -o pmc -- python3 $ROOT/bench.py \
-    --steps 4 --warmup 0 --no-cpu-baseline --no-kernel-timers > /dev/null 2> $OUT/pmc_busy.err
+    --steps 4 --warmup 0 --no-cpu-baseline --no-extras --no-kernel-timers > /dev/null 2> $OUT/pmc_busy.err
 python3 $ROOT/tools/pmc_mfma_busy.py $(find $OUT/pmc_busy -name '*counter_collection.csv' | head -1) \
     > $ROOT/gpurun_out/${TAG}_mfma_busy_clock.txt
 echo "[profile] done"
