@@ -45,7 +45,7 @@ SIGNATURES = {
     "cdml_scatter_rows": (_i, [_p, _i64, _p, _i, _i, _p, _i64, _p]),
     "cdml_l2norm_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p]),
     "cdml_l2norm_bwd": (_i, [_p, _i64, _p, _i64, _i, _i, _f, _p, _i64, _p]),
-    "cdml_fc_lrelu_fwd": (_i, [_p, _i64, _p, _i64, _p, _f, _i, _i, _i, _i, _p, _i64, _p]),
+    "cdml_fc_lrelu_fwd": (_i, [_p, _i64, _p, _i64, _p, _f, _i, _i, _i, _p, _i64, _p]),
     "cdml_fc_bwd_data": (_i, [_p, _i64, _p, _i64, _p, _i64, _f, _i, _i, _i, _p, _i64, _p]),
     "cdml_fc_bwd_weight_workspace": (_sz, [_i, _i, _i]),
     "cdml_fc_bwd_weight": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _sz, _p]),

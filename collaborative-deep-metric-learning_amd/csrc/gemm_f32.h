@@ -15,7 +15,6 @@ struct GemmArgs {
   float *colsum;                 // EPI_SLAB_COLSUM: [chunks][N] partial column sums of B (may be null)
   float alpha;
   int M, N, K;                   // output M x N, contraction K
-  int n_real;                    // fwd: columns >= n_real are padding (zero weights, zero bias); 0 = none
   int k_per_split;               // multiple of the K-tile; blockIdx.y = split
   int64_t slab_stride;           // elements between split outputs
   int tiles_m, tiles_n;

@@ -241,47 +241,6 @@ __global__ void __launch_bounds__(kThreads, NBLK) k_gemm_f32(GemmArgs g) {
 #undef CDML_MFMA_GROUP
   };
 
-  // Forward layer, last column tile: H = 5000 leaves 8 real columns in a 128-wide tile (padding
-  // to a multiple of 128 keeps every other tile on the fast path).  The MFMA groups of 32
-  // columns that hold only padding are skipped -- their outputs are lrelu(0 + 0) = 0 either
-  // way -- so such a block costs a quarter of the matrix work and hands its CU's MFMA pipe to
-  // the co-resident block.  active_n = this wave's 32-column groups with real columns.
-  int active_n = TN;
-  if constexpr (AKC && !BKC) {
-    if (g.n_real > 0) {
-      const int rem = g.n_real - n0 - wn * 32 * TN;
-      active_n = rem <= 0 ? 0 : min(TN, (rem + 31) / 32);
-    }
-  }
-  const bool narrow = (AKC && !BKC) && __builtin_amdgcn_readfirstlane(active_n) < TN;
-  auto compute_tile_narrow = [&](int buf) {
-    if constexpr (AKC && !BKC) {
-      const float *sA = smem + buf * STAGE;
-      const float *sB = sA + A_TILE;
-      const int an = __builtin_amdgcn_readfirstlane(active_n);
-      if (an == 0) return;
-#pragma unroll
-      for (int grp = 0; grp < BKT / 8; ++grp) {
-        float a[TM][4], b[4];
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-          const int row = wm * 32 * TM + mi * 32 + l31;
-          const int off = row * BKT + (((2 * grp + h) ^ ((row >> SWZ_SHIFT) % CPR)) << 2);
-          const f32x4 v = *reinterpret_cast<const f32x4 *>(sA + off);
-          a[mi][0] = v.x; a[mi][1] = v.y; a[mi][2] = v.z; a[mi][3] = v.w;
-        }
-        const int col = wn * 32 * TN + l31;                    // group ni = 0 (TN = 2: the only partial case)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) b[u] = sB[(8 * grp + 4 * h + u) * BN + col];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int mi = 0; mi < TM; ++mi)
-            acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][u], b[u], acc[mi][0], 0, 0, 0);
-      }
-    }
-  };
-
   // bias gradient of the bwd-weight GEMM: column sums of the dy tile now in LDS
   auto colsum_tile = [&](int buf) {
     const float *sB = smem + buf * STAGE + A_TILE;
@@ -303,8 +262,7 @@ __global__ void __launch_bounds__(kThreads, NBLK) k_gemm_f32(GemmArgs g) {
       const int buf = kt & 1;
       if (kt + 1 < n_ktiles) issue_tile(buf ^ 1, kt + 1);  // lands in the other stage under the MFMAs
       if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) colsum_tile(buf);
-      if (TN == 2 && narrow) compute_tile_narrow(buf);
-      else compute_tile(buf);
+      compute_tile(buf);
       dma_wait_all();    // this wave's pieces of tile kt+1 are in LDS ...
       __syncthreads();   // ... and so are everybody else's; stage `buf` is free again
     }
@@ -767,10 +725,9 @@ int bwd_weight_splits(int M, int K, int N) {
 using namespace cdml;
 
 extern "C" int cdml_fc_lrelu_fwd(const float *x, int64_t ldx, const float *W, int64_t ldw,
-                                 const float *b, float alpha, int M, int K, int N, int n_real, float *y,
+                                 const float *b, float alpha, int M, int K, int N, float *y,
                                  int64_t ldy, cdml_stream_t stream) {
-  CDML_REQUIRE(M > 0 && K > 0 && N > 0 && b && n_real >= 0 && n_real <= N, CDML_E_BADARG,
-               "fc_lrelu_fwd: bad argument");
+  CDML_REQUIRE(M > 0 && K > 0 && N > 0 && b, CDML_E_BADARG, "fc_lrelu_fwd: bad argument");
   CDML_REQUIRE(K % 32 == 0 && N % 64 == 0, CDML_E_UNSUPPORTED,
                "fc_lrelu_fwd: K must be a multiple of 32 and N of 64 (pad with zeros), got K=%d N=%d", K, N);
   int rc;
@@ -782,7 +739,6 @@ extern "C" int cdml_fc_lrelu_fwd(const float *x, int64_t ldx, const float *W, in
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = y; g.ldc = ldy;
   g.bias = b; g.alpha = alpha; g.M = M; g.N = N; g.K = K; g.k_per_split = K;
-  g.n_real = (n_real > 0 && n_real < N) ? n_real : 0;
   int tm, tn;
   pick_tile(M, N, tm, tn);
   return launch_gemm<true, false, EPI_BIAS_LRELU>(g, tm, tn, 1, (hipStream_t)stream);

@@ -165,8 +165,8 @@ def tower_forward(p, ws, n_rows=None, normalize=True):
     F = 1500, 157 instead of 160 for H = 5000."""
     L = p.layout
     R = ws.R if n_rows is None else n_rows
-    ops.fc_lrelu_fwd(ws.x_hat, p.W1, p.b1, ws.h1, R, round_up(L.F, 32), L.Hp, n_real=L.H)
-    ops.fc_lrelu_fwd(ws.h1, p.W2, p.b2, ws.z, R, round_up(L.H, 32), L.Dp, n_real=L.D)
+    ops.fc_lrelu_fwd(ws.x_hat, p.W1, p.b1, ws.h1, R, round_up(L.F, 32), L.Hp)
+    ops.fc_lrelu_fwd(ws.h1, p.W2, p.b2, ws.z, R, round_up(L.H, 32), L.Dp)
     ws.tail_done = False
     if normalize:
         ops.l2norm_fwd(ws.z[:R], L.Dp, ws.e)

@@ -126,12 +126,11 @@ def l2norm_bwd(z, g, n_cols, dz, lrelu_alpha=-1.0):
     return dz
 
 
-def fc_lrelu_fwd(x, W, b, y, M, K, N, alpha=LRELU_ALPHA, n_real=0):
-    """n_real: columns >= n_real of W / b are zero padding (0: none)."""
+def fc_lrelu_fwd(x, W, b, y, M, K, N, alpha=LRELU_ALPHA):
     xp, xld = _mat(x)
     wp, wld = _mat(W)
     yp, yld = _mat(y)
-    call("cdml_fc_lrelu_fwd", xp, xld, wp, wld, _p(b, torch.float32), alpha, M, K, N, n_real, yp, yld,
+    call("cdml_fc_lrelu_fwd", xp, xld, wp, wld, _p(b, torch.float32), alpha, M, K, N, yp, yld,
          _stream())
     return y
 

@@ -162,7 +162,7 @@ class TrainStep:
             # eager: two buffer sets, the NEXT block of steps is fetched on a side stream while this
             # block's GEMMs run (the gather is HBM-bound, the GEMMs MFMA-bound); a captured step
             # keeps the gather in-stream (one set)
-            K, nset = self.gather_ahead, (1 if (use_graph or os.environ.get("CDML_GATHER_SIDE") == "0") else 2)
+            K, nset = self.gather_ahead, (1 if use_graph else 2)
             self._xa = torch.zeros((nset, K) + tuple(self.ws.x_hat.shape), dtype=f32, device=dev)
             self._idxa = torch.zeros((nset, K, self.R), dtype=i32, device=dev)
             self._shifta = torch.zeros((nset, K), dtype=i32, device=dev)

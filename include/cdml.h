@@ -152,11 +152,9 @@ int cdml_l2norm_bwd(const float *z, int64_t ldz, const float *g, int64_t ldg,
 
 /* y[M][N] = leaky_relu(x[M][K] @ W[K][N] + b[N], alpha): slim.fully_connected
  * with tf.nn.leaky_relu (models.py:19-30,59-60).  W is [in,out] like slim.
- * K % 32 == 0 and N % 64 == 0 (pad with zeros); any M >= 1.  n_real (0 or N: none): columns
- * >= n_real of W and b are zero padding; the matrix work of a last column tile that is mostly
- * padding is skipped (its outputs are 0 either way). */
+ * K % 32 == 0 and N % 64 == 0 (pad with zeros); any M >= 1. */
 int cdml_fc_lrelu_fwd(const float *x, int64_t ldx, const float *W, int64_t ldw,
-                      const float *b, float alpha, int M, int K, int N, int n_real,
+                      const float *b, float alpha, int M, int K, int N,
                       float *y, int64_t ldy, cdml_stream_t stream);
 
 /* dx[M][K] = (dy[M][N] @ W[K][N]^T) * lrelu'(x_post[M][K]) -- the data gradient

@@ -43,7 +43,7 @@ def test_argument_errors_need_no_gpu(built):
     rc = lib.cdml_l2norm_fwd(None, 4, 4, 4, None, 4, None, None)
     assert rc in (-1, -3)
     assert lib.cdml_last_error()
-    rc = lib.cdml_fc_lrelu_fwd(C.c_void_p(16), 48, C.c_void_p(16), 64, C.c_void_p(16), 0.2, 8, 48, 64, 0,
+    rc = lib.cdml_fc_lrelu_fwd(C.c_void_p(16), 48, C.c_void_p(16), 64, C.c_void_p(16), 0.2, 8, 48, 64,
                                C.c_void_p(16), 64, None)
     assert rc == -4 and b"multiple of 32" in lib.cdml_last_error()
     assert lib.cdml_fc_bwd_weight_workspace(8192, 1536, 5120) >= 5120 * 4       # one split: bias partials only

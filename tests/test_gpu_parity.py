@@ -341,27 +341,6 @@ def test_fc_fwd_identity_asymmetric(cd):
     np.testing.assert_array_equal(y.cpu().numpy(), Bm.astype(np.float32))
 
 
-@pytest.mark.parametrize("M,K,N,n_real", [(1000, 1504, 5120, 5000), (640, 96, 1024, 897), (640, 96, 1024, 1000),
-                                          (512, 64, 512, 385), (300, 64, 5120, 5119)])
-def test_fc_fwd_padded_last_column_tile(cd, M, K, N, n_real):
-    """H = 5000 in a 5120-wide layout: the MFMA work of all-padding column groups is skipped;
-    the result is the full product's (padding columns exactly 0)."""
-    rng = np.random.RandomState(n_real)
-    x = rng.randn(M, K) / np.sqrt(K)
-    W = rng.randn(K, N) * 0.5
-    b = rng.randn(N) * 0.1
-    W[:, n_real:] = 0
-    b[n_real:] = 0
-    full = torch.full((M, N), 7.0, device=cd.dev)
-    cd.ops.fc_lrelu_fwd(dt(x, cd.dev), dt(W, cd.dev), dt(b, cd.dev), full, M, K, N)
-    y = torch.full((M, N), 7.0, device=cd.dev)
-    cd.ops.fc_lrelu_fwd(dt(x, cd.dev), dt(W, cd.dev), dt(b, cd.dev), y, M, K, N, n_real=n_real)
-    assert torch.equal(y, full) and float(y[:, n_real:].abs().max()) == 0
-    want = otower.fully_connected(x.astype(np.float32).astype(np.float64), W.astype(np.float32).astype(np.float64),
-                                  b.astype(np.float32).astype(np.float64))
-    assert np.abs(y.cpu().numpy() - want).max() < 1e-5
-
-
 @pytest.mark.parametrize("M,K,N", [(15, 64, 64), (130, 192, 96), (384, 5120, 256), (200, 128, 32)])
 def test_fc_bwd_data(cd, M, K, N):
     rng = np.random.RandomState(M + K)
