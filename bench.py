@@ -448,7 +448,7 @@ def main():
 
                 def launch():                               # (training on `ts` is over: its buffers are scratch now)
                     if n_st > 1:
-                        ts._gather_block(0, nxt[0])
+                        ts._gather_block(nxt[0])
                     else:
                         ops.sample_gather(m, ts.pairs, ts.seed, nxt[0], B, ts.table.data, F, ts.idx, ts.ws.x_hat,
                                           shift_out=ts.shift)

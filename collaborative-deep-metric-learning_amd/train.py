@@ -156,19 +156,13 @@ class TrainStep:
         if self.bf16 or exchange is not None or self.train_table:
             self.gather_ahead = 1
         self._ahead_base = None
-        self._next_base = None
-        self._blk = 0
         if self.gather_ahead > 1:
-            # eager: two buffer sets, the NEXT block of steps is fetched on a side stream while this
-            # block's GEMMs run (the gather is HBM-bound, the GEMMs MFMA-bound); a captured step
-            # keeps the gather in-stream (one set)
-            K, nset = self.gather_ahead, (1 if use_graph else 2)
-            self._xa = torch.zeros((nset, K) + tuple(self.ws.x_hat.shape), dtype=f32, device=dev)
-            self._idxa = torch.zeros((nset, K, self.R), dtype=i32, device=dev)
-            self._shifta = torch.zeros((nset, K), dtype=i32, device=dev)
-            if nset == 2:
-                self._gstream = torch.cuda.Stream(self.device)
-                self._gready = torch.cuda.Event()
+            # (fetching the NEXT block on a side stream under this block's GEMMs was measured: the
+            # gather left the critical path, but the GEMM it ran beside lost as much -- dropped)
+            K = self.gather_ahead
+            self._xa = torch.zeros((K,) + tuple(self.ws.x_hat.shape), dtype=f32, device=dev)
+            self._idxa = torch.zeros((K, self.R), dtype=i32, device=dev)
+            self._shifta = torch.zeros(K, dtype=i32, device=dev)
             self._select_ahead(0)
         self._graphs = {}
         self._warmed = False
@@ -224,14 +218,13 @@ class TrainStep:
         return t - b
 
     def _select_ahead(self, off):
-        k = self._blk
-        self.ws.x_hat, self.idx, self.shift = self._xa[k, off], self._idxa[k, off], self._shifta[k, off:off + 1]
+        self.ws.x_hat, self.idx, self.shift = self._xa[off], self._idxa[off], self._shifta[off:off + 1]
 
-    def _gather_block(self, k, step=None):
-        """Sample + gather the steps step .. step+gather_ahead-1 into buffer set k (step None: the
+    def _gather_block(self, step=None):
+        """Sample + gather the steps step .. step+gather_ahead-1 in one launch (step None: the
         device counter's value when the kernel runs)."""
         ops.sample_gather(_MODES[self.mode], self.pairs, self.seed, step, self.B, self.table.data,
-                          self.table.feature_size, self._idxa[k], self._xa[k], shift_out=self._shifta[k],
+                          self.table.feature_size, self._idxa, self._xa, shift_out=self._shifta,
                           slot0=self.slot0, batch_global=self.batch_global,
                           step_dev=self.step_dev if step is None else None, n_steps=self.gather_ahead)
 
@@ -241,21 +234,8 @@ class TrainStep:
         if self.gather_ahead > 1:
             off = self._ahead_offset()
             if off == 0:
-                t, K = self.global_step, self.gather_ahead
-                side = self._xa.shape[0] == 2 and not torch.cuda.is_current_stream_capturing()
-                cur = torch.cuda.current_stream(self.device)
-                if side and self._next_base == t:          # the side stream has fetched this block already
-                    cur.wait_event(self._gready)
-                    self._blk ^= 1
-                else:
-                    self._gather_block(self._blk)
-                self._ahead_base, self._next_base = t, None
-                if side:                                   # the block after this one, under this block's GEMMs
-                    self._gstream.wait_stream(cur)         # (its buffers' last readers are enqueued before here)
-                    with torch.cuda.stream(self._gstream):
-                        self._gather_block(self._blk ^ 1, t + K)
-                        self._gready.record(self._gstream)
-                    self._next_base = t + K
+                self._gather_block()
+                self._ahead_base = self.global_step
             self._select_ahead(off)
             return
         if self.prefetch is not None:
@@ -504,7 +484,7 @@ class TrainStep:
         self.step_dev.fill_(self.global_step)
         self.seed = int(state["seed"])
         self._graphs = {}
-        self._ahead_base = self._next_base = None
+        self._ahead_base = None
         self._filled = -1
 
 
