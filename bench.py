@@ -291,7 +291,9 @@ def main():
 
         # per-kernel event timers on the launch stream (off during graph replay)
         kt = KernelTimer()
-        timers_on = not args.no_kernel_timers and not ts.use_graph
+        timers_on = not args.no_kernel_timers
+        graph_run = ts.use_graph                        # timed region replays the graph; the per-kernel
+                                                        # event timers then run on extra EAGER steps after it
         real = {}
         if timers_on:
             def patch(name, label):
@@ -337,7 +339,7 @@ def main():
         # pairs a step are ~1 % of it; the sampled launches are still launches of the timed region
         t0 = time.perf_counter()
         for i in range(args.steps):
-            kt.on = timers_on and (i % 4 == 0)
+            kt.on = timers_on and not graph_run and (i % 4 == 0)
             ts.step()
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -345,6 +347,16 @@ def main():
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
         kt.on = False
+        sampled = (args.steps + 3) // 4
+        if graph_run and timers_on:                     # same kernels, launched eagerly, for the roofline
+            ts.use_graph = False
+            sampled = 8
+            for i in range(2 * sampled):
+                kt.on = i % 2 == 0
+                ts.step()
+            torch.cuda.synchronize(dev)
+            kt.on = False
+            ts.use_graph = True
         for name, fn in real.items():
             setattr(ops, name, fn)
         if timers_on:
@@ -396,7 +408,6 @@ def main():
         kname = "k_gemm_bf16_256<true, 3>" if bf16 else "k_gemm_f32<false, false, 2, 2, 3,"
         have_dw = kt.count("dW") or (kt.count("dW1") and kt.count("dW2"))
         if timers_on and have_dw and kt.count("fc1_fwd"):
-            sampled = (args.steps + 3) // 4
             if kt.count("dW"):                          # stream-K: dW1 and dW2 (+ the fix-up pass) in one call
                 n_launch, t_ms = kt.count("dW"), kt.mean_ms("dW")
                 kname, klabel = "k_gemm_f32_sk", "k_gemm_f32_sk (dW1+dW2 in one stream-K launch, fix-up pass included)"
@@ -411,7 +422,9 @@ def main():
                                "frac": round(ach / peak, 4),
                                "traffic": pmc_traffic(kname) if world == 1 else None,
                                "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch,
-                               "launches_per_step": n_launch / sampled, "timed_steps": sampled}
+                               "launches_per_step": n_launch / sampled, "timed_steps": sampled,
+                               "timed_how": "event pairs on every 4th timed step" if not graph_run else
+                                            "event pairs on 8 eager steps after the graph-replayed timed region"}
             ach1 = flops_gemm / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
             k1 = "k_gemm_bf16_256<false, 0>" if bf16 else "k_gemm_f32<true, false, 2, 2, 1,"
             out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": k1 + ("" if bf16 else " ...>"),
