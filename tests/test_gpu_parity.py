@@ -261,7 +261,9 @@ FC_SHAPES = [(15, 64, 64), (130, 96, 192), (384, 1536, 5120), (257, 5120, 256), 
 
 
 @pytest.mark.parametrize("M,K1,N1,K2,N2", [(777, 1024, 4096, 4096, 128), (8192, 1536, 5120, 5120, 256),
-                                            (4100, 1536, 5120, 5120, 256), (256, 2048, 2048, 128, 128)])
+                                            (4100, 1536, 5120, 5120, 256), (256, 2048, 2048, 128, 128),
+                                            (300, 4096, 4096, 128, 128),      # 1025 tiles: two whole rounds + one tile in 10 parts
+                                            (1000, 4096, 2048, 2048, 128)])   # 528 tiles: one whole round + 16 split
 def test_fc_bwd_weight2_stream_k(cd, M, K1, N1, K2, N2):
     """Both weight gradients in one stream-K launch == the per-layer launches (fp32 summation
     order aside) == x^T dy in fp64; bias gradients ride along; repeatable bit for bit."""
