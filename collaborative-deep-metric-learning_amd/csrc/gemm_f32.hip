@@ -636,34 +636,34 @@ __global__ void __launch_bounds__(kThreads, 2) k_gemm_f32_sk(SkArgs g) {
   }
 }
 
-// One block per output tile: a tile that was computed in parts is the sum of its parts, added in
-// block order (block b0 holds the part that starts the tile in its slot 1, every later block its
-// part in slot 0).  Whole tiles are already in place.
+// A tile that was computed in parts is the sum of its parts, added in block order (block b0
+// holds the part that starts the tile in its slot 1, every later block its part in slot 0).
+// 16 blocks per split tile (8 rows each: one float4 per thread and part, all parts' loads in
+// flight together) -- one block per tile left a 11-part tile to 704 KB of serial reads.
+constexpr int kFixChunks = 16;
 __global__ void __launch_bounds__(kThreads) k_gemm_f32_sk_fixup(SkArgs g, int first_split) {
-  const int T = first_split + blockIdx.x, t = threadIdx.x;       // one block per tile that was split
-  const int64_t first = (int64_t)blockIdx.x * g.n_kt;
+  const int ts = blockIdx.x / kFixChunks, chunk = blockIdx.x % kFixChunks;
+  const int T = first_split + ts, t = threadIdx.x;
+  const int64_t first = (int64_t)ts * g.n_kt;
   const int b0 = (int)(first / g.ipb), b1 = (int)((first + g.n_kt - 1) / g.ipb);
-  if (b0 == b1) return;
+  if (b0 == b1) return;                                          // written in place by one block
   int pi, tm, tn;
   sk_tile(g, T, pi, tm, tn);
   float *C = (pi ? g.p[1].C : g.p[0].C);
   const int64_t ldc = pi ? g.p[1].ldc : g.p[0].ldc;
   float *pcs = pi ? g.p[1].colsum : g.p[0].colsum;
   const int m0 = tm * 128, n0 = tn * 128;
-#pragma unroll 4
-  for (int j = 0; j < 16; ++j) {
-    const int idx = t + kThreads * j;
-    const int row = idx >> 5, c4 = idx & 31;
-    f32x4 sum = *reinterpret_cast<const f32x4 *>(g.slabs + ((int64_t)b0 * 2 + 1) * 16384 + row * 128 + c4 * 4);
+  const int row = chunk * 8 + (t >> 5), c4 = t & 31;
+  const int64_t off = (int64_t)row * 128 + c4 * 4;
+  f32x4 sum = *reinterpret_cast<const f32x4 *>(g.slabs + ((int64_t)b0 * 2 + 1) * 16384 + off);
+  for (int b = b0 + 1; b <= b1; ++b)
+    sum += *reinterpret_cast<const f32x4 *>(g.slabs + ((int64_t)b * 2) * 16384 + off);
+  *reinterpret_cast<f32x4 *>(C + (int64_t)(m0 + row) * ldc + n0 + c4 * 4) = sum;
+  if (pcs && tm == 0 && chunk == 0 && t < 32) {
+    f32x4 cs = *reinterpret_cast<const f32x4 *>(g.cs_slabs + ((int64_t)b0 * 2 + 1) * 128 + t * 4);
     for (int b = b0 + 1; b <= b1; ++b)
-      sum += *reinterpret_cast<const f32x4 *>(g.slabs + ((int64_t)b * 2) * 16384 + row * 128 + c4 * 4);
-    *reinterpret_cast<f32x4 *>(C + (int64_t)(m0 + row) * ldc + n0 + c4 * 4) = sum;
-  }
-  if (pcs && tm == 0 && t < 32) {
-    f32x4 sum = *reinterpret_cast<const f32x4 *>(g.cs_slabs + ((int64_t)b0 * 2 + 1) * 128 + t * 4);
-    for (int b = b0 + 1; b <= b1; ++b)
-      sum += *reinterpret_cast<const f32x4 *>(g.cs_slabs + ((int64_t)b * 2) * 128 + t * 4);
-    *reinterpret_cast<f32x4 *>(pcs + n0 + t * 4) = sum;
+      cs += *reinterpret_cast<const f32x4 *>(g.cs_slabs + ((int64_t)b * 2) * 128 + t * 4);
+    *reinterpret_cast<f32x4 *>(pcs + n0 + t * 4) = cs;
   }
 }
 
@@ -884,7 +884,7 @@ extern "C" int cdml_fc_bwd_weight2(const float *x1, int64_t ldx1, const float *d
   hipLaunchKernelGGL(k_gemm_f32_sk, dim3(kSkGrid), dim3(kThreads), 0, (hipStream_t)stream, g);
   if ((rc = check_launch("fc_bwd_weight2"))) return rc;
   if (n_split > 0) {
-    hipLaunchKernelGGL(k_gemm_f32_sk_fixup, dim3(n_split), dim3(kThreads), 0, (hipStream_t)stream, g,
+    hipLaunchKernelGGL(k_gemm_f32_sk_fixup, dim3(n_split * kFixChunks), dim3(kThreads), 0, (hipStream_t)stream, g,
                        g.whole_rounds * kSkGrid);
     rc = check_launch("fc_bwd_weight2 fix-up");
   }
