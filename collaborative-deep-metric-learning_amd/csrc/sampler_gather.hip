@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(kThreads)
 k_sample_uniform(const int32_t *__restrict__ pairs, int64_t n_pairs, uint32_t n_rows,
                  uint64_t seed, uint64_t step_imm, const uint64_t *__restrict__ step_dev,
                  int batch, int64_t slot0, int64_t batch_global, int32_t *__restrict__ idx_out) {
-  const uint64_t step = step_dev ? *step_dev : step_imm;
+  const uint64_t step = step_imm + (step_dev ? *step_dev : 0);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= batch) return;
   const uint64_t slot = (uint64_t)(slot0 + i);
@@ -84,7 +84,7 @@ k_sample_inbatch(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t se
                  uint64_t step_imm, const uint64_t *__restrict__ step_dev, int batch,
                  int64_t slot0, int64_t batch_global, int32_t *__restrict__ rows_out,
                  int32_t *__restrict__ shift_out) {
-  const uint64_t step = step_dev ? *step_dev : step_imm;
+  const uint64_t step = step_imm + (step_dev ? *step_dev : 0);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) *shift_out = sample_inbatch_shift(seed, step, batch);
   if (i >= batch) return;
@@ -248,7 +248,7 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
                 int n_steps, int64_t x_step_stride, int64_t idx_step_stride) {
   constexpr int RPT = (MODE == 0) ? 3 : 2;  // rows per triplet
   __shared__ int32_t s_id[2][kChunkRows];
-  const uint64_t step0 = step_dev ? *step_dev : step_imm;
+  const uint64_t step0 = step_imm + (step_dev ? *step_dev : 0);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t rows_per_step = (int64_t)RPT * batch;

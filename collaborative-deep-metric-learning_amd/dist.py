@@ -319,6 +319,16 @@ class Prefetcher:
         if self.cuda and not self._capturing():
             torch.cuda.current_stream(self.device).wait_event(self.ready[b])
 
+    def wait_ready(self, b):
+        """The compute stream (and what is issued on it next: the gradient all-reduce) waits for
+        the exchange into buffer b; inside a capture that is the join of the forked branch."""
+        if not self.cuda:
+            return
+        if self._capturing():
+            self.join()
+        else:
+            torch.cuda.current_stream(self.device).wait_event(self.ready[b])
+
     def release(self, b):
         if self.cuda and not self._capturing():
             self.free[b].record(torch.cuda.current_stream(self.device))

@@ -194,13 +194,14 @@ class TrainStep:
 
     # ---------------------------------------------------------------- pieces --
     def _fill(self, b, step):
-        """Sample step `step` and exchange its rows into buffer b.  Eager: the step is an
-        immediate (the side stream runs ahead of the device counter).  Inside a graph capture the
-        branch is forked behind the optimizer, which has advanced the device counter to exactly
-        this step, so the captured kernels read it from there and replays follow it."""
+        """Sample step `step` (= the current step + 1) and exchange its rows into buffer b.
+        Eager: the step is an immediate (the side stream runs ahead of the device counter).
+        Inside a graph capture the kernels read the device counter + 1 instead, so replays follow
+        it; the branch completes before the all-reduce is issued, hence before the optimizer
+        advances the counter."""
         sd = None
         if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
-            step, sd = None, self.step_dev
+            step, sd = 1, self.step_dev
         if _MODES[self.mode] == MODE_UNIFORM:
             ops.sample_uniform(self.pairs, self.table.n_rows_global, self.seed, step, self.B,
                                self._idx[b], slot0=self.slot0, batch_global=self.batch_global, step_dev=sd)
@@ -371,10 +372,20 @@ class TrainStep:
 
     def _enqueue(self):
         self.fetch()
+        if self.prefetch is not None:
+            # next step's rows right away (the sampler is counter-based): the exchange runs under
+            # this step's forward GEMMs, and the gradient all-reduce below is issued only after
+            # it has finished, so the two communicators never run side by side and every rank
+            # executes its collectives in the same order
+            t, b = self.global_step, self.global_step % 2
+            self.prefetch.launch(1 - b, lambda: self._fill(1 - b, t + 1))
+            self._filled = t + 1
         self.forward_loss()
         if self.grad_sync is None:
             self.backward()
         else:
+            if self.prefetch is not None:
+                self.prefetch.wait_ready(1 - b)
             # buckets: [dW1|db1] (85 % of the bytes) is all-reduced while later GEMMs run, in two
             # row blocks -- the first under the second block's GEMM, the second under the dW2
             # GEMM -- and [dW2|db2] right after its GEMM; the optimizer waits for all of them
@@ -386,14 +397,11 @@ class TrainStep:
             handles.append(self.grad_sync.start(self.params.grad, n1, self.layout.numel))
             self.grad_sync.finish(handles)
         if self.prefetch is not None:
-            t, b = self.global_step, self.global_step % 2
             self.prefetch.release(b)                 # backward was the last reader of x_hat[b]
         if self.train_table:
             self.update_table()
         self.apply_gradients()
-        if self.prefetch is not None:                # next step's rows, under this step's GEMMs
-            self.prefetch.launch(1 - b, lambda: self._fill(1 - b, t + 1))
-            self._filled = t + 1
+        if self.prefetch is not None:
             self.prefetch.join()                     # (inside a graph capture: the branch rejoins)
 
     # ------------------------------------------------------------------ step --

@@ -66,8 +66,9 @@ int cdml_fill_uniform_table(float *table, int64_t row0, int64_t n_rows,
  * pairs int32[n_pairs][2] co-watch (anchor,positive) video ids, read as one
  * sequential stream with wrap-around: slot s of step t is pair
  * (t*batch_global + s) mod n_pairs.  This call produces slots
- * [slot0, slot0+batch).  If step_dev is non-NULL the step is read from device
- * memory (graph replay); otherwise `step` is used.
+ * [slot0, slot0+batch).  The step is `step` plus, if step_dev is non-NULL, the
+ * counter read from device memory at execution (graph replay; `step` is then an
+ * offset, e.g. 1 to sample the NEXT step while the optimizer has not advanced yet).
  * Uniform mode: negative ~ U{0..n_rows-1} from the counter-based stream
  * specified in oracle/sampler.py, redrawn while it equals the anchor or the
  * positive (inputs.py:125-127).  idx_out int32[batch][3] = (a,p,n). */
