@@ -30,9 +30,6 @@ int gemm_bf16_256_splits(int M, int N, int K);
 // g.tiles_m / g.tiles_n / g.k_per_split / g.C (slabs when splits > 1) set by the caller
 int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t stream);
 
-// one-wave-per-SIMD 256x256x32 kernel (gemm_bf16_w4.hip): same shape contract as the 256x256 kernel
-int launch_gemm_bf16_w4(const BArgs &g, int epilogue, int splits, hipStream_t stream);
-
 // k-strided form C[M][N] = sum_k A[k][M] * B[k][N] (fp32 slabs): M, N % 256 == 0, K % 128 == 0
 bool gemm_bf16_tn_usable(int M, int N, int K, int64_t lda, int64_t ldb);
 int launch_gemm_bf16_tn(const BArgs &g, int splits, hipStream_t stream);

@@ -390,12 +390,6 @@ static int forced_tile() {
   return e ? atoi(e) : 0;
 }
 
-// the one-wave-per-SIMD kernel instead of the ping-pong one where the big tile applies
-static bool use_w4() {
-  const char *e = getenv("CDML_BF16_W4");
-  return e ? atoi(e) != 0 : false;
-}
-
 static bool use_256(int epilogue, int M, int N, int K, int64_t lda, int64_t ldb) {
   if (forced_tile() == 128 || !gemm_bf16_256_usable(M, N, K, lda, ldb)) return false;
   if (forced_tile() == 256) return true;
@@ -453,7 +447,7 @@ extern "C" int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda, c
       g.slab_stride = (int64_t)M * N;
       g.C = workspace; g.ldc = N;
       g.tiles_m = (M + 255) / 256; g.tiles_n = N / 256;
-      int rc = use_w4() ? launch_gemm_bf16_w4(g, BE_F32, fs, s) : launch_gemm_bf16_256(g, BE_F32, fs, s);
+      int rc = launch_gemm_bf16_256(g, BE_F32, fs, s);
       if (rc) return rc;
       hipLaunchKernelGGL(k_sum_slabs_bias_lrelu, dim3(grid1d((int64_t)M * N / 4, 1)), block, 0, s,
                          static_cast<const float *>(workspace), g.slab_stride, fs, M, N, bias, alpha,
@@ -479,7 +473,7 @@ extern "C" int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda, c
   int rc;
   if (big) {
     g.tiles_m = (M + 255) / 256; g.tiles_n = N / 256;
-    rc = use_w4() ? launch_gemm_bf16_w4(g, epilogue, splits, s) : launch_gemm_bf16_256(g, epilogue, splits, s);
+    rc = launch_gemm_bf16_256(g, epilogue, splits, s);
   } else {
   const dim3 grid(g.tiles_m * g.tiles_n, splits);
   switch (epilogue) {

@@ -38,15 +38,9 @@ def dbf(x, dev):
                                         (77, 128, 5120, 0),
                                         # the 256x256 ping-pong kernel: minimal, ragged M, long K, many tiles
                                         (256, 256, 128, 256), (700, 512, 384, 256), (1000, 1024, 1536, 256),
-                                        (77, 256, 5120, 256), (3100, 4096, 512, 0), (2000, 256, 5120, 0),
-                                        # the one-wave-per-SIMD 256x256x32 kernel (tile code 4)
-                                        (256, 256, 64, 4), (700, 512, 384, 4), (1000, 1024, 1536, 4),
-                                        (77, 256, 5120, 4), (3100, 4096, 512, 4), (24576, 512, 1536, 4)])
+                                        (77, 256, 5120, 256), (3100, 4096, 512, 0), (2000, 256, 5120, 0)])
 def test_gemm_bf16_epilogues(cd, M, N, K, tile, monkeypatch):
-    if tile == 4:
-        monkeypatch.setenv("CDML_BF16_TILE", "256")
-        monkeypatch.setenv("CDML_BF16_W4", "1")
-    elif tile:
+    if tile:
         monkeypatch.setenv("CDML_BF16_TILE", str(tile))
     rng = np.random.RandomState(M + N)
     A, B = rng.randn(M, K) / np.sqrt(K), rng.randn(N, K)

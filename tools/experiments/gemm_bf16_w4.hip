@@ -1,3 +1,8 @@
+// EXPERIMENT, NOT PART OF THE LIBRARY (measured slower than the shipped ping-pong kernel, see the
+// end of this header and DESIGN.md section 5; it was built into the library behind CDML_BF16_W4=1,
+// parity-tested with tests/test_gpu_bf16.py::test_gemm_bf16_epilogues and timed with
+// gemm_bf16_w4_bench.py next to this file).
+//
 // bf16 projection GEMM, one-wave-per-SIMD form: C[M][N] = epilogue(A[M][K] . B[N][K]^T),
 // both operands k-contiguous bf16, fp32 accumulation (v_mfma_f32_32x32x16_bf16).
 // Same layers and epilogues as gemm_bf16_256.hip (models.py:59-60, train.py:141 at BASELINE
@@ -17,7 +22,18 @@
 //     matrix pipe never waits for LDS;
 //   * 64-B image rows, 16-B chunks XOR-swizzled by (row>>2)&3 on the DMA's source address and on
 //     the read (conflict-free for ds_read_b128's 16-lane groups).
+// Result (R = 24 576, MI355X): long-K product 0.40 of 2.5 PF against the ping-pong kernel's 0.51,
+// FC1 0.33-0.37 against 0.38.  Timing ablations (CDML_W4_ABLATE): without the barrier 0.43, without
+// the fragment reads 0.41, WITHOUT THE LDS-DMA 0.62 -- the loop is bound by the global -> LDS
+// stream, and its 64-B image rows fetch every 128-B line of an operand row in two halves, two
+// K-tiles apart (the ping-pong kernel's 128-B rows fetch whole lines).
 #include "gemm_bf16.h"
+
+// timing ablations (WRONG RESULTS; tools/gemm_bf16_w4_bench.py with CDML_LIB_PATH): bit 0 = no
+// barrier / DMA wait in the loop, bit 1 = no DMA issue in the loop, bit 2 = no fragment reads
+#ifndef CDML_W4_ABLATE
+#define CDML_W4_ABLATE 0
+#endif
 
 namespace cdml {
 namespace {
@@ -89,13 +105,16 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_w4(BArgs g) {
     vb[i] = (uint32_t)(((int64_t)(n0 + row) * g.ldb + k_begin + q * 8) * 2);
   }
   const uint32_t lds_piece = __builtin_amdgcn_readfirstlane(lds_off(smem) + wave * 4096);
-  auto stage_tile = [&](int tile) {              // 8 wave-instructions: this wave's share of K-tile `tile`
+  // one wave-instruction (1 KiB) of this wave's share of K-tile `tile`: j = 0..3 A pieces, 4..7 B pieces
+  auto stage_piece = [&](int tile, int j) {
     const uint32_t kb = tile < n_kt ? (uint32_t)(tile * kBK * 2) : 0x80000000u;   // beyond the range: zeros
     const uint32_t base = lds_piece + (tile & (kStages - 1)) * STAGE;
+    if (j < 4) dma(srd_a, va[j] + kb, base + j * 1024);
+    else dma(srd_b, vb[j - 4] + kb, base + IMG + (j - 4) * 1024);
+  };
+  auto stage_tile = [&](int tile) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma(srd_a, va[i] + kb, base + i * 1024);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma(srd_b, vb[i] + kb, base + IMG + i * 1024);
+    for (int j = 0; j < 8; ++j) stage_piece(tile, j);
   };
 
   // ---- fragment reads: lane (l31, h) holds k = 16*ks + 8*h .. +7 of image row l31 ----
@@ -103,15 +122,10 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_w4(BArgs g) {
   const unsigned char *a_rd = smem + (wr * 128 + l31) * 64;
   const unsigned char *b_rd = smem + IMG + (wc * 128 + l31) * 64;
   const int sw0 = ((0 + h) ^ x) * 16, sw1 = ((2 + h) ^ x) * 16;
-  struct Frags { bf16x8 a[4], b[4]; };
-  auto read_frags = [&](int tile, int ks) {        // returned by value (by-reference arrays end up in scratch)
-    Frags f;
+  // fragment j of k-step ks of K-tile `tile`: j = 0..3 the wave's four 32-row groups of A, 4..7 of B
+  auto read_frag = [&](int tile, int ks, int j) {
     const int so = (tile & (kStages - 1)) * STAGE + (ks ? sw1 : sw0);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) f.a[mi] = *reinterpret_cast<const bf16x8 *>(a_rd + so + mi * 2048);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) f.b[ni] = *reinterpret_cast<const bf16x8 *>(b_rd + so + ni * 2048);
-    return f;
+    return *reinterpret_cast<const bf16x8 *>((j < 4 ? a_rd : b_rd) + so + (j & 3) * 2048);
   };
 
   f32x16 acc[4][4];
@@ -122,34 +136,46 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_w4(BArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#define CDML_W4_MFMA(F)                                                                        \
-  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
-  _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                             \
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((F).a[mi], (F).b[ni], acc[mi][ni], 0, 0, 0)
-
   // prologue: three K-tiles in flight, the first one landed and visible
   stage_tile(0);
   stage_tile(1);
   stage_tile(2);
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   CDML_W4_BARRIER();
-  Frags f0 = read_frags(0, 0), f1;
+  bf16x8 f0[8], f1[8];                           // [0..3] A fragments, [4..7] B fragments; two register sets
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f0[j] = read_frag(0, 0, j);
+  // One K-tile = two blocks of 16 MFMAs.  Everything else the wave has to issue rides in the
+  // issue slots BETWEEN the MFMAs (a 32x32x16 MFMA holds the pipe for 32 cycles and the wave is
+  // free to issue one LDS read or one DMA meanwhile): put after the MFMAs as one lump, the 8 reads
+  // + 8 DMAs + barrier left the pipe idle a third of the time (0.37 of peak on the long-K shape).
+  //   block 0 (k-step 0, set f0): the 8 fragment reads of k-step 1 -> f1 behind MFMAs 0..7, the 8
+  //            DMA pieces of K-tile tile+3 behind MFMAs 8..15 (its stage was last read in K-tile
+  //            tile-1; every wave retired those reads before the barrier inside that K-tile);
+  //   then     this wave's pieces of K-tile tile+1 have landed (16 newer may fly), own reads retired,
+  //            barrier: that now holds for every wave;
+  //   block 1 (k-step 1, set f1): the 8 fragment reads of K-tile tile+1, k-step 0 -> f0.
   for (int tile = 0; tile < n_kt; ++tile) {
-    // stage (tile+3)&3 was last read during K-tile tile-1; every wave retired those reads before
-    // the barrier inside that K-tile, so the stage may be refilled
-    stage_tile(tile + 3);
-    f1 = read_frags(tile, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    CDML_W4_MFMA(f0);
-    // K-tile tile+1: this wave's 8 pieces have landed (the 16 newer ones may still fly) and its
-    // own LDS reads are retired; after the barrier that holds for every wave
-    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-    CDML_W4_BARRIER();
-    f0 = read_frags(tile + 1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    CDML_W4_MFMA(f1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int mi = j >> 2, ni = j & 3;
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[mi], f0[4 + ni], acc[mi][ni], 0, 0, 0);
+      if (j < 8) { if (!(CDML_W4_ABLATE & 4)) f1[j] = read_frag(tile, 1, j); }
+      else if (!(CDML_W4_ABLATE & 2)) stage_piece(tile + 3, j - 8);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!(CDML_W4_ABLATE & 1)) {
+      asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      CDML_W4_BARRIER();
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int mi = j >> 2, ni = j & 3;
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[mi], f1[4 + ni], acc[mi][ni], 0, 0, 0);
+      if (j < 8 && !(CDML_W4_ABLATE & 4)) f0[j] = read_frag(tile + 1, 0, j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
-#undef CDML_W4_MFMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the out-of-range tail DMAs still write zeros
   CDML_W4_BARRIER();
 
