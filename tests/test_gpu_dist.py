@@ -278,6 +278,9 @@ def test_bench_two_rank_rehearsal(gpu):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 512 and out["value"] > 0
     assert out["roofline"]["launches_per_step"] == 3.0      # dW1 in two row blocks + dW2
+    comm = out["comm"]                                       # what the first real RCCL run will report
+    assert comm["allreduce_exposed_ms"] is not None and comm["exchange_exposed_ms"] is not None
+    assert comm["exchange_bytes"] > 2 * 256 * 1536 * 4 and comm["allreduce_bytes"] == 4 * 9180416
     assert np.isfinite(out["loss"])
 
 
