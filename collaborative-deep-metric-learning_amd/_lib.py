@@ -103,6 +103,10 @@ def load_library():
         raise CdmlError(-2, f"{path} not found: build it with "
                             f"`python -c 'import __graft_entry__ as g; g.build()'` "
                             f"(there is no CPU fallback)")
+    # torch first: the process must end up with ONE HIP runtime, the one torch ships and allocates
+    # device memory with.  Loaded before torch, this library pulls in the system libamdhip64 and
+    # its launches then fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
