@@ -335,11 +335,13 @@ def main():
             ts.step()
         sync_all()
         phase = "timed steps"
-        # kernel timers on every 4th timed step: an event pair costs the stream a few us, a dozen
-        # pairs a step are ~1 % of it; the sampled launches are still launches of the timed region
+        # kernel timers on every 4th timed step (every 8th in long runs): an event pair costs the
+        # stream ~5 us, seven pairs a step are 1.5 % of it; the sampled launches are still launches
+        # of the timed region
+        stride = 4 if args.steps < 100 else 8
         t0 = time.perf_counter()
         for i in range(args.steps):
-            kt.on = timers_on and not graph_run and (i % 4 == 0)
+            kt.on = timers_on and not graph_run and (i % stride == 0)
             ts.step()
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -347,7 +349,7 @@ def main():
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
         kt.on = False
-        sampled = (args.steps + 3) // 4
+        sampled = (args.steps + stride - 1) // stride
         if graph_run and timers_on:                     # same kernels, launched eagerly, for the roofline
             ts.use_graph = False
             sampled = 8
@@ -423,7 +425,7 @@ def main():
                                "traffic": pmc_traffic(kname) if world == 1 else None,
                                "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch,
                                "launches_per_step": n_launch / sampled, "timed_steps": sampled,
-                               "timed_how": "event pairs on every 4th timed step" if not graph_run else
+                               "timed_how": ("event pairs on every %dth timed step" % stride) if not graph_run else
                                             "event pairs on 8 eager steps after the graph-replayed timed region"}
             ach1 = flops_gemm / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
             k1 = "k_gemm_bf16_256<false, 0>" if bf16 else "k_gemm_f32<true, false, 2, 2, 1,"
@@ -491,7 +493,7 @@ def main():
                            "exchange_bytes": exchange.bytes_per_step(ts.R, ts.ws.x_hat),
                            "allreduce_bytes": int(ts.layout.numel * 4),
                            "note": "event pairs around GradSync.finish / Prefetcher.acquire on the compute stream "
-                                   "(every 4th timed step): what the step waits for, not the collectives' own duration"}
+                                   "(on the sampled timed steps): what the step waits for, not the collectives' own duration"}
         step_flops = R * (2.0 * F * H + 2.0 * H * D) + R * (2.0 * F * H + 4.0 * H * D)
         out["step_tflops"] = round(step_flops / (elapsed / args.steps) / 1e12, 2)
 
