@@ -600,6 +600,8 @@ class Trainer:
             self.ts.step()
             gs += 1
             if gs % self.show_step == 0 or gs == n:
+                if self.ts.exchange is not None:        # the device-side overflow / bad-id flag of the row
+                    self.ts.exchange.check_overflow()   # exchange, read where the loop syncs anyway
                 loss = self.ts.loss()
                 self.history.append((gs, loss))
                 self.log.info("Epoch %d Step %d | Loss: %.8f | %.1f triplets/s", gs // self.step_per_epoch + 1,
