@@ -283,10 +283,14 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
   float st_h = 0.f, st_p = 0.f, st_n = 0.f, st_a = 0.f;    // this wave's triplets: sums for the step's scalars
 #pragma unroll
   for (int c = 0; c < NCH; ++c) csum[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // The rows of a wave's LAST triplet are stored after the block has handed in its partial sums and
+  // its ticket (grid_last_block drains the wave's stores first: with 16 KB of row stores in front
+  // of it the ticket cost 7-14 us; now the last block reduces while the others still store).
+  TailRow<NCH> A, P, N;
+  float4 ga[NCH], gp[NCH], gn[NCH];
+  int64_t ra = 0, rp = 0;
+  bool pending = false;
   for (int i = blockIdx.x * kWavesPerBlock + wave; i < B; i += gridDim.x * kWavesPerBlock) {
-    TailRow<NCH> A, P, N;
-    float4 ga[NCH], gp[NCH];
-    int64_t ra, rp;
     bool valid_i = true;
     float pos, neg;
     if (MODE == 0) {
@@ -297,7 +301,6 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       tail_dist<NCH>(A, P, N, pos, neg);
       const float t = pos - neg + margin;
       const float s = (t >= 0.f) ? two_over_b : 0.f;       // MaximumGrad: inclusive at 0
-      float4 gn[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const float4 va = A.e(c), vp = P.e(c), vn = N.e(c);
@@ -307,8 +310,6 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       }
       if (lane == 0) { pos_o[i] = pos; neg_o[i] = neg; hinge_o[i] = fmaxf(t, 0.f); }
       st_h += fmaxf(t, 0.f); st_p += pos; st_n += neg; st_a += (t > 0.f) ? 1.f : 0.f;
-      tail_store_row<NCH>(N, gn, alpha, e + (ra + 2) * lde, dz2 + (ra + 2) * lddz,
-                          dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane);
     } else {
       const int j = (i + shift) % B;
       const int k = (i - shift % B + B) % B;
@@ -344,8 +345,15 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       const float hv = valid_i ? fmaxf(t, 0.f) : 0.f;
       st_h += hv; st_p += pos; st_n += neg; st_a += (hv > 0.f) ? 1.f : 0.f;
     }
-    tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane);
-    tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane);
+    if (stats && i + (int)(gridDim.x * kWavesPerBlock) >= B) {
+      pending = true;                                      // this wave's last triplet: stored below
+    } else {
+      if (MODE == 0)
+        tail_store_row<NCH>(N, gn, alpha, e + (ra + 2) * lde, dz2 + (ra + 2) * lddz,
+                            dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane);
+      tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane);
+      tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane);
+    }
     if (var_ws) {       // column sums and sum of squares of the [B,3,D] triplet tensor
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -392,7 +400,15 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       st_sc1(out + D, v);
     }
   }
-  if (!grid_last_block(tickets)) return;
+  const bool last_block = grid_last_block(tickets);
+  if (pending) {
+    if (MODE == 0)
+      tail_store_row<NCH>(N, gn, alpha, e + (ra + 2) * lde, dz2 + (ra + 2) * lddz,
+                          dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane);
+    tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane);
+    tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane);
+  }
+  if (!last_block) return;
   // ---- the last block: the step's scalars ----
   const float *parts = reinterpret_cast<const float *>(tickets + kTicketWords);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};

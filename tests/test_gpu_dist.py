@@ -175,6 +175,54 @@ def _nccl_worker(port, q):
         q.put(traceback.format_exc())
 
 
+def _trainer_worker(rank, world, port, q, ckdir):
+    """Two ranks run the reference's training loop (Trainer) on a row-sharded catalogue; the
+    dense state is replicated, so only rank 0 may write the checkpoint."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cdml_amd import dist as cdist, train
+        dev = torch.device("cuda:0")
+        ts = _make(dev, rank, world, cdist.RowExchange(CFG["n_rows"], group=dist.new_group()), cdist.GradSync())
+        n_pairs = ts.pairs.shape[0]
+        feats = ts.table.data[:, :CFG["F"]].cpu().numpy()
+        ev = [[0, 1], [2, 3], [4, 5]]                       # local rows of this shard: any pairs do
+        tr = train.Trainer(ts, num_epochs=1, n_pairs=n_pairs, checkpoint_dir=ckdir, eval_features=feats,
+                           eval_cowatches=ev, check_stop_epoch=0.0, best_eval_dist=1e9, eval_per_epoch=2,
+                           require_improve_num=1000)
+        tr.run(max_steps=8)
+        torch.cuda.synchronize()
+        q.put((rank, "ok", ts.global_step, sorted(os.listdir(ckdir)) if os.path.isdir(ckdir) else []))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_trainer_saves_once(gpu, tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q, str(tmp_path / "ck"))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
+    assert res[0][2] == res[1][2] == 8
+    files = sorted(os.listdir(tmp_path / "ck"))
+    assert len(files) == 1 and files[0].startswith("model.ckpt-") and "rank" not in files[0], files
+
+
 def _say(msg):
     sys.stderr.write("[nccl-graph worker] %s\n" % msg)
     sys.stderr.flush()
