@@ -410,11 +410,25 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
   }
   if (!last_block) return;
   // ---- the last block: the step's scalars ----
+  // every block's {sum hinge, sum pos, sum neg, active} record: one 16-B sc1 load each, all of a
+  // thread's loads (<= 8: grids <= 2048 blocks) in flight before the one wait -- relaxed atomic
+  // dword loads are waited for one by one and cost 10 us here
   const float *parts = reinterpret_cast<const float *>(tickets + kTicketWords);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int b = threadIdx.x; b < nb; b += kThreads) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  f4v rec[8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] += ld_sc1(parts + (int64_t)b * 4 + c);
+  for (int u = 0; u < 8; ++u) {
+    rec[u] = f4v{0.f, 0.f, 0.f, 0.f};
+    const int b = threadIdx.x + u * kThreads;
+    if (b < nb) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(rec[u]) : "v"(parts + (int64_t)b * 4) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(rec[0]), "+v"(rec[1]), "+v"(rec[2]), "+v"(rec[3]), "+v"(rec[4]), "+v"(rec[5]), "+v"(rec[6]), "+v"(rec[7])
+               :: "memory");
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {                  // blocks in ascending order per thread: fixed summation order
+    acc[0] += rec[u].x; acc[1] += rec[u].y; acc[2] += rec[u].z; acc[3] += rec[u].w;
   }
   double vsum = 0.0;
   if (var_ws) {         // var = [sum t^2 - n_rows * sum_d mean_d^2] / (n_rows * D), n_rows = 3B
