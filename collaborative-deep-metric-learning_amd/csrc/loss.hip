@@ -283,14 +283,10 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
   float st_h = 0.f, st_p = 0.f, st_n = 0.f, st_a = 0.f;    // this wave's triplets: sums for the step's scalars
 #pragma unroll
   for (int c = 0; c < NCH; ++c) csum[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // The rows of a wave's LAST triplet are stored after the block has handed in its partial sums and
-  // its ticket (grid_last_block drains the wave's stores first: with 16 KB of row stores in front
-  // of it the ticket cost 7-14 us; now the last block reduces while the others still store).
-  TailRow<NCH> A, P, N;
-  float4 ga[NCH], gp[NCH], gn[NCH];
-  int64_t ra = 0, rp = 0;
-  bool pending = false;
   for (int i = blockIdx.x * kWavesPerBlock + wave; i < B; i += gridDim.x * kWavesPerBlock) {
+    TailRow<NCH> A, P, N;
+    float4 ga[NCH], gp[NCH];
+    int64_t ra, rp;
     bool valid_i = true;
     float pos, neg;
     if (MODE == 0) {
@@ -301,6 +297,7 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       tail_dist<NCH>(A, P, N, pos, neg);
       const float t = pos - neg + margin;
       const float s = (t >= 0.f) ? two_over_b : 0.f;       // MaximumGrad: inclusive at 0
+      float4 gn[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const float4 va = A.e(c), vp = P.e(c), vn = N.e(c);
@@ -310,6 +307,8 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       }
       if (lane == 0) { pos_o[i] = pos; neg_o[i] = neg; hinge_o[i] = fmaxf(t, 0.f); }
       st_h += fmaxf(t, 0.f); st_p += pos; st_n += neg; st_a += (t > 0.f) ? 1.f : 0.f;
+      tail_store_row<NCH>(N, gn, alpha, e + (ra + 2) * lde, dz2 + (ra + 2) * lddz,
+                          dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane);
     } else {
       const int j = (i + shift) % B;
       const int k = (i - shift % B + B) % B;
@@ -345,15 +344,8 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       const float hv = valid_i ? fmaxf(t, 0.f) : 0.f;
       st_h += hv; st_p += pos; st_n += neg; st_a += (hv > 0.f) ? 1.f : 0.f;
     }
-    if (stats && i + (int)(gridDim.x * kWavesPerBlock) >= B) {
-      pending = true;                                      // this wave's last triplet: stored below
-    } else {
-      if (MODE == 0)
-        tail_store_row<NCH>(N, gn, alpha, e + (ra + 2) * lde, dz2 + (ra + 2) * lddz,
-                            dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane);
-      tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane);
-      tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane);
-    }
+    tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane);
+    tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane);
     if (var_ws) {       // column sums and sum of squares of the [B,3,D] triplet tensor
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -400,35 +392,13 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       st_sc1(out + D, v);
     }
   }
-  const bool last_block = grid_last_block(tickets);
-  if (pending) {
-    if (MODE == 0)
-      tail_store_row<NCH>(N, gn, alpha, e + (ra + 2) * lde, dz2 + (ra + 2) * lddz,
-                          dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane);
-    tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane);
-    tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane);
-  }
-  if (!last_block) return;
+  if (!grid_last_block(tickets)) return;
   // ---- the last block: the step's scalars ----
-  // every block's {sum hinge, sum pos, sum neg, active} record: one 16-B sc1 load each, all of a
-  // thread's loads (<= 8: grids <= 2048 blocks) in flight before the one wait -- relaxed atomic
-  // dword loads are waited for one by one and cost 10 us here
   const float *parts = reinterpret_cast<const float *>(tickets + kTicketWords);
-  typedef float f4v __attribute__((ext_vector_type(4)));
-  f4v rec[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    rec[u] = f4v{0.f, 0.f, 0.f, 0.f};
-    const int b = threadIdx.x + u * kThreads;
-    if (b < nb) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(rec[u]) : "v"(parts + (int64_t)b * 4) : "memory");
-  }
-  asm volatile("s_waitcnt vmcnt(0)"
-               : "+v"(rec[0]), "+v"(rec[1]), "+v"(rec[2]), "+v"(rec[3]), "+v"(rec[4]), "+v"(rec[5]), "+v"(rec[6]), "+v"(rec[7])
-               :: "memory");
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < nb; b += kThreads) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {                  // blocks in ascending order per thread: fixed summation order
-    acc[0] += rec[u].x; acc[1] += rec[u].y; acc[2] += rec[u].z; acc[3] += rec[u].w;
+    for (int c = 0; c < 4; ++c) acc[c] += ld_sc1(parts + (int64_t)b * 4 + c);
   }
   double vsum = 0.0;
   if (var_ws) {         // var = [sum t^2 - n_rows * sum_d mean_d^2] / (n_rows * D), n_rows = 3B
