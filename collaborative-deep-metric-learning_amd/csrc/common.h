@@ -37,27 +37,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---- "am I the last block of this grid to get here" ------------------------------------
-// For kernels whose last finisher folds a tiny grid-wide reduction (loss statistics, step
-// counter) into the same launch instead of paying another launch for it.  Two-level tickets
+// For a kernel whose last finisher does a piece of bookkeeping that needs no data from the other
+// blocks (Adam: global_step += 1 once every block has read the old value).  Two-level tickets
 // (groups of 32 blocks, then one top word) keep every word at <= 64 arrivals.  tickets:
-// uint32[kTicketWords], zero before the first launch; the last arrivers reset them, so one
-// buffer serves every later launch of the same kernel on the same stream.
-// NO FENCES here (an agent-scope release per block is an L2 write-back per block: it cost the
-// 2048-block Adam launch 100 us).  Whatever the last block reads from the others must therefore
-// travel write-through: stored with st_sc1 (every storing wave drains its stores, the block
-// barrier comes before lane 0's ticket -- both done here) and loaded with ld_sc1, which bypasses
-// this CU's L1 and the XCD's non-coherent L2 lines (MI355X_MICROARCH.md, inter-workgroup
-// visibility: "sc1 stores and loads both sides").
+// uint32[kTicketWords], zero before the first launch; the last arrivers reset them, so one buffer
+// serves every later launch of the same kernel on the same stream.  No fences: nothing is handed
+// over through memory (an agent-scope release per block is an L2 write-back per block: it cost
+// the 2048-block Adam launch 100 us).
 constexpr int kTicketWords = 80;          // 1 top + up to 64 groups (grids <= 2048 blocks) + slack
-__device__ __forceinline__ void st_sc1(float *p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_sc1(const float *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ bool grid_last_block(uint32_t *tickets) {
   __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's (write-through) stores have landed
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned nb = gridDim.x, g = blockIdx.x >> 5, ngroups = (nb + 31) >> 5;

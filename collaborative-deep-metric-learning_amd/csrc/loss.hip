@@ -185,10 +185,12 @@ k_triplet_hinge_inbatch(const float *__restrict__ e, int64_t lde, const int32_t 
 // layer (train.py:141), in ONE launch instead of three + the statistics pass: one wave per
 // triplet slot keeps the rows of z it needs in registers (NCH float4 per lane per row).  The
 // arithmetic is that of k_l2norm_fwd / dist_pair / k_triplet_hinge{,_inbatch} / k_l2norm_bwd,
-// operation for operation, so both routes give the same bits.  The last block to finish
-// (grid_last_block) reduces the per-triplet values to the step's scalars in a fixed order:
-// stats[0..3] = mean hinge, mean pos, mean neg, active fraction; stats[4] = calc_var of the
-// [B,3,D] triplet tensor (train.py:67-71) when var_ws is given.
+// operation for operation.  The step's scalars (stats[0..3] = mean hinge, mean pos, mean neg, active
+// fraction) come from k_loss_stats in a second small launch, stats[4] = calc_var of the [B,3,D]
+// triplet tensor (train.py:67-71) from per-block partials + k_tail_var_final when var_ws is given.
+// (Folding them into this launch's last block through ticket words and write-through partial sums
+// was built and measured: 21 us against 15 + 6 us for the two launches, i.e. nothing, and it
+// leaned on sc1 loads seeing another XCD's sc1 stores -- dropped.)
 // MODE 0: rows 3i, 3i+1, 3i+2 = anchor, positive, negative.  MODE 1 (in-batch negatives): slot i
 // owns rows 2i (a_i), 2i+1 (p_i); its negative is p_j, j = (i+shift) mod B, and p_i is also the
 // negative of slot k = (i-shift) mod B, so the wave of slot i recomputes triplet k's activity
@@ -269,8 +271,7 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
             const int32_t *__restrict__ shift_p, int B, int D, float margin, float alpha,
             float *__restrict__ e, int64_t lde, float *__restrict__ pos_o, float *__restrict__ neg_o,
             float *__restrict__ hinge_o, uint8_t *__restrict__ valid_o, float *__restrict__ dz2,
-            int64_t lddz, uint16_t *__restrict__ dz2_bf, int64_t ldbf, float *__restrict__ var_ws,
-            float *__restrict__ stats, uint32_t *__restrict__ tickets) {
+            int64_t lddz, uint16_t *__restrict__ dz2_bf, int64_t ldbf, float *__restrict__ var_ws) {
   __shared__ __attribute__((aligned(16))) float s_red[kWavesPerBlock][8];
   extern __shared__ __attribute__((aligned(16))) float s_col[];                 // [kWavesPerBlock][D] when var_ws
   const int lane = threadIdx.x & (kWave - 1);
@@ -280,7 +281,6 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
   const float two_over_b = 2.0f / (float)B;
   float4 csum[NCH];
   float tsq = 0.f;
-  float st_h = 0.f, st_p = 0.f, st_n = 0.f, st_a = 0.f;    // this wave's triplets: sums for the step's scalars
 #pragma unroll
   for (int c = 0; c < NCH; ++c) csum[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = blockIdx.x * kWavesPerBlock + wave; i < B; i += gridDim.x * kWavesPerBlock) {
@@ -306,7 +306,6 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
         gn[c] = mul4(sub4(va, vn), s);
       }
       if (lane == 0) { pos_o[i] = pos; neg_o[i] = neg; hinge_o[i] = fmaxf(t, 0.f); }
-      st_h += fmaxf(t, 0.f); st_p += pos; st_n += neg; st_a += (t > 0.f) ? 1.f : 0.f;
       tail_store_row<NCH>(N, gn, alpha, e + (ra + 2) * lde, dz2 + (ra + 2) * lddz,
                           dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane);
     } else {
@@ -341,8 +340,6 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
         hinge_o[i] = valid_i ? fmaxf(t, 0.f) : 0.f;
         if (valid_o) valid_o[i] = valid_i ? 1 : 0;
       }
-      const float hv = valid_i ? fmaxf(t, 0.f) : 0.f;
-      st_h += hv; st_p += pos; st_n += neg; st_a += (hv > 0.f) ? 1.f : 0.f;
     }
     tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane);
     tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane);
@@ -356,83 +353,54 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       }
     }
   }
-  if (!stats) return;
-  // ---- block partials, written through (st_sc1), then the ticket ----
-  // part[block] = {sum hinge, sum pos, sum neg, active count} (+ with var_ws: D column sums of the
-  // [B,3,D] triplet tensor and its sum of squares); waves in order, blocks in order: deterministic
-  const int nb = gridDim.x;
-  float *part = reinterpret_cast<float *>(tickets + kTicketWords) + (int64_t)blockIdx.x * 4;
-  if (lane == 0) { s_red[wave][0] = st_h; s_red[wave][1] = st_p; s_red[wave][2] = st_n; s_red[wave][3] = st_a; }
-  if (var_ws) {
-    float *mine = s_col + wave * D;
+  if (!var_ws) return;
+  // ---- block partial of the variance summary: D column sums of the [B,3,D] triplet tensor and its
+  // sum of squares (waves in order: deterministic); k_tail_var_final adds the blocks in order ----
+  float *mine = s_col + wave * D;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int q = lane + kWave * c;
-      if (q < nq) st4(mine, q, csum[c]);
-    }
-    tsq = wave_sum(tsq);
-    if (lane == 0) s_red[wave][4] = tsq;
+  for (int c = 0; c < NCH; ++c) {
+    const int q = lane + kWave * c;
+    if (q < nq) st4(mine, q, csum[c]);
   }
+  tsq = wave_sum(tsq);
+  if (lane == 0) s_red[wave][0] = tsq;
   __syncthreads();
-  if (threadIdx.x < 4) {
+  float *out = var_ws + (int64_t)blockIdx.x * (D + 4);
+  for (int d = threadIdx.x; d < D; d += kThreads) {
     float v = 0.f;
-    for (int w = 0; w < kWavesPerBlock; ++w) v += s_red[w][threadIdx.x];
-    st_sc1(part + threadIdx.x, v);
+    for (int w = 0; w < kWavesPerBlock; ++w) v += s_col[w * D + d];
+    out[d] = v;
   }
-  if (var_ws) {
-    float *out = var_ws + (int64_t)blockIdx.x * (D + 4);
-    for (int d = threadIdx.x; d < D; d += kThreads) {
-      float v = 0.f;
-      for (int w = 0; w < kWavesPerBlock; ++w) v += s_col[w * D + d];
-      st_sc1(out + d, v);
-    }
-    if (threadIdx.x == 0) {
-      float v = 0.f;
-      for (int w = 0; w < kWavesPerBlock; ++w) v += s_red[w][4];
-      st_sc1(out + D, v);
-    }
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int w = 0; w < kWavesPerBlock; ++w) v += s_red[w][0];
+    out[D] = v;
   }
-  if (!grid_last_block(tickets)) return;
-  // ---- the last block: the step's scalars ----
-  const float *parts = reinterpret_cast<const float *>(tickets + kTicketWords);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int b = threadIdx.x; b < nb; b += kThreads) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] += ld_sc1(parts + (int64_t)b * 4 + c);
-  }
+}
+
+// stats[4] = calc_var (train.py:67-71) = [sum t^2 - n_rows * sum_d mean_d^2] / (n_rows * D), n_rows = 3B,
+// from the nb block partials of k_vnet_tail (fixed order, double accumulation).
+__global__ void __launch_bounds__(kThreads)
+k_tail_var_final(const float *__restrict__ var_ws, int nb, int B, int D, float *__restrict__ stats) {
+  __shared__ double s_v[kWavesPerBlock];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const double n_rows = 3.0 * (double)B;
   double vsum = 0.0;
-  if (var_ws) {         // var = [sum t^2 - n_rows * sum_d mean_d^2] / (n_rows * D), n_rows = 3B
-    const double n_rows = 3.0 * (double)B;
-    for (int d = threadIdx.x; d < D; d += kThreads) {
-      double col = 0.0;
-      for (int b = 0; b < nb; ++b) col += (double)ld_sc1(var_ws + (int64_t)b * (D + 4) + d);
-      const double mean = col / n_rows;
-      vsum -= n_rows * mean * mean;
-    }
-    for (int b = threadIdx.x; b < nb; b += kThreads) vsum += (double)ld_sc1(var_ws + (int64_t)b * (D + 4) + D);
+  for (int d = threadIdx.x; d < D; d += kThreads) {
+    double col = 0.0;
+    for (int b = 0; b < nb; ++b) col += (double)var_ws[(int64_t)b * (D + 4) + d];
+    const double mean = col / n_rows;
+    vsum -= n_rows * mean * mean;
   }
-  __syncthreads();      // s_red is reused below
+  for (int b = threadIdx.x; b < nb; b += kThreads) vsum += (double)var_ws[(int64_t)b * (D + 4) + D];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float v = wave_sum(acc[c]);
-    if (lane == 0) s_red[wave][c] = v;
-  }
-  {
-    double v = vsum;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0) reinterpret_cast<double *>(&s_red[wave][4])[0] = v;
-  }
+  for (int off = 32; off > 0; off >>= 1) vsum += __shfl_xor(vsum, off, 64);
+  if (lane == 0) s_v[wave] = vsum;
   __syncthreads();
-  if (threadIdx.x < 4) {
-    float v = 0.f;
-    for (int w = 0; w < kWavesPerBlock; ++w) v += s_red[w][threadIdx.x];
-    stats[threadIdx.x] = v / (float)B;
-  }
-  if (threadIdx.x == 4 && var_ws) {
+  if (threadIdx.x == 0) {
     double v = 0.0;
-    for (int w = 0; w < kWavesPerBlock; ++w) v += reinterpret_cast<const double *>(&s_red[w][4])[0];
-    stats[4] = (float)(v / (3.0 * (double)B * (double)D));
+    for (int w = 0; w < kWavesPerBlock; ++w) v += s_v[w];
+    stats[4] = (float)(v / (n_rows * (double)D));
   }
 }
 
@@ -778,12 +746,10 @@ extern "C" int cdml_vnet_tail(int mode, const float *z, int64_t ldz, const int32
                               const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
                               float *e, int64_t lde, float *pos, float *neg, float *hinge,
                               uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_bf16,
-                              int64_t ldbf, float *stats, float *var_ws, uint32_t *tickets,
-                              cdml_stream_t stream) {
+                              int64_t ldbf, float *stats, float *var_ws, cdml_stream_t stream) {
   CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "vnet_tail: mode must be 0 (a,p,n rows) or 1 (in-batch)");
   CDML_REQUIRE(B >= (mode == 1 ? 2 : 1) && D > 0 && pos && neg && hinge, CDML_E_BADARG, "vnet_tail: bad argument");
   CDML_REQUIRE(mode == 0 || (rows && shift), CDML_E_BADARG, "vnet_tail: in-batch mode needs rows and shift");
-  CDML_REQUIRE(!stats || tickets, CDML_E_BADARG, "vnet_tail: stats needs the ticket words");
   CDML_REQUIRE(!var_ws || stats, CDML_E_BADARG, "vnet_tail: the variance is written to stats[4]");
   CDML_REQUIRE(D <= 1024, CDML_E_UNSUPPORTED, "vnet_tail: embedding size %d > 1024", D);
   int rc;
@@ -799,14 +765,23 @@ extern "C" int cdml_vnet_tail(int mode, const float *z, int64_t ldz, const int32
 #define CDML_LAUNCH_TAIL(M, N)                                                                       \
   hipLaunchKernelGGL((k_vnet_tail<M, N>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, z, ldz, \
                      rows, shift, B, D, margin, lrelu_alpha, e, lde, pos, neg, hinge, valid_out, dz2,  \
-                     lddz2, dz2_bf16, ldbf, var_ws, stats, tickets)
+                     lddz2, dz2_bf16, ldbf, var_ws)
   if (mode == 0) {
     if (nch <= 1) CDML_LAUNCH_TAIL(0, 1); else if (nch <= 2) CDML_LAUNCH_TAIL(0, 2); else CDML_LAUNCH_TAIL(0, 4);
   } else {
     if (nch <= 1) CDML_LAUNCH_TAIL(1, 1); else if (nch <= 2) CDML_LAUNCH_TAIL(1, 2); else CDML_LAUNCH_TAIL(1, 4);
   }
 #undef CDML_LAUNCH_TAIL
-  return check_launch("vnet_tail");
+  if ((rc = check_launch("vnet_tail"))) return rc;
+  if (stats) {
+    hipLaunchKernelGGL(k_loss_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, pos, neg, hinge, B, stats);
+    if ((rc = check_launch("vnet_tail stats"))) return rc;
+  }
+  if (var_ws) {
+    hipLaunchKernelGGL(k_tail_var_final, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, var_ws, grid, B, D, stats);
+    rc = check_launch("vnet_tail variance");
+  }
+  return rc;
 }
 
 extern "C" int cdml_semihard_select(const float *S, int64_t ldS, const float *e, int64_t lde,

@@ -194,11 +194,11 @@ def triplet_hinge_inbatch(e, rows, shift, B, D, margin, pos, neg, hinge, valid=N
          margin, _p(pos), _p(neg), _p(hinge), _p(valid, torch.uint8), _p(stats), dep, deld, _stream())
 
 
-TICKET_WORDS = 8320   # CDML_TICKET_WORDS (include/cdml.h): 80 tickets + per-block partial sums
+TICKET_WORDS = 128    # CDML_TICKET_WORDS (include/cdml.h)
 
 
 def new_tickets(device):
-    """Zeroed ticket words for the kernels whose last block folds a grid-wide reduction."""
+    """Zeroed ticket words for cdml_adam_step's advance_step (its last block advances the counter)."""
     return torch.zeros(TICKET_WORDS, dtype=torch.int32, device=device)
 
 
@@ -207,7 +207,7 @@ def vnet_tail_workspace_floats(B, D):
 
 
 def vnet_tail(mode, z, rows, shift, B, D, margin, e, pos, neg, hinge, dz2, valid=None, stats=None,
-              tickets=None, dz2_bf16=None, var_ws=None, alpha=LRELU_ALPHA):
+              dz2_bf16=None, var_ws=None, alpha=LRELU_ALPHA):
     """l2norm -> hinge loss -> its gradient -> l2norm backward -> lrelu' in one launch
     (mode 0: rows a,p,n per triplet; 1: in-batch negatives)."""
     zp, zld = _mat(z)
@@ -216,7 +216,7 @@ def vnet_tail(mode, z, rows, shift, B, D, margin, e, pos, neg, hinge, dz2, valid
     bp, bld = (C.c_void_p(0), 0) if dz2_bf16 is None else _mat16(dz2_bf16)
     call("cdml_vnet_tail", mode, zp, zld, _p(rows, torch.int32), _p(shift, torch.int32), B, D, margin, alpha,
          ep, eld, _p(pos), _p(neg), _p(hinge), _p(valid, torch.uint8), dp, dld, bp, bld, _p(stats), _p(var_ws),
-         _p(tickets, torch.int32), _stream())
+         _stream())
 
 
 def semihard_select(S, e, rows, B, D, sqn_scratch, neg_row_out):

@@ -112,7 +112,6 @@ class TrainStep:
         self.hinge = torch.zeros(self.B, dtype=f32, device=dev)
         self.valid = torch.ones(self.B, dtype=torch.uint8, device=dev)
         self.stats = torch.zeros(8, dtype=f32, device=dev)   # loss, mean pos, mean neg, active, variance
-        self.tail_tickets = ops.new_tickets(dev)             # fused tail: last block writes the stats
         self.adam_tickets = ops.new_tickets(dev)             # Adam: last block advances the step counter
         self.var_ws = None                                   # set by enable_variance()
         if mode == "semihard":
@@ -297,8 +296,7 @@ class TrainStep:
         if fused:
             ops.vnet_tail(0 if self.mode == "uniform" else 1, self.ws.z, self.idx, self.shift, self.B, L.Dp,
                           self.margin, self.ws.e, self.pos, self.neg, self.hinge, self.ws.dz2, valid=self.valid,
-                          stats=self.stats, tickets=self.tail_tickets,
-                          dz2_bf16=self.ws.dz2_bf if self.bf16 else None, var_ws=self.var_ws)
+                          stats=self.stats, dz2_bf16=self.ws.dz2_bf if self.bf16 else None, var_ws=self.var_ws)
             self.ws.tail_done = True
             return
         de = self.ws.de if with_grad else None

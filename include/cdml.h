@@ -221,18 +221,17 @@ int cdml_triplet_hinge_inbatch(const float *e, int64_t lde, const int32_t *rows,
  * Outputs: e (unit rows, "l2_norm"), pos/neg/hinge float[B], valid_out uint8[B] (mode 1,
  * nullable), dz2 = d loss / d (pre-activation of the output layer), optionally also as bf16
  * (dz2_bf16 nullable, round-to-nearest-even).  stats (nullable) float[8]: [0..3] as
- * cdml_triplet_hinge, written by the last block to finish -- needs tickets =
- * uint32[CDML_TICKET_WORDS], zero before the first call (the kernel leaves the tickets zero).
- * var_ws (nullable, cdml_vnet_tail_workspace bytes): stats[4] = calc_var (train.py:67-71) of
- * the [B,3,D] triplet tensor: mean over everything of (t - mean over [batch, role])^2. */
-#define CDML_TICKET_WORDS 8320   /* 80 ticket words (kept zero) + 4 floats of partial sums per block */
+ * cdml_triplet_hinge (a second small launch).  var_ws (nullable, cdml_vnet_tail_workspace bytes;
+ * needs stats): stats[4] = calc_var (train.py:67-71) of the [B,3,D] triplet tensor: mean over
+ * everything of (t - mean over [batch, role])^2. */
+/* ticket words of cdml_adam_step's advance_step: uint32[CDML_TICKET_WORDS], zero before the first call */
+#define CDML_TICKET_WORDS 128
 size_t cdml_vnet_tail_workspace(int B, int D);
 int cdml_vnet_tail(int mode, const float *z, int64_t ldz, const int32_t *rows,
                    const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
                    float *e, int64_t lde, float *pos, float *neg, float *hinge,
                    uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_bf16,
-                   int64_t ldbf, float *stats, float *var_ws, uint32_t *tickets,
-                   cdml_stream_t stream);
+                   int64_t ldbf, float *stats, float *var_ws, cdml_stream_t stream);
 
 /* ---- semi-hard negative mining (BASELINE config 2; build-defined, no reference
  * counterpart -- spec: oracle/tower.py semihard_select) -----------------------

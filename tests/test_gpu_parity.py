@@ -474,8 +474,7 @@ def test_vnet_tail_fused_equals_separate_kernels_and_oracle(cd, mode, B, D):
     else:
         cd.ops.triplet_hinge_inbatch(e0, rows, shift, B, D, 0.8, p0, n0, h0, None, st0, de0)
     cd.ops.l2norm_bwd(dz, de0, D, dz0, lrelu_alpha=0.2)
-    # fused, twice (the tickets must be clean again after the first launch)
-    tickets = cd.ops.new_tickets(cd.dev)
+    # fused, twice (second time with the variance summary)
     var_ws = torch.zeros(cd.ops.vnet_tail_workspace_floats(B, D), device=cd.dev)
     for rep in range(2):
         e1, dz1 = f(R, D), f(R, D)
@@ -483,7 +482,7 @@ def test_vnet_tail_fused_equals_separate_kernels_and_oracle(cd, mode, B, D):
         v1 = torch.full((B,), 9, dtype=torch.uint8, device=cd.dev)
         bf = torch.zeros((R, D), dtype=torch.bfloat16, device=cd.dev)
         cd.ops.vnet_tail(0 if mode == "uniform" else 1, dz, rows, shift, B, D, 0.8, e1, p1, n1, h1, dz1, valid=v1,
-                         stats=st1, tickets=tickets, dz2_bf16=bf, var_ws=var_ws if rep else None)
+                         stats=st1, dz2_bf16=bf, var_ws=var_ws if rep else None)
         torch.cuda.synchronize()
         # same formulas; the compiler contracts multiply-adds differently in the two kernels, so
         # equal to a few ulp, not bit for bit
@@ -492,7 +491,6 @@ def test_vnet_tail_fused_equals_separate_kernels_and_oracle(cd, mode, B, D):
         assert close(p1, p0, 1e-6) and close(n1, n0, 1e-6) and close(h1, h0, 1e-6)
         assert torch.equal(bf, dz1.bfloat16())                               # round-to-nearest-even copy
         np.testing.assert_allclose(st1[:4].cpu().numpy(), st0.cpu().numpy(), rtol=2e-6, atol=1e-7)
-        assert int(tickets[:80].abs().sum().item()) == 0
         if mode == "inbatch":
             np.testing.assert_array_equal(v1.cpu().numpy().astype(bool), valid)
     # oracle (fp64 on the fp32 inputs)
@@ -530,7 +528,7 @@ def test_adam_advances_step_counter_in_the_same_launch(cd):
             if not adv:
                 cd.ops.step_advance(t_dev)
         torch.cuda.synchronize()
-        assert int(t_dev.item()) == 9 and int(tick[:80].abs().sum().item()) == 0
+        assert int(t_dev.item()) == 9 and int(tick.abs().sum().item()) == 0
         res.append((w, m, v))
     for a, b in zip(*res):
         assert torch.equal(a, b)

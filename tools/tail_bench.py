@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the fused tower tail (l2norm -> hinge -> dE -> l2norm-bwd -> lrelu'), 10 launches
-per event pair: with and without the in-kernel step statistics, both negative modes, and the four
+per event pair: with and without the step statistics (a second small launch), both negative modes, and the four
 separate kernels it replaces.  usage: python tools/tail_bench.py [B]"""
 import os
 import sys
@@ -41,9 +41,8 @@ for mode, rpt in ((1, 2), (0, 3)):
     pos, neg, hinge = (torch.empty(B, device=dev) for _ in range(3))
     valid = torch.empty(B, dtype=torch.uint8, device=dev)
     stats = torch.zeros(8, device=dev)
-    tick = ops.new_tickets(dev)
     t_stats = timeit(lambda: ops.vnet_tail(mode, z, rows, shift, B, D, 0.8, e, pos, neg, hinge, dz, valid=valid,
-                                           stats=stats, tickets=tick))
+                                           stats=stats))
     t_plain = timeit(lambda: ops.vnet_tail(mode, z, rows, shift, B, D, 0.8, e, pos, neg, hinge, dz, valid=valid))
 
     def separate():
