@@ -443,31 +443,24 @@ def main():
         # the fp16 row gather (config 4), 10 back-to-back launches per event pair
         if world == 1 and not args.train_table:
             reps, per = 5, 10
+            n_st = ts.gather_ahead
+            m = train._MODES[mode]
             if bf16:
-                gk, n_st = "k_gather_rows_f16", 1
-                gbytes = R * F * (2 + 2.0)                  # fp16 rows read + bf16 normalised rows written
-
-                probe_idx = [torch.randint(0, ts.table.n_rows, (R,), dtype=torch.int32, device=dev) for _ in range(8)]
-                nxt = [0]
-
-                def launch():                               # other rows every launch (see the fp32 probe)
-                    ops.gather_rows_f16(ts.table.data, ts.table.row0, probe_idx[nxt[0] % 8], F, ts.ws.x_hat)
-                    nxt[0] += 1
+                gk = "k_sample_gather<%d," % (1 if rpt == 2 else 0)       # <mode, RowF16<3>>
+                gbytes = n_st * R * F * (2 + 2.0)          # fp16 rows read + bf16 normalised rows written
             else:
-                n_st = ts.gather_ahead
-                gk = "k_sample_gather<%d, 6>" % (1 if rpt == 2 else 0)
+                gk = "k_sample_gather<%d," % (1 if rpt == 2 else 0)       # <mode, RowF32<6>>
                 gbytes = n_st * 2.0 * R * F * 4             # rows read + normalised rows written
-                m = train._MODES[mode]
-                nxt = [ts.global_step + 1000]               # fresh steps every launch: re-reading the same rows
+            nxt = [ts.global_step + 1000]                   # fresh steps every launch: re-reading the same rows
                                                             # would be served from the 256 MB Infinity Cache
 
-                def launch():                               # (training on `ts` is over: its buffers are scratch now)
-                    if n_st > 1:
-                        ts._gather_block(nxt[0])
-                    else:
-                        ops.sample_gather(m, ts.pairs, ts.seed, nxt[0], B, ts.table.data, F, ts.idx, ts.ws.x_hat,
-                                          shift_out=ts.shift)
-                    nxt[0] += n_st
+            def launch():                                   # (training on `ts` is over: its buffers are scratch now)
+                if n_st > 1:
+                    ts._gather_block(nxt[0])
+                else:
+                    ops.sample_gather(m, ts.pairs, ts.seed, nxt[0], B, ts.table.data, F, ts.idx, ts.ws.x_hat,
+                                      shift_out=ts.shift)
+                nxt[0] += n_st
             for _ in range(3):
                 launch()
             evs = []
@@ -481,7 +474,7 @@ def main():
             torch.cuda.synchronize(dev)
             t_g = float(np.median([s.elapsed_time(e) for s, e in evs])) / per
             g_ach = gbytes / (t_g * 1e-3) / 1e9
-            out["gather"] = {"bound": "hbm", "kernel": gk, "achieved": round(g_ach, 1), "peak": PEAK_HBM_GBS,
+            out["gather"] = {"bound": "hbm", "kernel": gk + (" RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1), "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(gk),
                              "bytes_per_launch": gbytes, "launch_ms": round(t_g, 4), "steps_per_launch": n_st,
                              "method": "%d back-to-back launches per event pair (inter-launch gaps included), median of %d"

@@ -238,13 +238,86 @@ __device__ __forceinline__ void row_finish(RowRegs<NCH> &R, int F, float *__rest
   for (int q = lane + kWave * NCH; q < oq; q += kWave) d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <int MODE, int NCH>
+// Row policies of the fused kernel: how a wave loads one catalogue row into registers and how it
+// normalises and stores it.  RowF32: fp32 table -> fp32 rows (configs 1-3).  RowF16: fp16 table ->
+// bf16 rows, fp32 arithmetic (config 4; same formulas as k_gather_rows_f16).
+template <int NCH>
+struct RowF32 {
+  using In = float;
+  using Out = float;
+  using Regs = RowRegs<NCH>;
+  static constexpr int kPerChunk = 4;          // elements per 16-B chunk
+  __device__ static __forceinline__ void issue(Regs &R, const In *table, int64_t lr, int64_t stride, int F, int lane) {
+    row_issue<NCH>(R, table, lr, stride, (F + 3) >> 2, lane);
+  }
+  __device__ static __forceinline__ void finish(Regs &R, int F, Out *dst, int64_t out_stride, int lane) {
+    row_finish<NCH>(R, F, dst, out_stride, lane);
+  }
+};
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using bf16x8v = __attribute__((ext_vector_type(8))) __bf16;
+template <int NCH>
+struct RowF16 {
+  using In = _Float16;
+  using Out = __bf16;
+  struct Regs { half8 v[NCH]; };
+  static constexpr int kPerChunk = 8;
+  __device__ static __forceinline__ void issue(Regs &R, const In *table, int64_t lr, int64_t stride, int F, int lane) {
+    const half8 *src = reinterpret_cast<const half8 *>(table + lr * stride);
+    const int nq = (F + 7) >> 3;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      half8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < nq) {
+#if CDML_GATHER_NT
+        x = __builtin_nontemporal_load(src + q);
+#else
+        x = src[q];
+#endif
+      }
+      R.v[c] = x;
+    }
+  }
+  __device__ static __forceinline__ void finish(Regs &R, int F, Out *dst, int64_t out_stride, int lane) {
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (8 * q + u >= F) R.v[c][u] = 0;       // never trust the pad
+        const float f = (float)R.v[c][u];
+        ss += f * f;
+      }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    bf16x8v *d = reinterpret_cast<bf16x8v *>(dst);
+    const int oq = (int)(out_stride >> 3);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      if (q < oq) {
+        bf16x8v o;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = (__bf16)((float)R.v[c][u] * inv);
+        d[q] = o;
+      }
+    }
+    const bf16x8v z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = lane + kWave * NCH; q < oq; q += kWave) d[q] = z8;
+  }
+};
+
+template <int MODE, typename ROW>
 __global__ void __launch_bounds__(kThreads)
 k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t seed,
                 uint64_t step_imm, const uint64_t *__restrict__ step_dev, int batch,
-                int64_t slot0, int64_t batch_global, const float *__restrict__ table,
+                int64_t slot0, int64_t batch_global, const typename ROW::In *__restrict__ table,
                 int64_t n_rows, int64_t row_stride, int F, int32_t *__restrict__ idx_out,
-                int32_t *__restrict__ shift_out, float *__restrict__ x_out, int64_t out_stride,
+                int32_t *__restrict__ shift_out, typename ROW::Out *__restrict__ x_out, int64_t out_stride,
                 int n_steps, int64_t x_step_stride, int64_t idx_step_stride) {
   constexpr int RPT = (MODE == 0) ? 3 : 2;  // rows per triplet
   __shared__ int32_t s_id[2][kChunkRows];
@@ -254,7 +327,6 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
   const int64_t rows_per_step = (int64_t)RPT * batch;
   const int64_t total_rows = rows_per_step * n_steps;
   const int64_t n_chunks = (total_rows + kChunkRows - 1) / kChunkRows;
-  const int nq = (F + 3) >> 2;
 
   // ids of chunk c -> LDS buffer b (threads 0..kChunkRows-1), and to idx_out / shift_out
   auto stage_ids = [&](int64_t c, int b) {
@@ -287,11 +359,11 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
   int b = 0;
   for (; c < n_chunks; c += gridDim.x, b ^= 1) {
     const int64_t g0 = c * kChunkRows + wave * kRowsPerWave;
-    RowRegs<NCH> R[kRowsPerWave];
+    typename ROW::Regs R[kRowsPerWave];
 #pragma unroll
     for (int u = 0; u < kRowsPerWave; ++u) {
       const int32_t id = __builtin_amdgcn_readfirstlane(s_id[b][wave * kRowsPerWave + u]);
-      if (g0 + u < total_rows) row_issue<NCH>(R[u], table, clamp_row(id, 0, n_rows, nullptr), row_stride, nq, lane);
+      if (g0 + u < total_rows) ROW::issue(R[u], table, clamp_row(id, 0, n_rows, nullptr), row_stride, F, lane);
     }
     const int64_t cn = c + gridDim.x;
     if (cn < n_chunks) stage_ids(cn, b ^ 1);       // under the row loads in flight
@@ -300,7 +372,7 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
       const int64_t g = g0 + u;
       if (g < total_rows) {
         const int64_t s = g / rows_per_step, r = g - s * rows_per_step;
-        row_finish<NCH>(R[u], F, x_out + s * x_step_stride + r * out_stride, out_stride, lane);
+        ROW::finish(R[u], F, x_out + s * x_step_stride + r * out_stride, out_stride, lane);
       }
     }
     __syncthreads();                               // ids of the next chunk are staged; this buffer is free
@@ -500,7 +572,7 @@ extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pair
   const int grid = grid_for((int64_t)batch * (mode == 0 ? 3 : 2) * n_steps, kChunkRows);
   const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
 #define CDML_LAUNCH_SG(M, N)                                                                      \
-  hipLaunchKernelGGL((k_sample_gather<M, N>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
+  hipLaunchKernelGGL((k_sample_gather<M, RowF32<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
                      pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global, table,     \
                      n_rows, row_stride, F, idx_out, shift_out, x_out, out_stride, n_steps,       \
                      x_step_stride, idx_step_stride)
@@ -538,4 +610,42 @@ extern "C" int cdml_scatter_rows(const float *src, int64_t ld_src, const int32_t
   hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(n, kWavesPerBlock)), dim3(kThreads), 0, (hipStream_t)stream, src,
                      ld_src, slot, n, width, dst, ld_dst);
   return check_launch("scatter_rows");
+}
+
+extern "C" int cdml_sample_gather_f16(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                                      uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
+                                      int64_t batch_global, const uint16_t *table, int64_t n_rows,
+                                      int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
+                                      uint16_t *x_out_bf16, int64_t out_stride, int n_steps,
+                                      int64_t x_step_stride, int64_t idx_step_stride, cdml_stream_t stream) {
+  CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "sample_gather_f16: mode must be 0 or 1");
+  CDML_REQUIRE(pairs && table && idx_out && x_out_bf16 && n_pairs > 0 && slot0 >= 0, CDML_E_BADARG,
+               "sample_gather_f16: bad argument");
+  CDML_REQUIRE(n_rows >= 3 && n_rows <= 0x7FFFFFFFll, CDML_E_BADARG, "sample_gather_f16: n_rows must be in [3, 2^31)");
+  CDML_REQUIRE(batch >= (mode == 1 ? 2 : 1), CDML_E_BADARG, "sample_gather_f16: batch too small");
+  CDML_REQUIRE(mode == 0 || shift_out, CDML_E_BADARG, "sample_gather_f16: shift_out required in mode 1");
+  CDML_REQUIRE(batch_global >= slot0 + batch, CDML_E_BADARG, "sample_gather_f16: batch_global < slot0 + batch");
+  CDML_REQUIRE(n_steps >= 1 && n_steps <= 64, CDML_E_BADARG, "sample_gather_f16: n_steps must be in [1, 64]");
+  const int rpt = mode == 0 ? 3 : 2;
+  CDML_REQUIRE(n_steps == 1 || (x_step_stride >= (int64_t)batch * rpt * out_stride && (x_step_stride & 7) == 0 &&
+                                idx_step_stride >= (int64_t)batch * rpt),
+               CDML_E_BADARG, "sample_gather_f16: per-step strides too small for the batch");
+  CDML_REQUIRE(F > 0 && F <= 4096, CDML_E_UNSUPPORTED, "sample_gather_f16: feature size outside (0, 4096]");
+  CDML_REQUIRE(row_stride >= F && (row_stride & 7) == 0 && out_stride >= F && (out_stride & 7) == 0 &&
+                   aligned16(table) && aligned16(x_out_bf16),
+               CDML_E_ALIGN, "sample_gather_f16: strides must be >= F and multiples of 8, bases 16-B aligned");
+  const int grid = grid_for((int64_t)batch * rpt * n_steps, kChunkRows);
+  const int nch = ((F + 7) / 8 + kWave - 1) / kWave;
+#define CDML_LAUNCH_SGH(M, N)                                                                               \
+  hipLaunchKernelGGL((k_sample_gather<M, RowF16<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream,   \
+                     pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global,                       \
+                     reinterpret_cast<const _Float16 *>(table), n_rows, row_stride, F, idx_out, shift_out,   \
+                     reinterpret_cast<__bf16 *>(x_out_bf16), out_stride, n_steps, x_step_stride, idx_step_stride)
+  if (mode == 0) {
+    if (nch <= 1) CDML_LAUNCH_SGH(0, 1); else if (nch <= 3) CDML_LAUNCH_SGH(0, 3); else CDML_LAUNCH_SGH(0, 8);
+  } else {
+    if (nch <= 1) CDML_LAUNCH_SGH(1, 1); else if (nch <= 3) CDML_LAUNCH_SGH(1, 3); else CDML_LAUNCH_SGH(1, 8);
+  }
+#undef CDML_LAUNCH_SGH
+  return check_launch("sample_gather_f16");
 }

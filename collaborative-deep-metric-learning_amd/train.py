@@ -152,14 +152,14 @@ class TrainStep:
         # several steps' rows per gather launch (the frozen catalogue cannot change in between;
         # a trainable one can, and the sharded path has its own prefetcher)
         self.gather_ahead = max(1, int(gather_ahead))
-        if self.bf16 or exchange is not None or self.train_table:
+        if exchange is not None or self.train_table:
             self.gather_ahead = 1
         self._ahead_base = None
         if self.gather_ahead > 1:
             # (fetching the NEXT block on a side stream under this block's GEMMs was measured: the
             # gather left the critical path, but the GEMM it ran beside lost as much -- dropped)
             K = self.gather_ahead
-            self._xa = torch.zeros((K,) + tuple(self.ws.x_hat.shape), dtype=f32, device=dev)
+            self._xa = torch.zeros((K,) + tuple(self.ws.x_hat.shape), dtype=self.ws.x_hat.dtype, device=dev)
             self._idxa = torch.zeros((K, self.R), dtype=i32, device=dev)
             self._shifta = torch.zeros(K, dtype=i32, device=dev)
             self._select_ahead(0)
@@ -244,16 +244,6 @@ class TrainStep:
                 self.prefetch.launch(b, lambda: self._fill(b, t))       # cold start / after a resume
             self.prefetch.acquire(b)
             self.ws.x_hat, self.idx, self.shift = self._x[b], self._idx[b], self._shift[b]
-            return
-        if self.exchange is None and self.bf16:
-            if m == MODE_UNIFORM:
-                ops.sample_uniform(self.pairs, self.table.n_rows_global, self.seed, None, self.B, self.idx,
-                                   slot0=self.slot0, batch_global=self.batch_global, step_dev=self.step_dev)
-            else:
-                ops.sample_inbatch(self.pairs, self.seed, None, self.B, self.idx, self.shift,
-                                   slot0=self.slot0, batch_global=self.batch_global, step_dev=self.step_dev)
-            ops.gather_rows_f16(self.table.data, self.table.row0, self.idx, self.table.feature_size,
-                                self.ws.x_hat)
             return
         if self.exchange is None:
             ops.sample_gather(m, self.pairs, self.seed, None, self.B, self.table.data,

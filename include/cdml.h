@@ -356,6 +356,15 @@ int cdml_gather_rows_f16(const uint16_t *table, int64_t row0, int64_t n_rows,
                          int64_t row_stride, const int32_t *idx, int n_idx, int F,
                          uint16_t *x_out_bf16, int64_t out_stride,
                          int32_t *oob_flag, cdml_stream_t stream);
+/* cdml_sample_gather on the fp16 catalogue: same sampler, same staging, same n_steps semantics;
+ * rows are read as fp16 and written l2-normalised (fp32 arithmetic) as bf16. */
+int cdml_sample_gather_f16(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                           uint64_t step, const uint64_t *step_dev, int batch,
+                           int64_t slot0, int64_t batch_global, const uint16_t *table,
+                           int64_t n_rows, int64_t row_stride, int F, int32_t *idx_out,
+                           int32_t *shift_out, uint16_t *x_out_bf16, int64_t out_stride,
+                           int n_steps, int64_t x_step_stride, int64_t idx_step_stride,
+                           cdml_stream_t stream);
 
 /* ---- fusion towers MultiplyNet / MlpNet / ResNet (models.py:65-157): the
  * elementwise pieces between their FC layers; [M][N] fp32 views, N % 4 == 0. ----

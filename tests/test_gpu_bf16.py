@@ -182,6 +182,32 @@ def test_fp16_table_and_gather(cd):
     assert float(x[:, F:].float().abs().max()) == 0
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fused_sample_gather_f16_equals_separate(cd, mode):
+    """The fused sampler + gather on the fp16 catalogue (several steps per launch) == the sampler
+    kernel + k_gather_rows_f16, ids and rows bit for bit."""
+    N, F, B, K = 3000, 1500, 133, 3
+    table = cd.ebf.FeatureTableF16.synthetic(N, F, 0, cd.dev)
+    pairs = torch.as_tensor(osynth.cowatch_pairs(N, 300, 0)).to(cd.dev)
+    rpt = 3 if mode == 0 else 2
+    R = B * rpt
+    x = torch.full((K, R, 1536), 7.0, dtype=torch.bfloat16, device=cd.dev)
+    idx = torch.full((K, R), -1, dtype=torch.int32, device=cd.dev)
+    shift = torch.full((K,), -1, dtype=torch.int32, device=cd.dev)
+    cd.ops.sample_gather(mode, pairs, 1234, 5, B, table.data, F, idx, x, shift_out=shift, n_steps=K)
+    for s in range(K):
+        i1 = torch.full((R,), -1, dtype=torch.int32, device=cd.dev)
+        s1 = torch.full((1,), -1, dtype=torch.int32, device=cd.dev)
+        if mode == 0:
+            cd.ops.sample_uniform(pairs, N, 1234, 5 + s, B, i1)
+        else:
+            cd.ops.sample_inbatch(pairs, 1234, 5 + s, B, i1, s1)
+            assert int(s1.item()) == int(shift[s].item())
+        x1 = torch.full((R, 1536), 7.0, dtype=torch.bfloat16, device=cd.dev)
+        cd.ops.gather_rows_f16(table.data, 0, i1, F, x1)
+        assert torch.equal(i1, idx[s]) and torch.equal(x1, x[s])
+
+
 @pytest.mark.parametrize("mode", ["uniform", "inbatch"])
 def test_train_step_bf16_config4_precision(cd, mode):
     """fp16 table + bf16 MFMA step vs the fp64 oracle on the same fp16 features."""
