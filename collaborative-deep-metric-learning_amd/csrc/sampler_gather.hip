@@ -247,6 +247,7 @@ struct RowF32 {
   using Out = float;
   using Regs = RowRegs<NCH>;
   static constexpr int kPerChunk = 4;          // elements per 16-B chunk
+  static constexpr int kRows = kRowsPerWave;   // rows a wave keeps in flight (6 KB each)
   __device__ static __forceinline__ void issue(Regs &R, const In *table, int64_t lr, int64_t stride, int F, int lane) {
     row_issue<NCH>(R, table, lr, stride, (F + 3) >> 2, lane);
   }
@@ -263,6 +264,10 @@ struct RowF16 {
   using Out = __bf16;
   struct Regs { half8 v[NCH]; };
   static constexpr int kPerChunk = 8;
+#ifndef CDML_GATHER_ROWS_PER_WAVE_F16
+#define CDML_GATHER_ROWS_PER_WAVE_F16 4
+#endif
+  static constexpr int kRows = CDML_GATHER_ROWS_PER_WAVE_F16;   // 3-KB rows: four in flight per wave
   __device__ static __forceinline__ void issue(Regs &R, const In *table, int64_t lr, int64_t stride, int F, int lane) {
     const half8 *src = reinterpret_cast<const half8 *>(table + lr * stride);
     const int nq = (F + 7) >> 3;
@@ -320,18 +325,19 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
                 int32_t *__restrict__ shift_out, typename ROW::Out *__restrict__ x_out, int64_t out_stride,
                 int n_steps, int64_t x_step_stride, int64_t idx_step_stride) {
   constexpr int RPT = (MODE == 0) ? 3 : 2;  // rows per triplet
-  __shared__ int32_t s_id[2][kChunkRows];
+  constexpr int kRPW = ROW::kRows, kCR = kRPW * kWavesPerBlock;   // rows per wave / per chunk
+  __shared__ int32_t s_id[2][kCR];
   const uint64_t step0 = step_imm + (step_dev ? *step_dev : 0);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t rows_per_step = (int64_t)RPT * batch;
   const int64_t total_rows = rows_per_step * n_steps;
-  const int64_t n_chunks = (total_rows + kChunkRows - 1) / kChunkRows;
+  const int64_t n_chunks = (total_rows + kCR - 1) / kCR;
 
-  // ids of chunk c -> LDS buffer b (threads 0..kChunkRows-1), and to idx_out / shift_out
+  // ids of chunk c -> LDS buffer b (threads 0..kCR-1), and to idx_out / shift_out
   auto stage_ids = [&](int64_t c, int b) {
-    if (threadIdx.x < kChunkRows) {
-      const int64_t g = c * kChunkRows + threadIdx.x;
+    if (threadIdx.x < kCR) {
+      const int64_t g = c * kCR + threadIdx.x;
       int32_t id = 0;
       if (g < total_rows) {
         const int s = (int)(g / rows_per_step);
@@ -358,17 +364,17 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
   __syncthreads();
   int b = 0;
   for (; c < n_chunks; c += gridDim.x, b ^= 1) {
-    const int64_t g0 = c * kChunkRows + wave * kRowsPerWave;
-    typename ROW::Regs R[kRowsPerWave];
+    const int64_t g0 = c * kCR + wave * kRPW;
+    typename ROW::Regs R[kRPW];
 #pragma unroll
-    for (int u = 0; u < kRowsPerWave; ++u) {
-      const int32_t id = __builtin_amdgcn_readfirstlane(s_id[b][wave * kRowsPerWave + u]);
+    for (int u = 0; u < kRPW; ++u) {
+      const int32_t id = __builtin_amdgcn_readfirstlane(s_id[b][wave * kRPW + u]);
       if (g0 + u < total_rows) ROW::issue(R[u], table, clamp_row(id, 0, n_rows, nullptr), row_stride, F, lane);
     }
     const int64_t cn = c + gridDim.x;
     if (cn < n_chunks) stage_ids(cn, b ^ 1);       // under the row loads in flight
 #pragma unroll
-    for (int u = 0; u < kRowsPerWave; ++u) {
+    for (int u = 0; u < kRPW; ++u) {
       const int64_t g = g0 + u;
       if (g < total_rows) {
         const int64_t s = g / rows_per_step, r = g - s * rows_per_step;
@@ -569,7 +575,7 @@ extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pair
                "sample_gather: batch_global < slot0 + batch");
   int rc = check_gather_layout("sample_gather", table, row_stride, F, x_out, out_stride);
   if (rc) return rc;
-  const int grid = grid_for((int64_t)batch * (mode == 0 ? 3 : 2) * n_steps, kChunkRows);
+  const int grid = grid_for((int64_t)batch * (mode == 0 ? 3 : 2) * n_steps, RowF32<6>::kRows * kWavesPerBlock);
   const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
 #define CDML_LAUNCH_SG(M, N)                                                                      \
   hipLaunchKernelGGL((k_sample_gather<M, RowF32<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
@@ -634,7 +640,7 @@ extern "C" int cdml_sample_gather_f16(int mode, const int32_t *pairs, int64_t n_
   CDML_REQUIRE(row_stride >= F && (row_stride & 7) == 0 && out_stride >= F && (out_stride & 7) == 0 &&
                    aligned16(table) && aligned16(x_out_bf16),
                CDML_E_ALIGN, "sample_gather_f16: strides must be >= F and multiples of 8, bases 16-B aligned");
-  const int grid = grid_for((int64_t)batch * rpt * n_steps, kChunkRows);
+  const int grid = grid_for((int64_t)batch * rpt * n_steps, RowF16<3>::kRows * kWavesPerBlock);
   const int nch = ((F + 7) / 8 + kWave - 1) / kWave;
 #define CDML_LAUNCH_SGH(M, N)                                                                               \
   hipLaunchKernelGGL((k_sample_gather<M, RowF16<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream,   \
