@@ -30,6 +30,11 @@ int gemm_bf16_256_splits(int M, int N, int K);
 // g.tiles_m / g.tiles_n / g.k_per_split / g.C (slabs when splits > 1) set by the caller
 int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t stream);
 
+// streaming kernel for the mask / plain-bf16 epilogue (BE_MASK_BF16) at K == 256: N % 256 == 0,
+// lda / ldb / ldc / ldaux multiples of 8, A inside the 2 GiB buffer-descriptor window
+bool gemm_bf16_k256_usable(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux, bool has_aux);
+int launch_gemm_bf16_k256(const BArgs &g, hipStream_t stream);
+
 // k-strided form C[M][N] = sum_k A[k][M] * B[k][N] (fp32 slabs): M, N % 256 == 0, K % 128 == 0
 bool gemm_bf16_tn_usable(int M, int N, int K, int64_t lda, int64_t ldb);
 int launch_gemm_bf16_tn(const BArgs &g, int splits, hipStream_t stream);

@@ -455,6 +455,10 @@ extern "C" int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda, c
       return check_launch("gemm_bf16_nt combine + bias + lrelu");
     }
   }
+  // the K = 256 data gradient is a streaming problem, not a tiled one (gemm_bf16_k256.hip)
+  if (epilogue == BE_MASK_BF16 && forced_tile() == 0 && (int64_t)M * N >= ((int64_t)1 << 22) &&
+      gemm_bf16_k256_usable(M, N, K, lda, ldb, ldc, ldaux, aux != nullptr) && (!aux || aligned16(aux)))
+    return launch_gemm_bf16_k256(g, s);
   const bool big = use_256(epilogue, M, N, K, lda, ldb);
   int splits = 1;
   if (epilogue == BE_F32) {

@@ -99,6 +99,46 @@ def test_gemm_bf16_tn_weight_gradient_form(cd, M, N, K):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("M,N", [(16384, 256), (2075, 5120), (24576 + 17, 2048), (4096, 1024)])
+def test_gemm_bf16_k256_streaming_data_gradient(cd, M, N, monkeypatch):
+    """The K = 256 mask-epilogue product on the streaming kernel (gemm_bf16_k256.hip; taken when
+    M * N >= 2^22): values against fp64 on the bf16-rounded operands, bit-equal to the tiled kernel,
+    ragged M, no mask, strided views, and a repeated-launch screen for its DMA / barrier ordering."""
+    K = 256
+    g = torch.Generator(device=cd.dev)
+    g.manual_seed(M + N)
+    A = (torch.randn(M, K, device=cd.dev, generator=g) / 16).bfloat16()
+    B = torch.randn(N, K, device=cd.dev, generator=g).bfloat16()
+    aux = torch.randn(M, N, device=cd.dev, generator=g).bfloat16()
+    out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=cd.dev)
+    cd.ops.gemm_bf16_nt(cd.ops.BE_MASK_BF16, A, B, out, M, N, K, aux=aux)
+    ref = (A.double() @ B.double().T) * torch.where(aux.double() > 0, 1.0, 0.2)
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2 ** -8 * ref.abs().max().item() + 1e-4, err
+    monkeypatch.setenv("CDML_BF16_TILE", "256" if N % 256 == 0 and M >= 256 else "128")
+    tiled = torch.empty_like(out)
+    cd.ops.gemm_bf16_nt(cd.ops.BE_MASK_BF16, A, B, tiled, M, N, K, aux=aux)
+    monkeypatch.delenv("CDML_BF16_TILE")
+    assert torch.equal(out, tiled)
+    for _ in range(20):                                              # same buffers, every launch bit-equal
+        again = torch.empty_like(out)
+        cd.ops.gemm_bf16_nt(cd.ops.BE_MASK_BF16, A, B, again, M, N, K, aux=aux)
+        assert torch.equal(out, again)
+    plain = torch.empty_like(out)                                    # no mask: plain bf16 product
+    cd.ops.gemm_bf16_nt(cd.ops.BE_MASK_BF16, A, B, plain, M, N, K)
+    ref_p = A.double() @ B.double().T
+    assert (plain.double() - ref_p).abs().max().item() <= 2 ** -8 * ref_p.abs().max().item() + 1e-4
+    # operands and result as views into wider buffers; rows past M of the result stay untouched
+    wa = torch.zeros((M, K + 64), dtype=torch.bfloat16, device=cd.dev)
+    wa[:, :K] = A
+    wo = torch.full((M + 40, N + 128), 3.0, dtype=torch.bfloat16, device=cd.dev)
+    wm = torch.zeros((M, N + 8), dtype=torch.bfloat16, device=cd.dev)
+    wm[:, :N] = aux
+    cd.ops.gemm_bf16_nt(cd.ops.BE_MASK_BF16, wa[:, :K], B, wo[:M, :N], M, N, K, aux=wm[:, :N])
+    assert torch.equal(wo[:M, :N], out)
+    assert bool((wo[M:, :] == 3.0).all()) and bool((wo[:, N:] == 3.0).all())
+
+
 def test_gemm_bf16_256_race_screen(cd, monkeypatch):
     """The ping-pong kernel orders its LDS-DMA against the fragment reads by counted waits and
     barriers only; a misplaced wait shows up as rare wrong tiles.  Many launches, full chip,
