@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(kT, 2) k_gemm_bf16_k256_mask(K256Args g) {
         if (has_aux) v[j] *= ((float)mk[p][j] > 0.f) ? 1.f : g.alpha;
         o[j] = (bf16)v[j];
       }
-      if (row < g.M) *reinterpret_cast<bf16x8 *>(g.C + (int64_t)row * g.ldc + ncol0 + ec) = o;
+      // non-temporal: the result is read next by a different kernel on other CUs (5.2 vs 4.6 TB/s)
+      if (row < g.M) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8 *>(g.C + (int64_t)row * g.ldc + ncol0 + ec));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();

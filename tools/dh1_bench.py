@@ -22,15 +22,18 @@ bytes_ = R * H * 2 * 2 + R * D * 2 + H * D * 2
 for tile in sys.argv[3:] or ("128", "256", "0"):
     os.environ["CDML_BF16_TILE"] = tile
     fn = lambda: ops.gemm_bf16_nt(ops.BE_MASK_BF16, A, B, out, R, H, D, aux=aux)
-    for _ in range(3):
+    for _ in range(20):
         fn()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        fn()
-    e.record()
-    torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / iters
+    times = []
+    for _ in range(5):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        times.append(s.elapsed_time(e) / iters)
+    ms = sorted(times)[2]
     print("tile %s: %.4f ms  %.2f TB/s of %.0f MB  (%.0f TFLOP/s)  checksum %.6e"
           % (tile, ms, bytes_ / ms / 1e9, bytes_ / 1e6, 2.0 * R * H * D / ms / 1e9, out.float().abs().sum().item()))
