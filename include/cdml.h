@@ -311,7 +311,10 @@ int cdml_knn_merge(const float *scores, int64_t lds, int nq, int nb, int col0,
  *            3: C f32  = acc, deterministic split-K (workspace of cdml_gemm_bf16_workspace bytes)
  * N % 128 == 0, K % 64 == 0, any M >= 1.  Epilogue 1 uses the workspace too when given one
  * (a narrow output layer is split over K and finished by the slab combine); without it the
- * one-pass kernel runs.  Results of the two routes differ in summation order only. */
+ * one-pass kernel runs.  Results of the two routes differ in summation order only.
+ * Epilogue 2 at K == 256, N % 256 == 0 and M * N >= 2^22 (the output layer's data gradient,
+ * an HBM-bound product) runs on a streaming kernel: B held in registers, A by 32-row chunks,
+ * bit-equal to the tiled kernels. */
 size_t cdml_gemm_bf16_workspace(int M, int N, int K);
 int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda,
                       const uint16_t *B, int64_t ldb, int M, int N, int K, void *C,
