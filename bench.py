@@ -26,6 +26,9 @@ Prints ONE JSON line (rank 0).  Beside the contract's fields:
   data_learnable (N = 1) the same step on a learnable catalogue (co-watched videos share a
                  cluster): the iid imitation_data features collapse the embeddings
   comm           (N > 1) what the compute stream waits for: all-reduce and row exchange
+  order          what ran before the W warm-up steps: the first ~100 ms of MFMA work after an idle spell
+                 run ~2 % slower (clock ramp), so the default N = 1 line measures like_for_like and
+                 data_learnable first; the other lines run 0.3 s of GEMM launches on scratch buffers
 """
 import argparse
 import datetime
@@ -198,6 +201,24 @@ def learnable_catalogue(n_rows, dev, n_clusters=2000, seed=0):
     return table, pairs[torch.randperm(pairs.shape[0], device=dev, generator=g)].contiguous()
 
 
+def settle_gpu(dev, seconds=0.3):
+    """Projection-GEMM launches on scratch buffers for ~`seconds`: the first ~100 ms of MFMA work after an
+    idle spell run ~2 % slower on this part (clock ramp), and the default N = 1 line gets past that through
+    its secondary measurements; every other line gets the same start through this loop.  Not a step of the
+    measured job: no state of the TrainStep is touched."""
+    from cdml_amd import ops
+    M, K, N = 4096, 1536, 5120
+    x = torch.rand((M, K), device=dev)
+    W = torch.randn((K, N), device=dev) * 0.02
+    b = torch.zeros(N, device=dev)
+    y = torch.empty((M, N), device=dev)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            ops.fc_lrelu_fwd(x, W, b, y, M, K, N)
+        torch.cuda.synchronize(dev)
+
+
 def timed_steps(ts, steps, warmup, dev):
     for _ in range(warmup):
         ts.step()
@@ -330,6 +351,44 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
 
+        extras = {}
+        # The two secondary measurements run BEFORE the headline: the first ~100 ms of MFMA work after an
+        # idle spell run ~2 % slower (measured: --warmup 5 -> 2.51 ms/step, --warmup 100 -> 2.478), so the
+        # headline's W warm-up + K timed steps follow them back to back, at the clocks a real run sees.
+        if config1 and mode == "inbatch" and not args.no_extras and not args.train_table and rank == 0:
+            phase = "secondary measurements"
+            n_s, n_w = min(args.steps, 30), min(max(args.warmup, 3), 5)
+            # (b) the N > 1 line's per-GPU workload, whole 10 M-row catalogue on this one GPU
+            t10 = Table.synthetic(10000000, F, seed=0, device=dev)
+            p10 = torch.from_numpy(synth_pairs(10000000, 600000, seed=0)).to(dev)
+            ts10 = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
+                                   optimizer="adam", base_learning_rate=0.01, device=dev, gather_ahead=args.gather_ahead)
+            el = timed_steps(ts10, n_s, n_w, dev)
+            extras["like_for_like"] = {"workload": "config3 per-GPU batch on ONE GPU: 10000000 videos x 1500-d fp32 (61 GB) in "
+                                                "HBM, batch 8192 triplets, in-batch negatives (the N>1 lines run this per GPU "
+                                                "on a row-sharded catalogue)",
+                                    "value": round(8192 * n_s / el, 1), "unit": "triplets/s",
+                                    "ms_per_step": round(el / n_s * 1e3, 4), "steps": n_s, "warmup": n_w}
+            del ts10, t10, p10
+            torch.cuda.empty_cache()
+            # (c) the headline step on a learnable catalogue
+            tl, pl = learnable_catalogue(200000, dev)
+            tsl = train.TrainStep(tl, pl, B, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
+                                  optimizer="adam", base_learning_rate=2e-4, device=dev, gather_ahead=args.gather_ahead)
+            tsl.step()
+            l0 = tsl.loss()
+            n_l = max(n_s, 60)
+            el = timed_steps(tsl, n_l, n_w, dev)
+            extras["data_learnable"] = {"workload": "config1 step (batch %d in-batch) on a learnable 200000 x 1500 catalogue "
+                                                 "(co-watched videos share one of 2000 clusters), Adam 2e-4" % B,
+                                     "value": round(B * n_l / el, 1), "unit": "triplets/s",
+                                     "ms_per_step": round(el / n_l * 1e3, 4), "steps": n_l,
+                                     "loss_first_step": round(l0, 4), "loss_last_step": round(tsl.loss(), 4)}
+            del tsl, tl, pl
+            torch.cuda.empty_cache()
+        if not extras:
+            phase = "clock settle"
+            settle_gpu(dev)
         phase = "warm-up steps"
         for _ in range(args.warmup):
             ts.step()
@@ -490,38 +549,13 @@ def main():
         step_flops = R * (2.0 * F * H + 2.0 * H * D) + R * (2.0 * F * H + 4.0 * H * D)
         out["step_tflops"] = round(step_flops / (elapsed / args.steps) / 1e12, 2)
 
-        if config1 and mode == "inbatch" and not args.no_extras and not args.train_table:
-            del ts, table, pairs
-            torch.cuda.empty_cache()
-            n_s, n_w = min(args.steps, 30), min(max(args.warmup, 3), 5)
-            # (b) the N > 1 line's per-GPU workload, whole 10 M-row catalogue on this one GPU
-            t10 = Table.synthetic(10000000, F, seed=0, device=dev)
-            p10 = torch.from_numpy(synth_pairs(10000000, 600000, seed=0)).to(dev)
-            ts10 = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
-                                   optimizer="adam", base_learning_rate=0.01, device=dev, gather_ahead=args.gather_ahead)
-            el = timed_steps(ts10, n_s, n_w, dev)
-            out["like_for_like"] = {"workload": "config3 per-GPU batch on ONE GPU: 10000000 videos x 1500-d fp32 (61 GB) in "
-                                                "HBM, batch 8192 triplets, in-batch negatives (the N>1 lines run this per GPU "
-                                                "on a row-sharded catalogue)",
-                                    "value": round(8192 * n_s / el, 1), "unit": "triplets/s",
-                                    "ms_per_step": round(el / n_s * 1e3, 4), "steps": n_s, "warmup": n_w}
-            del ts10, t10, p10
-            torch.cuda.empty_cache()
-            # (c) the headline step on a learnable catalogue
-            tl, pl = learnable_catalogue(200000, dev)
-            tsl = train.TrainStep(tl, pl, B, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
-                                  optimizer="adam", base_learning_rate=2e-4, device=dev, gather_ahead=args.gather_ahead)
-            tsl.step()
-            l0 = tsl.loss()
-            n_l = max(n_s, 60)
-            el = timed_steps(tsl, n_l, n_w, dev)
-            out["data_learnable"] = {"workload": "config1 step (batch %d in-batch) on a learnable 200000 x 1500 catalogue "
-                                                 "(co-watched videos share one of 2000 clusters), Adam 2e-4" % B,
-                                     "value": round(B * n_l / el, 1), "unit": "triplets/s",
-                                     "ms_per_step": round(el / n_l * 1e3, 4), "steps": n_l,
-                                     "loss_first_step": round(l0, 4), "loss_last_step": round(tsl.loss(), 4)}
-            del tsl, tl, pl
-            torch.cuda.empty_cache()
+        out.update(extras)
+        if not extras:
+            out["order"] = ("0.3 s of projection-GEMM launches on scratch buffers (clock ramp after idle: the first ~100 ms "
+                            "of MFMA work run ~2 % slower), then warm-up + timed steps")
+        else:
+            out["order"] = ("like_for_like and data_learnable were measured first, the headline's warm-up + timed steps "
+                            "directly after them (GPU already at its sustained clocks), cpu_baseline last")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
         print(json.dumps(out), flush=True)
