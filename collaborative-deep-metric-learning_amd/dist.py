@@ -207,12 +207,15 @@ class RowExchange:
 class GradSync:
     """Average the flat gradient buffer over the data-parallel group."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, skip_self=True):
+        """``skip_self``: a single rank has nothing to average and issues no collective (False
+        keeps the RCCL calls: they then run, and can be captured, even at world size 1)."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.nccl = dist.get_backend(group) == "nccl"
+        self.active = self.world > 1 or (self.nccl and not skip_self)
         self.avg = False
-        if self.nccl and self.world > 1:
+        if self.nccl and self.active:
             # probe once whether the communicator implements ReduceOp.AVG (every rank
             # runs the same probe, so the collective order stays identical)
             dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -228,7 +231,7 @@ class GradSync:
         (it runs on the communicator's stream behind everything enqueued so far and
         overlaps whatever the compute stream does next).  Returns a handle for finish."""
         seg = flat_grad[lo:hi]
-        if self.world == 1:
+        if not self.active:
             return None
         if self.nccl:
             op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
@@ -246,7 +249,7 @@ class GradSync:
                     seg.div_(self.world)
 
     def __call__(self, flat_grad):
-        if self.world == 1:
+        if not self.active:
             return flat_grad
         if self.nccl:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, group=self.group)
@@ -273,15 +276,21 @@ class Prefetcher:
     collectives of one group execute in issue order, and the exchange of step t+1
     must not queue behind the gradient all-reduce of step t.
 
-    Inside a hipGraph capture the side stream is FORKED from the capturing stream and
-    joined again before the capture ends (``join``): the graph of step t then contains the
-    exchange of step t+1 as a parallel branch, and consecutive replays are ordered by the
-    stream, so the event hand-over between steps is not needed (and could not be captured:
-    its events belong to earlier launches)."""
+    Inside a hipGraph capture the exchange is recorded on the CAPTURING stream itself, ahead of
+    the step's forward pass (so in a replay it is not hidden under the GEMMs: eager is the faster
+    mode for N > 1).  Forking it onto the side stream would put RCCL's own stream two forks deep
+    -- capturing stream -> side stream -> communicator stream -- and on this stack (torch 2.10,
+    RCCL 2.26, HIP 7.0) that never returns from the capture (tools/probes/rccl_graph_capture.py:
+    one fork deep every collective captures and replays correctly, two deep it hangs or
+    crashes in hipStreamEndCapture).  ``fork_in_capture=True`` restores the fork for stacks
+    where it works.  The event hand-over between steps is not needed in a replay (consecutive
+    replays are ordered by the stream) and could not be captured anyway: its events belong to
+    earlier launches."""
 
-    def __init__(self, device):
+    def __init__(self, device, fork_in_capture=False):
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
+        self.fork_in_capture = bool(fork_in_capture)
         if self.cuda:
             self.stream = torch.cuda.Stream(self.device)
             self.ready = [torch.cuda.Event(), torch.cuda.Event()]
@@ -299,6 +308,9 @@ class Prefetcher:
             return
         cur = torch.cuda.current_stream(self.device)
         if self._capturing():
+            if not self.fork_in_capture:
+                fill_fn()                            # on the capturing stream (see the class docstring)
+                return
             self.stream.wait_stream(cur)             # fork: the branch starts behind what is captured so far
             with torch.cuda.stream(self.stream):
                 fill_fn()

@@ -171,15 +171,8 @@ class TrainStep:
         if self.use_graph and self.train_table and exchange is not None:
             self.use_graph = False                       # scatter_back sizes its scratch on the fly
             logging.getLogger("cdml.train").warning("use_graph ignored: trainable sharded table runs eagerly")
-        world = max(exchange.world if exchange is not None else 1, grad_sync.world if grad_sync is not None else 1)
-        if self.use_graph and world > 1 and not os.environ.get("CDML_GRAPH_COLLECTIVES"):
-            # measured on this stack (torch 2.10 / RCCL 2.26, world size 1): a captured
-            # all_to_all_single never returns from the capture.  The step is enqueue-only either
-            # way; opt in with CDML_GRAPH_COLLECTIVES=1 where the collectives do capture.
-            self.use_graph = False
-            logging.getLogger("cdml.train").warning(
-                "use_graph ignored: RCCL collectives inside a hipGraph capture hang on this stack "
-                "(set CDML_GRAPH_COLLECTIVES=1 to try); the data-parallel step runs eagerly")
+        # (with RCCL inside: under capture the exchange is recorded on the capturing stream, see
+        # dist.Prefetcher; verified over RCCL at world size 1, tests/test_gpu_dist.py)
         # row-sharded catalogue: the exchange of step t+1 runs ahead on a side stream
         # into the second x_hat / idx buffer while step t computes
         self.prefetch = None

@@ -151,8 +151,8 @@ def _nccl_worker(port, q):
         # side stream) and of the gradient sync (async AVG / SUM), with a single rank
         ts = _make(dev, 0, 1)                       # reference: whole table, no exchange
         ex = cdist.RowExchange(CFG["n_rows"], group=dist.new_group(), skip_self=False)
-        sync = cdist.GradSync(device=dev)
-        sync.world = 2                              # force the collective path (average of one rank x1 ... /2 below)
+        sync = cdist.GradSync(device=dev, skip_self=False)     # the collective runs although there is one rank
+        assert sync.active
         from cdml_amd import train
         ts2 = train.TrainStep(ts.table, ts.pairs, 2 * CFG["B"], hidden_size=CFG["H"], output_size=CFG["D"],
                               mode="uniform", device=dev, exchange=ex, grad_sync=None, batch_global=2 * CFG["B"])
@@ -164,7 +164,7 @@ def _nccl_worker(port, q):
         h = sync.start(g, 0, 1000)
         sync.finish([h])
         torch.cuda.synchronize()
-        ok_avg = abs(float(g[0].item()) - (3.0 if sync.avg else 1.5)) < 1e-6
+        ok_avg = abs(float(g[0].item()) - 3.0) < 1e-6          # the average over one rank
         ex.check_overflow()
         ok = same and ok_avg
         graph_msg = "-"
@@ -229,11 +229,10 @@ def _say(msg):
 
 
 def _nccl_graph_worker(port, q):
-    """The data-parallel step (row routing, owner gather, un-permute on the forked prefetch stream;
-    GradSync hooks in place) captured into hipGraphs, one per prefetch buffer, must equal the eager
-    step.  World size 1: the exchange skips its two all-to-alls (every request is local), so no
-    RCCL call sits inside the capture -- a captured all_to_all_single never came back on this
-    stack (torch 2.10 / RCCL 2.26), which is why TrainStep keeps world > 1 eager by default."""
+    """The data-parallel step captured into hipGraphs, one per prefetch buffer, WITH its RCCL
+    collectives inside the capture (world size 1, skip_self=False: the two equal-split
+    all-to-alls of the row exchange on their own communicator, the bucketed asynchronous
+    all-reduces of the gradient) must equal the eager step bit for bit."""
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -244,10 +243,11 @@ def _nccl_graph_worker(port, q):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         from cdml_amd import dist as cdist, train
         base = _make(dev, 0, 1)
-        sync = cdist.GradSync(device=dev)
+        sync = cdist.GradSync(device=dev, skip_self=False)
+        assert sync.active
         mk = lambda g_: train.TrainStep(base.table, base.pairs, 2 * CFG["B"], hidden_size=CFG["H"],
                                         output_size=CFG["D"], mode="uniform", device=dev,
-                                        exchange=cdist.RowExchange(CFG["n_rows"], group=dist.new_group()),
+                                        exchange=cdist.RowExchange(CFG["n_rows"], group=dist.new_group(), skip_self=False),
                                         grad_sync=sync, batch_global=2 * CFG["B"], use_graph=g_)
         e1, g1 = mk(False), mk(True)
         for i in range(6):
@@ -264,6 +264,8 @@ def _nccl_graph_worker(port, q):
             msg = "graph replay differs from eager: %g" % float((e1.params.flat - g1.params.flat).abs().max())
         else:
             msg = "ok"
+        g1._graphs.clear()                               # graphs go before the communicators they recorded
+        torch.cuda.synchronize()
         q.put(msg)
         dist.destroy_process_group()
     except Exception:
