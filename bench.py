@@ -105,11 +105,11 @@ class KernelTimer:
         return len(self.ev.get(name, []))
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, bf16=False):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary
-    (profiles/latest_pmc.csv: separate FETCH_SIZE / WRITE_SIZE passes of this bench, KiB;
-    FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
-    path = os.path.join(ROOT, "profiles", "latest_pmc.csv")
+    (profiles/latest_pmc.csv, latest_pmc_bf16.csv for --precision bf16: separate FETCH_SIZE /
+    WRITE_SIZE passes of this bench, KiB; FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "latest_pmc_bf16.csv" if bf16 else "latest_pmc.csv")
     if not os.path.exists(path):
         return None
     import csv
@@ -202,20 +202,23 @@ def learnable_catalogue(n_rows, dev, n_clusters=2000, seed=0):
 
 
 def settle_gpu(dev, seconds=0.3):
-    """Projection-GEMM launches on scratch buffers for ~`seconds`: the first ~100 ms of MFMA work after an
+    """Weight-gradient GEMM launches on scratch buffers for ~`seconds`: the first ~100 ms of MFMA work after an
     idle spell run ~2 % slower on this part (clock ramp), and the default N = 1 line gets past that through
     its secondary measurements; every other line gets the same start through this loop.  Not a step of the
     measured job: no state of the TrainStep is touched."""
     from cdml_amd import ops
     M, K, N = 4096, 1536, 5120
+    # the split-K weight-gradient entry point: an MFMA-bound launch that is NOT part of the N = 1 step
+    # (stream-K there), so a rocprofv3 run of this bench keeps clean per-kernel averages for the step
     x = torch.rand((M, K), device=dev)
-    W = torch.randn((K, N), device=dev) * 0.02
-    b = torch.zeros(N, device=dev)
-    y = torch.empty((M, N), device=dev)
+    dy = torch.randn((M, N), device=dev) * 0.02
+    dW = torch.empty((K, N), device=dev)
+    db = torch.empty(N, device=dev)
+    ws = torch.empty(max(ops.fc_bwd_weight_workspace(M, K, N), 16) // 4, device=dev)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(20):
-            ops.fc_lrelu_fwd(x, W, b, y, M, K, N)
+            ops.fc_bwd_weight(x, dy, dW, db, ws, M, K, N)
         torch.cuda.synchronize(dev)
 
 
@@ -248,6 +251,8 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true", help="50 timed CPU steps in all four runs (minutes)")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip like_for_like and data_learnable")
+    ap.add_argument("--no-settle", action="store_true",
+                    help="skip the 0.3 s GEMM loop before the warm-up steps (rocprof runs: keeps its launches out of the kernel averages)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -386,7 +391,7 @@ def main():
                                      "loss_first_step": round(l0, 4), "loss_last_step": round(tsl.loss(), 4)}
             del tsl, tl, pl
             torch.cuda.empty_cache()
-        if not extras:
+        if not extras and not args.no_settle:
             phase = "clock settle"
             settle_gpu(dev)
         phase = "warm-up steps"
@@ -481,7 +486,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": klabel,
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4),
-                               "traffic": pmc_traffic(kname) if world == 1 else None,
+                               "traffic": pmc_traffic(kname, bf16) if world == 1 else None,
                                "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch,
                                "launches_per_step": n_launch / sampled, "timed_steps": sampled,
                                "timed_how": ("event pairs on every %dth timed step" % stride) if not graph_run else
@@ -490,7 +495,7 @@ def main():
             k1 = "k_gemm_bf16_256<false, 0>" if bf16 else "k_gemm_f32<true, false, 2, 2, 1,"
             out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": k1 + ("" if bf16 else " ...>"),
                                        "achieved": round(ach1, 2), "peak": peak, "unit": "TFLOP/s",
-                                       "frac": round(ach1 / peak, 4), "traffic": pmc_traffic(k1) if world == 1 else None,
+                                       "frac": round(ach1 / peak, 4), "traffic": pmc_traffic(k1, bf16) if world == 1 else None,
                                        "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": flops_gemm}
             kern = {}
             for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "adam"):
@@ -534,7 +539,7 @@ def main():
             t_g = float(np.median([s.elapsed_time(e) for s, e in evs])) / per
             g_ach = gbytes / (t_g * 1e-3) / 1e9
             out["gather"] = {"bound": "hbm", "kernel": gk + (" RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1), "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(gk),
+                             "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(gk, bf16),
                              "bytes_per_launch": gbytes, "launch_ms": round(t_g, 4), "steps_per_launch": n_st,
                              "method": "%d back-to-back launches per event pair (inter-launch gaps included), median of %d"
                                        % (per, reps)}
@@ -550,8 +555,10 @@ def main():
         out["step_tflops"] = round(step_flops / (elapsed / args.steps) / 1e12, 2)
 
         out.update(extras)
-        if not extras:
-            out["order"] = ("0.3 s of projection-GEMM launches on scratch buffers (clock ramp after idle: the first ~100 ms "
+        if not extras and args.no_settle:
+            out["order"] = "warm-up + timed steps from a cold start (--no-settle)"
+        elif not extras:
+            out["order"] = ("0.3 s of weight-gradient GEMM launches on scratch buffers (clock ramp after idle: the first ~100 ms "
                             "of MFMA work run ~2 % slower), then warm-up + timed steps")
         else:
             out["order"] = ("like_for_like and data_learnable were measured first, the headline's warm-up + timed steps "

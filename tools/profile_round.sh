@@ -19,14 +19,14 @@ cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $ROOT/gpurun_out/${TAG
 echo "[profile] kernel stats done"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- python3 $ROOT/bench.py $ARGS --steps 4 --warmup 0 \
-      --no-cpu-baseline --no-extras --no-kernel-timers > /dev/null 2> $OUT/pmc_$C.err
+      --no-cpu-baseline --no-extras --no-settle --no-kernel-timers > /dev/null 2> $OUT/pmc_$C.err
   echo "[profile] pmc $C done"
 done
 python3 $ROOT/tools/pmc_summary.py $ROOT/gpurun_out/${TAG}_pmc_fetch_write.csv \
     FETCH_SIZE=$(find $OUT/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) \
     WRITE_SIZE=$(find $OUT/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) > /dev/null
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_busy -o pmc -- python3 $ROOT/bench.py $ARGS \
-    --steps 4 --warmup 0 --no-cpu-baseline --no-extras --no-kernel-timers > /dev/null 2> $OUT/pmc_busy.err
+    --steps 4 --warmup 0 --no-cpu-baseline --no-extras --no-settle --no-kernel-timers > /dev/null 2> $OUT/pmc_busy.err
 python3 $ROOT/tools/pmc_mfma_busy.py $(find $OUT/pmc_busy -name '*counter_collection.csv' | head -1) \
     > $ROOT/gpurun_out/${TAG}_mfma_busy_clock.txt
 echo "[profile] done"
