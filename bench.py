@@ -336,7 +336,11 @@ def main():
                 patch("fc_bwd_weight", lambda x, dy, dW, db, ws, M, K, N: "dW1" if N == L.Hp else "dW2")
                 patch("fc_bwd_weight2", "dW")             # single GPU: both products in one stream-K launch
                 patch("fc_bwd_data", "dH1")
-            patch("adam_step", "adam")
+            if bf16:                                      # matrices (with their bf16 operand copies), then the biases
+                patch("adam_matrix_bf16", lambda W, *a, **k: "adam_w1" if W.shape[0] == L.Fp else "adam_w2")
+                patch("adam_step", "adam_bias")
+            else:
+                patch("adam_step", "adam")
             patch("vnet_tail", "tail")
         comm = {}
         if world > 1:                                   # what the compute stream waits for
@@ -503,7 +507,7 @@ def main():
                                        "frac": round(ach1 / peak, 4), "traffic": pmc_traffic(k1, bf16) if world == 1 else None,
                                        "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": flops_gemm}
             kern = {}
-            for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "adam"):
+            for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "adam", "adam_w1", "adam_w2", "adam_bias"):
                 if kt.mean_ms(k) is not None:
                     kern[k + "_ms"] = round(kt.mean_ms(k), 4)
             kern["empty_event_pair_ms"] = round(kt.overhead_ms, 5)      # included in the figures above

@@ -72,6 +72,68 @@ k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m
   if (advance && grid_last_block(tickets) && threadIdx.x == 0) *t_dev += 1;
 }
 
+// Adam on a weight MATRIX W[K][N] (row-major, ld = N) that also writes the bf16 operand copies the
+// config-4 GEMMs read: W^T as bf16 [N][K] (wt, nullable) and W as bf16 [K][N] (wc, nullable) -- what
+// k_transpose_bf16 / k_cast_f32_bf16 would produce from the updated weights, without reading them
+// again.  One 64 x 64 tile per block: 16-B accesses on every fp32 stream, the transpose through LDS
+// (132-B rows: the 2-B column writes spread over the banks), whole 128-B lines on the bf16 rows.
+// Same arithmetic per element as k_adam (bit-equal).
+constexpr int kAT = 64;
+__global__ void __launch_bounds__(kThreads)
+k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
+                   float *__restrict__ v, int K, int N, float lr_imm, const float *__restrict__ lr_dev,
+                   float b1, float b2, float eps, int64_t t_imm, const uint64_t *__restrict__ t_dev,
+                   __bf16 *__restrict__ wt, int64_t ldt, __bf16 *__restrict__ wc, int64_t ldc) {
+  using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+  __shared__ float s_lr_t;
+  __shared__ __attribute__((aligned(16))) __bf16 sT[kAT][kAT + 2];
+  if (threadIdx.x == 0) {
+    const double t = (double)t_imm + (t_dev ? (double)(*t_dev) : 0.0);
+    const double lr = lr_dev ? (double)(*lr_dev) : (double)lr_imm;
+    s_lr_t = (float)(lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  }
+  __syncthreads();
+  const float lr_t = s_lr_t;
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  const int tiles_n = N / kAT;
+  const int k0 = (blockIdx.x / tiles_n) * kAT, n0 = (blockIdx.x % tiles_n) * kAT;
+  const int tr = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = p * 16 + tr;
+    const int64_t i = (int64_t)(k0 + r) * N + n0 + c4;
+    float4 w4 = *reinterpret_cast<float4 *>(w + i);
+    const float4 g4 = *reinterpret_cast<const float4 *>(g + i);
+    float4 m4 = *reinterpret_cast<float4 *>(m + i);
+    float4 v4 = *reinterpret_cast<float4 *>(v + i);
+#define CDML_ADAM1(c)                              \
+  m4.c += (g4.c - m4.c) * omb1;                    \
+  v4.c += (g4.c * g4.c - v4.c) * omb2;             \
+  w4.c -= (m4.c * lr_t) / (sqrtf(v4.c) + eps);
+    CDML_ADAM1(x) CDML_ADAM1(y) CDML_ADAM1(z) CDML_ADAM1(w)
+#undef CDML_ADAM1
+    *reinterpret_cast<float4 *>(w + i) = w4;
+    *reinterpret_cast<float4 *>(m + i) = m4;
+    *reinterpret_cast<float4 *>(v + i) = v4;
+    bf16x4 o;
+    o.x = (__bf16)w4.x; o.y = (__bf16)w4.y; o.z = (__bf16)w4.z; o.w = (__bf16)w4.w;
+    if (wc) *reinterpret_cast<bf16x4 *>(wc + (int64_t)(k0 + r) * ldc + n0 + c4) = o;
+    sT[c4 + 0][r] = o.x; sT[c4 + 1][r] = o.y; sT[c4 + 2][r] = o.z; sT[c4 + 3][r] = o.w;
+  }
+  if (!wt) return;                                   // (uniform: no barrier is left behind)
+  __syncthreads();
+  // transposed tile: row n of W^T holds 64 consecutive k = 128 B; 8 threads x 16 B per row
+  const int sr = threadIdx.x >> 3, seg = (threadIdx.x & 7) * 8;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = q * 32 + sr;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&sT[row][seg]);   // 132-B rows: 4-B aligned
+    uint4 o;
+    o.x = src[0]; o.y = src[1]; o.z = src[2]; o.w = src[3];
+    *reinterpret_cast<uint4 *>(wt + (int64_t)(n0 + row) * ldt + k0 + seg) = o;
+  }
+}
+
 // scratch layout: [0]=|w|^2, [1]=|g|^2, then kLarsBlocks x 2 block partials
 __global__ void __launch_bounds__(kThreads)
 k_lars_norm_partial(const float *__restrict__ w, const float *__restrict__ g, int64_t n,
@@ -207,6 +269,24 @@ extern "C" int cdml_adam_step(float *w, const float *g, float *m, float *v, int6
   hipLaunchKernelGGL(k_adam, dim3(grid_elems(n, 4)), dim3(kThreads), 0, (hipStream_t)stream, w, g, m,
                      v, n, lr, lr_dev, beta1, beta2, eps, t, t_dev, advance_step, tickets);
   return check_launch("adam_step");
+}
+
+extern "C" int cdml_adam_matrix_bf16(float *w, const float *g, float *m, float *v, int K, int N, float lr,
+                                     const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
+                                     const uint64_t *t_dev, uint16_t *wt_bf16, int64_t ldt, uint16_t *wc_bf16,
+                                     int64_t ldc, cdml_stream_t stream) {
+  CDML_REQUIRE(w && g && m && v && K > 0 && N > 0, CDML_E_BADARG, "adam_matrix_bf16: bad argument");
+  CDML_REQUIRE(K % kAT == 0 && N % kAT == 0, CDML_E_UNSUPPORTED,
+               "adam_matrix_bf16: K and N must be multiples of 64, got K=%d N=%d", K, N);
+  CDML_REQUIRE(t >= (t_dev ? 0 : 1), CDML_E_BADARG, "adam_matrix_bf16: step t is 1-based");
+  CDML_REQUIRE(aligned16(w) && aligned16(g) && aligned16(m) && aligned16(v) &&
+                   (!wt_bf16 || (aligned16(wt_bf16) && (ldt & 7) == 0 && ldt >= K)) &&
+                   (!wc_bf16 || (aligned16(wc_bf16) && (ldc & 3) == 0 && ldc >= N)),
+               CDML_E_ALIGN, "adam_matrix_bf16: 16-B aligned buffers, ldt a multiple of 8 (>= K), ldc of 4 (>= N)");
+  hipLaunchKernelGGL(k_adam_matrix_bf16, dim3((K / kAT) * (N / kAT)), dim3(kThreads), 0, (hipStream_t)stream, w, g,
+                     m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, reinterpret_cast<__bf16 *>(wt_bf16), ldt,
+                     reinterpret_cast<__bf16 *>(wc_bf16), ldc);
+  return check_launch("adam_matrix_bf16");
 }
 
 extern "C" size_t cdml_lars_scratch_floats(void) { return 2 + 2 * (size_t)kLarsBlocks; }

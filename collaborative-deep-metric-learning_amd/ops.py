@@ -409,6 +409,25 @@ def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, 
          _p(advance_tickets, torch.int32), _stream())
 
 
+def adam_matrix_bf16(W, g, m, v, lr, t, wt=None, wc=None, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, t_dev=None):
+    """Adam on the contiguous weight matrix W [K, N] (g, m, v alike) that also writes the bf16 operand
+    copies: wt = W^T as bf16 [N, >=K], wc = W as bf16 [K, >=N] (either may be None)."""
+    if W.dim() != 2 or not W.is_contiguous() or W.dtype != torch.float32:
+        raise ValueError("W must be a contiguous fp32 matrix")
+    K, N = W.shape
+    for name, x in (("g", g), ("m", m), ("v", v)):
+        if x.numel() != K * N or not x.is_contiguous() or x.dtype != torch.float32:
+            raise ValueError("%s must be contiguous fp32 with W's size" % name)
+    tp, tld = (C.c_void_p(0), 0) if wt is None else _mat16(wt)
+    cp, cld = (C.c_void_p(0), 0) if wc is None else _mat16(wc)
+    if wt is not None and (wt.shape[0] < N or wt.shape[1] < K):
+        raise ValueError("wt must be at least [N, K]")
+    if wc is not None and (wc.shape[0] < K or wc.shape[1] < N):
+        raise ValueError("wc must be at least [K, N]")
+    call("cdml_adam_matrix_bf16", _p(W), _p(g), _p(m), _p(v), K, N, lr, _p(lr_dev), beta1, beta2, eps,
+         0 if t is None else t, _p(t_dev, torch.int64), tp, tld, cp, cld, _stream())
+
+
 def table_adam_rows(table, row0, F, idx, grad_xhat, m_table, v_table, head, nxt, lr, t, beta1=0.9, beta2=0.999,
                     eps=1e-8, lr_dev=None, t_dev=None, grad_scale=1.0):
     """Lazy-Adam update of the catalogue rows a batch touched (see include/cdml.h)."""

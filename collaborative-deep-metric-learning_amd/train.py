@@ -335,9 +335,22 @@ class TrainStep:
             for i, (off, n) in enumerate(p.segments()):    # W1, b1, W2, b2: weights carry the regulariser
                 ops.grad_prepare(p.grad[off:off + n], p.flat[off:off + n], self.reg_scale if i % 2 == 0 else 0.0,
                                  self.clip_gradient_norm, self.lars_scratch, self.grad_norms[i])
-        if self.optimizer == "adam":
-            # the step counter advances inside the same launch unless something after it (the
-            # bf16 weight refresh is fine, LARS is not on this branch) still reads it
+        if self.optimizer == "adam" and self.bf16:
+            # config-4 precision: the weight matrices' update also writes the bf16 operand copies
+            # the GEMMs read (no separate transposes / cast); the biases follow, and the second
+            # of their launches advances the step counter
+            L, o, ws = self.layout, self.layout.offsets, self.ws
+            mat = lambda t, i, r, c: t[o[i]:o[i] + r * c].view(r, c)
+            kw = dict(lr_dev=self.lr_dev, t_dev=self.step_dev)
+            ops.adam_matrix_bf16(p.W1, mat(p.grad, 0, L.Fp, L.Hp), mat(self.m, 0, L.Fp, L.Hp),
+                                 mat(self.v, 0, L.Fp, L.Hp), 0.0, 1, wt=ws.W1T, **kw)
+            ops.adam_matrix_bf16(p.W2, mat(p.grad, 2, L.Hp, L.Dp), mat(self.m, 2, L.Hp, L.Dp),
+                                 mat(self.v, 2, L.Hp, L.Dp), 0.0, 1, wt=ws.W2T, wc=ws.W2, **kw)
+            b1, b2 = slice(o[1], o[1] + L.Hp), slice(o[3], o[3] + L.Dp)
+            ops.adam_step(p.flat[b1], p.grad[b1], self.m[b1], self.v[b1], 0.0, 1, **kw)
+            ops.adam_step(p.flat[b2], p.grad[b2], self.m[b2], self.v[b2], 0.0, 1, advance_tickets=self.adam_tickets, **kw)
+        elif self.optimizer == "adam":
+            # the step counter advances inside the same launch
             ops.adam_step(p.flat, p.grad, self.m, self.v, 0.0, 1, lr_dev=self.lr_dev,
                           t_dev=self.step_dev, advance_tickets=self.adam_tickets)
         elif self.optimizer == "momentum":
@@ -346,7 +359,7 @@ class TrainStep:
             for off, n in p.segments():       # LARS trust ratio is per variable
                 ops.lars_step(p.flat[off:off + n], p.grad[off:off + n], self.acc[off:off + n],
                               0.0, self.lars_scratch, lr_dev=self.lr_dev)
-        if self.bf16:
+        if self.bf16 and self.optimizer != "adam":
             engine_bf16.refresh_weights(p, self.ws)
         if self.optimizer != "adam":
             ops.step_advance(self.step_dev)

@@ -300,6 +300,17 @@ int cdml_knn_merge(const float *scores, int64_t lds, int nq, int nb, int col0,
                    int n_valid, const float *q_sq, const float *b_sq, int k,
                    float *best_d, int32_t *best_i, int first, cdml_stream_t stream);
 
+/* cdml_adam_step on a weight matrix W[K][N] (row-major, contiguous: ld = N) that also writes the
+ * bf16 operand copies the config-4 GEMMs read -- W^T as bf16 [N][ldt] (wt_bf16, nullable) and W as
+ * bf16 [K][ldc] (wc_bf16, nullable), round-to-nearest-even of the UPDATED weights: the optimizer
+ * step of train.py:146 and cdml_transpose_to_bf16 / cdml_cast_f32_bf16 in one pass over the
+ * weights (bit-equal to the separate calls).  K, N multiples of 64.  t / t_dev / lr_dev as
+ * cdml_adam_step; the step counter is not advanced here. */
+int cdml_adam_matrix_bf16(float *w, const float *g, float *m, float *v, int K, int N, float lr,
+                          const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
+                          const uint64_t *t_dev, uint16_t *wt_bf16, int64_t ldt,
+                          uint16_t *wc_bf16, int64_t ldc, cdml_stream_t stream);
+
 /* ---- reduced-precision tower (BASELINE config 4: fp16 catalogue + bf16 MFMA
  * projection; build-defined precision with its own tolerance, never the default).
  * bf16 / fp16 buffers are passed as uint16_t*.  Same layers as the fp32 entry

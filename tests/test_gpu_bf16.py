@@ -139,6 +139,40 @@ def test_gemm_bf16_k256_streaming_data_gradient(cd, M, N, monkeypatch):
     assert bool((wo[M:, :] == 3.0).all()) and bool((wo[:, N:] == 3.0).all())
 
 
+@pytest.mark.parametrize("K,N", [(64, 64), (1536, 5120), (5120, 256)])
+def test_adam_matrix_bf16_equals_adam_then_copies(cd, K, N):
+    """The optimizer step that also writes the GEMMs' bf16 operand copies: bit-equal to cdml_adam_step
+    followed by cdml_transpose_to_bf16 / cdml_cast_f32_bf16, and within fp32 rounding of the oracle."""
+    g_ = torch.Generator(device=cd.dev)
+    g_.manual_seed(K + N)
+    mk = lambda s: torch.randn(K, N, device=cd.dev, generator=g_) * s
+    W, G, M, V = mk(0.05), mk(1e-3), mk(1e-4), mk(1e-4).abs()
+    lr = torch.tensor([0.01], device=cd.dev)
+    step = torch.tensor([6], dtype=torch.int64, device=cd.dev)              # t = 1 + 6
+    w0, m0, v0 = W.clone(), M.clone(), V.clone()
+    cd.ops.adam_step(w0, G, m0, v0, 0.0, 1, lr_dev=lr, t_dev=step)
+    wt0 = torch.empty((N, K), dtype=torch.bfloat16, device=cd.dev)
+    wc0 = torch.empty((K, N), dtype=torch.bfloat16, device=cd.dev)
+    cd.ops.transpose_to_bf16(w0, wt0, K, N)
+    cd.ops.cast_f32_bf16(w0, wc0, K, N)
+    w1, m1, v1 = W.clone(), M.clone(), V.clone()
+    wt1 = torch.full((N, K + 64), 9.0, dtype=torch.bfloat16, device=cd.dev)  # wider buffers: strides honoured
+    wc1 = torch.full((K, N + 8), 9.0, dtype=torch.bfloat16, device=cd.dev)
+    cd.ops.adam_matrix_bf16(w1, G, m1, v1, 0.0, 1, wt=wt1, wc=wc1, lr_dev=lr, t_dev=step)
+    assert torch.equal(w0, w1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    assert torch.equal(wt0, wt1[:, :K]) and torch.equal(wc0, wc1[:, :N])
+    assert bool((wt1[:, K:] == 9.0).all()) and bool((wc1[:, N:] == 9.0).all())
+    assert int(step.item()) == 6                                             # the counter is not advanced here
+    w2 = W.clone()
+    cd.ops.adam_matrix_bf16(w2, G, M.clone(), V.clone(), 0.0, 1, lr_dev=lr, t_dev=step)   # no copies asked for
+    assert torch.equal(w2, w0)
+    ow, om, ov = otower.adam_step(W.cpu().numpy(), G.cpu().numpy(), M.cpu().numpy(), V.cpu().numpy(), 7, 0.01)[:3]
+    np.testing.assert_allclose(w1.cpu().numpy(), ow, rtol=2e-5, atol=3e-7)
+    with pytest.raises(cd.pkg.CdmlError):
+        cd.ops.adam_matrix_bf16(torch.zeros(96, 64, device=cd.dev), torch.zeros(96, 64, device=cd.dev),
+                                torch.zeros(96, 64, device=cd.dev), torch.zeros(96, 64, device=cd.dev), 0.01, 1)
+
+
 def test_gemm_bf16_256_race_screen(cd, monkeypatch):
     """The ping-pong kernel orders its LDS-DMA against the fragment reads by counted waits and
     barriers only; a misplaced wait shows up as rare wrong tiles.  Many launches, full chip,
