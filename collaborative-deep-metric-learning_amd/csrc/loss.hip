@@ -443,20 +443,40 @@ k_semihard_select(const float *__restrict__ S, int64_t ldS, const float *__restr
     const int32_t va = rows[2 * i], vp = rows[2 * i + 1];
     const float dp = sa + sqn[2 * i + 1] - 2.0f * Si[2 * i + 1];
     Cand out{inf, 0x7fffffff}, in{-inf, 0x7fffffff};
-    for (int q = lane; q < (R >> 2); q += kWave) {
-      const float4 s4 = ld4(Si, q);
+    // four candidates per lane and load: the S row, the video ids and the squared norms all as 16-B
+    // accesses (R = 2B is a multiple of 4)
+    auto scan4 = [&](int q, const float4 s4, const int4 r4, const float4 n4) {
       const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+      const int32_t rv[4] = {r4.x, r4.y, r4.z, r4.w};
+      const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = 4 * q + u;
-        const int32_t vc = rows[c];
-        if (vc != va && vc != vp) {
-          const float d = sa + sqn[c] - 2.0f * sv[u];
+        if (rv[u] != va && rv[u] != vp) {
+          const float d = sa + nv[u] - 2.0f * sv[u];
           if (d > dp) { if (closer(d, c, out)) out = Cand{d, c}; }
           if (farther(d, c, in)) in = Cand{d, c};
         }
       }
+    };
+    const int nq = R >> 2;
+    const int4 *rows4 = reinterpret_cast<const int4 *>(rows);
+    int q = lane;
+    for (; q + 3 * kWave < nq; q += 4 * kWave) {     // four groups (16 candidates) per lane in flight
+      float4 sv[4], nv[4];
+      int4 rv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        using f32x4 = __attribute__((ext_vector_type(4))) float;
+        const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Si) + q + u * kWave);   // S is read once
+        sv[u] = make_float4(t4.x, t4.y, t4.z, t4.w);
+        rv[u] = rows4[q + u * kWave];
+        nv[u] = ld4(sqn, q + u * kWave);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) scan4(q + u * kWave, sv[u], rv[u], nv[u]);
     }
+    for (; q < nq; q += kWave) scan4(q, ld4(Si, q), rows4[q], ld4(sqn, q));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const float od = __shfl_xor(out.d, off, 64); const int oc = __shfl_xor(out.c, off, 64);
@@ -518,22 +538,39 @@ k_hinge_indexed_bwd(const float *__restrict__ e, int64_t lde, const int32_t *__r
       const float4 va = ld4(a, q), vp = ld4(p, q), vn = ld4(n, q);
       st4(dr, q, (r & 1) ? mul4(sub4(vp, va), si) : mul4(sub4(vn, vp), si));
     }
-    for (int j0 = 0; j0 < B; j0 += kWave) {    // triplets that mined row r as negative
-      const int j = j0 + lane;
-      const bool hit = (j < B) && (neg_row[j] == r) && (scale[j] != 0.f);
-      unsigned long long m = __ballot(hit);
-      while (m) {
-        const int jj = j0 + __builtin_ctzll(m);
+    // triplets that mined row r as negative, in ascending triplet order: each lane checks four
+    // consecutive triplets per pass (16-B loads of neg_row / scale), hits are rare
+    auto add_term = [&](int jj) {
+      const float sj = scale[jj];
+      const float *aj = e + (int64_t)(2 * jj) * lde;
+      for (int q = lane; q < nq; q += kWave) {
+        const float4 g = mul4(sub4(ld4(aj, q), ld4(er, q)), sj);
+        const float4 cur = ld4(dr, q);
+        st4(dr, q, make_float4(cur.x + g.x, cur.y + g.y, cur.z + g.z, cur.w + g.w));
+      }
+    };
+    const int B4 = B & ~3;
+    for (int j0 = 0; j0 < B4; j0 += 4 * kWave) {
+      const int j = j0 + 4 * lane;
+      unsigned hits = 0;                         // bit u: triplet j + u mined r and is active
+      if (j < B4) {
+        const int4 n4 = *reinterpret_cast<const int4 *>(neg_row + j);
+        const float4 s4 = *reinterpret_cast<const float4 *>(scale + j);
+        hits = (unsigned)(n4.x == r && s4.x != 0.f) | ((unsigned)(n4.y == r && s4.y != 0.f) << 1) |
+               ((unsigned)(n4.z == r && s4.z != 0.f) << 2) | ((unsigned)(n4.w == r && s4.w != 0.f) << 3);
+      }
+      unsigned long long m = __ballot(hits != 0);
+      while (m) {                                // lanes ascending = triplets ascending
+        const int l = __builtin_ctzll(m);
         m &= m - 1;
-        const float sj = scale[jj];
-        const float *aj = e + (int64_t)(2 * jj) * lde;
-        for (int q = lane; q < nq; q += kWave) {
-          const float4 g = mul4(sub4(ld4(aj, q), ld4(er, q)), sj);
-          const float4 cur = ld4(dr, q);
-          st4(dr, q, make_float4(cur.x + g.x, cur.y + g.y, cur.z + g.z, cur.w + g.w));
-        }
+        const unsigned h = (unsigned)__shfl((int)hits, l, 64);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (h & (1u << u)) add_term(j0 + 4 * l + u);
       }
     }
+    for (int jj = B4; jj < B; ++jj)              // B not a multiple of 4: the last few, one by one
+      if (neg_row[jj] == r && scale[jj] != 0.f) add_term(jj);
   }
 }
 
@@ -792,6 +829,8 @@ extern "C" int cdml_semihard_select(const float *S, int64_t ldS, const float *e,
   int rc;
   if ((rc = check_rows("semihard_select e", e, lde, D))) return rc;
   if ((rc = check_rows("semihard_select S", S, ldS, 2 * B))) return rc;
+  CDML_REQUIRE(aligned16(rows) && aligned16(sqn_scratch), CDML_E_ALIGN,
+               "semihard_select: rows and sqn_scratch must be 16-B aligned");
   hipLaunchKernelGGL(k_row_sumsq, dim3(grid_rows(2 * B)), dim3(kThreads), 0, (hipStream_t)stream, e,
                      lde, 2 * B, D, sqn_scratch);
   hipLaunchKernelGGL(k_semihard_select, dim3(grid_rows(B)), dim3(kThreads), 0, (hipStream_t)stream, S,
@@ -808,6 +847,8 @@ extern "C" int cdml_triplet_hinge_indexed(const float *e, int64_t lde, const int
   int rc;
   if ((rc = check_rows("triplet_hinge_indexed", e, lde, D))) return rc;
   if (de && (rc = check_rows("triplet_hinge_indexed", de, ldde, D))) return rc;
+  CDML_REQUIRE(!de || (aligned16(neg_row) && aligned16(scale_scratch)), CDML_E_ALIGN,
+               "triplet_hinge_indexed: neg_row and scale_scratch must be 16-B aligned");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_hinge_indexed_fwd, dim3(grid_rows(B)), dim3(kThreads), 0, s, e, lde, neg_row, B,
                      D, margin, pos, neg, hinge, scale_scratch);
