@@ -358,6 +358,38 @@ def test_fc_bwd_data(cd, M, K, N):
     np.testing.assert_allclose(dx.cpu().numpy(), f(dy) @ f(W).T, atol=TOL)
 
 
+@pytest.mark.parametrize("M,K", [(8192, 5120), (4096, 2048), (12288, 384)])
+def test_fc_bwd_data_output_layer_shapes(cd, M, K):
+    """The output layer's data gradient (256-deep contraction) at step-sized shapes: against fp64,
+    without a mask, strided views, repeated launches bit-equal, a ragged row count."""
+    N = 256
+    g_ = torch.Generator(device=cd.dev)
+    g_.manual_seed(M + K)
+    dy = torch.randn(M, N, device=cd.dev, generator=g_) / 64
+    W = torch.randn(K, N, device=cd.dev, generator=g_) * (1.0 + (torch.arange(N, device=cd.dev) % 5) * 0.5)
+    xp = torch.randn(M, K, device=cd.dev, generator=g_)
+    dx = torch.full((M, K), 7.0, device=cd.dev)
+    cd.ops.fc_bwd_data(dy, W, xp, dx, M, K, N)
+    ref = (dy.double() @ W.double().T) * torch.where(xp > 0, 1.0, 0.2).double()
+    assert (dx.double() - ref).abs().max().item() <= TOL
+    for _ in range(5):
+        again = torch.empty_like(dx)
+        cd.ops.fc_bwd_data(dy, W, xp, again, M, K, N)
+        assert torch.equal(dx, again)
+    cd.ops.fc_bwd_data(dy, W, None, dx, M, K, N)
+    assert (dx.double() - dy.double() @ W.double().T).abs().max().item() <= TOL
+    wide_dy = torch.zeros((M, N + 64), device=cd.dev)
+    wide_dy[:, :N] = dy
+    wide_dx = torch.full((M + 8, K + 32), 3.0, device=cd.dev)
+    wide_xp = torch.zeros((M, K + 4), device=cd.dev)
+    wide_xp[:, :K] = xp
+    cd.ops.fc_bwd_data(wide_dy[:, :N], W, wide_xp[:, :K], wide_dx[:M, :K], M, K, N)
+    assert torch.equal(wide_dx[:M, :K], again)
+    assert bool((wide_dx[M:, :] == 3.0).all()) and bool((wide_dx[:, K:] == 3.0).all())
+    cd.ops.fc_bwd_data(dy[:M - 8], W, xp[:M - 8], dx[:M - 8], M - 8, K, N)
+    assert (dx[:M - 8].double() - ref[:M - 8]).abs().max().item() <= TOL
+
+
 @pytest.mark.parametrize("M,K,N", [(15, 64, 64), (130, 192, 128), (384, 1536, 5120),
                                    (3000, 5120, 256), (1000, 128, 64)])
 def test_fc_bwd_weight(cd, M, K, N):
