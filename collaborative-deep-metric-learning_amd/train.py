@@ -173,6 +173,14 @@ class TrainStep:
             logging.getLogger("cdml.train").warning("use_graph ignored: trainable sharded table runs eagerly")
         # (with RCCL inside: under capture the exchange is recorded on the capturing stream, see
         # dist.Prefetcher; verified over RCCL at world size 1, tests/test_gpu_dist.py)
+        if self.use_graph and (exchange is not None or grad_sync is not None):
+            from . import dist as _cdist
+            staged = [h for h in (exchange, grad_sync) if h is not None and h.world > 1
+                      and _cdist._host_staged(h.group)]
+            if staged:                                   # gloo rehearsal: collectives go through host memory
+                self.use_graph = False
+                logging.getLogger("cdml.train").warning(
+                    "use_graph ignored: host-staged (gloo) collectives cannot be captured; RCCL ones can")
         # row-sharded catalogue: the exchange of step t+1 runs ahead on a side stream
         # into the second x_hat / idx buffer while step t computes
         self.prefetch = None
