@@ -1,4 +1,4 @@
-"""world_size-2 gloo (CPU) test of the multi-GPU plumbing in cdml_amd.dist: row
+"""world_size-2 and -8 gloo (CPU) tests of the multi-GPU plumbing in cdml_amd.dist: row
 routing over a row-sharded catalogue (all-to-all ids -> owner gather ->
 all-to-all rows -> unpermute) and the gradient average.  The owner-side gather
 is injected from the oracle here (the HIP kernel needs a GPU); everything else
@@ -81,7 +81,8 @@ def _worker(rank, world, port, n_rows, F, q):
         # routing: per-owner segments of `cap` slots, requests in ascending order, -1 padding
         ids = torch.tensor([per + 1, 0, per, 3, 2 * per - 1], dtype=torch.int32).clamp(max=n_rows - 1)
         send, slot = ex.route(ids, 4)
-        assert send.tolist() == [0, 3, -1, -1, per + 1, per, min(2 * per - 1, n_rows - 1), -1]
+        assert send.tolist()[:8] == [0, 3, -1, -1, per + 1, per, min(2 * per - 1, n_rows - 1), -1]
+        assert send.tolist()[8:] == [-1] * (4 * (world - 2))          # nothing for the other owners
         assert slot.tolist() == [4, 0, 5, 1, 6]
         # a segment that is too small raises the flag (and only then)
         ex.check_overflow()
@@ -95,7 +96,7 @@ def _worker(rank, world, port, n_rows, F, q):
         sync = cdist.GradSync()
         g = torch.full((10,), float(rank + 1))
         sync(g)
-        np.testing.assert_allclose(g.numpy(), (1 + 2) / 2)
+        np.testing.assert_allclose(g.numpy(), (world + 1) / 2)
         q.put((rank, "ok"))
     except Exception as e:                                             # surface in the parent
         import traceback
@@ -104,18 +105,28 @@ def _worker(rank, world, port, n_rows, F, q):
         dist.destroy_process_group()
 
 
-def test_row_exchange_and_grad_sync_world2():
+def _run(world, n_rows, F):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 101, 12, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rows, F, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_row_exchange_and_grad_sync_world2():
+    _run(2, 101, 12)
+
+
+def test_row_exchange_and_grad_sync_world8():
+    """The node's form (BASELINE configs 3/4): eight ranks, uneven shards (1003 rows -> 7 x 126 + 121),
+    every pair of ranks exchanging rows and row gradients, the 1/8 gradient average."""
+    _run(8, 1003, 12)
 
 
 def test_shard_bounds_cover_catalogue():
