@@ -75,8 +75,8 @@ k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m
 // Adam on a weight MATRIX W[K][N] (row-major, ld = N) that also writes the bf16 operand copies the
 // config-4 GEMMs read: W^T as bf16 [N][K] (wt, nullable) and W as bf16 [K][N] (wc, nullable) -- what
 // k_transpose_bf16 / k_cast_f32_bf16 would produce from the updated weights, without reading them
-// again.  One 64 x 64 tile per block: 16-B accesses on every fp32 stream, the transpose through LDS
-// (132-B rows: the 2-B column writes spread over the banks), whole 128-B lines on the bf16 rows.
+// again.  One 64 x 64 tile per block: 16-B accesses on every fp32 stream, the transpose through LDS,
+// whole 128-B lines on the bf16 rows.
 // Same arithmetic per element as k_adam (bit-equal).
 constexpr int kAT = 64;
 __global__ void __launch_bounds__(kThreads)
@@ -86,7 +86,7 @@ k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__
                    __bf16 *__restrict__ wt, int64_t ldt, __bf16 *__restrict__ wc, int64_t ldc) {
   using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
   __shared__ float s_lr_t;
-  __shared__ __attribute__((aligned(16))) __bf16 sT[kAT][kAT + 2];
+  __shared__ uint32_t sT[kAT][kAT / 2 + 1];           // [column n][row pair]: two bf16 of one column per word
   if (threadIdx.x == 0) {
     const double t = (double)t_imm + (t_dev ? (double)(*t_dev) : 0.0);
     const double lr = lr_dev ? (double)(*lr_dev) : (double)lr_imm;
@@ -98,39 +98,48 @@ k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__
   const int tiles_n = N / kAT;
   const int k0 = (blockIdx.x / tiles_n) * kAT, n0 = (blockIdx.x % tiles_n) * kAT;
   const int tr = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+  // a thread takes two adjacent rows of four columns per pass: the transpose goes through LDS as
+  // 32-bit words (the two rows' values of one column), 33-word rows -> at most 2-way bank conflicts
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int r = p * 16 + tr;
-    const int64_t i = (int64_t)(k0 + r) * N + n0 + c4;
-    float4 w4 = *reinterpret_cast<float4 *>(w + i);
-    const float4 g4 = *reinterpret_cast<const float4 *>(g + i);
-    float4 m4 = *reinterpret_cast<float4 *>(m + i);
-    float4 v4 = *reinterpret_cast<float4 *>(v + i);
+  for (int p = 0; p < 2; ++p) {
+    const int r = p * 32 + 2 * tr;
+    bf16x4 o[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int64_t i = (int64_t)(k0 + r + q) * N + n0 + c4;
+      float4 w4 = *reinterpret_cast<float4 *>(w + i);
+      const float4 g4 = *reinterpret_cast<const float4 *>(g + i);
+      float4 m4 = *reinterpret_cast<float4 *>(m + i);
+      float4 v4 = *reinterpret_cast<float4 *>(v + i);
 #define CDML_ADAM1(c)                              \
   m4.c += (g4.c - m4.c) * omb1;                    \
   v4.c += (g4.c * g4.c - v4.c) * omb2;             \
   w4.c -= (m4.c * lr_t) / (sqrtf(v4.c) + eps);
-    CDML_ADAM1(x) CDML_ADAM1(y) CDML_ADAM1(z) CDML_ADAM1(w)
+      CDML_ADAM1(x) CDML_ADAM1(y) CDML_ADAM1(z) CDML_ADAM1(w)
 #undef CDML_ADAM1
-    *reinterpret_cast<float4 *>(w + i) = w4;
-    *reinterpret_cast<float4 *>(m + i) = m4;
-    *reinterpret_cast<float4 *>(v + i) = v4;
-    bf16x4 o;
-    o.x = (__bf16)w4.x; o.y = (__bf16)w4.y; o.z = (__bf16)w4.z; o.w = (__bf16)w4.w;
-    if (wc) *reinterpret_cast<bf16x4 *>(wc + (int64_t)(k0 + r) * ldc + n0 + c4) = o;
-    sT[c4 + 0][r] = o.x; sT[c4 + 1][r] = o.y; sT[c4 + 2][r] = o.z; sT[c4 + 3][r] = o.w;
+      *reinterpret_cast<float4 *>(w + i) = w4;
+      *reinterpret_cast<float4 *>(m + i) = m4;
+      *reinterpret_cast<float4 *>(v + i) = v4;
+      o[q].x = (__bf16)w4.x; o[q].y = (__bf16)w4.y; o[q].z = (__bf16)w4.z; o[q].w = (__bf16)w4.w;
+      if (wc) *reinterpret_cast<bf16x4 *>(wc + (int64_t)(k0 + r + q) * ldc + n0 + c4) = o[q];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+      const bf16x2 pr = {o[0][u], o[1][u]};            // rows r (low half), r + 1 (high half)
+      sT[c4 + u][r >> 1] = __builtin_bit_cast(uint32_t, pr);
+    }
   }
   if (!wt) return;                                   // (uniform: no barrier is left behind)
   __syncthreads();
   // transposed tile: row n of W^T holds 64 consecutive k = 128 B; 8 threads x 16 B per row
-  const int sr = threadIdx.x >> 3, seg = (threadIdx.x & 7) * 8;
+  const int sr = threadIdx.x >> 3, seg = (threadIdx.x & 7) * 4;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int row = q * 32 + sr;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&sT[row][seg]);   // 132-B rows: 4-B aligned
     uint4 o;
-    o.x = src[0]; o.y = src[1]; o.z = src[2]; o.w = src[3];
-    *reinterpret_cast<uint4 *>(wt + (int64_t)(n0 + row) * ldt + k0 + seg) = o;
+    o.x = sT[row][seg]; o.y = sT[row][seg + 1]; o.z = sT[row][seg + 2]; o.w = sT[row][seg + 3];
+    *reinterpret_cast<uint4 *>(wt + (int64_t)(n0 + row) * ldt + k0 + seg * 2) = o;
   }
 }
 
