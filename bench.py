@@ -9,32 +9,52 @@ Workloads (BASELINE.json `configs`, 0-based):
                     batch 4096 triplets, in-batch negatives, margin 0.8, Adam.
   N > 1             config 3: 10 M videos row-sharded over the ranks, batch 8192 triplets per
                     GPU (65 536 global at N = 8), RCCL all-to-all of sampled rows + all-reduce of
-                    the gradients.  Weak scaling (per-GPU work fixed).
+                    the gradients.  Weak scaling (per-GPU work fixed).  Started WITHOUT a launcher
+                    (`python bench.py --gpus N`, no RANK in the environment) the command starts its
+                    own N ranks -- before anything touches the GPU -- and relays rank 0's line;
+                    under `python -m torch.distributed.run` it is one of the ranks.
   --precision bf16  config 4: fp16 table + bf16 MFMA, uniform (global) negatives, batch 8192 per
                     GPU on the 10 M catalogue; --graph replays the step from a hipGraph.
+  --mode predict    catalogue inference (predict.py:71-96): forward-only tower over the 10 M-row
+                    table in chunks, rows/s, fp32 and (--precision bf16) config-4 precision.
 
 Prints ONE JSON line (rank 0).  Beside the contract's fields:
   roofline       the dominant kernel (weight-gradient GEMM), timed live with events on the
                  launch stream inside the timed region; `traffic` from the committed PMC summary
+                 named in `traffic_source` (a builder-run rocprofv3 --pmc pass, not this run)
   gather         the HBM-bound fused sampler+gather: 10 launches per event pair (a pair around
                  one 20-40 us launch costs 10-25 % of it), same arguments as the timed steps
   cpu_baseline   BASELINE.md section 4: the CPU restatement of the reference step (oracle/
                  tower_torch.py) on config 0's 10k x 1500 table, B = 128 and 1024, 1 and all
                  threads, fetch / train split, on this box's host cores
-  like_for_like  (N = 1) the per-GPU workload of the N > 1 line on ONE GPU holding the whole
-                 10 M-row catalogue, so that 8-vs-1 compares one workload
-  data_learnable (N = 1) the same step on a learnable catalogue (co-watched videos share a
-                 cluster): the iid imitation_data features collapse the embeddings
-  comm           (N > 1) what the compute stream waits for: all-reduce and row exchange
-  order          what ran before the W warm-up steps: the first ~100 ms of MFMA work after an idle spell
-                 run ~2 % slower (clock ramp), so the default N = 1 line measures like_for_like and
-                 data_learnable first; the other lines run 0.3 s of GEMM launches on scratch buffers
+  comm           (N > 1) what the compute stream waits for: all-reduce and row exchange; which
+                 gradient-sync form ran (`grad_sync`: both forms are timed for a few steps before
+                 the warm-up and the faster one is kept)
+  order / warmup_effective   what ran on the GPU before the timed region
+Secondary records of the default N = 1 line (measured AFTER the headline; each in its own try):
+  like_for_like      the per-GPU workload of the N > 1 line on ONE GPU holding the whole 10 M-row
+                     catalogue, so that 8-vs-1 compares one workload
+  dp_form_one_gpu    that workload through the N > 1 step FORM (row exchange + gradient sync hooks
+                     over RCCL at world size 1, nothing skipped): each rank's compute floor at N = 8,
+                     for both gradient-sync forms
+  config4_per_gpu    BASELINE config 4's per-GPU workload (10 M-row fp16 table, bf16 MFMA, B = 8192
+                     uniform) with its own kernel timers, roofline and gather records
+  reference_recipe   the reference's own run (train.py:354-364): B = 1024, uniform negatives, LARS
+                     lr 1.0, margin 0.8 on the 1 M-row table
+  fusion_resnet      the reference's production tower (models.py:125-157) at feature_size 1628
+  predict            catalogue inference throughput (rows/s) over the 10 M-row table
+  data_learnable     the headline step on a learnable catalogue (co-watched videos share a
+                     cluster): the iid imitation_data features collapse the embeddings
 """
 import argparse
 import datetime
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -51,6 +71,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: BF16 MFMA dense (spec)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
+# ------------------------------------------------------------------ helpers ------
 def synth_pairs(n_videos, n_users, seed, lo=0):
     """imitation_data.py:56-85-shaped co-watch pairs (own generator, product side)."""
     rng = np.random.RandomState(seed)
@@ -62,6 +83,30 @@ def synth_pairs(n_videos, n_users, seed, lo=0):
     pairs = np.stack([vids[:-1][keep], vids[1:][keep]], axis=1)
     pairs = pairs[rng.permutation(len(pairs))]      # one global shuffle (parse_data.py:206), vectorised
     return (pairs + lo).astype(np.int32)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+_PHASE = {"name": "start"}
+
+
+def set_phase(name):
+    """Where this rank is: named in a failure message; mirrored to a file the self-launching
+    parent reads when a rank hangs."""
+    _PHASE["name"] = name
+    d = os.environ.get("CDML_BENCH_PHASE_DIR")
+    if d:
+        try:
+            with open(os.path.join(d, "rank%s" % os.environ.get("RANK", "0")), "w") as f:
+                f.write(name)
+        except OSError:
+            pass
 
 
 class KernelTimer:
@@ -106,12 +151,15 @@ class KernelTimer:
 
 
 def pmc_traffic(kernel, bf16=False):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary
-    (profiles/latest_pmc.csv, latest_pmc_bf16.csv for --precision bf16: separate FETCH_SIZE /
-    WRITE_SIZE passes of this bench, KiB; FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
-    path = os.path.join(ROOT, "profiles", "latest_pmc_bf16.csv" if bf16 else "latest_pmc.csv")
+    """(bytes, source): HBM-side bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC summary
+    (profiles/latest_pmc.csv, latest_pmc_bf16.csv for the config-4 path: separate FETCH_SIZE /
+    WRITE_SIZE passes of this bench, KiB; FETCH_SIZE doubled per the gfx950 correction) -- an earlier
+    builder-run profiling pass, not a measurement of this run; `source` says which file and from when
+    (profiles/latest_pmc.json, written by tools/profile_round.sh).  (None, None) if absent."""
+    name = "latest_pmc_bf16" if bf16 else "latest_pmc"
+    path = os.path.join(ROOT, "profiles", name + ".csv")
     if not os.path.exists(path):
-        return None
+        return None, None
     import csv
     vals = {}
     for r in csv.DictReader(open(path)):
@@ -119,8 +167,14 @@ def pmc_traffic(kernel, bf16=False):
         if r["kernel"] == kernel or (kernel.endswith(",") and r["kernel"].startswith(kernel)):
             vals[r["counter"]] = float(r["mean_per_launch"])
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        return None, None
+    src = "profiles/%s.csv (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run" % name
+    try:
+        meta = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json"))).get(name, {})
+        src += "; taken %s at commit %s" % (meta.get("date", "?"), meta.get("commit", "?"))
+    except (OSError, ValueError):
+        pass
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, src + ")"
 
 
 def usable_cores():
@@ -157,9 +211,9 @@ def cpu_baseline(full=False):
     (imitation_data.py:41-53, np.random.seed(0)), imitation_data-shaped pairs, the reference's
     uniform-negative rule -- at B = 128 (config 0) and B = 1024 (the reference's production
     batch, train.py:360), with 1 thread and with all threads, fetch vs train split like
-    train.py:314-323, median over the timed steps.  Bounded: each of the four runs stops at 50
-    timed steps or at its share of ~25 s, whichever comes first (--cpu-baseline-full: 50 steps
-    everywhere)."""
+    train.py:314-323, median over the timed steps.  Bounded (~25 s in all): each run stops at 50
+    timed steps or at its time share, whichever comes first -- the count is in `runs[].timed_steps`
+    and in `sample` (--cpu-baseline-full: 50 steps everywhere, minutes)."""
     from oracle import synth as osynth, tower_torch
     table = osynth.features_numpy(10000, F, seed=0).astype(np.float32)
     pairs = osynth.cowatch_pairs(10000, 3000, 0)
@@ -167,7 +221,7 @@ def cpu_baseline(full=False):
     prev = torch.get_num_threads()
     runs = []
     for threads, B, budget, warm in ((all_threads, 128, 3.0, 5), (all_threads, 1024, 6.0, 3),
-                                     (1, 128, 8.0, 2), (1, 1024, 8.0, 1)):
+                                     (1, 128, 6.0, 2), (1, 1024, 10.0, 1)):
         torch.set_num_threads(threads)
         st = tower_torch.CpuStep(table, pairs, B, hidden=H, out=D, margin=MARGIN, lr=0.01)
         tf, tt, n = tower_torch.time_steps(st, 50, 1e9 if full else budget, 10 if full else warm)
@@ -179,8 +233,11 @@ def cpu_baseline(full=False):
             "cpu": cpu_model(), "host_cpu_count": os.cpu_count(),
             "sample": "CPU restatement of the TF1 path (oracle/tower_torch.py: numpy gather + torch-CPU fp32 "
                       "tower/loss/backward/Adam), config-0 table 10000x1500, uniform negatives; value = B=1024 on "
-                      "%d threads, median of %d timed steps (fetch %.1f ms + train %.1f ms); all four runs in `runs`"
-                      % (all_threads, head["timed_steps"], head["fetch_ms"], head["train_ms"]),
+                      "%d threads, median of %d timed steps (fetch %.1f ms + train %.1f ms); timed steps of the four "
+                      "runs (threads x batch): %s -- each run is cut at its share of ~25 s, BASELINE.md's 50 only "
+                      "with --cpu-baseline-full"
+                      % (all_threads, head["timed_steps"], head["fetch_ms"], head["train_ms"],
+                         ", ".join("%dx%d: %d" % (r["threads"], r["batch"], r["timed_steps"]) for r in runs)),
             "runs": runs}
 
 
@@ -203,9 +260,8 @@ def learnable_catalogue(n_rows, dev, n_clusters=2000, seed=0):
 
 def settle_gpu(dev, seconds=0.3):
     """Weight-gradient GEMM launches on scratch buffers for ~`seconds`: the first ~100 ms of MFMA work after an
-    idle spell run ~2 % slower on this part (clock ramp), and the default N = 1 line gets past that through
-    its secondary measurements; every other line gets the same start through this loop.  Not a step of the
-    measured job: no state of the TrainStep is touched."""
+    idle spell run ~2 % slower on this part (clock ramp).  Not a step of the measured job: no state of the
+    TrainStep is touched; disclosed in `order` / `warmup_effective`."""
     from cdml_amd import ops
     M, K, N = 4096, 1536, 5120
     # the split-K weight-gradient entry point: an MFMA-bound launch that is NOT part of the N = 1 step
@@ -233,36 +289,446 @@ def timed_steps(ts, steps, warmup, dev):
     return time.perf_counter() - t0
 
 
+# ------------------------------------------------- kernel timers and their records ------
+def install_timers(kt, L, bf16):
+    """Wrap the step's GEMM / tail / optimizer entry points of cdml_amd.ops with event pairs (active
+    while kt.on).  Returns the function that puts the originals back."""
+    from cdml_amd import ops
+    real = {}
+
+    def patch(name, label):
+        if hasattr(ops, name):
+            real[name] = getattr(ops, name)
+            setattr(ops, name, kt.wrap(label, real[name]))
+    if bf16:
+        # gemm_bf16_nt(epilogue, A, B, C, M, N, K, ...): FC1 has N = Hp, K = Fp; FC2 N = Dp; dH1 K = Dp
+        patch("gemm_bf16_nt", lambda e, A, Bm, C, M, N, K, **k:
+              "fc1_fwd" if (N == L.Hp and K == L.Fp) else ("fc2_fwd" if N == L.Dp else "dH1"))
+        # gemm_bf16_tn(A, B, C, M, N, K, ...): dW1 has N = Hp
+        patch("gemm_bf16_tn", lambda A, Bm, C, M, N, K, **k: "dW1" if N == L.Hp else "dW2")
+        patch("gemm_bf16_tn2", "dW")                   # both weight gradients in one launch
+        # matrices (with their bf16 operand copies), then the biases
+        patch("adam_matrix_bf16", lambda W, *a, **k: "adam_w1" if W.shape[0] == L.Fp else "adam_w2")
+        patch("adam_step", "adam_bias")
+    else:
+        patch("fc_lrelu_fwd", lambda x, W, b, y, M, K, N, *a, **k: "fc1_fwd" if N == L.Hp else "fc2_fwd")
+        patch("fc_bwd_weight", lambda x, dy, dW, db, ws, M, K, N: "dW1" if N == L.Hp else "dW2")
+        patch("fc_bwd_weight2", "dW")             # single GPU: both products in one stream-K launch
+        patch("fc_bwd_data", "dH1")
+        patch("adam_step", "adam")
+        patch("lars_step", "lars")
+        patch("lars_multi", "lars")
+    patch("vnet_tail", "tail")
+
+    def restore():
+        for name, fn in real.items():
+            setattr(ops, name, fn)
+    return restore
+
+
+def gemm_records(kt, R, bf16, sampled, how, single_gpu):
+    """roofline (dominant kernel: the weight-gradient GEMM), roofline_fc1_fwd, kernels -- from the
+    event-timed launches.  Algorithmic (unpadded) flop: dW1 2*R*F*H, dW2 2*R*H*D."""
+    out = {}
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    have_dw = kt.count("dW") or (kt.count("dW1") and kt.count("dW2"))
+    if not (have_dw and kt.count("fc1_fwd")):
+        return out
+    flops_gemm = 2.0 * R * F * H
+    if kt.count("dW"):                          # dW1 and dW2 (+ the fix-up pass) in one call
+        n_launch, t_ms = kt.count("dW"), kt.mean_ms("dW")
+        if bf16:
+            kname, klabel = "k_gemm_bf16_sk", "k_gemm_bf16_sk (dW1+dW2 in one launch, fix-up pass included)"
+        else:
+            kname, klabel = "k_gemm_f32_sk", "k_gemm_f32_sk (dW1+dW2 in one stream-K launch, fix-up pass included)"
+    else:
+        kname = "k_gemm_bf16_256<true, 3>" if bf16 else "k_gemm_f32<false, false, 2, 2, 3,"
+        n_launch = kt.count("dW1") + kt.count("dW2")
+        t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
+        klabel = kname + (" ...> (dW1+dW2 launches)" if not bf16 else " (dW1+dW2 launches)")
+    flop_launch = sampled * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
+    ach = flop_launch / (t_ms * 1e-3) / 1e12
+    tr, src = pmc_traffic(kname, bf16) if single_gpu else (None, None)
+    out["roofline"] = {"bound": "mfma", "kernel": klabel, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                       "frac": round(ach / peak, 4), "traffic": tr, "traffic_source": src,
+                       "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch,
+                       "launches_per_step": n_launch / sampled, "timed_steps": sampled, "timed_how": how}
+    ach1 = flops_gemm / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
+    k1 = "k_gemm_bf16_256<false, 0>" if bf16 else "k_gemm_f32<true, false, 2, 2, 1,"
+    tr1, src1 = pmc_traffic(k1, bf16) if single_gpu else (None, None)
+    out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": k1 + ("" if bf16 else " ...>"),
+                               "achieved": round(ach1, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach1 / peak, 4), "traffic": tr1, "traffic_source": src1,
+                               "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": flops_gemm}
+    kern = {}
+    for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "adam", "adam_w1", "adam_w2", "adam_bias", "lars"):
+        if kt.mean_ms(k) is not None:
+            kern[k + "_ms"] = round(kt.mean_ms(k), 4)
+            if kt.count(k) != sampled:
+                kern[k + "_launches_per_step"] = round(kt.count(k) / sampled, 2)
+    kern["empty_event_pair_ms"] = round(kt.overhead_ms, 5)      # included in the figures above
+    out["kernels"] = kern
+    return out
+
+
+def gather_record(ts, mode, bf16, dev):
+    """The HBM-bound kernel the metric also names: the fused sampler+gather (fp32 rows, or fp16 -> bf16
+    rows on the config-4 path), 10 back-to-back launches per event pair, fresh steps every launch."""
+    from cdml_amd import ops, train
+    reps, per = 5, 10
+    n_st, rpt, B = ts.gather_ahead, ts.rows_per_triplet, ts.B
+    R = B * rpt
+    m = train._MODES[mode]
+    gk = "k_sample_gather<%d," % (1 if rpt == 2 else 0)       # <mode, RowF32<6>> / <mode, RowF16<3>>
+    gbytes = n_st * R * F * (2 + 2.0) if bf16 else n_st * 2.0 * R * F * 4     # rows read + normalised rows written
+    nxt = [ts.global_step + 1000]                   # fresh steps every launch: re-reading the same rows
+                                                    # would be served from the 256 MB Infinity Cache
+
+    def launch():                                   # (training on `ts` is over: its buffers are scratch now)
+        if n_st > 1:
+            ts._gather_block(nxt[0])
+        else:
+            ops.sample_gather(m, ts.pairs, ts.seed, nxt[0], B, ts.table.data, F, ts.idx, ts.ws.x_hat,
+                              shift_out=ts.shift)
+        nxt[0] += n_st
+    for _ in range(3):
+        launch()
+    evs = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(per):
+            launch()
+        e.record()
+        evs.append((s, e))
+    torch.cuda.synchronize(dev)
+    t_g = float(np.median([s.elapsed_time(e) for s, e in evs])) / per
+    g_ach = gbytes / (t_g * 1e-3) / 1e9
+    tr, src = pmc_traffic(gk, bf16)
+    return {"bound": "hbm", "kernel": gk + (" RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1),
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": tr,
+            "traffic_source": src, "bytes_per_launch": gbytes, "launch_ms": round(t_g, 4), "steps_per_launch": n_st,
+            "method": "%d back-to-back launches per event pair (inter-launch gaps included), median of %d" % (per, reps)}
+
+
+def measure_job(ts, steps, warmup, dev, bf16, timers=True, barrier=None):
+    """W warm-up steps, then EXACTLY `steps` timed steps bracketed by (barrier +) synchronize on both
+    sides; kernel timers on every 4th timed step (every 8th in long runs): an event pair costs the
+    stream ~5 us, seven pairs a step are 1.5 % of it; the sampled launches are launches of the timed
+    region.  Under graph replay the timers run on 8 extra EAGER steps after it.  Returns
+    (elapsed_s, KernelTimer, sampled_steps, how)."""
+    kt = KernelTimer()
+    restore = install_timers(kt, ts.layout, bf16) if timers else (lambda: None)
+    graph_run = ts.use_graph
+    try:
+        for _ in range(warmup):
+            ts.step()
+        torch.cuda.synchronize(dev)
+        if barrier:
+            barrier()
+            torch.cuda.synchronize(dev)
+        set_phase("timed steps")
+        stride = 4 if steps < 100 else 8
+        t0 = time.perf_counter()
+        for i in range(steps):
+            kt.on = timers and not graph_run and (i % stride == 0)
+            ts.step()
+        torch.cuda.synchronize(dev)
+        if barrier:
+            barrier()
+            torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        kt.on = False
+        sampled = (steps + stride - 1) // stride
+        how = "event pairs on every %dth timed step" % stride
+        if graph_run and timers:                     # same kernels, launched eagerly, for the roofline
+            ts.use_graph = False
+            sampled = 8
+            for i in range(2 * sampled):
+                kt.on = i % 2 == 0
+                ts.step()
+            torch.cuda.synchronize(dev)
+            kt.on = False
+            ts.use_graph = True
+            how = "event pairs on 8 eager steps after the graph-replayed timed region"
+    finally:
+        kt.on = False
+        restore()
+    if timers:
+        kt.calibrate()
+    return elapsed, kt, sampled, how
+
+
+# ------------------------------------------------------- self-launch (no launcher) ------
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher in the environment: start N ranks of this same
+    command (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; one process per GPU), relay rank 0's
+    JSON line, exit non-zero naming the rank and its phase if a rank fails or the run exceeds
+    CDML_BENCH_TIMEOUT_S.  This parent never touches the GPU."""
+    n = args.gpus
+    port = free_port()
+    phase_dir = tempfile.mkdtemp(prefix="cdml_bench_")
+    limit = float(os.environ.get("CDML_BENCH_TIMEOUT_S", "1500"))
+    procs, lines = [], []
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CDML_BENCH_PHASE_DIR=phase_dir)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+        procs.append(subprocess.Popen(cmd, env=env, cwd=os.getcwd(), stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      text=(r == 0)))
+
+    def pump():
+        for ln in procs[0].stdout:
+            lines.append(ln.rstrip("\n"))
+    reader = threading.Thread(target=pump, daemon=True)
+    reader.start()
+
+    def phases():
+        out = []
+        for r in range(n):
+            try:
+                out.append("rank %d: %s" % (r, open(os.path.join(phase_dir, "rank%d" % r)).read()))
+            except OSError:
+                out.append("rank %d: (not started)" % r)
+        return "; ".join(out)
+
+    t0, failed = time.time(), None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = "rank %d exited with code %d" % bad[0]
+        elif all(c == 0 for c in codes):
+            break
+        elif time.time() - t0 > limit:
+            failed = "no result within %.0f s (CDML_BENCH_TIMEOUT_S)" % limit
+        else:
+            time.sleep(0.25)
+    if failed:
+        where = phases()
+        for p in procs:                               # these exact children, by handle
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+        sys.stderr.write("[bench] %d-rank run failed: %s [%s]\n" % (n, failed, where))
+        sys.exit(1)
+    reader.join(timeout=30)
+    js = [ln for ln in lines if ln.startswith("{")]
+    for ln in lines:
+        if not ln.startswith("{"):
+            sys.stderr.write(ln + "\n")
+    if len(js) != 1:
+        sys.stderr.write("[bench] rank 0 printed %d JSON lines (expected 1)\n" % len(js))
+        sys.exit(1)
+    print(js[0], flush=True)
+    sys.exit(0)
+
+
+# ------------------------------------------------------------ secondary records ------
+def table_10m(keep, dev):
+    """The 10 M-row fp32 catalogue (61 GB), shared by like_for_like and dp_form_one_gpu."""
+    from cdml_amd import engine
+    if "t10" not in keep:
+        keep["t10"] = engine.FeatureTable.synthetic(10000000, F, seed=0, device=dev)
+        keep["p10"] = torch.from_numpy(synth_pairs(10000000, 600000, seed=0)).to(dev)
+    return keep["t10"], keep["p10"]
+
+
+def rec_like_for_like(dev, args, n_s, n_w, keep):
+    from cdml_amd import train
+    t10, p10 = table_10m(keep, dev)
+    ts10 = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
+                           optimizer="adam", base_learning_rate=0.01, device=dev, gather_ahead=args.gather_ahead)
+    el = timed_steps(ts10, n_s, n_w, dev)
+    return {"workload": "config3 per-GPU batch on ONE GPU: 10000000 videos x 1500-d fp32 (61 GB) in HBM, batch 8192 "
+                        "triplets, in-batch negatives (the N>1 lines run this per GPU on a row-sharded catalogue)",
+            "value": round(8192 * n_s / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n_s * 1e3, 4),
+            "steps": n_s, "warmup": n_w}
+
+
+def rec_dp_form(dev, args, n_s, n_w, keep):
+    """config 3's per-GPU workload through the N > 1 step FORM on one GPU: row exchange (routing kernel,
+    two equal-split all-to-alls on their own communicator, un-permute) on the prefetch stream and the
+    gradient sync over RCCL at world size 1, nothing skipped -- the collectives are self-copies, so this
+    is each rank's COMPUTE floor at N = 8 (plus RCCL's launch costs), for both gradient-sync forms."""
+    import torch.distributed as dist
+    from cdml_amd import dist as cdist, train
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1,
+                                device_id=dev, timeout=datetime.timedelta(seconds=120))
+    try:
+        t10, p10 = table_10m(keep, dev)
+        ex = cdist.RowExchange(10000000, group=dist.new_group(), skip_self=False)
+        gs = cdist.GradSync(device=dev, skip_self=False)
+        out = {"workload": "like_for_like's workload as TrainStep(exchange=RowExchange(skip_self=False), "
+                           "grad_sync=GradSync(skip_self=False)) over RCCL at world size 1 (self-copies): the "
+                           "per-rank compute floor of the N>1 step form; exchange capacity = all requests at "
+                           "world 1 (1.39 x padded at world 8)",
+               "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())}
+        for form in ("bucketed", "single"):
+            ts = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
+                                 optimizer="adam", base_learning_rate=0.01, device=dev, exchange=ex, grad_sync=gs,
+                                 batch_global=8192, grad_sync_mode=form)
+            el = timed_steps(ts, n_s, n_w, dev)
+            ts.check_inputs()
+            out[form] = {"ms_per_step": round(el / n_s * 1e3, 4), "triplets_per_s": round(8192 * n_s / el, 1),
+                         "form": "dW1 in two split-K row blocks + dW2, all-reduce per bucket under the next GEMM"
+                                 if form == "bucketed" else "one stream-K launch for dW1+dW2, then ONE all-reduce"}
+            del ts
+        out["steps"], out["warmup"] = n_s, n_w
+        return out
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
+def rec_config4(dev, args, n_s, n_w):
+    from cdml_amd import engine_bf16, train
+    t = engine_bf16.FeatureTableF16.synthetic(10000000, F, seed=0, device=dev)
+    p = torch.from_numpy(synth_pairs(10000000, 600000, seed=0)).to(dev)
+    ts = train.TrainStep(t, p, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="uniform", optimizer="adam",
+                         base_learning_rate=0.01, device=dev, precision="bf16", gather_ahead=args.gather_ahead)
+    n_s, n_w = max(n_s, 100), max(n_w, 10)           # a 1.1-ms step: 20 of them would time the clock ramp
+    el, kt, sampled, how = measure_job(ts, n_s, n_w, dev, True)
+    ts.check_inputs()
+    out = {"workload": "config4 per-GPU shape on ONE GPU: 10000000 videos x 1500-d fp16 (30.7 GB) in HBM, bf16 MFMA "
+                       "tower (f32 accumulate, fp32 master weights), batch 8192 triplets, uniform (global) negatives, Adam",
+           "value": round(8192 * n_s / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n_s * 1e3, 4),
+           "steps": n_s, "warmup": n_w, "dtype": "bf16 (fp16 table, f32 accumulate)", "loss": round(ts.loss(), 6)}
+    out.update(gemm_records(kt, ts.R, True, sampled, how, True))
+    out["gather"] = gather_record(ts, "uniform", True, dev)
+    return out
+
+
+def rec_reference_recipe(dev, args, n_s, n_w, table):
+    """The reference's own run (train.py:354-364): batch 1024, uniform negatives with rejection, LARS
+    (tf.contrib defaults) at learning rate 1.0, margin 0.8 -- on the 1 M-row table."""
+    from cdml_amd import train
+    pairs = torch.from_numpy(synth_pairs(table.n_rows, 300000, seed=0)).to(dev)
+    ts = train.TrainStep(table, pairs, 1024, output_size=D, hidden_size=H, margin=MARGIN, mode="uniform",
+                         optimizer="lars", base_learning_rate=1.0, device=dev, gather_ahead=args.gather_ahead)
+    n = max(n_s, 60)
+    el, kt, sampled, how = measure_job(ts, n, max(n_w, 5), dev, False)
+    out = {"workload": "reference recipe (train.py:354-364): %d videos x 1500-d fp32, batch 1024 triplets (3072 rows), "
+                       "uniform negatives, LARS lr 1.0, margin 0.8, full step" % table.n_rows,
+           "value": round(1024 * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4), "steps": n,
+           "loss": round(ts.loss(), 6)}
+    out.update(gemm_records(kt, ts.R, False, sampled, how, False))
+    return out
+
+
+def rec_fusion(dev, args, n_s, n_w):
+    """The reference's production tower (ResNet, models.py:125-157) at feature_size 1628 = 1500 visual +
+    128 doc (online_data.py:38): batch 1024 uniform triplets, Adam."""
+    from cdml_amd import engine, fusion
+    n_rows = 1000000
+    table = engine.FeatureTable.synthetic(n_rows, 1628, seed=0, device=dev)
+    pairs = torch.from_numpy(synth_pairs(n_rows, 300000, seed=0)).to(dev)
+    ts = fusion.FusionTrainStep("ResNet", table, pairs, 1024, device=dev)
+    n = max(n_s, 40)
+    el = timed_steps(ts, n, max(n_w, 5), dev)
+    return {"workload": "ResNet fusion tower (models.py:125-157): %d videos x 1628-d fp32, batch 1024 uniform triplets "
+                        "(3072 rows), Adam, full step" % n_rows,
+            "value": round(1024 * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4), "steps": n,
+            "loss": round(ts.loss(), 6)}
+
+
+def rec_predict(dev, precision, n_rows=10000000, chunk=100000, reps=2):
+    """Catalogue inference (predict.py:71-96; the reference's chunk is 100 000 rows, predict.py:146):
+    forward-only tower over every row of the HBM-resident table, embeddings left in HBM.  Algorithmic
+    work per row: 2*F*H + 2*H*D flop; F*s bytes read + D*4 written."""
+    from cdml_amd import engine, engine_bf16, predict
+    bf16 = precision == "bf16"
+    Table = engine_bf16.FeatureTableF16 if bf16 else engine.FeatureTable
+    table = Table.synthetic(n_rows, F, seed=0, device=dev)
+    L = (engine_bf16.layout_bf16 if bf16 else engine.TowerLayout)(F, H, D)
+    pr = predict.Prediction(params=engine.VNetParams(L, dev, 42), precision=precision)
+    out = torch.empty((n_rows, D), dtype=torch.float32, device=dev)
+    pr.embed_table(table, chunk, out=out)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pr.embed_table(table, chunk, out=out)
+    torch.cuda.synchronize(dev)
+    el = (time.perf_counter() - t0) / reps
+    nrm = float((out[::9973].norm(dim=1) - 1).abs().max())
+    flops = n_rows * (2.0 * F * H + 2.0 * H * D)
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    return {"workload": "catalogue inference: %d videos x 1500-d %s in HBM -> 256-d unit-norm embeddings in HBM, "
+                        "%d-row chunks (l2norm + FC1 + FC2 + l2norm)" % (n_rows, "fp16" if bf16 else "fp32", chunk),
+            "value": round(n_rows / el, 1), "unit": "rows/s", "seconds": round(el, 4), "passes_timed": reps,
+            "tower_tflops": round(flops / el / 1e12, 2), "frac_of_mfma_peak": round(flops / el / 1e12 / peak, 4),
+            "max_abs_norm_error": nrm, "dtype": "bf16 (fp16 table, f32 accumulate)" if bf16 else "f32"}
+
+
+def rec_learnable(dev, args, n_s, n_w, B):
+    from cdml_amd import train
+    tl, pl = learnable_catalogue(200000, dev)
+    tsl = train.TrainStep(tl, pl, B, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
+                          optimizer="adam", base_learning_rate=2e-4, device=dev, gather_ahead=args.gather_ahead)
+    tsl.step()
+    l0 = tsl.loss()
+    n_l = max(n_s, 60)
+    el = timed_steps(tsl, n_l, n_w, dev)
+    return {"workload": "config1 step (batch %d in-batch) on a learnable 200000 x 1500 catalogue "
+                        "(co-watched videos share one of 2000 clusters), Adam 2e-4" % B,
+            "value": round(B * n_l / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n_l * 1e3, 4),
+            "steps": n_l, "loss_first_step": round(l0, 4), "loss_last_step": round(tsl.loss(), 4)}
+
+
+# ------------------------------------------------------------------------ main ------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=None, help="catalogue rows (default: 1M at N=1 fp32, else 10M)")
-    ap.add_argument("--mode", default=None, choices=["inbatch", "uniform", "semihard"])
+    ap.add_argument("--mode", default=None, choices=["inbatch", "uniform", "semihard", "predict"])
     ap.add_argument("--batch", type=int, default=None, help="triplets per GPU per step (default 4096 for config 1, else 8192)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="bf16 = BASELINE config 4 path (fp16 table + bf16 MFMA); not the headline metric")
     ap.add_argument("--train-table", action="store_true",
                     help="also train the catalogue rows (lazy Adam; build-defined, not the headline metric)")
-    ap.add_argument("--gather-ahead", type=int, default=4, help="steps fetched per sampler+gather launch (1 GPU, fp32)")
+    ap.add_argument("--gather-ahead", type=int, default=4, help="steps fetched per sampler+gather launch (1 GPU)")
+    ap.add_argument("--grad-sync", default="auto", choices=["auto", "bucketed", "single"],
+                    help="N>1: how the gradient all-reduce is issued (auto: both forms are timed for 5 steps "
+                         "before the warm-up, the faster one is kept)")
+    ap.add_argument("--capacity-factor", type=float, default=1.25,
+                    help="N>1: headroom of the fixed-capacity row exchange over the mean share per peer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="50 timed CPU steps in all four runs (minutes)")
     ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip like_for_like and data_learnable")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary records of the default N=1 line")
+    ap.add_argument("--extras", default=None,
+                    help="comma list of secondary records to run (default: all): like_for_like,dp_form_one_gpu,"
+                         "config4_per_gpu,reference_recipe,fusion_resnet,predict,data_learnable")
     ap.add_argument("--no-settle", action="store_true",
                     help="skip the 0.3 s GEMM loop before the warm-up steps (rocprof runs: keeps its launches out of the kernel averages)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    launched = "RANK" in os.environ and world >= 1
+    if args.gpus > 1 and not launched:
+        self_launch(args)                                # never returns
+    world = max(world, 1) if launched else 1
+    # ONE line on stdout: libraries write there too (RCCL prints a version banner when a communicator
+    # comes up), so from here on file descriptor 1 is stderr and the JSON line goes to the saved one
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                     "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
         sys.exit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    set_phase("start")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback)")
     backend = os.environ.get("CDML_DIST_BACKEND", "nccl")     # "gloo": 1-GPU-box rehearsal of N>1
@@ -271,12 +737,27 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    from cdml_amd import dist as cdist, engine, engine_bf16, ops, train
+    from cdml_amd import dist as cdist, engine, engine_bf16, train
     bf16 = args.precision == "bf16"
     Table = engine_bf16.FeatureTableF16 if bf16 else engine.FeatureTable
 
+    if args.mode == "predict":                           # catalogue inference throughput (N = 1)
+        if world != 1:
+            sys.exit("--mode predict is a one-GPU measurement")
+        set_phase("predict")
+        if not args.no_settle:
+            settle_gpu(dev)
+        r = rec_predict(dev, args.precision, n_rows=args.rows or 10000000)
+        out = {"metric": "catalogue rows embedded/sec", "value": r["value"], "unit": "rows/s", "n_gpus": 1,
+               "steps": r["passes_timed"], "warmup": 1, "ms_per_step": round(r["seconds"] * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": r["dtype"], "data": "synthetic",
+               "config": {"workload": r["workload"]}, "predict": r}
+        print(json.dumps(out), file=result_out, flush=True)
+        return
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        set_phase("init_process_group")
         # a finite timeout: a stuck collective ends the run with a non-zero exit instead of hanging
         tmo = datetime.timedelta(seconds=int(os.environ.get("CDML_DIST_TIMEOUT_S", "180")))
         if backend == "nccl":
@@ -288,19 +769,22 @@ def main():
     n_rows = args.rows or (1000000 if config1 else 10000000)
     B = args.batch or (4096 if config1 else 8192)
     mode = args.mode or ("uniform" if bf16 else "inbatch")
-    phase = "setup"
+    set_phase("setup")
+    probe = None
     try:
         if world > 1:
             lo, hi, _ = cdist.shard_bounds(n_rows, world, rank)
             table = Table.synthetic(hi - lo, F, seed=0, device=dev, row0=lo, n_rows_global=n_rows)
             # own communicator for the exchange so it never queues behind the gradient all-reduce
             ex_group = dist.new_group()
-            exchange, grad_sync = cdist.RowExchange(n_rows, group=ex_group), cdist.GradSync(device=dev)
+            exchange = cdist.RowExchange(n_rows, group=ex_group, capacity_factor=args.capacity_factor)
+            grad_sync = cdist.GradSync(device=dev)
             # bring both communicators up here (RCCL builds them on first use), not inside a step
-            phase = "communicator warm-up"
+            set_phase("communicator warm-up")
             warm = torch.zeros(1, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(warm)
             dist.all_reduce(warm, group=ex_group)
+            set_phase("setup")
         else:
             table = Table.synthetic(n_rows, F, seed=0, device=dev)
             exchange = grad_sync = None
@@ -312,139 +796,62 @@ def main():
                              optimizer="adam", base_learning_rate=0.01, seed=1234, weight_seed=42,
                              device=dev, exchange=exchange, grad_sync=grad_sync, slot0=rank * B,
                              batch_global=world * B, use_graph=args.graph, precision=args.precision,
-                             train_table=args.train_table, gather_ahead=args.gather_ahead)
-        L = ts.layout
-
-        # per-kernel event timers on the launch stream (off during graph replay)
-        kt = KernelTimer()
+                             train_table=args.train_table, gather_ahead=args.gather_ahead,
+                             grad_sync_mode="bucketed" if args.grad_sync == "auto" else args.grad_sync)
         timers_on = not args.no_kernel_timers
-        graph_run = ts.use_graph                        # timed region replays the graph; the per-kernel
-                                                        # event timers then run on extra EAGER steps after it
-        real = {}
-        if timers_on:
-            def patch(name, label):
-                real[name] = getattr(ops, name)
-                setattr(ops, name, kt.wrap(label, real[name]))
-            if bf16:
-                # gemm_bf16_nt(epilogue, A, B, C, M, N, K, ...): FC1 has N = Hp, K = Fp; FC2 N = Dp; dH1 K = Dp
-                patch("gemm_bf16_nt", lambda e, A, Bm, C, M, N, K, **k:
-                      "fc1_fwd" if (N == L.Hp and K == L.Fp) else ("fc2_fwd" if N == L.Dp else "dH1"))
-                # gemm_bf16_tn(A, B, C, M, N, K, ...): dW1 has N = Hp
-                patch("gemm_bf16_tn", lambda A, Bm, C, M, N, K, **k: "dW1" if N == L.Hp else "dW2")
-            else:
-                patch("fc_lrelu_fwd", lambda x, W, b, y, M, K, N, *a, **k: "fc1_fwd" if N == L.Hp else "fc2_fwd")
-                patch("fc_bwd_weight", lambda x, dy, dW, db, ws, M, K, N: "dW1" if N == L.Hp else "dW2")
-                patch("fc_bwd_weight2", "dW")             # single GPU: both products in one stream-K launch
-                patch("fc_bwd_data", "dH1")
-            if bf16:                                      # matrices (with their bf16 operand copies), then the biases
-                patch("adam_matrix_bf16", lambda W, *a, **k: "adam_w1" if W.shape[0] == L.Fp else "adam_w2")
-                patch("adam_step", "adam_bias")
-            else:
-                patch("adam_step", "adam")
-            patch("vnet_tail", "tail")
-        comm = {}
-        if world > 1:                                   # what the compute stream waits for
-            real_finish = grad_sync.finish
-            grad_sync.finish = kt.wrap("allreduce_wait", real_finish)
-            if ts.prefetch is not None:
-                ts.prefetch.acquire = kt.wrap("exchange_wait", ts.prefetch.acquire)
 
-        def sync_all():
-            torch.cuda.synchronize(dev)
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize(dev)
+        def barrier():
+            dist.barrier()
 
         def reduce_max(x):
             t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
 
-        extras = {}
-        # The two secondary measurements run BEFORE the headline: the first ~100 ms of MFMA work after an
-        # idle spell run ~2 % slower (measured: --warmup 5 -> 2.51 ms/step, --warmup 100 -> 2.478), so the
-        # headline's W warm-up + K timed steps follow them back to back, at the clocks a real run sees.
-        if config1 and mode == "inbatch" and not args.no_extras and not args.train_table and rank == 0:
-            phase = "secondary measurements"
-            try:                                        # their failure must not cost the headline
-                n_s, n_w = min(args.steps, 30), min(max(args.warmup, 3), 5)
-                # (b) the N > 1 line's per-GPU workload, whole 10 M-row catalogue on this one GPU
-                t10 = Table.synthetic(10000000, F, seed=0, device=dev)
-                p10 = torch.from_numpy(synth_pairs(10000000, 600000, seed=0)).to(dev)
-                ts10 = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
-                                       optimizer="adam", base_learning_rate=0.01, device=dev, gather_ahead=args.gather_ahead)
-                el = timed_steps(ts10, n_s, n_w, dev)
-                extras["like_for_like"] = {"workload": "config3 per-GPU batch on ONE GPU: 10000000 videos x 1500-d fp32 (61 GB) in "
-                                                    "HBM, batch 8192 triplets, in-batch negatives (the N>1 lines run this per GPU "
-                                                    "on a row-sharded catalogue)",
-                                        "value": round(8192 * n_s / el, 1), "unit": "triplets/s",
-                                        "ms_per_step": round(el / n_s * 1e3, 4), "steps": n_s, "warmup": n_w}
-                del ts10, t10, p10
-                torch.cuda.empty_cache()
-                # (c) the headline step on a learnable catalogue
-                tl, pl = learnable_catalogue(200000, dev)
-                tsl = train.TrainStep(tl, pl, B, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
-                                      optimizer="adam", base_learning_rate=2e-4, device=dev, gather_ahead=args.gather_ahead)
-                tsl.step()
-                l0 = tsl.loss()
-                n_l = max(n_s, 60)
-                el = timed_steps(tsl, n_l, n_w, dev)
-                extras["data_learnable"] = {"workload": "config1 step (batch %d in-batch) on a learnable 200000 x 1500 catalogue "
-                                                     "(co-watched videos share one of 2000 clusters), Adam 2e-4" % B,
-                                         "value": round(B * n_l / el, 1), "unit": "triplets/s",
-                                         "ms_per_step": round(el / n_l * 1e3, 4), "steps": n_l,
-                                         "loss_first_step": round(l0, 4), "loss_last_step": round(tsl.loss(), 4)}
-                del tsl, tl, pl
-                torch.cuda.empty_cache()
-            except Exception as e:                      # noqa: BLE001
-                extras.setdefault("secondary_error", repr(e)[:300])
-                ts10 = t10 = p10 = tsl = tl = pl = None
-                torch.cuda.empty_cache()
-        if not (extras.get("like_for_like") or extras.get("data_learnable")) and not args.no_settle:
-            phase = "clock settle"
+        pre_steps = 0
+        if not args.no_settle:
+            set_phase("clock settle")
             settle_gpu(dev)
-        phase = "warm-up steps"
-        for _ in range(args.warmup):
-            ts.step()
-        sync_all()
-        phase = "timed steps"
-        # kernel timers on every 4th timed step (every 8th in long runs): an event pair costs the
-        # stream ~5 us, seven pairs a step are 1.5 % of it; the sampled launches are still launches
-        # of the timed region
-        stride = 4 if args.steps < 100 else 8
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            kt.on = timers_on and not graph_run and (i % stride == 0)
-            ts.step()
-        torch.cuda.synchronize(dev)
+        if world > 1 and args.grad_sync == "auto" and not args.train_table:
+            # which gradient-sync form is faster HERE (link speed against kernel speed): a few steps of
+            # each, max over ranks (so every rank picks the same one), before the warm-up steps
+            set_phase("grad-sync probe")
+            probe = {}
+            for form in ("bucketed", "single"):
+                ts.grad_sync_mode = form
+                for _ in range(2):
+                    ts.step()
+                torch.cuda.synchronize(dev)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    ts.step()
+                torch.cuda.synchronize(dev)
+                barrier()
+                probe[form + "_ms_per_step"] = round(reduce_max(time.perf_counter() - t0) / 5 * 1e3, 4)
+                pre_steps += 7
+            ts.grad_sync_mode = "single" if probe["single_ms_per_step"] < probe["bucketed_ms_per_step"] else "bucketed"
+            probe["picked"] = ts.grad_sync_mode
+        set_phase("warm-up steps")
+        comm_kt = None
+        if world > 1:                                   # what the compute stream waits for
+            comm_kt = KernelTimer()
+            grad_sync.finish = comm_kt.wrap("allreduce_wait", grad_sync.finish)
+            if ts.prefetch is not None:
+                ts.prefetch.acquire = comm_kt.wrap("exchange_wait", ts.prefetch.acquire)
+            comm_kt.on = True
+        elapsed, kt, sampled, how = measure_job(ts, args.steps, args.warmup, dev, bf16, timers_on,
+                                                barrier if world > 1 else None)
+        if comm_kt is not None:
+            comm_kt.on = False
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        elapsed = time.perf_counter() - t0
-        kt.on = False
-        sampled = (args.steps + stride - 1) // stride
-        if graph_run and timers_on:                     # same kernels, launched eagerly, for the roofline
-            ts.use_graph = False
-            sampled = 8
-            for i in range(2 * sampled):
-                kt.on = i % 2 == 0
-                ts.step()
-            torch.cuda.synchronize(dev)
-            kt.on = False
-            ts.use_graph = True
-        for name, fn in real.items():
-            setattr(ops, name, fn)
-        if timers_on:
-            kt.calibrate()
-        if world > 1:
-            phase = "max over ranks"
+            set_phase("max over ranks")
             elapsed = reduce_max(elapsed)
-        loss = ts.loss()
+        set_phase("checks")
+        loss = ts.loss()                                 # (also reads the exchange-overflow / bad-id flags)
         assert np.isfinite(loss), "non-finite loss"
-        if exchange is not None:
-            exchange.check_overflow()
     except Exception as e:                               # noqa: BLE001 -- name the phase, exit non-zero
-        sys.stderr.write("[bench rank %d] failed during %s: %r\n" % (rank, phase, e))
+        sys.stderr.write("[bench rank %d] failed during %s: %r\n" % (rank, _PHASE["name"], e))
         raise
 
     if rank == 0:
@@ -475,110 +882,74 @@ def main():
                        "gather_steps_per_launch": ts.gather_ahead},
             "loss": round(loss, 6),
         }
-        # dominant kernel by total time: the weight-gradient GEMM (dW1: 2*R*F*H flop, dW2: 2*R*H*D
-        # flop, one kernel symbol); rocprof's per-kernel average is over all its launches, so the
-        # roofline is too.  Algorithmic (unpadded) flop.
-        flops_gemm = 2.0 * R * F * H
-        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-        kname = "k_gemm_bf16_256<true, 3>" if bf16 else "k_gemm_f32<false, false, 2, 2, 3,"
-        have_dw = kt.count("dW") or (kt.count("dW1") and kt.count("dW2"))
-        if timers_on and have_dw and kt.count("fc1_fwd"):
-            if kt.count("dW"):                          # stream-K: dW1 and dW2 (+ the fix-up pass) in one call
-                n_launch, t_ms = kt.count("dW"), kt.mean_ms("dW")
-                kname, klabel = "k_gemm_f32_sk", "k_gemm_f32_sk (dW1+dW2 in one stream-K launch, fix-up pass included)"
-            else:
-                n_launch = kt.count("dW1") + kt.count("dW2")
-                t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
-                klabel = kname + (" ...> (dW1+dW2 launches)" if not bf16 else " (dW1+dW2 launches)")
-            flop_launch = sampled * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
-            ach = flop_launch / (t_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": klabel,
-                               "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4),
-                               "traffic": pmc_traffic(kname, bf16) if world == 1 else None,
-                               "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch,
-                               "launches_per_step": n_launch / sampled, "timed_steps": sampled,
-                               "timed_how": ("event pairs on every %dth timed step" % stride) if not graph_run else
-                                            "event pairs on 8 eager steps after the graph-replayed timed region"}
-            ach1 = flops_gemm / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
-            k1 = "k_gemm_bf16_256<false, 0>" if bf16 else "k_gemm_f32<true, false, 2, 2, 1,"
-            out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": k1 + ("" if bf16 else " ...>"),
-                                       "achieved": round(ach1, 2), "peak": peak, "unit": "TFLOP/s",
-                                       "frac": round(ach1 / peak, 4), "traffic": pmc_traffic(k1, bf16) if world == 1 else None,
-                                       "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": flops_gemm}
-            kern = {}
-            for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "adam", "adam_w1", "adam_w2", "adam_bias"):
-                if kt.mean_ms(k) is not None:
-                    kern[k + "_ms"] = round(kt.mean_ms(k), 4)
-            kern["empty_event_pair_ms"] = round(kt.overhead_ms, 5)      # included in the figures above
-            out["kernels"] = kern
-        # the HBM-bound kernel the metric also names: the fused sampler+gather (fp32, 1 GPU) or
-        # the fp16 row gather (config 4), 10 back-to-back launches per event pair
-        if world == 1 and not args.train_table:
-            reps, per = 5, 10
-            n_st = ts.gather_ahead
-            m = train._MODES[mode]
-            if bf16:
-                gk = "k_sample_gather<%d," % (1 if rpt == 2 else 0)       # <mode, RowF16<3>>
-                gbytes = n_st * R * F * (2 + 2.0)          # fp16 rows read + bf16 normalised rows written
-            else:
-                gk = "k_sample_gather<%d," % (1 if rpt == 2 else 0)       # <mode, RowF32<6>>
-                gbytes = n_st * 2.0 * R * F * 4             # rows read + normalised rows written
-            nxt = [ts.global_step + 1000]                   # fresh steps every launch: re-reading the same rows
-                                                            # would be served from the 256 MB Infinity Cache
-
-            def launch():                                   # (training on `ts` is over: its buffers are scratch now)
-                if n_st > 1:
-                    ts._gather_block(nxt[0])
-                else:
-                    ops.sample_gather(m, ts.pairs, ts.seed, nxt[0], B, ts.table.data, F, ts.idx, ts.ws.x_hat,
-                                      shift_out=ts.shift)
-                nxt[0] += n_st
-            for _ in range(3):
-                launch()
-            evs = []
-            for _ in range(reps):
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                for _ in range(per):
-                    launch()
-                e.record()
-                evs.append((s, e))
-            torch.cuda.synchronize(dev)
-            t_g = float(np.median([s.elapsed_time(e) for s, e in evs])) / per
-            g_ach = gbytes / (t_g * 1e-3) / 1e9
-            out["gather"] = {"bound": "hbm", "kernel": gk + (" RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1), "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(gk, bf16),
-                             "bytes_per_launch": gbytes, "launch_ms": round(t_g, 4), "steps_per_launch": n_st,
-                             "method": "%d back-to-back launches per event pair (inter-launch gaps included), median of %d"
-                                       % (per, reps)}
         if world > 1:
-            ar, exw = kt.mean_ms("allreduce_wait"), kt.mean_ms("exchange_wait")
+            out["ranks_seen"] = dist.get_world_size()
+            out["comm_backend"] = {"backend": dist.get_backend(), "launcher": "self" if os.environ.get("CDML_BENCH_PHASE_DIR") else "external",
+                                   "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
+        if timers_on:
+            out.update(gemm_records(kt, R, bf16, sampled, how, world == 1))
+        if world == 1 and not args.train_table:
+            set_phase("gather record")
+            out["gather"] = gather_record(ts, mode, bf16, dev)
+        if world > 1:
+            ar, exw = comm_kt.mean_ms("allreduce_wait"), comm_kt.mean_ms("exchange_wait")
             out["comm"] = {"allreduce_exposed_ms": None if ar is None else round(ar, 4),
                            "exchange_exposed_ms": None if exw is None else round(exw, 4),
                            "exchange_bytes": exchange.bytes_per_step(ts.R, ts.ws.x_hat),
                            "allreduce_bytes": int(ts.layout.numel * 4),
-                           "note": "event pairs around GradSync.finish / Prefetcher.acquire on the compute stream "
-                                   "(on the sampled timed steps): what the step waits for, not the collectives' own duration"}
+                           "grad_sync": ts.grad_sync_mode, "grad_sync_probe": probe,
+                           "exchange_capacity_factor": args.capacity_factor,
+                           "note": "event pairs around GradSync.finish / Prefetcher.acquire on the compute stream (every "
+                                   "step of the run): what the step waits for, not the collectives' own duration"}
         step_flops = R * (2.0 * F * H + 2.0 * H * D) + R * (2.0 * F * H + 4.0 * H * D)
         out["step_tflops"] = round(step_flops / (elapsed / args.steps) / 1e12, 2)
+        out["warmup_effective"] = {"steps_of_this_job_before_the_timed_region": args.warmup + pre_steps,
+                                   "of_which_grad_sync_probe": pre_steps,
+                                   "settle_loop_s": 0.0 if args.no_settle else 0.3,
+                                   "note": "the settle loop launches weight-gradient GEMMs on scratch buffers (no state of the "
+                                           "job): the first ~100 ms of MFMA work after idle run ~2 % slower (clock ramp)"}
+        out["order"] = ("%swarm-up + timed steps, then the secondary records, cpu_baseline last"
+                        % ("" if args.no_settle else "0.3 s settle loop, "))
 
-        out.update(extras)
-        warmed = bool(extras.get("like_for_like") or extras.get("data_learnable"))
-        if not warmed and args.no_settle:
-            out["order"] = "warm-up + timed steps from a cold start (--no-settle)"
-        elif not warmed:
-            out["order"] = ("0.3 s of weight-gradient GEMM launches on scratch buffers (clock ramp after idle: the first ~100 ms "
-                            "of MFMA work run ~2 % slower), then warm-up + timed steps")
-        else:
-            out["order"] = ("like_for_like and data_learnable were measured first, the headline's warm-up + timed steps "
-                            "directly after them (GPU already at its sustained clocks), cpu_baseline last")
+        # ---- secondary records (after the headline; the failure of one must not cost the line) ----
+        run_extras = config1 and mode == "inbatch" and not args.no_extras and not args.train_table
+        if run_extras:
+            del ts
+            torch.cuda.empty_cache()
+            want = set((args.extras or "like_for_like,dp_form_one_gpu,config4_per_gpu,reference_recipe,fusion_resnet,"
+                                       "predict,data_learnable").split(","))
+            n_s, n_w = min(args.steps, 30), min(max(args.warmup, 3), 5)
+            keep = {}
+
+            def attempt(name, fn):
+                if name not in want:
+                    return
+                set_phase("secondary: " + name)
+                try:
+                    out[name] = fn()
+                except Exception as e:                   # noqa: BLE001
+                    out[name] = {"error": repr(e)[:300]}
+                torch.cuda.empty_cache()
+            attempt("reference_recipe", lambda: rec_reference_recipe(dev, args, n_s, n_w, table))
+            attempt("data_learnable", lambda: rec_learnable(dev, args, n_s, n_w, B))
+            del table, pairs
+            torch.cuda.empty_cache()
+            attempt("fusion_resnet", lambda: rec_fusion(dev, args, n_s, n_w))
+            attempt("like_for_like", lambda: rec_like_for_like(dev, args, n_s, n_w, keep))
+            attempt("dp_form_one_gpu", lambda: rec_dp_form(dev, args, n_s, n_w, keep))
+            keep.clear()
+            torch.cuda.empty_cache()
+            attempt("config4_per_gpu", lambda: rec_config4(dev, args, n_s, n_w))
+            attempt("predict", lambda: {"f32": rec_predict(dev, "f32"), "bf16": rec_predict(dev, "bf16")})
         if world == 1 and not args.no_cpu_baseline:
+            set_phase("cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
     if world > 1:
+        set_phase("shutdown")
         dist.barrier()
         dist.destroy_process_group()
+    set_phase("done")
 
 
 if __name__ == "__main__":

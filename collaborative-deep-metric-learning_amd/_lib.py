@@ -40,11 +40,11 @@ SIGNATURES = {
     "cdml_step_advance": (_i, [_p, _p]),
     "cdml_gather_rows": (_i, [_p, _i64, _i64, _i64, _p, _i, _i, _i, _p, _i64, _p, _p, _p]),
     "cdml_sample_gather": (_i, [_i, _p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _i64, _i64, _i,
-                                _p, _p, _p, _i64, _i, _i64, _i64, _p]),
+                                _p, _p, _p, _i64, _i, _i64, _i64, _p, _p]),
     "cdml_route_rows": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p]),
     "cdml_scatter_rows": (_i, [_p, _i64, _p, _i, _i, _p, _i64, _p]),
     "cdml_sample_gather_f16": (_i, [_i, _p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _i64, _i64, _i,
-                                    _p, _p, _p, _i64, _i, _i64, _i64, _p]),
+                                    _p, _p, _p, _i64, _i, _i64, _i64, _p, _p]),
     "cdml_l2norm_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p]),
     "cdml_l2norm_bwd": (_i, [_p, _i64, _p, _i64, _i, _i, _f, _p, _i64, _p]),
     "cdml_fc_lrelu_fwd": (_i, [_p, _i64, _p, _i64, _p, _f, _i, _i, _i, _p, _i64, _p]),

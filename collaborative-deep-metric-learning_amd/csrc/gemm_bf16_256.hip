@@ -38,12 +38,6 @@
 //   later, after every wave of both groups has passed its wait.
 #include "gemm_bf16.h"
 
-// timing ablations for tools/gemm_bf16_bench.py (WRONG RESULTS): bit 0 = no DMA issue in the loop,
-// bit 1 = no counted DMA waits, bit 2 = no fragment reads in the loop
-#ifndef CDML_PP_ABLATE
-#define CDML_PP_ABLATE 0
-#endif
-
 namespace cdml {
 namespace {
 
@@ -239,7 +233,6 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
                       "+v"(fb1[0]), "+v"(fb1[1]), "+v"(fb1[2]), "+v"(fb1[3]));
   };
   auto do_tile2 = [&](const int buf, const int tile) {
-    if (!(CDML_PP_ABLATE & 4) || tile == 0) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fb0[ks] = read_b(buf, 0, ks);
 #pragma unroll
@@ -248,12 +241,9 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = read_a(buf, 0, mi, ks);
-    }
-    if (!(CDML_PP_ABLATE & 1)) {
-      stage(0, 0, tile + 1, buf ^ 1);
-      stage(0, 1, tile + 1, buf ^ 1);
-    }
-    if (!(CDML_PP_ABLATE & 3)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    stage(0, 0, tile + 1, buf ^ 1);
+    stage(0, 1, tile + 1, buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     pin_b();
     pin_a();
     if (TN && cs_on && (tile % cs_period) == cs_owner) {
@@ -274,17 +264,13 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
       }
     __builtin_amdgcn_s_setprio(0);
     CDML_BARRIER();
-    if (!(CDML_PP_ABLATE & 4)) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = read_a(buf, 1, mi, ks);
-    }
-    if (!(CDML_PP_ABLATE & 1)) {
-      stage(1, 0, tile + 2, buf);
-      stage(1, 1, tile + 2, buf);
-    }
-    if (!(CDML_PP_ABLATE & 3)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    stage(1, 0, tile + 2, buf);
+    stage(1, 1, tile + 2, buf);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     pin_a();
     CDML_BARRIER();
     __builtin_amdgcn_s_setprio(1);

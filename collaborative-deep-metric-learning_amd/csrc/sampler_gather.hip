@@ -161,9 +161,19 @@ k_gather_rows(const float *__restrict__ table, int64_t row0, int64_t n_rows, int
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int r = blockIdx.x * kWavesPerBlock + wave; r < n_idx; r += gridDim.x * kWavesPerBlock) {
     const int32_t id = idx[r];
-    if (id == -1) continue;                    // padding slot of a fixed-capacity exchange: untouched
+    if (id == -1) {
+      // owner side of a fixed-capacity exchange: a padding slot, left untouched.  Requester side
+      // (flag bit 1 set): a request that found no slot -- the row is filled with all-ones words
+      // (NaN as fp32 and as bf16 pairs), so the same step's loss shows the overflow
+      if (normalize & 2) {
+        float4 *d = reinterpret_cast<float4 *>(x_out + (int64_t)r * out_stride);
+        const float nanf_ = __uint_as_float(0xFFFFFFFFu);
+        for (int q = lane; q < (int)(out_stride >> 2); q += kWave) d[q] = make_float4(nanf_, nanf_, nanf_, nanf_);
+      }
+      continue;
+    }
     const int64_t lr = clamp_row(id, row0, n_rows, oob_flag);
-    gather_one_row<NCH>(table, lr, row_stride, F, normalize, x_out + (int64_t)r * out_stride,
+    gather_one_row<NCH>(table, lr, row_stride, F, normalize & 1, x_out + (int64_t)r * out_stride,
                         out_stride, inv_norm_out ? inv_norm_out + r : nullptr, lane);
   }
 }
@@ -323,7 +333,8 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
                 int64_t slot0, int64_t batch_global, const typename ROW::In *__restrict__ table,
                 int64_t n_rows, int64_t row_stride, int F, int32_t *__restrict__ idx_out,
                 int32_t *__restrict__ shift_out, typename ROW::Out *__restrict__ x_out, int64_t out_stride,
-                int n_steps, int64_t x_step_stride, int64_t idx_step_stride) {
+                int n_steps, int64_t x_step_stride, int64_t idx_step_stride,
+                int32_t *__restrict__ oob_flag) {
   constexpr int RPT = (MODE == 0) ? 3 : 2;  // rows per triplet
   constexpr int kRPW = ROW::kRows, kCR = kRPW * kWavesPerBlock;   // rows per wave / per chunk
   __shared__ int32_t s_id[2][kCR];
@@ -350,6 +361,9 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
           id = sample_uniform_negative(seed, step, (uint32_t)slot, pairs[2 * q], pairs[2 * q + 1], (uint32_t)n_rows);
         } else {
           id = pairs[2 * q + (k ? 1 : 0)];
+          // a pair id outside the catalogue (the reference raises IndexError, inputs.py:158): the row
+          // load below clamps it for memory safety, the flag tells the caller (off the load path)
+          if (oob_flag && (id < 0 || id >= n_rows)) atomicOr(oob_flag, 1);
         }
         idx_out[(int64_t)s * idx_step_stride + r] = id;
         if (MODE == 1 && r == 0) shift_out[s] = sample_inbatch_shift(seed, step, batch);
@@ -559,7 +573,7 @@ extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pair
                                   int64_t batch_global, const float *table, int64_t n_rows,
                                   int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
                                   float *x_out, int64_t out_stride, int n_steps, int64_t x_step_stride,
-                                  int64_t idx_step_stride, cdml_stream_t stream) {
+                                  int64_t idx_step_stride, int32_t *oob_flag, cdml_stream_t stream) {
   CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "sample_gather: mode must be 0 or 1");
   CDML_REQUIRE(n_steps >= 1 && n_steps <= 64, CDML_E_BADARG, "sample_gather: n_steps must be in [1, 64]");
   CDML_REQUIRE(n_steps == 1 || (x_step_stride >= (int64_t)batch * (mode == 0 ? 3 : 2) * out_stride &&
@@ -581,7 +595,7 @@ extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pair
   hipLaunchKernelGGL((k_sample_gather<M, RowF32<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
                      pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global, table,     \
                      n_rows, row_stride, F, idx_out, shift_out, x_out, out_stride, n_steps,       \
-                     x_step_stride, idx_step_stride)
+                     x_step_stride, idx_step_stride, oob_flag)
   if (mode == 0) {
     if (nch <= 2) CDML_LAUNCH_SG(0, 2);
     else if (nch <= 6) CDML_LAUNCH_SG(0, 6);
@@ -623,7 +637,8 @@ extern "C" int cdml_sample_gather_f16(int mode, const int32_t *pairs, int64_t n_
                                       int64_t batch_global, const uint16_t *table, int64_t n_rows,
                                       int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
                                       uint16_t *x_out_bf16, int64_t out_stride, int n_steps,
-                                      int64_t x_step_stride, int64_t idx_step_stride, cdml_stream_t stream) {
+                                      int64_t x_step_stride, int64_t idx_step_stride, int32_t *oob_flag,
+                                      cdml_stream_t stream) {
   CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "sample_gather_f16: mode must be 0 or 1");
   CDML_REQUIRE(pairs && table && idx_out && x_out_bf16 && n_pairs > 0 && slot0 >= 0, CDML_E_BADARG,
                "sample_gather_f16: bad argument");
@@ -646,7 +661,8 @@ extern "C" int cdml_sample_gather_f16(int mode, const int32_t *pairs, int64_t n_
   hipLaunchKernelGGL((k_sample_gather<M, RowF16<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream,   \
                      pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global,                       \
                      reinterpret_cast<const _Float16 *>(table), n_rows, row_stride, F, idx_out, shift_out,   \
-                     reinterpret_cast<__bf16 *>(x_out_bf16), out_stride, n_steps, x_step_stride, idx_step_stride)
+                     reinterpret_cast<__bf16 *>(x_out_bf16), out_stride, n_steps, x_step_stride, idx_step_stride, \
+                     oob_flag)
   if (mode == 0) {
     if (nch <= 1) CDML_LAUNCH_SGH(0, 1); else if (nch <= 3) CDML_LAUNCH_SGH(0, 3); else CDML_LAUNCH_SGH(0, 8);
   } else {

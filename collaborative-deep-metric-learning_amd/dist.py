@@ -177,14 +177,18 @@ class RowExchange:
         return recv_ids, recv
 
     def unpermute(self, rows_in, slot, out):
-        """out[r] = rows_in[slot[r]] -- a row gather of the receive buffer."""
+        """out[r] = rows_in[slot[r]] -- a row gather of the receive buffer.  A request that found
+        no slot (slot -1: its owner's segment was full) gets a NaN row, so the SAME step's loss is
+        NaN and the overflow cannot train on a stale row unnoticed (``check_overflow`` names it)."""
         if rows_in.is_cuda:
             if rows_in.element_size() == 2:          # bf16 rows move as fp32 words (bitwise copy)
                 rows_in, out = rows_in.view(torch.float32), out.view(torch.float32)
-            ops.gather_rows(rows_in, 0, slot, out.shape[1], out[:slot.numel()], normalize=False)
+            ops.gather_rows(rows_in, 0, slot, out.shape[1], out[:slot.numel()], normalize=False,
+                            nan_missing=True)
         else:
             ok = slot >= 0
             out[:slot.numel()][ok] = rows_in[slot[ok].long()]
+            out[:slot.numel()][~ok] = float("nan")
 
     def check_overflow(self):
         """Host check of the device-side flag (a sync: call it off the critical path -- the
@@ -277,27 +281,27 @@ class Prefetcher:
     must not queue behind the gradient all-reduce of step t.
 
     Inside a hipGraph capture the exchange is recorded on the CAPTURING stream itself, ahead of
-    the step's forward pass (so in a replay it is not hidden under the GEMMs: eager is the faster
-    mode for N > 1).  Forking it onto the side stream would put RCCL's own stream two forks deep
-    -- capturing stream -> side stream -> communicator stream -- and on this stack (torch 2.10,
-    RCCL 2.26, HIP 7.0) that never returns from the capture (tools/probes/rccl_graph_capture.py:
-    one fork deep every collective captures and replays correctly, two deep it hangs or
-    crashes in hipStreamEndCapture).  ``fork_in_capture=True`` restores the fork for stacks
-    where it works.  The event hand-over between steps is not needed in a replay (consecutive
-    replays are ordered by the stream) and could not be captured anyway: its events belong to
-    earlier launches."""
+    the step's forward pass: forking it onto the side stream would put RCCL's own stream two forks
+    deep -- capturing stream -> side stream -> communicator stream -- and on this stack (torch
+    2.10, RCCL 2.26, HIP 7.0) that never returns from the capture (profiles/
+    r02_rccl_graph_capture_probe.txt: one fork deep every collective captures and replays
+    correctly, two deep it hangs or crashes in hipStreamEndCapture).  The overlapped form of a
+    replayed step is therefore TWO graphs per step (train.TrainStep, ``use_graph="split"``): the
+    exchange captured with THIS stream as the capture origin, the compute step with the compute
+    stream as origin -- each communicator stream is then one fork from its origin -- ordered by
+    events recorded eagerly between the two replays.  The event hand-over between steps is not
+    needed inside a single-graph replay (consecutive replays are ordered by the stream) and could
+    not be captured anyway: its events belong to earlier launches."""
 
-    def __init__(self, device, fork_in_capture=False):
+    def __init__(self, device):
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
-        self.fork_in_capture = bool(fork_in_capture)
         if self.cuda:
             self.stream = torch.cuda.Stream(self.device)
             self.ready = [torch.cuda.Event(), torch.cuda.Event()]
             self.free = [torch.cuda.Event(), torch.cuda.Event()]
         self._released = [False, False]
         self._cold = True
-        self._forked = False
 
     def _capturing(self):
         return self.cuda and torch.cuda.is_current_stream_capturing()
@@ -308,13 +312,7 @@ class Prefetcher:
             return
         cur = torch.cuda.current_stream(self.device)
         if self._capturing():
-            if not self.fork_in_capture:
-                fill_fn()                            # on the capturing stream (see the class docstring)
-                return
-            self.stream.wait_stream(cur)             # fork: the branch starts behind what is captured so far
-            with torch.cuda.stream(self.stream):
-                fill_fn()
-            self._forked = True
+            fill_fn()                                # on the capturing stream (see the class docstring)
             return
         if self._cold:
             # first use: everything set up on the compute stream so far (table fill,
@@ -333,12 +331,8 @@ class Prefetcher:
 
     def wait_ready(self, b):
         """The compute stream (and what is issued on it next: the gradient all-reduce) waits for
-        the exchange into buffer b; inside a capture that is the join of the forked branch."""
-        if not self.cuda:
-            return
-        if self._capturing():
-            self.join()
-        else:
+        the exchange into buffer b (inside a capture it sits on the capturing stream already)."""
+        if self.cuda and not self._capturing():
             torch.cuda.current_stream(self.device).wait_event(self.ready[b])
 
     def release(self, b):
@@ -346,14 +340,15 @@ class Prefetcher:
             self.free[b].record(torch.cuda.current_stream(self.device))
             self._released[b] = True
 
-    def join(self):
-        """End of a captured step: the forked branch rejoins the capturing stream."""
-        if self._forked:
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
-            self._forked = False
-
     def drain(self):
-        """Make the compute stream wait for everything the side stream has been given (before
-        switching between eager steps and graph replays)."""
+        """Order the two streams behind each other -- before switching between eager steps and
+        graph replays, and after a resume.  Both directions: the compute stream waits for what the
+        side stream has been given, AND the side stream waits for the compute stream -- a replay
+        records no ``free`` events (release() is a no-op under capture), so the events on hand date
+        from the last eager step and the next eager ``launch`` must not overwrite a buffer that a
+        replay still queued on the compute stream reads.  The stale ``free`` events are dropped."""
         if self.cuda:
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.stream)
+            self.stream.wait_stream(cur)
+            self._released = [False, False]

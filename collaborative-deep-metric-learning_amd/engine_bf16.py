@@ -60,25 +60,31 @@ def layout_bf16(feature_size, hidden=5000, output_size=256):
 
 
 class TowerWorkspaceBF16:
-    def __init__(self, layout, n_rows, device):
+    def __init__(self, layout, n_rows, device, backward=True):
         L, R = layout, int(n_rows)
         if R % 64:
             raise ValueError("the bf16 path needs a row count that is a multiple of 64 (got %d)" % R)
         self.layout, self.R = L, R
         bf = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=device)
         f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
+        self.x_hat, self.h1 = bf(R, L.Fp), bf(R, L.Hp)
+        self.z, self.e = f32(R, L.Dp), f32(R, L.Dp)
+        self.W1T, self.W2T, self.W2 = bf(L.Hp, L.Fp), bf(L.Dp, L.Hp), bf(L.Hp, L.Dp)
+        if not backward:                                   # catalogue inference: forward buffers only
+            self.gemm_ws = torch.empty(max(ops.gemm_bf16_workspace(R, L.Dp, L.Hp), 16) // 4, dtype=torch.float32,
+                                       device=device)
+            return
         # weight gradients straight from the activations as stored (k-strided GEMM with
         # transposed LDS reads) when the shapes allow; otherwise transposed bf16 copies
         self.tn1 = ops.gemm_bf16_tn_supported(L.Fp, L.Hp, R, L.Fp, L.Hp)
         self.tn2 = ops.gemm_bf16_tn_supported(L.Hp, L.Dp, R, L.Hp, L.Dp)
-        self.x_hat, self.h1, self.dz1 = bf(R, L.Fp), bf(R, L.Hp), bf(R, L.Hp)
-        self.z, self.e, self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp)
+        self.dz1 = bf(R, L.Hp)
+        self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp)
         self.dz2_bf = bf(R, L.Dp)
         if not self.tn1:
             self.xT, self.dz1T = bf(L.Fp, R), bf(L.Hp, R)
         if not self.tn2:
             self.h1T, self.dz2T = bf(L.Hp, R), bf(L.Dp, R)
-        self.W1T, self.W2T, self.W2 = bf(L.Hp, L.Fp), bf(L.Dp, L.Hp), bf(L.Hp, L.Dp)
         nb = max(ops.gemm_bf16_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_workspace(L.Fp, L.Hp, R),
                  ops.gemm_bf16_workspace(R, L.Dp, L.Hp),
                  ops.gemm_bf16_tn_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_tn_workspace(L.Fp, L.Hp, R),

@@ -68,19 +68,22 @@ def step_advance(step_dev):
 
 
 def gather_rows(table, row0, idx, feature_size, x_out, normalize=True, inv_norm_out=None,
-                oob_flag=None):
+                oob_flag=None, nan_missing=False):
+    """nan_missing: an idx of -1 is a request that got no row (exchange overflow) -> that output row
+    becomes NaN; otherwise -1 marks a padding slot and the output row is left untouched."""
     tp, tld = _mat(table)
     xp, xld = _mat(x_out)
     call("cdml_gather_rows", tp, row0, table.shape[0], tld, _p(idx, torch.int32), idx.numel(),
-         feature_size, 1 if normalize else 0, xp, xld, _p(inv_norm_out), _p(oob_flag, torch.int32),
-         _stream())
+         feature_size, (1 if normalize else 0) | (2 if nan_missing else 0), xp, xld, _p(inv_norm_out),
+         _p(oob_flag, torch.int32), _stream())
     return x_out
 
 
 def sample_gather(mode, pairs, seed, step, batch, table, feature_size, idx_out, x_out,
-                  shift_out=None, slot0=0, batch_global=None, step_dev=None, n_steps=1):
+                  shift_out=None, slot0=0, batch_global=None, step_dev=None, n_steps=1, oob_flag=None):
     """n_steps > 1: x_out is [n_steps, rows, stride], idx_out [n_steps, rows], shift_out [n_steps]
-    (steps step, step+1, ... in one launch)."""
+    (steps step, step+1, ... in one launch).  oob_flag (int32[1]): bit 0 set when a pair id lies
+    outside the catalogue (the reference's IndexError, inputs.py:158)."""
     bg = batch if batch_global is None else batch_global
     f16 = table.dtype == torch.float16              # fp16 catalogue -> bf16 rows (config 4)
     mat = _mat16 if f16 else _mat
@@ -96,7 +99,7 @@ def sample_gather(mode, pairs, seed, step, batch, table, feature_size, idx_out, 
     call("cdml_sample_gather_f16" if f16 else "cdml_sample_gather", mode, _p(pairs, torch.int32), pairs.shape[0], seed,
          0 if step is None else step, _p(step_dev, torch.int64), batch, slot0, bg, tp,
          table.shape[0], tld, feature_size, _p(idx_out, torch.int32), _p(shift_out, torch.int32),
-         xp, xld, n_steps, xss, iss, _stream())
+         xp, xld, n_steps, xss, iss, _p(oob_flag, torch.int32), _stream())
     return x_out
 
 

@@ -11,31 +11,48 @@ import os
 import numpy as np
 import torch
 
-from . import engine, ops
+from . import engine, engine_bf16, ops
 
 
 class Prediction():
-    def __init__(self, params=None, ckpt=None, device="cuda:0"):
+    def __init__(self, params=None, ckpt=None, device="cuda:0", precision="f32"):
+        """``precision``: "f32" (the reference's arithmetic) or "bf16" -- BASELINE config 4's
+        precision for catalogue inference: an fp16 ``FeatureTableF16`` in, bf16 MFMA projection,
+        fp32 accumulation and output normalisation (build-defined; tolerance 5e-3 on the unit-norm
+        embeddings, tests/test_gpu_bf16.py)."""
         if params is None:
             if ckpt is None or not os.path.exists(ckpt):
                 raise IOError("Prediction __init__ Cannot find %s" % ckpt)      # predict.py:54-55
             state = torch.load(ckpt, map_location="cpu")
-            layout = engine.TowerLayout(*state["layout"])
+            mk = engine_bf16.layout_bf16 if precision == "bf16" else engine.TowerLayout
+            layout = mk(*state["layout"])
             params = engine.VNetParams(layout, device)
             params.load(*[state["variables"][n] for n in engine.VNetParams.NAMES])
+        if precision not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
         self.params = params
         self.device = params.device
+        self.precision = precision
         self._ws = None
 
     def _workspace(self, n_rows):
+        if self.precision == "bf16":
+            n_rows = engine.round_up(n_rows, 64)
         if self._ws is None or self._ws.R < n_rows:
-            self._ws = engine.TowerWorkspace(self.params.layout, n_rows, self.device, backward=False)
+            if self.precision == "bf16":
+                self._ws = engine_bf16.TowerWorkspaceBF16(self.params.layout, n_rows, self.device, backward=False)
+                self._ids = torch.arange(n_rows, dtype=torch.int32, device=self.device)
+                self._idx = torch.zeros(n_rows, dtype=torch.int32, device=self.device)
+            else:
+                self._ws = engine.TowerWorkspace(self.params.layout, n_rows, self.device, backward=False)
         return self._ws
 
     def predict(self, input_batch):
         """input_batch: [n,F] ndarray / device tensor (raw features) or rows of a
         FeatureTable's padded storage.  Returns a device tensor [n,D]."""
         L = self.params.layout
+        if self.precision == "bf16":
+            raise ValueError("bf16 inference reads an fp16 catalogue: use embed_table / run_features(FeatureTableF16)")
         x = input_batch if torch.is_tensor(input_batch) else torch.as_tensor(np.asarray(input_batch, np.float32))
         x = x.to(self.device, torch.float32)
         if x.stride(-1) != 1 or (x.stride(0) % 4) or (x.data_ptr() % 16):
@@ -48,18 +65,43 @@ class Prediction():
         engine.tower_forward(self.params, ws, n)                                   # models.py:59-61
         return ws.e[:n, :L.D]
 
+    def embed_table(self, table, batch_size, out=None):
+        """Embeddings of every row of a device-resident catalogue, ``batch_size`` rows at a time,
+        into a DEVICE tensor [N, D] (predict.py:71-96 without its host round trip: the reference
+        converts every chunk with ``.tolist()``, predict.py:79-86).  Enqueue-only."""
+        L, N = self.params.layout, table.n_rows
+        if out is None:
+            out = torch.empty((N, L.D), dtype=torch.float32, device=self.device)
+        if self.precision == "bf16":
+            if table.data.dtype != torch.float16:
+                raise ValueError("precision 'bf16' reads an fp16 FeatureTableF16")
+            ws = self._workspace(min(batch_size, N))
+            engine_bf16.refresh_weights(self.params, ws)          # bf16 operand copies of the current weights
+            for lo in range(0, N, batch_size):
+                n = min(batch_size, N - lo)
+                torch.add(self._ids[:n], lo, out=self._idx[:n])
+                ops.gather_rows_f16(table.data, 0, self._idx[:n], table.feature_size, ws.x_hat)   # rows lo..lo+n, l2-normalised
+                engine_bf16.tower_forward(self.params, ws)
+                out[lo:lo + n] = ws.e[:n, :L.D]
+            return out
+        feats = table.data[:, :table.feature_size] if table.data.shape[1] == table.feature_size else table.data
+        for lo in range(0, N, batch_size):
+            hi = min(lo + batch_size, N)
+            out[lo:hi] = self.predict(feats[lo:hi])
+        return out
+
     def run_features(self, features, batch_size, output_dir='', suffix=''):
         """Embeddings of every row of ``features`` (ndarray, tensor or FeatureTable),
         ``batch_size`` rows at a time; float32 ndarray [N,D] like predict.py:71-96
         (saved to output_dir/output<suffix>.npy when output_dir is given)."""
         if isinstance(features, engine.FeatureTable):
-            features = features.data[:, :features.feature_size] if features.data.shape[1] == features.feature_size \
-                else features.data
-        N = features.shape[0]
-        out = torch.empty((N, self.params.layout.D), dtype=torch.float32, device=self.device)
-        for lo in range(0, N, batch_size):
-            hi = min(lo + batch_size, N)
-            out[lo:hi] = self.predict(features[lo:hi])
+            out = self.embed_table(features, batch_size)
+        else:
+            N = features.shape[0]
+            out = torch.empty((N, self.params.layout.D), dtype=torch.float32, device=self.device)
+            for lo in range(0, N, batch_size):
+                hi = min(lo + batch_size, N)
+                out[lo:hi] = self.predict(features[lo:hi])
         output_np = out.cpu().numpy()
         if output_dir:
             np.save(os.path.join(output_dir, "output" + suffix + ".npy"), output_np)

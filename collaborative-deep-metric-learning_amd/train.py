@@ -43,7 +43,8 @@ class TrainStep:
                  learning_rate_decay=0.96, seed=1234, weight_seed=42, device="cuda:0",
                  exchange=None, grad_sync=None, slot0=0, batch_global=None, use_graph=False,
                  prefetch=True, precision="f32", train_table=False, gather_ahead=4,
-                 clip_gradient_norm=0.0, regularization_penalty=0.0, l2_penalty=1e-8):
+                 clip_gradient_norm=0.0, regularization_penalty=0.0, l2_penalty=1e-8,
+                 grad_sync_mode="bucketed"):
         """table: FeatureTable (whole catalogue, or this rank's shard when
         ``exchange`` is given); pairs: int32 [P,2] device tensor; ``exchange`` /
         ``grad_sync``: the multi-GPU hooks of cdml_amd.dist (None on one GPU).
@@ -56,7 +57,11 @@ class TrainStep:
         (train.py:133-145; the reference's run passes 0 for both, train.py:221-222): per-variable
         tf.clip_by_norm, and penalty * sum_W l2_penalty*|W|^2/2 added to the loss (models.py:28).
         ``optimizer``: "adam" (build_graph's default), "lars" (what the reference's main() uses,
-        train.py:354) or "momentum" (Nesterov, momentum 0.9: train.py:115-116)."""
+        train.py:354) or "momentum" (Nesterov, momentum 0.9: train.py:115-116).
+        ``grad_sync_mode`` (with ``grad_sync``): "bucketed" = the weight gradients as split-K launches
+        in buckets whose all-reduce starts as soon as each is enqueued (hidden under the GEMMs that
+        follow); "single" = the one stream-K launch of the single-GPU step followed by ONE all-reduce
+        of the whole flat gradient (faster kernels, the collective exposed)."""
         if mode not in _MODES:
             raise ValueError("mode must be 'uniform', 'inbatch' or 'semihard'")
         if optimizer not in ("adam", "lars", "momentum"):
@@ -87,6 +92,9 @@ class TrainStep:
         self.decay_steps = learning_rate_decay_examples
         self.decay_rate = learning_rate_decay
         self.exchange, self.grad_sync = exchange, grad_sync
+        if grad_sync_mode not in ("bucketed", "single"):
+            raise ValueError("grad_sync_mode must be 'bucketed' or 'single'")
+        self._grad_sync_mode = grad_sync_mode
         self.slot0 = int(slot0)
         self.batch_global = self.B if batch_global is None else int(batch_global)
         F = table.feature_size if feature_size is None else feature_size
@@ -112,6 +120,7 @@ class TrainStep:
         self.hinge = torch.zeros(self.B, dtype=f32, device=dev)
         self.valid = torch.ones(self.B, dtype=torch.uint8, device=dev)
         self.stats = torch.zeros(8, dtype=f32, device=dev)   # loss, mean pos, mean neg, active, variance
+        self.oob = torch.zeros(1, dtype=i32, device=dev)     # fused sampler+gather: a pair id outside the table
         self.adam_tickets = ops.new_tickets(dev)             # Adam: last block advances the step counter
         self.var_ws = None                                   # set by enable_variance()
         if mode == "semihard":
@@ -165,6 +174,7 @@ class TrainStep:
             self._select_ahead(0)
         self._graphs = {}
         self._warmed = False
+        self._replayed = False                           # the previous step was a graph replay
         # the data-parallel step is enqueue-only too (fixed-capacity exchange, no host counts), so
         # it captures like the single-GPU one: one graph per prefetch buffer
         self.use_graph = bool(use_graph)
@@ -191,6 +201,18 @@ class TrainStep:
             self._x = [self.ws.x_hat, torch.zeros_like(self.ws.x_hat)]
             self._idx = [self.idx, torch.zeros_like(self.idx)]
             self._shift = [self.shift, torch.zeros_like(self.shift)]
+
+    @property
+    def grad_sync_mode(self):
+        return self._grad_sync_mode
+
+    @grad_sync_mode.setter
+    def grad_sync_mode(self, mode):
+        if mode not in ("bucketed", "single"):
+            raise ValueError("grad_sync_mode must be 'bucketed' or 'single'")
+        if mode != self._grad_sync_mode:
+            self._grad_sync_mode = mode
+            self._graphs = {}                            # captured steps recorded the other form
 
     # ---------------------------------------------------------------- pieces --
     def _fill(self, b, step):
@@ -227,7 +249,8 @@ class TrainStep:
         ops.sample_gather(_MODES[self.mode], self.pairs, self.seed, step, self.B, self.table.data,
                           self.table.feature_size, self._idxa, self._xa, shift_out=self._shifta,
                           slot0=self.slot0, batch_global=self.batch_global,
-                          step_dev=self.step_dev if step is None else None, n_steps=self.gather_ahead)
+                          step_dev=self.step_dev if step is None else None, n_steps=self.gather_ahead,
+                          oob_flag=self.oob)
 
     def fetch(self):
         """Sampler + gather (+ input l2norm): fills ws.x_hat and self.idx."""
@@ -250,7 +273,7 @@ class TrainStep:
             ops.sample_gather(m, self.pairs, self.seed, None, self.B, self.table.data,
                               self.table.feature_size, self.idx, self.ws.x_hat,
                               shift_out=self.shift, slot0=self.slot0,
-                              batch_global=self.batch_global, step_dev=self.step_dev)
+                              batch_global=self.batch_global, step_dev=self.step_dev, oob_flag=self.oob)
         else:
             if m == MODE_UNIFORM:
                 ops.sample_uniform(self.pairs, self.table.n_rows_global, self.seed, None, self.B,
@@ -385,6 +408,13 @@ class TrainStep:
         self.forward_loss()
         if self.grad_sync is None:
             self.backward()
+        elif self._grad_sync_mode == "single":
+            # the single-GPU backward (both weight gradients in one stream-K launch), then one
+            # all-reduce of the whole flat gradient, issued once the exchange of step t+1 is done
+            self.backward()
+            if self.prefetch is not None:
+                self.prefetch.wait_ready(1 - b)
+            self.grad_sync.finish([self.grad_sync.start(self.params.grad, 0, self.layout.numel)])
         else:
             if self.prefetch is not None:
                 self.prefetch.wait_ready(1 - b)
@@ -403,8 +433,6 @@ class TrainStep:
         if self.train_table:
             self.update_table()
         self.apply_gradients()
-        if self.prefetch is not None:
-            self.prefetch.join()                     # (inside a graph capture: the branch rejoins)
 
     # ------------------------------------------------------------------ step --
     def step(self):
@@ -435,9 +463,13 @@ class TrainStep:
                     self._ahead_base = t
                 self._select_ahead(key)
             self._graphs[key].replay()
+            self._replayed = True
         else:
-            if self.prefetch is not None and self._graphs:
+            if self.prefetch is not None and self._replayed:
+                # replay -> eager: a replay records no buffer-free events, so order the side stream
+                # behind the replays still queued on the compute stream (and the reverse)
                 self.prefetch.drain()
+            self._replayed = False
             self._enqueue()
             self._warmed = True
         self.global_step += 1
@@ -455,9 +487,22 @@ class TrainStep:
         torch.cuda.current_stream(self.device).wait_stream(side)
         return g
 
+    def check_inputs(self):
+        """Host check of the device-side input flags (synchronises; called by ``loss()``, by the
+        trainer before it saves or evaluates, by bench.py after the timed region): a pair id
+        outside the catalogue (the reference's IndexError, inputs.py:158) and, on a row-sharded
+        catalogue, an exchange segment that overflowed (the step then trained on NaN rows)."""
+        if int(self.oob.item()):
+            raise IndexError("a co-watch pair id lies outside the %d-row catalogue" % self.table.n_rows_global)
+        if self.exchange is not None:
+            self.exchange.check_overflow()
+
     def loss(self):
-        """Host value of the last step's mean hinge loss (synchronises)."""
-        return float(self.stats[0].item())
+        """Host value of the last step's mean hinge loss (synchronises; also reads the input
+        flags, so an exchange overflow raises here instead of returning NaN)."""
+        v = float(self.stats[0].item())
+        self.check_inputs()
+        return v
 
     # ------------------------------------------------------------ checkpoint --
     def state_dict(self):
@@ -496,6 +541,12 @@ class TrainStep:
         self._graphs = {}
         self._ahead_base = None
         self._filled = -1
+        # the first step after a resume runs eagerly (and refills the prefetch buffer): the side
+        # stream may still be filling a buffer for the old step
+        self._warmed = False
+        self._replayed = False
+        if self.prefetch is not None:
+            self.prefetch.drain()
 
 
 class Trainer:
@@ -547,6 +598,7 @@ class Trainer:
     def save(self, step):
         if not self.checkpoint_dir:
             return None
+        self.ts.check_inputs()        # never checkpoint weights that were stepped on overflowed (NaN) rows
         # data-parallel runs: the dense state is replicated -> rank 0 writes it; a trainable
         # table is sharded -> every rank writes its own shard file
         rank = 0
@@ -577,6 +629,7 @@ class Trainer:
     # ---- evaluation (train.py:224-252) ---------------------------------------
     def _eval(self, global_step):
         self.total_eval_num += 1
+        self.ts.check_inputs()
         emb = self.predictor.run_features(self.evaluater.features, batch_size=10000)
         self.eval_dist = self.evaluater.mean_dist(emb, self.evaluater.cowatches)
         if global_step <= self.check_stop_step:
@@ -602,9 +655,7 @@ class Trainer:
             self.ts.step()
             gs += 1
             if gs % self.show_step == 0 or gs == n:
-                if self.ts.exchange is not None:        # the device-side overflow / bad-id flag of the row
-                    self.ts.exchange.check_overflow()   # exchange, read where the loop syncs anyway
-                loss = self.ts.loss()
+                loss = self.ts.loss()                   # (also reads the device-side input flags)
                 self.history.append((gs, loss))
                 self.log.info("Epoch %d Step %d | Loss: %.8f | %.1f triplets/s", gs // self.step_per_epoch + 1,
                               gs, loss, gs * self.ts.batch_global / (time.time() - t0))

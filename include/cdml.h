@@ -97,7 +97,11 @@ int cdml_step_advance(uint64_t *step_dev, cdml_stream_t stream);
  * row_stride (>= F, multiple of 4; 16-B aligned base).  inv_norm_out may be
  * NULL.  idx must lie in [row0, row0+n_rows) -- out-of-range ids are clamped
  * and flagged in *oob_flag (int32, may be NULL); idx == -1 marks a padding slot
- * (fixed-capacity exchange): that output row is left untouched, nothing flagged. */
+ * (fixed-capacity exchange): that output row is left untouched, nothing flagged.
+ * `normalize` is a flag word: bit 0 = l2-normalise; bit 1 = idx == -1 means a
+ * MISSING row (a request that found no slot in the exchange): the output row is
+ * filled with all-ones words (NaN as fp32, NaN as bf16 pairs) so that the loss of
+ * the same step shows it. */
 int cdml_gather_rows(const float *table, int64_t row0, int64_t n_rows,
                      int64_t row_stride, const int32_t *idx, int n_idx, int F,
                      int normalize, float *x_out, int64_t out_stride,
@@ -128,7 +132,10 @@ int cdml_scatter_rows(const float *src, int64_t ld_src, const int32_t *slot, int
  * previous chunk's row loads are in flight; each wave gathers + l2-normalises two rows at a
  * time with whole-128-B-line loads.  Step s writes idx_out + s*idx_step_stride (int32[batch][3]
  * in mode 0, int32[2*batch] in mode 1), shift_out[s] (mode 1) and x_out + s*x_step_stride
- * (3*batch or 2*batch rows of out_stride floats).  n_steps = 1: the strides are unused. */
+ * (3*batch or 2*batch rows of out_stride floats).  n_steps = 1: the strides are unused.
+ * oob_flag (may be NULL): bit 0 is OR-ed in when a pair id lies outside [0, n_rows) -- the
+ * reference raises IndexError there (inputs.py:158); the row load itself clamps the id, as
+ * cdml_gather_rows does. */
 int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pairs,
                        uint64_t seed, uint64_t step, const uint64_t *step_dev,
                        int batch, int64_t slot0, int64_t batch_global,
@@ -136,7 +143,7 @@ int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pairs,
                        int F, int32_t *idx_out, int32_t *shift_out,
                        float *x_out, int64_t out_stride, int n_steps,
                        int64_t x_step_stride, int64_t idx_step_stride,
-                       cdml_stream_t stream);
+                       int32_t *oob_flag, cdml_stream_t stream);
 
 /* ---- tower pieces: VNet.create_model (models.py:46-62) ----------------------
  * y = x * rsqrt(max(sum(x^2), 1e-12)) per row (tf.nn.l2_normalize, models.py:58,
@@ -378,7 +385,7 @@ int cdml_sample_gather_f16(int mode, const int32_t *pairs, int64_t n_pairs, uint
                            int64_t n_rows, int64_t row_stride, int F, int32_t *idx_out,
                            int32_t *shift_out, uint16_t *x_out_bf16, int64_t out_stride,
                            int n_steps, int64_t x_step_stride, int64_t idx_step_stride,
-                           cdml_stream_t stream);
+                           int32_t *oob_flag, cdml_stream_t stream);
 
 /* ---- fusion towers MultiplyNet / MlpNet / ResNet (models.py:65-157): the
  * elementwise pieces between their FC layers; [M][N] fp32 views, N % 4 == 0. ----

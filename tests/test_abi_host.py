@@ -3,6 +3,7 @@ include/cdml.h declares (no compute call without a GPU), the ctypes table
 matches the header, and the host-side logic (layout, schedule, plug-in lookup)."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -159,3 +160,19 @@ def test_imitation_data_matches_reference_fixture(golden_dir):
     assert list(d) == ["a", "b"] and d["b"][1] == 1
     p = im.cowatch_pairs(1000, 100, seed=3)
     assert p.dtype == np.int32 and p.shape[1] == 2 and (p[:, 0] != p[:, 1]).all() and p.max() < 1000
+
+
+def test_bench_self_launch_reports_failed_rank():
+    """`python bench.py --gpus 2` with no launcher in the environment starts its own ranks; when a rank
+    fails (here: no GPU in this container) the parent exits non-zero and names the rank and its phase --
+    never a usage message, never a hang (VERDICT r2 #2)."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU: there the ranks fail at start")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1
+    assert "2-rank run failed: rank" in r.stderr and "exited with code" in r.stderr and "rank 1:" in r.stderr
+    assert "needs an MI355X" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -92,6 +92,27 @@ def _worker(rank, world, port, n_rows, F, q):
             ex.check_overflow()
         ex.overflow.zero_()
         assert cdist.exchange_capacity(16384, 8) == 2840 and cdist.exchange_capacity(100, 1) == 100
+        # skewed ids: every request of every rank goes to shard 0 (popularity-ordered
+        # ids), more of them than one segment holds -> the requests that found no slot come back as
+        # NaN rows (never as the stale row of an earlier step), the others are right, and the flag
+        # raises; a capacity_factor that covers the skew serves all of them
+        hot = torch.arange(400, dtype=torch.int32) % min(per, n_rows)
+        tight = cdist.RowExchange(n_rows, local_gather=oracle_gather)
+        cap = tight.capacity(hot.numel())
+        assert cap < hot.numel()
+        out = torch.full((hot.numel(), F + 4), 5.0)                      # "stale" content
+        tight.gather(Shard, hot, out)
+        served = torch.arange(hot.numel()) < cap
+        want = otower.l2_normalize(full[hot.numpy()], np.float32)[0]
+        np.testing.assert_allclose(out[served, :F].numpy(), want[served.numpy()], atol=1e-7)
+        assert torch.isnan(out[~served]).all()
+        with pytest.raises(RuntimeError, match="capacity_factor"):
+            tight.check_overflow()
+        roomy = cdist.RowExchange(n_rows, local_gather=oracle_gather, capacity_factor=float(world))
+        out = torch.full((hot.numel(), F + 4), 5.0)
+        roomy.gather(Shard, hot, out)
+        np.testing.assert_allclose(out[:, :F].numpy(), want, atol=1e-7)
+        roomy.check_overflow()
         # gradient average
         sync = cdist.GradSync()
         g = torch.full((10,), float(rank + 1))

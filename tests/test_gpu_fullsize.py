@@ -111,11 +111,18 @@ def test_sample_gather_content_past_4gib(cd, table_1m, mode):
     assert (got_idx[sel].astype(np.int64) * 6144 > GIB4).sum() > len(sel) // 2
 
 
-def test_gather_rows_f16_content_past_4gib(cd):
+@pytest.fixture(scope="module")
+def table_f16_15m(cd):
     """fp16 catalogue (config 4): 3072-B rows, so 1.5 M rows put a third of the table past 4 GiB."""
-    N = 1500000
-    table = cd.ebf.FeatureTableF16.synthetic(N, F, 0, cd.dev)
-    assert table.data.numel() * 2 > GIB4
+    t = cd.ebf.FeatureTableF16.synthetic(1500000, F, 0, cd.dev)
+    assert t.data.numel() * 2 > GIB4
+    yield t
+    del t
+    torch.cuda.empty_cache()
+
+
+def test_gather_rows_f16_content_past_4gib(cd, table_f16_15m):
+    table, N = table_f16_15m, table_f16_15m.n_rows
     ids = _rows_across_4gib(N, 3072, np.random.RandomState(3))
     np.testing.assert_array_equal(table.data[torch.as_tensor(ids.astype(np.int64)).to(cd.dev), :F].cpu().numpy(),
                                   _oracle_rows(ids).astype(np.float16))          # the fill kernel itself
@@ -124,8 +131,45 @@ def test_gather_rows_f16_content_past_4gib(cd):
     want = otower.l2_normalize(_oracle_rows(ids).astype(np.float16).astype(np.float64), np.float64)[0]
     np.testing.assert_allclose(x[:, :F].float().cpu().numpy(), want, rtol=2 ** -8, atol=1e-6)
     assert float(x[:, F:].float().abs().max()) == 0
-    del table
-    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode", ["inbatch", "uniform"])
+def test_sample_gather_f16_content_past_4gib(cd, table_f16_15m, mode):
+    """The kernel the config-4 step runs -- k_sample_gather<mode, RowF16>: sampler fused into the fp16
+    gather, four steps per launch -- on pairs that live past the 4 GiB mark of a 1.5 M-row table:
+    ids bit-exact against oracle/sampler.py for every step of the launch, rows against the oracle's
+    generator rounded to fp16 and normalised (bf16 output: rtol 2^-8).  inputs.py:125-127,158."""
+    table, N = table_f16_15m, table_f16_15m.n_rows
+    first_hi = GIB4 // 3072 + 1
+    rng = np.random.RandomState(4)
+    B, K, step0 = 384, 4, 7
+    pairs_np = rng.randint(first_hi, N, size=(900, 2)).astype(np.int32)
+    pairs_np[:3] = [[N - 1, N - 2], [first_hi - 1, first_hi], [N - 1, 0]]
+    pairs = torch.as_tensor(pairs_np).to(cd.dev)
+    rpt = 2 if mode == "inbatch" else 3
+    R = B * rpt
+    idx = torch.full((K, R), -1, dtype=torch.int32, device=cd.dev)
+    shift = torch.full((K,), -1, dtype=torch.int32, device=cd.dev)
+    x = torch.full((K, R, 1536), 7.0, dtype=torch.bfloat16, device=cd.dev)
+    oob = torch.zeros(1, dtype=torch.int32, device=cd.dev)
+    cd.ops.sample_gather(1 if mode == "inbatch" else 0, pairs, 1234, step0, B, table.data, F, idx, x,
+                         shift_out=shift, n_steps=K, oob_flag=oob)
+    got = idx.cpu().numpy()
+    far = 0
+    for s in range(K):
+        if mode == "inbatch":
+            want_idx, _, _, want_shift = osampler.device_inbatch(pairs_np, 1234, step0 + s, B)
+            assert int(shift[s].item()) == int(want_shift)
+        else:
+            want_idx = osampler.device_triplets_vec(pairs_np, N, 1234, step0 + s, B).reshape(-1)
+        np.testing.assert_array_equal(got[s], want_idx)
+        sel = np.unique(np.concatenate([np.arange(0, R, 41), np.arange(9), [R - 1]]))
+        raw = _oracle_rows(got[s][sel]).astype(np.float16)
+        want = otower.l2_normalize(raw.astype(np.float64), np.float64)[0]
+        np.testing.assert_allclose(x[s][sel, :F].float().cpu().numpy(), want, rtol=2 ** -8, atol=1e-6)
+        far += int((got[s][sel].astype(np.int64) * 3072 > GIB4).sum())
+    assert far > K * len(sel) // 2
+    assert float(x[:, :, F:].float().abs().max()) == 0 and int(oob.item()) == 0
 
 
 def _check_step_properties(cd, ts, pairs_np, B, rows_per_triplet):
@@ -190,6 +234,59 @@ def test_config2_step_on_1m_rows(cd, table_1m):
     assert bool((dn.cpu()[has] > dp.cpu()[has] - 2e-6).all())
     ts.step()
     assert np.isfinite(ts.loss())
+
+
+def test_config4_step_on_10m_rows_fp16(cd):
+    """BASELINE config 4's per-GPU workload at its TRUE size: the 10 M x 1500 fp16 catalogue (30.7 GB in
+    HBM), B = 8192 uniform (global) negatives -> 24 576 rows per step, bf16 MFMA tower, eager and
+    replayed from a hipGraph.  Size-independent properties + gathered content: ids bit-exact against
+    oracle/sampler.py (N = 10 M in the rejection rule), rows against the oracle's generator (fp16,
+    normalised; bf16 output), unit norms, dW1 = x_hat^T dz1 and db1 = column sums recomputed from the
+    SAME bf16 operands, bit-identical repetition, and graph replay == eager bit for bit over a
+    gather block boundary.  inputs.py:158, models.py:46-62, train.py:141."""
+    N, B = 10000000, 8192
+    table = cd.ebf.FeatureTableF16.synthetic(N, F, 0, cd.dev)
+    assert table.data.numel() * 2 > 7 * GIB4
+    pairs_np = osynth.cowatch_pairs(N, 60000, 0)
+    pairs = torch.as_tensor(pairs_np).to(cd.dev)
+    mk = lambda g: cd.train.TrainStep(table, pairs, B, mode="uniform", precision="bf16", device=cd.dev, use_graph=g)
+    a = mk(False)
+    a.fetch(); a.forward_loss(); a.backward()
+    torch.cuda.synchronize()
+    idx = osampler.device_triplets_vec(pairs_np, N, 1234, 0, B)
+    rows = a.idx.cpu().numpy()
+    np.testing.assert_array_equal(rows.reshape(B, 3), idx)
+    assert (rows.astype(np.int64) * 3072 > GIB4).mean() > 0.5 and (rows.astype(np.int64) * 3072 > 6 * GIB4).any()
+    sel = np.unique(np.concatenate([np.arange(0, len(rows), 769), np.argsort(rows)[-4:], [len(rows) - 1]]))
+    raw = _oracle_rows(rows[sel]).astype(np.float16)
+    np.testing.assert_array_equal(table.data[torch.as_tensor(rows[sel].astype(np.int64)).to(cd.dev), :F].cpu().numpy(), raw)
+    want = otower.l2_normalize(raw.astype(np.float64), np.float64)[0]
+    np.testing.assert_allclose(a.ws.x_hat[sel, :F].float().cpu().numpy(), want, rtol=2 ** -8, atol=1e-6)
+    assert float((a.ws.x_hat[:, :F].float().norm(dim=1) - 1).abs().max()) < 4e-3     # bf16 rows
+    assert float((a.ws.e.norm(dim=1) - 1).abs().max()) < 1e-5                        # output l2norm is fp32
+    assert torch.isfinite(a.params.grad).all() and abs(a.loss() - 0.8) < 0.2 and int(a.oob.item()) == 0
+    ref = a.ws.x_hat.double().T @ a.ws.dz1[:, :256].double()                         # same bf16 operands
+    scale = float(ref.abs().max())
+    assert float((a.params.gW1[:, :256].double() - ref).abs().max()) < 1e-5 * max(scale, 1e-3) + 1e-7
+    db1 = a.ws.dz1.double().sum(0)
+    assert float((a.params.gb1.double() - db1).abs().max()) < 1e-5 * max(float(db1.abs().max()), 1e-3) + 1e-7
+    ref2 = a.ws.h1[:, :512].double().T @ a.ws.dz2_bf.double()
+    assert float((a.params.gW2[:512].double() - ref2).abs().max()) < 1e-5 * max(float(ref2.abs().max()), 1e-3) + 1e-7
+    g0 = a.params.grad.clone()
+    a.fetch(); a.forward_loss(); a.backward()
+    assert torch.equal(g0, a.params.grad)
+    del g0, ref, ref2
+    b = mk(True)
+    for _ in range(6):                       # gather_ahead = 4: replays on both sides of a block boundary
+        a.step(); b.step()
+    torch.cuda.synchronize()
+    assert b.use_graph and len(b._graphs) == 4
+    assert torch.equal(a.params.flat, b.params.flat) and torch.equal(a.m, b.m)
+    assert torch.equal(a.idx, b.idx) and int(b.step_dev.item()) == 6
+    np.testing.assert_array_equal(b.idx.cpu().numpy().reshape(B, 3), osampler.device_triplets_vec(pairs_np, N, 1234, 5, B))
+    assert np.isfinite(b.loss())
+    del a, b, table
+    torch.cuda.empty_cache()
 
 
 # --------------------------------------------------------- config 3, per-GPU shape --

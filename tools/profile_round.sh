@@ -22,6 +22,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
       --no-cpu-baseline --no-extras --no-settle --no-kernel-timers > /dev/null 2> $OUT/pmc_$C.err
   echo "[profile] pmc $C done"
 done
+# (copy this summary to profiles/latest_pmc.csv -- latest_pmc_bf16.csv for --precision bf16 -- and note
+#  its date and commit in profiles/latest_pmc.json: bench.py quotes both in `traffic_source`)
 python3 $ROOT/tools/pmc_summary.py $ROOT/gpurun_out/${TAG}_pmc_fetch_write.csv \
     FETCH_SIZE=$(find $OUT/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) \
     WRITE_SIZE=$(find $OUT/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) > /dev/null
