@@ -795,7 +795,9 @@ def main():
         ts = train.TrainStep(table, pairs, B, output_size=D, hidden_size=H, margin=MARGIN, mode=mode,
                              optimizer="adam", base_learning_rate=0.01, seed=1234, weight_seed=42,
                              device=dev, exchange=exchange, grad_sync=grad_sync, slot0=rank * B,
-                             batch_global=world * B, use_graph=args.graph, precision=args.precision,
+                             batch_global=world * B, precision=args.precision,
+                             # N > 1: the overlapped replay (exchange graph on the prefetch stream); config 4's form
+                             use_graph=("split" if world > 1 else True) if args.graph else False,
                              train_table=args.train_table, gather_ahead=args.gather_ahead,
                              grad_sync_mode="bucketed" if args.grad_sync == "auto" else args.grad_sync)
         timers_on = not args.no_kernel_timers
@@ -878,7 +880,7 @@ def main():
                                       MARGIN),
                        "global_batch": world * B, "rows_per_triplet": rpt,
                        "parallelism": "dp%d" % world + ("" if world == 1 else " row-sharded table, all-to-all rows + all-reduce grads"),
-                       "hipgraph": bool(ts.use_graph), "trainable_table": bool(args.train_table),
+                       "hipgraph": ts.use_graph if ts.use_graph == "split" else bool(ts.use_graph), "trainable_table": bool(args.train_table),
                        "gather_steps_per_launch": ts.gather_ahead},
             "loss": round(loss, 6),
         }

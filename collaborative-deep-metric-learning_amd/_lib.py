@@ -91,6 +91,8 @@ SIGNATURES = {
     "cdml_momentum_step": (_i, [_p, _p, _p, _i64, _f, _p, _f, _i, _p]),
     "cdml_lars_scratch_floats": (_sz, []),
     "cdml_lars_step": (_i, [_p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p, _p]),
+    "cdml_lars_multi_scratch_floats": (_sz, []),
+    "cdml_lars_multi": (_i, [_p, _p, _p, _p, _p, _i, _f, _p, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
 }
 
 _lib = None

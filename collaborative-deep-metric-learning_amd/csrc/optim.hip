@@ -195,6 +195,106 @@ k_lars_apply(float *__restrict__ w, const float *__restrict__ g, float *__restri
   }
 }
 
+// ---- multi-tensor LARS: every variable of the flat parameter buffer in TWO launches ----------
+// The reference's own optimizer (train.py:354): per variable trust ratio, so per variable two norms.
+// cdml_lars_step is one variable at a time in three launches with 4-B lane accesses (13 launches a
+// step with the step counter: 196 us at the production shape against Adam's 48).  Here the
+// variables are SEGMENTS of one contiguous buffer (offsets and sizes multiples of 4 floats):
+//   k_lars_multi_norms  -- each block sums |w|^2 and |g|^2 over a slice of ONE segment (16-B loads,
+//                          blocks dealt to segments in proportion to their size), one partial pair per block;
+//   k_lars_multi_apply  -- every block first reduces the partials of all segments itself, in the
+//                          same fixed order (<= kLarsBlocks pairs out of L2: no third launch, no
+//                          hand-over between blocks), then streams its share of the flat buffer
+//                          with 16-B accesses; the last block advances the step counter on request.
+// Bytes: 2 x 4 x n for the norms + 5 x 4 x n for the update.
+constexpr int kMaxSeg = 8;
+struct LarsSegs {
+  int n_seg;
+  int64_t off[kMaxSeg + 1];       // float offsets into the flat buffer; off[n_seg] = total
+  int blk[kMaxSeg + 1];           // first norm block of each segment; blk[n_seg] = total norm blocks
+};
+
+__global__ void __launch_bounds__(kThreads)
+k_lars_multi_norms(const float *__restrict__ w, const float *__restrict__ g, LarsSegs S,
+                   float *__restrict__ scratch) {
+  __shared__ double s[2][kThreads / kWave];
+  int seg = 0;
+#pragma unroll
+  for (int k = 1; k < kMaxSeg; ++k) seg += (k < S.n_seg && (int)blockIdx.x >= S.blk[k]) ? 1 : 0;
+  const int nb = S.blk[seg + 1] - S.blk[seg], b = blockIdx.x - S.blk[seg];
+  const int64_t lo4 = S.off[seg] >> 2, hi4 = S.off[seg + 1] >> 2;
+  float sw = 0.f, sg = 0.f;
+  for (int64_t i = lo4 + (int64_t)b * kThreads + threadIdx.x; i < hi4; i += (int64_t)nb * kThreads) {
+    const float4 a = reinterpret_cast<const float4 *>(w)[i];
+    const float4 c = reinterpret_cast<const float4 *>(g)[i];
+    sw += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    sg += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+  }
+  sw = wave_sum(sw);
+  sg = wave_sum(sg);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  if (lane == 0) { s[0][wave] = sw; s[1][wave] = sg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, c = 0;
+    for (int k = 0; k < kThreads / kWave; ++k) { a += s[0][k]; c += s[1][k]; }
+    scratch[2 * blockIdx.x] = (float)a;
+    scratch[2 * blockIdx.x + 1] = (float)c;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_lars_multi_apply(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ acc, LarsSegs S,
+                   float lr_imm, const float *__restrict__ lr_dev, float momentum, float wd, float eeta,
+                   float eps, const float *__restrict__ scratch, float *__restrict__ norms_out,
+                   uint64_t *__restrict__ step_dev, uint32_t *__restrict__ tickets) {
+  __shared__ double s_part[2][kThreads / kWave];
+  __shared__ float s_slr[kMaxSeg];
+  const float lr = lr_dev ? *lr_dev : lr_imm;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  for (int seg = 0; seg < S.n_seg; ++seg) {           // every block, the same order: the same trust ratios
+    double a = 0, c = 0;
+    for (int k = S.blk[seg] + threadIdx.x; k < S.blk[seg + 1]; k += kThreads) {
+      a += (double)scratch[2 * k];
+      c += (double)scratch[2 * k + 1];
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, kWave);
+      c += __shfl_xor(c, o, kWave);
+    }
+    if (lane == 0) { s_part[0][wave] = a; s_part[1][wave] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double wn2 = 0, gn2 = 0;
+      for (int k = 0; k < kThreads / kWave; ++k) { wn2 += s_part[0][k]; gn2 += s_part[1][k]; }
+      const float wn = sqrtf((float)wn2), gn = sqrtf((float)gn2);
+      const float trust = (wn > 0.f && gn > 0.f) ? eeta * wn / (gn + wd * wn + eps) : 1.0f;
+      s_slr[seg] = lr * trust;
+      if (norms_out && blockIdx.x == 0) { norms_out[2 * seg] = wn; norms_out[2 * seg + 1] = gn; }
+    }
+    __syncthreads();
+  }
+  const int64_t n4 = S.off[S.n_seg] >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kThreads) {
+    int seg = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxSeg; ++k) seg += (k < S.n_seg && 4 * i >= S.off[k]) ? 1 : 0;
+    const float slr = s_slr[seg];
+    float4 w4 = reinterpret_cast<float4 *>(w)[i];
+    const float4 g4 = reinterpret_cast<const float4 *>(g)[i];
+    float4 a4 = reinterpret_cast<float4 *>(acc)[i];
+#define CDML_LARS1(c)                                    \
+  a4.c = momentum * a4.c + slr * (g4.c + wd * w4.c);     \
+  w4.c -= a4.c;
+    CDML_LARS1(x) CDML_LARS1(y) CDML_LARS1(z) CDML_LARS1(w)
+#undef CDML_LARS1
+    reinterpret_cast<float4 *>(acc)[i] = a4;
+    reinterpret_cast<float4 *>(w)[i] = w4;
+  }
+  if (step_dev && grid_last_block(tickets) && threadIdx.x == 0) *step_dev += 1;
+}
+
 // ---- build_graph's gradient options (train.py:133-145), off in the reference's own run -------
 // One variable at a time, in place, before the optimizer:
 //   g <- g + l2_scale * w                 the slim l2_regularizer term of a weight matrix
@@ -312,6 +412,46 @@ extern "C" int cdml_lars_step(float *w, const float *g, float *acc, int64_t n, f
   hipLaunchKernelGGL(k_lars_apply, dim3(grid_elems(n, 4)), dim3(kThreads), 0, s, w, g, acc, n, lr,
                      lr_dev, momentum, weight_decay, eeta, eps, scratch);
   return check_launch("lars_step");
+}
+
+extern "C" size_t cdml_lars_multi_scratch_floats(void) { return 2 * (size_t)kLarsBlocks; }
+
+extern "C" int cdml_lars_multi(float *w, const float *g, float *acc, const int64_t *seg_offsets,
+                               const int64_t *seg_sizes, int n_seg, float lr, const float *lr_dev,
+                               float momentum, float weight_decay, float eeta, float eps, float *scratch,
+                               float *norms_out, uint64_t *step_dev_advance, uint32_t *tickets,
+                               cdml_stream_t stream) {
+  CDML_REQUIRE(w && g && acc && scratch && seg_offsets && seg_sizes, CDML_E_BADARG, "lars_multi: bad argument");
+  CDML_REQUIRE(n_seg >= 1 && n_seg <= kMaxSeg, CDML_E_UNSUPPORTED, "lars_multi: 1..%d segments, got %d", kMaxSeg, n_seg);
+  CDML_REQUIRE(!step_dev_advance || tickets, CDML_E_BADARG, "lars_multi: advancing the step counter needs the ticket words");
+  CDML_REQUIRE(aligned16(w) && aligned16(g) && aligned16(acc), CDML_E_ALIGN, "lars_multi: buffers must be 16-B aligned");
+  LarsSegs S;
+  S.n_seg = n_seg;
+  int64_t total = 0;
+  for (int k = 0; k < n_seg; ++k) {
+    CDML_REQUIRE(seg_sizes[k] > 0 && (seg_sizes[k] & 3) == 0 && seg_offsets[k] == total, CDML_E_BADARG,
+                 "lars_multi: segments must tile the buffer contiguously in multiples of 4 floats (segment %d)", k);
+    S.off[k] = total;
+    total += seg_sizes[k];
+  }
+  S.off[n_seg] = total;
+  // norm blocks in proportion to the segment sizes, at least one each, kLarsBlocks at most in all
+  const int budget = kLarsBlocks - n_seg;
+  int nb = 0;
+  for (int k = 0; k < n_seg; ++k) {
+    S.blk[k] = nb;
+    int64_t want = (seg_sizes[k] / 4 + kThreads * 8 - 1) / (kThreads * 8);          // >= 8 float4 per thread
+    const int64_t share = 1 + (int64_t)((double)budget * (double)seg_sizes[k] / (double)total);
+    if (want > share) want = share;
+    nb += (int)(want < 1 ? 1 : want);
+  }
+  S.blk[n_seg] = nb;
+  for (int k = n_seg + 1; k <= kMaxSeg; ++k) { S.off[k] = total; S.blk[k] = nb; }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_lars_multi_norms, dim3(nb), dim3(kThreads), 0, s, w, g, S, scratch);
+  hipLaunchKernelGGL(k_lars_multi_apply, dim3(grid_elems(total, 4)), dim3(kThreads), 0, s, w, g, acc, S, lr, lr_dev,
+                     momentum, weight_decay, eeta, eps, scratch, norms_out, step_dev_advance, tickets);
+  return check_launch("lars_multi");
 }
 
 extern "C" int cdml_grad_prepare(float *g, const float *w, int64_t n, float l2_scale, float clip_norm,

@@ -284,11 +284,11 @@ class Prefetcher:
     the step's forward pass: forking it onto the side stream would put RCCL's own stream two forks
     deep -- capturing stream -> side stream -> communicator stream -- and on this stack (torch
     2.10, RCCL 2.26, HIP 7.0) that never returns from the capture (profiles/
-    r02_rccl_graph_capture_probe.txt: one fork deep every collective captures and replays
+    r03_rccl_graph_capture_probe.txt: one fork deep every collective captures and replays
     correctly, two deep it hangs or crashes in hipStreamEndCapture).  The overlapped form of a
-    replayed step is therefore TWO graphs per step (train.TrainStep, ``use_graph="split"``): the
-    exchange captured with THIS stream as the capture origin, the compute step with the compute
-    stream as origin -- each communicator stream is then one fork from its origin -- ordered by
+    replayed step is therefore SEVERAL graphs per step (train.TrainStep, ``use_graph="split"``): the
+    exchange captured with THIS stream as the capture origin, the compute step (in two parts) with
+    the compute stream as origin -- each communicator stream is then one fork from its origin -- ordered by
     events recorded eagerly between the two replays.  The event hand-over between steps is not
     needed inside a single-graph replay (consecutive replays are ordered by the stream) and could
     not be captured anyway: its events belong to earlier launches."""

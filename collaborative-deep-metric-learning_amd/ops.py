@@ -464,3 +464,19 @@ def lars_step(w, g, acc, lr, scratch, momentum=0.9, weight_decay=1e-4, eeta=1e-3
               lr_dev=None):
     call("cdml_lars_step", _p(w), _p(g), _p(acc), w.numel(), lr, _p(lr_dev), momentum, weight_decay,
          eeta, eps, _p(scratch), _stream())
+
+
+def lars_multi_scratch_floats():
+    return int(load_library().cdml_lars_multi_scratch_floats())
+
+
+def lars_multi(w, g, acc, segments, lr, scratch, momentum=0.9, weight_decay=1e-4, eeta=1e-3, eps=0.0,
+               lr_dev=None, norms_out=None, step_dev=None, tickets=None):
+    """LARS on every variable of the flat buffer in two launches: ``segments`` = [(offset, numel), ...]
+    tiling w contiguously; step_dev (with tickets): also global_step += 1."""
+    n = len(segments)
+    offs = (C.c_int64 * n)(*[int(o) for o, _ in segments])
+    sizes = (C.c_int64 * n)(*[int(m) for _, m in segments])
+    call("cdml_lars_multi", _p(w), _p(g), _p(acc), C.cast(offs, C.c_void_p), C.cast(sizes, C.c_void_p), n, lr,
+         _p(lr_dev), momentum, weight_decay, eeta, eps, _p(scratch), _p(norms_out), _p(step_dev, torch.int64),
+         _p(tickets, torch.int32), _stream())

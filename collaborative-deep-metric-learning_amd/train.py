@@ -50,6 +50,14 @@ class TrainStep:
         ``grad_sync``: the multi-GPU hooks of cdml_amd.dist (None on one GPU).
         ``train_table``: also train the catalogue rows (lazy Adam, states stored beside the
         shard; build-defined -- the reference keeps the features frozen, train.py:265).
+        ``use_graph``: False = eager; True = the whole step replayed from ONE hipGraph (single GPU: the
+        fast form; data-parallel: the exchange of step t+1 is then recorded on the capturing stream,
+        ahead of the forward pass, not under it); "split" (data-parallel with the prefetcher) = three
+        graphs per step -- the exchange captured with the prefetch stream as capture origin, forward +
+        loss and backward + all-reduce + optimizer with the compute stream as origin -- replayed on
+        their own streams and ordered by events recorded eagerly between the replays, so the exchange
+        of step t+1 runs UNDER step t's forward GEMMs as in the eager step and every RCCL stream is one
+        fork from its capture origin (two deep hangs on this stack: dist.Prefetcher).
         ``gather_ahead``: steps fetched per launch of the fused sampler+gather (single-GPU fp32
         path): the sampler is counter-based, so one launch samples and gathers the rows of
         this step and the next gather_ahead-1 into their own buffers.
@@ -140,7 +148,8 @@ class TrainStep:
             self.v = torch.zeros(n, dtype=f32, device=dev)
         else:
             self.acc = torch.zeros(n, dtype=f32, device=dev)
-        self.lars_scratch = torch.zeros(ops.lars_scratch_floats(), dtype=f32, device=dev)
+        self.lars_scratch = torch.zeros(max(ops.lars_scratch_floats(), ops.lars_multi_scratch_floats()), dtype=f32,
+                                        device=dev)
         self.clip_gradient_norm = float(clip_gradient_norm)
         self.reg_scale = float(regularization_penalty) * float(l2_penalty)
         self.l2_penalty = float(l2_penalty)
@@ -177,7 +186,7 @@ class TrainStep:
         self._replayed = False                           # the previous step was a graph replay
         # the data-parallel step is enqueue-only too (fixed-capacity exchange, no host counts), so
         # it captures like the single-GPU one: one graph per prefetch buffer
-        self.use_graph = bool(use_graph)
+        self.use_graph = "split" if use_graph == "split" else bool(use_graph)
         if self.use_graph and self.train_table and exchange is not None:
             self.use_graph = False                       # scatter_back sizes its scratch on the fly
             logging.getLogger("cdml.train").warning("use_graph ignored: trainable sharded table runs eagerly")
@@ -201,6 +210,8 @@ class TrainStep:
             self._x = [self.ws.x_hat, torch.zeros_like(self.ws.x_hat)]
             self._idx = [self.idx, torch.zeros_like(self.idx)]
             self._shift = [self.shift, torch.zeros_like(self.shift)]
+        if self.use_graph == "split" and self.prefetch is None:
+            self.use_graph = True                        # nothing to overlap: one graph per step
 
     @property
     def grad_sync_mode(self):
@@ -387,12 +398,13 @@ class TrainStep:
         elif self.optimizer == "momentum":
             ops.momentum_step(p.flat, p.grad, self.acc, 0.0, 0.9, True, lr_dev=self.lr_dev)
         else:
-            for off, n in p.segments():       # LARS trust ratio is per variable
-                ops.lars_step(p.flat[off:off + n], p.grad[off:off + n], self.acc[off:off + n],
-                              0.0, self.lars_scratch, lr_dev=self.lr_dev)
+            # LARS: one trust ratio per variable, all four variables in two launches; the second
+            # also advances the step counter
+            ops.lars_multi(p.flat, p.grad, self.acc, p.segments(), 0.0, self.lars_scratch, lr_dev=self.lr_dev,
+                           step_dev=self.step_dev, tickets=self.adam_tickets)
         if self.bf16 and self.optimizer != "adam":
             engine_bf16.refresh_weights(p, self.ws)
-        if self.optimizer != "adam":
+        if self.optimizer == "momentum":
             ops.step_advance(self.step_dev)
 
     def _enqueue(self):
@@ -406,17 +418,22 @@ class TrainStep:
             self.prefetch.launch(1 - b, lambda: self._fill(1 - b, t + 1))
             self._filled = t + 1
         self.forward_loss()
+        self._backward_and_update(b if self.prefetch is not None else None)
+
+    def _backward_and_update(self, b):
+        """Backward (with the gradient all-reduce hooks), then the optimizer.  ``b``: the prefetch
+        buffer this step computes on (None without a prefetcher)."""
         if self.grad_sync is None:
             self.backward()
         elif self._grad_sync_mode == "single":
             # the single-GPU backward (both weight gradients in one stream-K launch), then one
             # all-reduce of the whole flat gradient, issued once the exchange of step t+1 is done
             self.backward()
-            if self.prefetch is not None:
+            if b is not None:
                 self.prefetch.wait_ready(1 - b)
             self.grad_sync.finish([self.grad_sync.start(self.params.grad, 0, self.layout.numel)])
         else:
-            if self.prefetch is not None:
+            if b is not None:
                 self.prefetch.wait_ready(1 - b)
             # buckets: [dW1|db1] (85 % of the bytes) is all-reduced while later GEMMs run, in two
             # row blocks -- the first under the second block's GEMM, the second under the dW2
@@ -428,7 +445,7 @@ class TrainStep:
                 after_w1_chunk=lambda lo, hi: handles.append(self.grad_sync.start(self.params.grad, lo, hi)))
             handles.append(self.grad_sync.start(self.params.grad, n1, self.layout.numel))
             self.grad_sync.finish(handles)
-        if self.prefetch is not None:
+        if b is not None:
             self.prefetch.release(b)                 # backward was the last reader of x_hat[b]
         if self.train_table:
             self.update_table()
@@ -442,7 +459,10 @@ class TrainStep:
         if lr != self._lr_host:                         # staircase: rare
             self.lr_dev.fill_(lr)
             self._lr_host = lr
-        if self.use_graph and self._warmed:              # the first step of a process runs eagerly
+        if self.use_graph == "split" and self._warmed and self.prefetch is not None:
+            self._step_split(self.global_step)
+            self._replayed = True
+        elif self.use_graph and self._warmed:            # the first step of a process runs eagerly
             t = self.global_step                         # (it loads the kernels), also after a resume
             if self.prefetch is not None:
                 # one graph per prefetch buffer; the rows of step t were fetched by step t-1 (an
@@ -474,18 +494,49 @@ class TrainStep:
             self._warmed = True
         self.global_step += 1
 
-    def _capture(self):
+    def _capture(self, fn=None, origin=None):
+        """Record ``fn`` (default: the whole step) into a hipGraph.  ``origin``: the stream the capture
+        starts on (default: a fresh one) -- RCCL's communicator stream is then one fork from it."""
         torch.cuda.synchronize(self.device)
-        side = torch.cuda.Stream(self.device)
+        side = torch.cuda.Stream(self.device) if origin is None else origin
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             g = torch.cuda.CUDAGraph()
             # thread-local capture mode: the RCCL watchdog thread of torch.distributed may touch
             # the runtime while this thread captures
             with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                self._enqueue()
+                (fn or self._enqueue)()
         torch.cuda.current_stream(self.device).wait_stream(side)
         return g
+
+    def _step_split(self, t):
+        """One data-parallel step as three graph replays (``use_graph="split"``): the exchange of step
+        t+1 on the prefetch stream, forward + loss, then -- once that exchange has finished --
+        backward + all-reduce + optimizer on the compute stream; the events between them are recorded
+        eagerly, exactly where the eager step records them.  The exchange graph reads the device step
+        counter (+1): it runs after the optimizer of step t-1 advanced it (the buffer-free event) and
+        before the optimizer of step t does (which waits for the exchange)."""
+        pf, b = self.prefetch, t % 2
+        if self._filled != t:
+            raise RuntimeError("graph replay needs the previous step's prefetch (step %d)" % t)
+        G = self._graphs
+        if ("E", 1 - b) not in G:
+            G[("E", 1 - b)] = self._capture(lambda: self._fill(1 - b, None), origin=pf.stream)
+        self.ws.x_hat, self.idx, self.shift = self._x[b], self._idx[b], self._shift[b]
+        if ("F", b) not in G:
+            G[("F", b)] = self._capture(self.forward_loss)
+            G[("B", b)] = self._capture(lambda: self._backward_and_update(None))
+        pf.acquire(b)                                    # rows of step t (fetched during step t-1)
+        with torch.cuda.stream(pf.stream):
+            if pf._released[1 - b]:
+                pf.stream.wait_event(pf.free[1 - b])     # step t-1 is done with that buffer (and has advanced the counter)
+            G[("E", 1 - b)].replay()
+            pf.ready[1 - b].record(pf.stream)
+        self._filled = t + 1
+        G[("F", b)].replay()
+        pf.wait_ready(1 - b)                             # the all-reduce is issued only after the exchange
+        G[("B", b)].replay()
+        pf.release(b)
 
     def check_inputs(self):
         """Host check of the device-side input flags (synchronises; called by ``loss()``, by the

@@ -467,6 +467,21 @@ int cdml_lars_step(float *w, const float *g, float *acc, int64_t n, float lr,
                    const float *lr_dev, float momentum, float weight_decay,
                    float eeta, float eps, float *scratch, cdml_stream_t stream);
 
+/* The same update for EVERY variable of a flat parameter buffer in two launches (the training
+ * step's form; the reference applies LARS to weights and biases alike, train.py:354): the
+ * variables are n_seg (<= 8) contiguous segments, seg_offsets[k] = sum of the sizes before k,
+ * sizes multiples of 4 floats (host arrays).  One trust ratio per segment; 16-B accesses.
+ * scratch: cdml_lars_multi_scratch_floats() floats.  norms_out (nullable): float[2*n_seg] =
+ * {|w|, |g|} per segment.  step_dev_advance (nullable): *step_dev_advance += 1 by the last
+ * block of the update (train.py:146 apply_gradients(global_step=...)); needs `tickets`
+ * (CDML_TICKET_WORDS zeroed uint32, as cdml_adam_step). */
+size_t cdml_lars_multi_scratch_floats(void);
+int cdml_lars_multi(float *w, const float *g, float *acc, const int64_t *seg_offsets,
+                    const int64_t *seg_sizes, int n_seg, float lr, const float *lr_dev,
+                    float momentum, float weight_decay, float eeta, float eps,
+                    float *scratch, float *norms_out, uint64_t *step_dev_advance,
+                    uint32_t *tickets, cdml_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -249,46 +249,55 @@ def _nccl_graph_worker(port, q):
                                         output_size=CFG["D"], mode="uniform", device=dev,
                                         exchange=cdist.RowExchange(CFG["n_rows"], group=dist.new_group(), skip_self=False),
                                         grad_sync=sync, batch_global=2 * CFG["B"], use_graph=g_)
-        e1, g1 = mk(False), mk(True)
+        # g1: one graph per step (exchange on the capturing stream); s1: VERDICT r2 #8 -- three graphs per
+        # step, the exchange captured with the prefetch stream as origin and replayed UNDER the forward pass
+        e1, g1, s1 = mk(False), mk(True), mk("split")
         for i in range(6):
             _say("step %d eager" % i)
             e1.step()
             _say("step %d graph path" % i)
             g1.step()
+            _say("step %d split-graph path" % i)
+            s1.step()
         torch.cuda.synchronize()
         _say("replays done")
-        same = lambda: (torch.equal(e1.params.flat, g1.params.flat) and torch.equal(e1.idx, g1.idx)
-                        and int(g1.step_dev.item()) == e1.global_step == g1.global_step)
+        same = lambda: all(torch.equal(e1.params.flat, x.params.flat) and torch.equal(e1.idx, x.idx)
+                           and int(x.step_dev.item()) == e1.global_step == x.global_step for x in (g1, s1))
+        diff = lambda: max(float((e1.params.flat - x.params.flat).abs().max()) for x in (g1, s1))
         msg = "ok"
-        if len(g1._graphs) != 2:
-            msg = "expected 2 captured graphs, got %d" % len(g1._graphs)
+        if len(g1._graphs) != 2 or len(s1._graphs) != 6 or s1.use_graph != "split":
+            msg = "expected 2 / 6 captured graphs, got %d / %d" % (len(g1._graphs), len(s1._graphs))
         elif not same():
-            msg = "graph replay differs from eager: %g" % float((e1.params.flat - g1.params.flat).abs().max())
+            msg = "graph replay differs from eager: %g" % diff()
         if msg == "ok":
             # replay -> eager -> replay with NO device sync in between (the side stream must
             # not overwrite a prefetch buffer a queued replay still reads) == an all-eager run
             for use in (False, False, True, True):
                 g1.use_graph = use
+                s1.use_graph = "split" if use else False
                 g1.step()
+                s1.step()
                 e1.step()
             torch.cuda.synchronize()
             _say("toggled")
             if not same():
-                msg = "replay->eager->replay differs from eager: %g" % float((e1.params.flat - g1.params.flat).abs().max())
+                msg = "replay->eager->replay differs from eager: %g" % diff()
         if msg == "ok":
             # resume() in a process that has already stepped -- the next step runs eagerly
             # (and refills the prefetch buffer), the one after replays again
             state = e1.state_dict()
             for _ in range(2):
-                e1.step(); g1.step()
+                e1.step(); g1.step(); s1.step()
             g1.load_state_dict(state)
+            s1.load_state_dict(state)
             for _ in range(2):
-                g1.step()
+                g1.step(); s1.step()
             torch.cuda.synchronize()
             _say("resumed")
             if not same():
-                msg = "mid-run resume differs from eager: %g" % float((e1.params.flat - g1.params.flat).abs().max())
+                msg = "mid-run resume differs from eager: %g" % diff()
         g1._graphs.clear()                               # graphs go before the communicators they recorded
+        s1._graphs.clear()
         torch.cuda.synchronize()
         q.put(msg)
         dist.destroy_process_group()

@@ -678,6 +678,41 @@ def test_lars_vs_oracle(cd):
     np.testing.assert_allclose(z.cpu().numpy(), -1.0)
 
 
+def test_lars_multi_vs_oracle_and_single_variable_kernel(cd):
+    """The training step's LARS: every variable of the flat buffer in two launches (one trust ratio per
+    segment, the reference's tf.contrib LARSOptimizer on weights and biases alike, train.py:354) ==
+    the oracle per variable, == cdml_lars_step per variable, and the last block advances the counter."""
+    rng = np.random.RandomState(1)
+    sizes = [64 * 130, 128, 128 * 64, 64]                       # W1, b1, W2, b2-like; multiples of 4
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    n = int(sum(sizes))
+    w = rng.randn(n).astype(np.float32) * np.repeat([1.0, 0.1, 0.5, 0.0], sizes).astype(np.float32)   # last: |w| = 0
+    g = (rng.randn(n) * 0.05).astype(np.float32)
+    acc = np.zeros(n, np.float32)
+    segs = list(zip(offs.tolist(), sizes))
+    dw, da = dt(w, cd.dev), dt(acc, cd.dev)
+    dw1, da1 = dw.clone(), da.clone()
+    scratch = torch.zeros(max(cd.ops.lars_multi_scratch_floats(), cd.ops.lars_scratch_floats()), device=cd.dev)
+    norms = torch.zeros(8, device=cd.dev)
+    step = torch.zeros(1, dtype=torch.int64, device=cd.dev)
+    tickets = cd.ops.new_tickets(cd.dev)
+    for it in range(3):
+        dg = dt(g, cd.dev)
+        cd.ops.lars_multi(dw, dg, da, segs, 1.0, scratch, norms_out=norms, step_dev=step, tickets=tickets)
+        for o, m in segs:
+            cd.ops.lars_step(dw1[o:o + m], dg[o:o + m], da1[o:o + m], 1.0, scratch)
+            w[o:o + m], acc[o:o + m] = otower.lars_step(w[o:o + m], g[o:o + m], acc[o:o + m], 1.0, dtype=np.float64)
+        np.testing.assert_allclose(dw.cpu().numpy(), w, atol=1e-6)
+        np.testing.assert_allclose(da.cpu().numpy(), acc, atol=1e-6)
+        np.testing.assert_allclose(dw.cpu().numpy(), dw1.cpu().numpy(), atol=2e-7)
+        g = (rng.randn(n) * 0.05).astype(np.float32)
+    assert int(step.item()) == 3
+    got = norms.cpu().numpy().reshape(4, 2)
+    assert got[3, 1] > 0 and np.all(got[:, 0] > 0)              # (|w| of the last segment is no longer 0 after a step)
+    with pytest.raises(Exception):
+        cd.ops.lars_multi(dw, dt(g, cd.dev), da, [(0, 6), (6, n - 6)], 1.0, scratch)     # not multiples of 4
+
+
 # ------------------------------------------------------------ end-to-end step --
 def _oracle_step(feats, pairs, W, step, B, mode, seed, margin=0.8):
     """Embeddings, loss and gradients of one reference step from weights W (fp64)."""

@@ -1,7 +1,10 @@
 """Which torch.distributed settings let RCCL collectives be captured into a hipGraph on this stack?
 One child process per setting (world size 1 on cuda:0 -- the box has one GPU), each with its own
 timeout; a child that hangs is killed by handle.  Prints one line per setting.
-usage: python tools/probes/rccl_graph_capture.py"""
+usage: python tools/probes/rccl_graph_capture.py [--two-deep]
+  --two-deep  also try the collectives issued two stream-forks away from the capturing stream (round 2:
+              those never return from the capture on torch 2.10 / RCCL 2.26 / HIP 7.0 -- the child is killed
+              by handle after 60 s without progress)"""
 import multiprocessing as mp
 import os
 import socket
@@ -38,8 +41,10 @@ def child(name, env, port, q):
         dist.all_to_all_single(o, a, group=grp2)
         torch.cuda.synchronize()
         fork = torch.cuda.Stream(dev)
-        for what in ("all_reduce", "all_reduce_async", "all_to_all", "two_all_to_all", "all_to_all_other_group",
-                     "all_to_all_on_forked_stream", "all_to_all_other_group_on_forked_stream"):
+        cases = ["all_reduce", "all_reduce_async", "all_to_all", "two_all_to_all", "all_to_all_other_group"]
+        if "--two-deep" in sys.argv[1:]:
+            cases += ["all_to_all_on_forked_stream", "all_to_all_other_group_on_forked_stream"]
+        for what in cases:
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             g = torch.cuda.CUDAGraph()
