@@ -70,6 +70,7 @@ SIGNATURES = {
     "cdml_row_sqnorm": (_i, [_p, _i64, _i, _i, _p, _p]),
     "cdml_knn_merge": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
     "cdml_gemm_bf16_workspace": (_sz, [_i, _i, _i]),
+    "cdml_gemm_bf16_epilogue_supported": (_i, [_i, _i, _i, _i, _i64, _i64, _i64, _i64]),
     "cdml_gemm_bf16_nt": (_i, [_i, _p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _i64, _f, _p, _sz, _p]),
     "cdml_gemm_bf16_tn_supported": (_i, [_i, _i, _i, _i64, _i64]),
     "cdml_gemm_bf16_tn_workspace": (_sz, [_i, _i, _i]),
@@ -84,7 +85,8 @@ SIGNATURES = {
     "cdml_ew_fusion_bwd": (_i, [_i, _p, _i64, _p, _i64, _p, _i64, _i, _i, _f, _p, _i64, _p, _i64, _p]),
     "cdml_lrelu_bwd": (_i, [_p, _i64, _p, _i64, _i, _i, _f, _p, _i64, _p]),
     "cdml_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _i64, _p, _i, _p, _p]),
-    "cdml_adam_matrix_bf16": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _f, _f, _f, _i64, _p, _p, _i64, _p, _i64, _p]),
+    "cdml_adam_matrix_bf16": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _f, _f, _f, _i64, _p, _p, _i64, _p, _i64,
+                                   _p, _p, _p, _p, _i, _i, _p, _p]),
     "cdml_table_adam_rows": (_i, [_p, _i64, _i64, _i64, _i, _p, _i, _p, _i64, _p, _p, _p, _p, _f, _f, _p, _f, _f, _f,
                                   _i64, _p, _p]),
     "cdml_grad_prepare": (_i, [_p, _p, _i64, _f, _f, _p, _p, _p]),

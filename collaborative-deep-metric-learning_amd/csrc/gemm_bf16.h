@@ -7,7 +7,12 @@ namespace cdml {
 
 using bf16 = __bf16;
 
-enum { BE_BIAS_LRELU_BF16 = 0, BE_BIAS_LRELU_F32 = 1, BE_MASK_BF16 = 2, BE_F32 = 3 };
+// 4 = epilogue 0 that ALSO writes the sign bitmask of its output (bit j of byte b of row r = C[r][8b+j] > 0)
+// to `aux` (uint8 [M][ldaux bytes]); 5 = epilogue 2 reading that bitmask instead of the bf16 activations:
+// the leaky-relu derivative needs one bit per element, not the 2-byte value (252 MB -> 16 MB per step at
+// config 4's shape).  4 runs on the 256x256 kernel only, 5 on the K = 256 streaming kernel only.
+enum { BE_BIAS_LRELU_BF16 = 0, BE_BIAS_LRELU_F32 = 1, BE_MASK_BF16 = 2, BE_F32 = 3, BE_BIAS_LRELU_BF16_BITS = 4,
+       BE_MASKBITS_BF16 = 5 };
 
 struct BArgs {
   const bf16 *A; int64_t lda;
@@ -21,6 +26,8 @@ struct BArgs {
   int64_t slab_stride;
   int tiles_m, tiles_n;
   float *colsum_partial;   // k-strided form only: [splits*tiles_m*2][N] column sums of B (nullable)
+  uint8_t *mask_out; int64_t ldmask;   // epilogue 0 on the 256x256 kernel: sign bitmask of C (nullable), bytes per row
+  int aux_bits;            // K = 256 streaming kernel: aux is that bitmask (ldaux in bytes), not bf16 values
 };
 
 // 256x256x64 kernel: true if the shape can use it (N % 256 == 0, K per split a

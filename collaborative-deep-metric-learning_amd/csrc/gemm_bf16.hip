@@ -418,19 +418,37 @@ extern "C" size_t cdml_gemm_bf16_workspace(int M, int N, int K) {
   return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
+extern "C" int cdml_gemm_bf16_epilogue_supported(int epilogue, int M, int N, int K, int64_t lda, int64_t ldb,
+                                                 int64_t ldc, int64_t ldaux) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (epilogue >= 0 && epilogue <= 3) return (N % BN == 0 && K % BKB == 0) ? 1 : 0;
+  if (epilogue == BE_BIAS_LRELU_BF16_BITS)
+    return (gemm_bf16_256_usable(M, N, K, lda, ldb) && ldaux * 8 >= N) ? 1 : 0;
+  if (epilogue == BE_MASKBITS_BF16)
+    return (K == 256 && N % 256 == 0 && !(lda & 7) && !(ldb & 7) && !(ldc & 7) && ldaux * 8 >= N &&
+            gemm_bf16_k256_usable(M, N, K, lda, ldb, ldc, 8, true)) ? 1 : 0;
+  return 0;
+}
+
 extern "C" int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda, const uint16_t *B,
                                  int64_t ldb, int M, int N, int K, void *C, int64_t ldc,
                                  const float *bias, const uint16_t *aux, int64_t ldaux, float alpha,
                                  void *workspace, size_t workspace_bytes, cdml_stream_t stream) {
   CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16_nt: bad argument");
-  CDML_REQUIRE(epilogue >= 0 && epilogue <= 3, CDML_E_BADARG, "gemm_bf16_nt: epilogue must be 0..3");
+  CDML_REQUIRE(epilogue >= 0 && epilogue <= 5, CDML_E_BADARG, "gemm_bf16_nt: epilogue must be 0..5");
   CDML_REQUIRE(N % BN == 0 && K % BKB == 0, CDML_E_UNSUPPORTED,
                "gemm_bf16_nt: N must be a multiple of 128 and K of 64, got N=%d K=%d", N, K);
   CDML_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && (lda & 7) == 0 && (ldb & 7) == 0 &&
                    (ldc & 3) == 0 && lda >= K && ldb >= K && ldc >= N,
                CDML_E_ALIGN, "gemm_bf16_nt: 16-B aligned bases, lda/ldb multiples of 8, ldc of 4");
-  CDML_REQUIRE(epilogue > 1 || bias, CDML_E_BADARG, "gemm_bf16_nt: bias required");
+  CDML_REQUIRE(epilogue > 1 && epilogue != BE_BIAS_LRELU_BF16_BITS ? true : bias != nullptr, CDML_E_BADARG,
+               "gemm_bf16_nt: bias required");
   BArgs g{};
+  if (epilogue == BE_BIAS_LRELU_BF16_BITS || epilogue == BE_MASKBITS_BF16) {
+    CDML_REQUIRE(aux && ldaux * 8 >= N && cdml_gemm_bf16_epilogue_supported(epilogue, M, N, K, lda, ldb, ldc, ldaux),
+                 CDML_E_UNSUPPORTED, "gemm_bf16_nt: the bitmask epilogue %d does not take M=%d N=%d K=%d "
+                 "(cdml_gemm_bf16_epilogue_supported); use epilogue %d", epilogue, M, N, K, epilogue == 4 ? 0 : 2);
+  }
   g.A = reinterpret_cast<const bf16 *>(A); g.lda = lda;
   g.B = reinterpret_cast<const bf16 *>(B); g.ldb = ldb;
   g.C = C; g.ldc = ldc; g.bias = bias;
@@ -439,6 +457,16 @@ extern "C" int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda, c
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = N / BN;
   hipStream_t s = (hipStream_t)stream;
   const dim3 block(kThreads);
+  if (epilogue == BE_BIAS_LRELU_BF16_BITS) {       // epilogue 0 on the 256x256 kernel + the sign bitmask
+    g.mask_out = reinterpret_cast<uint8_t *>(const_cast<uint16_t *>(aux)); g.ldmask = ldaux;
+    g.aux = nullptr; g.ldaux = 0;
+    g.tiles_m = (M + 255) / 256; g.tiles_n = N / 256;
+    return launch_gemm_bf16_256(g, BE_BIAS_LRELU_BF16, 1, s);
+  }
+  if (epilogue == BE_MASKBITS_BF16) {              // the K = 256 streaming kernel reading the bitmask
+    g.aux_bits = 1;
+    return launch_gemm_bf16_k256(g, s);
+  }
   if (epilogue == BE_BIAS_LRELU_F32) {
     const int fs = fwd_f32_splits(M, N, K, lda, ldb);
     const size_t need = (size_t)fs * M * N * sizeof(float);

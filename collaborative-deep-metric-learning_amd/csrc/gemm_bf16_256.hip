@@ -37,6 +37,11 @@
 //   A wave waits for its OWN pieces before a barrier; the read of the image comes two barriers
 //   later, after every wave of both groups has passed its wait.
 #include "gemm_bf16.h"
+#include <stdlib.h>
+
+#ifndef CDML_BF16_MFMA_DEFAULT
+#define CDML_BF16_MFMA_DEFAULT 16   // measured: profiles/r03_bf16_mfma_shape.txt
+#endif
 
 namespace cdml {
 namespace {
@@ -90,7 +95,11 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
 //   ch ^ (((row&3)<<2) | ((row>>2)&3)) on the DMA source; fragments come out of LDS
 //   already transposed through ds_read_b64_tr_b16 (two per 32x16 fragment), so no
 //   transposed copy of the activations is ever made.
-template <bool TN, int EPI>
+// S16: the same tile, images, DMA schedule and phases on v_mfma_f32_16x16x32_bf16 (32 MFMAs of 16 cycles
+// per phase instead of 16 of 32: equal cycles per flop; the chip holds a higher clock on this shape under
+// load, MI355X_MICROARCH.md 'DVFS give-back' item 7).  A fragment = 16 rows x 32 k (lane l: row l & 15,
+// k = 8 (l >> 4) .. +7): one ds_read_b128 of the same 128-B-row images; accumulators 8 x 4 blocks of 16 x 16.
+template <bool TN, int EPI, bool S16>
 __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   static_assert(!TN || EPI == BE_F32, "the k-strided form only serves the weight gradients");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -189,20 +198,60 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
       return tr_read(smem + buf * BUF + IMG + hh * 2 * IMG + ks * 4096, tb[0], tb[1]);
   };
 
-  f32x16 acc[4][2];
+  // S16 fragment reads: lane (l15, q) holds k = 32*ks2 + 8*q .. +7 of image row l15 (+ 16-row block)
+  const int l15 = lane & 15, q16 = lane >> 4;
+  const unsigned char *a16_rd = smem + (grp * 64 + l15) * 128;
+  const unsigned char *b16_rd = smem + IMG + (wc * 32 + l15) * 128;
+  const int sw16[2] = {((q16) ^ ((l15 >> 1) & 7)) * 16, ((4 + q16) ^ ((l15 >> 1) & 7)) * 16};
+  // TN: a 16x16x32 fragment = k-rows 8q .. 8q+7 of the 32-deep k-step for the 16 columns l15 of a column
+  // block: the 16-lane group q reads rows 8q+4sh .. +3 (sh = 0, 1) x 16 columns through ds_read_b64_tr_b16;
+  // a 32-lane half takes two blocks 8 rows apart in the same columns (conflict-free on this image, T10)
+  auto tr_off16 = [&](int c0, int sh) {
+    const int row = 8 * q16 + 4 * sh + tq;
+    const int swz = (tq << 2) | ((2 * q16 + sh) & 3);
+    return 256 * row + 16 * ((c0 + (tp >> 1)) ^ swz) + 8 * (tp & 1);
+  };
+  int ta16[4][2], tb16[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int sh = 0; sh < 2; ++sh) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int rb = 0; rb < 4; ++rb) ta16[rb][sh] = tr_off16(grp * 8 + 2 * rb, sh);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) tb16[cb][sh] = tr_off16(wc * 4 + 2 * cb, sh);
+  }
+  auto read_a16 = [&](int buf, int hh, int rb, int ks2) {
+    if constexpr (!TN)
+      return *reinterpret_cast<const bf16x8 *>(a16_rd + buf * BUF + hh * 2 * IMG + rb * 2048 + sw16[ks2]);
+    else
+      return tr_read(smem + buf * BUF + hh * 2 * IMG + ks2 * 8192, ta16[rb][0], ta16[rb][1]);
+  };
+  auto read_b16 = [&](int buf, int hh, int cb, int ks2) {
+    if constexpr (!TN)
+      return *reinterpret_cast<const bf16x8 *>(b16_rd + buf * BUF + hh * 2 * IMG + cb * 2048 + sw16[ks2]);
+    else
+      return tr_read(smem + buf * BUF + IMG + hh * 2 * IMG + ks2 * 8192, tb16[cb][0], tb16[cb][1]);
+  };
+
+  f32x16 acc[S16 ? 1 : 4][S16 ? 1 : 2];
+  f32x4 acc16[S16 ? 8 : 1][S16 ? 4 : 1];
+#pragma unroll
+  for (int i = 0; i < (S16 ? 1 : 4); ++i)
+#pragma unroll
+    for (int j = 0; j < (S16 ? 1 : 2); ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  bf16x8 fa[2][4], fb0[4], fb1[4];
+#pragma unroll
+  for (int i = 0; i < (S16 ? 8 : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (S16 ? 4 : 1); ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[2][4], fb0[4], fb1[4];     // 32x32x16: [mi][ks], [ks];  16x16x32: fa[ks2][rb], fb0 = [cb of half 0..1][ks2] ...
 
   // Bias gradient riding along (k-strided form): db[n] = sum_k B[k][n].  The tiles_m blocks and
   // two row groups that share a B tile split its K-tiles between them (tile t belongs to
   // (tm, grp) = (t % (2*tiles_m)) >> 1, & 1); the owner adds its fragments' 8 k-values per lane
   // in the read part of the phase, where the wave only waits anyway.
   float cs[2] = {0.f, 0.f};
+  float cs16[4] = {0.f, 0.f, 0.f, 0.f};      // S16: column blocks 0, 1 of B-h0 and of B-h1
   const bool cs_on = TN && g.colsum_partial != nullptr;
   const int cs_owner = 2 * tm + grp, cs_period = 2 * g.tiles_m;
   auto frag_sum = [&](const bf16x8 &f) {
@@ -231,6 +280,69 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   auto pin_b = [&]() {
     asm volatile("" : "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]), "+v"(fb0[3]),
                       "+v"(fb1[0]), "+v"(fb1[1]), "+v"(fb1[2]), "+v"(fb1[3]));
+  };
+  // 16x16x32 form of the K-tile: fb0[2*cb + ks2] = column block cb (0, 1) of B-h0, fb1 likewise of B-h1,
+  // fa[ks2][rb] = row block rb (0..3) of the phase's A half image
+  auto do_tile2_s16 = [&](const int buf, const int tile) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        fb0[2 * cb + ks2] = read_b16(buf, 0, cb, ks2);
+        fb1[2 * cb + ks2] = read_b16(buf, 1, cb, ks2);
+      }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) fa[ks2][rb] = read_a16(buf, 0, rb, ks2);
+    stage(0, 0, tile + 1, buf ^ 1);
+    stage(0, 1, tile + 1, buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    pin_b();
+    pin_a();
+    if (TN && cs_on && (tile % cs_period) == cs_owner) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          cs16[cb] += frag_sum(fb0[2 * cb + ks2]);
+          cs16[2 + cb] += frag_sum(fb1[2 * cb + ks2]);
+        }
+    }
+    CDML_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          acc16[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[rb][cb], 0, 0, 0);
+          acc16[rb][2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[rb][2 + cb], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    CDML_BARRIER();
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) fa[ks2][rb] = read_a16(buf, 1, rb, ks2);
+    stage(1, 0, tile + 2, buf);
+    stage(1, 1, tile + 2, buf);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    pin_a();
+    CDML_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          acc16[4 + rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 + rb][cb], 0, 0, 0);
+          acc16[4 + rb][2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 + rb][2 + cb], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    CDML_BARRIER();
   };
   auto do_tile2 = [&](const int buf, const int tile) {
 #pragma unroll
@@ -292,20 +404,35 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   CDML_BARRIER();
   if (grp == 1) CDML_BARRIER();                          // group 1 runs one barrier behind
   for (int tile = 0; tile < n_ktiles; tile += 2) {
-    do_tile2(0, tile);
-    do_tile2(1, tile + 1);
+    if constexpr (S16) {
+      do_tile2_s16(0, tile);
+      do_tile2_s16(1, tile + 1);
+    } else {
+      do_tile2(0, tile);
+      do_tile2(1, tile + 1);
+    }
   }
 
   if (grp == 0) CDML_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the out-of-range tail DMAs still write zeros
   CDML_BARRIER();
 
-  if (TN && cs_on) {   // lanes l31 / l31+32 hold the two k-halves of column l31
+  if (TN && cs_on && !S16) {   // lanes l31 / l31+32 hold the two k-halves of column l31
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const float v = cs[ct] + __shfl_xor(cs[ct], 32, 64);
       if (h == 0)
         g.colsum_partial[(int64_t)((split * g.tiles_m + tm) * 2 + grp) * g.N + n0 + ct * 128 + wc * 32 + l31] = v;
+    }
+  }
+  if (TN && cs_on && S16) {    // the four 16-lane groups hold the four k-quarters of column l15
+#pragma unroll
+    for (int cbt = 0; cbt < 4; ++cbt) {
+      float v = cs16[cbt] + __shfl_xor(cs16[cbt], 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (q16 == 0)
+        g.colsum_partial[(int64_t)((split * g.tiles_m + tm) * 2 + grp) * g.N + n0 + (cbt >> 1) * 128 + wc * 32 +
+                         (cbt & 1) * 16 + l15] = v;
     }
   }
 
@@ -334,20 +461,32 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
     float *strip = sC + (rt & 1) * 2048;                 // alternate halves: no wait for the readers
+    if constexpr (S16) {
+      // 16x16 blocks: lane (l15, q) holds column l15, rows 4q .. 4q+3.  Rows 4 apart share their banks
+      // (64-float rows): the column block is XOR-ed with 16 on odd q, so a store is 2-way (free), not 4-way
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+      for (int rbb = 0; rbb < 2; ++rbb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        strip[row * 64 + ct * 32 + l31] = acc[rt][ct][r];
-      }
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            strip[(rbb * 16 + q16 * 4 + r) * 64 + ((cb * 16 + l15) ^ ((q16 & 1) << 4))] = acc16[2 * rt + rbb][cb][r];
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          strip[row * 64 + ct * 32 + l31] = acc[rt][ct][r];
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int lr = p * 4 + (lane >> 4);
       const int row = out_row(rt, p);
-      f32x4 v = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + c4 * 4);
+      f32x4 v = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c4 * 4) ^ (S16 ? (((lr >> 2) & 1) << 4) : 0)));
       if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) {
         v += bias4;
         v.x = fmaxf(v.x, v.x * g.alpha); v.y = fmaxf(v.y, v.y * g.alpha);
@@ -359,10 +498,19 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
           v.z *= ((float)m.z > 0.f) ? 1.f : g.alpha; v.w *= ((float)m.w > 0.f) ? 1.f : g.alpha;
         }
       }
+      bf16x4 o;
+      o.x = (bf16)v.x; o.y = (bf16)v.y; o.z = (bf16)v.z; o.w = (bf16)v.w;
+      unsigned nib = 0;
+      if (EPI == BE_BIAS_LRELU_BF16 && g.mask_out) {       // sign bits of the 4 stored values; lanes c4, c4^1
+        nib = ((float)o.x > 0.f ? 1u : 0u) | ((float)o.y > 0.f ? 2u : 0u) | ((float)o.z > 0.f ? 4u : 0u) |
+              ((float)o.w > 0.f ? 8u : 0u);                 // share a byte (8 columns): the even lane stores it
+        const unsigned other = __shfl_xor(nib, 1, 64);
+        nib |= other << 4;
+      }
       if (row >= g.M) continue;                            // stores only below this line
       if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_MASK_BF16) {
-        bf16x4 o;
-        o.x = (bf16)v.x; o.y = (bf16)v.y; o.z = (bf16)v.z; o.w = (bf16)v.w;
+        if (EPI == BE_BIAS_LRELU_BF16 && g.mask_out && !(c4 & 1))
+          g.mask_out[(int64_t)row * g.ldmask + (gcol >> 3)] = (uint8_t)nib;
         *reinterpret_cast<bf16x4 *>(static_cast<bf16 *>(g.C) + (int64_t)row * g.ldc + gcol) = o;
       } else {
         float *C = static_cast<float *>(g.C) + (EPI == BE_F32 ? (int64_t)split * g.slab_stride : 0);
@@ -372,18 +520,31 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   }
 }
 
-template <bool TN, int EPI>
-int launch(const BArgs &g, int splits, hipStream_t s) {
+template <bool TN, int EPI, bool S16>
+int launch1(const BArgs &g, int splits, hipStream_t s) {
   static bool configured = false;   // raising the dynamic-LDS limit is idempotent; a race only repeats it
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI, S16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16_256: cannot reserve %d B of LDS: %s", SMEM,
                                      hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), SMEM, s, g);
+  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, S16>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), SMEM, s, g);
   return check_launch("gemm_bf16_256");
+}
+
+// MFMA shape: CDML_BF16_MFMA = "32" (v_mfma_f32_32x32x16_bf16) or "16"
+// (v_mfma_f32_16x16x32_bf16); read per call so that one process can time both on one device
+static bool shape16() {
+  const char *e = getenv("CDML_BF16_MFMA");
+  return e ? atoi(e) == 16 : CDML_BF16_MFMA_DEFAULT == 16;
+}
+
+template <bool TN, int EPI>
+int launch(const BArgs &g, int splits, hipStream_t s) {
+  if (shape16()) return launch1<TN, EPI, true>(g, splits, s);
+  return launch1<TN, EPI, false>(g, splits, s);
 }
 
 }  // namespace

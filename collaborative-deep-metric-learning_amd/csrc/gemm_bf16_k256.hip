@@ -59,6 +59,7 @@ struct K256Args {
   const bf16 *B; int64_t ldb;      // [N][256]
   bf16 *C; int64_t ldc;            // [M][N]
   const bf16 *aux; int64_t ldaux;  // [M][N] or null
+  int aux_bits;                    // aux is the sign bitmask uint8 [M][ldaux bytes] (bit j of byte b = column 8b+j)
   float alpha;
   int M, N;
   int strips, segments, chunks_per_segment, n_chunks;
@@ -132,10 +133,15 @@ __global__ void __launch_bounds__(kT, 2) k_gemm_bf16_k256_mask(K256Args g) {
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < c_end) stage_chunk(c + 1);
     bf16x8 mk[4];
-    if (has_aux) {
+    unsigned mkb[4] = {0, 0, 0, 0};
+    if (has_aux && !g.aux_bits) {
 #pragma unroll
       for (int p = 0; p < 4; ++p)
         mk[p] = *reinterpret_cast<const bf16x8 *>(g.aux + (int64_t)min(m0 + p * 8 + er, g.M - 1) * g.ldaux + ncol0 + ec);
+    } else if (has_aux) {               // one byte = this lane's 8 columns
+      const uint8_t *mb = reinterpret_cast<const uint8_t *>(g.aux);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) mkb[p] = mb[(int64_t)min(m0 + p * 8 + er, g.M - 1) * g.ldaux + ((ncol0 + ec) >> 3)];
     }
     f32x16 acc0, acc1;
 #pragma unroll
@@ -168,7 +174,7 @@ __global__ void __launch_bounds__(kT, 2) k_gemm_bf16_k256_mask(K256Args g) {
       bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (has_aux) v[j] *= ((float)mk[p][j] > 0.f) ? 1.f : g.alpha;
+        if (has_aux) v[j] *= (g.aux_bits ? ((mkb[p] >> j) & 1u) != 0 : (float)mk[p][j] > 0.f) ? 1.f : g.alpha;
         o[j] = (bf16)v[j];
       }
       // non-temporal: the result is read next by a different kernel on other CUs (5.2 vs 4.6 TB/s)
@@ -184,7 +190,7 @@ __global__ void __launch_bounds__(kT, 2) k_gemm_bf16_k256_mask(K256Args g) {
 // the mask / plain-bf16 epilogue (BE_MASK_BF16) at K == 256, N % 256 == 0, 16-B aligned rows
 bool gemm_bf16_k256_usable(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux, bool has_aux) {
   if (K != kK || N % kStripN || M < 1) return false;
-  if ((lda & 7) || (ldb & 7) || (ldc & 7) || (has_aux && (ldaux & 7))) return false;
+  if ((lda & 7) || (ldb & 7) || (ldc & 7) || (has_aux && (ldaux & 7))) return false;   // (bitmask rows: ldaux in bytes)
   const int64_t lim = (int64_t)1 << 31;
   return ((int64_t)M + kChunkM) * lda * 2 < lim;
 }
@@ -201,6 +207,7 @@ int launch_gemm_bf16_k256(const BArgs &b, hipStream_t s) {
   K256Args g{};
   g.A = b.A; g.lda = b.lda; g.B = b.B; g.ldb = b.ldb;
   g.C = static_cast<bf16 *>(b.C); g.ldc = b.ldc; g.aux = b.aux; g.ldaux = b.ldaux; g.alpha = b.alpha;
+  g.aux_bits = b.aux_bits;
   g.M = b.M; g.N = b.N;
   g.strips = b.N / kStripN;
   g.n_chunks = (b.M + kChunkM - 1) / kChunkM;

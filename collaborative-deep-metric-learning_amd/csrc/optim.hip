@@ -28,6 +28,17 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kLarsBlocks = 1024;
 
+// One Adam update (TF's ApplyAdam functor), with the roundings spelled out -- m += (g-m)(1-b1);
+// v += (g*g-v)(1-b2); w -= (m*lr_t)/(sqrt(v)+eps) -- so that every kernel form (float4 stream, scalar tail,
+// matrix tiles, the bias vector riding along) gives the same bits whatever the compiler contracts.
+__device__ __forceinline__ void adam1(float &w, const float g, float &m, float &v, const float omb1,
+                                      const float omb2, const float lr_t, const float eps) {
+  m = __fmaf_rn(g - m, omb1, m);
+  v = __fmaf_rn(__fmaf_rn(g, g, -v), omb2, v);
+  w = w - __fdiv_rn(m * lr_t, __fsqrt_rn(v) + eps);
+}
+
+
 __global__ void __launch_bounds__(kThreads)
 k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
        float *__restrict__ v, int64_t n, float lr_imm, const float *__restrict__ lr_dev, float b1,
@@ -49,10 +60,7 @@ k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m
     const float4 g4 = reinterpret_cast<const float4 *>(g)[i];
     float4 m4 = reinterpret_cast<float4 *>(m)[i];
     float4 v4 = reinterpret_cast<float4 *>(v)[i];
-#define CDML_ADAM1(c)                              \
-  m4.c += (g4.c - m4.c) * omb1;                    \
-  v4.c += (g4.c * g4.c - v4.c) * omb2;             \
-  w4.c -= (m4.c * lr_t) / (sqrtf(v4.c) + eps);
+#define CDML_ADAM1(c) adam1(w4.c, g4.c, m4.c, v4.c, omb1, omb2, lr_t, eps);
     CDML_ADAM1(x) CDML_ADAM1(y) CDML_ADAM1(z) CDML_ADAM1(w)
 #undef CDML_ADAM1
     reinterpret_cast<float4 *>(w)[i] = w4;
@@ -60,12 +68,11 @@ k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m
     reinterpret_cast<float4 *>(v)[i] = v4;
   }
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float gi = g[i];
-    const float mi = m[i] + (gi - m[i]) * omb1;
-    const float vi = v[i] + (gi * gi - v[i]) * omb2;
+    float wi = w[i], mi = m[i], vi = v[i];
+    adam1(wi, g[i], mi, vi, omb1, omb2, lr_t, eps);
     m[i] = mi;
     v[i] = vi;
-    w[i] = w[i] - (mi * lr_t) / (sqrtf(vi) + eps);
+    w[i] = wi;
   }
   // global_step += 1 (train.py:146 apply_gradients(global_step=...)) by the last block to
   // finish: every block has read *t_dev by then, and no other kernel runs beside this one
@@ -78,12 +85,17 @@ k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m
 // again.  One 64 x 64 tile per block: 16-B accesses on every fp32 stream, the transpose through LDS,
 // whole 128-B lines on the bf16 rows.
 // Same arithmetic per element as k_adam (bit-equal).
+// The layer's BIAS vector (bw/bg/bm/bv, bn elements, nullable) rides along in the first blocks -- a
+// 5 000-element Adam launch of its own costs 5-7 us for 100 KB -- and on request the last block to
+// finish advances the step counter (as k_adam does): the optimizer of the config-4 step is two launches.
 constexpr int kAT = 64;
 __global__ void __launch_bounds__(kThreads)
 k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
                    float *__restrict__ v, int K, int N, float lr_imm, const float *__restrict__ lr_dev,
-                   float b1, float b2, float eps, int64_t t_imm, const uint64_t *__restrict__ t_dev,
-                   __bf16 *__restrict__ wt, int64_t ldt, __bf16 *__restrict__ wc, int64_t ldc) {
+                   float b1, float b2, float eps, int64_t t_imm, uint64_t *__restrict__ t_dev,
+                   __bf16 *__restrict__ wt, int64_t ldt, __bf16 *__restrict__ wc, int64_t ldc,
+                   float *__restrict__ bw, const float *__restrict__ bg, float *__restrict__ bm,
+                   float *__restrict__ bv, int bn, int advance, uint32_t *__restrict__ tickets) {
   using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
   __shared__ float s_lr_t;
   __shared__ uint32_t sT[kAT][kAT / 2 + 1];           // [column n][row pair]: two bf16 of one column per word
@@ -111,10 +123,7 @@ k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__
       const float4 g4 = *reinterpret_cast<const float4 *>(g + i);
       float4 m4 = *reinterpret_cast<float4 *>(m + i);
       float4 v4 = *reinterpret_cast<float4 *>(v + i);
-#define CDML_ADAM1(c)                              \
-  m4.c += (g4.c - m4.c) * omb1;                    \
-  v4.c += (g4.c * g4.c - v4.c) * omb2;             \
-  w4.c -= (m4.c * lr_t) / (sqrtf(v4.c) + eps);
+#define CDML_ADAM1(c) adam1(w4.c, g4.c, m4.c, v4.c, omb1, omb2, lr_t, eps);
       CDML_ADAM1(x) CDML_ADAM1(y) CDML_ADAM1(z) CDML_ADAM1(w)
 #undef CDML_ADAM1
       *reinterpret_cast<float4 *>(w + i) = w4;
@@ -130,17 +139,28 @@ k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__
       sT[c4 + u][r >> 1] = __builtin_bit_cast(uint32_t, pr);
     }
   }
-  if (!wt) return;                                   // (uniform: no barrier is left behind)
-  __syncthreads();
-  // transposed tile: row n of W^T holds 64 consecutive k = 128 B; 8 threads x 16 B per row
-  const int sr = threadIdx.x >> 3, seg = (threadIdx.x & 7) * 4;
+  if (wt) {                                          // (uniform)
+    __syncthreads();
+    // transposed tile: row n of W^T holds 64 consecutive k = 128 B; 8 threads x 16 B per row
+    const int sr = threadIdx.x >> 3, seg = (threadIdx.x & 7) * 4;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int row = q * 32 + sr;
-    uint4 o;
-    o.x = sT[row][seg]; o.y = sT[row][seg + 1]; o.z = sT[row][seg + 2]; o.w = sT[row][seg + 3];
-    *reinterpret_cast<uint4 *>(wt + (int64_t)(n0 + row) * ldt + k0 + seg * 2) = o;
+    for (int q = 0; q < 2; ++q) {
+      const int row = q * 32 + sr;
+      uint4 o;
+      o.x = sT[row][seg]; o.y = sT[row][seg + 1]; o.z = sT[row][seg + 2]; o.w = sT[row][seg + 3];
+      *reinterpret_cast<uint4 *>(wt + (int64_t)(n0 + row) * ldt + k0 + seg * 2) = o;
+    }
   }
+  if (bw) {                                          // the bias vector: element i of the first ceil(bn / 256) blocks
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < bn; i += gridDim.x * kThreads) {
+      float wi = bw[i], mi = bm[i], vi = bv[i];
+      adam1(wi, bg[i], mi, vi, omb1, omb2, lr_t, eps);
+      bm[i] = mi;
+      bv[i] = vi;
+      bw[i] = wi;
+    }
+  }
+  if (advance && grid_last_block(tickets) && threadIdx.x == 0) *t_dev += 1;
 }
 
 // scratch layout: [0]=|w|^2, [1]=|g|^2, then kLarsBlocks x 2 block partials
@@ -382,9 +402,15 @@ extern "C" int cdml_adam_step(float *w, const float *g, float *m, float *v, int6
 
 extern "C" int cdml_adam_matrix_bf16(float *w, const float *g, float *m, float *v, int K, int N, float lr,
                                      const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
-                                     const uint64_t *t_dev, uint16_t *wt_bf16, int64_t ldt, uint16_t *wc_bf16,
-                                     int64_t ldc, cdml_stream_t stream) {
+                                     uint64_t *t_dev, uint16_t *wt_bf16, int64_t ldt, uint16_t *wc_bf16,
+                                     int64_t ldc, float *bias_w, const float *bias_g, float *bias_m,
+                                     float *bias_v, int bias_n, int advance_step, uint32_t *tickets,
+                                     cdml_stream_t stream) {
   CDML_REQUIRE(w && g && m && v && K > 0 && N > 0, CDML_E_BADARG, "adam_matrix_bf16: bad argument");
+  CDML_REQUIRE(!bias_w || (bias_g && bias_m && bias_v && bias_n > 0), CDML_E_BADARG,
+               "adam_matrix_bf16: the bias vector needs its gradient and both moments");
+  CDML_REQUIRE(!advance_step || (t_dev && tickets), CDML_E_BADARG,
+               "adam_matrix_bf16: advance_step needs the device step counter and the ticket words");
   CDML_REQUIRE(K % kAT == 0 && N % kAT == 0, CDML_E_UNSUPPORTED,
                "adam_matrix_bf16: K and N must be multiples of 64, got K=%d N=%d", K, N);
   CDML_REQUIRE(t >= (t_dev ? 0 : 1), CDML_E_BADARG, "adam_matrix_bf16: step t is 1-based");
@@ -394,7 +420,8 @@ extern "C" int cdml_adam_matrix_bf16(float *w, const float *g, float *m, float *
                CDML_E_ALIGN, "adam_matrix_bf16: 16-B aligned buffers, ldt a multiple of 8 (>= K), ldc of 4 (>= N)");
   hipLaunchKernelGGL(k_adam_matrix_bf16, dim3((K / kAT) * (N / kAT)), dim3(kThreads), 0, (hipStream_t)stream, w, g,
                      m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, reinterpret_cast<__bf16 *>(wt_bf16), ldt,
-                     reinterpret_cast<__bf16 *>(wc_bf16), ldc);
+                     reinterpret_cast<__bf16 *>(wc_bf16), ldc, bias_w, bias_g, bias_m, bias_v, bias_w ? bias_n : 0,
+                     advance_step, tickets);
   return check_launch("adam_matrix_bf16");
 }
 

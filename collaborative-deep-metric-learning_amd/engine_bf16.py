@@ -79,6 +79,16 @@ class TowerWorkspaceBF16:
         self.tn1 = ops.gemm_bf16_tn_supported(L.Fp, L.Hp, R, L.Fp, L.Hp)
         self.tn2 = ops.gemm_bf16_tn_supported(L.Hp, L.Dp, R, L.Hp, L.Dp)
         self.dz1 = bf(R, L.Hp)
+        # leaky-relu' of the hidden layer as ONE BIT per element, written by FC1's epilogue and read by
+        # the data gradient instead of the 2-byte activations (epilogues 4 / 5).  OFF by default: measured
+        # on one box in the config-4 step (profiles/r03_bf16_maskbits_ab.txt) the byte stores cost FC1's
+        # epilogue 23 us and the data gradient did not get faster -- it is not bound by the mask bytes
+        # (tools/experiments/k256_ablate.sh: without any mask traffic 86 us of its 119)
+        self.h1_bits = None
+        if (os.environ.get("CDML_BF16_MASKBITS") == "1"
+                and ops.gemm_bf16_epilogue_supported(ops.BE_BIAS_LRELU_BF16_BITS, R, L.Hp, L.Fp, L.Fp, L.Fp, L.Hp, L.Hp // 8)
+                and ops.gemm_bf16_epilogue_supported(ops.BE_MASKBITS_BF16, R, L.Hp, L.Dp, L.Dp, L.Dp, L.Hp, L.Hp // 8)):
+            self.h1_bits = torch.zeros((R, L.Hp // 8), dtype=torch.uint8, device=device)
         self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp)
         self.dz2_bf = bf(R, L.Dp)
         if not self.tn1:
@@ -105,7 +115,11 @@ def tower_forward(p, ws, normalize=True):
     """x_hat (bf16, l2-normalised) -> h1 (bf16) -> z (fp32) -> e (fp32).  models.py:59-61.
     ``normalize=False``: stop at z (the fused tail of the training step takes over)."""
     L, R = p.layout, ws.R
-    ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_BF16, ws.x_hat, ws.W1T, ws.h1, R, L.Hp, L.Fp, bias=p.b1)
+    bits = getattr(ws, "h1_bits", None)
+    if bits is not None:
+        ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_BF16_BITS, ws.x_hat, ws.W1T, ws.h1, R, L.Hp, L.Fp, bias=p.b1, aux=bits)
+    else:
+        ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_BF16, ws.x_hat, ws.W1T, ws.h1, R, L.Hp, L.Fp, bias=p.b1)
     ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_F32, ws.h1, ws.W2T, ws.z, R, L.Dp, L.Hp, bias=p.b2, workspace=ws.gemm_ws)
     ws.tail_done = False
     if normalize:
@@ -129,9 +143,12 @@ def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
     w2_first = (after_w1 is None and after_w1_chunk is None and ws.tn2
                 and not os.environ.get("CDML_BF16_W2_LAST"))            # (the switch: A/B runs)
     if w2_first:
-        ops.colsum(ws.dz2, R, L.Dp, p.gb2, ws.colsum_ws)   # fp32 dz2: db2 keeps full precision
-        ops.gemm_bf16_tn(ws.h1, ws.dz2_bf, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
-    ops.gemm_bf16_nt(ops.BE_MASK_BF16, ws.dz2_bf, ws.W2, ws.dz1, R, L.Hp, L.Dp, aux=ws.h1)
+        # db2 = column sums of the bf16 dz2 the two products consume, from the LDS tiles of the same GEMM
+        ops.gemm_bf16_tn(ws.h1, ws.dz2_bf, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws, colsum=p.gb2)
+    if ws.h1_bits is not None:
+        ops.gemm_bf16_nt(ops.BE_MASKBITS_BF16, ws.dz2_bf, ws.W2, ws.dz1, R, L.Hp, L.Dp, aux=ws.h1_bits)
+    else:
+        ops.gemm_bf16_nt(ops.BE_MASK_BF16, ws.dz2_bf, ws.W2, ws.dz1, R, L.Hp, L.Dp, aux=ws.h1)
     rows = L.Fp // w1_chunks if w1_chunks > 1 else 0
     chunked = (after_w1_chunk is not None and w1_chunks > 1 and rows * w1_chunks == L.Fp and ws.tn1
                and ops.gemm_bf16_tn_supported(rows, L.Hp, R, L.Fp, L.Hp))
@@ -156,10 +173,10 @@ def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
         after_w1()
     if w2_first:
         return p.grad
-    ops.colsum(ws.dz2, R, L.Dp, p.gb2, ws.colsum_ws)       # fp32 dz2: db2 keeps full precision
     if ws.tn2:
-        ops.gemm_bf16_tn(ws.h1, ws.dz2_bf, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)
+        ops.gemm_bf16_tn(ws.h1, ws.dz2_bf, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws, colsum=p.gb2)
     else:
+        ops.colsum(ws.dz2, R, L.Dp, p.gb2, ws.colsum_ws)
         ops.transpose_to_bf16(ws.dz2, ws.dz2T, R, L.Dp)
         ops.transpose_to_bf16(ws.h1, ws.h1T, R, L.Hp)
         ops.gemm_bf16_nt(ops.BE_F32, ws.h1T, ws.dz2T, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws)

@@ -325,6 +325,11 @@ def lrelu_bwd(g, y, out, M, N, alpha=LRELU_ALPHA):
 
 # ------------------------------------------- reduced precision (config 4) -----
 BE_BIAS_LRELU_BF16, BE_BIAS_LRELU_F32, BE_MASK_BF16, BE_F32 = 0, 1, 2, 3
+BE_BIAS_LRELU_BF16_BITS, BE_MASKBITS_BF16 = 4, 5      # 0 + sign bitmask out (aux) / 2 reading that bitmask
+
+
+def gemm_bf16_epilogue_supported(epilogue, M, N, K, lda, ldb, ldc, ldaux):
+    return bool(load_library().cdml_gemm_bf16_epilogue_supported(epilogue, M, N, K, lda, ldb, ldc, ldaux))
 
 
 def _mat16(t):
@@ -343,6 +348,8 @@ def gemm_bf16_nt(epilogue, A, B, C, M, N, K, bias=None, aux=None, alpha=LRELU_AL
     if C.dim() != 2 or C.stride(1) != 1:
         raise ValueError("C must be 2-D with unit inner stride")
     xld = aux.stride(0) if aux is not None else 0
+    if aux is not None and (aux.dtype == torch.uint8) != (epilogue in (BE_BIAS_LRELU_BF16_BITS, BE_MASKBITS_BF16)):
+        raise ValueError("epilogues 4 / 5 take a uint8 bitmask as aux, epilogue 2 bf16 values")
     call("cdml_gemm_bf16_nt", epilogue, ap, ald, bp, bld, M, N, K, _p(C), C.stride(0), _p(bias),
          _p(aux), xld, alpha, _p(workspace), 0 if workspace is None else workspace.numel() * workspace.element_size(),
          _stream())
@@ -412,9 +419,12 @@ def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, 
          _p(advance_tickets, torch.int32), _stream())
 
 
-def adam_matrix_bf16(W, g, m, v, lr, t, wt=None, wc=None, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, t_dev=None):
+def adam_matrix_bf16(W, g, m, v, lr, t, wt=None, wc=None, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, t_dev=None,
+                     bias=None, advance_tickets=None):
     """Adam on the contiguous weight matrix W [K, N] (g, m, v alike) that also writes the bf16 operand
-    copies: wt = W^T as bf16 [N, >=K], wc = W as bf16 [K, >=N] (either may be None)."""
+    copies: wt = W^T as bf16 [N, >=K], wc = W as bf16 [K, >=N] (either may be None).  ``bias`` =
+    (b, gb, mb, vb): the layer's bias vector updated in the same launch; ``advance_tickets``
+    (ops.new_tickets): also global_step += 1 on *t_dev by the last block."""
     if W.dim() != 2 or not W.is_contiguous() or W.dtype != torch.float32:
         raise ValueError("W must be a contiguous fp32 matrix")
     K, N = W.shape
@@ -427,8 +437,13 @@ def adam_matrix_bf16(W, g, m, v, lr, t, wt=None, wc=None, beta1=0.9, beta2=0.999
         raise ValueError("wt must be at least [N, K]")
     if wc is not None and (wc.shape[0] < K or wc.shape[1] < N):
         raise ValueError("wc must be at least [K, N]")
+    b = bias if bias is not None else (None, None, None, None)
+    if bias is not None and any(x.numel() != b[0].numel() or not x.is_contiguous() for x in b):
+        raise ValueError("bias, its gradient and its moments must be contiguous vectors of one size")
     call("cdml_adam_matrix_bf16", _p(W), _p(g), _p(m), _p(v), K, N, lr, _p(lr_dev), beta1, beta2, eps,
-         0 if t is None else t, _p(t_dev, torch.int64), tp, tld, cp, cld, _stream())
+         0 if t is None else t, _p(t_dev, torch.int64), tp, tld, cp, cld, _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]),
+         0 if bias is None else b[0].numel(), 0 if advance_tickets is None else 1, _p(advance_tickets, torch.int32),
+         _stream())
 
 
 def table_adam_rows(table, row0, F, idx, grad_xhat, m_table, v_table, head, nxt, lr, t, beta1=0.9, beta2=0.999,

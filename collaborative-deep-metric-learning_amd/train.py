@@ -378,19 +378,19 @@ class TrainStep:
                 ops.grad_prepare(p.grad[off:off + n], p.flat[off:off + n], self.reg_scale if i % 2 == 0 else 0.0,
                                  self.clip_gradient_norm, self.lars_scratch, self.grad_norms[i])
         if self.optimizer == "adam" and self.bf16:
-            # config-4 precision: the weight matrices' update also writes the bf16 operand copies
-            # the GEMMs read (no separate transposes / cast); the biases follow, and the second
-            # of their launches advances the step counter
+            # config-4 precision: two launches -- each weight matrix with its bias vector; the update
+            # also writes the bf16 operand copies the GEMMs read (no separate transposes / cast), and
+            # the last block of the second launch advances the step counter
             L, o, ws = self.layout, self.layout.offsets, self.ws
             mat = lambda t, i, r, c: t[o[i]:o[i] + r * c].view(r, c)
             kw = dict(lr_dev=self.lr_dev, t_dev=self.step_dev)
-            ops.adam_matrix_bf16(p.W1, mat(p.grad, 0, L.Fp, L.Hp), mat(self.m, 0, L.Fp, L.Hp),
-                                 mat(self.v, 0, L.Fp, L.Hp), 0.0, 1, wt=ws.W1T, **kw)
-            ops.adam_matrix_bf16(p.W2, mat(p.grad, 2, L.Hp, L.Dp), mat(self.m, 2, L.Hp, L.Dp),
-                                 mat(self.v, 2, L.Hp, L.Dp), 0.0, 1, wt=ws.W2T, wc=ws.W2, **kw)
             b1, b2 = slice(o[1], o[1] + L.Hp), slice(o[3], o[3] + L.Dp)
-            ops.adam_step(p.flat[b1], p.grad[b1], self.m[b1], self.v[b1], 0.0, 1, **kw)
-            ops.adam_step(p.flat[b2], p.grad[b2], self.m[b2], self.v[b2], 0.0, 1, advance_tickets=self.adam_tickets, **kw)
+            vec = lambda sl: (p.flat[sl], p.grad[sl], self.m[sl], self.v[sl])
+            ops.adam_matrix_bf16(p.W1, mat(p.grad, 0, L.Fp, L.Hp), mat(self.m, 0, L.Fp, L.Hp),
+                                 mat(self.v, 0, L.Fp, L.Hp), 0.0, 1, wt=ws.W1T, bias=vec(b1), **kw)
+            ops.adam_matrix_bf16(p.W2, mat(p.grad, 2, L.Hp, L.Dp), mat(self.m, 2, L.Hp, L.Dp),
+                                 mat(self.v, 2, L.Hp, L.Dp), 0.0, 1, wt=ws.W2T, wc=ws.W2, bias=vec(b2),
+                                 advance_tickets=self.adam_tickets, **kw)
         elif self.optimizer == "adam":
             # the step counter advances inside the same launch
             ops.adam_step(p.flat, p.grad, self.m, self.v, 0.0, 1, lr_dev=self.lr_dev,

@@ -312,11 +312,15 @@ int cdml_knn_merge(const float *scores, int64_t lds, int nq, int nb, int col0,
  * bf16 [K][ldc] (wc_bf16, nullable), round-to-nearest-even of the UPDATED weights: the optimizer
  * step of train.py:146 and cdml_transpose_to_bf16 / cdml_cast_f32_bf16 in one pass over the
  * weights (bit-equal to the separate calls).  K, N multiples of 64.  t / t_dev / lr_dev as
- * cdml_adam_step; the step counter is not advanced here. */
+ * cdml_adam_step.  bias_w / bias_g / bias_m / bias_v (nullable together; bias_n elements): the
+ * layer's bias vector takes the same update in the same launch.  advance_step != 0: the last
+ * block to finish does *t_dev += 1, as in cdml_adam_step (tickets: CDML_TICKET_WORDS zeroed words). */
 int cdml_adam_matrix_bf16(float *w, const float *g, float *m, float *v, int K, int N, float lr,
                           const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
-                          const uint64_t *t_dev, uint16_t *wt_bf16, int64_t ldt,
-                          uint16_t *wc_bf16, int64_t ldc, cdml_stream_t stream);
+                          uint64_t *t_dev, uint16_t *wt_bf16, int64_t ldt,
+                          uint16_t *wc_bf16, int64_t ldc, float *bias_w, const float *bias_g,
+                          float *bias_m, float *bias_v, int bias_n, int advance_step,
+                          uint32_t *tickets, cdml_stream_t stream);
 
 /* ---- reduced-precision tower (BASELINE config 4: fp16 catalogue + bf16 MFMA
  * projection; build-defined precision with its own tolerance, never the default).
@@ -332,8 +336,16 @@ int cdml_adam_matrix_bf16(float *w, const float *g, float *m, float *v, int K, i
  * one-pass kernel runs.  Results of the two routes differ in summation order only.
  * Epilogue 2 at K == 256, N % 256 == 0 and M * N >= 2^22 (the output layer's data gradient,
  * an HBM-bound product) runs on a streaming kernel: B held in registers, A by 32-row chunks,
- * bit-equal to the tiled kernels. */
+ * bit-equal to the tiled kernels.
+ *            4: epilogue 0 that ALSO writes the sign bitmask of C through `aux` (an OUTPUT here):
+ *               uint8 [M][ldaux bytes], bit j of byte b of row m = (C[m][8b+j] > 0)
+ *            5: epilogue 2 reading that bitmask (aux, ldaux in bytes) instead of the bf16 values --
+ *               leaky-relu' needs one bit per element: 16 MB instead of 252 MB per step at config 4
+ * Epilogues 4 / 5 exist on the 256x256 kernel / the K == 256 streaming kernel only:
+ * cdml_gemm_bf16_epilogue_supported says whether a shape takes them (else use 0 / 2). */
 size_t cdml_gemm_bf16_workspace(int M, int N, int K);
+int cdml_gemm_bf16_epilogue_supported(int epilogue, int M, int N, int K, int64_t lda,
+                                      int64_t ldb, int64_t ldc, int64_t ldaux);
 int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda,
                       const uint16_t *B, int64_t ldb, int M, int N, int K, void *C,
                       int64_t ldc, const float *bias, const uint16_t *aux,

@@ -39,9 +39,13 @@ def dbf(x, dev):
                                         # the 256x256 ping-pong kernel: minimal, ragged M, long K, many tiles
                                         (256, 256, 128, 256), (700, 512, 384, 256), (1000, 1024, 1536, 256),
                                         (77, 256, 5120, 256), (3100, 4096, 512, 0), (2000, 256, 5120, 0)])
-def test_gemm_bf16_epilogues(cd, M, N, K, tile, monkeypatch):
+@pytest.mark.parametrize("mfma", ["32", "16"])
+def test_gemm_bf16_epilogues(cd, M, N, K, tile, mfma, monkeypatch):
     if tile:
         monkeypatch.setenv("CDML_BF16_TILE", str(tile))
+    if mfma == "16" and tile == 0 and not (N % 256 == 0 and K % 128 == 0):
+        pytest.skip("the MFMA shape only matters where the 256x256 kernel runs")
+    monkeypatch.setenv("CDML_BF16_MFMA", mfma)       # v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16
     rng = np.random.RandomState(M + N)
     A, B = rng.randn(M, K) / np.sqrt(K), rng.randn(N, K)
     bias, aux = rng.randn(N) * 0.1, rng.randn(M, N)
@@ -74,8 +78,11 @@ def test_gemm_bf16_epilogues(cd, M, N, K, tile, monkeypatch):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1280), (1536, 5120, 2048), (5120, 256, 3072)])
-def test_gemm_bf16_tn_weight_gradient_form(cd, M, N, K):
-    """C = A^T . B from k-strided operands (transposed LDS reads, no transposed copies)."""
+@pytest.mark.parametrize("mfma", ["16", "32"])
+def test_gemm_bf16_tn_weight_gradient_form(cd, M, N, K, mfma, monkeypatch):
+    """C = A^T . B from k-strided operands (transposed LDS reads, no transposed copies), on both
+    MFMA shapes (16x16x32 is what ships; 32x32x16 stays selectable for the A/B)."""
+    monkeypatch.setenv("CDML_BF16_MFMA", mfma)
     rng = np.random.RandomState(M + K)
     A, B = rng.randn(K, M) / np.sqrt(K), rng.randn(K, N)
     # make a wrong k-permutation or a swapped fragment half visible: scale rows of k
@@ -168,9 +175,61 @@ def test_adam_matrix_bf16_equals_adam_then_copies(cd, K, N):
     assert torch.equal(w2, w0)
     ow, om, ov = otower.adam_step(W.cpu().numpy(), G.cpu().numpy(), M.cpu().numpy(), V.cpu().numpy(), 7, 0.01)[:3]
     np.testing.assert_allclose(w1.cpu().numpy(), ow, rtol=2e-5, atol=3e-7)
+    # the layer's bias vector in the same launch (bit-equal to its own cdml_adam_step), and the step
+    # counter advanced by the last block
+    nb = N - 3 if N > 64 else 61                                            # not a multiple of the block size
+    vb = lambda sc: torch.randn(nb, device=cd.dev, generator=g_) * sc
+    B_, GB, MB, VB = vb(0.1), vb(1e-3), vb(1e-4), vb(1e-4).abs()
+    b0, mb0, vb0 = B_.clone(), MB.clone(), VB.clone()
+    cd.ops.adam_step(b0, GB, mb0, vb0, 0.0, 1, lr_dev=lr, t_dev=step)
+    w3, m3, v3, b3, mb3, vb3 = W.clone(), M.clone(), V.clone(), B_.clone(), MB.clone(), VB.clone()
+    tickets = cd.ops.new_tickets(cd.dev)
+    cd.ops.adam_matrix_bf16(w3, G, m3, v3, 0.0, 1, wt=wt1, lr_dev=lr, t_dev=step, bias=(b3, GB, mb3, vb3),
+                            advance_tickets=tickets)
+    assert torch.equal(w3, w0) and torch.equal(b3, b0) and torch.equal(mb3, mb0) and torch.equal(vb3, vb0)
+    assert int(step.item()) == 7 and int(tickets.abs().sum().item()) == 0   # advanced once, tickets back at zero
     with pytest.raises(cd.pkg.CdmlError):
         cd.ops.adam_matrix_bf16(torch.zeros(96, 64, device=cd.dev), torch.zeros(96, 64, device=cd.dev),
                                 torch.zeros(96, 64, device=cd.dev), torch.zeros(96, 64, device=cd.dev), 0.01, 1)
+
+
+@pytest.mark.parametrize("M", [24576, 1000])
+def test_bitmask_epilogues_equal_value_mask(cd, M):
+    """leaky-relu' as ONE BIT per element: FC1's epilogue 4 writes the layer's bf16 output (bit-equal to
+    epilogue 0) plus the sign bitmask; the K = 256 data gradient's epilogue 5 reads the bitmask and gives
+    the bits of epilogue 2 reading the bf16 values.  Ragged M, strided buffers, untouched padding."""
+    N, K1, K2 = 5120, 1536, 256
+    ops = cd.ops
+    assert ops.gemm_bf16_epilogue_supported(ops.BE_BIAS_LRELU_BF16_BITS, M, N, K1, K1, K1, N, N // 8)
+    assert ops.gemm_bf16_epilogue_supported(ops.BE_MASKBITS_BF16, M, N, K2, K2, K2, N, N // 8)
+    assert not ops.gemm_bf16_epilogue_supported(ops.BE_MASKBITS_BF16, M, N, 320, 320, 320, N, N // 8)
+    g_ = torch.Generator(device=cd.dev)
+    g_.manual_seed(M)
+    A = (torch.randn(M, K1, device=cd.dev, generator=g_) / K1 ** 0.5).bfloat16()
+    B = torch.randn(N, K1, device=cd.dev, generator=g_).bfloat16()
+    bias = torch.randn(N, device=cd.dev, generator=g_) * 0.1
+    h0 = torch.empty((M, N), dtype=torch.bfloat16, device=cd.dev)
+    h1 = torch.empty_like(h0)
+    bits = torch.full((M + 2, N // 8 + 16), 0xAA, dtype=torch.uint8, device=cd.dev)
+    ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_BF16, A, B, h0, M, N, K1, bias=bias)
+    ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_BF16_BITS, A, B, h1, M, N, K1, bias=bias, aux=bits[:M, :N // 8])
+    assert torch.equal(h0, h1)
+    want = torch.from_numpy(np.packbits((h0.float() > 0).cpu().numpy(), axis=1, bitorder="little")).to(cd.dev)
+    assert torch.equal(bits[:M, :N // 8], want)
+    assert bool((bits[M:] == 0xAA).all()) and bool((bits[:, N // 8:] == 0xAA).all())
+    frac = float((h0.float() > 0).float().mean())
+    assert 0.3 < frac < 0.7                                                  # both signs are exercised
+    dz2 = (torch.randn(M, K2, device=cd.dev, generator=g_) / 16).bfloat16()
+    W2 = torch.randn(N, K2, device=cd.dev, generator=g_).bfloat16()
+    d0 = torch.empty((M, N), dtype=torch.bfloat16, device=cd.dev)
+    d1 = torch.full((M, N), 3.0, dtype=torch.bfloat16, device=cd.dev)
+    ops.gemm_bf16_nt(ops.BE_MASK_BF16, dz2, W2, d0, M, N, K2, aux=h0)
+    ops.gemm_bf16_nt(ops.BE_MASKBITS_BF16, dz2, W2, d1, M, N, K2, aux=bits[:M, :N // 8])
+    assert torch.equal(d0, d1)
+    with pytest.raises(ValueError):
+        ops.gemm_bf16_nt(ops.BE_MASK_BF16, dz2, W2, d1, M, N, K2, aux=bits[:M, :N // 8])      # bits where values are expected
+    with pytest.raises(cd.pkg.CdmlError):
+        ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_BF16_BITS, A[:, :64], B[:, :64], h1, M, N, 64, bias=bias, aux=bits[:M, :N // 8])
 
 
 def test_gemm_bf16_256_race_screen(cd, monkeypatch):

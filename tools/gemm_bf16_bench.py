@@ -46,6 +46,39 @@ for name, epi, M, N, K in cases:
              res["256"][0], fl / res["256"][0] / 1e9, fl / res["256"][0] / 1e9 / 2500,
              abs(res["128"][1] - res["256"][1]) / max(res["128"][1], 1e-9)))
 
+# MFMA shape of the 256x256 kernel, k-contiguous form: 32x32x16 vs 16x16x32, interleaved rounds in this process
+os.environ["CDML_BF16_TILE"] = "256"
+for name, epi, M, N, K in cases[:2] + cases[3:]:
+    A = (torch.randn(M, K, device=dev) / K ** 0.5).bfloat16()
+    B = torch.randn(N, K, device=dev).bfloat16()
+    bias = torch.zeros(N, device=dev)
+    out = torch.empty((M, N), device=dev, dtype=torch.float32 if epi in (ops.BE_BIAS_LRELU_F32, ops.BE_F32) else torch.bfloat16)
+    ws = torch.empty(max(ops.gemm_bf16_workspace(M, N, K), 16) // 4, device=dev)
+    fn = lambda: ops.gemm_bf16_nt(epi, A, B, out, M, N, K, bias=bias, workspace=ws)
+    t = {"32": [], "16": []}
+    outs = {}
+    for rnd in range(6):
+        for shape in ("32", "16"):
+            os.environ["CDML_BF16_MFMA"] = shape
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(iters):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            t[shape].append(s.elapsed_time(e) / iters)
+            outs[shape] = out.float().clone()
+    fl = 2.0 * M * N * K
+    med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
+    print("%-16s mfma 32x32x16: median %7.4f ms (min %7.4f) %7.1f TF (%.3f) | 16x16x32: median %7.4f ms (min %7.4f) %7.1f TF (%.3f) | "
+          "max abs diff %.2e" % (name, med["32"], min(t["32"]), fl / med["32"] / 1e9, fl / med["32"] / 1e9 / 2500,
+                                 med["16"], min(t["16"]), fl / med["16"] / 1e9, fl / med["16"] / 1e9 / 2500,
+                                 (outs["32"] - outs["16"]).abs().max().item()))
+os.environ.pop("CDML_BF16_MFMA", None)
+
 # weight gradients from k-strided operands (no transposed copies) vs transposes + NT
 os.environ["CDML_BF16_TILE"] = "0"
 for name, M, N, K in (("dW1 tn F x H x R", F, H, R), ("dW2 tn H x D x R", H, D, R)):
@@ -61,6 +94,26 @@ for name, M, N, K in (("dW1 tn F x H x R", F, H, R), ("dW2 tn H x D x R", H, D, 
         ops.transpose_to_bf16(A, AT, K, M)
         ops.transpose_to_bf16(B, BT, K, N)
         ops.gemm_bf16_nt(ops.BE_F32, AT, BT, out2, M, N, K, workspace=ws)
+    t = {"32": [], "16": []}
+    for rnd in range(6):                                  # MFMA shape A/B on the k-strided form, interleaved rounds
+        for shape in ("32", "16"):
+            os.environ["CDML_BF16_MFMA"] = shape
+            for _ in range(2):
+                ops.gemm_bf16_tn(A, B, out, M, N, K, workspace=ws)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(iters):
+                ops.gemm_bf16_tn(A, B, out, M, N, K, workspace=ws)
+            e.record()
+            torch.cuda.synchronize()
+            t[shape].append(s.elapsed_time(e) / iters)
+    os.environ.pop("CDML_BF16_MFMA", None)
+    fl = 2.0 * M * N * K
+    med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
+    print("%-16s mfma 32x32x16: median %7.4f ms %7.1f TF (%.3f) | 16x16x32: median %7.4f ms %7.1f TF (%.3f)   [+ slab combine]"
+          % (name, med["32"], fl / med["32"] / 1e9, fl / med["32"] / 1e9 / 2500, med["16"], fl / med["16"] / 1e9,
+             fl / med["16"] / 1e9 / 2500))
     res = []
     for fn in (lambda: ops.gemm_bf16_tn(A, B, out, M, N, K, workspace=ws), via_transposes):
         for _ in range(3):
