@@ -46,4 +46,10 @@ int launch_gemm_bf16_k256(const BArgs &g, hipStream_t stream);
 bool gemm_bf16_tn_usable(int M, int N, int K, int64_t lda, int64_t ldb);
 int launch_gemm_bf16_tn(const BArgs &g, int splits, hipStream_t stream);
 
+// two k-strided products over the same K in one stream-K launch + one fix-up pass (gemm_bf16_256.hip);
+// g.C / g.ldc = the outputs, db1 / db2 (nullable) = column sums of the two B operands; 0 = shapes not taken
+size_t gemm_bf16_tn2_workspace(int M1, int N1, int M2, int N2, int K);
+int launch_gemm_bf16_tn2(const BArgs &g1, const BArgs &g2, float *db1, float *db2, void *workspace,
+                         size_t workspace_bytes, hipStream_t stream);
+
 }  // namespace cdml

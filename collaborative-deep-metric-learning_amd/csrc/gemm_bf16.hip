@@ -580,6 +580,34 @@ extern "C" int cdml_gemm_bf16_tn(const uint16_t *A, int64_t lda, const uint16_t 
   return rc;
 }
 
+extern "C" size_t cdml_gemm_bf16_tn2_workspace(int M1, int N1, int M2, int N2, int K) {
+  if (M1 <= 0 || N1 <= 0 || M2 <= 0 || N2 <= 0 || K <= 0) return 0;
+  return gemm_bf16_tn2_workspace(M1, N1, M2, N2, K);
+}
+
+extern "C" int cdml_gemm_bf16_tn2(const uint16_t *A1, int64_t lda1, const uint16_t *B1, int64_t ldb1, int M1, int N1,
+                                  float *C1, int64_t ldc1, float *colsum1, const uint16_t *A2, int64_t lda2,
+                                  const uint16_t *B2, int64_t ldb2, int M2, int N2, float *C2, int64_t ldc2,
+                                  float *colsum2, int K, void *workspace, size_t workspace_bytes,
+                                  cdml_stream_t stream) {
+  CDML_REQUIRE(A1 && B1 && C1 && A2 && B2 && C2 && M1 > 0 && N1 > 0 && M2 > 0 && N2 > 0 && K > 0, CDML_E_BADARG,
+               "gemm_bf16_tn2: bad argument");
+  CDML_REQUIRE(aligned16(A1) && aligned16(B1) && aligned16(C1) && aligned16(A2) && aligned16(B2) && aligned16(C2) &&
+                   !(lda1 & 7) && !(ldb1 & 7) && !(ldc1 & 3) && !(lda2 & 7) && !(ldb2 & 7) && !(ldc2 & 3) &&
+                   lda1 >= M1 && ldb1 >= N1 && ldc1 >= N1 && lda2 >= M2 && ldb2 >= N2 && ldc2 >= N2 && aligned16(workspace),
+               CDML_E_ALIGN, "gemm_bf16_tn2: 16-B aligned bases, lda/ldb multiples of 8, ldc of 4");
+  CDML_REQUIRE(gemm_bf16_tn_usable(M1, N1, K, lda1, ldb1) && gemm_bf16_tn_usable(M2, N2, K, lda2, ldb2) &&
+                   gemm_bf16_tn2_workspace(M1, N1, M2, N2, K) > 0,
+               CDML_E_UNSUPPORTED, "gemm_bf16_tn2: needs M, N multiples of 256 and K of 128 for both products "
+               "(cdml_gemm_bf16_tn2_workspace returns 0 otherwise); use cdml_gemm_bf16_tn per product");
+  BArgs g1{}, g2{};
+  g1.A = reinterpret_cast<const bf16 *>(A1); g1.lda = lda1; g1.B = reinterpret_cast<const bf16 *>(B1); g1.ldb = ldb1;
+  g1.C = C1; g1.ldc = ldc1; g1.M = M1; g1.N = N1; g1.K = K; g1.k_per_split = K;
+  g2.A = reinterpret_cast<const bf16 *>(A2); g2.lda = lda2; g2.B = reinterpret_cast<const bf16 *>(B2); g2.ldb = ldb2;
+  g2.C = C2; g2.ldc = ldc2; g2.M = M2; g2.N = N2; g2.K = K; g2.k_per_split = K;
+  return launch_gemm_bf16_tn2(g1, g2, colsum1, colsum2, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 extern "C" int cdml_transpose_to_bf16(int src_is_f32, const void *src, int64_t lds_, int rows, int cols,
                                       uint16_t *dst, int64_t ldd, cdml_stream_t stream) {
   CDML_REQUIRE(src && dst && rows > 0 && cols > 0 && lds_ >= cols && ldd >= rows, CDML_E_BADARG,

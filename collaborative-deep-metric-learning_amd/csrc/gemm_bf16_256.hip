@@ -99,25 +99,24 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
 // per phase instead of 16 of 32: equal cycles per flop; the chip holds a higher clock on this shape under
 // load, MI355X_MICROARCH.md 'DVFS give-back' item 7).  A fragment = 16 rows x 32 k (lane l: row l & 15,
 // k = 8 (l >> 4) .. +7): one ds_read_b128 of the same 128-B-row images; accumulators 8 x 4 blocks of 16 x 16.
+// One output tile over one K range: operands of `g` at tile origin (m0, n0), K-tiles k_begin/64 ..
+// + n_ktiles (even; 0 = nothing is multiplied, zeros come out).  The result goes to c_base as
+// c_base[(c_row0 + r) * c_ld + c_col0 + c] for tile-local (r, c) -- the caller's C (c_row0 = m0, c_col0 =
+// n0) or a tile-local partial slab (0, 0).  cs_row (TN, nullable): the column sums of B over the K-tiles
+// this (tile, row group) OWNS -- absolute K-tile index kt belongs to (tm, grp) = ((kt % (2 tiles_m)) >> 1,
+// kt & 1), so across the tiles_m tiles that share B every K-tile is counted once -- written to
+// cs_row[grp * cs_grp_stride + tile-local column].  Called by every wave of the block with the same arguments.
 template <bool TN, int EPI, bool S16>
-__global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
+__device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int m0, const int n0, const int k_begin,
+                                         const int n_ktiles, void *c_base, const int64_t c_ld, const int c_row0,
+                                         const int c_col0, float *cs_row, const int64_t cs_grp_stride,
+                                         unsigned char *smem) {
   static_assert(!TN || EPI == BE_F32, "the k-strided form only serves the weight gradients");
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int grp = wave >> 2, wc = wave & 3;
   const int l31 = lane & 31, h = lane >> 5;
-
-  int tm, tn;
-  if (g.K <= 512) tile_of_block_rowmajor(blockIdx.x, gridDim.x, g.tiles_n, tm, tn);   // output-bound
-  else tile_of_block(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, tm, tn);
-  const int m0 = tm * kTileM, n0 = tn * kTileN;
-  const int split = blockIdx.y;
-  const int k_begin = split * g.k_per_split;
-  const int k_end = min(g.K, k_begin + g.k_per_split);
-  const int n_ktiles = k_end > k_begin ? (k_end - k_begin) / kTileK : 0;   // even (host)
 
   const i32x4 srd_a = make_srd(g.A, (int64_t)(TN ? g.K : g.M) * g.lda * 2);
   const i32x4 srd_b = make_srd(g.B, (int64_t)(TN ? g.K : g.N) * g.ldb * 2);
@@ -252,8 +251,9 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   // in the read part of the phase, where the wave only waits anyway.
   float cs[2] = {0.f, 0.f};
   float cs16[4] = {0.f, 0.f, 0.f, 0.f};      // S16: column blocks 0, 1 of B-h0 and of B-h1
-  const bool cs_on = TN && g.colsum_partial != nullptr;
-  const int cs_owner = 2 * tm + grp, cs_period = 2 * g.tiles_m;
+  const bool cs_on = TN && cs_row != nullptr;
+  const int cs_period = 2 * g.tiles_m;
+  const int cs_owner = (2 * tm + grp + cs_period - (k_begin / kTileK) % cs_period) % cs_period;   // in K-tiles from k_begin
   auto frag_sum = [&](const bf16x8 &f) {
     float s = 0.f;
 #pragma unroll
@@ -421,8 +421,7 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const float v = cs[ct] + __shfl_xor(cs[ct], 32, 64);
-      if (h == 0)
-        g.colsum_partial[(int64_t)((split * g.tiles_m + tm) * 2 + grp) * g.N + n0 + ct * 128 + wc * 32 + l31] = v;
+      if (h == 0) cs_row[grp * cs_grp_stride + ct * 128 + wc * 32 + l31] = v;
     }
   }
   if (TN && cs_on && S16) {    // the four 16-lane groups hold the four k-quarters of column l15
@@ -430,9 +429,7 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
     for (int cbt = 0; cbt < 4; ++cbt) {
       float v = cs16[cbt] + __shfl_xor(cs16[cbt], 16, 64);
       v += __shfl_xor(v, 32, 64);
-      if (q16 == 0)
-        g.colsum_partial[(int64_t)((split * g.tiles_m + tm) * 2 + grp) * g.N + n0 + (cbt >> 1) * 128 + wc * 32 +
-                         (cbt & 1) * 16 + l15] = v;
+      if (q16 == 0) cs_row[grp * cs_grp_stride + (cbt >> 1) * 128 + wc * 32 + (cbt & 1) * 16 + l15] = v;
     }
   }
 
@@ -440,7 +437,8 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   float *sC = reinterpret_cast<float *>(smem + wave * 16384);
   const int c4 = lane & 15;
   // NT: the strip's 64 columns are contiguous; TN: 32 of each column half
-  const int gcol = TN ? n0 + (c4 >> 3) * 128 + wc * 32 + (c4 & 7) * 4 : n0 + wc * 64 + c4 * 4;
+  const int lcol = TN ? (c4 >> 3) * 128 + wc * 32 + (c4 & 7) * 4 : wc * 64 + c4 * 4;     // tile-local column
+  const int gcol = n0 + lcol;
   f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
   if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + gcol);
   const bool has_aux = (EPI == BE_MASK_BF16) && g.aux != nullptr;
@@ -511,13 +509,122 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
       if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_MASK_BF16) {
         if (EPI == BE_BIAS_LRELU_BF16 && g.mask_out && !(c4 & 1))
           g.mask_out[(int64_t)row * g.ldmask + (gcol >> 3)] = (uint8_t)nib;
-        *reinterpret_cast<bf16x4 *>(static_cast<bf16 *>(g.C) + (int64_t)row * g.ldc + gcol) = o;
+        *reinterpret_cast<bf16x4 *>(static_cast<bf16 *>(c_base) + (int64_t)(row - m0 + c_row0) * c_ld + c_col0 + lcol) = o;
       } else {
-        float *C = static_cast<float *>(g.C) + (EPI == BE_F32 ? (int64_t)split * g.slab_stride : 0);
-        *reinterpret_cast<f32x4 *>(C + (int64_t)row * g.ldc + gcol) = v;
+        *reinterpret_cast<f32x4 *>(static_cast<float *>(c_base) + (int64_t)(row - m0 + c_row0) * c_ld + c_col0 + lcol) = v;
       }
     }
   }
+}
+
+template <bool TN, int EPI, bool S16>
+__global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  int tm, tn;
+  if (g.K <= 512) tile_of_block_rowmajor(blockIdx.x, gridDim.x, g.tiles_n, tm, tn);   // output-bound
+  else tile_of_block(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, tm, tn);
+  const int m0 = tm * kTileM, n0 = tn * kTileN;
+  const int split = blockIdx.y;
+  const int k_begin = split * g.k_per_split;
+  const int k_end = min(g.K, k_begin + g.k_per_split);
+  const int n_ktiles = k_end > k_begin ? (k_end - k_begin) / kTileK : 0;   // even (host)
+  void *c_base = EPI == BE_F32 ? static_cast<void *>(static_cast<float *>(g.C) + (int64_t)split * g.slab_stride) : g.C;
+  float *cs_row = (TN && g.colsum_partial) ? g.colsum_partial + (int64_t)((split * g.tiles_m + tm) * 2) * g.N + n0 : nullptr;
+  run_tile<TN, EPI, S16>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
+}
+
+// ---- both weight gradients of the tower in ONE launch (k-strided form; dW1 = x_hat^T dz1, dW2 = h1^T dz2) ----
+// The two products contract over the same K (the batch rows).  Their output tiles, each cut into UNITS of two
+// K-tiles, form one line of work: tiles of problem 0 then problem 1, a tile's units in k order, tiles ordered
+// tm fastest (neighbouring blocks share the B panel).  The launch has one block per CU and block b takes the
+// units [b U, (b+1) U): at most a tile's tail and the next tile's head (U < units per tile at the shapes this is
+// used for; any number of pieces is handled).  Every piece -- a SEGMENT, the line cut at block AND tile
+// boundaries -- is written as a tile-local fp32 partial (256 x 256, contiguous) to slot number
+// u/U + u/upt - u/lcm(U, upt) (u = its first unit), with its owned column sums of B beside it; k_sk_fixup_tn
+// adds a tile's partials in k order (fixed order: bit-reproducible) and finishes the bias gradients.
+// What it buys over one split-K launch per product: the second layer's product (N = 256: 20 tiles, bound by
+// streaming h1 from HBM) no longer has the chip to itself -- its blocks run beside the first layer's MFMA-bound
+// ones -- and every CU gets the same number of K-tiles.
+struct SKArgs {
+  BArgs p[2];
+  int tiles0;              // tiles of problem 0
+  int upt;                 // units per tile = K / 128
+  int total_units, units_per_block, lcm_units;
+  float *partials;         // [slots][256 * 256]
+  float *cs_partials;      // [slots][2][256] (column sums of B per row group) or null
+};
+
+__device__ __forceinline__ int sk_slot(const SKArgs &a, int u) {
+  return u / a.units_per_block + u / a.upt - u / a.lcm_units;
+}
+
+template <bool S16>
+__global__ void __launch_bounds__(kT, 1) k_gemm_bf16_sk(SKArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  int u = blockIdx.x * a.units_per_block;
+  const int end = min(u + a.units_per_block, a.total_units);
+  bool first = true;
+  while (u < end) {
+    const int tg = u / a.upt, ku = u - tg * a.upt;
+    const int len = min(a.upt - ku, end - u);
+    const int pi = tg >= a.tiles0 ? 1 : 0;
+    const BArgs &g = a.p[pi];
+    const int tl = tg - (pi ? a.tiles0 : 0);
+    const int tn = tl / g.tiles_m, tm = tl - tn * g.tiles_m;
+    const int slot = sk_slot(a, u);
+    if (!first) CDML_BARRIER();                      // the previous segment's epilogue strips are LDS images again
+    first = false;
+    run_tile<true, BE_F32, S16>(g, tm, tm * kTileM, tn * kTileN, ku * 2 * kTileK, len * 2,
+                                a.partials + (int64_t)slot * (kTileM * kTileN), kTileN, 0, 0,
+                                a.cs_partials ? a.cs_partials + (int64_t)slot * (2 * kTileN) : nullptr, kTileN, smem);
+    u += len;
+  }
+}
+
+// Sum the partials of every tile (in k order) into the two outputs and finish the column sums.
+// Blocks [0, 16 n_tiles): 16 rows x 256 columns of one tile each; then one block per (problem, column tile).
+__global__ void __launch_bounds__(256) k_sk_fixup_tn(SKArgs a, float *db0, float *db1) {
+  const int n_tiles = a.total_units / a.upt;
+  const int U = a.units_per_block;
+  if ((int)blockIdx.x < 16 * n_tiles) {
+    const int tg = blockIdx.x >> 4, part = blockIdx.x & 15;
+    const int pi = tg >= a.tiles0 ? 1 : 0;
+    const BArgs &g = a.p[pi];
+    const int tl = tg - (pi ? a.tiles0 : 0);
+    const int tn = tl / g.tiles_m, tm = tl - tn * g.tiles_m;
+    const int g0 = tg * a.upt, g1 = g0 + a.upt;
+    const int r = part * 16 + (threadIdx.x >> 4), c = (threadIdx.x & 15) * 16;      // 16 floats per thread
+    f32x4 s[4];
+    bool have = false;
+    for (int st = g0; st < g1; st = (st / U + 1) * U) {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(a.partials + (int64_t)sk_slot(a, st) * (kTileM * kTileN) + r * kTileN + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] = have ? s[j] + src[j] : src[j];
+      have = true;
+    }
+    float *dst = static_cast<float *>(g.C) + (int64_t)(tm * kTileM + r) * g.ldc + tn * kTileN + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) reinterpret_cast<f32x4 *>(dst)[j] = s[j];
+    return;
+  }
+  if (!a.cs_partials) return;
+  int ct = blockIdx.x - 16 * n_tiles;                 // (problem, column tile)
+  const int pi = ct >= a.p[0].tiles_n ? 1 : 0;
+  const BArgs &g = a.p[pi];
+  float *db = pi ? db1 : db0;
+  if (!db) return;
+  const int tn = ct - (pi ? a.p[0].tiles_n : 0);
+  float acc = 0.f;
+  for (int tm = 0; tm < g.tiles_m; ++tm) {
+    const int tg = (pi ? a.tiles0 : 0) + tn * g.tiles_m + tm;
+    const int g0 = tg * a.upt, g1 = g0 + a.upt;
+    for (int st = g0; st < g1; st = (st / U + 1) * U) {
+      const float *src = a.cs_partials + (int64_t)sk_slot(a, st) * (2 * kTileN) + threadIdx.x;
+      acc += src[0];
+      acc += src[kTileN];
+    }
+  }
+  db[tn * kTileN + threadIdx.x] = acc;
 }
 
 template <bool TN, int EPI, bool S16>
@@ -586,5 +693,64 @@ bool gemm_bf16_tn_usable(int M, int N, int K, int64_t lda, int64_t ldb) {
 }
 
 int launch_gemm_bf16_tn(const BArgs &g, int splits, hipStream_t s) { return launch<true, BE_F32>(g, splits, s); }
+
+// ---- the joint launch: geometry shared by the workspace query and the launch ----
+namespace {
+struct SKGeom { int tiles0, tiles1, upt, total, U, lcm, slots; };
+int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+bool sk_geometry(int M1, int N1, int M2, int N2, int K, SKGeom &q) {
+  if (M1 % kTileM || N1 % kTileN || M2 % kTileM || N2 % kTileN || K % (2 * kTileK) || K < 2 * kTileK) return false;
+  q.tiles0 = (M1 / kTileM) * (N1 / kTileN);
+  q.tiles1 = (M2 / kTileM) * (N2 / kTileN);
+  q.upt = K / (2 * kTileK);
+  const int64_t total = (int64_t)(q.tiles0 + q.tiles1) * q.upt;
+  if (total > (1 << 28)) return false;
+  q.total = (int)total;
+  q.U = (q.total + kNumCU - 1) / kNumCU;
+  const int64_t l = (int64_t)q.U / gcd_i(q.U, q.upt) * q.upt;
+  q.lcm = l > (int64_t)q.total + 1 ? q.total + 1 : (int)l;           // beyond the line: never reached
+  q.slots = q.total / q.U + q.total / q.upt - q.total / q.lcm + 1;
+  return true;
+}
+}  // namespace
+
+size_t gemm_bf16_tn2_workspace(int M1, int N1, int M2, int N2, int K) {
+  SKGeom q;
+  if (!sk_geometry(M1, N1, M2, N2, K, q)) return 0;
+  return (size_t)q.slots * (kTileM * kTileN + 2 * kTileN) * sizeof(float);
+}
+
+int launch_gemm_bf16_tn2(const BArgs &g1, const BArgs &g2, float *db1, float *db2, void *workspace, size_t workspace_bytes,
+                         hipStream_t s) {
+  SKGeom q;
+  if (!sk_geometry(g1.M, g1.N, g2.M, g2.N, g1.K, q) || g1.K != g2.K)
+    return fail(CDML_E_UNSUPPORTED, "gemm_bf16_tn2: shapes must be multiples of 256 (M, N) and 128 (one K for both)");
+  const size_t need = (size_t)q.slots * (kTileM * kTileN + 2 * kTileN) * sizeof(float);
+  if (!workspace || workspace_bytes < need) return fail(CDML_E_BADARG, "gemm_bf16_tn2: workspace of %zu bytes required", need);
+  SKArgs a{};
+  a.p[0] = g1; a.p[1] = g2;
+  a.p[0].tiles_m = g1.M / kTileM; a.p[0].tiles_n = g1.N / kTileN;
+  a.p[1].tiles_m = g2.M / kTileM; a.p[1].tiles_n = g2.N / kTileN;
+  a.tiles0 = q.tiles0; a.upt = q.upt; a.total_units = q.total; a.units_per_block = q.U; a.lcm_units = q.lcm;
+  a.partials = static_cast<float *>(workspace);
+  a.cs_partials = (db1 || db2) ? a.partials + (size_t)q.slots * (kTileM * kTileN) : nullptr;
+  const bool s16 = shape16();
+  static bool configured[2] = {false, false};
+  if (!configured[s16]) {
+    const void *fn = s16 ? reinterpret_cast<const void *>(&k_gemm_bf16_sk<true>) : reinterpret_cast<const void *>(&k_gemm_bf16_sk<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16_tn2: cannot reserve %d B of LDS: %s", SMEM, hipGetErrorString(e));
+    configured[s16] = true;
+  }
+  const int blocks = (q.total + q.U - 1) / q.U;
+  if (s16) hipLaunchKernelGGL((k_gemm_bf16_sk<true>), dim3(blocks), dim3(kT), SMEM, s, a);
+  else hipLaunchKernelGGL((k_gemm_bf16_sk<false>), dim3(blocks), dim3(kT), SMEM, s, a);
+  int rc = check_launch("gemm_bf16_tn2");
+  if (rc) return rc;
+  const int n_tiles = q.tiles0 + q.tiles1;
+  const int cs_blocks = a.cs_partials ? a.p[0].tiles_n + a.p[1].tiles_n : 0;
+  hipLaunchKernelGGL(k_sk_fixup_tn, dim3(16 * n_tiles + cs_blocks), dim3(256), 0, s, a, db1, db2);
+  return check_launch("gemm_bf16_tn2 fix-up");
+}
 
 }  // namespace cdml

@@ -95,7 +95,10 @@ class TowerWorkspaceBF16:
             self.xT, self.dz1T = bf(L.Fp, R), bf(L.Hp, R)
         if not self.tn2:
             self.h1T, self.dz2T = bf(L.Hp, R), bf(L.Dp, R)
-        nb = max(ops.gemm_bf16_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_workspace(L.Fp, L.Hp, R),
+        # both weight gradients in one stream-K launch when the shapes allow (0 = they do not)
+        self.tn2_bytes = ops.gemm_bf16_tn2_workspace(L.Fp, L.Hp, L.Hp, L.Dp, R) if (self.tn1 and self.tn2) else 0
+        nb = max(self.tn2_bytes,
+                 ops.gemm_bf16_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_workspace(L.Fp, L.Hp, R),
                  ops.gemm_bf16_workspace(R, L.Dp, L.Hp),
                  ops.gemm_bf16_tn_workspace(L.Hp, L.Dp, R), ops.gemm_bf16_tn_workspace(L.Fp, L.Hp, R),
                  ops.gemm_bf16_tn_workspace(L.Fp // 2, L.Hp, R), 16)      # dW1 in two row blocks (data-parallel)
@@ -140,8 +143,23 @@ def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
     if not getattr(ws, "tail_done", False):          # the fused tail writes dz2 and its bf16 copy
         ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
         ops.cast_f32_bf16(ws.dz2, ws.dz2_bf, R, L.Dp)
-    w2_first = (after_w1 is None and after_w1_chunk is None and ws.tn2
-                and not os.environ.get("CDML_BF16_W2_LAST"))            # (the switch: A/B runs)
+    single = after_w1 is None and after_w1_chunk is None
+    how = os.environ.get("CDML_BF16_DW", "split")                        # (the switch: A/B runs)
+    joint = single and ws.tn2_bytes and how == "joint"
+    w2_first = single and not joint and ws.tn2 and not os.environ.get("CDML_BF16_W2_LAST")
+    if joint:
+        # NOT the default (profiles/r03_bf16_joint_dw.txt): data gradient first, then BOTH weight gradients and
+        # both bias gradients in one stream-K launch + fix-up pass.  Every block gets the same number of K-tiles,
+        # but blocks that sit at different k share no operand panels in L2 and the launch runs 29 % slower than
+        # the two split-K launches (the same finding as the fp32 pure stream-K of round 2).  Running dW2 on a
+        # side stream beside dW1 was measured too: the two finish 23 us sooner, the fork/join costs 34.
+        if ws.h1_bits is not None:
+            ops.gemm_bf16_nt(ops.BE_MASKBITS_BF16, ws.dz2_bf, ws.W2, ws.dz1, R, L.Hp, L.Dp, aux=ws.h1_bits)
+        else:
+            ops.gemm_bf16_nt(ops.BE_MASK_BF16, ws.dz2_bf, ws.W2, ws.dz1, R, L.Hp, L.Dp, aux=ws.h1)
+        ops.gemm_bf16_tn2(ws.x_hat, ws.dz1, p.gW1, L.Fp, L.Hp, ws.h1, ws.dz2_bf, p.gW2, L.Hp, L.Dp, R, ws.gemm_ws,
+                          colsum1=p.gb1, colsum2=p.gb2)
+        return p.grad
     if w2_first:
         # db2 = column sums of the bf16 dz2 the two products consume, from the LDS tiles of the same GEMM
         ops.gemm_bf16_tn(ws.h1, ws.dz2_bf, p.gW2, L.Hp, L.Dp, R, workspace=ws.gemm_ws, colsum=p.gb2)

@@ -375,6 +375,24 @@ def gemm_bf16_tn(A, B, C, M, N, K, workspace=None, colsum=None):
     return C
 
 
+def gemm_bf16_tn2_workspace(M1, N1, M2, N2, K):
+    """0 = shapes the joint launch does not take (use gemm_bf16_tn per product)."""
+    return int(load_library().cdml_gemm_bf16_tn2_workspace(M1, N1, M2, N2, K))
+
+
+def gemm_bf16_tn2(A1, B1, C1, M1, N1, A2, B2, C2, M2, N2, K, workspace, colsum1=None, colsum2=None):
+    """C1 = A1^T.B1 and C2 = A2^T.B2 (k-strided operands, one K) in one stream-K launch + fix-up pass."""
+    a1, lda1 = _mat16(A1)
+    b1, ldb1 = _mat16(B1)
+    c1, ldc1 = _mat(C1)
+    a2, lda2 = _mat16(A2)
+    b2, ldb2 = _mat16(B2)
+    c2, ldc2 = _mat(C2)
+    call("cdml_gemm_bf16_tn2", a1, lda1, b1, ldb1, M1, N1, c1, ldc1, _p(colsum1, torch.float32), a2, lda2, b2, ldb2,
+         M2, N2, c2, ldc2, _p(colsum2, torch.float32), K, _p(workspace), workspace.numel() * workspace.element_size(),
+         _stream())
+
+
 def transpose_to_bf16(src, dst, rows, cols):
     call("cdml_transpose_to_bf16", 1 if src.dtype == torch.float32 else 0, _p(src), src.stride(0), rows, cols,
          _p(dst, torch.bfloat16), dst.stride(0), _stream())

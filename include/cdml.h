@@ -365,6 +365,20 @@ int cdml_gemm_bf16_tn(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t
                       int M, int N, int K, float *C, int64_t ldc, float *colsum,
                       void *workspace, size_t workspace_bytes, cdml_stream_t stream);
 
+/* BOTH weight gradients of the two-layer tower in one launch (train.py:141): C1 = A1^T B1 and
+ * C2 = A2^T B2 over the same K (the batch rows), as cdml_gemm_bf16_tn each; colsum1 / colsum2
+ * (nullable) = column sums of B1 / B2 (the bias gradients).  One block per CU takes an equal run
+ * of the joint (tile, k) iteration space; the pieces are written as tile-local fp32 partials
+ * and a fix-up pass adds them in k order (bit-reproducible).  The narrow second-layer product,
+ * bound by streaming its activations from HBM, runs beside the first layer's MFMA-bound one.
+ * cdml_gemm_bf16_tn2_workspace: bytes needed; 0 = shapes not taken (M, N % 256, K % 128). */
+size_t cdml_gemm_bf16_tn2_workspace(int M1, int N1, int M2, int N2, int K);
+int cdml_gemm_bf16_tn2(const uint16_t *A1, int64_t lda1, const uint16_t *B1, int64_t ldb1,
+                       int M1, int N1, float *C1, int64_t ldc1, float *colsum1,
+                       const uint16_t *A2, int64_t lda2, const uint16_t *B2, int64_t ldb2,
+                       int M2, int N2, float *C2, int64_t ldc2, float *colsum2, int K,
+                       void *workspace, size_t workspace_bytes, cdml_stream_t stream);
+
 /* dst[c][r] = bf16(src[r][c]) (src fp32 or bf16): k-contiguous copies of weights
  * and of activations for the weight-gradient GEMMs (contraction over batch rows). */
 int cdml_transpose_to_bf16(int src_is_f32, const void *src, int64_t ld_src,

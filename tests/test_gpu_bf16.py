@@ -106,6 +106,52 @@ def test_gemm_bf16_tn_weight_gradient_form(cd, M, N, K, mfma, monkeypatch):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("mfma", ["16", "32"])
+@pytest.mark.parametrize("M1,N1,M2,N2,K", [(256, 256, 256, 256, 128), (512, 768, 1280, 256, 1280),
+                                            (1536, 5120, 5120, 256, 6144), (1536, 5120, 5120, 256, 24576)])
+def test_gemm_bf16_tn2_joint_weight_gradients(cd, M1, N1, M2, N2, K, mfma, monkeypatch):
+    """Both weight gradients (and both bias gradients) in ONE stream-K launch + fix-up pass: values against
+    fp64 on the bf16-rounded operands, column sums, equality with the one-product entry point up to the
+    summation order over k, bit-identical repetition, strided views; shapes from one tile per product (more
+    CUs than units) to config 4's (140 tiles x 192 units over 256 CUs: tile tails and heads everywhere)."""
+    monkeypatch.setenv("CDML_BF16_MFMA", mfma)
+    ops = cd.ops
+    g_ = torch.Generator(device=cd.dev)
+    g_.manual_seed(M1 + N2 + K)
+    rnd = lambda r, c, sc: (torch.randn(r, c, device=cd.dev, generator=g_) * sc)
+    kscale = (1.0 + (torch.arange(K, device=cd.dev) % 7) * 0.25)[:, None]       # a wrong k-permutation shows
+    A1 = (rnd(K, M1 + 64, K ** -0.5) * kscale).bfloat16()                       # wider buffers: strides honoured
+    B1 = rnd(K, N1, 1.0).bfloat16()
+    A2 = (rnd(K, M2, K ** -0.5) * kscale).bfloat16()
+    B2 = rnd(K, N2 + 8, 1.0).bfloat16()
+    nbytes = ops.gemm_bf16_tn2_workspace(M1, N1, M2, N2, K)
+    assert nbytes > 0 and ops.gemm_bf16_tn2_workspace(M1 + 8, N1, M2, N2, K) == 0
+    ws = torch.empty(nbytes // 4, device=cd.dev)
+    C1 = torch.full((M1, N1 + 4), 5.0, device=cd.dev)
+    C2 = torch.full((M2, N2), 5.0, device=cd.dev)
+    d1, d2 = torch.full((N1,), 5.0, device=cd.dev), torch.full((N2,), 5.0, device=cd.dev)
+    run = lambda c1, c2, e1, e2: ops.gemm_bf16_tn2(A1[:, :M1], B1, c1[:, :N1], M1, N1, A2, B2[:, :N2], c2, M2, N2, K, ws,
+                                                    colsum1=e1, colsum2=e2)
+    run(C1, C2, d1, d2)
+    tol = 1e-4 * (K / 64) ** 0.5
+    ref1 = A1[:, :M1].double().T @ B1.double()
+    ref2 = A2.double().T @ B2[:, :N2].double()
+    assert float((C1[:, :N1].double() - ref1).abs().max()) <= tol and float((C2.double() - ref2).abs().max()) <= tol
+    assert bool((C1[:, N1:] == 5.0).all())
+    assert float((d1.double() - B1.double().sum(0)).abs().max()) <= 2e-4 * K ** 0.5
+    assert float((d2.double() - B2[:, :N2].double().sum(0)).abs().max()) <= 2e-4 * K ** 0.5
+    # the one-product entry point: same products, other split of K
+    ws1 = torch.empty(max(ops.gemm_bf16_tn_workspace(M1, N1, K), ops.gemm_bf16_tn_workspace(M2, N2, K), 16) // 4, device=cd.dev)
+    S1, S2 = torch.empty((M1, N1), device=cd.dev), torch.empty((M2, N2), device=cd.dev)
+    ops.gemm_bf16_tn(A1[:, :M1], B1, S1, M1, N1, K, workspace=ws1)
+    ops.gemm_bf16_tn(A2, B2[:, :N2], S2, M2, N2, K, workspace=ws1)
+    assert float((C1[:, :N1] - S1).abs().max()) <= tol and float((C2 - S2).abs().max()) <= tol
+    for _ in range(3):                                                   # bit-identical repetition, no bias gradients asked
+        E1, E2 = torch.empty_like(C1), torch.empty_like(C2)
+        run(E1, E2, None, None)
+        assert torch.equal(E1[:, :N1], C1[:, :N1]) and torch.equal(E2, C2)
+
+
 @pytest.mark.parametrize("M,N", [(16384, 256), (2075, 5120), (24576 + 17, 2048), (4096, 1024)])
 def test_gemm_bf16_k256_streaming_data_gradient(cd, M, N, monkeypatch):
     """The K = 256 mask-epilogue product on the streaming kernel (gemm_bf16_k256.hip; taken when

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build build/variants/libcdml_<tag>.so from the CURRENT csrc/ with the named files taken from a git revision
+# instead (a same-box A/B of one kernel: CDML_LIB_PATH=build/variants/libcdml_<tag>.so python tools/...).
+# usage: tools/experiments/variant_from_rev.sh TAG REV file.hip [file2.hip ...]
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+CSRC=$ROOT/collaborative-deep-metric-learning_amd/csrc
+TAG=$1; REV=$2; shift 2
+d=$(mktemp -d)
+cp $CSRC/*.hip $CSRC/*.h $d/
+for f in "$@"; do git -C $ROOT show $REV:collaborative-deep-metric-learning_amd/csrc/$f > $d/$f; done
+mkdir -p $ROOT/build/variants
+(cd $d && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$CSRC -o $ROOT/build/variants/libcdml_$TAG.so *.hip 2>/dev/null)
+rm -rf $d
+echo built build/variants/libcdml_$TAG.so

@@ -130,6 +130,39 @@ for name, M, N, K in (("dW1 tn F x H x R", F, H, R), ("dW2 tn H x D x R", H, D, 
     print("%-16s tn: %7.4f ms %7.1f TF (%.3f) | transposes+nt: %7.4f ms | max abs diff %.2e"
           % (name, res[0], fl / res[0] / 1e9, fl / res[0] / 1e9 / 2500, res[1], (out - out2).abs().max().item()))
 
+# both weight gradients in one stream-K launch + fix-up against the two split-K launches + their combines
+M1, N1, M2, N2, K = F, H, H, D, R
+nb = ops.gemm_bf16_tn2_workspace(M1, N1, M2, N2, K)
+if nb:
+    A1 = (torch.randn(K, M1, device=dev) / K ** 0.5).bfloat16(); B1 = torch.randn(K, N1, device=dev).bfloat16()
+    A2 = (torch.randn(K, M2, device=dev) / K ** 0.5).bfloat16(); B2 = torch.randn(K, N2, device=dev).bfloat16()
+    C1, C2 = torch.empty((M1, N1), device=dev), torch.empty((M2, N2), device=dev)
+    d1, d2 = torch.empty(N1, device=dev), torch.empty(N2, device=dev)
+    ws = torch.empty(max(nb, ops.gemm_bf16_tn_workspace(M1, N1, K), ops.gemm_bf16_tn_workspace(M2, N2, K)) // 4, device=dev)
+
+    def two():
+        ops.gemm_bf16_tn(A2, B2, C2, M2, N2, K, workspace=ws, colsum=d2)
+        ops.gemm_bf16_tn(A1, B1, C1, M1, N1, K, workspace=ws, colsum=d1)
+    joint = lambda: ops.gemm_bf16_tn2(A1, B1, C1, M1, N1, A2, B2, C2, M2, N2, K, ws, colsum1=d1, colsum2=d2)
+    t = {"two": [], "joint": []}
+    for rnd in range(6):
+        for name, fn in (("two", two), ("joint", joint)):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(iters):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            t[name].append(s.elapsed_time(e) / iters)
+    fl = 2.0 * K * (M1 * N1 + M2 * N2)
+    med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
+    print("dW1 + dW2 (+ db1, db2): two split-K launches + combines: median %7.4f ms %7.1f TF (%.3f) | one stream-K launch + fix-up: "
+          "median %7.4f ms %7.1f TF (%.3f)" % (med["two"], fl / med["two"] / 1e9, fl / med["two"] / 1e9 / 2500,
+                                               med["joint"], fl / med["joint"] / 1e9, fl / med["joint"] / 1e9 / 2500))
+
 # the vendor library (torch.mm -> hipBLASLt, bf16 in / bf16 out, no fused epilogue) on the same shapes
 if len(sys.argv) > 3 and sys.argv[3] == "lib":
     for name, M, N, K, tb in (("lib fc1  NT", R, H, F, True), ("lib dW1  TN", F, H, R, False), ("lib fc2  NT", R, D, H, True)):
