@@ -710,6 +710,8 @@ def main():
     ap.add_argument("--extras", default=None,
                     help="comma list of secondary records to run (default: all): like_for_like,dp_form_one_gpu,"
                          "config4_per_gpu,reference_recipe,fusion_resnet,predict,data_learnable")
+    ap.add_argument("--only", default=None, choices=["reference_recipe", "fusion_resnet", "data_learnable"],
+                    help="run ONE secondary record as the job (its JSON line; for rocprofv3 runs of that workload)")
     ap.add_argument("--no-settle", action="store_true",
                     help="skip the 0.3 s GEMM loop before the warm-up steps (rocprof runs: keeps its launches out of the kernel averages)")
     args = ap.parse_args()
@@ -752,6 +754,25 @@ def main():
                "steps": r["passes_timed"], "warmup": 1, "ms_per_step": round(r["seconds"] * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": r["dtype"], "data": "synthetic",
                "config": {"workload": r["workload"]}, "predict": r}
+        print(json.dumps(out), file=result_out, flush=True)
+        return
+
+    if args.only:                                        # one secondary record as the whole job (N = 1)
+        if world != 1:
+            sys.exit("--only is a one-GPU measurement")
+        set_phase("only: " + args.only)
+        if not args.no_settle:
+            settle_gpu(dev)
+        n_s, n_w = args.steps, args.warmup
+        if args.only == "reference_recipe":
+            r = rec_reference_recipe(dev, args, n_s, n_w, engine.FeatureTable.synthetic(1000000, F, seed=0, device=dev))
+        elif args.only == "fusion_resnet":
+            r = rec_fusion(dev, args, n_s, n_w)
+        else:
+            r = rec_learnable(dev, args, n_s, n_w, args.batch or 4096)
+        out = {"metric": "triplets/sec", "value": r["value"], "unit": "triplets/s", "n_gpus": 1, "steps": r["steps"],
+               "warmup": n_w, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": r["workload"]}, args.only: r}
         print(json.dumps(out), file=result_out, flush=True)
         return
 

@@ -39,6 +39,10 @@ cases = [
     ("dH1      NT", 2.0 * R * H * D, lambda: ops.fc_bwd_data(ws.dz2, p.W2, ws.h1, ws.dz1, R, L.Hp, L.Dp)),
     ("dW1      TN", 2.0 * R * F * H, lambda: ops.fc_bwd_weight(ws.x_hat, ws.dz1, p.gW1, p.gb1, ws.bw, R, L.Fp, L.Hp)),
 ]
+if ws.sk_bytes:            # the single-GPU step's form: both weight gradients in one stream-K launch + fix-up
+    cases.append(("dW1+dW2  SK", 2.0 * R * F * H + 2.0 * R * H * D,
+                  lambda: ops.fc_bwd_weight2(ws.x_hat, ws.dz1, p.gW1, p.gb1, L.Fp, L.Hp, ws.h1, ws.dz2, p.gW2, p.gb2,
+                                             L.Hp, L.Dp, R, ws.bw)))
 if len(sys.argv) > 4 and sys.argv[4] == "lib":
     torch.backends.cuda.matmul.allow_tf32 = False
     xh, h1, dz1, dz2 = ws.x_hat[:R], ws.h1[:R], ws.dz1[:R], ws.dz2[:R]
