@@ -236,17 +236,20 @@ k_colsum_partial(const SRC *__restrict__ in, int64_t ld, int rows, int cols, int
 // (One thread per column walking all chunks one after the other took 34 us at 256 chunks.)
 __global__ void __launch_bounds__(kThreads)
 k_colsum_final(const float *__restrict__ partial, int chunks, int cols, float *__restrict__ out) {
-  __shared__ f32x4 red[8][32];
-  const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 128 + c4 * 4;
+  // CQ column quads x RL row lanes per block: few columns and many partial rows (the second layer's bias gradient:
+  // 480 rows x 256 columns) get 32 row lanes over 8 blocks instead of 8 over 2 (10.5 -> ~4 us)
+  __shared__ f32x4 red[kThreads];
+  const bool narrow = gridDim.x * 32 >= (unsigned)cols;     // launched with (cols + 31) / 32 blocks
+  const int CQ = narrow ? 8 : 32, RL = kThreads / CQ;
+  const int c4 = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+  const int c = blockIdx.x * (CQ * 4) + c4 * 4;
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
   if (c < cols)
-    for (int k = rl; k < chunks; k += 8) s += *reinterpret_cast<const f32x4 *>(partial + (int64_t)k * cols + c);
-  red[rl][c4] = s;
+    for (int k = rl; k < chunks; k += RL) s += *reinterpret_cast<const f32x4 *>(partial + (int64_t)k * cols + c);
+  red[rl * CQ + c4] = s;
   __syncthreads();
   if (rl == 0 && c < cols) {
-#pragma unroll
-    for (int j = 1; j < 8; ++j) s += red[j][c4];
+    for (int j = 1; j < RL; ++j) s += red[j * CQ + c4];
     *reinterpret_cast<f32x4 *>(out + c) = s;
   }
 }
@@ -408,6 +411,12 @@ static int fwd_f32_splits(int M, int N, int K, int64_t lda, int64_t ldb) {
   if (s > max_by_k) s = max_by_k;
   if (s > 8) s = 8;
   return s < 2 ? 1 : s;
+}
+
+// k_colsum_final's grid: 32 columns per block (32 row lanes) when there are many partial rows for few columns,
+// else 128 columns per block (8 row lanes); the kernel tells the two apart by gridDim.x
+static int colsum_final_blocks(int chunks, int cols) {
+  return (chunks >= 64 && cols <= 1024) ? (cols + 31) / 32 : (cols + 127) / 128;
 }
 
 extern "C" size_t cdml_gemm_bf16_workspace(int M, int N, int K) {
@@ -573,7 +582,7 @@ extern "C" int cdml_gemm_bf16_tn(const uint16_t *A, int64_t lda, const uint16_t 
     if ((rc = check_launch("gemm_bf16_tn combine"))) return rc;
   }
   if (colsum) {
-    hipLaunchKernelGGL(k_colsum_final, dim3((N + 127) / 128), dim3(kThreads), 0, s,
+    hipLaunchKernelGGL(k_colsum_final, dim3(colsum_final_blocks(chunks, N)), dim3(kThreads), 0, s,
                        g.colsum_partial, chunks, N, colsum);
     rc = check_launch("gemm_bf16_tn bias gradient");
   }
@@ -665,7 +674,7 @@ extern "C" int cdml_colsum(int src_is_bf16, const void *src, int64_t ld, int row
   else
     hipLaunchKernelGGL((k_colsum_partial<float>), grid, dim3(kThreads), 0, s,
                        static_cast<const float *>(src), ld, rows, cols, rpc, workspace);
-  hipLaunchKernelGGL(k_colsum_final, dim3((cols + 127) / 128), dim3(kThreads), 0, s, workspace,
+  hipLaunchKernelGGL(k_colsum_final, dim3(colsum_final_blocks(chunks, cols)), dim3(kThreads), 0, s, workspace,
                      chunks, cols, out);
   return check_launch("colsum");
 }

@@ -128,7 +128,13 @@ class FusionTower:
             self.vs, self.ds, self.dvs, self.dds = z(D), z(D), z(D), z(D)   # branch sums and their gradients
         self.din = {n: z(L.Kp) for n, L in Ls.items() if n in ("layer_fusion_1", "layer_fusion_2")}
         nb = max(ops.fc_bwd_weight_workspace(R, L.Kp, L.Np) for L in Ls.values())
-        self.bw = torch.empty(max(nb, 16) // 4, dtype=torch.float32, device=dev)
+        # the visual branch is VNet's two layers: both of its weight gradients in one stream-K launch when the
+        # shapes allow (0 = they do not), as train.TrainStep does on one GPU
+        self.sk_bytes = 0
+        if "layer_visual_1" in Ls and "layer_visual_2" in Ls:
+            v1, v2 = Ls["layer_visual_1"], Ls["layer_visual_2"]
+            self.sk_bytes = ops.fc_bwd_weight2_workspace(R, v1.Kp, v1.Np, v2.Kp, v2.Np)
+        self.bw = torch.empty(max(nb, self.sk_bytes, 16) // 4, dtype=torch.float32, device=dev)
 
     def _fc(self, n, x):
         L = self.p.layers[n]
@@ -178,8 +184,10 @@ class FusionTower:
             ops.fc_bwd_data(d_pre, p.W(n), mask, d_in, self.R, L.Kp, L.Np)
         return d_in
 
-    def backward(self, de=None):
-        """de (default self.de): gradient wrt e -> p.grad."""
+    def backward(self, de=None, joint_visual=True):
+        """de (default self.de): gradient wrt e -> p.grad.  ``joint_visual``: the visual branch's two weight
+        gradients in one stream-K launch where the shapes allow (False: one split-K launch per layer; a
+        data-parallel step that overlaps per-layer all-reduces would ask for that)."""
         p, R, D = self.p, self.R, self.p.Dp
         de = self.de if de is None else de
         A, dp = self.act, self.dpre
@@ -214,9 +222,17 @@ class FusionTower:
             return p.grad
         ops.ew_fusion_bwd(res, dfu, A["layer_visual_2"], A["layer_doc_2"], dp["layer_visual_2"],
                           dp["layer_doc_2"], R, D)
-        self._bwd_fc("layer_visual_2", A["layer_visual_1"], dp["layer_visual_2"], dp["layer_visual_1"],
-                     mask=A["layer_visual_1"])
-        self._bwd_fc("layer_visual_1", self.xv, dp["layer_visual_1"])
+        if self.sk_bytes and joint_visual:
+            v1, v2 = p.layers["layer_visual_1"], p.layers["layer_visual_2"]
+            ops.fc_bwd_data(dp["layer_visual_2"], p.W("layer_visual_2"), A["layer_visual_1"], dp["layer_visual_1"],
+                            R, v2.Kp, v2.Np)
+            ops.fc_bwd_weight2(self.xv, dp["layer_visual_1"], p.gW("layer_visual_1"), p.gb("layer_visual_1"), v1.Kp, v1.Np,
+                               A["layer_visual_1"], dp["layer_visual_2"], p.gW("layer_visual_2"), p.gb("layer_visual_2"),
+                               v2.Kp, v2.Np, R, self.bw)
+        else:
+            self._bwd_fc("layer_visual_2", A["layer_visual_1"], dp["layer_visual_2"], dp["layer_visual_1"],
+                         mask=A["layer_visual_1"])
+            self._bwd_fc("layer_visual_1", self.xv, dp["layer_visual_1"])
         self._bwd_fc("layer_doc_2", A["layer_doc_1"], dp["layer_doc_2"], dp["layer_doc_1"], mask=A["layer_doc_1"])
         self._bwd_fc("layer_doc_1", self.xd, dp["layer_doc_1"])
         return p.grad
