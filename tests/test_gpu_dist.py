@@ -25,6 +25,11 @@ CFG_TABLE = dict(CFG, train_table=True)
 # four ranks on the card: uneven shards (3000 = 4 x 750 here, 3001 rows -> 751/751/751/748), every
 # pair of ranks exchanging rows, the 1/4 gradient average
 CFG_W4 = dict(CFG, world=4, n_rows=3001, B=16)
+# BASELINE configs 3 and 4 at their TRUE per-rank size, two ranks: the 10 M-row catalogue row-sharded (2 x 5 M rows: 30.7 GB
+# fp32 / 15.4 GB fp16 per rank), B = 8192 triplets per rank, production tower, rows over the (host-staged) all-to-all
+CFG_C3 = dict(n_rows=10000000, F=1500, H=5000, D=256, B=8192, steps=2, precision="f32")
+CFG_C4 = dict(CFG_C3, precision="bf16")
+CFG_C3_W4 = dict(CFG_C3, world=4)       # four ranks x 2.5 M rows, global batch 32 768
 
 
 def _make(dev, rank, world, exchange=None, grad_sync=None, c=None):
@@ -76,7 +81,9 @@ def _worker(rank, world, port, q, CFG=CFG):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_TABLE, CFG_W4], ids=["f32", "bf16", "trainable-table", "4-ranks"])
+@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_TABLE, CFG_W4, CFG_C3, CFG_C4, CFG_C3_W4],
+                         ids=["f32", "bf16", "trainable-table", "4-ranks", "config3-full-size", "config4-full-size",
+                              "config3-full-size-4-ranks"])
 def test_two_rank_step_equals_single_rank(gpu, CFG):
     bf16 = CFG["precision"] == "bf16"
     s = socket.socket()
@@ -89,7 +96,7 @@ def test_two_rank_step_equals_single_rank(gpu, CFG):
     procs = [ctx.Process(target=_worker, args=(r, W, port, q, CFG)) for r in range(W)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
     for r in res:
