@@ -572,15 +572,17 @@ def rec_dp_form(dev, args, n_s, n_w, keep):
                            "per-rank compute floor of the N>1 step form; exchange capacity = all requests at "
                            "world 1 (1.39 x padded at world 8)",
                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())}
-        for form in ("bucketed", "single"):
+        forms = {"bucketed": "dW1 in two split-K row blocks + dW2, all-reduce per bucket under the next GEMM",
+                 "two": "dW1 as one split-K launch, its all-reduce under the dW2 launch, [dW2|db2] after",
+                 "single": "one stream-K launch for dW1+dW2, then ONE all-reduce"}
+        for form in train.TrainStep.GRAD_SYNC_MODES:
             ts = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
                                  optimizer="adam", base_learning_rate=0.01, device=dev, exchange=ex, grad_sync=gs,
                                  batch_global=8192, grad_sync_mode=form)
             el = timed_steps(ts, n_s, n_w, dev)
             ts.check_inputs()
             out[form] = {"ms_per_step": round(el / n_s * 1e3, 4), "triplets_per_s": round(8192 * n_s / el, 1),
-                         "form": "dW1 in two split-K row blocks + dW2, all-reduce per bucket under the next GEMM"
-                                 if form == "bucketed" else "one stream-K launch for dW1+dW2, then ONE all-reduce"}
+                         "form": forms[form]}
             del ts
         out["steps"], out["warmup"] = n_s, n_w
         return out
@@ -698,7 +700,7 @@ def main():
     ap.add_argument("--train-table", action="store_true",
                     help="also train the catalogue rows (lazy Adam; build-defined, not the headline metric)")
     ap.add_argument("--gather-ahead", type=int, default=4, help="steps fetched per sampler+gather launch (1 GPU)")
-    ap.add_argument("--grad-sync", default="auto", choices=["auto", "bucketed", "single"],
+    ap.add_argument("--grad-sync", default="auto", choices=["auto", "bucketed", "two", "single"],
                     help="N>1: how the gradient all-reduce is issued (auto: both forms are timed for 5 steps "
                          "before the warm-up, the faster one is kept)")
     ap.add_argument("--capacity-factor", type=float, default=1.25,
@@ -840,7 +842,7 @@ def main():
             # each, max over ranks (so every rank picks the same one), before the warm-up steps
             set_phase("grad-sync probe")
             probe = {}
-            for form in ("bucketed", "single"):
+            for form in train.TrainStep.GRAD_SYNC_MODES:
                 ts.grad_sync_mode = form
                 for _ in range(2):
                     ts.step()
@@ -853,7 +855,7 @@ def main():
                 barrier()
                 probe[form + "_ms_per_step"] = round(reduce_max(time.perf_counter() - t0) / 5 * 1e3, 4)
                 pre_steps += 7
-            ts.grad_sync_mode = "single" if probe["single_ms_per_step"] < probe["bucketed_ms_per_step"] else "bucketed"
+            ts.grad_sync_mode = min(train.TrainStep.GRAD_SYNC_MODES, key=lambda f: probe[f + "_ms_per_step"])
             probe["picked"] = ts.grad_sync_mode
         set_phase("warm-up steps")
         comm_kt = None

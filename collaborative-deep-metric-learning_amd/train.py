@@ -37,6 +37,8 @@ def exponential_decay(base_lr, global_step, decay_steps, decay_rate, staircase=T
 
 
 class TrainStep:
+    GRAD_SYNC_MODES = ("bucketed", "two", "single")
+
     def __init__(self, table, pairs, batch_size, feature_size=None, output_size=256,
                  hidden_size=5000, margin=0.8, mode="uniform", optimizer="adam",
                  base_learning_rate=0.01, learning_rate_decay_examples=1000000,
@@ -68,8 +70,10 @@ class TrainStep:
         train.py:354) or "momentum" (Nesterov, momentum 0.9: train.py:115-116).
         ``grad_sync_mode`` (with ``grad_sync``): "bucketed" = the weight gradients as split-K launches
         in buckets whose all-reduce starts as soon as each is enqueued (hidden under the GEMMs that
-        follow); "single" = the one stream-K launch of the single-GPU step followed by ONE all-reduce
-        of the whole flat gradient (faster kernels, the collective exposed)."""
+        follow); "two" = the first layer's weight gradient as ONE full split-K launch, its all-reduce
+        (86 % of the bytes) under the second layer's launch, [dW2|db2] after it; "single" = the one
+        stream-K launch of the single-GPU step followed by ONE all-reduce of the whole flat gradient
+        (fastest kernels, the collective exposed)."""
         if mode not in _MODES:
             raise ValueError("mode must be 'uniform', 'inbatch' or 'semihard'")
         if optimizer not in ("adam", "lars", "momentum"):
@@ -100,8 +104,8 @@ class TrainStep:
         self.decay_steps = learning_rate_decay_examples
         self.decay_rate = learning_rate_decay
         self.exchange, self.grad_sync = exchange, grad_sync
-        if grad_sync_mode not in ("bucketed", "single"):
-            raise ValueError("grad_sync_mode must be 'bucketed' or 'single'")
+        if grad_sync_mode not in self.GRAD_SYNC_MODES:
+            raise ValueError("grad_sync_mode must be one of %s" % (self.GRAD_SYNC_MODES,))
         self._grad_sync_mode = grad_sync_mode
         self.slot0 = int(slot0)
         self.batch_global = self.B if batch_global is None else int(batch_global)
@@ -219,8 +223,8 @@ class TrainStep:
 
     @grad_sync_mode.setter
     def grad_sync_mode(self, mode):
-        if mode not in ("bucketed", "single"):
-            raise ValueError("grad_sync_mode must be 'bucketed' or 'single'")
+        if mode not in self.GRAD_SYNC_MODES:
+            raise ValueError("grad_sync_mode must be one of %s" % (self.GRAD_SYNC_MODES,))
         if mode != self._grad_sync_mode:
             self._grad_sync_mode = mode
             self._graphs = {}                            # captured steps recorded the other form
@@ -432,6 +436,15 @@ class TrainStep:
             if b is not None:
                 self.prefetch.wait_ready(1 - b)
             self.grad_sync.finish([self.grad_sync.start(self.params.grad, 0, self.layout.numel)])
+        elif self._grad_sync_mode == "two":
+            if b is not None:
+                self.prefetch.wait_ready(1 - b)
+            n1 = self.layout.offsets[2]
+            handles = []
+            (engine_bf16 if self.bf16 else engine).tower_backward(
+                self.params, self.ws, after_w1=lambda: handles.append(self.grad_sync.start(self.params.grad, 0, n1)))
+            handles.append(self.grad_sync.start(self.params.grad, n1, self.layout.numel))
+            self.grad_sync.finish(handles)
         else:
             if b is not None:
                 self.prefetch.wait_ready(1 - b)

@@ -30,6 +30,10 @@ CFG_W4 = dict(CFG, world=4, n_rows=3001, B=16)
 CFG_C3 = dict(n_rows=10000000, F=1500, H=5000, D=256, B=8192, steps=2, precision="f32")
 CFG_C4 = dict(CFG_C3, precision="bf16")
 CFG_C3_W4 = dict(CFG_C3, world=4)       # four ranks x 2.5 M rows, global batch 32 768
+# the other two gradient-sync forms (TrainStep.GRAD_SYNC_MODES), at config 3's true per-rank size
+CFG_C3_TWO = dict(CFG_C3, grad_sync_mode="two")
+CFG_C3_SINGLE = dict(CFG_C3, grad_sync_mode="single")
+CFG_C4_SINGLE = dict(CFG_C4, grad_sync_mode="single")
 
 
 def _make(dev, rank, world, exchange=None, grad_sync=None, c=None):
@@ -49,7 +53,7 @@ def _make(dev, rank, world, exchange=None, grad_sync=None, c=None):
     return train.TrainStep(table, pairs, B, hidden_size=c["H"], output_size=c["D"], mode="uniform",
                            device=dev, exchange=exchange, grad_sync=grad_sync, slot0=slot0,
                            batch_global=W * c["B"], precision=c["precision"],
-                           train_table=c.get("train_table", False))
+                           train_table=c.get("train_table", False), grad_sync_mode=c.get("grad_sync_mode", "bucketed"))
 
 
 def _worker(rank, world, port, q, CFG=CFG):
@@ -81,9 +85,11 @@ def _worker(rank, world, port, q, CFG=CFG):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_TABLE, CFG_W4, CFG_C3, CFG_C4, CFG_C3_W4],
+@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_TABLE, CFG_W4, CFG_C3, CFG_C4, CFG_C3_W4, CFG_C3_TWO, CFG_C3_SINGLE,
+                                 CFG_C4_SINGLE],
                          ids=["f32", "bf16", "trainable-table", "4-ranks", "config3-full-size", "config4-full-size",
-                              "config3-full-size-4-ranks"])
+                              "config3-full-size-4-ranks", "config3-full-size-sync-two", "config3-full-size-sync-single",
+                              "config4-full-size-sync-single"])
 def test_two_rank_step_equals_single_rank(gpu, CFG):
     bf16 = CFG["precision"] == "bf16"
     s = socket.socket()
@@ -378,12 +384,12 @@ def test_bench_two_rank_rehearsal(gpu, launcher):
     assert out["comm_backend"]["launcher"] == ("self" if launcher == "self" else "external")
     assert out["config"]["global_batch"] == 512 and out["value"] > 0
     comm = out["comm"]                                       # what the first real RCCL run will report
-    assert comm["grad_sync"] in ("bucketed", "single") and comm["grad_sync"] == comm["grad_sync_probe"]["picked"]
-    # bucketed: dW1 in two row blocks + dW2; single: one stream-K launch
-    assert out["roofline"]["launches_per_step"] == (3.0 if comm["grad_sync"] == "bucketed" else 1.0)
+    assert comm["grad_sync"] in ("bucketed", "two", "single") and comm["grad_sync"] == comm["grad_sync_probe"]["picked"]
+    # bucketed: dW1 in two row blocks + dW2; two: dW1, dW2; single: one stream-K launch
+    assert out["roofline"]["launches_per_step"] == {"bucketed": 3.0, "two": 2.0, "single": 1.0}[comm["grad_sync"]]
     assert comm["allreduce_exposed_ms"] is not None and comm["exchange_exposed_ms"] is not None
     assert comm["exchange_bytes"] > 2 * 256 * 1536 * 4 and comm["allreduce_bytes"] == 4 * 9180416
-    assert out["warmup_effective"]["of_which_grad_sync_probe"] == 14
+    assert out["warmup_effective"]["of_which_grad_sync_probe"] == 21
     assert np.isfinite(out["loss"])
 
 
