@@ -43,8 +43,6 @@ def dbf(x, dev):
 def test_gemm_bf16_epilogues(cd, M, N, K, tile, mfma, monkeypatch):
     if tile:
         monkeypatch.setenv("CDML_BF16_TILE", str(tile))
-    if mfma == "16" and tile == 0 and not (N % 256 == 0 and K % 128 == 0):
-        pytest.skip("the MFMA shape only matters where the 256x256 kernel runs")
     monkeypatch.setenv("CDML_BF16_MFMA", mfma)       # v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16
     rng = np.random.RandomState(M + N)
     A, B = rng.randn(M, K) / np.sqrt(K), rng.randn(N, K)
