@@ -446,6 +446,76 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     const int lr = p * 4 + (lane >> 4);
     return TN ? m0 + (rt >> 1) * 128 + grp * 64 + (rt & 1) * 32 + lr : m0 + grp * 128 + rt * 32 + lr;
   };
+  if constexpr (!TN && (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_MASK_BF16)) {
+    // bf16 outputs of the k-contiguous form: 16 B per lane and store (8 rows x 128 B per instruction) instead of
+    // 8 B -- half the store instructions of the tile's tail (cdna guide T21: such a tail is issue-bound)
+    const int c8 = lane & 7, lcol8 = wc * 64 + c8 * 8;
+    f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (EPI == BE_BIAS_LRELU_BF16) {
+      b0 = *reinterpret_cast<const f32x4 *>(g.bias + n0 + lcol8);
+      b1 = *reinterpret_cast<const f32x4 *>(g.bias + n0 + lcol8 + 4);
+    }
+    auto row8 = [&](int rt, int p) { return m0 + grp * 128 + rt * 32 + p * 8 + (lane >> 3); };
+    bf16x8 mk8[4][4];
+    if (EPI == BE_MASK_BF16 && has_aux) {                    // all 16 mask loads of the wave go out together
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          mk8[rt][p] = *reinterpret_cast<const bf16x8 *>(g.aux + (int64_t)min(row8(rt, p), g.M - 1) * g.ldaux + n0 + lcol8);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      float *strip = sC + (rt & 1) * 2048;                 // alternate halves: no wait for the readers
+      if constexpr (S16) {
+#pragma unroll
+        for (int rbb = 0; rbb < 2; ++rbb)
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              strip[(rbb * 16 + q16 * 4 + r) * 64 + ((cb * 16 + l15) ^ ((q16 & 1) << 4))] = acc16[2 * rt + rbb][cb][r];
+      } else {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            strip[row * 64 + ct * 32 + l31] = acc[rt][ct][r];
+          }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int lr = p * 8 + (lane >> 3);
+        const int row = row8(rt, p);
+        const int sw = S16 ? (((lr >> 2) & 1) << 4) : 0;
+        f32x4 v0 = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c8 * 8) ^ sw));
+        f32x4 v1 = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c8 * 8 + 4) ^ sw));
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        bf16x8 o;
+        unsigned bits = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (EPI == BE_BIAS_LRELU_BF16) {
+            v[j] += bb[j];
+            v[j] = fmaxf(v[j], v[j] * g.alpha);
+          } else if (has_aux) {
+            v[j] *= ((float)mk8[rt][p][j] > 0.f) ? 1.f : g.alpha;
+          }
+          o[j] = (bf16)v[j];
+          if (EPI == BE_BIAS_LRELU_BF16 && (float)o[j] > 0.f) bits |= 1u << j;
+        }
+        if (row >= g.M) continue;                            // stores only below this line
+        if (EPI == BE_BIAS_LRELU_BF16 && g.mask_out)         // this lane's 8 columns = one byte of the sign bitmask
+          g.mask_out[(int64_t)row * g.ldmask + ((n0 + lcol8) >> 3)] = (uint8_t)bits;
+        *reinterpret_cast<bf16x8 *>(static_cast<bf16 *>(c_base) + (int64_t)(row - m0 + c_row0) * c_ld + c_col0 + lcol8) = o;
+      }
+    }
+    return;
+  }
   // all 32 mask loads of the wave go out together (rows clamped, not branched around: a load
   // under a branch is waited for on the spot, 32 dependent round trips per tile)
   bf16x4 mk[4][8];
