@@ -65,6 +65,9 @@ struct K256Args {
   int strips, segments, chunks_per_segment, n_chunks;
 };
 
+// BITS: aux is the sign bitmask (epilogue 5), a compile-time choice -- as a run-time branch beside the value mask it
+// cost the kernel 25 % (registers for both forms, a select per element in the store loop).
+template <bool BITS>
 __global__ void __launch_bounds__(kT, 2) k_gemm_bf16_k256_mask(K256Args g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x;
@@ -132,13 +135,15 @@ __global__ void __launch_bounds__(kT, 2) k_gemm_bf16_k256_mask(K256Args g) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < c_end) stage_chunk(c + 1);
-    bf16x8 mk[4];
-    unsigned mkb[4] = {0, 0, 0, 0};
-    if (has_aux && !g.aux_bits) {
+    bf16x8 mk[BITS ? 1 : 4];
+    unsigned mkb[BITS ? 4 : 1];
+    if constexpr (!BITS) {
+      if (has_aux) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
-        mk[p] = *reinterpret_cast<const bf16x8 *>(g.aux + (int64_t)min(m0 + p * 8 + er, g.M - 1) * g.ldaux + ncol0 + ec);
-    } else if (has_aux) {               // one byte = this lane's 8 columns
+        for (int p = 0; p < 4; ++p)
+          mk[p] = *reinterpret_cast<const bf16x8 *>(g.aux + (int64_t)min(m0 + p * 8 + er, g.M - 1) * g.ldaux + ncol0 + ec);
+      }
+    } else {                            // one byte = this lane's 8 columns
       const uint8_t *mb = reinterpret_cast<const uint8_t *>(g.aux);
 #pragma unroll
       for (int p = 0; p < 4; ++p) mkb[p] = mb[(int64_t)min(m0 + p * 8 + er, g.M - 1) * g.ldaux + ((ncol0 + ec) >> 3)];
@@ -174,7 +179,8 @@ __global__ void __launch_bounds__(kT, 2) k_gemm_bf16_k256_mask(K256Args g) {
       bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (has_aux) v[j] *= (g.aux_bits ? ((mkb[p] >> j) & 1u) != 0 : (float)mk[p][j] > 0.f) ? 1.f : g.alpha;
+        if constexpr (BITS) v[j] *= ((mkb[p] >> j) & 1u) ? 1.f : g.alpha;
+        else if (has_aux) v[j] *= ((float)mk[p][j] > 0.f) ? 1.f : g.alpha;
         o[j] = (bf16)v[j];
       }
       // non-temporal: the result is read next by a different kernel on other CUs (5.2 vs 4.6 TB/s)
@@ -196,13 +202,15 @@ bool gemm_bf16_k256_usable(int M, int N, int K, int64_t lda, int64_t ldb, int64_
 }
 
 int launch_gemm_bf16_k256(const BArgs &b, hipStream_t s) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_k256_mask),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+  const bool bits = b.aux_bits && b.aux;
+  static bool configured[2] = {false, false};
+  if (!configured[bits]) {
+    const void *fn = bits ? reinterpret_cast<const void *>(&k_gemm_bf16_k256_mask<true>)
+                          : reinterpret_cast<const void *>(&k_gemm_bf16_k256_mask<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
     if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16_k256: cannot reserve %d B of LDS: %s", kSmem,
                                      hipGetErrorString(e));
-    configured = true;
+    configured[bits] = true;
   }
   K256Args g{};
   g.A = b.A; g.lda = b.lda; g.B = b.B; g.ldb = b.ldb;
@@ -217,7 +225,8 @@ int launch_gemm_bf16_k256(const BArgs &b, hipStream_t s) {
   if (segs > g.n_chunks) segs = g.n_chunks;
   g.chunks_per_segment = (g.n_chunks + segs - 1) / segs;
   g.segments = segs;
-  hipLaunchKernelGGL(k_gemm_bf16_k256_mask, dim3(g.strips * g.segments), dim3(kT), kSmem, s, g);
+  if (bits) hipLaunchKernelGGL(k_gemm_bf16_k256_mask<true>, dim3(g.strips * g.segments), dim3(kT), kSmem, s, g);
+  else hipLaunchKernelGGL(k_gemm_bf16_k256_mask<false>, dim3(g.strips * g.segments), dim3(kT), kSmem, s, g);
   return check_launch("gemm_bf16_k256");
 }
 
