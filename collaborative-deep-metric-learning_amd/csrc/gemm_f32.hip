@@ -70,6 +70,24 @@ __device__ __forceinline__ void dma_buffer_to_lds(i32x4 srd, uint32_t voff, uint
                :: "s"(lds_base), "v"(voff), "s"(srd) : "memory", "m0");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// A 16-B load the compiler's wait-count pass does not see either (it would answer a visible load issued between
+// the DMA pieces with vmcnt(0)): the destination is valid only after a wait_loads<N>() that names it.
+__device__ __forceinline__ void load16_async(f32x4 &dst, const float *gptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(gptr) : "memory");
+}
+// Wait until at most N of this wave's loads are in flight.  Returns 0.0f produced BEHIND the wait: what reads
+// an asynchronously loaded register compares against it, so that the compiler cannot schedule the read in
+// front of the wait (and a and b as plain inputs are not copied on the way in, which a tied operand would be
+// -- a copy of a register still in flight).
+template <int N>
+__device__ __forceinline__ float wait_loads(const f32x4 &a, const f32x4 &b) {
+  float zero;
+  asm volatile("s_waitcnt vmcnt(%1)\n\tv_mov_b32 %0, 0" : "=v"(zero) : "n"(N), "v"(a), "v"(b) : "memory");
+  return zero;
+}
+__device__ __forceinline__ uint32_t sign_bits(f32x4 m, float zero) {
+  return (m.x > zero ? 1u : 0u) | (m.y > zero ? 2u : 0u) | (m.z > zero ? 4u : 0u) | (m.w > zero ? 8u : 0u);
+}
 
 __device__ __forceinline__ i32x4 make_srd(const float *base, int64_t bytes) {
   const uint64_t a = (uint64_t)(uintptr_t)base;
@@ -254,17 +272,51 @@ __global__ void __launch_bounds__(kThreads, NBLK) k_gemm_f32(GemmArgs g) {
     }
   };
 
+  // EPI_LRELU_MASK through LDS (the data gradient, short contraction): the tile's 64 KB of mask operand, loaded
+  // in the epilogue, were 40 us of the 197-us dH1 (tools/f32_nt_probe.py) -- HBM latency with nothing to hide
+  // it.  Instead each of the first eight K-tiles requests two of the epilogue's sixteen 16-B pieces per thread
+  // right after its operand DMA; the counted wait at the end of the K-tile leaves them in flight, the next K-tile
+  // collects them as 8 sign bits.  (All sixteen requested at once after the first K-tile only moved the stall
+  // to that K-tile's vmcnt(0): 197 -> 194 us.)
+  constexpr bool MPF = (EPI == EPI_LRELU_MASK) && LEPI && NSTG == 2 && BM == 128 && BN == 128;
+  constexpr int MPF_KT = 8, P_TILE = (A_TILE + B_TILE) / 256 / 4;      // DMA pieces per wave and K-tile
+  const bool mask_ahead = MPF && g.aux != nullptr && m0 + BM <= g.M && n_ktiles == MPF_KT;   // uniform
+  uint64_t mbits = 0;
+
   if constexpr (NSTG == 2) {
     if (n_ktiles > 0) issue_tile(0, 0);
     dma_wait_all();
     __syncthreads();
-    for (int kt = 0; kt < n_ktiles; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < n_ktiles) issue_tile(buf ^ 1, kt + 1);  // lands in the other stage under the MFMAs
-      if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) colsum_tile(buf);
-      compute_tile(buf);
-      dma_wait_all();    // this wave's pieces of tile kt+1 are in LDS ...
-      __syncthreads();   // ... and so are everybody else's; stage `buf` is free again
+    if (MPF && mask_ahead) {
+      // a loop of its own: the plain loop below pays ~4 % for carrying these branches
+      f32x4 mq0 = zero4, mq1 = zero4;
+      const float *mptr = g.aux + (int64_t)(m0 + t / 32) * g.ldaux + n0 + (t % 32) * 4;
+      for (int kt = 0; kt < MPF_KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < MPF_KT) issue_tile(buf ^ 1, kt + 1);
+        if (kt >= 1) {                                       // the pieces requested one K-tile ago
+          const float z = (kt + 1 < MPF_KT) ? wait_loads<P_TILE>(mq0, mq1) : wait_loads<0>(mq0, mq1);
+          mbits |= (uint64_t)(sign_bits(mq0, z) | (sign_bits(mq1, z) << 4)) << (8 * (kt - 1));
+        }
+        load16_async(mq0, mptr);                             // rows 16 kt + t/32 and + 8 of the tile
+        load16_async(mq1, mptr + 8 * g.ldaux);
+        mptr += 16 * g.ldaux;
+        compute_tile(buf);
+        // this wave's pieces of tile kt+1 are in LDS (the two mask pieces requested after them may still fly) ...
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __syncthreads();   // ... and so are everybody else's; stage `buf` is free again
+      }
+      const float z = wait_loads<0>(mq0, mq1);               // the last two pieces
+      mbits |= (uint64_t)(sign_bits(mq0, z) | (sign_bits(mq1, z) << 4)) << (8 * (MPF_KT - 1));
+    } else {
+      for (int kt = 0; kt < n_ktiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < n_ktiles) issue_tile(buf ^ 1, kt + 1);  // lands in the other stage under the MFMAs
+        if (KPRED && EPI == EPI_SLAB_COLSUM && do_colsum) colsum_tile(buf);
+        compute_tile(buf);
+        dma_wait_all();    // this wave's pieces of tile kt+1 are in LDS ...
+        __syncthreads();   // ... and so are everybody else's; stage `buf` is free again
+      }
     }
   } else {
     // three stages: the DMA runs TWO K-tiles ahead, so a tile has two compute phases to
@@ -359,9 +411,18 @@ __global__ void __launch_bounds__(kThreads, NBLK) k_gemm_f32(GemmArgs g) {
       // every store is in flight at once instead of one round trip per pass
       f32x4 m[PASSES];
       if (EPI == EPI_LRELU_MASK && has_aux) {
+        if (MPF && mask_ahead) {
+          static_assert(!MPF || (PASSES == 2 * MPF_KT && ROWS_PER_PASS == 8 && C4 == 32), "mask pieces per K-tile");
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p)
-          m[p] = *reinterpret_cast<const f32x4 *>(g.aux + (int64_t)(m0 + p * ROWS_PER_PASS + lr0) * g.ldaux + col);
+          for (int p = 0; p < PASSES; ++p) {               // finish() only looks at the signs
+            const uint32_t b = (uint32_t)(mbits >> (4 * p));
+            m[p] = f32x4{(b & 1u) ? 1.f : 0.f, (b & 2u) ? 1.f : 0.f, (b & 4u) ? 1.f : 0.f, (b & 8u) ? 1.f : 0.f};
+          }
+        } else {
+#pragma unroll
+          for (int p = 0; p < PASSES; ++p)
+            m[p] = *reinterpret_cast<const f32x4 *>(g.aux + (int64_t)(m0 + p * ROWS_PER_PASS + lr0) * g.ldaux + col);
+        }
       }
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
