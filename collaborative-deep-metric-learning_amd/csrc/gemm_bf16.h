@@ -12,7 +12,10 @@ using bf16 = __bf16;
 // the leaky-relu derivative needs one bit per element, not the 2-byte value (252 MB -> 16 MB per step at
 // config 4's shape).  4 runs on the 256x256 kernel only, 5 on the K = 256 streaming kernel only.
 enum { BE_BIAS_LRELU_BF16 = 0, BE_BIAS_LRELU_F32 = 1, BE_MASK_BF16 = 2, BE_F32 = 3, BE_BIAS_LRELU_BF16_BITS = 4,
-       BE_MASKBITS_BF16 = 5 };
+       BE_MASKBITS_BF16 = 5,
+       // fp32 products on the bf16 MFMA (gemm_bf16x3.hip): the result, bias + leaky-relu / times the mask
+       // applied, split into three bf16 planes hi | mid | lo (C = bf16, planes x3_plane_c elements apart)
+       BE_BIAS_LRELU_X3 = 6, BE_MASK_X3 = 7 };
 
 struct BArgs {
   const bf16 *A; int64_t lda;
@@ -28,6 +31,12 @@ struct BArgs {
   float *colsum_partial;   // k-strided form only: [splits*tiles_m*2][N] column sums of B (nullable)
   uint8_t *mask_out; int64_t ldmask;   // epilogue 0 on the 256x256 kernel: sign bitmask of C (nullable), bytes per row
   int aux_bits;            // K = 256 streaming kernel: aux is that bitmask (ldaux in bytes), not bf16 values
+  // Split-fp32 form (X3 instantiations of the 256x256 kernel): every operand is three bf16 planes hi | mid | lo
+  // with hi + mid + lo = the fp32 value; K counts the K-tiles of ALL plane products, x3_tpp K-tiles each, walked
+  // as (A, B) = (hi,hi) (hi,mid) (mid,hi) (hi,lo) (lo,hi) (mid,mid).  Plane p of A starts x3_plane_a elements
+  // (k-contiguous form: along k; k-strided form: along the columns) after plane p - 1; B likewise.
+  int x3_tpp;
+  int64_t x3_plane_a, x3_plane_b, x3_plane_c;
 };
 
 // 256x256x64 kernel: true if the shape can use it (N % 256 == 0, K per split a
@@ -36,6 +45,8 @@ bool gemm_bf16_256_usable(int M, int N, int K, int64_t lda, int64_t ldb);
 int gemm_bf16_256_splits(int M, int N, int K);
 // g.tiles_m / g.tiles_n / g.k_per_split / g.C (slabs when splits > 1) set by the caller
 int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t stream);
+// the split-fp32 forms (g.x3_* set; epilogues 1, 3, 6, 7 k-contiguous, 3 k-strided)
+int launch_gemm_bf16_256_x3(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t stream);
 
 // streaming kernel for the mask / plain-bf16 epilogue (BE_MASK_BF16) at K == 256: N % 256 == 0,
 // lda / ldb / ldc / ldaux multiples of 8, A inside the 2 GiB buffer-descriptor window

@@ -106,20 +106,23 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
 // this (tile, row group) OWNS -- absolute K-tile index kt belongs to (tm, grp) = ((kt % (2 tiles_m)) >> 1,
 // kt & 1), so across the tiles_m tiles that share B every K-tile is counted once -- written to
 // cs_row[grp * cs_grp_stride + tile-local column].  Called by every wave of the block with the same arguments.
-template <bool TN, int EPI, bool S16>
+// X3: the operands are three bf16 planes each (BArgs::x3_*): the K-tiles walk the six plane products.
+template <bool TN, int EPI, bool S16, bool X3 = false>
 __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int m0, const int n0, const int k_begin,
                                          const int n_ktiles, void *c_base, const int64_t c_ld, const int c_row0,
                                          const int c_col0, float *cs_row, const int64_t cs_grp_stride,
                                          unsigned char *smem) {
   static_assert(!TN || EPI == BE_F32, "the k-strided form only serves the weight gradients");
+  static_assert(X3 || (EPI != BE_BIAS_LRELU_X3 && EPI != BE_MASK_X3), "plane outputs belong to the split-fp32 form");
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int grp = wave >> 2, wc = wave & 3;
   const int l31 = lane & 31, h = lane >> 5;
 
-  const i32x4 srd_a = make_srd(g.A, (int64_t)(TN ? g.K : g.M) * g.lda * 2);
-  const i32x4 srd_b = make_srd(g.B, (int64_t)(TN ? g.K : g.N) * g.ldb * 2);
+  const int k_rows = X3 ? g.x3_tpp * kTileK : g.K;              // k-strided form: rows of the operands in memory
+  const i32x4 srd_a = make_srd(g.A, (int64_t)(TN ? k_rows : g.M) * g.lda * 2);
+  const i32x4 srd_b = make_srd(g.B, (int64_t)(TN ? k_rows : g.N) * g.ldb * 2);
 
   // ---- DMA lane constants.  NT: piece pc = wave*2+i covers image rows pc*8 .. pc*8+7
   //      (128-B rows); TN: k-rows pc*4 .. pc*4+3 (256-B rows) ----
@@ -144,8 +147,19 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   const uint32_t lds_piece = __builtin_amdgcn_readfirstlane(lds_off(smem) + wave * 2048);
 
   // img 0 = A, 1 = B; hh = half; tile beyond the split's range -> every lane out of range (zeros)
+  // X3: K-tile v of the whole walk = K-tile v % tpp of plane product v / tpp
+  const float x3_inv = X3 ? 1.0f / (float)g.x3_tpp : 0.f;
+  const int x3_t0 = k_begin / kTileK;
+  auto x3_segment = [&](int v) { return __builtin_amdgcn_readfirstlane((int)(((float)v + 0.5f) * x3_inv)); };
   auto stage = [&](int img, int hh, int tile, int buf) {
-    const int64_t k_elems = (int64_t)(k_begin + tile * kTileK) * (TN ? (img == 0 ? g.lda : g.ldb) : 1);
+    int64_t k_elems;
+    if constexpr (X3) {
+      const int v = x3_t0 + tile, sgm = x3_segment(v), w = v - sgm * g.x3_tpp;
+      const int plane = ((img == 0 ? 0x120100 : 0x102010) >> (4 * sgm)) & 3;
+      k_elems = (int64_t)w * kTileK * (TN ? (img == 0 ? g.lda : g.ldb) : 1) + plane * (img == 0 ? g.x3_plane_a : g.x3_plane_b);
+    } else {
+      k_elems = (int64_t)(k_begin + tile * kTileK) * (TN ? (img == 0 ? g.lda : g.ldb) : 1);
+    }
     const uint32_t kb = tile < n_ktiles ? (uint32_t)(k_elems * 2) : 0x80000000u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -300,7 +314,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     pin_b();
     pin_a();
-    if (TN && cs_on && (tile % cs_period) == cs_owner) {
+    if (TN && cs_on && (tile % cs_period) == cs_owner && (!X3 || ((0xB >> x3_segment(x3_t0 + tile)) & 1))) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -358,7 +372,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     pin_b();
     pin_a();
-    if (TN && cs_on && (tile % cs_period) == cs_owner) {
+    if (TN && cs_on && (tile % cs_period) == cs_owner && (!X3 || ((0xB >> x3_segment(x3_t0 + tile)) & 1))) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         cs[0] += frag_sum(fb0[ks]);
@@ -440,8 +454,9 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   const int lcol = TN ? (c4 >> 3) * 128 + wc * 32 + (c4 & 7) * 4 : wc * 64 + c4 * 4;     // tile-local column
   const int gcol = n0 + lcol;
   f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + gcol);
-  const bool has_aux = (EPI == BE_MASK_BF16) && g.aux != nullptr;
+  if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32 || EPI == BE_BIAS_LRELU_X3)
+    bias4 = *reinterpret_cast<const f32x4 *>(g.bias + gcol);
+  const bool has_aux = (EPI == BE_MASK_BF16 || EPI == BE_MASK_X3) && g.aux != nullptr;
   auto out_row = [&](int rt, int p) {
     const int lr = p * 4 + (lane >> 4);
     return TN ? m0 + (rt >> 1) * 128 + grp * 64 + (rt & 1) * 32 + lr : m0 + grp * 128 + rt * 32 + lr;
@@ -519,7 +534,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   // all 32 mask loads of the wave go out together (rows clamped, not branched around: a load
   // under a branch is waited for on the spot, 32 dependent round trips per tile)
   bf16x4 mk[4][8];
-  if (EPI == BE_MASK_BF16 && has_aux) {
+  if ((EPI == BE_MASK_BF16 || EPI == BE_MASK_X3) && has_aux) {
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -555,11 +570,11 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       const int lr = p * 4 + (lane >> 4);
       const int row = out_row(rt, p);
       f32x4 v = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c4 * 4) ^ (S16 ? (((lr >> 2) & 1) << 4) : 0)));
-      if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32) {
+      if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32 || EPI == BE_BIAS_LRELU_X3) {
         v += bias4;
         v.x = fmaxf(v.x, v.x * g.alpha); v.y = fmaxf(v.y, v.y * g.alpha);
         v.z = fmaxf(v.z, v.z * g.alpha); v.w = fmaxf(v.w, v.w * g.alpha);
-      } else if (EPI == BE_MASK_BF16) {
+      } else if (EPI == BE_MASK_BF16 || EPI == BE_MASK_X3) {
         if (has_aux) {
           const bf16x4 m = mk[rt][p];
           v.x *= ((float)m.x > 0.f) ? 1.f : g.alpha; v.y *= ((float)m.y > 0.f) ? 1.f : g.alpha;
@@ -576,6 +591,19 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
         nib |= other << 4;
       }
       if (row >= g.M) continue;                            // stores only below this line
+      if constexpr (EPI == BE_BIAS_LRELU_X3 || EPI == BE_MASK_X3) {
+        // three roundings to nearest hold the 24 significant bits: hi + mid + lo == v exactly
+        bf16 *dst = static_cast<bf16 *>(c_base) + (int64_t)(row - m0 + c_row0) * c_ld + c_col0 + lcol;
+        f32x4 r = v;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          bf16x4 q;
+          q.x = (bf16)r.x; q.y = (bf16)r.y; q.z = (bf16)r.z; q.w = (bf16)r.w;
+          *reinterpret_cast<bf16x4 *>(dst + pl * g.x3_plane_c) = q;
+          r.x -= (float)q.x; r.y -= (float)q.y; r.z -= (float)q.z; r.w -= (float)q.w;
+        }
+        continue;
+      }
       if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_MASK_BF16) {
         if (EPI == BE_BIAS_LRELU_BF16 && g.mask_out && !(c4 & 1))
           g.mask_out[(int64_t)row * g.ldmask + (gcol >> 3)] = (uint8_t)nib;
@@ -587,11 +615,11 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   }
 }
 
-template <bool TN, int EPI, bool S16>
+template <bool TN, int EPI, bool S16, bool X3 = false>
 __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   int tm, tn;
-  if (g.K <= 512) tile_of_block_rowmajor(blockIdx.x, gridDim.x, g.tiles_n, tm, tn);   // output-bound
+  if (g.K <= (X3 ? 3072 : 512)) tile_of_block_rowmajor(blockIdx.x, gridDim.x, g.tiles_n, tm, tn);   // output-bound
   else tile_of_block(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, tm, tn);
   const int m0 = tm * kTileM, n0 = tn * kTileN;
   const int split = blockIdx.y;
@@ -600,7 +628,7 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   const int n_ktiles = k_end > k_begin ? (k_end - k_begin) / kTileK : 0;   // even (host)
   void *c_base = EPI == BE_F32 ? static_cast<void *>(static_cast<float *>(g.C) + (int64_t)split * g.slab_stride) : g.C;
   float *cs_row = (TN && g.colsum_partial) ? g.colsum_partial + (int64_t)((split * g.tiles_m + tm) * 2) * g.N + n0 : nullptr;
-  run_tile<TN, EPI, S16>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
+  run_tile<TN, EPI, S16, X3>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
 }
 
 // ---- both weight gradients of the tower in ONE launch (k-strided form; dW1 = x_hat^T dz1, dW2 = h1^T dz2) ----
@@ -753,6 +781,31 @@ int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t s
     case BE_BIAS_LRELU_F32: return launch<false, BE_BIAS_LRELU_F32>(g, splits, s);
     case BE_MASK_BF16: return launch<false, BE_MASK_BF16>(g, splits, s);
     default: return launch<false, BE_F32>(g, splits, s);
+  }
+}
+
+namespace {
+template <bool TN, int EPI>
+int launch_x3(const BArgs &g, int splits, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3: cannot reserve %d B of LDS: %s", SMEM, hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), SMEM, s, g);
+  return check_launch("gemm_bf16x3");
+}
+}  // namespace
+
+int launch_gemm_bf16_256_x3(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t s) {
+  if (tn) return launch_x3<true, BE_F32>(g, splits, s);
+  switch (epilogue) {
+    case BE_BIAS_LRELU_F32: return launch_x3<false, BE_BIAS_LRELU_F32>(g, splits, s);
+    case BE_BIAS_LRELU_X3: return launch_x3<false, BE_BIAS_LRELU_X3>(g, splits, s);
+    case BE_MASK_X3: return launch_x3<false, BE_MASK_X3>(g, splits, s);
+    default: return launch_x3<false, BE_F32>(g, splits, s);
   }
 }
 

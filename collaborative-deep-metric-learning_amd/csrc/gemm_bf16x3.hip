@@ -1,0 +1,263 @@
+// fp32 products of the tower on the bf16 matrix cores ("split-fp32", precision "f32x3").
+//
+// gfx950 multiplies bf16 sixteen times faster than fp32 (2.5 PFLOP/s against 157 TFLOP/s dense).  An fp32 value
+// is EXACTLY the sum of three bf16 values -- hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): three
+// roundings to nearest hold 24 significant bits, and bf16 has fp32's exponent range -- and a product of two
+// bf16 values is exact in the fp32 accumulator of the MFMA.  So
+//     a b = (ah + am + al)(bh + bm + bl) = ah bh + ah bm + am bh + ah bl + al bh + am bm  [+ am bl + al bm + al bl]
+// with the three dropped terms below 2^-26 |a b|: six bf16 MFMAs give an fp32 product to better than one fp32
+// rounding, at 6 / 16 of the fp32 MFMA's cost.  Measured at FC1's shape (tools/f32x3_probe.py): 0.556 ms against
+// 0.936 ms for the fp32 kernel, max error against fp64 2.6e-6 of max|C| against 2.2e-6 for the fp32 kernel.
+// (`products` = 3 keeps ah bh + ah bm + am bh only: 16-bit operands, error 4.7e-6, half the time again.)
+//
+// Operands live in memory as three planes side by side: a k-contiguous operand A[M][K] as [M][hi K | mid K | lo K]
+// (plane stride along k), a k-strided one A[K][M] as [K][hi M | mid M | lo M] (plane stride along the columns).
+// The GEMMs are the 256x256 ping-pong kernel of gemm_bf16_256.hip with a K loop that walks the plane products
+// (BArgs::x3_*); epilogues 6 / 7 write their result as planes again, so the chain FC1 -> FC2 / dH1 -> dW1 never
+// holds an activation in fp32.  Replaces the same reference lines as gemm_f32.hip (models.py:59-60, train.py:141).
+#include "gemm_bf16.h"
+
+namespace cdml {
+namespace {
+
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ void split3(float v, bf16 &h, bf16 &m, bf16 &l) {
+  h = (bf16)v;
+  const float r = v - (float)h;
+  m = (bf16)r;
+  l = (bf16)(r - (float)m);
+}
+
+// dst[r][p * plane + c] = plane p of src[r][c]; 4 columns per thread
+__global__ void __launch_bounds__(kThreads)
+k_split3(const float *__restrict__ src, int64_t lds_, int rows, int cols, bf16 *__restrict__ dst, int64_t ldd,
+         int64_t plane) {
+  const int c4n = cols >> 2;
+  const int64_t total = (int64_t)rows * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * lds_ + c);
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16 a, b, c_;
+      split3(v[j], a, b, c_);
+      h[j] = a; m[j] = b; l[j] = c_;
+    }
+    bf16 *d = dst + r * ldd + c;
+    *reinterpret_cast<bf16x4 *>(d) = h;
+    *reinterpret_cast<bf16x4 *>(d + plane) = m;
+    *reinterpret_cast<bf16x4 *>(d + 2 * plane) = l;
+  }
+}
+
+// dst[c][p * plane + r] = plane p of src[r][c]: 64 x 64 tiles through LDS
+__global__ void __launch_bounds__(kThreads)
+k_split3_transpose(const float *__restrict__ src, int64_t lds_, int rows, int cols, bf16 *__restrict__ dst,
+                   int64_t ldd, int64_t plane) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int j = ty; j < 64; j += 4) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 64; j += 4) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < cols && r < rows) {
+      bf16 h, m, l;
+      split3(tile[tx][j], h, m, l);
+      bf16 *d = dst + (int64_t)c * ldd + r;
+      d[0] = h; d[plane] = m; d[2 * plane] = l;
+    }
+  }
+}
+
+int grid1d(int64_t n) {
+  const int64_t b = (n + kThreads - 1) / kThreads;
+  return (int)(b < 1 ? 1 : (b > 65535 * 16 ? 65535 * 16 : b));
+}
+
+// split-K for the k-contiguous forms with too few tiles for the chip (fp32 slab output only)
+int x3_nt_splits(int M, int N, int ktiles) {
+  const int64_t tiles = (int64_t)((M + 255) / 256) * (N / 256);
+  if (tiles >= 192) return 1;
+  int s = (int)((220 + tiles - 1) / tiles);
+  if (s > 16) s = 16;
+  while (s > 1 && ktiles / s < 8) --s;
+  return s < 2 ? 1 : s;
+}
+
+}  // namespace
+}  // namespace cdml
+
+using namespace cdml;
+
+extern "C" int cdml_split_f32_bf16x3(const float *src, int64_t ld_src, int rows, int cols, uint16_t *dst,
+                                     int64_t ld_dst, int64_t plane, int transpose, cdml_stream_t stream) {
+  CDML_REQUIRE(src && dst && rows > 0 && cols > 0, CDML_E_BADARG, "split_f32_bf16x3: bad argument");
+  const int out_cols = transpose ? rows : cols;
+  CDML_REQUIRE(plane >= out_cols && ld_dst >= 2 * plane + out_cols && ld_src >= cols, CDML_E_BADARG,
+               "split_f32_bf16x3: planes of %d columns need plane >= %d and ld_dst >= 2 plane + %d", out_cols, out_cols, out_cols);
+  hipStream_t s = (hipStream_t)stream;
+  if (transpose) {
+    hipLaunchKernelGGL(k_split3_transpose, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(kThreads), 0, s, src, ld_src,
+                       rows, cols, reinterpret_cast<bf16 *>(dst), ld_dst, plane);
+  } else {
+    CDML_REQUIRE((cols & 3) == 0 && (ld_src & 3) == 0 && (ld_dst & 3) == 0 && (plane & 3) == 0 && aligned16(src) &&
+                     (reinterpret_cast<uintptr_t>(dst) & 7) == 0,
+                 CDML_E_ALIGN, "split_f32_bf16x3: columns, strides and plane must be multiples of 4");
+    hipLaunchKernelGGL(k_split3, dim3(grid1d((int64_t)rows * (cols / 4))), dim3(kThreads), 0, s, src, ld_src, rows, cols,
+                       reinterpret_cast<bf16 *>(dst), ld_dst, plane);
+  }
+  return check_launch("split_f32_bf16x3");
+}
+
+extern "C" size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int products) {
+  if (M <= 0 || N <= 0 || K <= 0 || (products != 3 && products != 6) || K % 64) return 0;
+  const int ktiles = products * (K / 64);
+  const int splits = tn ? gemm_bf16_256_splits(M, N, ktiles * 64) : x3_nt_splits(M, N, ktiles);
+  const size_t cs = tn ? (size_t)splits * (M / 256) * 2 * N * sizeof(float) + (size_t)N * sizeof(float) : 0;
+  return (splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0) + cs;
+}
+
+namespace cdml {
+namespace {
+// sums `splits` fp32 slabs (+ bias, leaky-relu when bias != null) into out
+__global__ void __launch_bounds__(kThreads)
+k_x3_sum_slabs(const float *__restrict__ slabs, int64_t slab_stride, int splits, int rows, int N,
+               const float *__restrict__ bias, float alpha, float *__restrict__ out, int64_t ldo) {
+  const int n4 = N >> 2;
+  const int64_t total = (int64_t)rows * n4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / n4;
+    const int c = (int)(i - r * n4);
+    f32x4 s = reinterpret_cast<const f32x4 *>(slabs)[i];
+    for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4 *>(slabs + (int64_t)z * slab_stride)[i];
+    if (bias) {
+      s += reinterpret_cast<const f32x4 *>(bias)[c];
+      s.x = fmaxf(s.x, s.x * alpha); s.y = fmaxf(s.y, s.y * alpha);
+      s.z = fmaxf(s.z, s.z * alpha); s.w = fmaxf(s.w, s.w * alpha);
+    }
+    reinterpret_cast<f32x4 *>(out + r * ldo)[c] = s;
+  }
+}
+// colsum[n] = sum over the partial rows
+__global__ void __launch_bounds__(kThreads)
+k_x3_colsum_final(const float *__restrict__ partial, int n_rows, int N, float *__restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int r = 0; r < n_rows; ++r) s += partial[(int64_t)r * N + c];
+  out[c] = s;
+}
+}  // namespace
+}  // namespace cdml
+
+// C = epilogue(A . B^T) for fp32 A[M][K], B[N][K] given as planes [rows][hi K | mid K | lo K] (plane strides
+// plane_a / plane_b >= K along k).  epilogue 1: fp32 C = lrelu(. + bias); 3: fp32 C; 6: C = planes of lrelu(. + bias)
+// (bf16 [M][ldc], planes plane_c apart); 7: C = planes of (. times (aux > 0 ? 1 : alpha)), aux = bf16 [M][ldaux].
+extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
+                                   int64_t ldb, int64_t plane_b, int M, int N, int K, int products, void *C,
+                                   int64_t ldc, int64_t plane_c, const float *bias, const uint16_t *aux,
+                                   int64_t ldaux, float alpha, void *workspace, size_t workspace_bytes,
+                                   cdml_stream_t stream) {
+  CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16x3_nt: bad argument");
+  CDML_REQUIRE(epilogue == BE_BIAS_LRELU_F32 || epilogue == BE_F32 || epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3,
+               CDML_E_BADARG, "gemm_bf16x3_nt: epilogue must be 1, 3, 6 or 7");
+  CDML_REQUIRE(products == 3 || products == 6, CDML_E_BADARG, "gemm_bf16x3_nt: products must be 3 or 6");
+  CDML_REQUIRE(N % 256 == 0 && K % 64 == 0, CDML_E_UNSUPPORTED,
+               "gemm_bf16x3_nt: N must be a multiple of 256 and K of 64, got N=%d K=%d", N, K);
+  CDML_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && !(lda & 7) && !(ldb & 7) && !(plane_a & 7) && !(plane_b & 7) &&
+                   plane_a >= K && plane_b >= K && lda >= 2 * plane_a + K && ldb >= 2 * plane_b + K,
+               CDML_E_ALIGN, "gemm_bf16x3_nt: 16-B aligned bases, strides multiples of 8, ld >= 2 plane + K");
+  const bool planes_out = epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3;
+  CDML_REQUIRE(planes_out ? (!(ldc & 3) && !(plane_c & 3) && plane_c >= N && ldc >= 2 * plane_c + N) : (!(ldc & 3) && ldc >= N),
+               CDML_E_ALIGN, "gemm_bf16x3_nt: ldc / plane_c");
+  CDML_REQUIRE((epilogue != BE_BIAS_LRELU_F32 && epilogue != BE_BIAS_LRELU_X3) || bias, CDML_E_BADARG, "gemm_bf16x3_nt: bias required");
+  CDML_REQUIRE(((int64_t)M + 256) * lda * 2 < ((int64_t)1 << 31) && (int64_t)N * ldb * 2 < ((int64_t)1 << 31), CDML_E_UNSUPPORTED,
+               "gemm_bf16x3_nt: an operand exceeds the 2 GiB buffer-descriptor range");
+  BArgs g{};
+  g.A = reinterpret_cast<const bf16 *>(A); g.lda = lda;
+  g.B = reinterpret_cast<const bf16 *>(B); g.ldb = ldb;
+  g.C = C; g.ldc = ldc; g.bias = bias; g.alpha = alpha;
+  g.aux = reinterpret_cast<const bf16 *>(aux); g.ldaux = ldaux;
+  g.M = M; g.N = N;
+  g.x3_tpp = K / 64; g.x3_plane_a = plane_a; g.x3_plane_b = plane_b; g.x3_plane_c = plane_c;
+  const int ktiles = products * g.x3_tpp;
+  CDML_REQUIRE(ktiles % 2 == 0, CDML_E_UNSUPPORTED, "gemm_bf16x3_nt: products * K / 64 must be even");
+  g.K = ktiles * 64; g.k_per_split = g.K;
+  g.tiles_m = (M + 255) / 256; g.tiles_n = N / 256;
+  hipStream_t s = (hipStream_t)stream;
+  int splits = planes_out ? 1 : x3_nt_splits(M, N, ktiles);
+  if (splits > 1) {
+    const size_t need = (size_t)splits * M * N * sizeof(float);
+    if (!workspace || workspace_bytes < need || !aligned16(workspace)) splits = 1;     // one pass, fewer blocks
+  }
+  if (splits == 1) return launch_gemm_bf16_256_x3(g, false, epilogue, 1, s);
+  const int per = (ktiles + splits - 1) / splits;
+  g.k_per_split = (per + 1) / 2 * 2 * 64;
+  g.slab_stride = (int64_t)M * N;
+  g.C = workspace; g.ldc = N;
+  int rc = launch_gemm_bf16_256_x3(g, false, BE_F32, splits, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_x3_sum_slabs, dim3(grid1d((int64_t)M * N / 4)), dim3(kThreads), 0, s,
+                     static_cast<const float *>(workspace), g.slab_stride, splits, M, N,
+                     epilogue == BE_BIAS_LRELU_F32 ? bias : nullptr, alpha, static_cast<float *>(C), ldc);
+  return check_launch("gemm_bf16x3_nt combine");
+}
+
+// C[M][N] (fp32) = sum_k A[k][M] B[k][N] for fp32 operands given as planes [K][hi | mid | lo] (plane strides along
+// the columns); colsum[n] = sum_k B[k][n] on request (the bias gradient).
+extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B, int64_t ldb,
+                                   int64_t plane_b, int M, int N, int K, int products, float *C, int64_t ldc,
+                                   float *colsum, void *workspace, size_t workspace_bytes, cdml_stream_t stream) {
+  CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16x3_tn: bad argument");
+  CDML_REQUIRE(products == 3 || products == 6, CDML_E_BADARG, "gemm_bf16x3_tn: products must be 3 or 6");
+  CDML_REQUIRE(M % 256 == 0 && N % 256 == 0 && K % 128 == 0, CDML_E_UNSUPPORTED,
+               "gemm_bf16x3_tn: M, N must be multiples of 256 and K of 128, got M=%d N=%d K=%d", M, N, K);
+  CDML_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && !(lda & 7) && !(ldb & 7) && !(plane_a & 7) && !(plane_b & 7) &&
+                   !(ldc & 3) && plane_a >= M && plane_b >= N && lda >= 2 * plane_a + M && ldb >= 2 * plane_b + N && ldc >= N,
+               CDML_E_ALIGN, "gemm_bf16x3_tn: 16-B aligned bases, strides multiples of 8, ld >= 2 plane + columns");
+  CDML_REQUIRE((int64_t)K * lda * 2 < ((int64_t)1 << 31) && (int64_t)K * ldb * 2 < ((int64_t)1 << 31), CDML_E_UNSUPPORTED,
+               "gemm_bf16x3_tn: an operand exceeds the 2 GiB buffer-descriptor range");
+  BArgs g{};
+  g.A = reinterpret_cast<const bf16 *>(A); g.lda = lda;
+  g.B = reinterpret_cast<const bf16 *>(B); g.ldb = ldb;
+  g.M = M; g.N = N;
+  g.x3_tpp = K / 64; g.x3_plane_a = plane_a; g.x3_plane_b = plane_b;
+  const int ktiles = products * g.x3_tpp;
+  g.K = ktiles * 64;
+  g.tiles_m = M / 256; g.tiles_n = N / 256;
+  const int splits = gemm_bf16_256_splits(M, N, g.K);
+  const size_t slab_bytes = splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+  const size_t cs_rows = (size_t)splits * g.tiles_m * 2;
+  const size_t need = slab_bytes + (colsum ? cs_rows * N * sizeof(float) : 0);
+  CDML_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && aligned16(workspace)), CDML_E_BADARG,
+               "gemm_bf16x3_tn: workspace of %zu bytes required (cdml_gemm_bf16x3_workspace)", need);
+  hipStream_t s = (hipStream_t)stream;
+  const int per = (ktiles + splits - 1) / splits;
+  g.k_per_split = (per + 1) / 2 * 2 * 64;
+  g.slab_stride = (int64_t)M * N;
+  g.C = splits > 1 ? workspace : static_cast<void *>(C);
+  g.ldc = splits > 1 ? N : ldc;
+  g.colsum_partial = colsum ? reinterpret_cast<float *>(static_cast<char *>(workspace) + slab_bytes) : nullptr;
+  int rc = launch_gemm_bf16_256_x3(g, true, BE_F32, splits, s);
+  if (rc) return rc;
+  if (splits > 1) {
+    hipLaunchKernelGGL(k_x3_sum_slabs, dim3(grid1d((int64_t)M * N / 4)), dim3(kThreads), 0, s,
+                       static_cast<const float *>(workspace), g.slab_stride, splits, M, N, (const float *)nullptr, 0.f, C, ldc);
+    if ((rc = check_launch("gemm_bf16x3_tn combine"))) return rc;
+  }
+  if (colsum) {
+    hipLaunchKernelGGL(k_x3_colsum_final, dim3((N + kThreads - 1) / kThreads), dim3(kThreads), 0, s, g.colsum_partial,
+                       (int)cs_rows, N, colsum);
+    rc = check_launch("gemm_bf16x3_tn bias gradient");
+  }
+  return rc;
+}

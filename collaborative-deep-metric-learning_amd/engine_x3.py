@@ -1,0 +1,93 @@
+"""fp32 tower on the bf16 matrix cores (precision "f32x3").
+
+Same layers, same fp32 master weights, loss, normalisation and optimizer kernels as ``engine`` -- only the five
+projection GEMMs change: every fp32 operand is held as three bf16 planes hi | mid | lo whose sum IS the fp32
+value, and a product is the six plane products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid accumulated in the
+fp32 accumulator of ``v_mfma_f32_16x16x32_bf16`` (csrc/gemm_bf16x3.hip: what is dropped is below 2^-26 of a
+product).  The bf16 MFMA is sixteen times the fp32 MFMA's rate on gfx950, so six of them for one fp32 product
+is 2.7 x faster at equal efficiency.  Errors against fp64 are those of the fp32 kernels
+(tests/test_gpu_f32x3.py); the parity tests of the fp32 path run against this one with the same bounds.
+
+Activations never exist in fp32 between the GEMMs: FC1's epilogue writes h1 as planes, the data gradient's
+writes dz1 as planes (and takes leaky-relu' from h1's hi plane -- rounding keeps the sign).  Reference lines:
+models.py:59-61 (forward), train.py:141 (its autodiff).
+"""
+import torch
+
+from . import ops
+from .engine_bf16 import layout_bf16
+
+
+def layout_x3(feature_size, hidden=5000, output_size=256):
+    L = layout_bf16(feature_size, hidden, output_size)
+    if L.Fp % 256 or L.Hp % 256 or L.Dp % 256:
+        raise ValueError("precision 'f32x3' needs padded layer widths that are multiples of 256 "
+                         "(got F %d, H %d, D %d)" % (L.Fp, L.Hp, L.Dp))
+    return L
+
+
+class TowerWorkspaceX3:
+    def __init__(self, layout, n_rows, device, products=6):
+        L, R = layout, int(n_rows)
+        if R % 128:
+            raise ValueError("precision 'f32x3' needs a row count that is a multiple of 128 (got %d)" % R)
+        if products not in (3, 6):
+            raise ValueError("products must be 6 (fp32-equivalent) or 3 (16-bit operands)")
+        self.layout, self.R, self.products = L, R, products
+        bf = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=device)
+        f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
+        self.x_hat = f32(R, L.Fp)                          # the gather's output (l2-normalised rows)
+        self.x3, self.h1, self.dz1 = bf(R, 3 * L.Fp), bf(R, 3 * L.Hp), bf(R, 3 * L.Hp)
+        self.z, self.e, self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp)
+        self.dz2_3 = bf(R, 3 * L.Dp)
+        self.W1T, self.W2T, self.W2 = bf(L.Hp, 3 * L.Fp), bf(L.Dp, 3 * L.Hp), bf(L.Hp, 3 * L.Dp)
+        q = products
+        nb = max(ops.gemm_bf16x3_workspace(False, R, L.Dp, L.Hp, q), ops.gemm_bf16x3_workspace(True, L.Fp, L.Hp, R, q),
+                 ops.gemm_bf16x3_workspace(True, L.Hp, L.Dp, R, q), 16)
+        self.gemm_ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
+        self.tail_done = False
+
+
+def refresh_weights(p, ws):
+    """plane copies of the fp32 master weights in the orientations the GEMMs read (after every optimizer step)"""
+    L = p.layout
+    ops.split_f32_bf16x3(p.W1, ws.W1T, L.Fp, transpose=True)        # [Hp][3 Fp]
+    ops.split_f32_bf16x3(p.W2, ws.W2T, L.Hp, transpose=True)        # [Dp][3 Hp]
+    ops.split_f32_bf16x3(p.W2, ws.W2, L.Dp)                         # [Hp][3 Dp]
+
+
+def tower_forward(p, ws, normalize=True):
+    """x_hat (fp32, l2-normalised) -> planes -> h1 (planes) -> z (fp32) -> e (fp32).  models.py:59-61."""
+    L, R, q = p.layout, ws.R, ws.products
+    ops.split_f32_bf16x3(ws.x_hat, ws.x3, L.Fp)
+    ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, ws.x3, L.Fp, ws.W1T, L.Fp, ws.h1, R, L.Hp, L.Fp, products=q,
+                       plane_c=L.Hp, bias=p.b1)
+    ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, ws.h1, L.Hp, ws.W2T, L.Hp, ws.z, R, L.Dp, L.Hp, products=q,
+                       bias=p.b2, workspace=ws.gemm_ws)
+    ws.tail_done = False
+    if normalize:
+        ops.l2norm_fwd(ws.z, L.Dp, ws.e)
+    return ws.e
+
+
+def tower_backward(p, ws, after_w1=None):
+    """ws.dz2 (from the fused tail) or ws.de -> p.grad (fp32).  train.py:141; no dX.  The second layer's weight
+    gradient goes first on one GPU (it and the data gradient both stream h1); with ``after_w1`` (the
+    data-parallel all-reduce of [dW1|db1]) the first layer's goes first and the hook fires right after it."""
+    L, R, q = p.layout, ws.R, ws.products
+    if not ws.tail_done:
+        ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
+    ops.split_f32_bf16x3(ws.dz2, ws.dz2_3, L.Dp)
+    w2 = lambda: ops.gemm_bf16x3_tn(ws.h1, L.Hp, ws.dz2_3, L.Dp, p.gW2, L.Hp, L.Dp, R, products=q,
+                                    workspace=ws.gemm_ws, colsum=p.gb2)
+    if after_w1 is None:
+        w2()
+    # dz1 = (dz2 . W2^T) * lrelu'(h1), written as planes; the sign comes from h1's hi plane
+    ops.gemm_bf16x3_nt(ops.BE_MASK_X3, ws.dz2_3, L.Dp, ws.W2, L.Dp, ws.dz1, R, L.Hp, L.Dp, products=q, plane_c=L.Hp,
+                       aux=ws.h1)
+    ops.gemm_bf16x3_tn(ws.x3, L.Fp, ws.dz1, L.Hp, p.gW1, L.Fp, L.Hp, R, products=q, workspace=ws.gemm_ws,
+                       colsum=p.gb1)
+    if after_w1 is not None:
+        after_w1()
+        w2()
+    return p.grad

@@ -375,6 +375,46 @@ def gemm_bf16_tn(A, B, C, M, N, K, workspace=None, colsum=None):
     return C
 
 
+# ---- fp32 products on the bf16 MFMA: operands as three bf16 planes (csrc/gemm_bf16x3.hip) ----
+BE_BIAS_LRELU_X3, BE_MASK_X3 = 6, 7
+
+
+def split_f32_bf16x3(src, dst, plane, transpose=False):
+    """dst[r][p*plane + c] = bf16 plane p (hi, mid, lo) of the fp32 src[r][c]; transpose: dst[c][p*plane + r]."""
+    sp, sld = _mat(src)
+    dp, dld = _mat16(dst)
+    call("cdml_split_f32_bf16x3", sp, sld, src.shape[0], src.shape[1], dp, dld, plane, 1 if transpose else 0, _stream())
+    return dst
+
+
+def gemm_bf16x3_workspace(tn, M, N, K, products=6):
+    return int(load_library().cdml_gemm_bf16x3_workspace(1 if tn else 0, M, N, K, products))
+
+
+def gemm_bf16x3_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, products=6, plane_c=0, bias=None, aux=None,
+                   alpha=LRELU_ALPHA, workspace=None):
+    """C = epilogue(A . B^T) for fp32 operands given as bf16 planes [rows][hi K | mid K | lo K]."""
+    ap, ald = _mat16(A)
+    bp, bld = _mat16(B)
+    if C.dim() != 2 or C.stride(1) != 1:
+        raise ValueError("C must be 2-D with unit inner stride")
+    call("cdml_gemm_bf16x3_nt", epilogue, ap, ald, plane_a, bp, bld, plane_b, M, N, K, products, _p(C), C.stride(0),
+         plane_c, _p(bias), _p(aux), aux.stride(0) if aux is not None else 0, alpha, _p(workspace),
+         0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())
+    return C
+
+
+def gemm_bf16x3_tn(A, plane_a, B, plane_b, C, M, N, K, products=6, workspace=None, colsum=None):
+    """C[M][N] f32 = sum_k A[k][M] B[k][N] for fp32 operands given as bf16 planes [K][hi | mid | lo]."""
+    ap, ald = _mat16(A)
+    bp, bld = _mat16(B)
+    cp, cld = _mat(C)
+    call("cdml_gemm_bf16x3_tn", ap, ald, plane_a, bp, bld, plane_b, M, N, K, products, cp, cld,
+         _p(colsum, torch.float32), _p(workspace),
+         0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())
+    return C
+
+
 def gemm_bf16_tn2_workspace(M1, N1, M2, N2, K):
     """0 = shapes the joint launch does not take (use gemm_bf16_tn per product)."""
     return int(load_library().cdml_gemm_bf16_tn2_workspace(M1, N1, M2, N2, K))
