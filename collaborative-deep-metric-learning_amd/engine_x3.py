@@ -47,6 +47,11 @@ class TowerWorkspaceX3:
         self.gemm_ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
         self.tail_done = False
 
+    def h1_f32(self):
+        """the hidden activations as one fp32 tensor (tests, debugging): the planes summed"""
+        H = self.layout.Hp
+        return self.h1[:, :H].float() + self.h1[:, H:2 * H].float() + self.h1[:, 2 * H:].float()
+
 
 def refresh_weights(p, ws):
     """plane copies of the fp32 master weights in the orientations the GEMMs read (after every optimizer step)"""

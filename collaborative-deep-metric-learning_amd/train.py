@@ -20,7 +20,7 @@ import time
 
 import torch
 
-from . import engine, engine_bf16, ops
+from . import engine, engine_bf16, engine_x3, ops
 from .inputs import MODE_INBATCH, MODE_UNIFORM
 
 # sampler mode per negative policy: "semihard" samples like "inbatch" (rows a_i, p_i)
@@ -110,12 +110,21 @@ class TrainStep:
         self.slot0 = int(slot0)
         self.batch_global = self.B if batch_global is None else int(batch_global)
         F = table.feature_size if feature_size is None else feature_size
-        if precision not in ("f32", "bf16"):
-            raise ValueError("precision must be 'f32' or 'bf16'")
+        if precision not in ("f32", "bf16", "f32x3", "f32x3-3"):
+            raise ValueError("precision must be 'f32', 'f32x3' or 'bf16'")
+        self.precision = precision
         self.bf16 = precision == "bf16"          # BASELINE config 4: fp16 table + bf16 MFMA
+        # fp32 products on the bf16 MFMA: operands as three exact bf16 planes, six plane products (engine_x3;
+        # "f32x3-3": the three leading products only -- 16-bit operands, not an fp32 equivalent)
+        self.x3 = precision.startswith("f32x3")
         if self.bf16 != (table.data.dtype == torch.float16):
-            raise ValueError("precision 'bf16' goes with an fp16 FeatureTableF16, 'f32' with an fp32 table")
-        if self.bf16:
+            raise ValueError("precision 'bf16' goes with an fp16 FeatureTableF16, 'f32' / 'f32x3' with an fp32 table")
+        if self.x3:
+            self.layout = engine_x3.layout_x3(F, hidden_size, output_size)
+            self.params = engine.VNetParams(self.layout, self.device, weight_seed)
+            self.ws = engine_x3.TowerWorkspaceX3(self.layout, self.R, self.device, products=3 if precision.endswith("-3") else 6)
+            engine_x3.refresh_weights(self.params, self.ws)
+        elif self.bf16:
             self.layout = engine_bf16.layout_bf16(F, hidden_size, output_size)
             self.params = engine.VNetParams(self.layout, self.device, weight_seed)
             self.ws = engine_bf16.TowerWorkspaceBF16(self.layout, self.R, self.device)
@@ -160,7 +169,7 @@ class TrainStep:
         self.grad_norms = torch.zeros((4, 2), dtype=f32, device=dev)   # per variable: |g|, |w|^2
         self.train_table = bool(train_table)
         if self.train_table:
-            if self.bf16 or optimizer != "adam":
+            if self.bf16 or self.x3 or optimizer != "adam":
                 raise ValueError("train_table goes with the fp32 path and the Adam optimizer")
             self.tab_m = torch.zeros_like(table.data)
             self.tab_v = torch.zeros_like(table.data)
@@ -317,7 +326,9 @@ class TrainStep:
         # uniform / in-batch negatives: one launch normalises z, takes the loss and starts the
         # backward pass (semi-hard mining needs every embedded row first: separate kernels)
         fused = with_grad and self.mode != "semihard"
-        if self.bf16:
+        if self.x3:
+            engine_x3.tower_forward(self.params, self.ws, normalize=not fused)
+        elif self.bf16:
             engine_bf16.tower_forward(self.params, self.ws, normalize=not fused)
         else:
             engine.tower_forward(self.params, self.ws, normalize=not fused)
@@ -344,7 +355,9 @@ class TrainStep:
                                       self.pos, self.neg, self.hinge, self.valid, self.stats, de)
 
     def backward(self, after_w1=None):
-        if self.bf16:
+        if self.x3:
+            engine_x3.tower_backward(self.params, self.ws, after_w1=after_w1)
+        elif self.bf16:
             engine_bf16.tower_backward(self.params, self.ws, after_w1=after_w1)
         else:
             engine.tower_backward(self.params, self.ws, after_w1=after_w1)
@@ -408,6 +421,8 @@ class TrainStep:
                            step_dev=self.step_dev, tickets=self.adam_tickets)
         if self.bf16 and self.optimizer != "adam":
             engine_bf16.refresh_weights(p, self.ws)
+        if self.x3:
+            engine_x3.refresh_weights(p, self.ws)
         if self.optimizer == "momentum":
             ops.step_advance(self.step_dev)
 
@@ -436,12 +451,12 @@ class TrainStep:
             if b is not None:
                 self.prefetch.wait_ready(1 - b)
             self.grad_sync.finish([self.grad_sync.start(self.params.grad, 0, self.layout.numel)])
-        elif self._grad_sync_mode == "two":
+        elif self._grad_sync_mode == "two" or self.x3:   # (the split-fp32 engine has no row-block form of dW1)
             if b is not None:
                 self.prefetch.wait_ready(1 - b)
             n1 = self.layout.offsets[2]
             handles = []
-            (engine_bf16 if self.bf16 else engine).tower_backward(
+            (engine_x3 if self.x3 else engine_bf16 if self.bf16 else engine).tower_backward(
                 self.params, self.ws, after_w1=lambda: handles.append(self.grad_sync.start(self.params.grad, 0, n1)))
             handles.append(self.grad_sync.start(self.params.grad, n1, self.layout.numel))
             self.grad_sync.finish(handles)
@@ -599,6 +614,8 @@ class TrainStep:
             self.tab_v.copy_(state["table"]["v"].to(self.device))
         if self.bf16:                                    # the GEMMs read the bf16 copies, not the masters
             engine_bf16.refresh_weights(self.params, self.ws)
+        if self.x3:
+            engine_x3.refresh_weights(self.params, self.ws)
         self.global_step = int(state["global_step"])
         self.step_dev.fill_(self.global_step)
         self.seed = int(state["seed"])

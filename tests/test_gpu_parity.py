@@ -730,9 +730,10 @@ def _oracle_step(feats, pairs, W, step, B, mode, seed, margin=0.8):
     return fwd["l2_norm"], float(loss["hinge_loss"]), grads
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])
 @pytest.mark.parametrize("mode,optimizer", [("uniform", "adam"), ("inbatch", "adam"),
                                             ("uniform", "lars")])
-def test_train_steps_config0(cd, mode, optimizer):
+def test_train_steps_config0(cd, mode, optimizer, precision):
     """BASELINE config 0 shape: 10k x 1500 catalogue (imitation_data-shaped), 5000
     hidden, 256-d, batch 128.  Every step is checked from the device's own
     weights (Adam amplifies 1e-9 gradient noise near g = 0 into lr-sized update
@@ -744,8 +745,9 @@ def test_train_steps_config0(cd, mode, optimizer):
     pairs = osynth.cowatch_pairs(N, 3000, 0)
     table = cd.engine.FeatureTable.from_numpy(feats, cd.dev)
     lr = 0.01 if optimizer == "adam" else 1.0
+    # (precision "f32x3": the same products from three bf16 planes per operand on the bf16 MFMA -- same bounds)
     ts = cd.train.TrainStep(table, dt(pairs, cd.dev, torch.int32), B, margin=0.8, mode=mode,
-                            optimizer=optimizer, base_learning_rate=lr, device=cd.dev)
+                            optimizer=optimizer, base_learning_rate=lr, device=cd.dev, precision=precision)
     f64 = feats.astype(np.float64)
     host = lambda ts_: [t.detach().cpu().numpy().copy() for t in ts_]
     names = ("dW1", "db1", "dW2", "db2")
