@@ -310,6 +310,13 @@ def install_timers(kt, L, bf16):
         # matrices (with their bf16 operand copies), then the biases
         patch("adam_matrix_bf16", lambda W, *a, **k: "adam_w1" if W.shape[0] == L.Fp else "adam_w2")
         patch("adam_step", "adam_bias")
+    elif bf16 is None:                             # precision f32x3: the split-fp32 GEMMs (+ the fp32 Adam)
+        # gemm_bf16x3_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, ...); _tn(A, pa, B, pb, C, M, N, K, ...)
+        patch("gemm_bf16x3_nt", lambda e, A, pa, Bm, pb, C, M, N, K, **k:
+              "fc1_fwd" if (N == L.Hp and K == L.Fp) else ("fc2_fwd" if N == L.Dp else "dH1"))
+        patch("gemm_bf16x3_tn", lambda A, pa, Bm, pb, C, M, N, K, **k: "dW1" if N == L.Hp else "dW2")
+        patch("split_f32_bf16x3", "split_planes")
+        patch("adam_step", "adam")
     else:
         patch("fc_lrelu_fwd", lambda x, W, b, y, M, K, N, *a, **k: "fc1_fwd" if N == L.Hp else "fc2_fwd")
         patch("fc_bwd_weight", lambda x, dy, dW, db, ws, M, K, N: "dW1" if N == L.Hp else "dW2")
@@ -326,11 +333,15 @@ def install_timers(kt, L, bf16):
     return restore
 
 
-def gemm_records(kt, R, bf16, sampled, how, single_gpu):
+def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0):
     """roofline (dominant kernel: the weight-gradient GEMM), roofline_fc1_fwd, kernels -- from the
-    event-timed launches.  Algorithmic (unpadded) flop: dW1 2*R*F*H, dW2 2*R*H*D."""
+    event-timed launches.  Algorithmic (unpadded) flop: dW1 2*R*F*H, dW2 2*R*H*D.
+    x3_products (precision f32x3): every algorithmic fp32 flop is that many bf16 MFMA flops, so the peak the
+    fp32-equivalent rate is held against is the dense bf16 peak divided by it."""
     out = {}
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    if x3_products:
+        peak = round(PEAK_BF16_MFMA_TFLOPS / x3_products, 1)
     have_dw = kt.count("dW") or (kt.count("dW1") and kt.count("dW2"))
     if not (have_dw and kt.count("fc1_fwd")):
         return out
@@ -342,26 +353,32 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu):
         else:
             kname, klabel = "k_gemm_f32_sk", "k_gemm_f32_sk (dW1+dW2 in one stream-K launch, fix-up pass included)"
     else:
-        kname = "k_gemm_bf16_256<true, 3>" if bf16 else "k_gemm_f32<false, false, 2, 2, 3,"
+        kname = "k_gemm_bf16_256<true, 3>" if (bf16 or x3_products) else "k_gemm_f32<false, false, 2, 2, 3,"
         n_launch = kt.count("dW1") + kt.count("dW2")
         t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
-        klabel = kname + (" ...> (dW1+dW2 launches)" if not bf16 else " (dW1+dW2 launches)")
+        klabel = kname + (" ...> (dW1+dW2 launches)" if not (bf16 or x3_products) else " (dW1+dW2 launches)")
+        if x3_products:
+            klabel = ("k_gemm_bf16_256<true, 3, true, true> (dW1+dW2 launches: fp32 products as %d bf16 plane products; "
+                      "achieved = fp32-equivalent rate, peak = bf16 dense peak / %d)" % (x3_products, x3_products))
     flop_launch = sampled * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
     ach = flop_launch / (t_ms * 1e-3) / 1e12
-    tr, src = pmc_traffic(kname, bf16) if single_gpu else (None, None)
+    tr, src = pmc_traffic(kname, bf16) if (single_gpu and not x3_products) else (None, None)
     out["roofline"] = {"bound": "mfma", "kernel": klabel, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                        "frac": round(ach / peak, 4), "traffic": tr, "traffic_source": src,
                        "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch,
                        "launches_per_step": n_launch / sampled, "timed_steps": sampled, "timed_how": how}
     ach1 = flops_gemm / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
     k1 = "k_gemm_bf16_256<false, 0>" if bf16 else "k_gemm_f32<true, false, 2, 2, 1,"
-    tr1, src1 = pmc_traffic(k1, bf16) if single_gpu else (None, None)
-    out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": k1 + ("" if bf16 else " ...>"),
+    if x3_products:
+        k1 = "k_gemm_bf16_256<false, 6, true, true>"
+    tr1, src1 = pmc_traffic(k1, bf16) if (single_gpu and not x3_products) else (None, None)
+    out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": k1 + ("" if (bf16 or x3_products) else " ...>"),
                                "achieved": round(ach1, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach1 / peak, 4), "traffic": tr1, "traffic_source": src1,
                                "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": flops_gemm}
     kern = {}
-    for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "adam", "adam_w1", "adam_w2", "adam_bias", "lars"):
+    for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "adam", "adam_w1", "adam_w2", "adam_bias", "lars",
+              "split_planes"):
         if kt.mean_ms(k) is not None:
             kern[k + "_ms"] = round(kt.mean_ms(k), 4)
             if kt.count(k) != sampled:
@@ -695,7 +712,7 @@ def main():
     ap.add_argument("--mode", default=None, choices=["inbatch", "uniform", "semihard", "predict"])
     ap.add_argument("--batch", type=int, default=None, help="triplets per GPU per step (default 4096 for config 1, else 8192)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "f32x3", "f32x3-3"],
                     help="bf16 = BASELINE config 4 path (fp16 table + bf16 MFMA); not the headline metric")
     ap.add_argument("--train-table", action="store_true",
                     help="also train the catalogue rows (lazy Adam; build-defined, not the headline metric)")
@@ -743,6 +760,7 @@ def main():
     import torch.distributed as dist
     from cdml_amd import dist as cdist, engine, engine_bf16, train
     bf16 = args.precision == "bf16"
+    x3 = 0 if not args.precision.startswith("f32x3") else (3 if args.precision.endswith("-3") else 6)
     Table = engine_bf16.FeatureTableF16 if bf16 else engine.FeatureTable
 
     if args.mode == "predict":                           # catalogue inference throughput (N = 1)
@@ -865,7 +883,7 @@ def main():
             if ts.prefetch is not None:
                 ts.prefetch.acquire = comm_kt.wrap("exchange_wait", ts.prefetch.acquire)
             comm_kt.on = True
-        elapsed, kt, sampled, how = measure_job(ts, args.steps, args.warmup, dev, bf16, timers_on,
+        elapsed, kt, sampled, how = measure_job(ts, args.steps, args.warmup, dev, None if x3 else bf16, timers_on,
                                                 barrier if world > 1 else None)
         if comm_kt is not None:
             comm_kt.on = False
@@ -893,7 +911,10 @@ def main():
             "metric": "triplets/sec", "value": round(world * B * args.steps / elapsed, 1),
             "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if not bf16 else "bf16 (fp16 table, f32 accumulate)",
+            "vs_baseline": None,
+            "dtype": ("bf16 (fp16 table, f32 accumulate)" if bf16 else "f32" if not x3 else
+                      "f32 values as 3 exact bf16 planes, %d plane products per fp32 product on the bf16 MFMA, f32 accumulate%s"
+                      % (x3, "" if x3 == 6 else " (16-bit operands: NOT an fp32 equivalent)")),
             "data": "synthetic",
             "config": {"workload": "%s: %d videos x %d-d %s in HBM%s, %d hidden, %d-d embed, batch %d triplets/GPU "
                                    "(%d global), %s negatives, margin %.1f, Adam, full step (sample+gather+fwd+loss+bwd+opt)"
@@ -912,7 +933,7 @@ def main():
             out["comm_backend"] = {"backend": dist.get_backend(), "launcher": "self" if os.environ.get("CDML_BENCH_PHASE_DIR") else "external",
                                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
         if timers_on:
-            out.update(gemm_records(kt, R, bf16, sampled, how, world == 1))
+            out.update(gemm_records(kt, R, bf16, sampled, how, world == 1, x3_products=x3))
         if world == 1 and not args.train_table:
             set_phase("gather record")
             out["gather"] = gather_record(ts, mode, bf16, dev)
@@ -937,7 +958,7 @@ def main():
                         % ("" if args.no_settle else "0.3 s settle loop, "))
 
         # ---- secondary records (after the headline; the failure of one must not cost the line) ----
-        run_extras = config1 and mode == "inbatch" and not args.no_extras and not args.train_table
+        run_extras = config1 and mode == "inbatch" and not args.no_extras and not args.train_table and not x3
         if run_extras:
             del ts
             torch.cuda.empty_cache()
