@@ -398,6 +398,10 @@ def gather_record(ts, mode, bf16, dev):
     m = train._MODES[mode]
     gk = "k_sample_gather<%d," % (1 if rpt == 2 else 0)       # <mode, RowF32<6>> / <mode, RowF16<3>>
     gbytes = n_st * R * F * (2 + 2.0) if bf16 else n_st * 2.0 * R * F * 4     # rows read + normalised rows written
+    x3 = (not bf16) and ts.ws.x_hat.dtype == torch.bfloat16
+    if x3:
+        gbytes = n_st * R * F * (4 + 6.0)                                     # fp32 rows read, three bf16 planes written
+        gk = "k_sample_gather<%d, RowF32X3" % (1 if rpt == 2 else 0)
     nxt = [ts.global_step + 1000]                   # fresh steps every launch: re-reading the same rows
                                                     # would be served from the 256 MB Infinity Cache
 
@@ -421,8 +425,8 @@ def gather_record(ts, mode, bf16, dev):
     torch.cuda.synchronize(dev)
     t_g = float(np.median([s.elapsed_time(e) for s, e in evs])) / per
     g_ach = gbytes / (t_g * 1e-3) / 1e9
-    tr, src = pmc_traffic(gk, bf16)
-    return {"bound": "hbm", "kernel": gk + (" RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1),
+    tr, src = (None, None) if x3 else pmc_traffic(gk, bf16)
+    return {"bound": "hbm", "kernel": gk + ("<6>>" if x3 else " RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": tr,
             "traffic_source": src, "bytes_per_launch": gbytes, "launch_ms": round(t_g, 4), "steps_per_launch": n_st,
             "method": "%d back-to-back launches per event pair (inter-launch gaps included), median of %d" % (per, reps)}
@@ -640,6 +644,40 @@ def rec_reference_recipe(dev, args, n_s, n_w, table):
            "value": round(1024 * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4), "steps": n,
            "loss": round(ts.loss(), 6)}
     out.update(gemm_records(kt, ts.R, False, sampled, how, False))
+    return out
+
+
+def rec_f32x3(dev, args, n_s, n_w, table, pairs, B, mode):
+    """The headline step with its fp32 products on the bf16 MFMA (precision "f32x3": every operand as three exact
+    bf16 planes, six plane products per fp32 product, fp32 accumulate -- csrc/gemm_bf16x3.hip), same table, batch,
+    sampler and optimizer.  Before timing, one step of it and one of the native fp32 step are taken from the same
+    weights on the same triplets and compared on the device."""
+    from cdml_amd import train
+    mk = lambda prec: train.TrainStep(table, pairs, B, output_size=D, hidden_size=H, margin=MARGIN, mode=mode,
+                                      optimizer="adam", base_learning_rate=0.01, seed=1234, weight_seed=42, device=dev,
+                                      precision=prec, gather_ahead=args.gather_ahead)
+    a, b = mk("f32"), mk("f32x3")
+    a.step(); b.step()
+    torch.cuda.synchronize(dev)
+    ga, gb = a.params.grad.double(), b.params.grad.double()
+    check = {"same_triplets": bool(torch.equal(a.idx, b.idx)),
+             "max_abs_embedding_diff": float((a.ws.e - b.ws.e).abs().max().item()),
+             "loss_native_f32": round(a.loss(), 7), "loss_f32x3": round(b.loss(), 7),
+             "gradient_rel_l2_diff": float(((ga - gb).norm() / ga.norm().clamp_min(1e-300)).item()),
+             "note": "one step each from identical weights; the parity tests hold both paths to the same bounds against "
+                     "the fp64 oracle (tests/test_gpu_parity.py::test_train_steps_config0, tests/test_gpu_fullsize.py::"
+                     "test_gradients_well_conditioned_production_shape, tests/test_gpu_f32x3.py)"}
+    del a
+    torch.cuda.empty_cache()
+    n = max(n_s, 60)
+    el, kt, sampled, how = measure_job(b, n, max(n_w, 10), dev, None)
+    out = {"workload": "the headline workload (%d videos, batch %d, %s negatives, Adam) with precision f32x3: fp32 operands as "
+                       "three exact bf16 planes, six bf16 MFMA plane products per fp32 product, fp32 accumulate"
+                       % (table.n_rows, B, mode),
+           "value": round(B * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4), "steps": n,
+           "dtype": "f32 values as 3 exact bf16 planes, 6 plane products on the bf16 MFMA, f32 accumulate",
+           "loss": round(b.loss(), 6), "against_native_f32": check}
+    out.update(gemm_records(kt, b.R, False, sampled, how, False, x3_products=6))
     return out
 
 
@@ -963,7 +1001,7 @@ def main():
             del ts
             torch.cuda.empty_cache()
             want = set((args.extras or "like_for_like,dp_form_one_gpu,config4_per_gpu,reference_recipe,fusion_resnet,"
-                                       "predict,data_learnable").split(","))
+                                       "predict,data_learnable,f32x3").split(","))
             n_s, n_w = min(args.steps, 30), min(max(args.warmup, 3), 5)
             keep = {}
 
@@ -976,6 +1014,7 @@ def main():
                 except Exception as e:                   # noqa: BLE001
                     out[name] = {"error": repr(e)[:300]}
                 torch.cuda.empty_cache()
+            attempt("f32x3", lambda: rec_f32x3(dev, args, n_s, n_w, table, pairs, B, mode))
             attempt("reference_recipe", lambda: rec_reference_recipe(dev, args, n_s, n_w, table))
             attempt("data_learnable", lambda: rec_learnable(dev, args, n_s, n_w, B))
             del table, pairs

@@ -592,8 +592,10 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       }
       if (row >= g.M) continue;                            // stores only below this line
       if constexpr (EPI == BE_BIAS_LRELU_X3 || EPI == BE_MASK_X3) {
-        // three roundings to nearest hold the 24 significant bits: hi + mid + lo == v exactly
+        // three roundings to nearest hold the 24 significant bits: hi + mid + lo == v exactly (v pinned as
+        // computed: the products above must not be contracted with the residual subtractions into fmas)
         bf16 *dst = static_cast<bf16 *>(c_base) + (int64_t)(row - m0 + c_row0) * c_ld + c_col0 + lcol;
+        asm volatile("" : "+v"(v));
         f32x4 r = v;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {

@@ -147,14 +147,22 @@ k_x3_sum_slabs(const float *__restrict__ slabs, int64_t slab_stride, int splits,
     reinterpret_cast<f32x4 *>(out + r * ldo)[c] = s;
   }
 }
-// colsum[n] = sum over the partial rows
+// colsum[n] = sum over the partial rows: 32 columns per block, 8 row lanes, added in a fixed order
 __global__ void __launch_bounds__(kThreads)
 k_x3_colsum_final(const float *__restrict__ partial, int n_rows, int N, float *__restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
+  __shared__ float red[8][33];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
   float s = 0.f;
-  for (int r = 0; r < n_rows; ++r) s += partial[(int64_t)r * N + c];
-  out[c] = s;
+  if (c < N)
+    for (int r = rl; r < n_rows; r += 8) s += partial[(int64_t)r * N + c];
+  red[rl][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t += red[j][threadIdx.x];
+    out[c] = t;
+  }
 }
 }  // namespace
 }  // namespace cdml
@@ -255,7 +263,7 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
     if ((rc = check_launch("gemm_bf16x3_tn combine"))) return rc;
   }
   if (colsum) {
-    hipLaunchKernelGGL(k_x3_colsum_final, dim3((N + kThreads - 1) / kThreads), dim3(kThreads), 0, s, g.colsum_partial,
+    hipLaunchKernelGGL(k_x3_colsum_final, dim3((N + 31) / 32), dim3(kThreads), 0, s, g.colsum_partial,
                        (int)cs_rows, N, colsum);
     rc = check_launch("gemm_bf16x3_tn bias gradient");
   }

@@ -266,6 +266,64 @@ struct RowF32 {
   }
 };
 
+// RowF32X3: fp32 table -> the l2-normalised row as three bf16 planes hi | mid | lo (hi + mid + lo = the fp32 value,
+// exactly; the split-fp32 GEMMs of gemm_bf16x3.hip read them) -- out_stride = 3 planes of out_stride / 3 columns.
+template <int NCH>
+struct RowF32X3 {
+  using In = float;
+  using Out = __bf16;
+  using Regs = RowRegs<NCH>;
+  static constexpr int kPerChunk = 4;
+  static constexpr int kRows = kRowsPerWave;
+  __device__ static __forceinline__ void issue(Regs &R, const In *table, int64_t lr, int64_t stride, int F, int lane) {
+    row_issue<NCH>(R, table, lr, stride, (F + 3) >> 2, lane);
+  }
+  __device__ static __forceinline__ void finish(Regs &R, int F, Out *dst, int64_t out_stride, int lane) {
+    using bf16x4v = __attribute__((ext_vector_type(4))) __bf16;
+    if (F & 3) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int j = 4 * (lane + kWave * c);
+        if (j + 1 >= F && j < F) R.v[c].y = 0.f;
+        if (j + 2 >= F && j < F) R.v[c].z = 0.f;
+        if (j + 3 >= F && j < F) R.v[c].w = 0.f;
+      }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      ss += R.v[c].x * R.v[c].x + R.v[c].y * R.v[c].y + R.v[c].z * R.v[c].z + R.v[c].w * R.v[c].w;
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    const int64_t plane = out_stride / 3;
+    const int oq = (int)(plane >> 2);
+    const bf16x4v z4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      if (q < oq) {
+        // the planes are those of the ROUNDED product, the value the fp32 gather stores: no contraction of the
+        // product with the residual subtraction below into an fma on the unrounded one
+#pragma clang fp contract(off)
+        float r[4] = {R.v[c].x * inv, R.v[c].y * inv, R.v[c].z * inv, R.v[c].w * inv};
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          bf16x4v o;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            o[u] = (__bf16)r[u];
+            r[u] -= (float)o[u];
+          }
+          *reinterpret_cast<bf16x4v *>(dst + pl * plane + 4 * q) = o;
+        }
+      }
+    }
+    for (int q = lane + kWave * NCH; q < oq; q += kWave)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x4v *>(dst + pl * plane + 4 * q) = z4;
+  }
+};
+
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using bf16x8v = __attribute__((ext_vector_type(8))) __bf16;
 template <int NCH>
@@ -607,6 +665,46 @@ extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pair
   }
 #undef CDML_LAUNCH_SG
   return check_launch("sample_gather");
+}
+
+// The fused sampler + gather writing each row as three bf16 planes (precision "f32x3"): x_out = bf16
+// [rows][out_stride], out_stride = 3 planes of out_stride / 3 >= F columns each (a multiple of 4).
+extern "C" int cdml_sample_gather_x3(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                                     uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
+                                     int64_t batch_global, const float *table, int64_t n_rows,
+                                     int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
+                                     uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
+                                     int64_t idx_step_stride, int32_t *oob_flag, cdml_stream_t stream) {
+  CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "sample_gather_x3: mode must be 0 or 1");
+  CDML_REQUIRE(n_steps >= 1 && n_steps <= 64, CDML_E_BADARG, "sample_gather_x3: n_steps must be in [1, 64]");
+  const int rpt = mode == 0 ? 3 : 2;
+  CDML_REQUIRE(n_steps == 1 || (x_step_stride >= (int64_t)batch * rpt * out_stride && (x_step_stride & 3) == 0 &&
+                                idx_step_stride >= (int64_t)batch * rpt),
+               CDML_E_BADARG, "sample_gather_x3: per-step strides too small for the batch");
+  CDML_REQUIRE(pairs && table && idx_out && x_out_planes && n_pairs > 0 && slot0 >= 0, CDML_E_BADARG,
+               "sample_gather_x3: bad argument");
+  CDML_REQUIRE(n_rows >= 3 && n_rows <= 0x7FFFFFFFll, CDML_E_BADARG, "sample_gather_x3: n_rows must be in [3, 2^31)");
+  CDML_REQUIRE(batch >= (mode == 1 ? 2 : 1), CDML_E_BADARG, "sample_gather_x3: batch too small");
+  CDML_REQUIRE(mode == 0 || shift_out, CDML_E_BADARG, "sample_gather_x3: shift_out required in mode 1");
+  CDML_REQUIRE(batch_global >= slot0 + batch, CDML_E_BADARG, "sample_gather_x3: batch_global < slot0 + batch");
+  CDML_REQUIRE(F > 0 && F <= 2048, CDML_E_UNSUPPORTED, "sample_gather_x3: feature size %d outside (0, 2048]", F);
+  CDML_REQUIRE(row_stride >= F && (row_stride & 3) == 0 && out_stride % 3 == 0 && out_stride / 3 >= F &&
+                   ((out_stride / 3) & 3) == 0 && aligned16(table) && (reinterpret_cast<uintptr_t>(x_out_planes) & 7) == 0,
+               CDML_E_ALIGN, "sample_gather_x3: out_stride must be 3 planes of >= F columns (multiples of 4)");
+  const int grid = grid_for((int64_t)batch * rpt * n_steps, RowF32X3<6>::kRows * kWavesPerBlock);
+  const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
+#define CDML_LAUNCH_SGX(M, N)                                                                              \
+  hipLaunchKernelGGL((k_sample_gather<M, RowF32X3<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
+                     pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global, table,               \
+                     n_rows, row_stride, F, idx_out, shift_out, reinterpret_cast<__bf16 *>(x_out_planes),   \
+                     out_stride, n_steps, x_step_stride, idx_step_stride, oob_flag)
+  if (mode == 0) {
+    if (nch <= 6) CDML_LAUNCH_SGX(0, 6); else CDML_LAUNCH_SGX(0, 8);
+  } else {
+    if (nch <= 6) CDML_LAUNCH_SGX(1, 6); else CDML_LAUNCH_SGX(1, 8);
+  }
+#undef CDML_LAUNCH_SGX
+  return check_launch("sample_gather_x3");
 }
 
 extern "C" int cdml_route_rows(const int32_t *ids, int n, int64_t rows_per_shard, int world, int capacity,

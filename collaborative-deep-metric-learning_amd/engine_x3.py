@@ -27,7 +27,9 @@ def layout_x3(feature_size, hidden=5000, output_size=256):
 
 
 class TowerWorkspaceX3:
-    def __init__(self, layout, n_rows, device, products=6):
+    def __init__(self, layout, n_rows, device, products=6, planes_in=True):
+        """planes_in: ``x_hat`` IS the plane buffer (the fused sampler + gather writes planes); False: ``x_hat`` is
+        fp32 (rows arriving through the exchange) and the forward pass splits it."""
         L, R = layout, int(n_rows)
         if R % 128:
             raise ValueError("precision 'f32x3' needs a row count that is a multiple of 128 (got %d)" % R)
@@ -36,8 +38,9 @@ class TowerWorkspaceX3:
         self.layout, self.R, self.products = L, R, products
         bf = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=device)
         f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
-        self.x_hat = f32(R, L.Fp)                          # the gather's output (l2-normalised rows)
-        self.x3, self.h1, self.dz1 = bf(R, 3 * L.Fp), bf(R, 3 * L.Hp), bf(R, 3 * L.Hp)
+        self.x3 = bf(R, 3 * L.Fp)
+        self.x_hat = self.x3 if planes_in else f32(R, L.Fp)    # the gather's output (l2-normalised rows)
+        self.h1, self.dz1 = bf(R, 3 * L.Hp), bf(R, 3 * L.Hp)
         self.z, self.e, self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp)
         self.dz2_3 = bf(R, 3 * L.Dp)
         self.W1T, self.W2T, self.W2 = bf(L.Hp, 3 * L.Fp), bf(L.Dp, 3 * L.Hp), bf(L.Hp, 3 * L.Dp)
@@ -64,7 +67,10 @@ def refresh_weights(p, ws):
 def tower_forward(p, ws, normalize=True):
     """x_hat (fp32, l2-normalised) -> planes -> h1 (planes) -> z (fp32) -> e (fp32).  models.py:59-61."""
     L, R, q = p.layout, ws.R, ws.products
-    ops.split_f32_bf16x3(ws.x_hat, ws.x3, L.Fp)
+    if ws.x_hat.dtype == torch.float32:                 # rows from the exchange / a caller: split here; the fused
+        ops.split_f32_bf16x3(ws.x_hat, ws.x3, L.Fp)     # sampler + gather writes the planes itself (x_hat IS x3 then)
+    else:
+        ws.x3 = ws.x_hat
     ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, ws.x3, L.Fp, ws.W1T, L.Fp, ws.h1, R, L.Hp, L.Fp, products=q,
                        plane_c=L.Hp, bias=p.b1)
     ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, ws.h1, L.Hp, ws.W2T, L.Hp, ws.z, R, L.Dp, L.Hp, products=q,

@@ -86,17 +86,20 @@ def sample_gather(mode, pairs, seed, step, batch, table, feature_size, idx_out, 
     outside the catalogue (the reference's IndexError, inputs.py:158)."""
     bg = batch if batch_global is None else batch_global
     f16 = table.dtype == torch.float16              # fp16 catalogue -> bf16 rows (config 4)
+    x3 = not f16 and x_out.dtype == torch.bfloat16   # fp32 catalogue -> rows as three bf16 planes (precision f32x3)
     mat = _mat16 if f16 else _mat
+    omat = _mat16 if (f16 or x3) else _mat
     tp, tld = mat(table)
     if n_steps > 1:
         if x_out.dim() != 3 or idx_out.dim() != 2 or x_out.shape[0] != n_steps or idx_out.shape[0] != n_steps:
             raise ValueError("n_steps > 1 needs x_out [n_steps, rows, stride] and idx_out [n_steps, rows]")
-        xp, xld = mat(x_out[0])
+        xp, xld = omat(x_out[0])
         xss, iss = x_out.stride(0), idx_out.stride(0)
     else:
-        xp, xld = mat(x_out)
+        xp, xld = omat(x_out)
         xss = iss = 0
-    call("cdml_sample_gather_f16" if f16 else "cdml_sample_gather", mode, _p(pairs, torch.int32), pairs.shape[0], seed,
+    call("cdml_sample_gather_f16" if f16 else "cdml_sample_gather_x3" if x3 else "cdml_sample_gather",
+         mode, _p(pairs, torch.int32), pairs.shape[0], seed,
          0 if step is None else step, _p(step_dev, torch.int64), batch, slot0, bg, tp,
          table.shape[0], tld, feature_size, _p(idx_out, torch.int32), _p(shift_out, torch.int32),
          xp, xld, n_steps, xss, iss, _p(oob_flag, torch.int32), _stream())

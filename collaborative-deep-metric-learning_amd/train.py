@@ -122,7 +122,8 @@ class TrainStep:
         if self.x3:
             self.layout = engine_x3.layout_x3(F, hidden_size, output_size)
             self.params = engine.VNetParams(self.layout, self.device, weight_seed)
-            self.ws = engine_x3.TowerWorkspaceX3(self.layout, self.R, self.device, products=3 if precision.endswith("-3") else 6)
+            self.ws = engine_x3.TowerWorkspaceX3(self.layout, self.R, self.device, products=3 if precision.endswith("-3") else 6,
+                                                 planes_in=exchange is None)
             engine_x3.refresh_weights(self.params, self.ws)
         elif self.bf16:
             self.layout = engine_bf16.layout_bf16(F, hidden_size, output_size)

@@ -392,6 +392,14 @@ int cdml_gemm_bf16_tn2(const uint16_t *A1, int64_t lda1, const uint16_t *B1, int
  * colsum[n] = sum_k B[k][n] on request.  M, N % 256, K % 128.  Workspace: cdml_gemm_bf16x3_workspace(tn, ...). */
 int cdml_split_f32_bf16x3(const float *src, int64_t ld_src, int rows, int cols, uint16_t *dst,
                           int64_t ld_dst, int64_t plane, int transpose, cdml_stream_t stream);
+/* cdml_sample_gather (inputs.py:102-166, models.py:58) writing every l2-normalised row as its three planes:
+ * x_out_planes = bf16 [rows][out_stride], out_stride = 3 planes of out_stride / 3 >= F columns. */
+int cdml_sample_gather_x3(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                          uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
+                          int64_t batch_global, const float *table, int64_t n_rows,
+                          int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
+                          uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
+                          int64_t idx_step_stride, int32_t *oob_flag, cdml_stream_t stream);
 size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int products);
 int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
                         int64_t ldb, int64_t plane_b, int M, int N, int K, int products, void *C,

@@ -117,3 +117,25 @@ def test_gemm_x3_tn_weight_gradient(M, N, K, products):
     refb = dY.double().sum(0)
     errb = (db.double() - refb).abs().max().item() / refb.abs().max().item()
     assert errb <= (5e-6 if products == 6 else 1e-4), errb
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sample_gather_planes_equal_split_of_the_fp32_gather(mode):
+    """the fused sampler + gather writing planes == its fp32 rows, split (ids bit-equal, planes bit-equal)"""
+    dev = _dev()
+    from cdml_amd import engine
+    N, F, B, K = 5000, 1500, 96, 3
+    table = engine.FeatureTable.synthetic(N, F, 0, dev)
+    rng = np.random.RandomState(0)
+    pairs = rng.randint(0, N, size=(4000, 2)).astype(np.int32)
+    pairs = torch.from_numpy(pairs[pairs[:, 0] != pairs[:, 1]]).to(dev)
+    rows, Fp = B * (3 if mode == 0 else 2), 1536
+    x32 = torch.zeros(K, rows, Fp, device=dev)
+    x3 = torch.zeros(K, rows, 3 * Fp, dtype=torch.bfloat16, device=dev)
+    i32, i3 = (torch.zeros(K, rows, dtype=torch.int32, device=dev) for _ in range(2))
+    s32, s3 = (torch.zeros(K, dtype=torch.int32, device=dev) for _ in range(2))
+    ops.sample_gather(mode, pairs, 1234, 7, B, table.data, F, i32, x32, shift_out=s32, n_steps=K)
+    ops.sample_gather(mode, pairs, 1234, 7, B, table.data, F, i3, x3, shift_out=s3, n_steps=K)
+    assert torch.equal(i32, i3) and torch.equal(s32, s3)
+    for k in range(K):
+        assert torch.equal(x3[k], _planes(x32[k], Fp))
