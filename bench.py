@@ -316,6 +316,7 @@ def install_timers(kt, L, bf16):
               "fc1_fwd" if (N == L.Hp and K == L.Fp) else ("fc2_fwd" if N == L.Dp else "dH1"))
         patch("gemm_bf16x3_tn", lambda A, pa, Bm, pb, C, M, N, K, **k: "dW1" if N == L.Hp else "dW2")
         patch("split_f32_bf16x3", "split_planes")
+        patch("adam_matrix_bf16", lambda W, *a, **k: "adam_w1" if W.shape[0] == L.Fp else "adam_w2")
         patch("adam_step", "adam")
     else:
         patch("fc_lrelu_fwd", lambda x, W, b, y, M, K, N, *a, **k: "fc1_fwd" if N == L.Hp else "fc2_fwd")

@@ -97,6 +97,8 @@ SIGNATURES = {
     "cdml_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _i64, _p, _i, _p, _p]),
     "cdml_adam_matrix_bf16": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _f, _f, _f, _i64, _p, _p, _i64, _p, _i64,
                                    _p, _p, _p, _p, _i, _i, _p, _p]),
+    "cdml_adam_matrix_planes": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _f, _f, _f, _i64, _p, _p, _i64, _i64, _p, _i64, _i64,
+                                     _p, _p, _p, _p, _i, _i, _p, _p]),
     "cdml_table_adam_rows": (_i, [_p, _i64, _i64, _i64, _i, _p, _i, _p, _i64, _p, _p, _p, _p, _f, _f, _p, _f, _f, _f,
                                   _i64, _p, _p]),
     "cdml_grad_prepare": (_i, [_p, _p, _i64, _f, _f, _p, _p, _p]),

@@ -461,18 +461,21 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     const int lr = p * 4 + (lane >> 4);
     return TN ? m0 + (rt >> 1) * 128 + grp * 64 + (rt & 1) * 32 + lr : m0 + grp * 128 + rt * 32 + lr;
   };
-  if constexpr (!TN && (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_MASK_BF16)) {
+  constexpr bool kBiasEpi = EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_X3;
+  constexpr bool kMaskEpi = EPI == BE_MASK_BF16 || EPI == BE_MASK_X3;
+  constexpr bool kPlanes = EPI == BE_BIAS_LRELU_X3 || EPI == BE_MASK_X3;
+  if constexpr (!TN && (kBiasEpi || kMaskEpi)) {
     // bf16 outputs of the k-contiguous form: 16 B per lane and store (8 rows x 128 B per instruction) instead of
     // 8 B -- half the store instructions of the tile's tail (cdna guide T21: such a tail is issue-bound)
     const int c8 = lane & 7, lcol8 = wc * 64 + c8 * 8;
     f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
-    if (EPI == BE_BIAS_LRELU_BF16) {
+    if (kBiasEpi) {
       b0 = *reinterpret_cast<const f32x4 *>(g.bias + n0 + lcol8);
       b1 = *reinterpret_cast<const f32x4 *>(g.bias + n0 + lcol8 + 4);
     }
     auto row8 = [&](int rt, int p) { return m0 + grp * 128 + rt * 32 + p * 8 + (lane >> 3); };
     bf16x8 mk8[4][4];
-    if (EPI == BE_MASK_BF16 && has_aux) {                    // all 16 mask loads of the wave go out together
+    if (kMaskEpi && has_aux) {                               // all 16 mask loads of the wave go out together
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -514,16 +517,32 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
         unsigned bits = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          if (EPI == BE_BIAS_LRELU_BF16) {
+          if (kBiasEpi) {
             v[j] += bb[j];
             v[j] = fmaxf(v[j], v[j] * g.alpha);
           } else if (has_aux) {
             v[j] *= ((float)mk8[rt][p][j] > 0.f) ? 1.f : g.alpha;
           }
+          if constexpr (kPlanes) asm volatile("" : "+v"(v[j]));   // the planes are those of the ROUNDED value
           o[j] = (bf16)v[j];
           if (EPI == BE_BIAS_LRELU_BF16 && (float)o[j] > 0.f) bits |= 1u << j;
         }
         if (row >= g.M) continue;                            // stores only below this line
+        if constexpr (kPlanes) {
+          // three roundings to nearest hold the 24 significant bits: hi + mid + lo == v exactly
+          bf16 *dst = static_cast<bf16 *>(c_base) + (int64_t)(row - m0 + c_row0) * c_ld + c_col0 + lcol8;
+          *reinterpret_cast<bf16x8 *>(dst) = o;
+#pragma unroll
+          for (int pl = 1; pl < 3; ++pl) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              v[j] -= (float)o[j];
+              o[j] = (bf16)v[j];
+            }
+            *reinterpret_cast<bf16x8 *>(dst + pl * g.x3_plane_c) = o;
+          }
+          continue;
+        }
         if (EPI == BE_BIAS_LRELU_BF16 && g.mask_out)         // this lane's 8 columns = one byte of the sign bitmask
           g.mask_out[(int64_t)row * g.ldmask + ((n0 + lcol8) >> 3)] = (uint8_t)bits;
         *reinterpret_cast<bf16x8 *>(static_cast<bf16 *>(c_base) + (int64_t)(row - m0 + c_row0) * c_ld + c_col0 + lcol8) = o;

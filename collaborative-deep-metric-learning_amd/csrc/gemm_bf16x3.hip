@@ -185,8 +185,10 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
                    plane_a >= K && plane_b >= K && lda >= 2 * plane_a + K && ldb >= 2 * plane_b + K,
                CDML_E_ALIGN, "gemm_bf16x3_nt: 16-B aligned bases, strides multiples of 8, ld >= 2 plane + K");
   const bool planes_out = epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3;
-  CDML_REQUIRE(planes_out ? (!(ldc & 3) && !(plane_c & 3) && plane_c >= N && ldc >= 2 * plane_c + N) : (!(ldc & 3) && ldc >= N),
-               CDML_E_ALIGN, "gemm_bf16x3_nt: ldc / plane_c");
+  CDML_REQUIRE(planes_out ? (!(ldc & 7) && !(plane_c & 7) && plane_c >= N && ldc >= 2 * plane_c + N) : (!(ldc & 3) && ldc >= N),
+               CDML_E_ALIGN, "gemm_bf16x3_nt: ldc (plane outputs: ldc and plane_c multiples of 8, ldc >= 2 plane_c + N)");
+  CDML_REQUIRE(epilogue != BE_MASK_X3 || !aux || (aligned16(aux) && !(ldaux & 7) && ldaux >= N), CDML_E_ALIGN,
+               "gemm_bf16x3_nt: aux must be 16-B aligned with ldaux a multiple of 8");
   CDML_REQUIRE((epilogue != BE_BIAS_LRELU_F32 && epilogue != BE_BIAS_LRELU_X3) || bias, CDML_E_BADARG, "gemm_bf16x3_nt: bias required");
   CDML_REQUIRE(((int64_t)M + 256) * lda * 2 < ((int64_t)1 << 31) && (int64_t)N * ldb * 2 < ((int64_t)1 << 31), CDML_E_UNSUPPORTED,
                "gemm_bf16x3_nt: an operand exceeds the 2 GiB buffer-descriptor range");

@@ -88,14 +88,18 @@ k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m
 // The layer's BIAS vector (bw/bg/bm/bv, bn elements, nullable) rides along in the first blocks -- a
 // 5 000-element Adam launch of its own costs 5-7 us for 100 KB -- and on request the last block to
 // finish advances the step counter (as k_adam does): the optimizer of the config-4 step is two launches.
+// PLANES = 3 (precision "f32x3"): the copies are the three bf16 planes hi | mid | lo of the new weights (their
+// sum is the fp32 value; plane p of W^T starts plane_t elements after plane p - 1 in every row, of W plane_c).
 constexpr int kAT = 64;
+template <int PLANES>
 __global__ void __launch_bounds__(kThreads)
 k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
                    float *__restrict__ v, int K, int N, float lr_imm, const float *__restrict__ lr_dev,
                    float b1, float b2, float eps, int64_t t_imm, uint64_t *__restrict__ t_dev,
                    __bf16 *__restrict__ wt, int64_t ldt, __bf16 *__restrict__ wc, int64_t ldc,
                    float *__restrict__ bw, const float *__restrict__ bg, float *__restrict__ bm,
-                   float *__restrict__ bv, int bn, int advance, uint32_t *__restrict__ tickets) {
+                   float *__restrict__ bv, int bn, int advance, uint32_t *__restrict__ tickets,
+                   int64_t plane_t, int64_t plane_c) {
   using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
   __shared__ float s_lr_t;
   __shared__ uint32_t sT[kAT][kAT / 2 + 1];           // [column n][row pair]: two bf16 of one column per word
@@ -112,10 +116,10 @@ k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__
   const int tr = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
   // a thread takes two adjacent rows of four columns per pass: the transpose goes through LDS as
   // 32-bit words (the two rows' values of one column), 33-word rows -> at most 2-way bank conflicts
+  float res[2][2][4];                                  // the new weights (PLANES > 1: what the planes so far leave)
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int r = p * 32 + 2 * tr;
-    bf16x4 o[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int64_t i = (int64_t)(k0 + r + q) * N + n0 + c4;
@@ -129,26 +133,43 @@ k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__
       *reinterpret_cast<float4 *>(w + i) = w4;
       *reinterpret_cast<float4 *>(m + i) = m4;
       *reinterpret_cast<float4 *>(v + i) = v4;
-      o[q].x = (__bf16)w4.x; o[q].y = (__bf16)w4.y; o[q].z = (__bf16)w4.z; o[q].w = (__bf16)w4.w;
-      if (wc) *reinterpret_cast<bf16x4 *>(wc + (int64_t)(k0 + r + q) * ldc + n0 + c4) = o[q];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-      const bf16x2 pr = {o[0][u], o[1][u]};            // rows r (low half), r + 1 (high half)
-      sT[c4 + u][r >> 1] = __builtin_bit_cast(uint32_t, pr);
+      res[p][q][0] = w4.x; res[p][q][1] = w4.y; res[p][q][2] = w4.z; res[p][q][3] = w4.w;
     }
   }
-  if (wt) {                                          // (uniform)
-    __syncthreads();
-    // transposed tile: row n of W^T holds 64 consecutive k = 128 B; 8 threads x 16 B per row
-    const int sr = threadIdx.x >> 3, seg = (threadIdx.x & 7) * 4;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int row = q * 32 + sr;
-      uint4 o;
-      o.x = sT[row][seg]; o.y = sT[row][seg + 1]; o.z = sT[row][seg + 2]; o.w = sT[row][seg + 3];
-      *reinterpret_cast<uint4 *>(wt + (int64_t)(n0 + row) * ldt + k0 + seg * 2) = o;
+  for (int pl = 0; pl < PLANES; ++pl) {
+    if (pl && wt) __syncthreads();                     // the previous plane's tile has been read out
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = p * 32 + 2 * tr;
+      bf16x4 o[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          o[q][u] = (__bf16)res[p][q][u];
+          if (PLANES > 1) res[p][q][u] -= (float)o[q][u];
+        }
+        if (wc) *reinterpret_cast<bf16x4 *>(wc + (int64_t)(k0 + r + q) * ldc + pl * plane_c + n0 + c4) = o[q];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+        const bf16x2 pr = {o[0][u], o[1][u]};            // rows r (low half), r + 1 (high half)
+        sT[c4 + u][r >> 1] = __builtin_bit_cast(uint32_t, pr);
+      }
+    }
+    if (wt) {                                          // (uniform)
+      __syncthreads();
+      // transposed tile: row n of W^T holds 64 consecutive k = 128 B; 8 threads x 16 B per row
+      const int sr = threadIdx.x >> 3, seg = (threadIdx.x & 7) * 4;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int row = q * 32 + sr;
+        uint4 o;
+        o.x = sT[row][seg]; o.y = sT[row][seg + 1]; o.z = sT[row][seg + 2]; o.w = sT[row][seg + 3];
+        *reinterpret_cast<uint4 *>(wt + (int64_t)(n0 + row) * ldt + pl * plane_t + k0 + seg * 2) = o;
+      }
     }
   }
   if (bw) {                                          // the bias vector: element i of the first ceil(bn / 256) blocks
@@ -400,12 +421,12 @@ extern "C" int cdml_adam_step(float *w, const float *g, float *m, float *v, int6
   return check_launch("adam_step");
 }
 
-extern "C" int cdml_adam_matrix_bf16(float *w, const float *g, float *m, float *v, int K, int N, float lr,
-                                     const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
-                                     uint64_t *t_dev, uint16_t *wt_bf16, int64_t ldt, uint16_t *wc_bf16,
-                                     int64_t ldc, float *bias_w, const float *bias_g, float *bias_m,
-                                     float *bias_v, int bias_n, int advance_step, uint32_t *tickets,
-                                     cdml_stream_t stream) {
+static int adam_matrix_impl(float *w, const float *g, float *m, float *v, int K, int N, float lr,
+                            const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
+                            uint64_t *t_dev, uint16_t *wt_bf16, int64_t ldt, uint16_t *wc_bf16,
+                            int64_t ldc, float *bias_w, const float *bias_g, float *bias_m,
+                            float *bias_v, int bias_n, int advance_step, uint32_t *tickets,
+                            int planes, int64_t plane_t, int64_t plane_c, cdml_stream_t stream) {
   CDML_REQUIRE(w && g && m && v && K > 0 && N > 0, CDML_E_BADARG, "adam_matrix_bf16: bad argument");
   CDML_REQUIRE(!bias_w || (bias_g && bias_m && bias_v && bias_n > 0), CDML_E_BADARG,
                "adam_matrix_bf16: the bias vector needs its gradient and both moments");
@@ -418,11 +439,44 @@ extern "C" int cdml_adam_matrix_bf16(float *w, const float *g, float *m, float *
                    (!wt_bf16 || (aligned16(wt_bf16) && (ldt & 7) == 0 && ldt >= K)) &&
                    (!wc_bf16 || (aligned16(wc_bf16) && (ldc & 3) == 0 && ldc >= N)),
                CDML_E_ALIGN, "adam_matrix_bf16: 16-B aligned buffers, ldt a multiple of 8 (>= K), ldc of 4 (>= N)");
-  hipLaunchKernelGGL(k_adam_matrix_bf16, dim3((K / kAT) * (N / kAT)), dim3(kThreads), 0, (hipStream_t)stream, w, g,
-                     m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, reinterpret_cast<__bf16 *>(wt_bf16), ldt,
-                     reinterpret_cast<__bf16 *>(wc_bf16), ldc, bias_w, bias_g, bias_m, bias_v, bias_w ? bias_n : 0,
-                     advance_step, tickets);
+  if (planes == 3) {
+    CDML_REQUIRE((!wt_bf16 || (!(plane_t & 7) && plane_t >= K && ldt >= 2 * plane_t + K)) &&
+                     (!wc_bf16 || (!(plane_c & 3) && plane_c >= N && ldc >= 2 * plane_c + N)),
+                 CDML_E_ALIGN, "adam_matrix_planes: plane strides (W^T: multiple of 8, >= K; W: multiple of 4, >= N) and "
+                 "leading dimensions >= 2 planes + the matrix width");
+    hipLaunchKernelGGL(k_adam_matrix_bf16<3>, dim3((K / kAT) * (N / kAT)), dim3(kThreads), 0, (hipStream_t)stream, w, g,
+                       m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, reinterpret_cast<__bf16 *>(wt_bf16), ldt,
+                       reinterpret_cast<__bf16 *>(wc_bf16), ldc, bias_w, bias_g, bias_m, bias_v, bias_w ? bias_n : 0,
+                       advance_step, tickets, plane_t, plane_c);
+  } else {
+    hipLaunchKernelGGL(k_adam_matrix_bf16<1>, dim3((K / kAT) * (N / kAT)), dim3(kThreads), 0, (hipStream_t)stream, w, g,
+                       m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, reinterpret_cast<__bf16 *>(wt_bf16), ldt,
+                       reinterpret_cast<__bf16 *>(wc_bf16), ldc, bias_w, bias_g, bias_m, bias_v, bias_w ? bias_n : 0,
+                       advance_step, tickets, (int64_t)0, (int64_t)0);
+  }
   return check_launch("adam_matrix_bf16");
+}
+
+extern "C" int cdml_adam_matrix_bf16(float *w, const float *g, float *m, float *v, int K, int N, float lr,
+                                     const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
+                                     uint64_t *t_dev, uint16_t *wt_bf16, int64_t ldt, uint16_t *wc_bf16,
+                                     int64_t ldc, float *bias_w, const float *bias_g, float *bias_m,
+                                     float *bias_v, int bias_n, int advance_step, uint32_t *tickets,
+                                     cdml_stream_t stream) {
+  return adam_matrix_impl(w, g, m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, wt_bf16, ldt, wc_bf16, ldc, bias_w,
+                          bias_g, bias_m, bias_v, bias_n, advance_step, tickets, 1, 0, 0, stream);
+}
+
+// The same update writing the copies as the three bf16 planes hi | mid | lo of the new weights (precision "f32x3":
+// wt = planes of W^T, [N][hi K | mid K | lo K] with plane stride plane_t; wc = planes of W, [K][hi N | ...], plane_c).
+extern "C" int cdml_adam_matrix_planes(float *w, const float *g, float *m, float *v, int K, int N, float lr,
+                                       const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
+                                       uint64_t *t_dev, uint16_t *wt_planes, int64_t ldt, int64_t plane_t,
+                                       uint16_t *wc_planes, int64_t ldc, int64_t plane_c, float *bias_w,
+                                       const float *bias_g, float *bias_m, float *bias_v, int bias_n,
+                                       int advance_step, uint32_t *tickets, cdml_stream_t stream) {
+  return adam_matrix_impl(w, g, m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, wt_planes, ldt, wc_planes, ldc, bias_w,
+                          bias_g, bias_m, bias_v, bias_n, advance_step, tickets, 3, plane_t, plane_c, stream);
 }
 
 extern "C" size_t cdml_lars_scratch_floats(void) { return 2 + 2 * (size_t)kLarsBlocks; }

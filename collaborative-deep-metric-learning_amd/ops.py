@@ -481,7 +481,7 @@ def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, 
 
 
 def adam_matrix_bf16(W, g, m, v, lr, t, wt=None, wc=None, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, t_dev=None,
-                     bias=None, advance_tickets=None):
+                     bias=None, advance_tickets=None, plane_t=0, plane_c=0):
     """Adam on the contiguous weight matrix W [K, N] (g, m, v alike) that also writes the bf16 operand
     copies: wt = W^T as bf16 [N, >=K], wc = W as bf16 [K, >=N] (either may be None).  ``bias`` =
     (b, gb, mb, vb): the layer's bias vector updated in the same launch; ``advance_tickets``
@@ -494,13 +494,20 @@ def adam_matrix_bf16(W, g, m, v, lr, t, wt=None, wc=None, beta1=0.9, beta2=0.999
             raise ValueError("%s must be contiguous fp32 with W's size" % name)
     tp, tld = (C.c_void_p(0), 0) if wt is None else _mat16(wt)
     cp, cld = (C.c_void_p(0), 0) if wc is None else _mat16(wc)
-    if wt is not None and (wt.shape[0] < N or wt.shape[1] < K):
-        raise ValueError("wt must be at least [N, K]")
-    if wc is not None and (wc.shape[0] < K or wc.shape[1] < N):
-        raise ValueError("wc must be at least [K, N]")
+    planes = bool(plane_t or plane_c)                # the copies as three bf16 planes (precision f32x3)
+    if wt is not None and (wt.shape[0] < N or wt.shape[1] < (2 * plane_t + K if planes else K)):
+        raise ValueError("wt must be at least [N, K] (planes: [N, 2 plane_t + K])")
+    if wc is not None and (wc.shape[0] < K or wc.shape[1] < (2 * plane_c + N if planes else N)):
+        raise ValueError("wc must be at least [K, N] (planes: [K, 2 plane_c + N])")
     b = bias if bias is not None else (None, None, None, None)
     if bias is not None and any(x.numel() != b[0].numel() or not x.is_contiguous() for x in b):
         raise ValueError("bias, its gradient and its moments must be contiguous vectors of one size")
+    if planes:
+        call("cdml_adam_matrix_planes", _p(W), _p(g), _p(m), _p(v), K, N, lr, _p(lr_dev), beta1, beta2, eps,
+             0 if t is None else t, _p(t_dev, torch.int64), tp, tld, plane_t, cp, cld, plane_c, _p(b[0]), _p(b[1]),
+             _p(b[2]), _p(b[3]), 0 if bias is None else b[0].numel(), 0 if advance_tickets is None else 1,
+             _p(advance_tickets, torch.int32), _stream())
+        return
     call("cdml_adam_matrix_bf16", _p(W), _p(g), _p(m), _p(v), K, N, lr, _p(lr_dev), beta1, beta2, eps,
          0 if t is None else t, _p(t_dev, torch.int64), tp, tld, cp, cld, _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]),
          0 if bias is None else b[0].numel(), 0 if advance_tickets is None else 1, _p(advance_tickets, torch.int32),

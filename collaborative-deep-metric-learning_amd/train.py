@@ -395,7 +395,20 @@ class TrainStep:
             for i, (off, n) in enumerate(p.segments()):    # W1, b1, W2, b2: weights carry the regulariser
                 ops.grad_prepare(p.grad[off:off + n], p.flat[off:off + n], self.reg_scale if i % 2 == 0 else 0.0,
                                  self.clip_gradient_norm, self.lars_scratch, self.grad_norms[i])
-        if self.optimizer == "adam" and self.bf16:
+        if self.optimizer == "adam" and self.x3:
+            # split-fp32 precision: as on the config-4 path two launches, each weight matrix with its bias vector;
+            # the update writes the plane copies the GEMMs read (W1^T; W2^T and W2)
+            L, o, ws = self.layout, self.layout.offsets, self.ws
+            mat = lambda t, i, r, c: t[o[i]:o[i] + r * c].view(r, c)
+            kw = dict(lr_dev=self.lr_dev, t_dev=self.step_dev)
+            b1, b2 = slice(o[1], o[1] + L.Hp), slice(o[3], o[3] + L.Dp)
+            vec = lambda sl: (p.flat[sl], p.grad[sl], self.m[sl], self.v[sl])
+            ops.adam_matrix_bf16(p.W1, mat(p.grad, 0, L.Fp, L.Hp), mat(self.m, 0, L.Fp, L.Hp),
+                                 mat(self.v, 0, L.Fp, L.Hp), 0.0, 1, wt=ws.W1T, plane_t=L.Fp, bias=vec(b1), **kw)
+            ops.adam_matrix_bf16(p.W2, mat(p.grad, 2, L.Hp, L.Dp), mat(self.m, 2, L.Hp, L.Dp),
+                                 mat(self.v, 2, L.Hp, L.Dp), 0.0, 1, wt=ws.W2T, plane_t=L.Hp, wc=ws.W2, plane_c=L.Dp,
+                                 bias=vec(b2), advance_tickets=self.adam_tickets, **kw)
+        elif self.optimizer == "adam" and self.bf16:
             # config-4 precision: two launches -- each weight matrix with its bias vector; the update
             # also writes the bf16 operand copies the GEMMs read (no separate transposes / cast), and
             # the last block of the second launch advances the step counter
@@ -422,7 +435,7 @@ class TrainStep:
                            step_dev=self.step_dev, tickets=self.adam_tickets)
         if self.bf16 and self.optimizer != "adam":
             engine_bf16.refresh_weights(p, self.ws)
-        if self.x3:
+        if self.x3 and self.optimizer != "adam":
             engine_x3.refresh_weights(p, self.ws)
         if self.optimizer == "momentum":
             ops.step_advance(self.step_dev)

@@ -400,6 +400,14 @@ int cdml_sample_gather_x3(int mode, const int32_t *pairs, int64_t n_pairs, uint6
                           int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
                           uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
                           int64_t idx_step_stride, int32_t *oob_flag, cdml_stream_t stream);
+/* cdml_adam_matrix_bf16 (train.py:146) writing the operand copies as planes: wt_planes = W^T as
+ * [N][hi K | mid K | lo K] (plane stride plane_t), wc_planes = W as [K][hi N | mid N | lo N] (plane_c). */
+int cdml_adam_matrix_planes(float *w, const float *g, float *m, float *v, int K, int N, float lr,
+                            const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
+                            uint64_t *t_dev, uint16_t *wt_planes, int64_t ldt, int64_t plane_t,
+                            uint16_t *wc_planes, int64_t ldc, int64_t plane_c, float *bias_w,
+                            const float *bias_g, float *bias_m, float *bias_v, int bias_n,
+                            int advance_step, uint32_t *tickets, cdml_stream_t stream);
 size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int products);
 int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
                         int64_t ldb, int64_t plane_b, int M, int N, int K, int products, void *C,
