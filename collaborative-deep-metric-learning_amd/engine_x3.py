@@ -15,14 +15,20 @@ models.py:59-61 (forward), train.py:141 (its autodiff).
 import torch
 
 from . import ops
-from .engine_bf16 import layout_bf16
+from .engine import TowerLayout, round_up
 
 
 def layout_x3(feature_size, hidden=5000, output_size=256):
-    L = layout_bf16(feature_size, hidden, output_size)
-    if L.Fp % 256 or L.Hp % 256 or L.Dp % 256:
-        raise ValueError("precision 'f32x3' needs padded layer widths that are multiples of 256 "
-                         "(got F %d, H %d, D %d)" % (L.Fp, L.Hp, L.Dp))
+    """TowerLayout whose padded widths are multiples of 256 (the plane GEMMs' tile; 1536 / 5120 / 256 at the
+    production sizes, as on the other paths).  Padding rows and columns of the weights are zero and stay zero."""
+    L = TowerLayout(feature_size, hidden, output_size)
+    L.Fp, L.Hp, L.Dp = round_up(L.F, 256), round_up(L.H, 256), round_up(L.D, 256)
+    L.sizes = (L.Fp * L.Hp, L.Hp, L.Hp * L.Dp, L.Dp)
+    off = [0]
+    for n in L.sizes[:-1]:
+        off.append(off[-1] + n)
+    L.offsets = tuple(off)
+    L.numel = int(sum(L.sizes))
     return L
 
 

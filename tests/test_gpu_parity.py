@@ -786,11 +786,12 @@ def test_train_steps_config0(cd, mode, optimizer, precision):
     assert int(ts.step_dev.item()) == 3
 
 
-def test_graph_replay_equals_eager(cd):
-    N, F, B = 4000, 200, 64
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+def test_graph_replay_equals_eager(cd, precision):
+    N, F, B = 4000, 200, 64 if precision == "f32" else 128
     table = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev)
     pairs = dt(osynth.cowatch_pairs(N, 500, 0), cd.dev, torch.int32)
-    kw = dict(hidden_size=300, output_size=64, mode="uniform", device=cd.dev)
+    kw = dict(hidden_size=300, output_size=64, mode="uniform", device=cd.dev, precision=precision)
     a = cd.train.TrainStep(table, pairs, B, use_graph=False, **kw)
     b = cd.train.TrainStep(table, pairs, B, use_graph=True, **kw)
     for _ in range(4):
