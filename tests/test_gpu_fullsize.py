@@ -474,14 +474,16 @@ def test_gradients_well_conditioned_production_shape(cd, mode, precision, bar):
     print("worst relative L2 error per tensor (%s, %s):" % (precision, mode), worst)
 
 
-def test_resume_bf16_is_bit_exact(cd, tmp_path):
-    """load_state_dict must refresh the bf16 operand copies of the weights --
+@pytest.mark.parametrize("precision", ["bf16", "f32x3"])
+def test_resume_bf16_is_bit_exact(cd, tmp_path, precision):
+    """load_state_dict must refresh the bf16 operand copies of the weights (f32x3: their planes) --
     5 steps + save/load into a fresh TrainStep + 5 steps == 10 straight steps."""
     N = 4000
-    table = cd.ebf.FeatureTableF16.synthetic(N, 200, 0, cd.dev)
+    Table = cd.ebf.FeatureTableF16 if precision == "bf16" else cd.engine.FeatureTable
+    table = Table.synthetic(N, 200, 0, cd.dev)
     pairs = torch.as_tensor(osynth.cowatch_pairs(N, 500, 0)).to(cd.dev)
-    mk = lambda: cd.train.TrainStep(table, pairs, 64, hidden_size=256, output_size=128, mode="uniform",
-                                    precision="bf16", device=cd.dev)
+    mk = lambda: cd.train.TrainStep(table, pairs, 128, hidden_size=256, output_size=128, mode="uniform",
+                                    precision=precision, device=cd.dev)
     a, b = mk(), mk()
     for _ in range(10):
         a.step()
