@@ -540,6 +540,14 @@ class TrainStep:
         """Record ``fn`` (default: the whole step) into a hipGraph.  ``origin``: the stream the capture
         starts on (default: a fresh one) -- RCCL's communicator stream is then one fork from it."""
         torch.cuda.synchronize(self.device)
+        if self.grad_sync is not None or self.exchange is not None:
+            # torch.distributed's RCCL watchdog thread polls the end events of the collectives issued EAGERLY so
+            # far (every 100 ms) until it has seen them complete.  If a capture that involves the same communicator
+            # starts while such a work is still on its list, the poll fails with hipErrorCapturedEvent ("event last
+            # recorded in a capturing stream") and the watchdog ends the process -- seen once in a few runs of the
+            # capture tests on torch 2.10 / RCCL 2.26.  The device is idle here (synchronize above): give the
+            # watchdog two of its periods to retire what the eager steps left.  Captures happen a few times per run.
+            time.sleep(0.25)
         side = torch.cuda.Stream(self.device) if origin is None else origin
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):

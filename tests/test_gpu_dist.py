@@ -342,7 +342,7 @@ def _run_worker(target, timeout):
 
 
 def test_data_parallel_step_replays_from_hipgraph_over_rccl(gpu):
-    msg = _run_worker(_nccl_graph_worker, 300)
+    msg = _run_worker(_nccl_graph_worker, 120)
     assert msg == "ok", msg
 
 
