@@ -33,7 +33,7 @@ def layout_x3(feature_size, hidden=5000, output_size=256):
 
 
 class TowerWorkspaceX3:
-    def __init__(self, layout, n_rows, device, products=6, planes_in=True):
+    def __init__(self, layout, n_rows, device, products=6, planes_in=True, backward=True):
         """planes_in: ``x_hat`` IS the plane buffer (the fused sampler + gather writes planes); False: ``x_hat`` is
         fp32 (rows arriving through the exchange) and the forward pass splits it."""
         L, R = layout, int(n_rows)
@@ -46,13 +46,16 @@ class TowerWorkspaceX3:
         f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
         self.x3 = bf(R, 3 * L.Fp)
         self.x_hat = self.x3 if planes_in else f32(R, L.Fp)    # the gather's output (l2-normalised rows)
-        self.h1, self.dz1 = bf(R, 3 * L.Hp), bf(R, 3 * L.Hp)
-        self.z, self.e, self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp), f32(R, L.Dp)
-        self.dz2_3 = bf(R, 3 * L.Dp)
+        self.h1 = bf(R, 3 * L.Hp)
+        self.z, self.e = f32(R, L.Dp), f32(R, L.Dp)
         self.W1T, self.W2T, self.W2 = bf(L.Hp, 3 * L.Fp), bf(L.Dp, 3 * L.Hp), bf(L.Hp, 3 * L.Dp)
         q = products
-        nb = max(ops.gemm_bf16x3_workspace(False, R, L.Dp, L.Hp, q), ops.gemm_bf16x3_workspace(True, L.Fp, L.Hp, R, q),
-                 ops.gemm_bf16x3_workspace(True, L.Hp, L.Dp, R, q), 16)
+        nb = max(ops.gemm_bf16x3_workspace(False, R, L.Dp, L.Hp, q), 16)
+        if backward:                                       # (catalogue inference: forward buffers only)
+            self.dz1 = bf(R, 3 * L.Hp)
+            self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp)
+            self.dz2_3 = bf(R, 3 * L.Dp)
+            nb = max(nb, ops.gemm_bf16x3_workspace(True, L.Fp, L.Hp, R, q), ops.gemm_bf16x3_workspace(True, L.Hp, L.Dp, R, q))
         self.gemm_ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
         self.tail_done = False
 

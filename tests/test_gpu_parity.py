@@ -1074,7 +1074,7 @@ def test_prediction_run_features(cd, tmp_path):
         predict.Prediction(ckpt=str(tmp_path / "missing.pt"))
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "f32x3", "bf16"])
 def test_prediction_embed_table_production_shape(cd, precision):
     """Catalogue inference (predict.py:71-96) with the result left on the device, at the production
     width: every row of an HBM-resident catalogue in ragged chunks (last one short), fp32 against the
@@ -1087,20 +1087,21 @@ def test_prediction_embed_table_production_shape(cd, precision):
         table = engine_bf16.FeatureTableF16.from_numpy(feats, cd.dev)
         layout = engine_bf16.layout_bf16(F, H, D)
     else:
+        from cdml_amd import engine_x3
         feats = feats.astype(np.float32)
         table = cd.engine.FeatureTable.from_numpy(feats, cd.dev)
-        layout = cd.engine.TowerLayout(F, H, D)
+        layout = (engine_x3.layout_x3 if precision == "f32x3" else cd.engine.TowerLayout)(F, H, D)
     params = cd.engine.VNetParams(layout, cd.dev, seed=2)
     pred = predict.Prediction(params=params, precision=precision)
     out = pred.embed_table(table, chunk)
     assert out.is_cuda and out.shape == (N, D) and out.dtype == torch.float32
     W = [t.cpu().numpy().astype(np.float64) for t in params.unpadded()]
     want = otower.vnet_forward(feats.astype(np.float64), *W, dtype=np.float64)["l2_norm"]
-    np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL if precision == "f32" else 5e-3)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL if precision != "bf16" else 5e-3)
     np.testing.assert_allclose(out.norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)
     again = torch.empty_like(out)
     pred.embed_table(table, 777, out=again)                                 # other chunking, caller's buffer
-    np.testing.assert_allclose(again.cpu().numpy(), out.cpu().numpy(), atol=2e-6 if precision == "f32" else 1e-3)
+    np.testing.assert_allclose(again.cpu().numpy(), out.cpu().numpy(), atol=2e-6 if precision != "bf16" else 1e-3)
     np.testing.assert_array_equal(pred.run_features(table, chunk), out.cpu().numpy())        # the ndarray API on top
     if precision == "bf16":
         with pytest.raises(ValueError):
