@@ -139,3 +139,39 @@ def test_sample_gather_planes_equal_split_of_the_fp32_gather(mode):
     assert torch.equal(i32, i3) and torch.equal(s32, s3)
     for k in range(K):
         assert torch.equal(x3[k], _planes(x32[k], Fp))
+
+
+@pytest.mark.parametrize("mode,optimizer", [("uniform", "adam"), ("inbatch", "adam"), ("semihard", "adam"),
+                                            ("uniform", "lars"), ("inbatch", "momentum")])
+def test_train_step_matches_the_fp32_mfma_step(mode, optimizer):
+    """TrainStep(precision="f32x3") against TrainStep(precision="f32") from the same seeds: same triplets, embeddings
+    and loss of the first step within 1e-5 (both are within 1e-5 of fp64: test_train_steps_config0), every sampler mode
+    and optimizer (semi-hard mining picks its negatives from the embeddings: the same ones)."""
+    dev = _dev()
+    from cdml_amd import engine, train
+    N, F, B = 6000, 500, 128
+    table = engine.FeatureTable.synthetic(N, F, 0, dev)
+    rng = np.random.RandomState(1)
+    pairs = rng.randint(0, N, size=(3000, 2)).astype(np.int32)
+    pairs = torch.from_numpy(pairs[pairs[:, 0] != pairs[:, 1]]).to(dev)
+    lr = {"adam": 0.01, "lars": 1.0, "momentum": 0.01}[optimizer]
+    mk = lambda prec: train.TrainStep(table, pairs, B, hidden_size=700, output_size=256, mode=mode, optimizer=optimizer,
+                                      base_learning_rate=lr, device=dev, precision=prec)
+    a, b = mk("f32"), mk("f32x3")
+    a.step(); b.step()
+    torch.cuda.synchronize()
+    D = 256
+    assert torch.equal(a.idx, b.idx)
+    assert (a.ws.e[:, :D] - b.ws.e[:, :D]).abs().max().item() < 1e-5
+    assert abs(a.loss() - b.loss()) < 1e-5
+    if mode == "semihard":
+        assert torch.equal(a.neg_row, b.neg_row)
+    for _ in range(3):                                   # keeps stepping: the plane copies follow the optimizer
+        a.step(); b.step()
+    assert abs(a.loss() - b.loss()) < 2e-3
+    # the planes the GEMMs read ARE the master weights
+    L = b.layout
+    w1t = b.ws.W1T[:, :L.Fp].float() + b.ws.W1T[:, L.Fp:2 * L.Fp].float() + b.ws.W1T[:, 2 * L.Fp:].float()
+    assert torch.equal(w1t, b.params.W1.t())
+    w2 = b.ws.W2[:, :L.Dp].float() + b.ws.W2[:, L.Dp:2 * L.Dp].float() + b.ws.W2[:, 2 * L.Dp:].float()
+    assert torch.equal(w2, b.params.W2)
