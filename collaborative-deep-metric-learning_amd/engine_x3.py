@@ -90,24 +90,40 @@ def tower_forward(p, ws, normalize=True):
     return ws.e
 
 
-def tower_backward(p, ws, after_w1=None):
+def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
     """ws.dz2 (from the fused tail) or ws.de -> p.grad (fp32).  train.py:141; no dX.  The second layer's weight
     gradient goes first on one GPU (it and the data gradient both stream h1); with ``after_w1`` (the
-    data-parallel all-reduce of [dW1|db1]) the first layer's goes first and the hook fires right after it."""
+    data-parallel all-reduce of [dW1|db1]) the first layer's goes first and the hook fires right after it; with
+    ``w1_chunks`` > 1 dW1 comes in row blocks of W1 and ``after_w1_chunk(lo, hi)`` fires after each (flat-gradient
+    ranges; the last one ends after db1), as in engine.tower_backward."""
     L, R, q = p.layout, ws.R, ws.products
     if not ws.tail_done:
         ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
     ops.split_f32_bf16x3(ws.dz2, ws.dz2_3, L.Dp)
     w2 = lambda: ops.gemm_bf16x3_tn(ws.h1, L.Hp, ws.dz2_3, L.Dp, p.gW2, L.Hp, L.Dp, R, products=q,
                                     workspace=ws.gemm_ws, colsum=p.gb2)
-    if after_w1 is None:
+    single = after_w1 is None and after_w1_chunk is None
+    if single:
         w2()
     # dz1 = (dz2 . W2^T) * lrelu'(h1), written as planes; the sign comes from h1's hi plane
     ops.gemm_bf16x3_nt(ops.BE_MASK_X3, ws.dz2_3, L.Dp, ws.W2, L.Dp, ws.dz1, R, L.Hp, L.Dp, products=q, plane_c=L.Hp,
                        aux=ws.h1)
-    ops.gemm_bf16x3_tn(ws.x3, L.Fp, ws.dz1, L.Hp, p.gW1, L.Fp, L.Hp, R, products=q, workspace=ws.gemm_ws,
-                       colsum=p.gb1)
+    rows = L.Fp // w1_chunks if w1_chunks > 1 else 0
+    if after_w1_chunk is not None and w1_chunks > 1 and rows * w1_chunks == L.Fp and rows % 256 == 0:
+        for c in range(w1_chunks):
+            lo, hi = c * rows, (c + 1) * rows
+            last = c == w1_chunks - 1
+            # columns lo .. hi of every plane of x_hat: the same plane stride, the base moved by lo
+            ops.gemm_bf16x3_tn(ws.x3[:, lo:], L.Fp, ws.dz1, L.Hp, p.gW1[lo:hi], rows, L.Hp, R, products=q,
+                               workspace=ws.gemm_ws, colsum=p.gb1 if last else None)
+            after_w1_chunk(lo * L.Hp, hi * L.Hp + (L.Hp if last else 0))
+    else:
+        ops.gemm_bf16x3_tn(ws.x3, L.Fp, ws.dz1, L.Hp, p.gW1, L.Fp, L.Hp, R, products=q, workspace=ws.gemm_ws,
+                           colsum=p.gb1)
+        if after_w1_chunk is not None:
+            after_w1_chunk(0, L.Fp * L.Hp + L.Hp)
     if after_w1 is not None:
         after_w1()
+    if not single:
         w2()
     return p.grad

@@ -465,7 +465,7 @@ class TrainStep:
             if b is not None:
                 self.prefetch.wait_ready(1 - b)
             self.grad_sync.finish([self.grad_sync.start(self.params.grad, 0, self.layout.numel)])
-        elif self._grad_sync_mode == "two" or self.x3:   # (the split-fp32 engine has no row-block form of dW1)
+        elif self._grad_sync_mode == "two":
             if b is not None:
                 self.prefetch.wait_ready(1 - b)
             n1 = self.layout.offsets[2]
@@ -482,7 +482,7 @@ class TrainStep:
             # GEMM -- and [dW2|db2] right after its GEMM; the optimizer waits for all of them
             n1 = self.layout.offsets[2]
             handles = []
-            (engine_bf16 if self.bf16 else engine).tower_backward(
+            (engine_x3 if self.x3 else engine_bf16 if self.bf16 else engine).tower_backward(
                 self.params, self.ws, w1_chunks=2,
                 after_w1_chunk=lambda lo, hi: handles.append(self.grad_sync.start(self.params.grad, lo, hi)))
             handles.append(self.grad_sync.start(self.params.grad, n1, self.layout.numel))

@@ -24,6 +24,7 @@ CFG_BF16 = dict(CFG, B=64, precision="bf16")
 CFG_TABLE = dict(CFG, train_table=True)
 # the fp32 tower on the bf16 MFMA (three exact planes per operand): rows cross the wire in fp32 and are split on arrival
 CFG_X3 = dict(CFG, F=250, H=500, D=256, B=128, precision="f32x3")
+CFG_X3_BUCKETS = dict(CFG_X3, F=500)              # F padded to 512: dW1 in two 256-row blocks, an all-reduce after each
 # four ranks on the card: uneven shards (3000 = 4 x 750 here, 3001 rows -> 751/751/751/748), every
 # pair of ranks exchanging rows, the 1/4 gradient average
 CFG_W4 = dict(CFG, world=4, n_rows=3001, B=16)
@@ -87,9 +88,9 @@ def _worker(rank, world, port, q, CFG=CFG):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_X3, CFG_TABLE, CFG_W4, CFG_C3, CFG_C4, CFG_C3_W4, CFG_C3_TWO, CFG_C3_SINGLE,
+@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_X3, CFG_X3_BUCKETS, CFG_TABLE, CFG_W4, CFG_C3, CFG_C4, CFG_C3_W4, CFG_C3_TWO, CFG_C3_SINGLE,
                                  CFG_C4_SINGLE],
-                         ids=["f32", "bf16", "f32x3", "trainable-table", "4-ranks", "config3-full-size", "config4-full-size",
+                         ids=["f32", "bf16", "f32x3", "f32x3-bucketed", "trainable-table", "4-ranks", "config3-full-size", "config4-full-size",
                               "config3-full-size-4-ranks", "config3-full-size-sync-two", "config3-full-size-sync-single",
                               "config4-full-size-sync-single"])
 def test_two_rank_step_equals_single_rank(gpu, CFG):
