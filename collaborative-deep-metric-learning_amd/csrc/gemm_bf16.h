@@ -36,6 +36,7 @@ struct BArgs {
   // as (A, B) = (hi,hi) (hi,mid) (mid,hi) (hi,lo) (lo,hi) (mid,mid).  Plane p of A starts x3_plane_a elements
   // (k-contiguous form: along k; k-strided form: along the columns) after plane p - 1; B likewise.
   int x3_tpp;
+  int x3_products;         // K-major walk (> 0): K-tile v = product v % x3_products of K-tile v / x3_products (0: product-major)
   int64_t x3_plane_a, x3_plane_b, x3_plane_c;
 };
 

@@ -148,13 +148,24 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 
   // img 0 = A, 1 = B; hh = half; tile beyond the split's range -> every lane out of range (zeros)
   // X3: K-tile v of the whole walk = K-tile v % tpp of plane product v / tpp
-  const float x3_inv = X3 ? 1.0f / (float)g.x3_tpp : 0.f;
+  // (K-major, x3_products > 0: K-tile v = product v % P of K-tile v / P -- the three reads of an operand's hi
+  // plane K-tile, two of its mid plane, come within six steps of each other, out of L2 instead of HBM)
+  const bool x3_kmajor = X3 && g.x3_products > 0;
+  const float x3_inv = X3 ? 1.0f / (float)(x3_kmajor ? g.x3_products : g.x3_tpp) : 0.f;
   const int x3_t0 = k_begin / kTileK;
-  auto x3_segment = [&](int v) { return __builtin_amdgcn_readfirstlane((int)(((float)v + 0.5f) * x3_inv)); };
+  auto x3_div = [&](int v) { return __builtin_amdgcn_readfirstlane((int)(((float)v + 0.5f) * x3_inv)); };
+  // product (0..5) and K-tile within the plane of walk position v
+  auto x3_where = [&](int v, int &sgm, int &w) {
+    const int qd = x3_div(v);
+    if (x3_kmajor) { w = qd; sgm = v - qd * g.x3_products; }
+    else { sgm = qd; w = v - qd * g.x3_tpp; }
+  };
+  auto x3_segment = [&](int v) { int sgm, w; x3_where(v, sgm, w); return sgm; };
   auto stage = [&](int img, int hh, int tile, int buf) {
     int64_t k_elems;
     if constexpr (X3) {
-      const int v = x3_t0 + tile, sgm = x3_segment(v), w = v - sgm * g.x3_tpp;
+      int sgm, w;
+      x3_where(x3_t0 + tile, sgm, w);
       const int plane = ((img == 0 ? 0x120100 : 0x102010) >> (4 * sgm)) & 3;
       k_elems = (int64_t)w * kTileK * (TN ? (img == 0 ? g.lda : g.ldb) : 1) + plane * (img == 0 ? g.x3_plane_a : g.x3_plane_b);
     } else {

@@ -16,6 +16,7 @@
 // (BArgs::x3_*); epilogues 6 / 7 write their result as planes again, so the chain FC1 -> FC2 / dH1 -> dW1 never
 // holds an activation in fp32.  Replaces the same reference lines as gemm_f32.hip (models.py:59-60, train.py:141).
 #include "gemm_bf16.h"
+#include <stdlib.h>
 
 namespace cdml {
 namespace {
@@ -81,6 +82,12 @@ k_split3_transpose(const float *__restrict__ src, int64_t lds_, int rows, int co
 int grid1d(int64_t n) {
   const int64_t b = (n + kThreads - 1) / kThreads;
   return (int)(b < 1 ? 1 : (b > 65535 * 16 ? 65535 * 16 : b));
+}
+
+// walk order of the plane products: K-major unless CDML_X3_ORDER=product (A/B runs; read per call)
+bool x3_kmajor() {
+  const char *e = getenv("CDML_X3_ORDER");
+  return !(e && e[0] == 'p');
 }
 
 // split-K for the k-contiguous forms with too few tiles for the chip (fp32 slab output only)
@@ -199,6 +206,7 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   g.aux = reinterpret_cast<const bf16 *>(aux); g.ldaux = ldaux;
   g.M = M; g.N = N;
   g.x3_tpp = K / 64; g.x3_plane_a = plane_a; g.x3_plane_b = plane_b; g.x3_plane_c = plane_c;
+  g.x3_products = x3_kmajor() ? products : 0;
   const int ktiles = products * g.x3_tpp;
   CDML_REQUIRE(ktiles % 2 == 0, CDML_E_UNSUPPORTED, "gemm_bf16x3_nt: products * K / 64 must be even");
   g.K = ktiles * 64; g.k_per_split = g.K;
@@ -241,6 +249,7 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
   g.B = reinterpret_cast<const bf16 *>(B); g.ldb = ldb;
   g.M = M; g.N = N;
   g.x3_tpp = K / 64; g.x3_plane_a = plane_a; g.x3_plane_b = plane_b;
+  g.x3_products = x3_kmajor() ? products : 0;
   const int ktiles = products * g.x3_tpp;
   g.K = ktiles * 64;
   g.tiles_m = M / 256; g.tiles_n = N / 256;
