@@ -679,6 +679,16 @@ def rec_f32x3(dev, args, n_s, n_w, table, pairs, B, mode):
            "dtype": "f32 values as 3 exact bf16 planes, 6 plane products on the bf16 MFMA, f32 accumulate",
            "loss": round(b.loss(), 6), "against_native_f32": check}
     out.update(gemm_records(kt, b.R, False, sampled, how, False, x3_products=6))
+    del b
+    torch.cuda.empty_cache()
+    # the reference's own recipe (train.py:354-364: batch 1024, uniform negatives, LARS lr 1.0) on this path
+    rp = torch.from_numpy(synth_pairs(table.n_rows, 300000, seed=0)).to(dev)
+    r = train.TrainStep(table, rp, 1024, output_size=D, hidden_size=H, margin=MARGIN, mode="uniform", optimizer="lars",
+                        base_learning_rate=1.0, device=dev, precision="f32x3", gather_ahead=args.gather_ahead)
+    el = timed_steps(r, n, max(n_w, 10), dev)
+    out["reference_recipe"] = {"workload": "batch 1024 triplets (3072 rows), uniform negatives, LARS lr 1.0, margin 0.8 at precision f32x3",
+                               "value": round(1024 * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4),
+                               "steps": n, "loss": round(r.loss(), 6)}
     return out
 
 
