@@ -94,10 +94,15 @@ bool x3_kmajor() {
 int x3_nt_splits(int M, int N, int ktiles) {
   const int64_t tiles = (int64_t)((M + 255) / 256) * (N / 256);
   if (tiles >= 192) return 1;
-  int s = (int)((220 + tiles - 1) / tiles);
-  if (s > 16) s = 16;
-  while (s > 1 && ktiles / s < 8) --s;
-  return s < 2 ? 1 : s;
+  // fill one round of the 256 CUs as evenly as possible with the fewest slabs, at least 8 K-tiles per block
+  int best = 1;
+  double best_eff = 0.0;
+  for (int s = 1; s <= 16 && ktiles / s >= 8; ++s) {
+    const int64_t blocks = tiles * s;
+    const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+    if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+  }
+  return best;
 }
 
 }  // namespace
