@@ -686,9 +686,27 @@ def rec_f32x3(dev, args, n_s, n_w, table, pairs, B, mode):
     r = train.TrainStep(table, rp, 1024, output_size=D, hidden_size=H, margin=MARGIN, mode="uniform", optimizer="lars",
                         base_learning_rate=1.0, device=dev, precision="f32x3", gather_ahead=args.gather_ahead)
     el = timed_steps(r, n, max(n_w, 10), dev)
+    r_loss = round(r.loss(), 6)
+    del r
+    torch.cuda.empty_cache()
+    # and a run that LEARNS (data_learnable's catalogue): both paths from the same seeds, the loss along the way
+    tl, pl = learnable_catalogue(200000, dev)
+    curves = {}
+    for prec in ("f32", "f32x3"):
+        t = train.TrainStep(tl, pl, B, output_size=D, hidden_size=H, margin=MARGIN, mode=mode, optimizer="adam",
+                            base_learning_rate=2e-4, device=dev, precision=prec, gather_ahead=args.gather_ahead)
+        losses = []
+        for i in range(61):
+            t.step()
+            if i % 15 == 0:
+                losses.append(round(t.loss(), 4))
+        curves[prec] = losses
+        del t
+        torch.cuda.empty_cache()
+    out["learnable_catalogue_loss_every_15_steps"] = curves
     out["reference_recipe"] = {"workload": "batch 1024 triplets (3072 rows), uniform negatives, LARS lr 1.0, margin 0.8 at precision f32x3",
                                "value": round(1024 * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4),
-                               "steps": n, "loss": round(r.loss(), 6)}
+                               "steps": n, "loss": r_loss}
     return out
 
 
