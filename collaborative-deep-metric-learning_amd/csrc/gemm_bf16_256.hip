@@ -37,6 +37,7 @@
 //   A wave waits for its OWN pieces before a barrier; the read of the image comes two barriers
 //   later, after every wave of both groups has passed its wait.
 #include "gemm_bf16.h"
+#include <type_traits>
 #include <stdlib.h>
 
 #ifndef CDML_BF16_MFMA_DEFAULT
@@ -107,7 +108,9 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
 // kt & 1), so across the tiles_m tiles that share B every K-tile is counted once -- written to
 // cs_row[grp * cs_grp_stride + tile-local column].  Called by every wave of the block with the same arguments.
 // X3: the operands are three bf16 planes each (BArgs::x3_*): the K-tiles walk the six plane products.
-template <bool TN, int EPI, bool S16, bool X3 = false>
+// F6 (X3 only): the walk is K-major over six products in whole six-step periods (the host guarantees it): the loop is
+// the unrolled period with its compile-time DMA skipping, and the general loop is not compiled in.
+template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false>
 __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int m0, const int n0, const int k_begin,
                                          const int n_ktiles, void *c_base, const int64_t c_ld, const int c_row0,
                                          const int c_col0, float *cs_row, const int64_t cs_grp_stride,
@@ -171,6 +174,18 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     } else {
       k_elems = (int64_t)(k_begin + tile * kTileK) * (TN ? (img == 0 ? g.lda : g.ldb) : 1);
     }
+    const uint32_t kb = tile < n_ktiles ? (uint32_t)(k_elems * 2) : 0x80000000u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t voff = (img == 0 ? va[i] + hh * d_a : vb[i] + hh * d_b) + kb;
+      dma(img == 0 ? srd_a : srd_b, voff, lds_piece + i * 1024 + buf * BUF + (hh * 2 + img) * IMG);
+    }
+  };
+
+  // X3 fast walk: the image of plane `plane` (compile time at the call sites), K-tile w of the plane
+  auto stage_pw = [&](int img, int hh, int plane, int w, int tile, int buf) {
+    const int64_t k_elems = (int64_t)w * kTileK * (TN ? (img == 0 ? g.lda : g.ldb) : 1) +
+                            plane * (img == 0 ? g.x3_plane_a : g.x3_plane_b);
     const uint32_t kb = tile < n_ktiles ? (uint32_t)(k_elems * 2) : 0x80000000u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -369,6 +384,85 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     __builtin_amdgcn_s_setprio(0);
     CDML_BARRIER();
   };
+  // X3, K-major, six products: step S (compile time) of the six-step period of K-tile w.  Same phases as
+  // do_tile2_s16; what is known at compile time here -- which planes a step multiplies and stages for -- lets the
+  // loop SKIP the DMA of an image its LDS buffer already holds (B = hi on steps 0, 2, 4: the B image staged for
+  // step 0 serves 2 and 4; A = hi on steps 1 and 3) with the counted waits adjusted as immediates: 9 image loads
+  // per K-tile instead of 12, no division per DMA.  (Decided at run time the same skipping cost 19 %.)
+  auto step6 = [&](auto Sc, const int tile, const int w) {
+    constexpr int S = decltype(Sc)::value;
+    constexpr int PA[6] = {0, 0, 1, 0, 2, 1}, PB[6] = {0, 1, 0, 2, 0, 1};      // (A, B) planes of the six products
+    constexpr int buf = S & 1;
+    constexpr bool skip_a = (S >= 1 && S <= 4) && PA[(S + 1) % 6] == PA[(S + 5) % 6];   // A of step + 1 == A of step - 1
+    constexpr bool skip_b = (S <= 3) && PB[(S + 2) % 6] == PB[S];                       // B of step + 2 == B of this step
+    constexpr int SP = (S + 5) % 6;                                                      // the previous step
+    constexpr bool b_next_issued = !((SP <= 3) && PB[(SP + 2) % 6] == PB[SP]);           // B of step + 1: staged by it?
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        fb0[2 * cb + ks2] = read_b16(buf, 0, cb, ks2);
+        fb1[2 * cb + ks2] = read_b16(buf, 1, cb, ks2);
+      }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) fa[ks2][rb] = read_a16(buf, 0, rb, ks2);
+    if constexpr (!skip_a) {
+      stage_pw(0, 0, PA[(S + 1) % 6], w + (S == 5 ? 1 : 0), tile + 1, buf ^ 1);
+      stage_pw(0, 1, PA[(S + 1) % 6], w + (S == 5 ? 1 : 0), tile + 1, buf ^ 1);
+    }
+    // in flight behind A-h1 of this step (read in phase B): B of step + 1 and A of step + 1, where issued
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (int)b_next_issued + 4 * (int)!skip_a) : "memory");
+    pin_b();
+    pin_a();
+    if (TN && cs_on && ((0xB >> S) & 1) && (tile % cs_period) == cs_owner) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          cs16[cb] += frag_sum(fb0[2 * cb + ks2]);
+          cs16[2 + cb] += frag_sum(fb1[2 * cb + ks2]);
+        }
+    }
+    CDML_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          acc16[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[rb][cb], 0, 0, 0);
+          acc16[rb][2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[rb][2 + cb], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    CDML_BARRIER();
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) fa[ks2][rb] = read_a16(buf, 1, rb, ks2);
+    if constexpr (!skip_b) {
+      stage_pw(1, 0, PB[(S + 2) % 6], w + (S >= 4 ? 1 : 0), tile + 2, buf);
+      stage_pw(1, 1, PB[(S + 2) % 6], w + (S >= 4 ? 1 : 0), tile + 2, buf);
+    }
+    // in flight behind A-h0 and B of step + 1 (read in its phase A): A-h1 of step + 1 and B of step + 2, where issued
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (int)!skip_a + 4 * (int)!skip_b) : "memory");
+    pin_a();
+    CDML_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          acc16[4 + rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 + rb][cb], 0, 0, 0);
+          acc16[4 + rb][2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 + rb][2 + cb], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    CDML_BARRIER();
+  };
   auto do_tile2 = [&](const int buf, const int tile) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fb0[ks] = read_b(buf, 0, ks);
@@ -428,13 +522,28 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   CDML_BARRIER();
   if (grp == 1) CDML_BARRIER();                          // group 1 runs one barrier behind
-  for (int tile = 0; tile < n_ktiles; tile += 2) {
-    if constexpr (S16) {
-      do_tile2_s16(0, tile);
-      do_tile2_s16(1, tile + 1);
-    } else {
-      do_tile2(0, tile);
-      do_tile2(1, tile + 1);
+  constexpr bool kFast6 = X3 && S16 && F6;
+  if constexpr (kFast6) {
+    {
+      int w = x3_t0 / 6;
+      for (int tile = 0; tile < n_ktiles; tile += 6, ++w) {
+        step6(std::integral_constant<int, 0>{}, tile, w);
+        step6(std::integral_constant<int, 1>{}, tile + 1, w);
+        step6(std::integral_constant<int, 2>{}, tile + 2, w);
+        step6(std::integral_constant<int, 3>{}, tile + 3, w);
+        step6(std::integral_constant<int, 4>{}, tile + 4, w);
+        step6(std::integral_constant<int, 5>{}, tile + 5, w);
+      }
+    }
+  } else {
+    for (int tile = 0; tile < n_ktiles; tile += 2) {
+      if constexpr (S16) {
+        do_tile2_s16(0, tile);
+        do_tile2_s16(1, tile + 1);
+      } else {
+        do_tile2(0, tile);
+        do_tile2(1, tile + 1);
+      }
     }
   }
 
@@ -647,7 +756,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   }
 }
 
-template <bool TN, int EPI, bool S16, bool X3 = false>
+template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false>
 __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   int tm, tn;
@@ -660,7 +769,7 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   const int n_ktiles = k_end > k_begin ? (k_end - k_begin) / kTileK : 0;   // even (host)
   void *c_base = EPI == BE_F32 ? static_cast<void *>(static_cast<float *>(g.C) + (int64_t)split * g.slab_stride) : g.C;
   float *cs_row = (TN && g.colsum_partial) ? g.colsum_partial + (int64_t)((split * g.tiles_m + tm) * 2) * g.N + n0 : nullptr;
-  run_tile<TN, EPI, S16, X3>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
+  run_tile<TN, EPI, S16, X3, F6>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
 }
 
 // ---- both weight gradients of the tower in ONE launch (k-strided form; dW1 = x_hat^T dz1, dW2 = h1^T dz2) ----
@@ -817,17 +926,28 @@ int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t s
 }
 
 namespace {
-template <bool TN, int EPI>
-int launch_x3(const BArgs &g, int splits, hipStream_t s) {
+template <bool TN, int EPI, bool F6>
+int launch_x3_1(const BArgs &g, int splits, hipStream_t s) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI, true, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI, true, true, F6>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3: cannot reserve %d B of LDS: %s", SMEM, hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), SMEM, s, g);
+  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true, F6>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), SMEM, s, g);
   return check_launch("gemm_bf16x3");
+}
+// the unrolled six-step walk when every block's K range is whole periods of the K-major six-product walk
+template <bool TN, int EPI>
+int launch_x3(const BArgs &g, int splits, hipStream_t s) {
+  // (k-contiguous form only: the k-strided form with its transposed-read offsets and column sums does not fit the
+  // unrolled period into 256 VGPRs -- 58 spilled, the weight gradients 2.4 x slower, measured)
+  if constexpr (!TN) {
+    const int kt = g.K / kTileK, per = g.k_per_split / kTileK;
+    if (g.x3_products == 6 && kt % 6 == 0 && per % 6 == 0 && per > 0) return launch_x3_1<TN, EPI, true>(g, splits, s);
+  }
+  return launch_x3_1<TN, EPI, false>(g, splits, s);
 }
 }  // namespace
 

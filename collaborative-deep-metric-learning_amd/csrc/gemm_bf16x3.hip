@@ -224,7 +224,7 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   }
   if (splits == 1) return launch_gemm_bf16_256_x3(g, false, epilogue, 1, s);
   const int per = (ktiles + splits - 1) / splits;
-  g.k_per_split = (per + 1) / 2 * 2 * 64;
+  g.k_per_split = (per + 5) / 6 * 6 * 64;                // whole six-step periods of the K-major walk (and an even count)
   g.slab_stride = (int64_t)M * N;
   g.C = workspace; g.ldc = N;
   int rc = launch_gemm_bf16_256_x3(g, false, BE_F32, splits, s);
