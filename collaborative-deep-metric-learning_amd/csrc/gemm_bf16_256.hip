@@ -154,14 +154,20 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   // (K-major, x3_products > 0: K-tile v = product v % P of K-tile v / P -- the three reads of an operand's hi
   // plane K-tile, two of its mid plane, come within six steps of each other, out of L2 instead of HBM)
   const bool x3_kmajor = X3 && g.x3_products > 0;
-  const float x3_inv = X3 ? 1.0f / (float)(x3_kmajor ? g.x3_products : g.x3_tpp) : 0.f;
+  // (through readfirstlane: a uniform float computed on the VALU otherwise lives in a VGPR, and the k-strided kernel
+  // has none to spare -- it was keeping 12 B of stack)
+  const float x3_inv = X3 ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
+                                int, 1.0f / (float)(x3_kmajor ? g.x3_products : g.x3_tpp)))) : 0.f;
   const int x3_t0 = k_begin / kTileK;
   auto x3_div = [&](int v) { return __builtin_amdgcn_readfirstlane((int)(((float)v + 0.5f) * x3_inv)); };
   // product (0..5) and K-tile within the plane of walk position v
+  // (selects, not assignments under a branch: with those hipcc kept the two results on the stack and read the product
+  // back behind an s_waitcnt vmcnt(0) -- draining the DMA pipeline wherever the k-strided form asked for it)
   auto x3_where = [&](int v, int &sgm, int &w) {
     const int qd = x3_div(v);
-    if (x3_kmajor) { w = qd; sgm = v - qd * g.x3_products; }
-    else { sgm = qd; w = v - qd * g.x3_tpp; }
+    const int rem = v - qd * (x3_kmajor ? g.x3_products : g.x3_tpp);
+    sgm = x3_kmajor ? rem : qd;
+    w = x3_kmajor ? qd : rem;
   };
   auto x3_segment = [&](int v) { int sgm, w; x3_where(v, sgm, w); return sgm; };
   auto stage = [&](int img, int hh, int tile, int buf) {
