@@ -188,6 +188,14 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     }
   };
 
+  // X3, general loop, K-major: walk positions packed as 8 w + product -- of the step being multiplied (c), of step + 1
+  // (a: its A images are staged) and of step + 2 (b: its B images) -- advanced once per step by VALUE (no references:
+  // hipcc puts referenced loop-carried scalars on the stack, and this loop cannot afford a stack): no division per DMA
+  const bool x3_run = X3 && !F6 && x3_kmajor;
+  auto x3_pack = [&](int v) { const int qd = x3_div(v); return qd * 8 + (v - qd * g.x3_products); };
+  auto x3_step = [&](int pos) { return ((pos & 7) + 1 == g.x3_products) ? (pos & ~7) + 8 : pos + 1; };
+  int xp_c = 0, xp_a = 0, xp_b = 0;
+  if (x3_run) { xp_c = x3_pack(x3_t0); xp_a = x3_pack(x3_t0 + 1); xp_b = x3_pack(x3_t0 + 2); }
   // X3 fast walk: the image of plane `plane` (compile time at the call sites), K-tile w of the plane
   auto stage_pw = [&](int img, int hh, int plane, int w, int tile, int buf) {
     const int64_t k_elems = (int64_t)w * kTileK * (TN ? (img == 0 ? g.lda : g.ldb) : 1) +
@@ -341,12 +349,18 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     for (int ks2 = 0; ks2 < 2; ++ks2)
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) fa[ks2][rb] = read_a16(buf, 0, rb, ks2);
-    stage(0, 0, tile + 1, buf ^ 1);
-    stage(0, 1, tile + 1, buf ^ 1);
+    if (X3 && x3_run) {
+      const int pl = (0x120100 >> (4 * (xp_a & 7))) & 3;
+      stage_pw(0, 0, pl, xp_a >> 3, tile + 1, buf ^ 1);
+      stage_pw(0, 1, pl, xp_a >> 3, tile + 1, buf ^ 1);
+    } else {
+      stage(0, 0, tile + 1, buf ^ 1);
+      stage(0, 1, tile + 1, buf ^ 1);
+    }
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     pin_b();
     pin_a();
-    if (TN && cs_on && (tile % cs_period) == cs_owner && (!X3 || ((0xB >> x3_segment(x3_t0 + tile)) & 1))) {
+    if (TN && cs_on && (tile % cs_period) == cs_owner && (!X3 || ((0xB >> (x3_run ? (xp_c & 7) : x3_segment(x3_t0 + tile))) & 1))) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -372,8 +386,14 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     for (int ks2 = 0; ks2 < 2; ++ks2)
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) fa[ks2][rb] = read_a16(buf, 1, rb, ks2);
-    stage(1, 0, tile + 2, buf);
-    stage(1, 1, tile + 2, buf);
+    if (X3 && x3_run) {
+      const int pl = (0x102010 >> (4 * (xp_b & 7))) & 3;
+      stage_pw(1, 0, pl, xp_b >> 3, tile + 2, buf);
+      stage_pw(1, 1, pl, xp_b >> 3, tile + 2, buf);
+    } else {
+      stage(1, 0, tile + 2, buf);
+      stage(1, 1, tile + 2, buf);
+    }
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     pin_a();
     CDML_BARRIER();
@@ -389,6 +409,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
         }
     __builtin_amdgcn_s_setprio(0);
     CDML_BARRIER();
+    if (X3 && x3_run) { xp_c = x3_step(xp_c); xp_a = x3_step(xp_a); xp_b = x3_step(xp_b); }
   };
   // X3, K-major, six products: step S (compile time) of the six-step period of K-tile w.  Same phases as
   // do_tile2_s16; what is known at compile time here -- which planes a step multiplies and stages for -- lets the
