@@ -230,7 +230,8 @@ __device__ __forceinline__ void tail_dist(const TailRow<NCH> &a, const TailRow<N
 // dz = inv * (g - z*c) * lrelu'(z), c = inv^2 <z,g>  (k_l2norm_bwd); also stores e
 template <int NCH>
 __device__ __forceinline__ void tail_store_row(const TailRow<NCH> &r, const float4 (&g)[NCH], float alpha,
-                                               float *er, float *dr, uint16_t *br, int nq, int lane) {
+                                               float *er, float *dr, uint16_t *br, int nq, int lane,
+                                               int64_t plane = 0) {
   float zg = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) zg += dot4(r.v[c], g[c]);
@@ -261,6 +262,22 @@ __device__ __forceinline__ void tail_store_row(const TailRow<NCH> &r, const floa
       w.x = rn(d.x) | (rn(d.y) << 16);
       w.y = rn(d.z) | (rn(d.w) << 16);
       reinterpret_cast<uint2 *>(br)[q] = w;
+      if (plane) {   // precision "f32x3": the mid and lo planes too (hi + mid + lo == d exactly), `plane` elements apart
+        float r[4] = {d.x, d.y, d.z, d.w};
+        uint32_t hb[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
+#pragma unroll
+        for (int pl = 1; pl < 3; ++pl) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            r[u] -= __uint_as_float(hb[u] << 16);
+            hb[u] = rn(r[u]);
+          }
+          uint2 m;
+          m.x = hb[0] | (hb[1] << 16);
+          m.y = hb[2] | (hb[3] << 16);
+          reinterpret_cast<uint2 *>(br + pl * plane)[q] = m;
+        }
+      }
     }
   }
 }
@@ -271,7 +288,8 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
             const int32_t *__restrict__ shift_p, int B, int D, float margin, float alpha,
             float *__restrict__ e, int64_t lde, float *__restrict__ pos_o, float *__restrict__ neg_o,
             float *__restrict__ hinge_o, uint8_t *__restrict__ valid_o, float *__restrict__ dz2,
-            int64_t lddz, uint16_t *__restrict__ dz2_bf, int64_t ldbf, float *__restrict__ var_ws) {
+            int64_t lddz, uint16_t *__restrict__ dz2_bf, int64_t ldbf, float *__restrict__ var_ws,
+            int64_t plane_bf) {
   __shared__ __attribute__((aligned(16))) float s_red[kWavesPerBlock][8];
   extern __shared__ __attribute__((aligned(16))) float s_col[];                 // [kWavesPerBlock][D] when var_ws
   const int lane = threadIdx.x & (kWave - 1);
@@ -307,7 +325,7 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       }
       if (lane == 0) { pos_o[i] = pos; neg_o[i] = neg; hinge_o[i] = fmaxf(t, 0.f); }
       tail_store_row<NCH>(N, gn, alpha, e + (ra + 2) * lde, dz2 + (ra + 2) * lddz,
-                          dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane);
+                          dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane, plane_bf);
     } else {
       const int j = (i + shift) % B;
       const int k = (i - shift % B + B) % B;
@@ -341,8 +359,8 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
         if (valid_o) valid_o[i] = valid_i ? 1 : 0;
       }
     }
-    tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane);
-    tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane);
+    tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane, plane_bf);
+    tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane, plane_bf);
     if (var_ws) {       // column sums and sum of squares of the [B,3,D] triplet tensor
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -779,11 +797,11 @@ extern "C" size_t cdml_vnet_tail_workspace(int B, int D) {
   return (size_t)kTailVarBlocks * (size_t)(D + 4) * sizeof(float);
 }
 
-extern "C" int cdml_vnet_tail(int mode, const float *z, int64_t ldz, const int32_t *rows,
-                              const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
-                              float *e, int64_t lde, float *pos, float *neg, float *hinge,
-                              uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_bf16,
-                              int64_t ldbf, float *stats, float *var_ws, cdml_stream_t stream) {
+static int vnet_tail_impl(int mode, const float *z, int64_t ldz, const int32_t *rows,
+                          const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
+                          float *e, int64_t lde, float *pos, float *neg, float *hinge,
+                          uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_bf16,
+                          int64_t ldbf, int64_t plane_bf, float *stats, float *var_ws, cdml_stream_t stream) {
   CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "vnet_tail: mode must be 0 (a,p,n rows) or 1 (in-batch)");
   CDML_REQUIRE(B >= (mode == 1 ? 2 : 1) && D > 0 && pos && neg && hinge, CDML_E_BADARG, "vnet_tail: bad argument");
   CDML_REQUIRE(mode == 0 || (rows && shift), CDML_E_BADARG, "vnet_tail: in-batch mode needs rows and shift");
@@ -795,6 +813,8 @@ extern "C" int cdml_vnet_tail(int mode, const float *z, int64_t ldz, const int32
   if ((rc = check_rows("vnet_tail dz2", dz2, lddz2, D))) return rc;
   CDML_REQUIRE(!dz2_bf16 || (ldbf >= D && (ldbf & 3) == 0 && (reinterpret_cast<uintptr_t>(dz2_bf16) & 7) == 0),
                CDML_E_ALIGN, "vnet_tail: bf16 copy needs an 8-B aligned base and a leading dimension multiple of 4");
+  CDML_REQUIRE(plane_bf == 0 || (dz2_bf16 && plane_bf >= D && (plane_bf & 3) == 0 && ldbf >= 2 * plane_bf + D), CDML_E_ALIGN,
+               "vnet_tail: planes need plane >= D (a multiple of 4) and a leading dimension >= 2 plane + D");
   int grid = grid_rows(B);
   if (var_ws && grid > kTailVarBlocks) grid = kTailVarBlocks;
   const size_t lds = var_ws ? (size_t)kWavesPerBlock * D * sizeof(float) : 0;
@@ -802,7 +822,7 @@ extern "C" int cdml_vnet_tail(int mode, const float *z, int64_t ldz, const int32
 #define CDML_LAUNCH_TAIL(M, N)                                                                       \
   hipLaunchKernelGGL((k_vnet_tail<M, N>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, z, ldz, \
                      rows, shift, B, D, margin, lrelu_alpha, e, lde, pos, neg, hinge, valid_out, dz2,  \
-                     lddz2, dz2_bf16, ldbf, var_ws)
+                     lddz2, dz2_bf16, ldbf, var_ws, plane_bf)
   if (mode == 0) {
     if (nch <= 1) CDML_LAUNCH_TAIL(0, 1); else if (nch <= 2) CDML_LAUNCH_TAIL(0, 2); else CDML_LAUNCH_TAIL(0, 4);
   } else {
@@ -819,6 +839,28 @@ extern "C" int cdml_vnet_tail(int mode, const float *z, int64_t ldz, const int32
     rc = check_launch("vnet_tail variance");
   }
   return rc;
+}
+
+extern "C" int cdml_vnet_tail(int mode, const float *z, int64_t ldz, const int32_t *rows,
+                              const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
+                              float *e, int64_t lde, float *pos, float *neg, float *hinge,
+                              uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_bf16,
+                              int64_t ldbf, float *stats, float *var_ws, cdml_stream_t stream) {
+  return vnet_tail_impl(mode, z, ldz, rows, shift, B, D, margin, lrelu_alpha, e, lde, pos, neg, hinge, valid_out, dz2, lddz2,
+                        dz2_bf16, ldbf, 0, stats, var_ws, stream);
+}
+
+// cdml_vnet_tail writing dz2 also as its three bf16 planes hi | mid | lo (precision "f32x3": the split-fp32 GEMMs of
+// the backward pass read them): dz2_planes = bf16 [rows][ldbf], plane p at columns p * plane_bf.
+extern "C" int cdml_vnet_tail_planes(int mode, const float *z, int64_t ldz, const int32_t *rows,
+                                     const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
+                                     float *e, int64_t lde, float *pos, float *neg, float *hinge,
+                                     uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_planes,
+                                     int64_t ldbf, int64_t plane_bf, float *stats, float *var_ws,
+                                     cdml_stream_t stream) {
+  CDML_REQUIRE(dz2_planes && plane_bf > 0, CDML_E_BADARG, "vnet_tail_planes: the plane buffer and its plane stride are required");
+  return vnet_tail_impl(mode, z, ldz, rows, shift, B, D, margin, lrelu_alpha, e, lde, pos, neg, hinge, valid_out, dz2, lddz2,
+                        dz2_planes, ldbf, plane_bf, stats, var_ws, stream);
 }
 
 extern "C" int cdml_semihard_select(const float *S, int64_t ldS, const float *e, int64_t lde,

@@ -85,6 +85,7 @@ def tower_forward(p, ws, normalize=True):
     ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, ws.h1, L.Hp, ws.W2T, L.Hp, ws.z, R, L.Dp, L.Hp, products=q,
                        bias=p.b2, workspace=ws.gemm_ws)
     ws.tail_done = False
+    ws.dz2_planes_done = False
     if normalize:
         ops.l2norm_fwd(ws.z, L.Dp, ws.e)
     return ws.e
@@ -99,7 +100,8 @@ def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
     L, R, q = p.layout, ws.R, ws.products
     if not ws.tail_done:
         ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
-    ops.split_f32_bf16x3(ws.dz2, ws.dz2_3, L.Dp)
+    if not (ws.tail_done and getattr(ws, "dz2_planes_done", False)):      # the fused tail writes the planes itself
+        ops.split_f32_bf16x3(ws.dz2, ws.dz2_3, L.Dp)
     w2 = lambda: ops.gemm_bf16x3_tn(ws.h1, L.Hp, ws.dz2_3, L.Dp, p.gW2, L.Hp, L.Dp, R, products=q,
                                     workspace=ws.gemm_ws, colsum=p.gb2)
     single = after_w1 is None and after_w1_chunk is None

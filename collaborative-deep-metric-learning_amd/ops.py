@@ -215,13 +215,18 @@ def vnet_tail_workspace_floats(B, D):
 
 
 def vnet_tail(mode, z, rows, shift, B, D, margin, e, pos, neg, hinge, dz2, valid=None, stats=None,
-              dz2_bf16=None, var_ws=None, alpha=LRELU_ALPHA):
+              dz2_bf16=None, var_ws=None, alpha=LRELU_ALPHA, plane_bf=0):
     """l2norm -> hinge loss -> its gradient -> l2norm backward -> lrelu' in one launch
     (mode 0: rows a,p,n per triplet; 1: in-batch negatives)."""
     zp, zld = _mat(z)
     ep, eld = _mat(e)
     dp, dld = _mat(dz2)
     bp, bld = (C.c_void_p(0), 0) if dz2_bf16 is None else _mat16(dz2_bf16)
+    if plane_bf:                                     # dz2 also as its three bf16 planes (precision f32x3)
+        call("cdml_vnet_tail_planes", mode, zp, zld, _p(rows, torch.int32), _p(shift, torch.int32), B, D, margin, alpha,
+             ep, eld, _p(pos), _p(neg), _p(hinge), _p(valid, torch.uint8), dp, dld, bp, bld, plane_bf, _p(stats),
+             _p(var_ws), _stream())
+        return
     call("cdml_vnet_tail", mode, zp, zld, _p(rows, torch.int32), _p(shift, torch.int32), B, D, margin, alpha,
          ep, eld, _p(pos), _p(neg), _p(hinge), _p(valid, torch.uint8), dp, dld, bp, bld, _p(stats), _p(var_ws),
          _stream())

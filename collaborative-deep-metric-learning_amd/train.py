@@ -337,8 +337,11 @@ class TrainStep:
         if fused:
             ops.vnet_tail(0 if self.mode == "uniform" else 1, self.ws.z, self.idx, self.shift, self.B, L.Dp,
                           self.margin, self.ws.e, self.pos, self.neg, self.hinge, self.ws.dz2, valid=self.valid,
-                          stats=self.stats, dz2_bf16=self.ws.dz2_bf if self.bf16 else None, var_ws=self.var_ws)
+                          stats=self.stats, var_ws=self.var_ws,
+                          dz2_bf16=self.ws.dz2_bf if self.bf16 else self.ws.dz2_3 if self.x3 else None,
+                          plane_bf=L.Dp if self.x3 else 0)
             self.ws.tail_done = True
+            self.ws.dz2_planes_done = self.x3
             return
         de = self.ws.de if with_grad else None
         if self.mode == "uniform":

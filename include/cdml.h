@@ -400,6 +400,14 @@ int cdml_sample_gather_x3(int mode, const int32_t *pairs, int64_t n_pairs, uint6
                           int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
                           uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
                           int64_t idx_step_stride, int32_t *oob_flag, cdml_stream_t stream);
+/* cdml_vnet_tail (models.py:61, losses.py:32-38, train.py:141) writing dz2 also as its three planes:
+ * dz2_planes = bf16 [rows][ldbf], plane p at columns p * plane_bf (plane_bf >= D, ldbf >= 2 plane_bf + D). */
+int cdml_vnet_tail_planes(int mode, const float *z, int64_t ldz, const int32_t *rows,
+                          const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
+                          float *e, int64_t lde, float *pos, float *neg, float *hinge,
+                          uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_planes,
+                          int64_t ldbf, int64_t plane_bf, float *stats, float *var_ws,
+                          cdml_stream_t stream);
 /* cdml_adam_matrix_bf16 (train.py:146) writing the operand copies as planes: wt_planes = W^T as
  * [N][hi K | mid K | lo K] (plane stride plane_t), wc_planes = W as [K][hi N | mid N | lo N] (plane_c). */
 int cdml_adam_matrix_planes(float *w, const float *g, float *m, float *v, int K, int N, float lr,

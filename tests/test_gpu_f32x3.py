@@ -175,3 +175,21 @@ def test_train_step_matches_the_fp32_mfma_step(mode, optimizer):
     assert torch.equal(w1t, b.params.W1.t())
     w2 = b.ws.W2[:, :L.Dp].float() + b.ws.W2[:, L.Dp:2 * L.Dp].float() + b.ws.W2[:, 2 * L.Dp:].float()
     assert torch.equal(w2, b.params.W2)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_vnet_tail_writes_the_planes_of_dz2(mode):
+    """the fused tail's plane output == the split of the fp32 dz2 it writes beside it (bit for bit)"""
+    dev = _dev()
+    torch.manual_seed(5)
+    B, D = 96, 256
+    rows = B * (3 if mode == 0 else 2)
+    z = torch.randn(rows, D, device=dev)
+    e, dz2 = torch.zeros(rows, D, device=dev), torch.zeros(rows, D, device=dev)
+    pos, neg, hinge = (torch.zeros(B, device=dev) for _ in range(3))
+    idx = torch.arange(rows, dtype=torch.int32, device=dev)
+    shift = torch.tensor([7], dtype=torch.int32, device=dev)
+    planes = torch.zeros(rows, 3 * D, dtype=torch.bfloat16, device=dev)
+    ops.vnet_tail(mode, z, idx, shift, B, D, 0.8, e, pos, neg, hinge, dz2, dz2_bf16=planes, plane_bf=D)
+    assert float(dz2.abs().max()) > 0
+    assert torch.equal(planes, _planes(dz2, D))
