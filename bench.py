@@ -312,9 +312,13 @@ def install_timers(kt, L, bf16):
         patch("adam_step", "adam_bias")
     elif bf16 is None:                             # precision f32x3: the split-fp32 GEMMs (+ the fp32 Adam)
         # gemm_bf16x3_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, ...); _tn(A, pa, B, pb, C, M, N, K, ...)
+        # (by epilogue: 6 / 8 = FC1 with plane output, 1 = FC2, 7 = the data gradient, 3 = a weight gradient in the
+        # k-contiguous form of the transposed activation layout; the k-strided form: FC2 when it carries a bias)
         patch("gemm_bf16x3_nt", lambda e, A, pa, Bm, pb, C, M, N, K, **k:
-              "fc1_fwd" if (N == L.Hp and K == L.Fp) else ("fc2_fwd" if N == L.Dp else "dH1"))
-        patch("gemm_bf16x3_tn", lambda A, pa, Bm, pb, C, M, N, K, **k: "dW1" if N == L.Hp else "dW2")
+              {6: "fc1_fwd", 8: "fc1_fwd", 1: "fc2_fwd", 7: "dH1"}.get(e, "dW1" if N == L.Hp else "dW2"))
+        patch("gemm_bf16x3_tn", lambda A, pa, Bm, pb, C, M, N, K, **k:
+              "fc2_fwd" if k.get("bias") is not None else ("dW1" if N == L.Hp else "dW2"))
+        patch("transpose_to_bf16", "transpose_planes")
         patch("split_f32_bf16x3", "split_planes")
         patch("adam_matrix_bf16", lambda W, *a, **k: "adam_w1" if W.shape[0] == L.Fp else "adam_w2")
         patch("adam_step", "adam")
@@ -379,7 +383,7 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0):
                                "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": flops_gemm}
     kern = {}
     for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "adam", "adam_w1", "adam_w2", "adam_bias", "lars",
-              "split_planes"):
+              "split_planes", "transpose_planes"):
         if kt.mean_ms(k) is not None:
             kern[k + "_ms"] = round(kt.mean_ms(k), 4)
             if kt.count(k) != sampled:

@@ -85,8 +85,8 @@ SIGNATURES = {
     "cdml_split_f32_bf16x3": (_i, [_p, _i64, _i, _i, _p, _i64, _i64, _i, _p]),
     "cdml_gemm_bf16x3_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "cdml_gemm_bf16x3_nt": (_i, [_i, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _p, _i64, _i64, _p, _p, _i64, _f,
-                                 _p, _sz, _p]),
-    "cdml_gemm_bf16x3_tn": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _p, _i64, _p, _p, _sz, _p]),
+                                 _p, _p, _sz, _p]),
+    "cdml_gemm_bf16x3_tn": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _p, _i64, _p, _f, _p, _p, _sz, _p]),
     "cdml_transpose_to_bf16": (_i, [_i, _p, _i64, _i, _i, _p, _i64, _p]),
     "cdml_cast_f32_bf16": (_i, [_p, _i64, _i, _i, _p, _i64, _p]),
     "cdml_colsum_workspace_floats": (_sz, [_i, _i]),

@@ -15,7 +15,9 @@ enum { BE_BIAS_LRELU_BF16 = 0, BE_BIAS_LRELU_F32 = 1, BE_MASK_BF16 = 2, BE_F32 =
        BE_MASKBITS_BF16 = 5,
        // fp32 products on the bf16 MFMA (gemm_bf16x3.hip): the result, bias + leaky-relu / times the mask
        // applied, split into three bf16 planes hi | mid | lo (C = bf16, planes x3_plane_c elements apart)
-       BE_BIAS_LRELU_X3 = 6, BE_MASK_X3 = 7 };
+       BE_BIAS_LRELU_X3 = 6, BE_MASK_X3 = 7,
+       // 6 with the bias indexed by the output ROW (a layer computed transposed: C = W^T-planes . x-planes^T)
+       BE_ROWBIAS_LRELU_X3 = 8 };
 
 struct BArgs {
   const bf16 *A; int64_t lda;

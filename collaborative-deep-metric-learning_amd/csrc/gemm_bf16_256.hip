@@ -110,13 +110,16 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
 // X3: the operands are three bf16 planes each (BArgs::x3_*): the K-tiles walk the six plane products.
 // F6 (X3 only): the walk is K-major over six products in whole six-step periods (the host guarantees it): the loop is
 // the unrolled period with its compile-time DMA skipping, and the general loop is not compiled in.
-template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false>
+// NTCS (X3, k-contiguous form): also sum B over k per column (its own instantiation: compiled into the plain kernels the
+// four sums and their branch cost FC1 25 % -- 514 -> 642 us, measured).
+template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false>
 __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int m0, const int n0, const int k_begin,
                                          const int n_ktiles, void *c_base, const int64_t c_ld, const int c_row0,
                                          const int c_col0, float *cs_row, const int64_t cs_grp_stride,
                                          unsigned char *smem) {
   static_assert(!TN || EPI == BE_F32, "the k-strided form only serves the weight gradients");
-  static_assert(X3 || (EPI != BE_BIAS_LRELU_X3 && EPI != BE_MASK_X3), "plane outputs belong to the split-fp32 form");
+  static_assert(X3 || (EPI != BE_BIAS_LRELU_X3 && EPI != BE_MASK_X3 && EPI != BE_ROWBIAS_LRELU_X3),
+                "plane outputs belong to the split-fp32 form");
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -305,7 +308,9 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   // in the read part of the phase, where the wave only waits anyway.
   float cs[2] = {0.f, 0.f};
   float cs16[4] = {0.f, 0.f, 0.f, 0.f};      // S16: column blocks 0, 1 of B-h0 and of B-h1
-  const bool cs_on = TN && cs_row != nullptr;
+  // (X3, k-contiguous form too: B[N][K] there, and a B fragment has the register layout the transposed read gives
+  // the k-strided form, so the same per-lane sums serve: colsum[n] = sum_k B[n][k])
+  const bool cs_on = (TN || (NTCS && X3 && S16)) && cs_row != nullptr;
   const int cs_period = 2 * g.tiles_m;
   const int cs_owner = (2 * tm + grp + cs_period - (k_begin / kTileK) % cs_period) % cs_period;   // in K-tiles from k_begin
   auto frag_sum = [&](const bf16x8 &f) {
@@ -360,7 +365,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     pin_b();
     pin_a();
-    if (TN && cs_on && (tile % cs_period) == cs_owner && (!X3 || ((0xB >> (x3_run ? (xp_c & 7) : x3_segment(x3_t0 + tile))) & 1))) {
+    if (cs_on && (tile % cs_period) == cs_owner && (!X3 || ((0xB >> (x3_run ? (xp_c & 7) : x3_segment(x3_t0 + tile))) & 1))) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -443,7 +448,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (int)b_next_issued + 4 * (int)!skip_a) : "memory");
     pin_b();
     pin_a();
-    if (TN && cs_on && ((0xB >> S) & 1) && (tile % cs_period) == cs_owner) {
+    if (cs_on && ((0xB >> S) & 1) && (tile % cs_period) == cs_owner) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -585,6 +590,14 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       if (h == 0) cs_row[grp * cs_grp_stride + ct * 128 + wc * 32 + l31] = v;
     }
   }
+  if (!TN && cs_on && S16) {   // k-contiguous form: B-h0 / B-h1 = the first / second 32 columns of the strip's 64
+#pragma unroll
+    for (int cbt = 0; cbt < 4; ++cbt) {
+      float v = cs16[cbt] + __shfl_xor(cs16[cbt], 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (q16 == 0) cs_row[grp * cs_grp_stride + wc * 64 + (cbt >> 1) * 32 + (cbt & 1) * 16 + l15] = v;
+    }
+  }
   if (TN && cs_on && S16) {    // the four 16-lane groups hold the four k-quarters of column l15
 #pragma unroll
     for (int cbt = 0; cbt < 4; ++cbt) {
@@ -608,15 +621,16 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     const int lr = p * 4 + (lane >> 4);
     return TN ? m0 + (rt >> 1) * 128 + grp * 64 + (rt & 1) * 32 + lr : m0 + grp * 128 + rt * 32 + lr;
   };
-  constexpr bool kBiasEpi = EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_X3;
+  constexpr bool kRowBias = EPI == BE_ROWBIAS_LRELU_X3;
+  constexpr bool kBiasEpi = EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_X3 || kRowBias;
   constexpr bool kMaskEpi = EPI == BE_MASK_BF16 || EPI == BE_MASK_X3;
-  constexpr bool kPlanes = EPI == BE_BIAS_LRELU_X3 || EPI == BE_MASK_X3;
+  constexpr bool kPlanes = EPI == BE_BIAS_LRELU_X3 || EPI == BE_MASK_X3 || kRowBias;
   if constexpr (!TN && (kBiasEpi || kMaskEpi)) {
     // bf16 outputs of the k-contiguous form: 16 B per lane and store (8 rows x 128 B per instruction) instead of
     // 8 B -- half the store instructions of the tile's tail (cdna guide T21: such a tail is issue-bound)
     const int c8 = lane & 7, lcol8 = wc * 64 + c8 * 8;
     f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
-    if (kBiasEpi) {
+    if (kBiasEpi && !kRowBias) {
       b0 = *reinterpret_cast<const f32x4 *>(g.bias + n0 + lcol8);
       b1 = *reinterpret_cast<const f32x4 *>(g.bias + n0 + lcol8 + 4);
     }
@@ -659,7 +673,12 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
         f32x4 v0 = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c8 * 8) ^ sw));
         f32x4 v1 = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c8 * 8 + 4) ^ sw));
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        if constexpr (kRowBias) {
+          const float br = g.bias[min(row, g.M - 1)];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bb[j] = br;
+        }
         bf16x8 o;
         unsigned bits = 0;
 #pragma unroll
@@ -783,7 +802,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   }
 }
 
-template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false>
+template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false>
 __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   int tm, tn;
@@ -795,8 +814,8 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   const int k_end = min(g.K, k_begin + g.k_per_split);
   const int n_ktiles = k_end > k_begin ? (k_end - k_begin) / kTileK : 0;   // even (host)
   void *c_base = EPI == BE_F32 ? static_cast<void *>(static_cast<float *>(g.C) + (int64_t)split * g.slab_stride) : g.C;
-  float *cs_row = (TN && g.colsum_partial) ? g.colsum_partial + (int64_t)((split * g.tiles_m + tm) * 2) * g.N + n0 : nullptr;
-  run_tile<TN, EPI, S16, X3, F6>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
+  float *cs_row = ((TN || NTCS) && g.colsum_partial) ? g.colsum_partial + (int64_t)((split * g.tiles_m + tm) * 2) * g.N + n0 : nullptr;
+  run_tile<TN, EPI, S16, X3, F6, NTCS>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
 }
 
 // ---- both weight gradients of the tower in ONE launch (k-strided form; dW1 = x_hat^T dz1, dW2 = h1^T dz2) ----
@@ -953,16 +972,16 @@ int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t s
 }
 
 namespace {
-template <bool TN, int EPI, bool F6>
+template <bool TN, int EPI, bool F6, bool NTCS = false>
 int launch_x3_1(const BArgs &g, int splits, hipStream_t s) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI, true, true, F6>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3: cannot reserve %d B of LDS: %s", SMEM, hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true, F6>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), SMEM, s, g);
+  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), SMEM, s, g);
   return check_launch("gemm_bf16x3");
 }
 // the unrolled six-step walk when every block's K range is whole periods of the K-major six-product walk
@@ -972,7 +991,11 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
   // unrolled period into 256 VGPRs -- 58 spilled, the weight gradients 2.4 x slower, measured)
   if constexpr (!TN) {
     const int kt = g.K / kTileK, per = g.k_per_split / kTileK;
-    if (g.x3_products == 6 && kt % 6 == 0 && per % 6 == 0 && per > 0) return launch_x3_1<TN, EPI, true>(g, splits, s);
+    const bool f6 = g.x3_products == 6 && kt % 6 == 0 && per % 6 == 0 && per > 0;
+    if constexpr (EPI == BE_F32) {        // the weight gradients of the transposed activation layout: with the column sums
+      if (g.colsum_partial) return f6 ? launch_x3_1<TN, EPI, true, true>(g, splits, s) : launch_x3_1<TN, EPI, false, true>(g, splits, s);
+    }
+    if (f6) return launch_x3_1<TN, EPI, true>(g, splits, s);
   }
   return launch_x3_1<TN, EPI, false>(g, splits, s);
 }
@@ -984,6 +1007,7 @@ int launch_gemm_bf16_256_x3(const BArgs &g, bool tn, int epilogue, int splits, h
     case BE_BIAS_LRELU_F32: return launch_x3<false, BE_BIAS_LRELU_F32>(g, splits, s);
     case BE_BIAS_LRELU_X3: return launch_x3<false, BE_BIAS_LRELU_X3>(g, splits, s);
     case BE_MASK_X3: return launch_x3<false, BE_MASK_X3>(g, splits, s);
+    case BE_ROWBIAS_LRELU_X3: return launch_x3<false, BE_ROWBIAS_LRELU_X3>(g, splits, s);
     default: return launch_x3<false, BE_F32>(g, splits, s);
   }
 }

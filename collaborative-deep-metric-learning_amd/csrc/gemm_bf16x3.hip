@@ -134,8 +134,8 @@ extern "C" size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int pr
   if (M <= 0 || N <= 0 || K <= 0 || (products != 3 && products != 6) || K % 64) return 0;
   const int ktiles = products * (K / 64);
   const int splits = tn ? gemm_bf16_256_splits(M, N, ktiles * 64) : x3_nt_splits(M, N, ktiles);
-  const size_t cs = tn ? (size_t)splits * (M / 256) * 2 * N * sizeof(float) + (size_t)N * sizeof(float) : 0;
-  return (splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0) + cs;
+  const size_t cs = (size_t)splits * ((M + 255) / 256) * 2 * N * sizeof(float) + (size_t)N * sizeof(float);   // bias-gradient partials
+  return (size_t)splits * M * N * sizeof(float) + cs;       // (a slab even unsplit: the k-strided form's bias pass reads one)
 }
 
 namespace cdml {
@@ -185,23 +185,27 @@ k_x3_colsum_final(const float *__restrict__ partial, int n_rows, int N, float *_
 extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
                                    int64_t ldb, int64_t plane_b, int M, int N, int K, int products, void *C,
                                    int64_t ldc, int64_t plane_c, const float *bias, const uint16_t *aux,
-                                   int64_t ldaux, float alpha, void *workspace, size_t workspace_bytes,
-                                   cdml_stream_t stream) {
+                                   int64_t ldaux, float alpha, float *colsum, void *workspace,
+                                   size_t workspace_bytes, cdml_stream_t stream) {
   CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16x3_nt: bad argument");
-  CDML_REQUIRE(epilogue == BE_BIAS_LRELU_F32 || epilogue == BE_F32 || epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3,
-               CDML_E_BADARG, "gemm_bf16x3_nt: epilogue must be 1, 3, 6 or 7");
+  CDML_REQUIRE(epilogue == BE_BIAS_LRELU_F32 || epilogue == BE_F32 || epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3 ||
+                   epilogue == BE_ROWBIAS_LRELU_X3,
+               CDML_E_BADARG, "gemm_bf16x3_nt: epilogue must be 1, 3, 6, 7 or 8");
   CDML_REQUIRE(products == 3 || products == 6, CDML_E_BADARG, "gemm_bf16x3_nt: products must be 3 or 6");
   CDML_REQUIRE(N % 256 == 0 && K % 64 == 0, CDML_E_UNSUPPORTED,
                "gemm_bf16x3_nt: N must be a multiple of 256 and K of 64, got N=%d K=%d", N, K);
   CDML_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && !(lda & 7) && !(ldb & 7) && !(plane_a & 7) && !(plane_b & 7) &&
                    plane_a >= K && plane_b >= K && lda >= 2 * plane_a + K && ldb >= 2 * plane_b + K,
                CDML_E_ALIGN, "gemm_bf16x3_nt: 16-B aligned bases, strides multiples of 8, ld >= 2 plane + K");
-  const bool planes_out = epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3;
+  const bool planes_out = epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3 || epilogue == BE_ROWBIAS_LRELU_X3;
   CDML_REQUIRE(planes_out ? (!(ldc & 7) && !(plane_c & 7) && plane_c >= N && ldc >= 2 * plane_c + N) : (!(ldc & 3) && ldc >= N),
                CDML_E_ALIGN, "gemm_bf16x3_nt: ldc (plane outputs: ldc and plane_c multiples of 8, ldc >= 2 plane_c + N)");
   CDML_REQUIRE(epilogue != BE_MASK_X3 || !aux || (aligned16(aux) && !(ldaux & 7) && ldaux >= N), CDML_E_ALIGN,
                "gemm_bf16x3_nt: aux must be 16-B aligned with ldaux a multiple of 8");
-  CDML_REQUIRE((epilogue != BE_BIAS_LRELU_F32 && epilogue != BE_BIAS_LRELU_X3) || bias, CDML_E_BADARG, "gemm_bf16x3_nt: bias required");
+  CDML_REQUIRE((epilogue != BE_BIAS_LRELU_F32 && epilogue != BE_BIAS_LRELU_X3 && epilogue != BE_ROWBIAS_LRELU_X3) || bias,
+               CDML_E_BADARG, "gemm_bf16x3_nt: bias required");
+  CDML_REQUIRE(!colsum || (M % 256 == 0 && products == 6 && epilogue == BE_F32), CDML_E_UNSUPPORTED,
+               "gemm_bf16x3_nt: colsum (sum over k of B[n][k]) goes with epilogue 3, M a multiple of 256 and six products");
   CDML_REQUIRE(((int64_t)M + 256) * lda * 2 < ((int64_t)1 << 31) && (int64_t)N * ldb * 2 < ((int64_t)1 << 31), CDML_E_UNSUPPORTED,
                "gemm_bf16x3_nt: an operand exceeds the 2 GiB buffer-descriptor range");
   BArgs g{};
@@ -219,27 +223,42 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   hipStream_t s = (hipStream_t)stream;
   int splits = planes_out ? 1 : x3_nt_splits(M, N, ktiles);
   if (splits > 1) {
-    const size_t need = (size_t)splits * M * N * sizeof(float);
+    const size_t need = (size_t)splits * M * N * sizeof(float) + (colsum ? (size_t)splits * g.tiles_m * 2 * N * sizeof(float) : 0);
     if (!workspace || workspace_bytes < need || !aligned16(workspace)) splits = 1;     // one pass, fewer blocks
   }
-  if (splits == 1) return launch_gemm_bf16_256_x3(g, false, epilogue, 1, s);
-  const int per = (ktiles + splits - 1) / splits;
-  g.k_per_split = (per + 5) / 6 * 6 * 64;                // whole six-step periods of the K-major walk (and an even count)
-  g.slab_stride = (int64_t)M * N;
-  g.C = workspace; g.ldc = N;
-  int rc = launch_gemm_bf16_256_x3(g, false, BE_F32, splits, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_x3_sum_slabs, dim3(grid1d((int64_t)M * N / 4)), dim3(kThreads), 0, s,
-                     static_cast<const float *>(workspace), g.slab_stride, splits, M, N,
-                     epilogue == BE_BIAS_LRELU_F32 ? bias : nullptr, alpha, static_cast<float *>(C), ldc);
-  return check_launch("gemm_bf16x3_nt combine");
+  const size_t slab_bytes = splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+  const size_t cs_rows = (size_t)splits * g.tiles_m * 2;
+  if (colsum) {      // colsum[n] = sum_k B[n][k] (the bias gradient when B holds a transposed activation gradient)
+    CDML_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= slab_bytes + cs_rows * N * sizeof(float), CDML_E_BADARG,
+                 "gemm_bf16x3_nt: colsum needs a workspace (cdml_gemm_bf16x3_workspace)");
+    g.colsum_partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + slab_bytes);
+  }
+  int rc;
+  if (splits == 1) {
+    rc = launch_gemm_bf16_256_x3(g, false, epilogue, 1, s);
+  } else {
+    const int per = (ktiles + splits - 1) / splits;
+    g.k_per_split = (per + 5) / 6 * 6 * 64;                // whole six-step periods of the K-major walk (and an even count)
+    g.slab_stride = (int64_t)M * N;
+    g.C = workspace; g.ldc = N;
+    rc = launch_gemm_bf16_256_x3(g, false, BE_F32, splits, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_x3_sum_slabs, dim3(grid1d((int64_t)M * N / 4)), dim3(kThreads), 0, s,
+                       static_cast<const float *>(workspace), g.slab_stride, splits, M, N,
+                       epilogue == BE_BIAS_LRELU_F32 ? bias : nullptr, alpha, static_cast<float *>(C), ldc);
+    rc = check_launch("gemm_bf16x3_nt combine");
+  }
+  if (rc || !colsum) return rc;
+  hipLaunchKernelGGL(k_x3_colsum_final, dim3((N + 31) / 32), dim3(kThreads), 0, s, g.colsum_partial, (int)cs_rows, N, colsum);
+  return check_launch("gemm_bf16x3_nt bias gradient");
 }
 
 // C[M][N] (fp32) = sum_k A[k][M] B[k][N] for fp32 operands given as planes [K][hi | mid | lo] (plane strides along
 // the columns); colsum[n] = sum_k B[k][n] on request (the bias gradient).
 extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B, int64_t ldb,
                                    int64_t plane_b, int M, int N, int K, int products, float *C, int64_t ldc,
-                                   float *colsum, void *workspace, size_t workspace_bytes, cdml_stream_t stream) {
+                                   const float *bias, float alpha, float *colsum, void *workspace,
+                                   size_t workspace_bytes, cdml_stream_t stream) {
   CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16x3_tn: bad argument");
   CDML_REQUIRE(products == 3 || products == 6, CDML_E_BADARG, "gemm_bf16x3_tn: products must be 3 or 6");
   CDML_REQUIRE(M % 256 == 0 && N % 256 == 0 && K % 128 == 0, CDML_E_UNSUPPORTED,
@@ -259,7 +278,8 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
   g.K = ktiles * 64;
   g.tiles_m = M / 256; g.tiles_n = N / 256;
   const int splits = gemm_bf16_256_splits(M, N, g.K);
-  const size_t slab_bytes = splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+  const bool slabs = splits > 1 || bias != nullptr;       // (bias + leaky-relu are applied by the combine pass)
+  const size_t slab_bytes = slabs ? (size_t)splits * M * N * sizeof(float) : 0;
   const size_t cs_rows = (size_t)splits * g.tiles_m * 2;
   const size_t need = slab_bytes + (colsum ? cs_rows * N * sizeof(float) : 0);
   CDML_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && aligned16(workspace)), CDML_E_BADARG,
@@ -268,14 +288,14 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
   const int per = (ktiles + splits - 1) / splits;
   g.k_per_split = (per + 1) / 2 * 2 * 64;
   g.slab_stride = (int64_t)M * N;
-  g.C = splits > 1 ? workspace : static_cast<void *>(C);
-  g.ldc = splits > 1 ? N : ldc;
+  g.C = slabs ? workspace : static_cast<void *>(C);
+  g.ldc = slabs ? N : ldc;
   g.colsum_partial = colsum ? reinterpret_cast<float *>(static_cast<char *>(workspace) + slab_bytes) : nullptr;
   int rc = launch_gemm_bf16_256_x3(g, true, BE_F32, splits, s);
   if (rc) return rc;
-  if (splits > 1) {
+  if (slabs) {
     hipLaunchKernelGGL(k_x3_sum_slabs, dim3(grid1d((int64_t)M * N / 4)), dim3(kThreads), 0, s,
-                       static_cast<const float *>(workspace), g.slab_stride, splits, M, N, (const float *)nullptr, 0.f, C, ldc);
+                       static_cast<const float *>(workspace), g.slab_stride, splits, M, N, bias, alpha, C, ldc);
     if ((rc = check_launch("gemm_bf16x3_tn combine"))) return rc;
   }
   if (colsum) {

@@ -12,6 +12,8 @@ Activations never exist in fp32 between the GEMMs: FC1's epilogue writes h1 as p
 writes dz1 as planes (and takes leaky-relu' from h1's hi plane -- rounding keeps the sign).  Reference lines:
 models.py:59-61 (forward), train.py:141 (its autodiff).
 """
+import os
+
 import torch
 
 from . import ops
@@ -33,7 +35,7 @@ def layout_x3(feature_size, hidden=5000, output_size=256):
 
 
 class TowerWorkspaceX3:
-    def __init__(self, layout, n_rows, device, products=6, planes_in=True, backward=True):
+    def __init__(self, layout, n_rows, device, products=6, planes_in=True, backward=True, transposed=None):
         """planes_in: ``x_hat`` IS the plane buffer (the fused sampler + gather writes planes); False: ``x_hat`` is
         fp32 (rows arriving through the exchange) and the forward pass splits it."""
         L, R = layout, int(n_rows)
@@ -44,24 +46,46 @@ class TowerWorkspaceX3:
         self.layout, self.R, self.products = L, R, products
         bf = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=device)
         f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
+        # ``transposed`` (training, R % 256 == 0, six products): the hidden layer's activations and their gradient are
+        # held TRANSPOSED -- h1^T, dz1^T as [H][hi R | mid R | lo R] -- by computing FC1 and the data gradient with their
+        # operands swapped (C^T = W^T-planes . x-planes^T).  Every product but the narrow FC2 then has BOTH operands
+        # k-contiguous: the weight gradients, which contract over the batch rows, run in the k-contiguous form (0.57 of
+        # the bf16 peak / 6 against 0.47 for the transposed LDS reads of the k-strided form); FC2 (6 % of the flop) takes
+        # the k-strided form instead, and the gathered planes get one transposed copy.
+        # MEASURED SLOWER (1.72 against 1.62 ms/step on one box): dW1 gains less than hoped (605 -> 572 us: it needs a 2-way
+        # K split with a slab combine where FC1 does not), FC2 and dW2 lose 25 us between them, and the transposed copy
+        # of the gathered planes costs 88 us in three launches -- even a perfect copy kernel (25 us) would only draw
+        # level.  Off unless CDML_X3_TRANSPOSED=1; kept, with its tests, as the measured alternative.
+        if transposed is None:
+            transposed = (os.environ.get("CDML_X3_TRANSPOSED") == "1" and backward and R % 256 == 0 and products == 6)
+        if transposed and (R % 256 or not backward):
+            raise ValueError("the transposed activation layout needs a training workspace with rows % 256 == 0")
+        self.transposed = bool(transposed)
         self.x3 = bf(R, 3 * L.Fp)
         self.x_hat = self.x3 if planes_in else f32(R, L.Fp)    # the gather's output (l2-normalised rows)
-        self.h1 = bf(R, 3 * L.Hp)
+        self.h1 = bf(L.Hp, 3 * R) if self.transposed else bf(R, 3 * L.Hp)
         self.z, self.e = f32(R, L.Dp), f32(R, L.Dp)
         self.W1T, self.W2T, self.W2 = bf(L.Hp, 3 * L.Fp), bf(L.Dp, 3 * L.Hp), bf(L.Hp, 3 * L.Dp)
         q = products
         nb = max(ops.gemm_bf16x3_workspace(False, R, L.Dp, L.Hp, q), 16)
         if backward:                                       # (catalogue inference: forward buffers only)
-            self.dz1 = bf(R, 3 * L.Hp)
+            self.dz1 = bf(L.Hp, 3 * R) if self.transposed else bf(R, 3 * L.Hp)
             self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp)
             self.dz2_3 = bf(R, 3 * L.Dp)
             nb = max(nb, ops.gemm_bf16x3_workspace(True, L.Fp, L.Hp, R, q), ops.gemm_bf16x3_workspace(True, L.Hp, L.Dp, R, q))
+            if self.transposed:
+                self.xT = bf(L.Fp, 3 * R)                  # the gathered planes, transposed (dW1's A operand)
+                self.dz2T = bf(L.Dp, 3 * R)                # dz2's planes, transposed (dW2's B operand)
+                nb = max(nb, ops.gemm_bf16x3_workspace(True, R, L.Dp, L.Hp, q),        # FC2 in the k-strided form
+                         ops.gemm_bf16x3_workspace(False, L.Fp, L.Hp, R, q), ops.gemm_bf16x3_workspace(False, L.Hp, L.Dp, R, q))
         self.gemm_ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
         self.tail_done = False
 
     def h1_f32(self):
         """the hidden activations as one fp32 tensor (tests, debugging): the planes summed"""
-        H = self.layout.Hp
+        H, R = self.layout.Hp, self.R
+        if self.transposed:
+            return (self.h1[:, :R].float() + self.h1[:, R:2 * R].float() + self.h1[:, 2 * R:].float()).t().contiguous()
         return self.h1[:, :H].float() + self.h1[:, H:2 * H].float() + self.h1[:, 2 * H:].float()
 
 
@@ -80,10 +104,16 @@ def tower_forward(p, ws, normalize=True):
         ops.split_f32_bf16x3(ws.x_hat, ws.x3, L.Fp)     # sampler + gather writes the planes itself (x_hat IS x3 then)
     else:
         ws.x3 = ws.x_hat
-    ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, ws.x3, L.Fp, ws.W1T, L.Fp, ws.h1, R, L.Hp, L.Fp, products=q,
-                       plane_c=L.Hp, bias=p.b1)
-    ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, ws.h1, L.Hp, ws.W2T, L.Hp, ws.z, R, L.Dp, L.Hp, products=q,
-                       bias=p.b2, workspace=ws.gemm_ws)
+    if ws.transposed:
+        # h1^T = lrelu(W1^T x^T + b1[row]): the weights as the row operand; then z = (h1^T)^T W2 in the k-strided form
+        ops.gemm_bf16x3_nt(ops.BE_ROWBIAS_LRELU_X3, ws.W1T, L.Fp, ws.x3, L.Fp, ws.h1, L.Hp, R, L.Fp, products=q,
+                           plane_c=R, bias=p.b1)
+        ops.gemm_bf16x3_tn(ws.h1, R, ws.W2, L.Dp, ws.z, R, L.Dp, L.Hp, products=q, workspace=ws.gemm_ws, bias=p.b2)
+    else:
+        ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, ws.x3, L.Fp, ws.W1T, L.Fp, ws.h1, R, L.Hp, L.Fp, products=q,
+                           plane_c=L.Hp, bias=p.b1)
+        ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, ws.h1, L.Hp, ws.W2T, L.Hp, ws.z, R, L.Dp, L.Hp, products=q,
+                           bias=p.b2, workspace=ws.gemm_ws)
     ws.tail_done = False
     ws.dz2_planes_done = False
     if normalize:
@@ -102,26 +132,43 @@ def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
         ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
     if not (ws.tail_done and getattr(ws, "dz2_planes_done", False)):      # the fused tail writes the planes itself
         ops.split_f32_bf16x3(ws.dz2, ws.dz2_3, L.Dp)
-    w2 = lambda: ops.gemm_bf16x3_tn(ws.h1, L.Hp, ws.dz2_3, L.Dp, p.gW2, L.Hp, L.Dp, R, products=q,
-                                    workspace=ws.gemm_ws, colsum=p.gb2)
+    T = ws.transposed
+    if T:
+        ops.split_f32_bf16x3(ws.dz2, ws.dz2T, R, transpose=True)                  # [Dp][3 R]
+        # both operands k-contiguous (k = the batch rows): dW2 = h1^T . (dz2^T)^T, db2 = the row sums of dz2^T
+        w2 = lambda: ops.gemm_bf16x3_nt(ops.BE_F32, ws.h1, R, ws.dz2T, R, p.gW2, L.Hp, L.Dp, R, products=q,
+                                        workspace=ws.gemm_ws, colsum=p.gb2)
+    else:
+        w2 = lambda: ops.gemm_bf16x3_tn(ws.h1, L.Hp, ws.dz2_3, L.Dp, p.gW2, L.Hp, L.Dp, R, products=q,
+                                        workspace=ws.gemm_ws, colsum=p.gb2)
     single = after_w1 is None and after_w1_chunk is None
     if single:
         w2()
     # dz1 = (dz2 . W2^T) * lrelu'(h1), written as planes; the sign comes from h1's hi plane
-    ops.gemm_bf16x3_nt(ops.BE_MASK_X3, ws.dz2_3, L.Dp, ws.W2, L.Dp, ws.dz1, R, L.Hp, L.Dp, products=q, plane_c=L.Hp,
-                       aux=ws.h1)
+    if T:
+        ops.gemm_bf16x3_nt(ops.BE_MASK_X3, ws.W2, L.Dp, ws.dz2_3, L.Dp, ws.dz1, L.Hp, R, L.Dp, products=q, plane_c=R,
+                           aux=ws.h1)                                             # dz1^T = (W2 dz2^T) * lrelu'(h1^T)
+        for pl in range(3):                                                       # the gathered planes, transposed
+            ops.transpose_to_bf16(ws.x3[:, pl * L.Fp:(pl + 1) * L.Fp], ws.xT[:, pl * R:(pl + 1) * R], R, L.Fp)
+    else:
+        ops.gemm_bf16x3_nt(ops.BE_MASK_X3, ws.dz2_3, L.Dp, ws.W2, L.Dp, ws.dz1, R, L.Hp, L.Dp, products=q, plane_c=L.Hp,
+                           aux=ws.h1)
     rows = L.Fp // w1_chunks if w1_chunks > 1 else 0
+
+    def dw1(lo, hi, db):
+        if T:      # rows lo .. hi of x^T against all of dz1^T; db1 = the row sums of dz1^T
+            ops.gemm_bf16x3_nt(ops.BE_F32, ws.xT[lo:hi], R, ws.dz1, R, p.gW1[lo:hi], hi - lo, L.Hp, R, products=q,
+                               workspace=ws.gemm_ws, colsum=db)
+        else:      # columns lo .. hi of every plane of x_hat: the same plane stride, the base moved by lo
+            ops.gemm_bf16x3_tn(ws.x3[:, lo:], L.Fp, ws.dz1, L.Hp, p.gW1[lo:hi], hi - lo, L.Hp, R, products=q,
+                               workspace=ws.gemm_ws, colsum=db)
     if after_w1_chunk is not None and w1_chunks > 1 and rows * w1_chunks == L.Fp and rows % 256 == 0:
         for c in range(w1_chunks):
-            lo, hi = c * rows, (c + 1) * rows
             last = c == w1_chunks - 1
-            # columns lo .. hi of every plane of x_hat: the same plane stride, the base moved by lo
-            ops.gemm_bf16x3_tn(ws.x3[:, lo:], L.Fp, ws.dz1, L.Hp, p.gW1[lo:hi], rows, L.Hp, R, products=q,
-                               workspace=ws.gemm_ws, colsum=p.gb1 if last else None)
-            after_w1_chunk(lo * L.Hp, hi * L.Hp + (L.Hp if last else 0))
+            dw1(c * rows, (c + 1) * rows, p.gb1 if last else None)
+            after_w1_chunk(c * rows * L.Hp, (c + 1) * rows * L.Hp + (L.Hp if last else 0))
     else:
-        ops.gemm_bf16x3_tn(ws.x3, L.Fp, ws.dz1, L.Hp, p.gW1, L.Fp, L.Hp, R, products=q, workspace=ws.gemm_ws,
-                           colsum=p.gb1)
+        dw1(0, L.Fp, p.gb1)
         if after_w1_chunk is not None:
             after_w1_chunk(0, L.Fp * L.Hp + L.Hp)
     if after_w1 is not None:

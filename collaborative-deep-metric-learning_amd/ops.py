@@ -384,7 +384,7 @@ def gemm_bf16_tn(A, B, C, M, N, K, workspace=None, colsum=None):
 
 
 # ---- fp32 products on the bf16 MFMA: operands as three bf16 planes (csrc/gemm_bf16x3.hip) ----
-BE_BIAS_LRELU_X3, BE_MASK_X3 = 6, 7
+BE_BIAS_LRELU_X3, BE_MASK_X3, BE_ROWBIAS_LRELU_X3 = 6, 7, 8
 
 
 def split_f32_bf16x3(src, dst, plane, transpose=False):
@@ -400,24 +400,27 @@ def gemm_bf16x3_workspace(tn, M, N, K, products=6):
 
 
 def gemm_bf16x3_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, products=6, plane_c=0, bias=None, aux=None,
-                   alpha=LRELU_ALPHA, workspace=None):
-    """C = epilogue(A . B^T) for fp32 operands given as bf16 planes [rows][hi K | mid K | lo K]."""
+                   alpha=LRELU_ALPHA, workspace=None, colsum=None):
+    """C = epilogue(A . B^T) for fp32 operands given as bf16 planes [rows][hi K | mid K | lo K]; colsum[n] = sum_k
+    B[n][k] on request."""
     ap, ald = _mat16(A)
     bp, bld = _mat16(B)
     if C.dim() != 2 or C.stride(1) != 1:
         raise ValueError("C must be 2-D with unit inner stride")
     call("cdml_gemm_bf16x3_nt", epilogue, ap, ald, plane_a, bp, bld, plane_b, M, N, K, products, _p(C), C.stride(0),
-         plane_c, _p(bias), _p(aux), aux.stride(0) if aux is not None else 0, alpha, _p(workspace),
-         0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())
+         plane_c, _p(bias), _p(aux), aux.stride(0) if aux is not None else 0, alpha, _p(colsum, torch.float32),
+         _p(workspace), 0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())
     return C
 
 
-def gemm_bf16x3_tn(A, plane_a, B, plane_b, C, M, N, K, products=6, workspace=None, colsum=None):
-    """C[M][N] f32 = sum_k A[k][M] B[k][N] for fp32 operands given as bf16 planes [K][hi | mid | lo]."""
+def gemm_bf16x3_tn(A, plane_a, B, plane_b, C, M, N, K, products=6, workspace=None, colsum=None, bias=None,
+                   alpha=LRELU_ALPHA):
+    """C[M][N] f32 = sum_k A[k][M] B[k][N] for fp32 operands given as bf16 planes [K][hi | mid | lo]
+    (bias given: C = lrelu(. + bias))."""
     ap, ald = _mat16(A)
     bp, bld = _mat16(B)
     cp, cld = _mat(C)
-    call("cdml_gemm_bf16x3_tn", ap, ald, plane_a, bp, bld, plane_b, M, N, K, products, cp, cld,
+    call("cdml_gemm_bf16x3_tn", ap, ald, plane_a, bp, bld, plane_b, M, N, K, products, cp, cld, _p(bias), alpha,
          _p(colsum, torch.float32), _p(workspace),
          0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())
     return C

@@ -387,8 +387,10 @@ int cdml_gemm_bf16_tn2(const uint16_t *A1, int64_t lda1, const uint16_t *B1, int
  * problem's.  cdml_split_f32_bf16x3: dst[r][p*plane + c] = plane p of src[r][c] (transpose != 0:
  * dst[c][p*plane + r]).  _nt: C = epilogue(A . B^T), A[M][hi K|mid K|lo K] (plane stride plane_a along k), B[N][..];
  * epilogue 1: fp32 C = lrelu(. + bias); 3: fp32 C; 6: C = the three planes (bf16, plane_c apart) of
- * lrelu(. + bias); 7: C = planes of (. * (aux > 0 ? 1 : alpha)), aux = bf16 [M][ldaux].  N % 256, K % 64.
+ * lrelu(. + bias); 7: C = planes of (. * (aux > 0 ? 1 : alpha)), aux = bf16 [M][ldaux]; 8: 6 with bias[ROW] (a layer
+ * computed transposed).  colsum (nullable; M % 256): colsum[n] = sum_k B[n][k].  N % 256, K % 64.
  * _tn: C[M][N] fp32 = sum_k A[k][M] B[k][N], A[K][hi M|mid M|lo M] (plane stride along the columns), B[K][..];
+ * C = lrelu(. + bias) when bias is given (a forward layer whose activations are stored transposed);
  * colsum[n] = sum_k B[k][n] on request.  M, N % 256, K % 128.  Workspace: cdml_gemm_bf16x3_workspace(tn, ...). */
 int cdml_split_f32_bf16x3(const float *src, int64_t ld_src, int rows, int cols, uint16_t *dst,
                           int64_t ld_dst, int64_t plane, int transpose, cdml_stream_t stream);
@@ -420,11 +422,12 @@ size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int products);
 int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
                         int64_t ldb, int64_t plane_b, int M, int N, int K, int products, void *C,
                         int64_t ldc, int64_t plane_c, const float *bias, const uint16_t *aux,
-                        int64_t ldaux, float alpha, void *workspace, size_t workspace_bytes,
-                        cdml_stream_t stream);
+                        int64_t ldaux, float alpha, float *colsum, void *workspace,
+                        size_t workspace_bytes, cdml_stream_t stream);
 int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B, int64_t ldb,
                         int64_t plane_b, int M, int N, int K, int products, float *C, int64_t ldc,
-                        float *colsum, void *workspace, size_t workspace_bytes, cdml_stream_t stream);
+                        const float *bias, float alpha, float *colsum, void *workspace,
+                        size_t workspace_bytes, cdml_stream_t stream);
 
 /* dst[c][r] = bf16(src[r][c]) (src fp32 or bf16): k-contiguous copies of weights
  * and of activations for the weight-gradient GEMMs (contraction over batch rows). */

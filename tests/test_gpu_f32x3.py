@@ -141,15 +141,18 @@ def test_sample_gather_planes_equal_split_of_the_fp32_gather(mode):
         assert torch.equal(x3[k], _planes(x32[k], Fp))
 
 
+@pytest.mark.parametrize("transposed", [False, True])
 @pytest.mark.parametrize("mode,optimizer", [("uniform", "adam"), ("inbatch", "adam"), ("semihard", "adam"),
                                             ("uniform", "lars"), ("inbatch", "momentum")])
-def test_train_step_matches_the_fp32_mfma_step(mode, optimizer):
+def test_train_step_matches_the_fp32_mfma_step(mode, optimizer, transposed, monkeypatch):
     """TrainStep(precision="f32x3") against TrainStep(precision="f32") from the same seeds: same triplets, embeddings
     and loss of the first step within 1e-5 (both are within 1e-5 of fp64: test_train_steps_config0), every sampler mode
     and optimizer (semi-hard mining picks its negatives from the embeddings: the same ones)."""
     dev = _dev()
     from cdml_amd import engine, train
-    N, F, B = 6000, 500, 128
+    # (transposed: the hidden activations held as h1^T / dz1^T -- engine_x3.TowerWorkspaceX3; rows % 256 == 0)
+    monkeypatch.setenv("CDML_X3_TRANSPOSED", "1" if transposed else "0")
+    N, F, B = 6000, 500, 256 if transposed else 128
     table = engine.FeatureTable.synthetic(N, F, 0, dev)
     rng = np.random.RandomState(1)
     pairs = rng.randint(0, N, size=(3000, 2)).astype(np.int32)
@@ -158,6 +161,7 @@ def test_train_step_matches_the_fp32_mfma_step(mode, optimizer):
     mk = lambda prec: train.TrainStep(table, pairs, B, hidden_size=700, output_size=256, mode=mode, optimizer=optimizer,
                                       base_learning_rate=lr, device=dev, precision=prec)
     a, b = mk("f32"), mk("f32x3")
+    assert b.ws.transposed == transposed
     a.step(); b.step()
     torch.cuda.synchronize()
     D = 256
@@ -193,3 +197,43 @@ def test_vnet_tail_writes_the_planes_of_dz2(mode):
     ops.vnet_tail(mode, z, idx, shift, B, D, 0.8, e, pos, neg, hinge, dz2, dz2_bf16=planes, plane_bf=D)
     assert float(dz2.abs().max()) > 0
     assert torch.equal(planes, _planes(dz2, D))
+
+
+def test_gemm_x3_nt_row_bias_planes_and_colsum():
+    """the two pieces the transposed activation layout adds to the k-contiguous form: epilogue 8 (bias indexed by
+    the output row) and colsum[n] = sum_k B[n][k] (the bias gradient when B is a transposed activation gradient)"""
+    torch.manual_seed(7)
+    dev = _dev()
+    M, N, K = 512, 768, 1024
+    A = torch.randn(M, K, device=dev) * 0.05
+    B = torch.randn(N, K, device=dev) * 0.05
+    bias = torch.randn(M, device=dev) * 0.1
+    A3, B3 = _planes(A, K), _planes(B, K)
+    pc = N + 8
+    out = torch.zeros(M, 3 * pc, dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16x3_nt(ops.BE_ROWBIAS_LRELU_X3, A3, K, B3, K, out, M, N, K, plane_c=pc, bias=bias, alpha=0.2)
+    got = out[:, :N].float() + out[:, pc:pc + N].float() + out[:, 2 * pc:2 * pc + N].float()
+    ref = A.double() @ B.double().t() + bias.double()[:, None]
+    ref = torch.maximum(ref, 0.2 * ref)
+    assert (got.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+    C = torch.empty(M, N, device=dev)
+    cs = torch.empty(N, device=dev)
+    ops.gemm_bf16x3_nt(ops.BE_F32, A3, K, B3, K, C, M, N, K, workspace=_ws(False, M, N, K), colsum=cs)
+    ref2 = A.double() @ B.double().t()
+    assert (C.double() - ref2).abs().max().item() <= 3e-6 * ref2.abs().max().item()
+    refc = B.double().sum(1)
+    assert (cs.double() - refc).abs().max().item() <= 5e-6 * refc.abs().max().item()
+
+
+def test_gemm_x3_tn_with_bias():
+    torch.manual_seed(8)
+    dev = _dev()
+    M, N, K = 512, 256, 1024
+    X = torch.randn(K, M, device=dev) * 0.05
+    W = torch.randn(K, N, device=dev) * 0.05
+    bias = torch.randn(N, device=dev) * 0.1
+    C = torch.empty(M, N, device=dev)
+    ops.gemm_bf16x3_tn(_planes(X, M), M, _planes(W, N), N, C, M, N, K, workspace=_ws(True, M, N, K), bias=bias, alpha=0.2)
+    ref = X.double().t() @ W.double() + bias.double()
+    ref = torch.maximum(ref, 0.2 * ref)
+    assert (C.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
