@@ -993,7 +993,8 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
     const int kt = g.K / kTileK, per = g.k_per_split / kTileK;
     const bool f6 = g.x3_products == 6 && kt % 6 == 0 && per % 6 == 0 && per > 0;
     if constexpr (EPI == BE_F32) {        // the weight gradients of the transposed activation layout: with the column sums
-      if (g.colsum_partial) return f6 ? launch_x3_1<TN, EPI, true, true>(g, splits, s) : launch_x3_1<TN, EPI, false, true>(g, splits, s);
+      // (the general loop: the unrolled period plus the sums is 14 VGPRs over the budget)
+      if (g.colsum_partial) return launch_x3_1<TN, EPI, false, true>(g, splits, s);
     }
     if (f6) return launch_x3_1<TN, EPI, true>(g, splits, s);
   }

@@ -52,8 +52,9 @@ class TowerWorkspaceX3:
         # k-contiguous: the weight gradients, which contract over the batch rows, run in the k-contiguous form (0.57 of
         # the bf16 peak / 6 against 0.47 for the transposed LDS reads of the k-strided form); FC2 (6 % of the flop) takes
         # the k-strided form instead, and the gathered planes get one transposed copy.
-        # MEASURED SLOWER (1.72 against 1.62 ms/step on one box): dW1 gains less than hoped (605 -> 572 us: it needs a 2-way
-        # K split with a slab combine where FC1 does not), FC2 and dW2 lose 25 us between them, and the transposed copy
+        # MEASURED SLOWER (1.69 against 1.62 ms/step on one box): dW1 gains less than hoped (605 -> 558 us: it needs a 2-way
+        # K split with a slab combine where FC1 does not, and the general loop -- the unrolled period plus the column sums
+        # does not fit 256 VGPRs), dW2 gains 7 us, FC2 loses 13, and the transposed copy
         # of the gathered planes costs 88 us in three launches -- even a perfect copy kernel (25 us) would only draw
         # level.  Off unless CDML_X3_TRANSPOSED=1; kept, with its tests, as the measured alternative.
         if transposed is None:
