@@ -34,6 +34,7 @@ CFG_C3 = dict(n_rows=10000000, F=1500, H=5000, D=256, B=8192, steps=2, precision
 CFG_C4 = dict(CFG_C3, precision="bf16")
 CFG_C3_W4 = dict(CFG_C3, world=4)       # four ranks x 2.5 M rows, global batch 32 768
 # the other two gradient-sync forms (TrainStep.GRAD_SYNC_MODES), at config 3's true per-rank size
+CFG_C3_X3 = dict(CFG_C3, precision="f32x3")   # the split-fp32 tower at config 3's per-GPU size, two ranks
 CFG_C3_TWO = dict(CFG_C3, grad_sync_mode="two")
 CFG_C3_SINGLE = dict(CFG_C3, grad_sync_mode="single")
 CFG_C4_SINGLE = dict(CFG_C4, grad_sync_mode="single")
@@ -88,9 +89,10 @@ def _worker(rank, world, port, q, CFG=CFG):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_X3, CFG_X3_BUCKETS, CFG_TABLE, CFG_W4, CFG_C3, CFG_C4, CFG_C3_W4, CFG_C3_TWO, CFG_C3_SINGLE,
-                                 CFG_C4_SINGLE],
-                         ids=["f32", "bf16", "f32x3", "f32x3-bucketed", "trainable-table", "4-ranks", "config3-full-size", "config4-full-size",
+@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_X3, CFG_X3_BUCKETS, CFG_TABLE, CFG_W4, CFG_C3, CFG_C3_X3, CFG_C4, CFG_C3_W4, CFG_C3_TWO,
+                                 CFG_C3_SINGLE, CFG_C4_SINGLE],
+                         ids=["f32", "bf16", "f32x3", "f32x3-bucketed", "trainable-table", "4-ranks", "config3-full-size",
+                              "config3-full-size-f32x3", "config4-full-size",
                               "config3-full-size-4-ranks", "config3-full-size-sync-two", "config3-full-size-sync-single",
                               "config4-full-size-sync-single"])
 def test_two_rank_step_equals_single_rank(gpu, CFG):
@@ -124,8 +126,12 @@ def test_two_rank_step_equals_single_rank(gpu, CFG):
     # mean over the global batch == average of the two ranks' local means
     # (bf16: the ranks round their activations exactly as the single rank does -- same rows, same
     # kernels -- but the k-split of the weight gradient follows the local row count)
-    gtol = 2e-5 if bf16 else 1e-6
-    assert all(np.abs(r[5] - g0).max() < gtol for r in res)
+    # (f32x3: the narrow forward layer splits K by the LOCAL row count -- 8 slabs at 24 576 rows, none at 49 152 -- so z
+    # differs in its last bits between the two runs; where a pre-activation sits within that of zero leaky-relu' flips
+    # and single gradient elements move by 0.8 of one term: 3e-5 seen at config 3's size against max |g| 1e-2.  The fp32
+    # kernels use one K order for every row count and stay within 1e-6.)
+    gtol = 2e-5 if bf16 else 1e-4 if CFG["precision"] == "f32x3" else 1e-6
+    assert all(np.abs(r[5] - g0).max() < gtol for r in res), [float(np.abs(r[5] - g0).max()) for r in res]
     want_idx = np.stack(idx)                                           # [steps, W*B*3]
     got_idx = np.concatenate([r[2] for r in res], axis=1)
     np.testing.assert_array_equal(got_idx, want_idx)                   # same global triplets
