@@ -669,7 +669,10 @@ def rec_f32x3(dev, args, n_s, n_w, table, pairs, B, mode):
              "max_abs_embedding_diff": float((a.ws.e - b.ws.e).abs().max().item()),
              "loss_native_f32": round(a.loss(), 7), "loss_f32x3": round(b.loss(), 7),
              "gradient_rel_l2_diff": float(((ga - gb).norm() / ga.norm().clamp_min(1e-300)).item()),
-             "note": "one step each from identical weights; the parity tests hold both paths to the same bounds against "
+             "note": "one step each from identical weights.  The gradient difference is what two fp32-accurate forward "
+                     "passes give on this iid catalogue: where a pre-activation lies within rounding of zero leaky-relu' "
+                     "flips between them and single gradient elements move by most of one term (|g| itself is a sum of "
+                     "cancelling terms here).  The parity tests hold both paths to the same bounds against "
                      "the fp64 oracle (tests/test_gpu_parity.py::test_train_steps_config0, tests/test_gpu_fullsize.py::"
                      "test_gradients_well_conditioned_production_shape, tests/test_gpu_f32x3.py)"}
     del a
