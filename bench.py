@@ -7,6 +7,13 @@ hinge loss + backward + Adam) on synthetic imitation_data-shaped input.
 Workloads (BASELINE.json `configs`, 0-based):
   N = 1 (default)   config 1: 1 M videos x 1500-d fp32 in HBM, 5000 hidden, 256-d embedding,
                     batch 4096 triplets, in-batch negatives, margin 0.8, Adam.
+  --precision       how the step's fp32 projection products are computed.  "f32x3" (the default since round 4,
+                    by the round-3 ruling): every fp32 operand held as three exact bf16 planes hi | mid | lo
+                    (hi + mid + lo == the fp32 value), every fp32 product as six bf16 plane products on the bf16
+                    MFMA with fp32 accumulation -- fp32 results (held to the fp32 bounds by the parity tests), the
+                    fp32-equivalent flop rate against the bf16 dense peak / 6.  "f32": the same step on the fp32
+                    MFMA (v_mfma_f32_32x32x2_f32); the default line carries it as the `f32_mfma` record, measured
+                    in the same run on the same table, so either reading has a measured number.
   N > 1             config 3: 10 M videos row-sharded over the ranks, batch 8192 triplets per
                     GPU (65 536 global at N = 8), RCCL all-to-all of sampled rows + all-reduce of
                     the gradients.  Weak scaling (per-GPU work fixed).  Started WITHOUT a launcher
@@ -31,9 +38,13 @@ Prints ONE JSON line (rank 0).  Beside the contract's fields:
                  gradient-sync form ran (`grad_sync`: both forms are timed for a few steps before
                  the warm-up and the faster one is kept)
   order / warmup_effective   what ran on the GPU before the timed region
-Secondary records of the default N = 1 line (measured AFTER the headline; each in its own try):
+Secondary records of the default N = 1 line (measured AFTER the headline; each in its own try; those that
+train run at the headline's precision):
+  f32_mfma           the headline workload on the fp32 MFMA (precision "f32": the headline of rounds 1-3), full
+                     record with roofline, after one step of each path from identical weights on identical
+                     triplets compared on the device
   like_for_like      the per-GPU workload of the N > 1 line on ONE GPU holding the whole 10 M-row
-                     catalogue, so that 8-vs-1 compares one workload
+                     catalogue, so that 8-vs-1 compares one workload (the N > 1 lines name it as `scaling_base`)
   dp_form_one_gpu    that workload through the N > 1 step FORM (row exchange + gradient sync hooks
                      over RCCL at world size 1, nothing skipped): each rank's compute floor at N = 8,
                      for both gradient-sync forms
@@ -150,13 +161,27 @@ class KernelTimer:
         return len(self.ev.get(name, []))
 
 
-def pmc_traffic(kernel, bf16=False):
+def csrc_hash():
+    """sha256[:16] over the kernel sources (csrc/*.hip, *.h, sorted): the PMC summaries under profiles/ are
+    stamped with it (profiles/latest_pmc.json, tools/pmc_stamp.py), so a summary taken from other kernels than
+    the ones this run launches is recognised without git (the GPU box has none)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "collaborative-deep-metric-learning_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, bf16=False, name=None):
     """(bytes, source): HBM-side bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC summary
     (profiles/latest_pmc.csv, latest_pmc_bf16.csv for the config-4 path: separate FETCH_SIZE /
     WRITE_SIZE passes of this bench, KiB; FETCH_SIZE doubled per the gfx950 correction) -- an earlier
     builder-run profiling pass, not a measurement of this run; `source` says which file and from when
     (profiles/latest_pmc.json, written by tools/profile_round.sh).  (None, None) if absent."""
-    name = "latest_pmc_bf16" if bf16 else "latest_pmc"
+    name = name or ("latest_pmc_bf16" if bf16 else "latest_pmc")
     path = os.path.join(ROOT, "profiles", name + ".csv")
     if not os.path.exists(path):
         return None, None
@@ -164,7 +189,7 @@ def pmc_traffic(kernel, bf16=False):
     vals = {}
     for r in csv.DictReader(open(path)):
         # `kernel` may leave trailing template arguments (tile-depth / stage tuning) open
-        if r["kernel"] == kernel or (kernel.endswith(",") and r["kernel"].startswith(kernel)):
+        if r["kernel"] == kernel or (not kernel.endswith(">") and r["kernel"].startswith(kernel)):
             vals[r["counter"]] = float(r["mean_per_launch"])
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None, None
@@ -173,7 +198,10 @@ def pmc_traffic(kernel, bf16=False):
         meta = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json"))).get(name, {})
         src += "; taken %s at commit %s" % (meta.get("date", "?"), meta.get("commit", "?"))
     except (OSError, ValueError):
-        pass
+        meta = {}
+    if meta.get("csrc_sha16") != csrc_hash():
+        # the kernels changed since that pass (or it predates the stamp): a byte count of other code is not evidence
+        return None, src + "; STALE: csrc/ differs from the sources that pass profiled, traffic withheld)"
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, src + ")"
 
 
@@ -367,7 +395,10 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0):
                       "achieved = fp32-equivalent rate, peak = bf16 dense peak / %d)" % (x3_products, x3_products))
     flop_launch = sampled * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
     ach = flop_launch / (t_ms * 1e-3) / 1e12
-    tr, src = pmc_traffic(kname, bf16) if (single_gpu and not x3_products) else (None, None)
+    if x3_products:
+        tr, src = pmc_traffic("k_gemm_bf16_256<true, 3, true, true", name="latest_pmc_x3") if single_gpu else (None, None)
+    else:
+        tr, src = pmc_traffic(kname, bf16) if single_gpu else (None, None)
     out["roofline"] = {"bound": "mfma", "kernel": klabel, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                        "frac": round(ach / peak, 4), "traffic": tr, "traffic_source": src,
                        "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch,
@@ -376,7 +407,10 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0):
     k1 = "k_gemm_bf16_256<false, 0>" if bf16 else "k_gemm_f32<true, false, 2, 2, 1,"
     if x3_products:
         k1 = "k_gemm_bf16_256<false, 6, true, true>"
-    tr1, src1 = pmc_traffic(k1, bf16) if (single_gpu and not x3_products) else (None, None)
+    if x3_products:
+        tr1, src1 = pmc_traffic("k_gemm_bf16_256<false, 6, true, true, true", name="latest_pmc_x3") if single_gpu else (None, None)
+    else:
+        tr1, src1 = pmc_traffic(k1, bf16) if single_gpu else (None, None)
     out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": k1 + ("" if (bf16 or x3_products) else " ...>"),
                                "achieved": round(ach1, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach1 / peak, 4), "traffic": tr1, "traffic_source": src1,
@@ -430,7 +464,7 @@ def gather_record(ts, mode, bf16, dev):
     torch.cuda.synchronize(dev)
     t_g = float(np.median([s.elapsed_time(e) for s, e in evs])) / per
     g_ach = gbytes / (t_g * 1e-3) / 1e9
-    tr, src = (None, None) if x3 else pmc_traffic(gk, bf16)
+    tr, src = pmc_traffic("k_sample_gather<%d," % (1 if rpt == 2 else 0), name="latest_pmc_x3") if x3 else pmc_traffic(gk, bf16)
     return {"bound": "hbm", "kernel": gk + ("<6>>" if x3 else " RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": tr,
             "traffic_source": src, "bytes_per_launch": gbytes, "launch_ms": round(t_g, 4), "steps_per_launch": n_st,
@@ -557,6 +591,10 @@ def self_launch(args):
 
 
 # ------------------------------------------------------------ secondary records ------
+LIKE_FOR_LIKE_WORKLOAD = ("config3 per-GPU batch on ONE GPU: 10000000 videos x 1500-d fp32 (61 GB) in HBM, batch 8192 "
+                          "triplets, in-batch negatives (the N>1 lines run this per GPU on a row-sharded catalogue)")
+
+
 def table_10m(keep, dev):
     """The 10 M-row fp32 catalogue (61 GB), shared by like_for_like and dp_form_one_gpu."""
     from cdml_amd import engine
@@ -570,10 +608,10 @@ def rec_like_for_like(dev, args, n_s, n_w, keep):
     from cdml_amd import train
     t10, p10 = table_10m(keep, dev)
     ts10 = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
-                           optimizer="adam", base_learning_rate=0.01, device=dev, gather_ahead=args.gather_ahead)
+                           optimizer="adam", base_learning_rate=0.01, device=dev, gather_ahead=args.gather_ahead,
+                           precision=args.precision)
     el = timed_steps(ts10, n_s, n_w, dev)
-    return {"workload": "config3 per-GPU batch on ONE GPU: 10000000 videos x 1500-d fp32 (61 GB) in HBM, batch 8192 "
-                        "triplets, in-batch negatives (the N>1 lines run this per GPU on a row-sharded catalogue)",
+    return {"workload": LIKE_FOR_LIKE_WORKLOAD, "precision": args.precision,
             "value": round(8192 * n_s / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n_s * 1e3, 4),
             "steps": n_s, "warmup": n_w}
 
@@ -597,14 +635,14 @@ def rec_dp_form(dev, args, n_s, n_w, keep):
                            "grad_sync=GradSync(skip_self=False)) over RCCL at world size 1 (self-copies): the "
                            "per-rank compute floor of the N>1 step form; exchange capacity = all requests at "
                            "world 1 (1.39 x padded at world 8)",
-               "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())}
+               "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()), "precision": args.precision}
         forms = {"bucketed": "dW1 in two split-K row blocks + dW2, all-reduce per bucket under the next GEMM",
                  "two": "dW1 as one split-K launch, its all-reduce under the dW2 launch, [dW2|db2] after",
                  "single": "one stream-K launch for dW1+dW2, then ONE all-reduce"}
         for form in train.TrainStep.GRAD_SYNC_MODES:
             ts = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
                                  optimizer="adam", base_learning_rate=0.01, device=dev, exchange=ex, grad_sync=gs,
-                                 batch_global=8192, grad_sync_mode=form)
+                                 batch_global=8192, grad_sync_mode=form, precision=args.precision)
             el = timed_steps(ts, n_s, n_w, dev)
             ts.check_inputs()
             out[form] = {"ms_per_step": round(el / n_s * 1e3, 4), "triplets_per_s": round(8192 * n_s / el, 1),
@@ -640,22 +678,29 @@ def rec_reference_recipe(dev, args, n_s, n_w, table):
     (tf.contrib defaults) at learning rate 1.0, margin 0.8 -- on the 1 M-row table."""
     from cdml_amd import train
     pairs = torch.from_numpy(synth_pairs(table.n_rows, 300000, seed=0)).to(dev)
+    x3 = 6 if args.precision == "f32x3" else 0
     ts = train.TrainStep(table, pairs, 1024, output_size=D, hidden_size=H, margin=MARGIN, mode="uniform",
-                         optimizer="lars", base_learning_rate=1.0, device=dev, gather_ahead=args.gather_ahead)
+                         optimizer="lars", base_learning_rate=1.0, device=dev, gather_ahead=args.gather_ahead,
+                         precision="f32x3" if x3 else "f32")
     n = max(n_s, 60)
-    el, kt, sampled, how = measure_job(ts, n, max(n_w, 5), dev, False)
+    el, kt, sampled, how = measure_job(ts, n, max(n_w, 5), dev, None if x3 else False)
     out = {"workload": "reference recipe (train.py:354-364): %d videos x 1500-d fp32, batch 1024 triplets (3072 rows), "
                        "uniform negatives, LARS lr 1.0, margin 0.8, full step" % table.n_rows,
+           "precision": "f32x3" if x3 else "f32",
            "value": round(1024 * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4), "steps": n,
            "loss": round(ts.loss(), 6)}
-    out.update(gemm_records(kt, ts.R, False, sampled, how, False))
+    out.update(gemm_records(kt, ts.R, False, sampled, how, False, x3_products=x3))
     return out
 
 
-def rec_f32x3(dev, args, n_s, n_w, table, pairs, B, mode):
-    """The headline step with its fp32 products on the bf16 MFMA (precision "f32x3": every operand as three exact
-    bf16 planes, six plane products per fp32 product, fp32 accumulate -- csrc/gemm_bf16x3.hip), same table, batch,
-    sampler and optimizer.  Before timing, one step of it and one of the native fp32 step are taken from the same
+X3_DTYPE = ("f32 values as 3 exact bf16 planes (hi + mid + lo == the f32 value), 6 bf16-MFMA plane products per f32 product, "
+            "f32 accumulate")
+
+
+def rec_other_fp32_path(dev, args, n_s, n_w, table, pairs, B, mode, other):
+    """The headline workload on the OTHER fp32 path -- `other` = "f32" (v_mfma_f32_32x32x2_f32: the headline of rounds
+    1-3, record `f32_mfma`) when the headline runs precision "f32x3", and the reverse -- same table, batch, sampler and
+    optimizer, with its own kernel timers and roofline.  Before timing, one step of each path is taken from the same
     weights on the same triplets and compared on the device."""
     from cdml_amd import train
     mk = lambda prec: train.TrainStep(table, pairs, B, output_size=D, hidden_size=H, margin=MARGIN, mode=mode,
@@ -667,7 +712,7 @@ def rec_f32x3(dev, args, n_s, n_w, table, pairs, B, mode):
     ga, gb = a.params.grad.double(), b.params.grad.double()
     check = {"same_triplets": bool(torch.equal(a.idx, b.idx)),
              "max_abs_embedding_diff": float((a.ws.e - b.ws.e).abs().max().item()),
-             "loss_native_f32": round(a.loss(), 7), "loss_f32x3": round(b.loss(), 7),
+             "loss_f32_mfma": round(a.loss(), 7), "loss_f32x3": round(b.loss(), 7),
              "gradient_rel_l2_diff": float(((ga - gb).norm() / ga.norm().clamp_min(1e-300)).item()),
              "note": "one step each from identical weights.  The gradient difference is what two fp32-accurate forward "
                      "passes give on this iid catalogue: where a pre-activation lies within rounding of zero leaky-relu' "
@@ -675,28 +720,22 @@ def rec_f32x3(dev, args, n_s, n_w, table, pairs, B, mode):
                      "cancelling terms here).  The parity tests hold both paths to the same bounds against "
                      "the fp64 oracle (tests/test_gpu_parity.py::test_train_steps_config0, tests/test_gpu_fullsize.py::"
                      "test_gradients_well_conditioned_production_shape, tests/test_gpu_f32x3.py)"}
-    del a
+    ts = a if other == "f32" else b
+    del a, b
     torch.cuda.empty_cache()
+    x3 = 6 if other == "f32x3" else 0
     n = max(n_s, 60)
-    el, kt, sampled, how = measure_job(b, n, max(n_w, 10), dev, None)
-    out = {"workload": "the headline workload (%d videos, batch %d, %s negatives, Adam) with precision f32x3: fp32 operands as "
-                       "three exact bf16 planes, six bf16 MFMA plane products per fp32 product, fp32 accumulate"
-                       % (table.n_rows, B, mode),
+    el, kt, sampled, how = measure_job(ts, n, max(n_w, 10), dev, None if x3 else False)
+    out = {"workload": "the headline workload (%d videos, batch %d, %s negatives, Adam) with precision %s"
+                       % (table.n_rows, B, mode, "f32x3" if x3 else "f32: the projection products on the fp32 MFMA "
+                                                                    "(v_mfma_f32_32x32x2_f32), the headline path of rounds 1-3"),
            "value": round(B * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4), "steps": n,
-           "dtype": "f32 values as 3 exact bf16 planes, 6 plane products on the bf16 MFMA, f32 accumulate",
-           "loss": round(b.loss(), 6), "against_native_f32": check}
-    out.update(gemm_records(kt, b.R, False, sampled, how, False, x3_products=6))
-    del b
+           "dtype": X3_DTYPE if x3 else "f32 (fp32 MFMA)",
+           "loss": round(ts.loss(), 6), "f32_mfma_against_f32x3": check}
+    out.update(gemm_records(kt, ts.R, False, sampled, how, True, x3_products=x3))
+    del ts
     torch.cuda.empty_cache()
-    # the reference's own recipe (train.py:354-364: batch 1024, uniform negatives, LARS lr 1.0) on this path
-    rp = torch.from_numpy(synth_pairs(table.n_rows, 300000, seed=0)).to(dev)
-    r = train.TrainStep(table, rp, 1024, output_size=D, hidden_size=H, margin=MARGIN, mode="uniform", optimizer="lars",
-                        base_learning_rate=1.0, device=dev, precision="f32x3", gather_ahead=args.gather_ahead)
-    el = timed_steps(r, n, max(n_w, 10), dev)
-    r_loss = round(r.loss(), 6)
-    del r
-    torch.cuda.empty_cache()
-    # and a run that LEARNS (data_learnable's catalogue): both paths from the same seeds, the loss along the way
+    # a run that LEARNS (data_learnable's catalogue): both paths from the same seeds, the loss along the way
     tl, pl = learnable_catalogue(200000, dev)
     curves = {}
     for prec in ("f32", "f32x3"):
@@ -711,9 +750,6 @@ def rec_f32x3(dev, args, n_s, n_w, table, pairs, B, mode):
         del t
         torch.cuda.empty_cache()
     out["learnable_catalogue_loss_every_15_steps"] = curves
-    out["reference_recipe"] = {"workload": "batch 1024 triplets (3072 rows), uniform negatives, LARS lr 1.0, margin 0.8 at precision f32x3",
-                               "value": round(1024 * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4),
-                               "steps": n, "loss": r_loss}
     return out
 
 
@@ -768,13 +804,14 @@ def rec_learnable(dev, args, n_s, n_w, B):
     from cdml_amd import train
     tl, pl = learnable_catalogue(200000, dev)
     tsl = train.TrainStep(tl, pl, B, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
-                          optimizer="adam", base_learning_rate=2e-4, device=dev, gather_ahead=args.gather_ahead)
+                          optimizer="adam", base_learning_rate=2e-4, device=dev, gather_ahead=args.gather_ahead,
+                          precision=args.precision)
     tsl.step()
     l0 = tsl.loss()
     n_l = max(n_s, 60)
     el = timed_steps(tsl, n_l, n_w, dev)
     return {"workload": "config1 step (batch %d in-batch) on a learnable 200000 x 1500 catalogue "
-                        "(co-watched videos share one of 2000 clusters), Adam 2e-4" % B,
+                        "(co-watched videos share one of 2000 clusters), Adam 2e-4" % B, "precision": args.precision,
             "value": round(B * n_l / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n_l * 1e3, 4),
             "steps": n_l, "loss_first_step": round(l0, 4), "loss_last_step": round(tsl.loss(), 4)}
 
@@ -789,8 +826,10 @@ def main():
     ap.add_argument("--mode", default=None, choices=["inbatch", "uniform", "semihard", "predict"])
     ap.add_argument("--batch", type=int, default=None, help="triplets per GPU per step (default 4096 for config 1, else 8192)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "f32x3", "f32x3-3"],
-                    help="bf16 = BASELINE config 4 path (fp16 table + bf16 MFMA); not the headline metric")
+    ap.add_argument("--precision", default="f32x3", choices=["f32x3", "f32", "bf16", "f32x3-3"],
+                    help="f32x3 (default): fp32 operands as three exact bf16 planes, six plane products per fp32 product on "
+                         "the bf16 MFMA, f32 accumulate; f32: the fp32 MFMA; bf16 = BASELINE config 4 path (fp16 table + "
+                         "bf16 MFMA), not the headline metric; f32x3-3: three products (16-bit operands), measurement only")
     ap.add_argument("--train-table", action="store_true",
                     help="also train the catalogue rows (lazy Adam; build-defined, not the headline metric)")
     ap.add_argument("--gather-ahead", type=int, default=4, help="steps fetched per sampler+gather launch (1 GPU)")
@@ -805,7 +844,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary records of the default N=1 line")
     ap.add_argument("--extras", default=None,
                     help="comma list of secondary records to run (default: all): like_for_like,dp_form_one_gpu,"
-                         "config4_per_gpu,reference_recipe,fusion_resnet,predict,data_learnable")
+                         "config4_per_gpu,reference_recipe,fusion_resnet,predict,data_learnable,f32_mfma")
     ap.add_argument("--only", default=None, choices=["reference_recipe", "fusion_resnet", "data_learnable"],
                     help="run ONE secondary record as the job (its JSON line; for rocprofv3 runs of that workload)")
     ap.add_argument("--no-settle", action="store_true",
@@ -869,7 +908,8 @@ def main():
             r = rec_learnable(dev, args, n_s, n_w, args.batch or 4096)
         out = {"metric": "triplets/sec", "value": r["value"], "unit": "triplets/s", "n_gpus": 1, "steps": r["steps"],
                "warmup": n_w, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": r["workload"]}, args.only: r}
+               "vs_baseline": None, "dtype": X3_DTYPE if args.precision == "f32x3" else "f32 (fp32 MFMA)", "data": "synthetic",
+               "config": {"workload": r["workload"], "precision": args.precision}, args.only: r}
         print(json.dumps(out), file=result_out, flush=True)
         return
 
@@ -989,9 +1029,9 @@ def main():
             "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("bf16 (fp16 table, f32 accumulate)" if bf16 else "f32" if not x3 else
-                      "f32 values as 3 exact bf16 planes, %d plane products per fp32 product on the bf16 MFMA, f32 accumulate%s"
-                      % (x3, "" if x3 == 6 else " (16-bit operands: NOT an fp32 equivalent)")),
+            "dtype": ("bf16 (fp16 table, f32 accumulate)" if bf16 else "f32 (fp32 MFMA)" if not x3 else X3_DTYPE if x3 == 6 else
+                      "f32 values as 3 bf16 planes, 3 plane products per f32 product on the bf16 MFMA (16-bit operands: NOT "
+                      "an fp32 equivalent; measurement only)"),
             "data": "synthetic",
             "config": {"workload": "%s: %d videos x %d-d %s in HBM%s, %d hidden, %d-d embed, batch %d triplets/GPU "
                                    "(%d global), %s negatives, margin %.1f, Adam, full step (sample+gather+fwd+loss+bwd+opt)"
@@ -1002,10 +1042,16 @@ def main():
                        "global_batch": world * B, "rows_per_triplet": rpt,
                        "parallelism": "dp%d" % world + ("" if world == 1 else " row-sharded table, all-to-all rows + all-reduce grads"),
                        "hipgraph": ts.use_graph if ts.use_graph == "split" else bool(ts.use_graph), "trainable_table": bool(args.train_table),
-                       "gather_steps_per_launch": ts.gather_ahead},
+                       "gather_steps_per_launch": ts.gather_ahead, "precision": args.precision},
             "loss": round(loss, 6),
         }
         if world > 1:
+            # 1 -> N compares ONE workload only against this base: the bare N = 1 command times BASELINE config 1 (1 M rows,
+            # batch 4096), the N > 1 commands config 3's per-GPU shape (10 M rows row-sharded, batch 8192 per GPU)
+            out["scaling_base"] = {"workload": LIKE_FOR_LIKE_WORKLOAD, "precision": args.precision,
+                                   "where": "the `like_for_like` record of the N = 1 line (python bench.py --gpus 1): its value "
+                                            "is the 1-GPU triplets/s of the workload every rank of this line runs",
+                                   "per_gpu_batch": B, "rows_global": n_rows}
             out["ranks_seen"] = dist.get_world_size()
             out["comm_backend"] = {"backend": dist.get_backend(), "launcher": "self" if os.environ.get("CDML_BENCH_PHASE_DIR") else "external",
                                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
@@ -1035,12 +1081,14 @@ def main():
                         % ("" if args.no_settle else "0.3 s settle loop, "))
 
         # ---- secondary records (after the headline; the failure of one must not cost the line) ----
-        run_extras = config1 and mode == "inbatch" and not args.no_extras and not args.train_table and not x3
+        run_extras = config1 and mode == "inbatch" and not args.no_extras and not args.train_table and x3 in (0, 6)
         if run_extras:
             del ts
             torch.cuda.empty_cache()
+            other = "f32" if x3 else "f32x3"
+            other_name = "f32_mfma" if x3 else "f32x3"
             want = set((args.extras or "like_for_like,dp_form_one_gpu,config4_per_gpu,reference_recipe,fusion_resnet,"
-                                       "predict,data_learnable,f32x3").split(","))
+                                       "predict,data_learnable," + other_name).split(","))
             n_s, n_w = min(args.steps, 30), min(max(args.warmup, 3), 5)
             keep = {}
 
@@ -1053,7 +1101,7 @@ def main():
                 except Exception as e:                   # noqa: BLE001
                     out[name] = {"error": repr(e)[:300]}
                 torch.cuda.empty_cache()
-            attempt("f32x3", lambda: rec_f32x3(dev, args, n_s, n_w, table, pairs, B, mode))
+            attempt(other_name, lambda: rec_other_fp32_path(dev, args, n_s, n_w, table, pairs, B, mode, other))
             attempt("reference_recipe", lambda: rec_reference_recipe(dev, args, n_s, n_w, table))
             attempt("data_learnable", lambda: rec_learnable(dev, args, n_s, n_w, B))
             del table, pairs

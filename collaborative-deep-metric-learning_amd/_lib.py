@@ -109,6 +109,11 @@ SIGNATURES = {
     "cdml_lars_step": (_i, [_p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p, _p]),
     "cdml_lars_multi_scratch_floats": (_sz, []),
     "cdml_lars_multi": (_i, [_p, _p, _p, _p, _p, _i, _f, _p, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
+    "cdml_lars_multi_norms": (_i, [_p, _p, _p, _p, _i, _p, _p]),
+    "cdml_lars_matrix": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _f, _f, _f, _f, _p, _p, _p, _i64, _i64, _p,
+                              _i64, _i64, _i, _p, _p, _p]),
+    "cdml_momentum_matrix": (_i, [_p, _p, _p, _i, _i, _f, _p, _f, _i, _p, _i64, _i64, _p, _i64, _i64, _i, _p, _p, _p, _i,
+                                  _p, _p, _p]),
 }
 
 _lib = None

@@ -90,19 +90,17 @@ bool x3_kmajor() {
   return !(e && e[0] == 'p');
 }
 
-// split-K for the k-contiguous forms with too few tiles for the chip (fp32 slab output only)
-int x3_nt_splits(int M, int N, int ktiles) {
-  const int64_t tiles = (int64_t)((M + 255) / 256) * (N / 256);
-  if (tiles >= 192) return 1;
-  // fill one round of the 256 CUs as evenly as possible with the fewest slabs, at least 8 K-tiles per block
-  int best = 1;
-  double best_eff = 0.0;
-  for (int s = 1; s <= 16 && ktiles / s >= 8; ++s) {
-    const int64_t blocks = tiles * s;
-    const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
-    if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
-  }
-  return best;
+// split-K for the k-contiguous forms whose output is ONE tile column wide (N = 256: the narrow forward layer, whose
+// M / 256 tiles alone would leave most of the chip idle; fp32 slab output only).  The K partition is a function of K
+// ALONE -- slabs of ten six-step periods (60 K-tile steps), at most 16 of them, summed in slab order by k_x3_sum_slabs --
+// so the result does not depend on how many rows the call carries: a batch computed whole and the same batch computed
+// in row blocks (two ranks against one) give the same bits.  (Round 3 chose the slab count from the tile count: 8
+// slabs at 8 192 rows, none at 49 152, and leaky-relu' flips near zero then loosened the two-rank gradient bound.)
+// Wider outputs are never split: their tiles fill the chip at every batch size the step uses.
+int x3_nt_splits(int N, int ktiles) {
+  if (N / 256 != 1) return 1;
+  const int s = ktiles / 60;
+  return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 
 }  // namespace
@@ -133,7 +131,7 @@ extern "C" int cdml_split_f32_bf16x3(const float *src, int64_t ld_src, int rows,
 extern "C" size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int products) {
   if (M <= 0 || N <= 0 || K <= 0 || (products != 3 && products != 6) || K % 64) return 0;
   const int ktiles = products * (K / 64);
-  const int splits = tn ? gemm_bf16_256_splits(M, N, ktiles * 64) : x3_nt_splits(M, N, ktiles);
+  const int splits = tn ? gemm_bf16_256_splits(M, N, ktiles * 64) : x3_nt_splits(N, ktiles);
   const size_t cs = (size_t)splits * ((M + 255) / 256) * 2 * N * sizeof(float) + (size_t)N * sizeof(float);   // bias-gradient partials
   return (size_t)splits * M * N * sizeof(float) + cs;       // (a slab even unsplit: the k-strided form's bias pass reads one)
 }
@@ -221,7 +219,7 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   g.K = ktiles * 64; g.k_per_split = g.K;
   g.tiles_m = (M + 255) / 256; g.tiles_n = N / 256;
   hipStream_t s = (hipStream_t)stream;
-  int splits = planes_out ? 1 : x3_nt_splits(M, N, ktiles);
+  int splits = planes_out ? 1 : x3_nt_splits(N, ktiles);
   if (splits > 1) {
     const size_t need = (size_t)splits * M * N * sizeof(float) + (colsum ? (size_t)splits * g.tiles_m * 2 * N * sizeof(float) : 0);
     if (!workspace || workspace_bytes < need || !aligned16(workspace)) splits = 1;     // one pass, fewer blocks

@@ -38,6 +38,21 @@ __device__ __forceinline__ void adam1(float &w, const float g, float &m, float &
   w = w - __fdiv_rn(m * lr_t, __fsqrt_rn(v) + eps);
 }
 
+// One LARS update (tf.contrib.opt.LARSOptimizer: compute_lr + apply_momentum) given the variable's scaled learning
+// rate slr = lr * trust: g' = g + wd w; acc = momentum acc + slr g'; w -= acc.  Roundings spelled out for the same
+// reason as adam1: the flat kernel and the matrix kernel (which also writes the GEMMs' operand copies) agree bit for bit.
+__device__ __forceinline__ void lars1(float &w, const float g, float &a, const float slr, const float momentum,
+                                      const float wd) {
+  a = __fmaf_rn(momentum, a, slr * __fmaf_rn(wd, w, g));
+  w = w - a;
+}
+
+// tf.train.MomentumOptimizer (TF's ApplyMomentum): accum = accum*momentum + g; w -= nesterov ? g*lr + accum*momentum*lr : accum*lr
+__device__ __forceinline__ void momentum1(float &w, const float g, float &a, const float lr, const float momentum,
+                                          const int nesterov) {
+  a = __fmaf_rn(a, momentum, g);
+  w = w - (nesterov ? __fmaf_rn(g, lr, a * momentum * lr) : a * lr);
+}
 
 __global__ void __launch_bounds__(kThreads)
 k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
@@ -91,51 +106,14 @@ k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m
 // PLANES = 3 (precision "f32x3"): the copies are the three bf16 planes hi | mid | lo of the new weights (their
 // sum is the fp32 value; plane p of W^T starts plane_t elements after plane p - 1 in every row, of W plane_c).
 constexpr int kAT = 64;
+// The bf16 operand copies of one updated 64 x 64 tile (res[p][q][u] = new W[k0 + 32 p + 2 tr + q][n0 + c4 + u]): wc = W as
+// bf16 [K][N], wt = W^T as bf16 [N][K] through the LDS tile sT; PLANES = 3: the three planes hi | mid | lo of the value.
 template <int PLANES>
-__global__ void __launch_bounds__(kThreads)
-k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
-                   float *__restrict__ v, int K, int N, float lr_imm, const float *__restrict__ lr_dev,
-                   float b1, float b2, float eps, int64_t t_imm, uint64_t *__restrict__ t_dev,
-                   __bf16 *__restrict__ wt, int64_t ldt, __bf16 *__restrict__ wc, int64_t ldc,
-                   float *__restrict__ bw, const float *__restrict__ bg, float *__restrict__ bm,
-                   float *__restrict__ bv, int bn, int advance, uint32_t *__restrict__ tickets,
-                   int64_t plane_t, int64_t plane_c) {
+__device__ __forceinline__ void tile_copies(float (&res)[2][2][4], uint32_t (&sT)[64][64 / 2 + 1], __bf16 *__restrict__ wt,
+                                            int64_t ldt, __bf16 *__restrict__ wc, int64_t ldc, int64_t plane_t,
+                                            int64_t plane_c, int k0, int n0) {
   using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
-  __shared__ float s_lr_t;
-  __shared__ uint32_t sT[kAT][kAT / 2 + 1];           // [column n][row pair]: two bf16 of one column per word
-  if (threadIdx.x == 0) {
-    const double t = (double)t_imm + (t_dev ? (double)(*t_dev) : 0.0);
-    const double lr = lr_dev ? (double)(*lr_dev) : (double)lr_imm;
-    s_lr_t = (float)(lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
-  }
-  __syncthreads();
-  const float lr_t = s_lr_t;
-  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-  const int tiles_n = N / kAT;
-  const int k0 = (blockIdx.x / tiles_n) * kAT, n0 = (blockIdx.x % tiles_n) * kAT;
   const int tr = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
-  // a thread takes two adjacent rows of four columns per pass: the transpose goes through LDS as
-  // 32-bit words (the two rows' values of one column), 33-word rows -> at most 2-way bank conflicts
-  float res[2][2][4];                                  // the new weights (PLANES > 1: what the planes so far leave)
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int r = p * 32 + 2 * tr;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int64_t i = (int64_t)(k0 + r + q) * N + n0 + c4;
-      float4 w4 = *reinterpret_cast<float4 *>(w + i);
-      const float4 g4 = *reinterpret_cast<const float4 *>(g + i);
-      float4 m4 = *reinterpret_cast<float4 *>(m + i);
-      float4 v4 = *reinterpret_cast<float4 *>(v + i);
-#define CDML_ADAM1(c) adam1(w4.c, g4.c, m4.c, v4.c, omb1, omb2, lr_t, eps);
-      CDML_ADAM1(x) CDML_ADAM1(y) CDML_ADAM1(z) CDML_ADAM1(w)
-#undef CDML_ADAM1
-      *reinterpret_cast<float4 *>(w + i) = w4;
-      *reinterpret_cast<float4 *>(m + i) = m4;
-      *reinterpret_cast<float4 *>(v + i) = v4;
-      res[p][q][0] = w4.x; res[p][q][1] = w4.y; res[p][q][2] = w4.z; res[p][q][3] = w4.w;
-    }
-  }
 #pragma unroll
   for (int pl = 0; pl < PLANES; ++pl) {
     if (pl && wt) __syncthreads();                     // the previous plane's tile has been read out
@@ -172,6 +150,53 @@ k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__
       }
     }
   }
+}
+
+template <int PLANES>
+__global__ void __launch_bounds__(kThreads)
+k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
+                   float *__restrict__ v, int K, int N, float lr_imm, const float *__restrict__ lr_dev,
+                   float b1, float b2, float eps, int64_t t_imm, uint64_t *__restrict__ t_dev,
+                   __bf16 *__restrict__ wt, int64_t ldt, __bf16 *__restrict__ wc, int64_t ldc,
+                   float *__restrict__ bw, const float *__restrict__ bg, float *__restrict__ bm,
+                   float *__restrict__ bv, int bn, int advance, uint32_t *__restrict__ tickets,
+                   int64_t plane_t, int64_t plane_c) {
+  __shared__ float s_lr_t;
+  __shared__ uint32_t sT[kAT][kAT / 2 + 1];           // [column n][row pair]: two bf16 of one column per word
+  if (threadIdx.x == 0) {
+    const double t = (double)t_imm + (t_dev ? (double)(*t_dev) : 0.0);
+    const double lr = lr_dev ? (double)(*lr_dev) : (double)lr_imm;
+    s_lr_t = (float)(lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  }
+  __syncthreads();
+  const float lr_t = s_lr_t;
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  const int tiles_n = N / kAT;
+  const int k0 = (blockIdx.x / tiles_n) * kAT, n0 = (blockIdx.x % tiles_n) * kAT;
+  const int tr = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+  // a thread takes two adjacent rows of four columns per pass: the transpose goes through LDS as
+  // 32-bit words (the two rows' values of one column), 33-word rows -> at most 2-way bank conflicts
+  float res[2][2][4];                                  // the new weights (PLANES > 1: what the planes so far leave)
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int r = p * 32 + 2 * tr;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int64_t i = (int64_t)(k0 + r + q) * N + n0 + c4;
+      float4 w4 = *reinterpret_cast<float4 *>(w + i);
+      const float4 g4 = *reinterpret_cast<const float4 *>(g + i);
+      float4 m4 = *reinterpret_cast<float4 *>(m + i);
+      float4 v4 = *reinterpret_cast<float4 *>(v + i);
+#define CDML_ADAM1(c) adam1(w4.c, g4.c, m4.c, v4.c, omb1, omb2, lr_t, eps);
+      CDML_ADAM1(x) CDML_ADAM1(y) CDML_ADAM1(z) CDML_ADAM1(w)
+#undef CDML_ADAM1
+      *reinterpret_cast<float4 *>(w + i) = w4;
+      *reinterpret_cast<float4 *>(m + i) = m4;
+      *reinterpret_cast<float4 *>(v + i) = v4;
+      res[p][q][0] = w4.x; res[p][q][1] = w4.y; res[p][q][2] = w4.z; res[p][q][3] = w4.w;
+    }
+  }
+  tile_copies<PLANES>(res, sT, wt, ldt, wc, ldc, plane_t, plane_c, k0, n0);
   if (bw) {                                          // the bias vector: element i of the first ceil(bn / 256) blocks
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < bn; i += gridDim.x * kThreads) {
       float wi = bw[i], mi = bm[i], vi = bv[i];
@@ -228,11 +253,10 @@ k_lars_apply(float *__restrict__ w, const float *__restrict__ g, float *__restri
   const float slr = lr * trust;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const float wi = w[i];
-    const float gi = g[i] + wd * wi;
-    const float a = momentum * acc[i] + slr * gi;
+    float wi = w[i], a = acc[i];
+    lars1(wi, g[i], a, slr, momentum, wd);
     acc[i] = a;
-    w[i] = wi - a;
+    w[i] = wi;
   }
 }
 
@@ -325,13 +349,102 @@ k_lars_multi_apply(float *__restrict__ w, const float *__restrict__ g, float *__
     float4 w4 = reinterpret_cast<float4 *>(w)[i];
     const float4 g4 = reinterpret_cast<const float4 *>(g)[i];
     float4 a4 = reinterpret_cast<float4 *>(acc)[i];
-#define CDML_LARS1(c)                                    \
-  a4.c = momentum * a4.c + slr * (g4.c + wd * w4.c);     \
-  w4.c -= a4.c;
+#define CDML_LARS1(c) lars1(w4.c, g4.c, a4.c, slr, momentum, wd);
     CDML_LARS1(x) CDML_LARS1(y) CDML_LARS1(z) CDML_LARS1(w)
 #undef CDML_LARS1
     reinterpret_cast<float4 *>(acc)[i] = a4;
     reinterpret_cast<float4 *>(w)[i] = w4;
+  }
+  if (step_dev && grid_last_block(tickets) && threadIdx.x == 0) *step_dev += 1;
+}
+
+// ---- LARS / momentum on a weight MATRIX, writing the GEMMs' operand copies with the update ----------------------
+// What k_adam_matrix_bf16 is for Adam: the bf16 (config 4) or three-plane (precision "f32x3") copies of the new
+// weights come out of the update's own registers, so the reference's actual recipe (LARS, train.py:354) needs no
+// separate split / transpose / cast launches after the optimizer.  RULE 1 = LARS: the trust ratios of the matrix'
+// segment and of the bias' segment are reduced from k_lars_multi_norms' partials by every block itself, in the fixed
+// order k_lars_multi_apply uses (same bits); RULE 2 = momentum (Nesterov on request).  Same element arithmetic as the
+// flat kernels (lars1 / momentum1).
+struct MatRule {
+  float lr_imm; const float *lr_dev;
+  float momentum, wd, eeta, eps;
+  int nesterov;
+  const float *scratch;          // LARS: k_lars_multi_norms' partial pairs
+  int blk_w0, blk_w1, blk_b0, blk_b1;   // partial-pair ranges of the matrix' and of the bias' segment
+  float *norms_w, *norms_b;      // optional: (|w|, |g|) of the two variables (block 0 writes them)
+};
+
+template <int PLANES, int RULE>
+__global__ void __launch_bounds__(kThreads)
+k_rule_matrix(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ acc, int K, int N, MatRule R,
+              __bf16 *__restrict__ wt, int64_t ldt, __bf16 *__restrict__ wc, int64_t ldc, float *__restrict__ bw,
+              const float *__restrict__ bg, float *__restrict__ bacc, int bn, uint64_t *__restrict__ step_dev,
+              uint32_t *__restrict__ tickets, int64_t plane_t, int64_t plane_c) {
+  __shared__ uint32_t sT[kAT][kAT / 2 + 1];
+  __shared__ double s_part[2][kThreads / kWave];
+  __shared__ float s_slr[2];
+  const float lr = R.lr_dev ? *R.lr_dev : R.lr_imm;
+  if (RULE == 1) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    for (int v = 0; v < 2; ++v) {                        // the matrix, then its bias vector
+      const int b0 = v ? R.blk_b0 : R.blk_w0, b1 = v ? R.blk_b1 : R.blk_w1;
+      double a = 0, c = 0;
+      for (int k = b0 + threadIdx.x; k < b1; k += kThreads) {
+        a += (double)R.scratch[2 * k];
+        c += (double)R.scratch[2 * k + 1];
+      }
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, kWave);
+        c += __shfl_xor(c, o, kWave);
+      }
+      if (lane == 0) { s_part[0][wave] = a; s_part[1][wave] = c; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double wn2 = 0, gn2 = 0;
+        for (int k = 0; k < kThreads / kWave; ++k) { wn2 += s_part[0][k]; gn2 += s_part[1][k]; }
+        const float wn = sqrtf((float)wn2), gn = sqrtf((float)gn2);
+        const float trust = (wn > 0.f && gn > 0.f) ? R.eeta * wn / (gn + R.wd * wn + R.eps) : 1.0f;
+        s_slr[v] = (b1 > b0) ? lr * trust : lr;
+        float *no = v ? R.norms_b : R.norms_w;
+        if (no && blockIdx.x == 0 && b1 > b0) { no[0] = wn; no[1] = gn; }
+      }
+      __syncthreads();
+    }
+  }
+  const float slr_w = RULE == 1 ? s_slr[0] : lr, slr_b = RULE == 1 ? s_slr[1] : lr;
+  const int tiles_n = N / kAT;
+  const int k0 = (blockIdx.x / tiles_n) * kAT, n0 = (blockIdx.x % tiles_n) * kAT;
+  const int tr = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+  float res[2][2][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int r = p * 32 + 2 * tr;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int64_t i = (int64_t)(k0 + r + q) * N + n0 + c4;
+      float4 w4 = *reinterpret_cast<float4 *>(w + i);
+      const float4 g4 = *reinterpret_cast<const float4 *>(g + i);
+      float4 a4 = *reinterpret_cast<float4 *>(acc + i);
+#define CDML_RULE1(c)                                                  \
+  if (RULE == 1) lars1(w4.c, g4.c, a4.c, slr_w, R.momentum, R.wd);     \
+  else momentum1(w4.c, g4.c, a4.c, lr, R.momentum, R.nesterov);
+      CDML_RULE1(x) CDML_RULE1(y) CDML_RULE1(z) CDML_RULE1(w)
+#undef CDML_RULE1
+      *reinterpret_cast<float4 *>(w + i) = w4;
+      *reinterpret_cast<float4 *>(acc + i) = a4;
+      res[p][q][0] = w4.x; res[p][q][1] = w4.y; res[p][q][2] = w4.z; res[p][q][3] = w4.w;
+    }
+  }
+  tile_copies<PLANES>(res, sT, wt, ldt, wc, ldc, plane_t, plane_c, k0, n0);
+  if (bw) {
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < bn; i += gridDim.x * kThreads) {
+      float wi = bw[i], ai = bacc[i];
+      if (RULE == 1) lars1(wi, bg[i], ai, slr_b, R.momentum, R.wd);
+      else momentum1(wi, bg[i], ai, lr, R.momentum, R.nesterov);
+      bacc[i] = ai;
+      bw[i] = wi;
+    }
   }
   if (step_dev && grid_last_block(tickets) && threadIdx.x == 0) *step_dev += 1;
 }
@@ -385,10 +498,10 @@ k_momentum(float *__restrict__ w, const float *__restrict__ g, float *__restrict
   const float lr = lr_dev ? *lr_dev : lr_imm;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    const float a = acc[i] * momentum + gi;
+    float wi = w[i], a = acc[i];
+    momentum1(wi, g[i], a, lr, momentum, nesterov);
     acc[i] = a;
-    w[i] -= nesterov ? (gi * lr + a * momentum * lr) : (a * lr);
+    w[i] = wi;
   }
 }
 
@@ -403,7 +516,7 @@ int grid_elems(int64_t n, int per_thread) {
 
 using namespace cdml;
 
-extern "C" int cdml_version(void) { return 2000; }
+extern "C" int cdml_version(void) { return 3000; }
 extern "C" const char *cdml_last_error(void) { return err_buf(); }
 
 extern "C" int cdml_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float lr,
@@ -495,30 +608,23 @@ extern "C" int cdml_lars_step(float *w, const float *g, float *acc, int64_t n, f
   return check_launch("lars_step");
 }
 
-extern "C" size_t cdml_lars_multi_scratch_floats(void) { return 2 * (size_t)kLarsBlocks; }
-
-extern "C" int cdml_lars_multi(float *w, const float *g, float *acc, const int64_t *seg_offsets,
-                               const int64_t *seg_sizes, int n_seg, float lr, const float *lr_dev,
-                               float momentum, float weight_decay, float eeta, float eps, float *scratch,
-                               float *norms_out, uint64_t *step_dev_advance, uint32_t *tickets,
-                               cdml_stream_t stream) {
-  CDML_REQUIRE(w && g && acc && scratch && seg_offsets && seg_sizes, CDML_E_BADARG, "lars_multi: bad argument");
-  CDML_REQUIRE(n_seg >= 1 && n_seg <= kMaxSeg, CDML_E_UNSUPPORTED, "lars_multi: 1..%d segments, got %d", kMaxSeg, n_seg);
-  CDML_REQUIRE(!step_dev_advance || tickets, CDML_E_BADARG, "lars_multi: advancing the step counter needs the ticket words");
-  CDML_REQUIRE(aligned16(w) && aligned16(g) && aligned16(acc), CDML_E_ALIGN, "lars_multi: buffers must be 16-B aligned");
-  LarsSegs S;
+// segments -> LarsSegs: offsets, and the norm blocks dealt in proportion to the segment sizes (at least one each,
+// kLarsBlocks at most in all).  One function for every LARS entry point: the norms launch and the launches that
+// reduce its partials must agree on the layout.
+static int lars_layout(const int64_t *seg_offsets, const int64_t *seg_sizes, int n_seg, LarsSegs &S, int &nb, int64_t &total) {
+  CDML_REQUIRE(seg_offsets && seg_sizes, CDML_E_BADARG, "lars: segment arrays required");
+  CDML_REQUIRE(n_seg >= 1 && n_seg <= kMaxSeg, CDML_E_UNSUPPORTED, "lars: 1..%d segments, got %d", kMaxSeg, n_seg);
   S.n_seg = n_seg;
-  int64_t total = 0;
+  total = 0;
   for (int k = 0; k < n_seg; ++k) {
     CDML_REQUIRE(seg_sizes[k] > 0 && (seg_sizes[k] & 3) == 0 && seg_offsets[k] == total, CDML_E_BADARG,
-                 "lars_multi: segments must tile the buffer contiguously in multiples of 4 floats (segment %d)", k);
+                 "lars: segments must tile the buffer contiguously in multiples of 4 floats (segment %d)", k);
     S.off[k] = total;
     total += seg_sizes[k];
   }
   S.off[n_seg] = total;
-  // norm blocks in proportion to the segment sizes, at least one each, kLarsBlocks at most in all
   const int budget = kLarsBlocks - n_seg;
-  int nb = 0;
+  nb = 0;
   for (int k = 0; k < n_seg; ++k) {
     S.blk[k] = nb;
     int64_t want = (seg_sizes[k] / 4 + kThreads * 8 - 1) / (kThreads * 8);          // >= 8 float4 per thread
@@ -528,11 +634,131 @@ extern "C" int cdml_lars_multi(float *w, const float *g, float *acc, const int64
   }
   S.blk[n_seg] = nb;
   for (int k = n_seg + 1; k <= kMaxSeg; ++k) { S.off[k] = total; S.blk[k] = nb; }
+  return CDML_OK;
+}
+
+extern "C" size_t cdml_lars_multi_scratch_floats(void) { return 2 * (size_t)kLarsBlocks; }
+
+extern "C" int cdml_lars_multi(float *w, const float *g, float *acc, const int64_t *seg_offsets,
+                               const int64_t *seg_sizes, int n_seg, float lr, const float *lr_dev,
+                               float momentum, float weight_decay, float eeta, float eps, float *scratch,
+                               float *norms_out, uint64_t *step_dev_advance, uint32_t *tickets,
+                               cdml_stream_t stream) {
+  CDML_REQUIRE(w && g && acc && scratch && seg_offsets && seg_sizes, CDML_E_BADARG, "lars_multi: bad argument");
+  CDML_REQUIRE(!step_dev_advance || tickets, CDML_E_BADARG, "lars_multi: advancing the step counter needs the ticket words");
+  CDML_REQUIRE(aligned16(w) && aligned16(g) && aligned16(acc), CDML_E_ALIGN, "lars_multi: buffers must be 16-B aligned");
+  LarsSegs S;
+  int nb = 0;
+  int64_t total = 0;
+  if (int rc = lars_layout(seg_offsets, seg_sizes, n_seg, S, nb, total)) return rc;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_lars_multi_norms, dim3(nb), dim3(kThreads), 0, s, w, g, S, scratch);
   hipLaunchKernelGGL(k_lars_multi_apply, dim3(grid_elems(total, 4)), dim3(kThreads), 0, s, w, g, acc, S, lr, lr_dev,
                      momentum, weight_decay, eeta, eps, scratch, norms_out, step_dev_advance, tickets);
   return check_launch("lars_multi");
+}
+
+// LARS with the GEMMs' operand copies written by the update (config 4: bf16, planes = 1; precision "f32x3": three bf16
+// planes, planes = 3).  cdml_lars_multi_norms first (one launch over every variable of the flat buffer), then one
+// cdml_lars_matrix launch per weight matrix, each with its bias vector riding along: w / g / acc are the FLAT buffers,
+// seg_matrix / seg_bias (-1: none) index the segment arrays the norms launch was given, K x N the matrix' shape.
+extern "C" int cdml_lars_multi_norms(const float *w, const float *g, const int64_t *seg_offsets, const int64_t *seg_sizes,
+                                     int n_seg, float *scratch, cdml_stream_t stream) {
+  CDML_REQUIRE(w && g && scratch, CDML_E_BADARG, "lars_multi_norms: bad argument");
+  CDML_REQUIRE(aligned16(w) && aligned16(g), CDML_E_ALIGN, "lars_multi_norms: buffers must be 16-B aligned");
+  LarsSegs S;
+  int nb = 0;
+  int64_t total = 0;
+  if (int rc = lars_layout(seg_offsets, seg_sizes, n_seg, S, nb, total)) return rc;
+  hipLaunchKernelGGL(k_lars_multi_norms, dim3(nb), dim3(kThreads), 0, (hipStream_t)stream, w, g, S, scratch);
+  return check_launch("lars_multi_norms");
+}
+
+static int check_copies(const char *who, int K, int N, const uint16_t *wt, int64_t ldt, int64_t plane_t, const uint16_t *wc,
+                        int64_t ldc, int64_t plane_c, int planes) {
+  CDML_REQUIRE(planes == 1 || planes == 3, CDML_E_BADARG, "%s: planes must be 1 (bf16 copies) or 3 (hi | mid | lo)", who);
+  CDML_REQUIRE(K > 0 && N > 0 && K % kAT == 0 && N % kAT == 0, CDML_E_UNSUPPORTED,
+               "%s: K and N must be multiples of 64, got K=%d N=%d", who, K, N);
+  CDML_REQUIRE((!wt || (aligned16(wt) && (ldt & 7) == 0 && ldt >= K)) && (!wc || (aligned16(wc) && (ldc & 3) == 0 && ldc >= N)),
+               CDML_E_ALIGN, "%s: 16-B aligned copies, ldt a multiple of 8 (>= K), ldc of 4 (>= N)", who);
+  if (planes == 3)
+    CDML_REQUIRE((!wt || (!(plane_t & 7) && plane_t >= K && ldt >= 2 * plane_t + K)) &&
+                     (!wc || (!(plane_c & 3) && plane_c >= N && ldc >= 2 * plane_c + N)),
+                 CDML_E_ALIGN, "%s: plane strides (W^T: multiple of 8, >= K; W: multiple of 4, >= N) and leading dimensions "
+                 ">= 2 planes + the matrix width", who);
+  return CDML_OK;
+}
+
+extern "C" int cdml_lars_matrix(float *w, const float *g, float *acc, const int64_t *seg_offsets, const int64_t *seg_sizes,
+                                int n_seg, int seg_matrix, int seg_bias, int K, int N, float lr, const float *lr_dev,
+                                float momentum, float weight_decay, float eeta, float eps, const float *scratch,
+                                float *norms_out, uint16_t *wt, int64_t ldt, int64_t plane_t, uint16_t *wc, int64_t ldc,
+                                int64_t plane_c, int planes, uint64_t *step_dev_advance, uint32_t *tickets,
+                                cdml_stream_t stream) {
+  CDML_REQUIRE(w && g && acc && scratch, CDML_E_BADARG, "lars_matrix: bad argument");
+  CDML_REQUIRE(!step_dev_advance || tickets, CDML_E_BADARG, "lars_matrix: advancing the step counter needs the ticket words");
+  CDML_REQUIRE(aligned16(w) && aligned16(g) && aligned16(acc), CDML_E_ALIGN, "lars_matrix: buffers must be 16-B aligned");
+  LarsSegs S;
+  int nb = 0;
+  int64_t total = 0;
+  if (int rc = lars_layout(seg_offsets, seg_sizes, n_seg, S, nb, total)) return rc;
+  CDML_REQUIRE(seg_matrix >= 0 && seg_matrix < n_seg && seg_bias < n_seg && seg_bias != seg_matrix, CDML_E_BADARG,
+               "lars_matrix: segment indices out of range");
+  CDML_REQUIRE(seg_sizes[seg_matrix] == (int64_t)K * N, CDML_E_BADARG, "lars_matrix: segment %d holds %lld floats, not %d x %d",
+               seg_matrix, (long long)seg_sizes[seg_matrix], K, N);
+  if (int rc = check_copies("lars_matrix", K, N, wt, ldt, plane_t, wc, ldc, plane_c, planes)) return rc;
+  MatRule R{};
+  R.lr_imm = lr; R.lr_dev = lr_dev; R.momentum = momentum; R.wd = weight_decay; R.eeta = eeta; R.eps = eps;
+  R.scratch = scratch;
+  R.blk_w0 = S.blk[seg_matrix]; R.blk_w1 = S.blk[seg_matrix + 1];
+  R.norms_w = norms_out ? norms_out + 2 * seg_matrix : nullptr;
+  float *bw = nullptr, *bacc = nullptr;
+  const float *bg = nullptr;
+  int bn = 0;
+  if (seg_bias >= 0) {
+    R.blk_b0 = S.blk[seg_bias]; R.blk_b1 = S.blk[seg_bias + 1];
+    R.norms_b = norms_out ? norms_out + 2 * seg_bias : nullptr;
+    bw = w + S.off[seg_bias]; bg = g + S.off[seg_bias]; bacc = acc + S.off[seg_bias];
+    bn = (int)seg_sizes[seg_bias];
+  }
+  const int64_t o = S.off[seg_matrix];
+  const dim3 grid((K / kAT) * (N / kAT));
+  if (planes == 3)
+    hipLaunchKernelGGL((k_rule_matrix<3, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, w + o, g + o, acc + o, K, N, R,
+                       reinterpret_cast<__bf16 *>(wt), ldt, reinterpret_cast<__bf16 *>(wc), ldc, bw, bg, bacc, bn,
+                       step_dev_advance, tickets, plane_t, plane_c);
+  else
+    hipLaunchKernelGGL((k_rule_matrix<1, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, w + o, g + o, acc + o, K, N, R,
+                       reinterpret_cast<__bf16 *>(wt), ldt, reinterpret_cast<__bf16 *>(wc), ldc, bw, bg, bacc, bn,
+                       step_dev_advance, tickets, (int64_t)0, (int64_t)0);
+  return check_launch("lars_matrix");
+}
+
+// tf.train.MomentumOptimizer on a weight matrix W[K][N] (+ its bias vector), writing the operand copies like
+// cdml_lars_matrix; step_dev_advance (with tickets): also global_step += 1 by the last block.
+extern "C" int cdml_momentum_matrix(float *w, const float *g, float *acc, int K, int N, float lr, const float *lr_dev,
+                                    float momentum, int use_nesterov, uint16_t *wt, int64_t ldt, int64_t plane_t,
+                                    uint16_t *wc, int64_t ldc, int64_t plane_c, int planes, float *bias_w,
+                                    const float *bias_g, float *bias_acc, int bias_n, uint64_t *step_dev_advance,
+                                    uint32_t *tickets, cdml_stream_t stream) {
+  CDML_REQUIRE(w && g && acc, CDML_E_BADARG, "momentum_matrix: bad argument");
+  CDML_REQUIRE(!bias_w || (bias_g && bias_acc && bias_n > 0), CDML_E_BADARG,
+               "momentum_matrix: the bias vector needs its gradient and accumulator");
+  CDML_REQUIRE(!step_dev_advance || tickets, CDML_E_BADARG, "momentum_matrix: advancing the step counter needs the ticket words");
+  CDML_REQUIRE(aligned16(w) && aligned16(g) && aligned16(acc), CDML_E_ALIGN, "momentum_matrix: buffers must be 16-B aligned");
+  if (int rc = check_copies("momentum_matrix", K, N, wt, ldt, plane_t, wc, ldc, plane_c, planes)) return rc;
+  MatRule R{};
+  R.lr_imm = lr; R.lr_dev = lr_dev; R.momentum = momentum; R.nesterov = use_nesterov;
+  const dim3 grid((K / kAT) * (N / kAT));
+  if (planes == 3)
+    hipLaunchKernelGGL((k_rule_matrix<3, 2>), grid, dim3(kThreads), 0, (hipStream_t)stream, w, g, acc, K, N, R,
+                       reinterpret_cast<__bf16 *>(wt), ldt, reinterpret_cast<__bf16 *>(wc), ldc, bias_w, bias_g, bias_acc,
+                       bias_w ? bias_n : 0, step_dev_advance, tickets, plane_t, plane_c);
+  else
+    hipLaunchKernelGGL((k_rule_matrix<1, 2>), grid, dim3(kThreads), 0, (hipStream_t)stream, w, g, acc, K, N, R,
+                       reinterpret_cast<__bf16 *>(wt), ldt, reinterpret_cast<__bf16 *>(wc), ldc, bias_w, bias_g, bias_acc,
+                       bias_w ? bias_n : 0, step_dev_advance, tickets, (int64_t)0, (int64_t)0);
+  return check_launch("momentum_matrix");
 }
 
 extern "C" int cdml_grad_prepare(float *g, const float *w, int64_t n, float l2_scale, float clip_norm,

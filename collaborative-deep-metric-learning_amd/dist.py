@@ -43,6 +43,36 @@ def _host_staged(group):
     return dist.get_backend(group) != "nccl"
 
 
+def _capturing(t=None):
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def new_capture_group(like=None):
+    """A process group over the ranks of ``like`` (None: the world) that is used ONLY inside hipGraph captures.
+
+    Why a group of its own (the hazard round 3 slept around): torch.distributed's RCCL watchdog thread keeps every
+    collective issued EAGERLY on a process group on that group's work list and polls its end event (hipEventQuery,
+    every 100 ms) until it has seen it complete.  The event was recorded on the group's communicator stream; once a
+    capture pulls that stream in (a captured collective on the same group), HIP answers the query of ANY event last
+    recorded there with hipErrorCapturedEvent, the watchdog rethrows, and the process ends -- whenever a capture
+    begins before the watchdog's next poll has retired the last eager work.  Collectives issued DURING a capture are
+    never put on the work list.  So a group that carries no eager collective at all has an empty work list for ever,
+    and its communicator stream may enter captures freely; the groups that do carry eager collectives never see a
+    capture.  Deterministic: nothing depends on the watchdog's period or on how loaded the host is.
+
+    The communicator must come up without a collective (a first collective would be an eager work, and communicator
+    setup cannot run inside a capture): with the default group bound to its device -- init_process_group(...,
+    device_id=torch.device("cuda", i)) -- torch connects a new group's communicator eagerly at creation
+    (distributed_c10d._new_process_group_helper -> eager_connect_single_device / ncclCommSplit).  Without that binding
+    this raises.  Collective call: every rank of ``like`` creates the group at the same point."""
+    default = dist.distributed_c10d._get_default_group()
+    if getattr(default, "bound_device_id", None) is None:
+        raise RuntimeError("capturing RCCL collectives into a hipGraph needs a process group bound to its device: "
+                           "init_process_group(..., device_id=torch.device('cuda', local_rank))")
+    ranks = None if like is None or like is default else dist.get_process_group_ranks(like)
+    return dist.new_group(ranks=ranks, backend="nccl")
+
+
 def all_to_all(out, inp, group=None):
     """Equal-split all-to-all of the leading dimension."""
     if inp.is_cuda and _host_staged(group):
@@ -84,10 +114,14 @@ def exchange_capacity(n_requests, world, factor=1.25):
 class RowExchange:
     """Fetch (normalised) feature rows by GLOBAL id from a row-sharded table."""
 
-    def __init__(self, n_rows_global, group=None, local_gather=None, capacity_factor=1.25, skip_self=True):
+    def __init__(self, n_rows_global, group=None, local_gather=None, capacity_factor=1.25, skip_self=True,
+                 capture_group=None):
         """``skip_self``: with a single rank every request is local, so the two all-to-alls are
-        skipped (False keeps them: the RCCL entry points then run even at world size 1)."""
+        skipped (False keeps them: the RCCL entry points then run even at world size 1).
+        ``capture_group``: the process group the all-to-alls go through INSIDE a hipGraph capture
+        (``new_capture_group``; TrainStep creates it when asked to replay an RCCL step from graphs)."""
         self.group = group
+        self.capture_group = capture_group
         self.skip_self = bool(skip_self)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -144,14 +178,15 @@ class RowExchange:
         n_slots = self.world * cap
         local_only = self.world == 1 and self.skip_self
         recv_ids = send_ids if local_only else self._scratch("recv_ids", (n_slots,), torch.int32, dev)
+        group = self.capture_group if (self.capture_group is not None and _capturing()) else self.group
         if not local_only:
-            all_to_all(recv_ids, send_ids, self.group)
+            all_to_all(recv_ids, send_ids, group)
         stride = out.shape[1]
         rows_out = self._scratch("rows_out", (n_slots, stride), out.dtype, out.device)
         self.local_gather(table, recv_ids, rows_out)
         rows_in = rows_out if local_only else self._scratch("rows_in", (n_slots, stride), out.dtype, out.device)
         if not local_only:
-            all_to_all(rows_in, rows_out, self.group)
+            all_to_all(rows_in, rows_out, group)
         self.unpermute(rows_in, slot, out)
         # kept for scatter_back(): the same routing carries row gradients to their owners
         self.last = (slot, recv_ids, cap)
@@ -173,7 +208,7 @@ class RowExchange:
         if self.world == 1 and self.skip_self:
             return recv_ids, send
         recv = self._scratch("back_recv", (n_slots, stride), rows.dtype, rows.device)
-        all_to_all(recv, send, self.group)
+        all_to_all(recv, send, self.capture_group if (self.capture_group is not None and _capturing()) else self.group)
         return recv_ids, recv
 
     def unpermute(self, rows_in, slot, out):
@@ -211,10 +246,13 @@ class RowExchange:
 class GradSync:
     """Average the flat gradient buffer over the data-parallel group."""
 
-    def __init__(self, group=None, device=None, skip_self=True):
+    def __init__(self, group=None, device=None, skip_self=True, capture_group=None):
         """``skip_self``: a single rank has nothing to average and issues no collective (False
-        keeps the RCCL calls: they then run, and can be captured, even at world size 1)."""
+        keeps the RCCL calls: they then run, and can be captured, even at world size 1).
+        ``capture_group``: the group the all-reduces go through inside a hipGraph capture
+        (``new_capture_group``)."""
         self.group = group
+        self.capture_group = capture_group
         self.world = dist.get_world_size(group)
         self.nccl = dist.get_backend(group) == "nccl"
         self.active = self.world > 1 or (self.nccl and not skip_self)
@@ -239,7 +277,8 @@ class GradSync:
             return None
         if self.nccl:
             op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
-            return (dist.all_reduce(seg, op=op, group=self.group, async_op=True), seg)
+            group = self.capture_group if (self.capture_group is not None and _capturing()) else self.group
+            return (dist.all_reduce(seg, op=op, group=group, async_op=True), seg)
         self(seg)                                    # gloo: synchronous, host-staged
         return None
 
@@ -256,7 +295,8 @@ class GradSync:
         if not self.active:
             return flat_grad
         if self.nccl:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, group=self.group)
+            group = self.capture_group if (self.capture_group is not None and _capturing()) else self.group
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, group=group)
             if not self.avg:
                 flat_grad.div_(self.world)
         elif flat_grad.is_cuda:                      # gloo rehearsal: stage through host
@@ -267,6 +307,27 @@ class GradSync:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             flat_grad.div_(self.world)
         return flat_grad
+
+
+def reduce_input_flags(oob, overflow, group=None, world=None):
+    """The device-side input flags of ONE rank -- ``oob`` (int32[1]: a pair id outside the catalogue) and ``overflow``
+    (RowExchange.overflow, int32[1] bit field: 1 = a peer segment overflowed, 2 = a requested id outside the catalogue;
+    None = no exchange) -- as (oob, overflowed, bad_id) over EVERY rank of ``group`` (maximum; a host read, a sync).
+    Collective: an overflow on one rank poisons every rank's weights through the gradient all-reduce (its rows come back
+    NaN), so every rank has to learn of it -- and raise -- at the same point; a rank that read only its own flag would
+    save a NaN checkpoint while the overflowing rank raised alone and left the others waiting in their next collective."""
+    dev = oob.device
+    ov = overflow.to(torch.int32).view(1) if overflow is not None else torch.zeros(1, dtype=torch.int32, device=dev)
+    f = torch.cat([oob.to(torch.int32).view(1), ov & 1, (ov >> 1) & 1])
+    world = dist.get_world_size(group) if (world is None and dist.is_available() and dist.is_initialized()) else (world or 1)
+    if world > 1:
+        if f.is_cuda and _host_staged(group):
+            h = f.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+            f = h
+        else:
+            dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)
+    return tuple(int(v) for v in f.tolist())
 
 
 class Prefetcher:

@@ -68,19 +68,39 @@ class TowerWorkspaceX3:
         self.z, self.e = f32(R, L.Dp), f32(R, L.Dp)
         self.W1T, self.W2T, self.W2 = bf(L.Hp, 3 * L.Fp), bf(L.Dp, 3 * L.Hp), bf(L.Hp, 3 * L.Dp)
         q = products
-        nb = max(ops.gemm_bf16x3_workspace(False, R, L.Dp, L.Hp, q), 16)
+        # FC2 (one tile column) splits its contraction into slabs -- a partition that depends on K alone, so a batch gives
+        # the same bits whole or in row blocks -- when it is handed the slab workspace; without one it runs in a single
+        # pass.  Catalogue inference in big chunks (>= 192 row tiles fill the chip unsplit) skips the slabs' round trip.
+        nb = max(ops.gemm_bf16x3_workspace(False, R, L.Dp, L.Hp, q), 16) if (backward or R // 256 < 192) else 16
         if backward:                                       # (catalogue inference: forward buffers only)
             self.dz1 = bf(L.Hp, 3 * R) if self.transposed else bf(R, 3 * L.Hp)
             self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp)
             self.dz2_3 = bf(R, 3 * L.Dp)
             nb = max(nb, ops.gemm_bf16x3_workspace(True, L.Fp, L.Hp, R, q), ops.gemm_bf16x3_workspace(True, L.Hp, L.Dp, R, q))
+            if L.Fp % 512 == 0:                            # the bucketed data-parallel step: dW1 in two row blocks of W1,
+                nb = max(nb, ops.gemm_bf16x3_workspace(True, L.Fp // 2, L.Hp, R, q))   # which may pick more slabs each
             if self.transposed:
                 self.xT = bf(L.Fp, 3 * R)                  # the gathered planes, transposed (dW1's A operand)
                 self.dz2T = bf(L.Dp, 3 * R)                # dz2's planes, transposed (dW2's B operand)
                 nb = max(nb, ops.gemm_bf16x3_workspace(True, R, L.Dp, L.Hp, q),        # FC2 in the k-strided form
                          ops.gemm_bf16x3_workspace(False, L.Fp, L.Hp, R, q), ops.gemm_bf16x3_workspace(False, L.Hp, L.Dp, R, q))
+                if L.Fp % 512 == 0:
+                    nb = max(nb, ops.gemm_bf16x3_workspace(False, L.Fp // 2, L.Hp, R, q))
         self.gemm_ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
         self.tail_done = False
+
+    def _sum_planes(self, t, width):
+        return t[:, :width].float() + t[:, width:2 * width].float() + t[:, 2 * width:3 * width].float()
+
+    def x_hat_f32(self):
+        """the gathered, l2-normalised rows as one fp32 tensor [R, Fp] (tests, debugging)"""
+        return self.x_hat if self.x_hat.dtype == torch.float32 else self._sum_planes(self.x_hat, self.layout.Fp)
+
+    def dz1_f32(self):
+        """the hidden layer's pre-activation gradient as one fp32 tensor [R, Hp]"""
+        if self.transposed:
+            return self._sum_planes(self.dz1, self.R).t().contiguous()
+        return self._sum_planes(self.dz1, self.layout.Hp)
 
     def h1_f32(self):
         """the hidden activations as one fp32 tensor (tests, debugging): the planes summed"""

@@ -214,6 +214,16 @@ class TrainStep:
                 self.use_graph = False
                 logging.getLogger("cdml.train").warning(
                     "use_graph ignored: host-staged (gloo) collectives cannot be captured; RCCL ones can")
+            else:
+                # captured collectives go through process groups of their own, which never carry an eager one: the RCCL
+                # watchdog's work list of a captured communicator is then empty by construction (dist.new_capture_group
+                # says why that matters -- round 3 slept 0.25 s before a capture instead).  Created here, in the same
+                # order on every rank (constructing a TrainStep is a collective call when it is to replay RCCL from graphs).
+                for h in (exchange, grad_sync):
+                    if h is not None and getattr(h, "capture_group", None) is None and \
+                            torch.distributed.get_backend(h.group) == "nccl" and (h.world > 1 or not getattr(h, "skip_self", True)
+                                                                                 or getattr(h, "active", False)):
+                        h.capture_group = _cdist.new_capture_group(h.group)
         # row-sharded catalogue: the exchange of step t+1 runs ahead on a side stream
         # into the second x_hat / idx buffer while step t computes
         self.prefetch = None
@@ -429,19 +439,37 @@ class TrainStep:
             # the step counter advances inside the same launch
             ops.adam_step(p.flat, p.grad, self.m, self.v, 0.0, 1, lr_dev=self.lr_dev,
                           t_dev=self.step_dev, advance_tickets=self.adam_tickets)
+        elif self.x3 or self.bf16:
+            # LARS / momentum on the plane (f32x3) or bf16 (config 4) paths: two matrix launches, each weight matrix with
+            # its bias vector, writing the operand copies the GEMMs read with the update (as the Adam launches above do --
+            # round 3 ran separate split / transpose launches after the optimizer); the last one advances the step counter
+            L, o, ws = self.layout, self.layout.offsets, self.ws
+            pt1, pt2, pc2 = (L.Fp, L.Hp, L.Dp) if self.x3 else (0, 0, 0)
+            if self.optimizer == "lars":
+                segs = p.segments()
+                ops.lars_multi_norms(p.flat, p.grad, segs, self.lars_scratch)
+                kw = dict(lr_dev=self.lr_dev)
+                ops.lars_matrix(p.flat, p.grad, self.acc, segs, 0, 1, L.Fp, L.Hp, 0.0, self.lars_scratch, wt=ws.W1T,
+                                plane_t=pt1, **kw)
+                ops.lars_matrix(p.flat, p.grad, self.acc, segs, 2, 3, L.Hp, L.Dp, 0.0, self.lars_scratch, wt=ws.W2T, wc=ws.W2,
+                                plane_t=pt2, plane_c=pc2, step_dev=self.step_dev, tickets=self.adam_tickets, **kw)
+            else:
+                mat = lambda t, i, r, c: t[o[i]:o[i] + r * c].view(r, c)
+                b1, b2 = slice(o[1], o[1] + L.Hp), slice(o[3], o[3] + L.Dp)
+                vec = lambda sl: (p.flat[sl], p.grad[sl], self.acc[sl])
+                ops.momentum_matrix(p.W1, mat(p.grad, 0, L.Fp, L.Hp), mat(self.acc, 0, L.Fp, L.Hp), 0.0, wt=ws.W1T,
+                                    plane_t=pt1, lr_dev=self.lr_dev, bias=vec(b1))
+                ops.momentum_matrix(p.W2, mat(p.grad, 2, L.Hp, L.Dp), mat(self.acc, 2, L.Hp, L.Dp), 0.0, wt=ws.W2T, wc=ws.W2,
+                                    plane_t=pt2, plane_c=pc2, lr_dev=self.lr_dev, bias=vec(b2), step_dev=self.step_dev,
+                                    tickets=self.adam_tickets)
         elif self.optimizer == "momentum":
             ops.momentum_step(p.flat, p.grad, self.acc, 0.0, 0.9, True, lr_dev=self.lr_dev)
+            ops.step_advance(self.step_dev)
         else:
             # LARS: one trust ratio per variable, all four variables in two launches; the second
             # also advances the step counter
             ops.lars_multi(p.flat, p.grad, self.acc, p.segments(), 0.0, self.lars_scratch, lr_dev=self.lr_dev,
                            step_dev=self.step_dev, tickets=self.adam_tickets)
-        if self.bf16 and self.optimizer != "adam":
-            engine_bf16.refresh_weights(p, self.ws)
-        if self.x3 and self.optimizer != "adam":
-            engine_x3.refresh_weights(p, self.ws)
-        if self.optimizer == "momentum":
-            ops.step_advance(self.step_dev)
 
     def _enqueue(self):
         self.fetch()
@@ -543,14 +571,9 @@ class TrainStep:
         """Record ``fn`` (default: the whole step) into a hipGraph.  ``origin``: the stream the capture
         starts on (default: a fresh one) -- RCCL's communicator stream is then one fork from it."""
         torch.cuda.synchronize(self.device)
-        if self.grad_sync is not None or self.exchange is not None:
-            # torch.distributed's RCCL watchdog thread polls the end events of the collectives issued EAGERLY so
-            # far (every 100 ms) until it has seen them complete.  If a capture that involves the same communicator
-            # starts while such a work is still on its list, the poll fails with hipErrorCapturedEvent ("event last
-            # recorded in a capturing stream") and the watchdog ends the process -- seen once in a few runs of the
-            # capture tests on torch 2.10 / RCCL 2.26.  The device is idle here (synchronize above): give the
-            # watchdog two of its periods to retire what the eager steps left.  Captures happen a few times per run.
-            time.sleep(0.25)
+        # (RCCL collectives recorded below go through the hooks' capture-only process groups -- dist.new_capture_group:
+        # no eager collective is ever issued on them, so the watchdog thread has nothing of theirs to poll while their
+        # communicator streams are inside this capture; the eager steps' groups are never captured)
         side = torch.cuda.Stream(self.device) if origin is None else origin
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -595,11 +618,25 @@ class TrainStep:
         """Host check of the device-side input flags (synchronises; called by ``loss()``, by the
         trainer before it saves or evaluates, by bench.py after the timed region): a pair id
         outside the catalogue (the reference's IndexError, inputs.py:158) and, on a row-sharded
-        catalogue, an exchange segment that overflowed (the step then trained on NaN rows)."""
-        if int(self.oob.item()):
-            raise IndexError("a co-watch pair id lies outside the %d-row catalogue" % self.table.n_rows_global)
-        if self.exchange is not None:
-            self.exchange.check_overflow()
+        catalogue, an exchange segment that overflowed (the step then trained on NaN rows).
+        Data-parallel runs: a COLLECTIVE call -- the flags are reduced (maximum) over the gradient
+        all-reduce's group first, because one rank's overflow reaches every rank's weights through
+        the gradient average: every rank raises, at the same point, whichever rank overflowed."""
+        ex = self.exchange
+        if self.grad_sync is not None and self.grad_sync.world > 1:
+            from .dist import reduce_input_flags
+            oob, over, bad = reduce_input_flags(self.oob, None if ex is None else ex.overflow, self.grad_sync.group,
+                                                self.grad_sync.world)
+            where = " (on at least one rank)"
+        else:
+            oob = int(self.oob.item())
+            f = 0 if (ex is None or ex.overflow is None) else int(ex.overflow.item())
+            over, bad, where = f & 1, (f >> 1) & 1, ""
+        if oob or bad:
+            raise IndexError("a co-watch pair id lies outside the %d-row catalogue%s" % (self.table.n_rows_global, where))
+        if over:
+            raise RuntimeError("row exchange: a peer segment overflowed%s (requests are skewed towards one shard): the step "
+                               "trained on NaN rows; raise RowExchange(capacity_factor=%.2f)" % (where, ex.capacity_factor))
 
     def loss(self):
         """Host value of the last step's mean hinge loss (synchronises; also reads the input
@@ -704,7 +741,13 @@ class Trainer:
     def save(self, step):
         if not self.checkpoint_dir:
             return None
-        self.ts.check_inputs()        # never checkpoint weights that were stepped on overflowed (NaN) rows
+        # never checkpoint weights that were stepped on overflowed (NaN) rows: the check is collective (every rank
+        # learns of any rank's overflow and raises here), and a state whose last loss is not finite is not written --
+        # the previous checkpoint (max_to_keep = 1 deletes it below) stays the last good one
+        self.ts.check_inputs()
+        if not torch.isfinite(self.ts.stats[0]).item():
+            self.log.warning("step %d: loss is not finite -- checkpoint NOT written, the previous one is kept", step)
+            return None
         # data-parallel runs: the dense state is replicated -> rank 0 writes it; a trainable
         # table is sharded -> every rank writes its own shard file
         rank = 0

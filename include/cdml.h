@@ -558,6 +558,33 @@ int cdml_lars_multi(float *w, const float *g, float *acc, const int64_t *seg_off
                     float *scratch, float *norms_out, uint64_t *step_dev_advance,
                     uint32_t *tickets, cdml_stream_t stream);
 
+/* LARS / momentum with the GEMMs' operand copies written by the update itself -- what cdml_adam_matrix_bf16 /
+ * cdml_adam_matrix_planes are for Adam, for the optimizer the reference actually runs (train.py:354: LARSOptimizer;
+ * train.py:115-116: MomentumOptimizer).  planes = 1: bf16 copies (config 4); planes = 3: the three bf16 planes
+ * hi | mid | lo of the new weights (precision "f32x3"; plane strides as in cdml_adam_matrix_planes).
+ *   cdml_lars_multi_norms: launch 1 of cdml_lars_multi alone -- per-block partial sums of |w|^2, |g|^2 of every segment
+ *     into scratch (cdml_lars_multi_scratch_floats() floats);
+ *   cdml_lars_matrix: the update of ONE weight matrix (segment seg_matrix of the same segment arrays, K x N row-major)
+ *     and of its bias vector (segment seg_bias, or -1), each with its own trust ratio reduced from those partials;
+ *     w / g / acc are the FLAT buffers; norms_out (nullable) float[2*n_seg] gets (|w|, |g|) of the two variables;
+ *     step_dev_advance (nullable, with tickets): global_step += 1 by the last block -- pass it on the last launch.
+ *   cdml_momentum_matrix: ApplyMomentum on a matrix (w / g / acc point AT the matrix) + its bias vector.
+ * wt_copy = W^T [N][>= K] (nullable), wc_copy = W [K][>= N] (nullable).  Element arithmetic = cdml_lars_multi /
+ * cdml_momentum_step bit for bit. */
+int cdml_lars_multi_norms(const float *w, const float *g, const int64_t *seg_offsets, const int64_t *seg_sizes,
+                          int n_seg, float *scratch, cdml_stream_t stream);
+int cdml_lars_matrix(float *w, const float *g, float *acc, const int64_t *seg_offsets, const int64_t *seg_sizes,
+                     int n_seg, int seg_matrix, int seg_bias, int K, int N, float lr, const float *lr_dev,
+                     float momentum, float weight_decay, float eeta, float eps, const float *scratch,
+                     float *norms_out, uint16_t *wt_copy, int64_t ldt, int64_t plane_t, uint16_t *wc_copy,
+                     int64_t ldc, int64_t plane_c, int planes, uint64_t *step_dev_advance, uint32_t *tickets,
+                     cdml_stream_t stream);
+int cdml_momentum_matrix(float *w, const float *g, float *acc, int K, int N, float lr, const float *lr_dev,
+                         float momentum, int use_nesterov, uint16_t *wt_copy, int64_t ldt, int64_t plane_t,
+                         uint16_t *wc_copy, int64_t ldc, int64_t plane_c, int planes, float *bias_w,
+                         const float *bias_g, float *bias_acc, int bias_n, uint64_t *step_dev_advance,
+                         uint32_t *tickets, cdml_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

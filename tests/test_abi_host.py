@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built):
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(built.SIGNATURES) == syms          # binding table == header
-    assert lib.cdml_version() == 2000
+    assert lib.cdml_version() == 3000
     assert lib.cdml_last_error() is not None
 
 

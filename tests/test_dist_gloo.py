@@ -113,6 +113,14 @@ def _worker(rank, world, port, n_rows, F, q):
         roomy.gather(Shard, hot, out)
         np.testing.assert_allclose(out[:, :F].numpy(), want, atol=1e-7)
         roomy.check_overflow()
+        # the input flags are collective: ONLY the last rank overflowed, every rank learns of it -- one
+        # rank's NaN rows reach every rank's weights through the gradient average, so all of them must raise together
+        oob = torch.zeros(1, dtype=torch.int32)
+        mine = torch.tensor([1 if rank == world - 1 else 0], dtype=torch.int32)
+        assert cdist.reduce_input_flags(oob, mine) == (0, 1, 0)
+        assert cdist.reduce_input_flags(oob, torch.tensor([2 if rank == 0 else 0], dtype=torch.int32)) == (0, 0, 1)
+        assert cdist.reduce_input_flags(torch.tensor([rank % 2], dtype=torch.int32), None) == (1, 0, 0)
+        assert cdist.reduce_input_flags(oob, torch.zeros(1, dtype=torch.int32)) == (0, 0, 0)
         # gradient average
         sync = cdist.GradSync()
         g = torch.full((10,), float(rank + 1))

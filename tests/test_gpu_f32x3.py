@@ -237,3 +237,128 @@ def test_gemm_x3_tn_with_bias():
     ref = X.double().t() @ W.double() + bias.double()
     ref = torch.maximum(ref, 0.2 * ref)
     assert (C.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+
+
+def test_error_at_the_five_production_shapes_against_the_fp32_mfma_kernels():
+    """Every product of the step at its production shape (config 1: 8 192 rows, F = 1500 -> 1536, H = 5000 -> 5120,
+    D = 256) on operands shaped like the step's: max error against fp64, relative to max |result|, of the six-plane
+    form <= 1.5 x the fp32-MFMA kernel's on the SAME operands (plus 2e-8 for products whose fp32 error is at the rounding
+    floor).  The ruling under which precision "f32x3" is the headline path (models.py:59-60, train.py:141)."""
+    torch.manual_seed(7)
+    dev = _dev()
+    R, F, H, D = 8192, 1536, 5120, 256
+    x = torch.rand(R, F, device=dev)
+    x[:, 1500:] = 0
+    x = x / x.norm(dim=1, keepdim=True)                              # unit rows, as the gather hands them over
+    W1 = (torch.rand(F, H, device=dev) * 2 - 1) * (6.0 / 6500) ** 0.5  # Xavier-uniform (models.py:26-30)
+    W2 = (torch.rand(H, D, device=dev) * 2 - 1) * (6.0 / 5256) ** 0.5
+    b1, b2 = torch.randn(H, device=dev) * 0.01, torch.randn(D, device=dev) * 0.01
+    lrelu = lambda t: torch.maximum(t, 0.2 * t)
+    h1 = lrelu(x.double() @ W1.double() + b1.double()).float()
+    dz2 = torch.randn(R, D, device=dev) * 1e-3
+    dz1 = ((dz2.double() @ W2.double().t()) * torch.where(h1 > 0, 1.0, 0.2).double()).float()
+    err = lambda got, ref: (got.double() - ref).abs().max().item() / ref.abs().max().item()
+    res = {}
+    x3, h13, dz13, dz23 = _planes(x, F), _planes(h1, H), _planes(dz1, H), _planes(dz2, D)
+    W1T3, W2T3, W23 = _planes(W1.t().contiguous(), F), _planes(W2.t().contiguous(), H), _planes(W2, D)
+    # FC1
+    ref = lrelu(x.double() @ W1.double() + b1.double())
+    c32 = torch.empty(R, H, device=dev)
+    ops.fc_lrelu_fwd(x, W1, b1, c32, R, F, H, alpha=0.2)
+    c3 = torch.empty(R, H, device=dev)
+    ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, x3, F, W1T3, F, c3, R, H, F, bias=b1, alpha=0.2)
+    res["FC1"] = (err(c3, ref), err(c32, ref))
+    # FC2
+    ref = lrelu(h1.double() @ W2.double() + b2.double())
+    c32 = torch.empty(R, D, device=dev)
+    ops.fc_lrelu_fwd(h1, W2, b2, c32, R, H, D, alpha=0.2)
+    c3 = torch.empty(R, D, device=dev)
+    ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, h13, H, W2T3, H, c3, R, D, H, bias=b2, alpha=0.2, workspace=_ws(False, R, D, H))
+    res["FC2"] = (err(c3, ref), err(c32, ref))
+    # dH1 (times leaky-relu' of h1)
+    ref = (dz2.double() @ W2.double().t()) * torch.where(h1 > 0, 1.0, 0.2).double()
+    c32 = torch.empty(R, H, device=dev)
+    ops.fc_bwd_data(dz2, W2, h1, c32, R, H, D, alpha=0.2)
+    o3 = torch.zeros(R, 3 * H, dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16x3_nt(ops.BE_MASK_X3, dz23, D, W23, D, o3, R, H, D, plane_c=H, aux=h13, alpha=0.2)
+    c3 = o3[:, :H].float() + o3[:, H:2 * H].float() + o3[:, 2 * H:].float()
+    res["dH1"] = (err(c3, ref), err(c32, ref))
+    # dW1, dW2 (+ the bias gradients riding along)
+    for name, a, a3, pa, g, g3, pg, M, N in (("dW1", x, x3, F, dz1, dz13, H, F, H), ("dW2", h1, h13, H, dz2, dz23, D, H, D)):
+        ref = a.double().t() @ g.double()
+        refb = g.double().sum(0)
+        c32, db32 = torch.empty(M, N, device=dev), torch.empty(N, device=dev)
+        ws32 = torch.empty(max(ops.fc_bwd_weight_workspace(R, M, N), 16) // 4, device=dev)
+        ops.fc_bwd_weight(a, g, c32, db32, ws32, R, M, N)
+        c3, db3 = torch.empty(M, N, device=dev), torch.empty(N, device=dev)
+        ops.gemm_bf16x3_tn(a3, pa, g3, pg, c3, M, N, R, workspace=_ws(True, M, N, R), colsum=db3)
+        res[name] = (err(c3, ref), err(c32, ref))
+        res["db" + name[2]] = (err(db3, refb), err(db32, refb))
+    bad = {k: v for k, v in res.items() if not v[0] <= 1.5 * v[1] + 2e-8}
+    assert not bad, "six-plane error above 1.5 x the fp32-MFMA kernel's: %s (all: %s)" % (bad, res)
+
+
+@pytest.mark.parametrize("planes", [3, 1])
+@pytest.mark.parametrize("rule", ["lars", "momentum"])
+def test_lars_and_momentum_write_the_operand_copies_with_the_update(rule, planes):
+    """The reference's own optimizer (LARS, train.py:354) and Nesterov momentum (train.py:115-116) on the weight
+    matrices with the GEMMs' operand copies written by the update itself (cdml_lars_matrix / cdml_momentum_matrix):
+    weights and slots bit-equal to the flat kernels (cdml_lars_multi / cdml_momentum_step), the three planes summing to
+    the new fp32 weights exactly (planes = 3), the bf16 copies their rounding (planes = 1), the step counter advanced
+    once by the last launch."""
+    torch.manual_seed(11)
+    dev = _dev()
+    Fp, Hp, Dp = 256, 512, 256
+    sizes = [Fp * Hp, Hp, Hp * Dp, Dp]
+    segs, o = [], 0
+    for n in sizes:
+        segs.append((o, n))
+        o += n
+    w0 = torch.randn(o, device=dev) * 0.05
+    g = torch.randn(o, device=dev) * 1e-3
+    acc0 = torch.randn(o, device=dev) * 1e-4
+    lr_dev = torch.full((1,), 0.5, device=dev)
+    # flat kernels
+    wa, acca = w0.clone(), acc0.clone()
+    step_a = torch.zeros(1, dtype=torch.int64, device=dev)
+    scratch = torch.zeros(max(ops.lars_scratch_floats(), ops.lars_multi_scratch_floats()), device=dev)
+    if rule == "lars":
+        ops.lars_multi(wa, g, acca, segs, 0.0, scratch, lr_dev=lr_dev, step_dev=step_a, tickets=ops.new_tickets(dev))
+    else:
+        ops.momentum_step(wa, g, acca, 0.0, 0.9, True, lr_dev=lr_dev)
+        ops.step_advance(step_a)
+    # matrix kernels
+    wb, accb = w0.clone(), acc0.clone()
+    step_b = torch.zeros(1, dtype=torch.int64, device=dev)
+    tick = ops.new_tickets(dev)
+    mult = 3 if planes == 3 else 1
+    W1T = torch.zeros(Hp, mult * Fp, dtype=torch.bfloat16, device=dev)
+    W2T = torch.zeros(Dp, mult * Hp, dtype=torch.bfloat16, device=dev)
+    W2 = torch.zeros(Hp, mult * Dp, dtype=torch.bfloat16, device=dev)
+    pt1, pt2, pc2 = (Fp, Hp, Dp) if planes == 3 else (0, 0, 0)
+    if rule == "lars":
+        scratch2 = torch.zeros_like(scratch)
+        ops.lars_multi_norms(wb, g, segs, scratch2)
+        ops.lars_matrix(wb, g, accb, segs, 0, 1, Fp, Hp, 0.0, scratch2, wt=W1T, plane_t=pt1, lr_dev=lr_dev)
+        ops.lars_matrix(wb, g, accb, segs, 2, 3, Hp, Dp, 0.0, scratch2, wt=W2T, wc=W2, plane_t=pt2, plane_c=pc2, lr_dev=lr_dev,
+                        step_dev=step_b, tickets=tick)
+    else:
+        v = lambda t, i, r, c: t[segs[i][0]:segs[i][0] + r * c].view(r, c)
+        b = lambda i: tuple(t[segs[i][0]:segs[i][0] + segs[i][1]] for t in (wb, g, accb))
+        ops.momentum_matrix(v(wb, 0, Fp, Hp), v(g, 0, Fp, Hp), v(accb, 0, Fp, Hp), 0.0, wt=W1T, plane_t=pt1, lr_dev=lr_dev,
+                            bias=b(1))
+        ops.momentum_matrix(v(wb, 2, Hp, Dp), v(g, 2, Hp, Dp), v(accb, 2, Hp, Dp), 0.0, wt=W2T, wc=W2, plane_t=pt2, plane_c=pc2,
+                            lr_dev=lr_dev, bias=b(3), step_dev=step_b, tickets=tick)
+    torch.cuda.synchronize()
+    assert torch.equal(wa, wb) and torch.equal(acca, accb), "matrix form differs from the flat kernel"
+    assert not torch.equal(wb, w0)
+    assert int(step_a.item()) == 1 and int(step_b.item()) == 1
+    W1 = wb[:Fp * Hp].view(Fp, Hp)
+    W2m = wb[segs[2][0]:segs[2][0] + Hp * Dp].view(Hp, Dp)
+    if planes == 3:
+        s3 = lambda t, p: t[:, :p].float() + t[:, p:2 * p].float() + t[:, 2 * p:3 * p].float()
+        assert torch.equal(s3(W1T, Fp), W1.t()) and torch.equal(s3(W2T, Hp), W2m.t()) and torch.equal(s3(W2, Dp), W2m)
+        assert torch.equal(W1T[:, :Fp], W1.t().to(torch.bfloat16))
+    else:
+        assert torch.equal(W1T, W1.t().to(torch.bfloat16)) and torch.equal(W2T, W2m.t().to(torch.bfloat16))
+        assert torch.equal(W2, W2m.to(torch.bfloat16))

@@ -172,31 +172,43 @@ def test_sample_gather_f16_content_past_4gib(cd, table_f16_15m, mode):
     assert float(x[:, :, F:].float().abs().max()) == 0 and int(oob.item()) == 0
 
 
+def _f32_views(ts):
+    """(x_hat, dz1) as fp32 tensors: the fp32 path holds them so, precision "f32x3" as three bf16 planes"""
+    if ts.x3:
+        return ts.ws.x_hat_f32(), ts.ws.dz1_f32()
+    return ts.ws.x_hat, ts.ws.dz1
+
+
 def _check_step_properties(cd, ts, pairs_np, B, rows_per_triplet):
     """Size-independent properties of one step at full size (+ gathered content)."""
     rows = ts.idx.cpu().numpy()
-    xn = ts.ws.x_hat[:, :F].norm(dim=1)
+    x_hat, dz1 = _f32_views(ts)
+    xn = x_hat[:, :F].norm(dim=1)
     assert float((xn - 1).abs().max()) < 1e-5
     en = ts.ws.e.norm(dim=1)
     assert float((en - 1).abs().max()) < 1e-5
     sel = np.unique(np.concatenate([np.arange(0, len(rows), 997), [len(rows) - 1]]))
     want = otower.l2_normalize(_oracle_rows(rows[sel]).astype(np.float64), np.float64)[0]
-    np.testing.assert_allclose(ts.ws.x_hat[sel, :F].cpu().numpy(), want, atol=1e-6)
+    np.testing.assert_allclose(x_hat[sel, :F].cpu().numpy(), want, atol=1e-6)
     assert (rows.astype(np.int64) * 6144 > GIB4).sum() > len(rows) // 5       # the far part IS visited
     assert torch.isfinite(ts.params.grad).all()
-    ref = ts.ws.x_hat.double().T @ ts.ws.dz1[:, :256].double()
+    ref = x_hat.double().T @ dz1[:, :256].double()
     assert float((ts.params.gW1[:, :256].double() - ref).abs().max()) < 1e-5
-    sub = otower.vnet_forward(ts.ws.x_hat[:64, :F].cpu().numpy().astype(np.float64),
+    sub = otower.vnet_forward(x_hat[:64, :F].cpu().numpy().astype(np.float64),
                               *[t.cpu().numpy().astype(np.float64) for t in ts.params.unpadded()],
                               dtype=np.float64)
     assert np.abs(ts.ws.e[:64, :D].cpu().numpy() - sub["l2_norm"]).max() < 1e-5
 
 
-def test_config1_step_on_1m_rows(cd, table_1m):
-    """BASELINE config 1 as stated: 1 M x 1500 fp32 in HBM, B = 4096, in-batch negatives."""
+@pytest.mark.parametrize("precision", ["f32x3", "f32"])
+def test_config1_step_on_1m_rows(cd, table_1m, precision):
+    """BASELINE config 1 as stated: 1 M x 1500 fp32 in HBM, B = 4096, in-batch negatives -- on the headline's path
+    (precision "f32x3": fp32 values as three exact bf16 planes, six plane products per fp32 product) and on the
+    fp32-MFMA path, the same bounds for both."""
     B = 4096
     pairs_np = osynth.cowatch_pairs(table_1m.n_rows, 60000, 0)
-    ts = cd.train.TrainStep(table_1m, torch.as_tensor(pairs_np).to(cd.dev), B, mode="inbatch", device=cd.dev)
+    ts = cd.train.TrainStep(table_1m, torch.as_tensor(pairs_np).to(cd.dev), B, mode="inbatch", device=cd.dev,
+                            precision=precision)
     ts.fetch(); ts.forward_loss(); ts.backward()
     torch.cuda.synchronize()
     np.testing.assert_array_equal(ts.idx.cpu().numpy().reshape(B, 2), pairs_np[np.arange(B) % len(pairs_np)])
@@ -209,11 +221,13 @@ def test_config1_step_on_1m_rows(cd, table_1m):
     assert np.isfinite(ts.loss()) and int(ts.step_dev.item()) == 2
 
 
-def test_config2_step_on_1m_rows(cd, table_1m):
-    """BASELINE config 2 as stated: same catalogue, semi-hard mining over the batch, B = 8192."""
+@pytest.mark.parametrize("precision", ["f32x3", "f32"])
+def test_config2_step_on_1m_rows(cd, table_1m, precision):
+    """BASELINE config 2 as stated: same catalogue, semi-hard mining over the batch, B = 8192 (both fp32 paths)."""
     B = 8192
     pairs_np = osynth.cowatch_pairs(table_1m.n_rows, 60000, 0)
-    ts = cd.train.TrainStep(table_1m, torch.as_tensor(pairs_np).to(cd.dev), B, mode="semihard", device=cd.dev)
+    ts = cd.train.TrainStep(table_1m, torch.as_tensor(pairs_np).to(cd.dev), B, mode="semihard", device=cd.dev,
+                            precision=precision)
     ts.fetch(); ts.forward_loss(); ts.backward()
     torch.cuda.synchronize()
     _check_step_properties(cd, ts, pairs_np, B, 2)

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Stamp a PMC summary under profiles/ with when and from which kernel sources it was taken:
+profiles/latest_pmc.json[NAME] = {date, commit, command, csrc_sha16}.  bench.py withholds `traffic` when the
+stamp's csrc_sha16 is not the hash of the csrc/ it runs (a byte count of other kernels is not evidence).
+usage: python tools/pmc_stamp.py NAME "date text" COMMIT "command"   (run where the summary was taken from: the hash is
+of the working tree's csrc/)"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+name, date, commit, command = sys.argv[1:5]
+path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+meta = json.load(open(path)) if os.path.exists(path) else {}
+meta[name] = {"date": date, "commit": commit, "command": command, "csrc_sha16": bench.csrc_hash()}
+json.dump(meta, open(path, "w"), indent=1)
+print(json.dumps(meta[name]))
