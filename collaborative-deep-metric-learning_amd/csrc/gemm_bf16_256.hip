@@ -56,7 +56,11 @@ using i32x4 = __attribute__((ext_vector_type(4))) int;
 constexpr int kT = 512;
 constexpr int kTileM = 256, kTileN = 256, kTileK = 64;
 constexpr int IMG = 16384;       // one half image: 128 rows x 128 B
-constexpr int BUF = 4 * IMG;     // A-h0 | B-h0 | A-h1 | B-h1
+constexpr int BUF = 4 * IMG;     // one K-tile: A-h0, A-h1, B-h0, B-h1
+// LDS by OPERAND: [A: buf0 h0 | buf0 h1 | buf1 h0 | buf1 h1][B: likewise] (round 4; rounds 1-3 laid it out by buffer).  Every
+// fragment read of an operand is then within 64 KiB of ONE lane base, i.e. inside the 16-bit offset immediate of a ds_read:
+// the second buffer costs no v_add per read (k-strided form: 24 fewer VALU per K-tile, -2 % measured) and no second set
+// of base registers (k-contiguous forms: 229-240 -> 205-226 VGPRs).
 constexpr int SMEM = 2 * BUF;    // 128 KiB
 
 __device__ __forceinline__ uint32_t lds_off(const void *p) {
@@ -187,7 +191,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const uint32_t voff = (img == 0 ? va[i] + hh * d_a : vb[i] + hh * d_b) + kb;
-      dma(img == 0 ? srd_a : srd_b, voff, lds_piece + i * 1024 + buf * BUF + (hh * 2 + img) * IMG);
+      dma(img == 0 ? srd_a : srd_b, voff, lds_piece + i * 1024 + img * (4 * IMG) + buf * (2 * IMG) + hh * IMG);
     }
   };
 
@@ -207,14 +211,14 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const uint32_t voff = (img == 0 ? va[i] + hh * d_a : vb[i] + hh * d_b) + kb;
-      dma(img == 0 ? srd_a : srd_b, voff, lds_piece + i * 1024 + buf * BUF + (hh * 2 + img) * IMG);
+      dma(img == 0 ? srd_a : srd_b, voff, lds_piece + i * 1024 + img * (4 * IMG) + buf * (2 * IMG) + hh * IMG);
     }
   };
 
   // ---- fragment reads: lane (l31, h) holds k = 16*ks + 8*h .. +7 of image row l31 ----
   const int x = (l31 >> 1) & 7;
   const unsigned char *a_rd = smem + (grp * 64 + l31) * 128;
-  const unsigned char *b_rd = smem + IMG + (wc * 32 + l31) * 128;
+  const unsigned char *b_rd = smem + 4 * IMG + (wc * 32 + l31) * 128;
   int sw[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) sw[ks] = ((2 * ks + h) ^ x) * 16;
@@ -243,21 +247,21 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   };
   auto read_a = [&](int buf, int hh, int mi, int ks) {
     if constexpr (!TN)
-      return *reinterpret_cast<const bf16x8 *>(a_rd + buf * BUF + hh * 2 * IMG + mi * 4096 + sw[ks]);
+      return *reinterpret_cast<const bf16x8 *>(a_rd + buf * (2 * IMG) + hh * IMG + mi * 4096 + sw[ks]);
     else
-      return tr_read(smem + buf * BUF + hh * 2 * IMG + ks * 4096, ta[mi][0], ta[mi][1]);
+      return tr_read(smem + buf * (2 * IMG) + hh * IMG + ks * 4096, ta[mi][0], ta[mi][1]);
   };
   auto read_b = [&](int buf, int hh, int ks) {
     if constexpr (!TN)
-      return *reinterpret_cast<const bf16x8 *>(b_rd + buf * BUF + hh * 2 * IMG + sw[ks]);
+      return *reinterpret_cast<const bf16x8 *>(b_rd + buf * (2 * IMG) + hh * IMG + sw[ks]);
     else
-      return tr_read(smem + buf * BUF + IMG + hh * 2 * IMG + ks * 4096, tb[0], tb[1]);
+      return tr_read(smem + 4 * IMG + buf * (2 * IMG) + hh * IMG + ks * 4096, tb[0], tb[1]);
   };
 
   // S16 fragment reads: lane (l15, q) holds k = 32*ks2 + 8*q .. +7 of image row l15 (+ 16-row block)
   const int l15 = lane & 15, q16 = lane >> 4;
   const unsigned char *a16_rd = smem + (grp * 64 + l15) * 128;
-  const unsigned char *b16_rd = smem + IMG + (wc * 32 + l15) * 128;
+  const unsigned char *b16_rd = smem + 4 * IMG + (wc * 32 + l15) * 128;
   const int sw16[2] = {((q16) ^ ((l15 >> 1) & 7)) * 16, ((4 + q16) ^ ((l15 >> 1) & 7)) * 16};
   // TN: a 16x16x32 fragment = k-rows 8q .. 8q+7 of the 32-deep k-step for the 16 columns l15 of a column
   // block: the 16-lane group q reads rows 8q+4sh .. +3 (sh = 0, 1) x 16 columns through ds_read_b64_tr_b16;
@@ -277,15 +281,15 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   }
   auto read_a16 = [&](int buf, int hh, int rb, int ks2) {
     if constexpr (!TN)
-      return *reinterpret_cast<const bf16x8 *>(a16_rd + buf * BUF + hh * 2 * IMG + rb * 2048 + sw16[ks2]);
+      return *reinterpret_cast<const bf16x8 *>(a16_rd + buf * (2 * IMG) + hh * IMG + rb * 2048 + sw16[ks2]);
     else
-      return tr_read(smem + buf * BUF + hh * 2 * IMG + ks2 * 8192, ta16[rb][0], ta16[rb][1]);
+      return tr_read(smem + buf * (2 * IMG) + hh * IMG + ks2 * 8192, ta16[rb][0], ta16[rb][1]);
   };
   auto read_b16 = [&](int buf, int hh, int cb, int ks2) {
     if constexpr (!TN)
-      return *reinterpret_cast<const bf16x8 *>(b16_rd + buf * BUF + hh * 2 * IMG + cb * 2048 + sw16[ks2]);
+      return *reinterpret_cast<const bf16x8 *>(b16_rd + buf * (2 * IMG) + hh * IMG + cb * 2048 + sw16[ks2]);
     else
-      return tr_read(smem + buf * BUF + IMG + hh * 2 * IMG + ks2 * 8192, tb16[cb][0], tb16[cb][1]);
+      return tr_read(smem + 4 * IMG + buf * (2 * IMG) + hh * IMG + ks2 * 8192, tb16[cb][0], tb16[cb][1]);
   };
 
   f32x16 acc[S16 ? 1 : 4][S16 ? 1 : 2];
