@@ -62,6 +62,7 @@ constexpr int BUF = 4 * IMG;     // one K-tile: A-h0, A-h1, B-h0, B-h1
 // the second buffer costs no v_add per read (k-strided form: 24 fewer VALU per K-tile, -2 % measured) and no second set
 // of base registers (k-contiguous forms: 229-240 -> 205-226 VGPRs).
 constexpr int SMEM = 2 * BUF;    // 128 KiB
+constexpr int SMEM_R6 = 10 * IMG;  // 160 KiB (the whole LDS of a CU): the resident-plane walk's 3 A slots + 2 B slots
 
 __device__ __forceinline__ uint32_t lds_off(const void *p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
@@ -72,6 +73,13 @@ __device__ __forceinline__ uint32_t lds_off(const void *p) {
 __device__ __forceinline__ void dma(i32x4 srd, uint32_t voff, uint32_t lds_base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                :: "s"(lds_base), "v"(voff), "s"(srd) : "memory", "m0");
+}
+// the same with the wave-uniform part of the source offset in an SGPR (the instruction's soffset field): the per-lane
+// offset register is then loop-invariant -- no v_add per piece, and nothing for the compiler to hoist into extra VGPRs
+// when a loop is unrolled over many (plane, half, K-tile) combinations
+__device__ __forceinline__ void dma_s(i32x4 srd, uint32_t voff, uint32_t soff, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory", "m0");
 }
 __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
   const uint64_t a = (uint64_t)(uintptr_t)base;
@@ -116,7 +124,7 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
 // the unrolled period with its compile-time DMA skipping, and the general loop is not compiled in.
 // NTCS (X3, k-contiguous form): also sum B over k per column (its own instantiation: compiled into the plain kernels the
 // four sums and their branch cost FC1 25 % -- 514 -> 642 us, measured).
-template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false>
+template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false>
 __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int m0, const int n0, const int k_begin,
                                          const int n_ktiles, void *c_base, const int64_t c_ld, const int c_row0,
                                          const int c_col0, float *cs_row, const int64_t cs_grp_stride,
@@ -552,6 +560,204 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     CDML_BARRIER();
   };
 
+  // ---- X3, six products, whole periods: the RESIDENT-PLANE walk (R6; round 4) ------------------------------------------
+  // What bounds the ping-pong loop is the length of a phase's READ part -- an in-order wave issues its fragment reads,
+  // its LDS-DMA pieces (60-185 cycles each to the issuing wave), their address arithmetic and the walk's scalar
+  // bookkeeping one after the other, and that sum, not the other group's 512-cycle MFMA part, sets the barrier interval
+  // (profiles/r04_tn_ablations.txt: without the DMA issues the k-strided product runs 21 % faster, with half the A
+  // reads 6 %, without the bias-gradient sums 5 %; profiles/r04_tn_lds_counters.csv: the LDS array itself is 20-28 % busy,
+  // no bank conflicts).  The six plane products of a K-tile use A0 three times, A1 twice, A2 once (B alike), and the
+  // K-major walks of round 3 staged 12 (general loop) or 9 (F6) images per K-tile for them.  Here every plane image of a
+  // K-tile is staged ONCE -- 6 images, the minimum -- by keeping the planes RESIDENT: three A slots and two B slots fill
+  // the CU's whole 160 KiB of LDS, the products are ordered B-constant
+  //     (A0,B0) (A1,B0) (A2,B0) (A0,B1) (A1,B1) (A0,B2)          [hh, mh, lh, hm, mm, hl: the same six products]
+  // so that the B FRAGMENTS are read from LDS on three of the six steps only and stay in registers in between (their
+  // slot is free again right after that read), and every one of the period's 12 phases issues exactly ONE half image
+  // (2 pieces per wave) with its source offset in an SGPR: half the DMA pieces of the general loop, two thirds of F6's,
+  // 120 fragment reads per period for 144, no division, no per-piece VALU.
+  //   phase p = 2 S + h (step S, row half h) reads A(S) half h [+ the B fragments at p = 0, 6, 10] and issues:
+  //     p:     0      1      2      3      4      5       6       7       8       9       10      11
+  //     load:  A2.h1  B1.h0  B1.h1  B2.h0  B2.h1  A0'.h0  A0'.h1  B0'.h0  B0'.h1  A1'.h0  A1'.h1  A2'.h0     (' = next K-tile)
+  //     need:  5      6      6      10     10     12      13      12      12      14      15      16         (first read, phase)
+  //     vmcnt: 8      8      8      8      8      6       8       10      12      10      12      6          (what may stay in flight)
+  //   Slots (parity = K-tile & 1 of the block's walk): A1 always slot 1; A0 / A2 slots 0 / 2, swapped on odd K-tiles
+  //   (A0' is loaded into the slot A2 left at phase 5, A2' into the one A0 leaves at phase 11); B0, B1, B2, B0', ...
+  //   alternate between the two B slots.  Every overwrite is issued at least one phase after the last read of what it
+  //   replaces (reads are retired before a phase's first barrier, the lagging group is one barrier behind: the rule of
+  //   the schedule at the top of this file), every image is waited for one phase before its first read.
+  constexpr bool kR6 = X3 && S16 && R6;
+  if constexpr (kR6) {
+    const int n_per = n_ktiles / 6;                        // whole periods (host)
+    if (n_per > 0) {                                       // (an empty split writes zeros)
+      const int w_first = x3_t0 / 6, w_last = w_first + n_per - 1;
+      const uint32_t ws_a = TN ? (uint32_t)(kTileK * g.lda * 2) : (uint32_t)(kTileK * 2);   // bytes per K-tile of a plane
+      const uint32_t ws_b = TN ? (uint32_t)(kTileK * g.ldb * 2) : (uint32_t)(kTileK * 2);
+      const uint32_t ps_a = (uint32_t)(g.x3_plane_a * 2), ps_b = (uint32_t)(g.x3_plane_b * 2);
+      const unsigned char *b16r = smem + 6 * IMG + (wc * 32 + l15) * 128;
+      // k-strided form: the transposed reads address LDS as (lane offset register) + (16-bit immediate).  160 KiB need
+      // three 64-KiB windows: A slots 0, 1 from the lane offsets as they are, A slot 2 and the B slots from copies moved
+      // by 64 / 96 KiB -- made opaque to the optimizer, which otherwise forms one hoisted register per DISTINCT large
+      // constant (dozens over the 24 unrolled phases: 61 spilled VGPRs, measured)
+      int ta_w2[4][2], tb_w[2][2];
+      if constexpr (TN) {
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) {
+            ta_w2[rb][sh] = ta16[rb][sh] + 4 * IMG;
+            asm volatile("" : "+v"(ta_w2[rb][sh]));
+          }
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            tb_w[cb][sh] = tb16[cb][sh] + 6 * IMG;
+            asm volatile("" : "+v"(tb_w[cb][sh]));
+          }
+        }
+      }
+      auto rd_a = [&](int slot, int hh, int rb, int ks2) {
+        if constexpr (!TN)
+          return *reinterpret_cast<const bf16x8 *>(a16_rd + slot * 2 * IMG + hh * IMG + rb * 2048 + sw16[ks2]);
+        else if (slot < 2)
+          return tr_read(smem + slot * 2 * IMG + hh * IMG + ks2 * 8192, ta16[rb][0], ta16[rb][1]);
+        else
+          return tr_read(smem + hh * IMG + ks2 * 8192, ta_w2[rb][0], ta_w2[rb][1]);
+      };
+      auto rd_b = [&](int slot, int hh, int cb, int ks2) {
+        if constexpr (!TN)
+          return *reinterpret_cast<const bf16x8 *>(b16r + slot * 2 * IMG + hh * IMG + cb * 2048 + sw16[ks2]);
+        else
+          return tr_read(smem + slot * 2 * IMG + hh * IMG + ks2 * 8192, tb_w[cb][0], tb_w[cb][1]);
+      };
+      // one half image: plane pl, half hh of operand img at K-tile offset kw (= w * ws_x) -> slot
+      auto issue = [&](int img, int pl, int hh, int slot, uint32_t kw) {
+        const uint32_t so = (img == 0 ? hh * d_a + pl * ps_a : hh * d_b + pl * ps_b) + kw;
+        const uint32_t dst = lds_piece + (img == 0 ? 0 : 6 * IMG) + slot * 2 * IMG + hh * IMG;
+        dma_s(img == 0 ? srd_a : srd_b, img == 0 ? va[0] : vb[0], so, dst);
+        dma_s(img == 0 ? srd_a : srd_b, img == 0 ? va[1] : vb[1], so, dst + 1024);
+      };
+      auto dot_sum = [&](const bf16x8 &f, float acc) {     // acc + the 8 values of f (v_dot2c_f32_bf16 against (1, 1))
+        using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+        const bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf16x2 pr = {f[2 * e], f[2 * e + 1]};
+          acc = __builtin_amdgcn_fdot2_f32_bf16(pr, one, acc, false);
+        }
+        return acc;
+      };
+      // the phase: PH = 2 S + half (compile time), PAR = parity of the K-tile; kw_* = byte offsets of this / the next K-tile
+      auto phase = [&](auto phc, auto parc, const uint32_t kwa_c, const uint32_t kwb_c, const uint32_t kwa_n,
+                       const uint32_t kwb_n, const bool own) {
+        constexpr int PH = decltype(phc)::value, PAR = decltype(parc)::value;
+        constexpr int S = PH >> 1, HALF = PH & 1;
+        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {0, 0, 0, 1, 1, 2};
+        constexpr int SLOT_A[2][3] = {{0, 1, 2}, {2, 1, 0}};     // [parity][plane]
+        constexpr int sa = SLOT_A[PAR][PA[S]];
+        constexpr bool rdB = HALF == 0 && (S == 0 || S == 3 || S == 5);
+        if constexpr (rdB) {
+          constexpr int sb = (PB[S] & 1) ^ PAR;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+              fb0[2 * cb + ks2] = rd_b(sb, 0, cb, ks2);
+              fb1[2 * cb + ks2] = rd_b(sb, 1, cb, ks2);
+            }
+        }
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) fa[ks2][rb] = rd_a(sa, HALF, rb, ks2);
+        if constexpr (PH == 0) issue(0, 2, 1, SLOT_A[PAR][2], kwa_c);
+        if constexpr (PH == 1) issue(1, 1, 0, 1 ^ PAR, kwb_c);
+        if constexpr (PH == 2) issue(1, 1, 1, 1 ^ PAR, kwb_c);
+        if constexpr (PH == 3) issue(1, 2, 0, PAR, kwb_c);
+        if constexpr (PH == 4) issue(1, 2, 1, PAR, kwb_c);
+        if constexpr (PH == 5) issue(0, 0, 0, SLOT_A[PAR ^ 1][0], kwa_n);
+        if constexpr (PH == 6) issue(0, 0, 1, SLOT_A[PAR ^ 1][0], kwa_n);
+        if constexpr (PH == 7) issue(1, 0, 0, PAR ^ 1, kwb_n);
+        if constexpr (PH == 8) issue(1, 0, 1, PAR ^ 1, kwb_n);
+        if constexpr (PH == 9) issue(0, 1, 0, 1, kwa_n);
+        if constexpr (PH == 10) issue(0, 1, 1, 1, kwa_n);
+        if constexpr (PH == 11) issue(0, 2, 0, SLOT_A[PAR ^ 1][2], kwa_n);
+        constexpr int VM[12] = {8, 8, 8, 8, 8, 6, 8, 10, 12, 10, 12, 6};
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM[PH]) : "memory");
+        if constexpr (rdB) pin_b();
+        pin_a();
+        if constexpr (rdB) {
+          if (own) {                                       // bias gradient: this (tile, row group) owns the K-tile
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+              for (int ks2 = 0; ks2 < 2; ++ks2) {
+                cs16[cb] = dot_sum(fb0[2 * cb + ks2], cs16[cb]);
+                cs16[2 + cb] = dot_sum(fb1[2 * cb + ks2], cs16[2 + cb]);
+              }
+          }
+        }
+        CDML_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              acc16[4 * HALF + rb][cb] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 * HALF + rb][cb], 0, 0, 0);
+              acc16[4 * HALF + rb][2 + cb] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 * HALF + rb][2 + cb], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        CDML_BARRIER();
+      };
+      auto period = [&](auto parc, const int w, const bool own) {
+        const int wn = min(w + 1, w_last);                 // past the end: a valid K-tile again (its images are never read)
+        const uint32_t kwa_c = (uint32_t)w * ws_a, kwb_c = (uint32_t)w * ws_b;
+        const uint32_t kwa_n = (uint32_t)wn * ws_a, kwb_n = (uint32_t)wn * ws_b;
+        phase(std::integral_constant<int, 0>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+        phase(std::integral_constant<int, 1>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+        phase(std::integral_constant<int, 2>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+        phase(std::integral_constant<int, 3>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+        phase(std::integral_constant<int, 4>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+        phase(std::integral_constant<int, 5>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+        phase(std::integral_constant<int, 6>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+        phase(std::integral_constant<int, 7>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+        phase(std::integral_constant<int, 8>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+        phase(std::integral_constant<int, 9>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+        phase(std::integral_constant<int, 10>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+        phase(std::integral_constant<int, 11>{}, parc, kwa_c, kwb_c, kwa_n, kwb_n, own);
+      };
+      // prologue: the steady state at phase 0 of the first K-tile (parity 0): what phases 5 .. 11 of a previous period
+      // would have issued, in their order, then the wait of its phase 11
+      {
+        const uint32_t ka = (uint32_t)w_first * ws_a, kb_ = (uint32_t)w_first * ws_b;
+        issue(0, 0, 0, 0, ka); issue(0, 0, 1, 0, ka);
+        issue(1, 0, 0, 0, kb_); issue(1, 0, 1, 0, kb_);
+        issue(0, 1, 0, 1, ka); issue(0, 1, 1, 1, ka);
+        issue(0, 2, 0, 2, ka);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      }
+      CDML_BARRIER();
+      if (grp == 1) CDML_BARRIER();                        // group 1 runs one barrier behind
+      // the bias gradient's owner of K-tile w: (w mod 2 tiles_m) == 2 tm + grp -- every K-tile of a B column tile counted once
+      // (through readfirstlane: the integer remainder runs on the VALU and would leave the countdown in a VGPR)
+      int cs_wait = __builtin_amdgcn_readfirstlane(cs_on ? (2 * tm + grp + cs_period - w_first % cs_period) % cs_period : 0x40000000);
+      for (int w = w_first;;) {
+        bool own = cs_wait == 0;
+        cs_wait = own ? cs_period - 1 : cs_wait - 1;
+        period(std::integral_constant<int, 0>{}, w, own);
+        if (++w > w_last) break;
+        own = cs_wait == 0;
+        cs_wait = own ? cs_period - 1 : cs_wait - 1;
+        period(std::integral_constant<int, 1>{}, w, own);
+        if (++w > w_last) break;
+      }
+      if (grp == 0) CDML_BARRIER();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the run-ahead loads of the last K-tile
+      CDML_BARRIER();
+    }
+  } else {
   // prologue: the steady state at the first phase of tile 0
   stage(1, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 0, 0, 0); stage(0, 1, 0, 0);
   stage(1, 0, 1, 1); stage(1, 1, 1, 1);
@@ -586,6 +792,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   if (grp == 0) CDML_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the out-of-range tail DMAs still write zeros
   CDML_BARRIER();
+  }   // (!kR6)
 
   if (TN && cs_on && !S16) {   // lanes l31 / l31+32 hold the two k-halves of column l31
 #pragma unroll
@@ -806,7 +1013,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   }
 }
 
-template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false>
+template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false>
 __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   int tm, tn;
@@ -819,7 +1026,7 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   const int n_ktiles = k_end > k_begin ? (k_end - k_begin) / kTileK : 0;   // even (host)
   void *c_base = EPI == BE_F32 ? static_cast<void *>(static_cast<float *>(g.C) + (int64_t)split * g.slab_stride) : g.C;
   float *cs_row = ((TN || NTCS) && g.colsum_partial) ? g.colsum_partial + (int64_t)((split * g.tiles_m + tm) * 2) * g.N + n0 : nullptr;
-  run_tile<TN, EPI, S16, X3, F6, NTCS>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
+  run_tile<TN, EPI, S16, X3, F6, NTCS, R6>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
 }
 
 // ---- both weight gradients of the tower in ONE launch (k-strided form; dW1 = x_hat^T dz1, dW2 = h1^T dz2) ----
@@ -976,31 +1183,40 @@ int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t s
 }
 
 namespace {
-template <bool TN, int EPI, bool F6, bool NTCS = false>
+template <bool TN, int EPI, bool F6, bool NTCS = false, bool R6 = false>
 int launch_x3_1(const BArgs &g, int splits, hipStream_t s) {
   static bool configured = false;
+  constexpr int smem = R6 ? SMEM_R6 : SMEM;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3: cannot reserve %d B of LDS: %s", SMEM, hipGetErrorString(e));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS, R6>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3: cannot reserve %d B of LDS: %s", smem, hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), SMEM, s, g);
+  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS, R6>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), smem, s, g);
   return check_launch("gemm_bf16x3");
 }
-// the unrolled six-step walk when every block's K range is whole periods of the K-major six-product walk
+// which K loop walks the six plane products: CDML_X3_WALK = "r6" (default: the resident-plane walk, both forms),
+// "f6" (round 3's unrolled six-step period with DMA skipping; k-contiguous form only), "general" (round 3's general loop);
+// read per call so that one process can time them against each other
+int x3_walk() {
+  const char *e = getenv("CDML_X3_WALK");
+  return !e ? 2 : (e[0] == 'g' ? 0 : (e[0] == 'f' ? 1 : 2));
+}
+// the unrolled walks need every block's K range to be whole periods of the K-major six-product walk
 template <bool TN, int EPI>
 int launch_x3(const BArgs &g, int splits, hipStream_t s) {
-  // (k-contiguous form only: the k-strided form with its transposed-read offsets and column sums does not fit the
-  // unrolled period into 256 VGPRs -- 58 spilled, the weight gradients 2.4 x slower, measured)
+  const int kt = g.K / kTileK, per = g.k_per_split / kTileK;
+  const bool whole = g.x3_products == 6 && kt % 6 == 0 && per % 6 == 0 && per > 0;
+  const int walk = whole ? x3_walk() : 0;
+  if constexpr (!TN && EPI == BE_F32) {   // the weight gradients of the transposed activation layout: with the column sums
+    // (the general loop: round 3's unrolled period plus the sums was 14 VGPRs over the budget)
+    if (g.colsum_partial) return launch_x3_1<TN, EPI, false, true>(g, splits, s);
+  }
+  if (walk == 2) return launch_x3_1<TN, EPI, false, false, true>(g, splits, s);
   if constexpr (!TN) {
-    const int kt = g.K / kTileK, per = g.k_per_split / kTileK;
-    const bool f6 = g.x3_products == 6 && kt % 6 == 0 && per % 6 == 0 && per > 0;
-    if constexpr (EPI == BE_F32) {        // the weight gradients of the transposed activation layout: with the column sums
-      // (the general loop: the unrolled period plus the sums is 14 VGPRs over the budget)
-      if (g.colsum_partial) return launch_x3_1<TN, EPI, false, true>(g, splits, s);
-    }
-    if (f6) return launch_x3_1<TN, EPI, true>(g, splits, s);
+    // (round 3: the k-strided form did not fit the F6 period into 256 VGPRs -- 58 spilled, 2.4 x slower)
+    if (walk == 1) return launch_x3_1<TN, EPI, true>(g, splits, s);
   }
   return launch_x3_1<TN, EPI, false>(g, splits, s);
 }

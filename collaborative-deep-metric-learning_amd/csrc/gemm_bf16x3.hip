@@ -284,7 +284,8 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
                "gemm_bf16x3_tn: workspace of %zu bytes required (cdml_gemm_bf16x3_workspace)", need);
   hipStream_t s = (hipStream_t)stream;
   const int per = (ktiles + splits - 1) / splits;
-  g.k_per_split = (per + 1) / 2 * 2 * 64;
+  // whole six-step periods of the K-major walk per block (the unrolled loops need them); three products: an even count
+  g.k_per_split = (products == 6 && g.x3_products == 6 ? (per + 5) / 6 * 6 : (per + 1) / 2 * 2) * 64;
   g.slab_stride = (int64_t)M * N;
   g.C = slabs ? workspace : static_cast<void *>(C);
   g.ldc = slabs ? N : ldc;

@@ -43,7 +43,7 @@ def unit_rows(r, c):
 
 cases = {}
 want = args.cases.split(",")
-if any(c in want for c in ("fc1", "fc2", "dh1", "dw1", "dw2")):
+if any(c in want for c in ("fc1", "fc1a", "fc1b", "fc2", "dh1", "dw1", "dw2")):
     x3 = planes(unit_rows(R, F))
     W1T = planes((torch.rand(H, F, device=dev) * 2 - 1) * (6.0 / 6500) ** 0.5)
     W2T = planes((torch.rand(D, H, device=dev) * 2 - 1) * (6.0 / 5256) ** 0.5)
@@ -62,6 +62,12 @@ if any(c in want for c in ("fc1", "fc2", "dh1", "dw1", "dw2")):
     gW2, gb2 = torch.empty(H, D, device=dev), torch.empty(D, device=dev)
     cases["fc1"] = (2.0 * R * F * H, 6, lambda: ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, x3, F, W1T, F, h1o, R, H, F,
                                                                     plane_c=H, bias=b1))
+    # FC1 by tile columns: 16 of the 20 (512 tiles: exactly two rounds of 256 CUs) and the last 4 (128 tiles: half a round)
+    h1a = torch.empty(R, 3 * H, dtype=torch.bfloat16, device=dev)
+    cases["fc1a"] = (2.0 * R * F * 4096, 6, lambda: ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, x3, F, W1T[:4096], F, h1a, R, 4096, F,
+                                                                       plane_c=H, bias=b1[:4096]))
+    cases["fc1b"] = (2.0 * R * F * 1024, 6, lambda: ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, x3, F, W1T[4096:], F, h1a[:, 4096:], R, 1024, F,
+                                                                       plane_c=H, bias=b1[4096:]))
     cases["fc2"] = (2.0 * R * H * D, 6, lambda: ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, h1, H, W2T, H, z, R, D, H,
                                                                     bias=b2, workspace=ws))
     cases["dh1"] = (2.0 * R * H * D, 6, lambda: ops.gemm_bf16x3_nt(ops.BE_MASK_X3, dz2, D, W2, D, dz1o, R, H, D,
