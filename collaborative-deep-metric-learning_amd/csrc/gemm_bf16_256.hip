@@ -325,6 +325,20 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   const bool cs_on = (TN || (NTCS && X3 && S16)) && cs_row != nullptr;
   const int cs_period = 2 * g.tiles_m;
   const int cs_owner = (2 * tm + grp + cs_period - (k_begin / kTileK) % cs_period) % cs_period;   // in K-tiles from k_begin
+  // acc + the 8 values of a fragment: four v_dot2c_f32_bf16 against (1, 1) -- no conversions, no temporaries (the
+  // shift / mask / add form of rounds 1-3 took 17 VALU instructions and 16 VGPRs of temporaries per owned K-tile pair)
+  auto dot_sum = [&](const bf16x8 &f, float acc) {
+    using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+    const bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bf16x2 pr = {f[2 * e], f[2 * e + 1]};
+      acc = __builtin_amdgcn_fdot2_f32_bf16(pr, one, acc, false);
+    }
+    return acc;
+  };
+  // K-tiles until the next one this (tile, row group) owns (0x40000000: none -- no bias gradient asked for)
+  int cs_left = __builtin_amdgcn_readfirstlane(cs_on ? cs_owner : 0x40000000);
   auto frag_sum = [&](const bf16x8 &f) {
     float s = 0.f;
 #pragma unroll
@@ -377,13 +391,16 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     pin_b();
     pin_a();
-    if (cs_on && (tile % cs_period) == cs_owner && (!X3 || ((0xB >> (x3_run ? (xp_c & 7) : x3_segment(x3_t0 + tile))) & 1))) {
+    // (the owner test as a countdown in an SGPR: `tile % cs_period` was a dozen scalar instructions per K-tile)
+    const bool cs_mine = cs_left == 0;
+    cs_left = cs_mine ? cs_period - 1 : cs_left - 1;
+    if (cs_mine && (!X3 || ((0xB >> (x3_run ? (xp_c & 7) : x3_segment(x3_t0 + tile))) & 1))) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
-          cs16[cb] += frag_sum(fb0[2 * cb + ks2]);
-          cs16[2 + cb] += frag_sum(fb1[2 * cb + ks2]);
+          cs16[cb] = dot_sum(fb0[2 * cb + ks2], cs16[cb]);
+          cs16[2 + cb] = dot_sum(fb1[2 * cb + ks2], cs16[2 + cb]);
         }
     }
     CDML_BARRIER();
@@ -628,22 +645,18 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
         else
           return tr_read(smem + slot * 2 * IMG + hh * IMG + ks2 * 8192, tb_w[cb][0], tb_w[cb][1]);
       };
-      // one half image: plane pl, half hh of operand img at K-tile offset kw (= w * ws_x) -> slot
+      // one half image: plane pl, half hh of operand img at K-tile offset kw (= w * ws_x) -> slot.  The SGPR part of the
+      // source offset carries only what moves ALONG a row (plane, K-tile; k-strided form: the column half too); the
+      // k-contiguous form's second half is 64 / 32 ROWS further, and rows past the operand's last one are zero-filled
+      // by the descriptor's range check on the per-lane offset -- so there the half lives in a second lane register
+      // (whether the check also sees the scalar offset is not something to depend on)
+      uint32_t va_h1[2] = {va[0] + d_a, va[1] + d_a}, vb_h1[2] = {vb[0] + d_b, vb[1] + d_b};
       auto issue = [&](int img, int pl, int hh, int slot, uint32_t kw) {
-        const uint32_t so = (img == 0 ? hh * d_a + pl * ps_a : hh * d_b + pl * ps_b) + kw;
+        const uint32_t so = (img == 0 ? pl * ps_a : pl * ps_b) + kw + (TN ? hh * 256u : 0u);
         const uint32_t dst = lds_piece + (img == 0 ? 0 : 6 * IMG) + slot * 2 * IMG + hh * IMG;
-        dma_s(img == 0 ? srd_a : srd_b, img == 0 ? va[0] : vb[0], so, dst);
-        dma_s(img == 0 ? srd_a : srd_b, img == 0 ? va[1] : vb[1], so, dst + 1024);
-      };
-      auto dot_sum = [&](const bf16x8 &f, float acc) {     // acc + the 8 values of f (v_dot2c_f32_bf16 against (1, 1))
-        using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-        const bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bf16x2 pr = {f[2 * e], f[2 * e + 1]};
-          acc = __builtin_amdgcn_fdot2_f32_bf16(pr, one, acc, false);
-        }
-        return acc;
+        const bool h1 = !TN && hh == 1;
+        dma_s(img == 0 ? srd_a : srd_b, img == 0 ? (h1 ? va_h1[0] : va[0]) : (h1 ? vb_h1[0] : vb[0]), so, dst);
+        dma_s(img == 0 ? srd_a : srd_b, img == 0 ? (h1 ? va_h1[1] : va[1]) : (h1 ? vb_h1[1] : vb[1]), so, dst + 1024);
       };
       // the phase: PH = 2 S + half (compile time), PAR = parity of the K-tile; kw_* = byte offsets of this / the next K-tile
       auto phase = [&](auto phc, auto parc, const uint32_t kwa_c, const uint32_t kwb_c, const uint32_t kwa_n,
