@@ -402,6 +402,26 @@ class TrainStep:
         n = self.grad_norms.cpu()
         return float(self.l2_penalty * (n[0, 1] + n[2, 1]) / 2.0)
 
+    def summaries(self):
+        """The scalars build_graph and HingeLoss hand to TensorBoard (train.py:154-160: loss, reg_loss, variance,
+        final_learning_rate; losses.py:40-41: mean_pos_dist, mean_neg_dist), as of the last step, under the reference's
+        names -- ONE device-to-host copy (the step's own stats words and the weight matrices' row norms; the step
+        itself is untouched: `variance` needs enable_variance() before the step and is None otherwise).  Synchronises:
+        the trainer calls it at its evaluation cadence, where it waits for the device anyway."""
+        L, p = self.layout, self.params
+        if getattr(self, "_wsq", None) is None:
+            self._wsq = torch.zeros(8 + L.Fp + L.Hp, dtype=torch.float32, device=self.device)
+        # reg_loss = sum over the weight matrices of l2_penalty * |W|^2 / 2 (models.py:28, train.py:133-136): the rows'
+        # squared norms by the HIP kernel, added up on the host
+        ops.row_sqnorm(p.W1, L.Hp, self._wsq[8:8 + L.Fp])
+        ops.row_sqnorm(p.W2, L.Dp, self._wsq[8 + L.Fp:])
+        self._wsq[:8].copy_(self.stats)
+        h = self._wsq.cpu().double()
+        return {"loss": float(h[0]), "reg_loss": float(self.l2_penalty * h[8:].sum() / 2.0),
+                "variance": float(h[4]) if self.var_ws is not None else None,
+                "final_learning_rate": float(self._lr_host), "mean_pos_dist": float(h[1]), "mean_neg_dist": float(h[2]),
+                "active_triplets": float(h[3])}
+
     def apply_gradients(self):
         p = self.params
         if self.clip_gradient_norm > 0.0 or self.reg_scale != 0.0:
@@ -714,7 +734,7 @@ class Trainer:
 
     def __init__(self, train_step, num_epochs, n_pairs, checkpoint_dir=None, eval_features=None,
                  eval_cowatches=None, check_stop_epoch=3, best_eval_dist=1.0, eval_per_epoch=100,
-                 require_improve_num=10, logger=None):
+                 require_improve_num=10, logger=None, summary_path=None):
         from .evaluate import Evaluation
         from .predict import Prediction
         self.ts = train_step
@@ -732,6 +752,14 @@ class Trainer:
         self.require_improve_num = require_improve_num
         self.log = logger or logging.getLogger("cdml.train")
         self.history, self.eval_history, self.saved = [], [], []
+        # the reference's TensorBoard scalars (train.py:154-160, 246-249; losses.py:40-41) as one JSON line per
+        # evaluation, under its names: `summary_path` (default <checkpoint_dir>/summaries.jsonl; rank 0 writes)
+        if summary_path is None and checkpoint_dir:
+            summary_path = os.path.join(checkpoint_dir, "summaries.jsonl")
+        self.summary_path = summary_path
+        self.summaries = []
+        if summary_path and train_step.mode != "semihard" and train_step.var_ws is None:
+            train_step.enable_variance()                                # calc_var (train.py:67-71,151) rides in the fused tail
         self.evaluater = None
         if eval_cowatches is not None:
             self.evaluater = Evaluation(eval_features, eval_cowatches, device=train_step.device)
@@ -788,8 +816,23 @@ class Trainer:
             self.save(global_step)
             self.last_improve_num = self.total_eval_num
         self.eval_history.append((global_step, self.eval_dist, self.best_eval_dist))
+        self._emit_summaries(global_step)
         self.log.info("Eval %d | step %d eval_dist %.6f best %.6f", self.total_eval_num, global_step,
                       self.eval_dist, self.best_eval_dist)
+
+    def _emit_summaries(self, global_step):
+        """One record per evaluation with the reference's scalar names (train.py:326-327 runs summary_op exactly here)."""
+        rec = {"global_step": int(global_step)}
+        rec.update(self.ts.summaries())
+        rec["eval/eval_dist"] = float(self.eval_dist)                   # train.py:246-249
+        rec["eval/best_eval_dist"] = float(self.best_eval_dist)
+        self.summaries.append(rec)
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        if self.summary_path and rank == 0:
+            import json
+            os.makedirs(os.path.dirname(os.path.abspath(self.summary_path)), exist_ok=True)
+            with open(self.summary_path, "a") as f:
+                f.write(json.dumps(rec) + "\n")
 
     def run(self, max_steps=None):
         n = self.num_batches if max_steps is None else min(self.num_batches, max_steps)

@@ -1147,8 +1147,30 @@ def test_trainer_learns_evaluates_checkpoints_and_resumes(cd, tmp_path):
     ev = tr.eval_history
     assert len(ev) >= 8 and ev[-1][1] < 0.8 * ev[0][1]          # held-out positive distance too
     assert tr.best_eval_dist == min(e[1] for e in ev if e[0] > tr.check_stop_step)
-    files = sorted(os.listdir(tmp_path))
-    assert len(files) == 1 and files[0].startswith("model.ckpt-")           # max_to_keep=1
+    files = sorted(f for f in os.listdir(tmp_path) if f.startswith("model.ckpt-"))
+    assert len(files) == 1                                                  # max_to_keep=1
+    # the reference's TensorBoard scalars (train.py:154-160, 246-249; losses.py:40-41), one JSON line per evaluation
+    import json
+    recs = [json.loads(ln) for ln in open(tmp_path / "summaries.jsonl")]
+    assert len(recs) == len(ev) and [r["global_step"] for r in recs] == [e[0] for e in ev]
+    names = {"loss", "reg_loss", "variance", "final_learning_rate", "mean_pos_dist", "mean_neg_dist", "eval/eval_dist",
+             "eval/best_eval_dist"}
+    assert names <= set(recs[-1])
+    last = recs[-1]
+    assert abs(last["eval/eval_dist"] - ev[-1][1]) < 1e-12 and abs(last["eval/best_eval_dist"] - ev[-1][2]) < 1e-12
+    assert last["final_learning_rate"] == 0.002 and all(np.isfinite(last[k]) for k in names)
+    W1, _, W2, _ = [t.cpu().numpy().astype(np.float64) for t in ts.params.unpadded()]
+    reg = 1e-8 * ((W1 ** 2).sum() + (W2 ** 2).sum()) / 2                    # models.py:28, train.py:133-136
+    # (the record is the LAST EVALUATION's; a few more steps may have moved the weights since)
+    assert abs(last["reg_loss"] - reg) < (1e-6 if last["global_step"] == ts.global_step else 1e-2) * reg
+    # loss / distances / variance of the last step, when the run ended on an evaluation step
+    if last["global_step"] == ts.global_step:
+        assert abs(last["loss"] - ts.loss()) < 1e-7
+        e = ts.ws.e[:, :32].double().view(B, 3, 32)
+        assert abs(last["mean_pos_dist"] - float(((e[:, 0] - e[:, 1]) ** 2).sum(1).mean())) < 1e-6
+        assert abs(last["mean_neg_dist"] - float(((e[:, 0] - e[:, 2]) ** 2).sum(1).mean())) < 1e-6
+        var = float(((e - e.mean(dim=(0, 1), keepdim=True)) ** 2).mean())            # calc_var, train.py:67-71
+        assert abs(last["variance"] - var) < 1e-6
     # resume: 5 steps + save + 5 steps  ==  10 steps straight
     a, b = mk(), mk()
     for _ in range(10):
