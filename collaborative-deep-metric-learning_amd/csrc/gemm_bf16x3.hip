@@ -138,13 +138,47 @@ extern "C" size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int pr
 
 namespace cdml {
 namespace {
-// sums `splits` fp32 slabs (+ bias, leaky-relu when bias != null) into out
+// colsum[n] = the partial rows added in a fixed order: 16 columns x 16 row lanes per block, four loads in flight per lane
+__device__ __forceinline__ void x3_colsum_block(const float *__restrict__ partial, int n_rows, int N, float *__restrict__ out,
+                                                int blk) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blk * 16 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < N) {
+    int r = rl;
+    for (; r + 48 < n_rows; r += 64) {
+      s0 += partial[(int64_t)r * N + c];
+      s1 += partial[(int64_t)(r + 16) * N + c];
+      s2 += partial[(int64_t)(r + 32) * N + c];
+      s3 += partial[(int64_t)(r + 48) * N + c];
+    }
+    for (; r < n_rows; r += 16) s0 += partial[(int64_t)r * N + c];
+  }
+  red[rl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) t += red[j][cl];
+    out[c] = t;
+  }
+}
+
+// sums `splits` fp32 slabs (+ bias, leaky-relu when bias != null) into out -- blocks [0, slab_blocks) -- and, in the SAME
+// launch, finishes the bias gradient from its per-(split, tile, row group) partial rows -- the blocks after them (round 3
+// ran k_x3_colsum_final as a launch of its own: 2 x 10 us per step for a few KB of sums)
 __global__ void __launch_bounds__(kThreads)
 k_x3_sum_slabs(const float *__restrict__ slabs, int64_t slab_stride, int splits, int rows, int N,
-               const float *__restrict__ bias, float alpha, float *__restrict__ out, int64_t ldo) {
+               const float *__restrict__ bias, float alpha, float *__restrict__ out, int64_t ldo, int slab_blocks,
+               const float *__restrict__ cs_partial, int cs_rows, float *__restrict__ cs_out) {
+  if ((int)blockIdx.x >= slab_blocks) {
+    x3_colsum_block(cs_partial, cs_rows, N, cs_out, blockIdx.x - slab_blocks);
+    return;
+  }
   const int n4 = N >> 2;
   const int64_t total = (int64_t)rows * n4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)slab_blocks * blockDim.x) {
     const int64_t r = i / n4;
     const int c = (int)(i - r * n4);
     f32x4 s = reinterpret_cast<const f32x4 *>(slabs)[i];
@@ -155,23 +189,6 @@ k_x3_sum_slabs(const float *__restrict__ slabs, int64_t slab_stride, int splits,
       s.z = fmaxf(s.z, s.z * alpha); s.w = fmaxf(s.w, s.w * alpha);
     }
     reinterpret_cast<f32x4 *>(out + r * ldo)[c] = s;
-  }
-}
-// colsum[n] = sum over the partial rows: 32 columns per block, 8 row lanes, added in a fixed order
-__global__ void __launch_bounds__(kThreads)
-k_x3_colsum_final(const float *__restrict__ partial, int n_rows, int N, float *__restrict__ out) {
-  __shared__ float red[8][33];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
-  float s = 0.f;
-  if (c < N)
-    for (int r = rl; r < n_rows; r += 8) s += partial[(int64_t)r * N + c];
-  red[rl][threadIdx.x & 31] = s;
-  __syncthreads();
-  if (rl == 0 && c < N) {
-    float t = red[0][threadIdx.x];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) t += red[j][threadIdx.x];
-    out[c] = t;
   }
 }
 }  // namespace
@@ -241,13 +258,17 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
     g.C = workspace; g.ldc = N;
     rc = launch_gemm_bf16_256_x3(g, false, BE_F32, splits, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_x3_sum_slabs, dim3(grid1d((int64_t)M * N / 4)), dim3(kThreads), 0, s,
+    const int sb = grid1d((int64_t)M * N / 4), cb = colsum ? (N + 15) / 16 : 0;
+    hipLaunchKernelGGL(k_x3_sum_slabs, dim3(sb + cb), dim3(kThreads), 0, s,
                        static_cast<const float *>(workspace), g.slab_stride, splits, M, N,
-                       epilogue == BE_BIAS_LRELU_F32 ? bias : nullptr, alpha, static_cast<float *>(C), ldc);
-    rc = check_launch("gemm_bf16x3_nt combine");
+                       epilogue == BE_BIAS_LRELU_F32 ? bias : nullptr, alpha, static_cast<float *>(C), ldc, sb,
+                       g.colsum_partial, (int)cs_rows, colsum);
+    return check_launch("gemm_bf16x3_nt combine");
   }
   if (rc || !colsum) return rc;
-  hipLaunchKernelGGL(k_x3_colsum_final, dim3((N + 31) / 32), dim3(kThreads), 0, s, g.colsum_partial, (int)cs_rows, N, colsum);
+  hipLaunchKernelGGL(k_x3_sum_slabs, dim3((N + 15) / 16), dim3(kThreads), 0, s, static_cast<const float *>(nullptr), (int64_t)0, 0, 0,
+                     N, static_cast<const float *>(nullptr), 0.f, static_cast<float *>(nullptr), (int64_t)0, 0, g.colsum_partial,
+                     (int)cs_rows, colsum);
   return check_launch("gemm_bf16x3_nt bias gradient");
 }
 
@@ -292,15 +313,11 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
   g.colsum_partial = colsum ? reinterpret_cast<float *>(static_cast<char *>(workspace) + slab_bytes) : nullptr;
   int rc = launch_gemm_bf16_256_x3(g, true, BE_F32, splits, s);
   if (rc) return rc;
-  if (slabs) {
-    hipLaunchKernelGGL(k_x3_sum_slabs, dim3(grid1d((int64_t)M * N / 4)), dim3(kThreads), 0, s,
-                       static_cast<const float *>(workspace), g.slab_stride, splits, M, N, bias, alpha, C, ldc);
-    if ((rc = check_launch("gemm_bf16x3_tn combine"))) return rc;
-  }
-  if (colsum) {
-    hipLaunchKernelGGL(k_x3_colsum_final, dim3((N + 31) / 32), dim3(kThreads), 0, s, g.colsum_partial,
-                       (int)cs_rows, N, colsum);
-    rc = check_launch("gemm_bf16x3_tn bias gradient");
+  if (slabs || colsum) {                                   // one launch: the slab sum and, in extra blocks, the bias gradient
+    const int sb = slabs ? grid1d((int64_t)M * N / 4) : 0, cb = colsum ? (N + 15) / 16 : 0;
+    hipLaunchKernelGGL(k_x3_sum_slabs, dim3(sb + cb), dim3(kThreads), 0, s, static_cast<const float *>(workspace), g.slab_stride,
+                       splits, M, N, bias, alpha, C, ldc, sb, g.colsum_partial, (int)cs_rows, colsum);
+    rc = check_launch("gemm_bf16x3_tn combine");
   }
   return rc;
 }

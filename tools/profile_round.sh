@@ -13,7 +13,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py $ARGS > $ROOT/gpurun_out/${TAG}_bench.json
 echo "[profile] plain bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py $ARGS --steps 60 --warmup 5 \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py $ARGS --steps 60 --warmup 5 --no-settle \
     --no-cpu-baseline --no-extras > $ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $ROOT/gpurun_out/${TAG}_kernel_stats.csv
 echo "[profile] kernel stats done"

@@ -4,7 +4,7 @@ shapes, one by one: timed with event pairs in interleaved rounds (one process, o
 of times under `rocprofv3 --pmc ...` (tools/pmc_passes.sh) so that every counter row belongs to a known product.
 
 usage: python tools/x3_gemm_probe.py [--cases fc1,dw1,...] [--iters N] [--rounds M] [--rows R] [--rows4 R4]
-cases: x3 step (R rows, default 8192 = config 1): fc1 fc2 dh1 dw1 dw2;  config 4 (R4 rows, default 24576): c4fc1 c4dw1 c4dw2
+cases: x3 step (R rows, default 8192 = config 1): fc1 fc2 dh1 dw1 dw2;  config 4 (R4 rows, default 24576): c4fc1 c4fc2 c4dh1 c4dw1 c4dw2
 """
 import argparse
 import os
@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cdml_amd import ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--cases", default="fc1,fc2,dh1,dw1,dw2,c4fc1,c4dw1,c4dw2")
+ap.add_argument("--cases", default="fc1,fc2,dh1,dw1,dw2,c4fc1,c4fc2,c4dh1,c4dw1,c4dw2")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--rows", type=int, default=8192)
@@ -87,6 +87,14 @@ if any(c.startswith("c4") for c in want):
     nb4 = max(ops.gemm_bf16_tn_workspace(F, H, R4), ops.gemm_bf16_tn_workspace(H, D, R4), 16)
     ws4 = torch.empty(nb4 // 4, device=dev)
     cases["c4fc1"] = (2.0 * R4 * F * H, 1, lambda: ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_BF16, xb, W1Tb, h1ob, R4, H, F, bias=b1b))
+    W2Tb = ((torch.rand(D, H, device=dev) * 2 - 1) * (6.0 / 5256) ** 0.5).bfloat16()
+    W2b = W2Tb.t().contiguous()
+    zb = torch.empty(R4, D, device=dev)
+    b2b = torch.zeros(D, device=dev)
+    dz1ob = torch.empty_like(dz1b)
+    wsf = torch.empty(max(ops.gemm_bf16_workspace(R4, D, H), 16) // 4, device=dev)
+    cases["c4fc2"] = (2.0 * R4 * H * D, 1, lambda: ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_F32, h1b, W2Tb, zb, R4, D, H, bias=b2b, workspace=wsf))
+    cases["c4dh1"] = (2.0 * R4 * H * D, 1, lambda: ops.gemm_bf16_nt(ops.BE_MASK_BF16, dz2b, W2b, dz1ob, R4, H, D, aux=h1b))
     cases["c4dw1"] = (2.0 * R4 * F * H, 1, lambda: ops.gemm_bf16_tn(xb, dz1b, gW1b, F, H, R4, workspace=ws4, colsum=gb1b))
     cases["c4dw2"] = (2.0 * R4 * H * D, 1, lambda: ops.gemm_bf16_tn(h1b, dz2b, gW2b, H, D, R4, workspace=ws4, colsum=gb2b))
 
