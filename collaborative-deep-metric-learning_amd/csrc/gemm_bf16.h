@@ -17,7 +17,10 @@ enum { BE_BIAS_LRELU_BF16 = 0, BE_BIAS_LRELU_F32 = 1, BE_MASK_BF16 = 2, BE_F32 =
        // applied, split into three bf16 planes hi | mid | lo (C = bf16, planes x3_plane_c elements apart)
        BE_BIAS_LRELU_X3 = 6, BE_MASK_X3 = 7,
        // 6 with the bias indexed by the output ROW (a layer computed transposed: C = W^T-planes . x-planes^T)
-       BE_ROWBIAS_LRELU_X3 = 8 };
+       BE_ROWBIAS_LRELU_X3 = 8,
+       // ABI-level ids of cdml_gemm_bf16x3_nt (mapped to 6 / 7 with BArgs::mask_out / aux_bits set): 6 that also writes the
+       // sign bitmask of its result to `aux`, 7 reading that bitmask
+       BE_BIAS_LRELU_X3_BITS = 9, BE_MASKBITS_X3 = 10 };
 
 struct BArgs {
   const bf16 *A; int64_t lda;

@@ -860,12 +860,25 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     }
     auto row8 = [&](int rt, int p) { return m0 + grp * 128 + rt * 32 + p * 8 + (lane >> 3); };
     bf16x8 mk8[4][4];
+    unsigned mb8[4][4];
+    // the leaky-relu' mask operand: bf16 values (sign of the hi plane) or, split-fp32 form with g.aux_bits, ONE BIT per
+    // element written by the forward layer's epilogue below (this lane's 8 columns = one byte; ldaux in bytes) -- the
+    // value form reads 84 MB of h1's hi plane from HBM inside the store-bound epilogue (30 us of the data gradient's 151)
+    const bool mask_bits = X3 && kMaskEpi && has_aux && g.aux_bits;
     if (kMaskEpi && has_aux) {                               // all 16 mask loads of the wave go out together
+      if (mask_bits) {
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-          mk8[rt][p] = *reinterpret_cast<const bf16x8 *>(g.aux + (int64_t)min(row8(rt, p), g.M - 1) * g.ldaux + n0 + lcol8);
+          for (int p = 0; p < 4; ++p)
+            mb8[rt][p] = reinterpret_cast<const uint8_t *>(g.aux)[(int64_t)min(row8(rt, p), g.M - 1) * g.ldaux + ((n0 + lcol8) >> 3)];
+      } else {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            mk8[rt][p] = *reinterpret_cast<const bf16x8 *>(g.aux + (int64_t)min(row8(rt, p), g.M - 1) * g.ldaux + n0 + lcol8);
+      }
     }
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
@@ -911,14 +924,18 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
             v[j] += bb[j];
             v[j] = fmaxf(v[j], v[j] * g.alpha);
           } else if (has_aux) {
-            v[j] *= ((float)mk8[rt][p][j] > 0.f) ? 1.f : g.alpha;
+            if (mask_bits) v[j] *= ((mb8[rt][p] >> j) & 1u) ? 1.f : g.alpha;
+            else v[j] *= ((float)mk8[rt][p][j] > 0.f) ? 1.f : g.alpha;
           }
           if constexpr (kPlanes) asm volatile("" : "+v"(v[j]));   // the planes are those of the ROUNDED value
           o[j] = (bf16)v[j];
           if (EPI == BE_BIAS_LRELU_BF16 && (float)o[j] > 0.f) bits |= 1u << j;
+          if (X3 && kBiasEpi && v[j] > 0.f) bits |= 1u << j;   // sign of the fp32 activation itself
         }
         if (row >= g.M) continue;                            // stores only below this line
         if constexpr (kPlanes) {
+          if (kBiasEpi && g.mask_out)                        // this lane's 8 columns = one byte of the sign bitmask
+            g.mask_out[(int64_t)row * g.ldmask + ((n0 + lcol8) >> 3)] = (uint8_t)bits;
           // three roundings to nearest hold the 24 significant bits: hi + mid + lo == v exactly
           bf16 *dst = static_cast<bf16 *>(c_base) + (int64_t)(row - m0 + c_row0) * c_ld + c_col0 + lcol8;
           *reinterpret_cast<bf16x8 *>(dst) = o;

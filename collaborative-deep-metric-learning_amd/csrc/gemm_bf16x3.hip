@@ -196,16 +196,23 @@ k_x3_sum_slabs(const float *__restrict__ slabs, int64_t slab_stride, int splits,
 
 // C = epilogue(A . B^T) for fp32 A[M][K], B[N][K] given as planes [rows][hi K | mid K | lo K] (plane strides
 // plane_a / plane_b >= K along k).  epilogue 1: fp32 C = lrelu(. + bias); 3: fp32 C; 6: C = planes of lrelu(. + bias)
-// (bf16 [M][ldc], planes plane_c apart); 7: C = planes of (. times (aux > 0 ? 1 : alpha)), aux = bf16 [M][ldaux].
+// (bf16 [M][ldc], planes plane_c apart); 7: C = planes of (. times (aux > 0 ? 1 : alpha)), aux = bf16 [M][ldaux];
+// 9 = 6 that ALSO writes the sign bitmask of its result to aux (uint8 [M][ldaux BYTES]: bit j of byte b of row r =
+// C[r][8 b + j] > 0); 10 = 7 reading that bitmask instead of bf16 values (one bit per element instead of two bytes).
 extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
                                    int64_t ldb, int64_t plane_b, int M, int N, int K, int products, void *C,
                                    int64_t ldc, int64_t plane_c, const float *bias, const uint16_t *aux,
                                    int64_t ldaux, float alpha, float *colsum, void *workspace,
                                    size_t workspace_bytes, cdml_stream_t stream) {
   CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16x3_nt: bad argument");
+  const bool bits_out = epilogue == BE_BIAS_LRELU_X3_BITS, bits_in = epilogue == BE_MASKBITS_X3;
+  if (bits_out) epilogue = BE_BIAS_LRELU_X3;
+  if (bits_in) epilogue = BE_MASK_X3;
   CDML_REQUIRE(epilogue == BE_BIAS_LRELU_F32 || epilogue == BE_F32 || epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3 ||
                    epilogue == BE_ROWBIAS_LRELU_X3,
-               CDML_E_BADARG, "gemm_bf16x3_nt: epilogue must be 1, 3, 6, 7 or 8");
+               CDML_E_BADARG, "gemm_bf16x3_nt: epilogue must be 1, 3, 6, 7, 8, 9 or 10");
+  CDML_REQUIRE(!(bits_out || bits_in) || (aux && N % 8 == 0 && ldaux >= N / 8), CDML_E_BADARG,
+               "gemm_bf16x3_nt: epilogues 9 / 10 need the bitmask in aux (ldaux >= N / 8 bytes)");
   CDML_REQUIRE(products == 3 || products == 6, CDML_E_BADARG, "gemm_bf16x3_nt: products must be 3 or 6");
   CDML_REQUIRE(N % 256 == 0 && K % 64 == 0, CDML_E_UNSUPPORTED,
                "gemm_bf16x3_nt: N must be a multiple of 256 and K of 64, got N=%d K=%d", N, K);
@@ -215,7 +222,7 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   const bool planes_out = epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3 || epilogue == BE_ROWBIAS_LRELU_X3;
   CDML_REQUIRE(planes_out ? (!(ldc & 7) && !(plane_c & 7) && plane_c >= N && ldc >= 2 * plane_c + N) : (!(ldc & 3) && ldc >= N),
                CDML_E_ALIGN, "gemm_bf16x3_nt: ldc (plane outputs: ldc and plane_c multiples of 8, ldc >= 2 plane_c + N)");
-  CDML_REQUIRE(epilogue != BE_MASK_X3 || !aux || (aligned16(aux) && !(ldaux & 7) && ldaux >= N), CDML_E_ALIGN,
+  CDML_REQUIRE(epilogue != BE_MASK_X3 || !aux || bits_in || (aligned16(aux) && !(ldaux & 7) && ldaux >= N), CDML_E_ALIGN,
                "gemm_bf16x3_nt: aux must be 16-B aligned with ldaux a multiple of 8");
   CDML_REQUIRE((epilogue != BE_BIAS_LRELU_F32 && epilogue != BE_BIAS_LRELU_X3 && epilogue != BE_ROWBIAS_LRELU_X3) || bias,
                CDML_E_BADARG, "gemm_bf16x3_nt: bias required");
@@ -228,6 +235,8 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   g.B = reinterpret_cast<const bf16 *>(B); g.ldb = ldb;
   g.C = C; g.ldc = ldc; g.bias = bias; g.alpha = alpha;
   g.aux = reinterpret_cast<const bf16 *>(aux); g.ldaux = ldaux;
+  if (bits_out) { g.mask_out = reinterpret_cast<uint8_t *>(const_cast<uint16_t *>(aux)); g.ldmask = ldaux; g.aux = nullptr; g.ldaux = 0; }
+  g.aux_bits = bits_in ? 1 : 0;
   g.M = M; g.N = N;
   g.x3_tpp = K / 64; g.x3_plane_a = plane_a; g.x3_plane_b = plane_b; g.x3_plane_c = plane_c;
   g.x3_products = x3_kmajor() ? products : 0;

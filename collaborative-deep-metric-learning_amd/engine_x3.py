@@ -72,6 +72,13 @@ class TowerWorkspaceX3:
         # the same bits whole or in row blocks -- when it is handed the slab workspace; without one it runs in a single
         # pass.  Catalogue inference in big chunks (>= 192 row tiles fill the chip unsplit) skips the slabs' round trip.
         nb = max(ops.gemm_bf16x3_workspace(False, R, L.Dp, L.Hp, q), 16) if (backward or R // 256 < 192) else 16
+        # leaky-relu' of the hidden layer as ONE BIT per element (round 4): FC1's epilogue writes the sign bitmask of h1
+        # (this lane's 8 columns = one byte), the data gradient's epilogue reads 5 MB of bits instead of the 84 MB of
+        # h1's hi plane -- that read sat in its store-bound epilogue and cost 30 us of its 151 (profiles/r04_stagger_and_
+        # fc1_rounds.txt, item 3).  CDML_X3_MASKBITS=0 for the value mask (A/B runs); the transposed layout keeps it.
+        self.h1_bits = None
+        if backward and not self.transposed and os.environ.get("CDML_X3_MASKBITS", "1") != "0":
+            self.h1_bits = torch.zeros((R, L.Hp // 8), dtype=torch.uint8, device=device)
         if backward:                                       # (catalogue inference: forward buffers only)
             self.dz1 = bf(L.Hp, 3 * R) if self.transposed else bf(R, 3 * L.Hp)
             self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp)
@@ -131,8 +138,12 @@ def tower_forward(p, ws, normalize=True):
                            plane_c=R, bias=p.b1)
         ops.gemm_bf16x3_tn(ws.h1, R, ws.W2, L.Dp, ws.z, R, L.Dp, L.Hp, products=q, workspace=ws.gemm_ws, bias=p.b2)
     else:
-        ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, ws.x3, L.Fp, ws.W1T, L.Fp, ws.h1, R, L.Hp, L.Fp, products=q,
-                           plane_c=L.Hp, bias=p.b1)
+        if getattr(ws, "h1_bits", None) is not None:
+            ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3_BITS, ws.x3, L.Fp, ws.W1T, L.Fp, ws.h1, R, L.Hp, L.Fp, products=q,
+                               plane_c=L.Hp, bias=p.b1, aux=ws.h1_bits)
+        else:
+            ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, ws.x3, L.Fp, ws.W1T, L.Fp, ws.h1, R, L.Hp, L.Fp, products=q,
+                               plane_c=L.Hp, bias=p.b1)
         ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, ws.h1, L.Hp, ws.W2T, L.Hp, ws.z, R, L.Dp, L.Hp, products=q,
                            bias=p.b2, workspace=ws.gemm_ws)
     ws.tail_done = False
@@ -172,8 +183,12 @@ def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
         for pl in range(3):                                                       # the gathered planes, transposed
             ops.transpose_to_bf16(ws.x3[:, pl * L.Fp:(pl + 1) * L.Fp], ws.xT[:, pl * R:(pl + 1) * R], R, L.Fp)
     else:
-        ops.gemm_bf16x3_nt(ops.BE_MASK_X3, ws.dz2_3, L.Dp, ws.W2, L.Dp, ws.dz1, R, L.Hp, L.Dp, products=q, plane_c=L.Hp,
-                           aux=ws.h1)
+        if getattr(ws, "h1_bits", None) is not None:
+            ops.gemm_bf16x3_nt(ops.BE_MASKBITS_X3, ws.dz2_3, L.Dp, ws.W2, L.Dp, ws.dz1, R, L.Hp, L.Dp, products=q,
+                               plane_c=L.Hp, aux=ws.h1_bits)
+        else:
+            ops.gemm_bf16x3_nt(ops.BE_MASK_X3, ws.dz2_3, L.Dp, ws.W2, L.Dp, ws.dz1, R, L.Hp, L.Dp, products=q, plane_c=L.Hp,
+                               aux=ws.h1)
     rows = L.Fp // w1_chunks if w1_chunks > 1 else 0
 
     def dw1(lo, hi, db):

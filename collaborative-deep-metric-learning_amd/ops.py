@@ -385,6 +385,7 @@ def gemm_bf16_tn(A, B, C, M, N, K, workspace=None, colsum=None):
 
 # ---- fp32 products on the bf16 MFMA: operands as three bf16 planes (csrc/gemm_bf16x3.hip) ----
 BE_BIAS_LRELU_X3, BE_MASK_X3, BE_ROWBIAS_LRELU_X3 = 6, 7, 8
+BE_BIAS_LRELU_X3_BITS, BE_MASKBITS_X3 = 9, 10         # 6 + sign bitmask out (aux, uint8 [M][N / 8]) / 7 reading that bitmask
 
 
 def split_f32_bf16x3(src, dst, plane, transpose=False):
@@ -407,6 +408,8 @@ def gemm_bf16x3_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, products=6, pla
     bp, bld = _mat16(B)
     if C.dim() != 2 or C.stride(1) != 1:
         raise ValueError("C must be 2-D with unit inner stride")
+    if aux is not None and (aux.dtype == torch.uint8) != (epilogue in (BE_BIAS_LRELU_X3_BITS, BE_MASKBITS_X3)):
+        raise ValueError("epilogues 9 / 10 take a uint8 bitmask as aux, epilogue 7 bf16 values")
     call("cdml_gemm_bf16x3_nt", epilogue, ap, ald, plane_a, bp, bld, plane_b, M, N, K, products, _p(C), C.stride(0),
          plane_c, _p(bias), _p(aux), aux.stride(0) if aux is not None else 0, alpha, _p(colsum, torch.float32),
          _p(workspace), 0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())

@@ -418,6 +418,12 @@ int cdml_adam_matrix_planes(float *w, const float *g, float *m, float *v, int K,
                             uint16_t *wc_planes, int64_t ldc, int64_t plane_c, float *bias_w,
                             const float *bias_g, float *bias_m, float *bias_v, int bias_n,
                             int advance_step, uint32_t *tickets, cdml_stream_t stream);
+/* cdml_gemm_bf16x3_nt epilogues: 1 fp32 C = lrelu(. + bias); 3 fp32 C; 6 C = the three planes of lrelu(. + bias);
+ * 7 C = planes of (. times (aux > 0 ? 1 : alpha)), aux = bf16 values [M][ldaux]; 8 = 6 with the bias indexed by the
+ * output row; 9 = 6 that ALSO writes the sign bitmask of its result to aux (as uint8 [M][ldaux BYTES], bit j of byte b of
+ * row r = C[r][8 b + j] > 0); 10 = 7 reading that bitmask (leaky-relu' of the hidden layer, models.py:59 / train.py:141,
+ * as one bit per element instead of a 2-byte value).  The narrow forward layer (N == 256) splits its contraction into
+ * slabs of 60 K-tile steps when given the workspace -- a partition that depends on K alone. */
 size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int products);
 int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
                         int64_t ldb, int64_t plane_b, int M, int N, int K, int products, void *C,

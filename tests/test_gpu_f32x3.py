@@ -362,3 +362,40 @@ def test_lars_and_momentum_write_the_operand_copies_with_the_update(rule, planes
     else:
         assert torch.equal(W1T, W1.t().to(torch.bfloat16)) and torch.equal(W2T, W2m.t().to(torch.bfloat16))
         assert torch.equal(W2, W2m.to(torch.bfloat16))
+
+
+def test_sign_bitmask_epilogues_equal_the_value_mask():
+    """Epilogue 9 (= 6 + the sign bitmask of its result) and epilogue 10 (= 7 reading that bitmask): the planes out of
+    9 are those of 6 bit for bit, bit j of byte b of row r is C[r][8 b + j] > 0, and 10 gives what 7 gives from the hi
+    plane -- leaky-relu' of the hidden layer carried as one bit per element instead of two bytes (models.py:59, train.py:141)."""
+    torch.manual_seed(5)
+    dev = _dev()
+    M, N, K = 1000, 512, 256                                  # a ragged last row tile
+    A = torch.randn(M, K, device=dev) * 0.1
+    B = torch.randn(N, K, device=dev) * 0.1
+    bias = torch.randn(N, device=dev) * 0.05
+    A3, B3 = _planes(A, K), _planes(B, K)
+    o6 = torch.zeros(M, 3 * N, dtype=torch.bfloat16, device=dev)
+    o9 = torch.zeros_like(o6)
+    bits = torch.full((M, N // 8), 0xAA, dtype=torch.uint8, device=dev)
+    ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, A3, K, B3, K, o6, M, N, K, plane_c=N, bias=bias, alpha=0.2)
+    ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3_BITS, A3, K, B3, K, o9, M, N, K, plane_c=N, bias=bias, alpha=0.2, aux=bits)
+    assert torch.equal(o6, o9)
+    h = o9[:, :N].float() + o9[:, N:2 * N].float() + o9[:, 2 * N:].float()
+    want = (h > 0).view(M, N // 8, 8).to(torch.int32)
+    want = (want << torch.arange(8, device=dev, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, want)
+    # the data gradient with the mask as values (hi plane) and as bits
+    G = torch.randn(M, 256, device=dev) * 1e-3
+    W = torch.randn(N, 256, device=dev) * 0.05
+    G3, W3 = _planes(G, 256), _planes(W, 256)
+    d7 = torch.zeros(M, 3 * N, dtype=torch.bfloat16, device=dev)
+    d10 = torch.zeros_like(d7)
+    ops.gemm_bf16x3_nt(ops.BE_MASK_X3, G3, 256, W3, 256, d7, M, N, 256, plane_c=N, aux=o9, alpha=0.2)
+    ops.gemm_bf16x3_nt(ops.BE_MASKBITS_X3, G3, 256, W3, 256, d10, M, N, 256, plane_c=N, aux=bits, alpha=0.2)
+    # (the hi plane of a tiny positive fp32 value can round to +0: the bit form takes the sign of the fp32 value itself)
+    same = (h > 0) == (o9[:, :N].float() > 0)
+    assert float(same.float().mean()) > 0.9999
+    v7 = d7[:, :N].float() + d7[:, N:2 * N].float() + d7[:, 2 * N:].float()
+    v10 = d10[:, :N].float() + d10[:, N:2 * N].float() + d10[:, 2 * N:].float()
+    assert torch.equal(v7[same], v10[same])
