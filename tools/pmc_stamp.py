@@ -17,4 +17,8 @@ path = os.path.join(ROOT, "profiles", "latest_pmc.json")
 meta = json.load(open(path)) if os.path.exists(path) else {}
 meta[name] = {"date": date, "commit": commit, "command": command, "csrc_sha16": bench.csrc_hash()}
 json.dump(meta, open(path, "w"), indent=1)
+# (the GPU box returns only gpurun_out/: leave a copy there to carry the stamp back into profiles/)
+out = os.path.join(ROOT, "gpurun_out")
+if os.path.isdir(out):
+    json.dump(meta, open(os.path.join(out, "latest_pmc.json"), "w"), indent=1)
 print(json.dumps(meta[name]))
