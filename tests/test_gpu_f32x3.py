@@ -45,7 +45,9 @@ def test_split_planes_are_exact(rows, cols, transpose):
     assert torch.equal(s, x.t() if transpose else x), "hi + mid + lo is the fp32 value, bit for bit"
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 512, 384), (2048, 256, 1024), (8192, 5120, 1536)])
+# (K = 192 / 320: three / five K-tiles -- an ODD number of the resident-plane walk's periods, whose slots alternate by parity)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 256, 192), (300, 512, 320), (1000, 512, 384), (2048, 256, 1024),
+                                   (8192, 5120, 1536)])
 @pytest.mark.parametrize("products", [6, 3])
 def test_gemm_x3_nt_matches_fp64_like_fp32(M, N, K, products):
     torch.manual_seed(1)
