@@ -234,15 +234,14 @@ k_colsum_partial(const SRC *__restrict__ in, int64_t ld, int rows, int cols, int
 // out[c] = sum_k partial[k][c], fixed order: a block owns 128 columns; its 8 row groups add every
 // 8th partial row (independent loads, pipelined), then the 8 group sums are added in order.
 // (One thread per column walking all chunks one after the other took 34 us at 256 chunks.)
-__global__ void __launch_bounds__(kThreads)
-k_colsum_final(const float *__restrict__ partial, int chunks, int cols, float *__restrict__ out) {
+__device__ __forceinline__ void colsum_final_block(const float *__restrict__ partial, int chunks, int cols,
+                                                   float *__restrict__ out, int blk, bool narrow) {
   // CQ column quads x RL row lanes per block: few columns and many partial rows (the second layer's bias gradient:
   // 480 rows x 256 columns) get 32 row lanes over 8 blocks instead of 8 over 2 (10.5 -> ~4 us)
   __shared__ f32x4 red[kThreads];
-  const bool narrow = gridDim.x * 32 >= (unsigned)cols;     // launched with (cols + 31) / 32 blocks
   const int CQ = narrow ? 8 : 32, RL = kThreads / CQ;
   const int c4 = threadIdx.x % CQ, rl = threadIdx.x / CQ;
-  const int c = blockIdx.x * (CQ * 4) + c4 * 4;
+  const int c = blk * (CQ * 4) + c4 * 4;
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
   if (c < cols)
     for (int k = rl; k < chunks; k += RL) s += *reinterpret_cast<const f32x4 *>(partial + (int64_t)k * cols + c);
@@ -253,14 +252,25 @@ k_colsum_final(const float *__restrict__ partial, int chunks, int cols, float *_
     *reinterpret_cast<f32x4 *>(out + c) = s;
   }
 }
+__global__ void __launch_bounds__(kThreads)
+k_colsum_final(const float *__restrict__ partial, int chunks, int cols, float *__restrict__ out) {
+  colsum_final_block(partial, chunks, cols, out, blockIdx.x, gridDim.x * 32 >= (unsigned)cols);   // (cols + 31) / 32 blocks = narrow
+}
 
+// blocks [0, slab_blocks): out = the slabs added in order; the blocks after them (round 4): the bias gradient's final
+// sums from its partial rows, in the same launch (cs_narrow: colsum_final_blocks' choice)
 __global__ void __launch_bounds__(kThreads)
 k_sum_slabs_f32(const float *__restrict__ slabs, int64_t slab_stride, int splits, int rows, int N,
-                float *__restrict__ out, int64_t ldo) {
+                float *__restrict__ out, int64_t ldo, int slab_blocks, const float *__restrict__ cs_partial, int cs_chunks,
+                float *__restrict__ cs_out, int cs_narrow) {
+  if ((int)blockIdx.x >= slab_blocks) {
+    colsum_final_block(cs_partial, cs_chunks, N, cs_out, blockIdx.x - slab_blocks, cs_narrow != 0);
+    return;
+  }
   const int n4 = N >> 2;
   const int64_t total = (int64_t)rows * n4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
+       i += (int64_t)slab_blocks * blockDim.x) {
     const int64_t r = i / n4;
     const int c = (int)(i - r * n4);
     f32x4 s = reinterpret_cast<const f32x4 *>(slabs)[i];
@@ -526,9 +536,9 @@ extern "C" int cdml_gemm_bf16_nt(int epilogue, const uint16_t *A, int64_t lda, c
   rc = check_launch("gemm_bf16_nt");
   }
   if (rc || splits == 1) return rc;
-  hipLaunchKernelGGL(k_sum_slabs_f32, dim3(grid1d((int64_t)M * N / 4, 1)), block, 0, s,
-                     static_cast<const float *>(workspace), g.slab_stride, splits, M, N,
-                     static_cast<float *>(C), ldc);
+  const int sbn = grid1d((int64_t)M * N / 4, 1);
+  hipLaunchKernelGGL(k_sum_slabs_f32, dim3(sbn), block, 0, s, static_cast<const float *>(workspace), g.slab_stride, splits, M, N,
+                     static_cast<float *>(C), ldc, sbn, static_cast<const float *>(nullptr), 0, static_cast<float *>(nullptr), 0);
   return check_launch("gemm_bf16_nt combine");
 }
 
@@ -576,10 +586,11 @@ extern "C" int cdml_gemm_bf16_tn(const uint16_t *A, int64_t lda, const uint16_t 
   if (colsum) g.colsum_partial = static_cast<float *>(workspace) + slab_floats;
   int rc = launch_gemm_bf16_tn(g, splits, s);
   if (rc) return rc;
-  if (splits > 1) {
-    hipLaunchKernelGGL(k_sum_slabs_f32, dim3(grid1d((int64_t)M * N / 4, 1)), dim3(kThreads), 0, s,
-                       static_cast<const float *>(workspace), g.slab_stride, splits, M, N, C, ldc);
-    if ((rc = check_launch("gemm_bf16_tn combine"))) return rc;
+  if (splits > 1) {                                        // the slab sum and, in extra blocks, the bias gradient's final sums
+    const int sb = grid1d((int64_t)M * N / 4, 1), cb = colsum ? colsum_final_blocks(chunks, N) : 0;
+    hipLaunchKernelGGL(k_sum_slabs_f32, dim3(sb + cb), dim3(kThreads), 0, s, static_cast<const float *>(workspace), g.slab_stride,
+                       splits, M, N, C, ldc, sb, g.colsum_partial, chunks, colsum, (cb * 32 >= N) ? 1 : 0);
+    return check_launch("gemm_bf16_tn combine");
   }
   if (colsum) {
     hipLaunchKernelGGL(k_colsum_final, dim3(colsum_final_blocks(chunks, N)), dim3(kThreads), 0, s,
