@@ -286,23 +286,38 @@ def learnable_catalogue(n_rows, dev, n_clusters=2000, seed=0):
     return table, pairs[torch.randperm(pairs.shape[0], device=dev, generator=g)].contiguous()
 
 
-def settle_gpu(dev, seconds=0.3):
-    """Weight-gradient GEMM launches on scratch buffers for ~`seconds`: the first ~100 ms of MFMA work after an
-    idle spell run ~2 % slower on this part (clock ramp).  Not a step of the measured job: no state of the
-    TrainStep is touched; disclosed in `order` / `warmup_effective`."""
+def settle_gpu(dev, seconds=0.3, precision="f32"):
+    """GEMM launches on scratch buffers for ~`seconds`: the first ~100 ms of MFMA work after an idle spell run
+    ~2 % slower on this part (clock ramp).  Not a step of the measured job: no state of the TrainStep is touched;
+    disclosed in `order` / `warmup_effective`.  The launches are of the measured step's KIND of matrix work -- fp32 MFMA
+    for precision "f32", bf16 MFMA for "f32x3" / "bf16" (the chip settles at a different clock under each) -- but of a
+    kernel instantiation the step itself does not use, so a rocprofv3 run of this bench keeps clean per-kernel averages."""
     from cdml_amd import ops
-    M, K, N = 4096, 1536, 5120
-    # the split-K weight-gradient entry point: an MFMA-bound launch that is NOT part of the N = 1 step
-    # (stream-K there), so a rocprofv3 run of this bench keeps clean per-kernel averages for the step
-    x = torch.rand((M, K), device=dev)
-    dy = torch.randn((M, N), device=dev) * 0.02
-    dW = torch.empty((K, N), device=dev)
-    db = torch.empty(N, device=dev)
-    ws = torch.empty(max(ops.fc_bwd_weight_workspace(M, K, N), 16) // 4, device=dev)
+    if precision == "f32":
+        M, K, N = 4096, 1536, 5120
+        # the split-K weight-gradient entry point: an MFMA-bound launch that is NOT part of the N = 1 step (stream-K there)
+        x = torch.rand((M, K), device=dev)
+        dy = torch.randn((M, N), device=dev) * 0.02
+        dW = torch.empty((K, N), device=dev)
+        db = torch.empty(N, device=dev)
+        ws = torch.empty(max(ops.fc_bwd_weight_workspace(M, K, N), 16) // 4, device=dev)
+        launch = lambda: ops.fc_bwd_weight(x, dy, dW, db, ws, M, K, N)
+    else:
+        M, K, N = 8192, 1536, 5120
+        A = (torch.rand((M, K), device=dev) * 0.05).to(torch.bfloat16)
+        Bm = (torch.randn((N, K), device=dev) * 0.03).to(torch.bfloat16)
+        bias = torch.zeros(N, device=dev)
+        if precision == "bf16":        # config 4's step runs the plain bf16 kernels: settle on the plane-walking one
+            A3, B3 = torch.cat([A, A, A], 1).contiguous(), torch.cat([Bm, Bm, Bm], 1).contiguous()
+            C = torch.empty((M, N), device=dev)
+            launch = lambda: ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, A3, K, B3, K, C, M, N, K, bias=bias)
+        else:                          # the f32x3 step runs the plane-walking kernels: settle on the plain bf16 one
+            C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            launch = lambda: ops.gemm_bf16_nt(ops.BE_BIAS_LRELU_BF16, A, Bm, C, M, N, K, bias=bias)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(20):
-            ops.fc_bwd_weight(x, dy, dW, db, ws, M, K, N)
+            launch()
         torch.cuda.synchronize(dev)
 
 
@@ -884,7 +899,7 @@ def main():
             sys.exit("--mode predict is a one-GPU measurement")
         set_phase("predict")
         if not args.no_settle:
-            settle_gpu(dev)
+            settle_gpu(dev, precision=args.precision[:5])
         r = rec_predict(dev, args.precision, n_rows=args.rows or 10000000)
         out = {"metric": "catalogue rows embedded/sec", "value": r["value"], "unit": "rows/s", "n_gpus": 1,
                "steps": r["passes_timed"], "warmup": 1, "ms_per_step": round(r["seconds"] * 1e3, 3),
@@ -898,7 +913,7 @@ def main():
             sys.exit("--only is a one-GPU measurement")
         set_phase("only: " + args.only)
         if not args.no_settle:
-            settle_gpu(dev)
+            settle_gpu(dev, precision=args.precision[:5])
         n_s, n_w = args.steps, args.warmup
         if args.only == "reference_recipe":
             r = rec_reference_recipe(dev, args, n_s, n_w, engine.FeatureTable.synthetic(1000000, F, seed=0, device=dev))
@@ -969,9 +984,29 @@ def main():
             return float(t.item())
 
         pre_steps = 0
+        settle_how = None
         if not args.no_settle:
             set_phase("clock settle")
-            settle_gpu(dev)
+            settle_how = os.environ.get("CDML_SETTLE", "clone" if (world == 1 and not args.train_table) else "gemm")
+            if settle_how == "clone":
+                # 0.3 s of steps of a SECOND TrainStep of the same shape -- its own weights (another seed), optimizer state,
+                # activations and gather buffers; it shares only the read-only catalogue and pair list -- then it is freed.
+                # Why not GEMM launches alone (rounds 2-3): the chip takes ~100 ms of THIS mix of matrix and memory phases to
+                # reach the clock it then holds; after 0.3 s of bare GEMMs (fp32 or bf16 alike) a 20-step run still read
+                # 3-4 % above the 200-step rate (profiles/r04_settle_kinds.txt), after this it reads the same.  Nothing of the
+                # measured job runs or changes before its W warm-up steps; `warmup_effective` says what did.
+                clone = train.TrainStep(table, pairs, B, output_size=D, hidden_size=H, margin=MARGIN, mode=mode, optimizer="adam",
+                                        base_learning_rate=0.01, seed=99, weight_seed=7, device=dev, precision=args.precision,
+                                        gather_ahead=args.gather_ahead)
+                t0 = time.perf_counter()
+                while time.perf_counter() - t0 < 0.3:
+                    for _ in range(20):
+                        clone.step()
+                    torch.cuda.synchronize(dev)
+                del clone
+                torch.cuda.empty_cache()
+            else:
+                settle_gpu(dev, precision=args.precision[:5])
         if world > 1 and args.grad_sync == "auto" and not args.train_table:
             # which gradient-sync form is faster HERE (link speed against kernel speed): a few steps of
             # each, max over ranks (so every rank picks the same one), before the warm-up steps
@@ -1075,10 +1110,15 @@ def main():
         out["warmup_effective"] = {"steps_of_this_job_before_the_timed_region": args.warmup + pre_steps,
                                    "of_which_grad_sync_probe": pre_steps,
                                    "settle_loop_s": 0.0 if args.no_settle else 0.3,
-                                   "note": "the settle loop launches weight-gradient GEMMs on scratch buffers (no state of the "
-                                           "job): the first ~100 ms of MFMA work after idle run ~2 % slower (clock ramp)"}
+                                   "settle_kind": None if args.no_settle else settle_how,
+                                   "note": "settle_kind clone: 0.3 s of steps of a SECOND TrainStep of the same shape on its own "
+                                           "buffers (own weights, optimizer state, activations; only the read-only catalogue and "
+                                           "pair list are shared), freed before the warm-up steps; gemm: 0.3 s of GEMM launches on "
+                                           "scratch buffers.  No state of the measured job is touched: the chip needs ~100 ms of "
+                                           "this kind of work to reach the clock it then holds (a 20-step run from idle reads "
+                                           "3-4 % above the 200-step rate)"}
         out["order"] = ("%swarm-up + timed steps, then the secondary records, cpu_baseline last"
-                        % ("" if args.no_settle else "0.3 s settle loop, "))
+                        % ("" if args.no_settle else "0.3 s settle loop (%s), " % settle_how))
 
         # ---- secondary records (after the headline; the failure of one must not cost the line) ----
         run_extras = config1 and mode == "inbatch" and not args.no_extras and not args.train_table and x3 in (0, 6)
