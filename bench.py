@@ -37,7 +37,9 @@ Prints ONE JSON line (rank 0).  Beside the contract's fields:
   comm           (N > 1) what the compute stream waits for: all-reduce and row exchange; which
                  gradient-sync form ran (`grad_sync`: both forms are timed for a few steps before
                  the warm-up and the faster one is kept)
-  order / warmup_effective   what ran on the GPU before the timed region
+  order / warmup_effective   what ran on the GPU before the timed region (N = 1: a 0.3-s clock-settle loop of steps of a
+                 SECOND TrainStep of the same shape on its own buffers -- the measured job's state is untouched -- then the
+                 W warm-up steps; DESIGN.md section 8 says why bare GEMM launches were not enough)
 Secondary records of the default N = 1 line (measured AFTER the headline; each in its own try; those that
 train run at the headline's precision):
   f32_mfma           the headline workload on the fp32 MFMA (precision "f32": the headline of rounds 1-3), full
