@@ -1,0 +1,85 @@
+"""The resident-plane walk (R6) of csrc/gemm_bf16_256.hip has a 12-phase LDS-DMA schedule with counted waits; this test
+reads the schedule OUT OF THE KERNEL SOURCE -- the product order, the slot tables, what every phase issues, the vmcnt
+immediates, the prologue -- and replays it: every fragment read must find the plane / half / K-tile it expects in its slot
+(content), every half image must be guaranteed landed by a wait at least one phase before its first read (RAW, with the
+in-order vmcnt semantics: a wait for N leaves the N newest pieces in flight, two pieces per half image), and every
+overwrite must be issued at least one phase after the last read of what it replaces (WAR; reads retire before a phase's
+first barrier and the lagging row group is one barrier behind -- the rule of the round-1 schedule).  A pitfall the GPU
+tests cannot be trusted to catch: an early read passes whenever the DMA happens to land first."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = open(os.path.join(ROOT, "collaborative-deep-metric-learning_amd", "csrc", "gemm_bf16_256.hip")).read()
+
+
+def _ints(name, text):
+    m = re.search(name + r"\s*=\s*\{([^;]*?)\}[,;]", text)
+    assert m, name
+    return [int(x) for x in re.findall(r"-?\d+", m.group(1))]
+
+
+def _schedule():
+    i = SRC.index("auto phase = [&](auto phc, auto parc")
+    body = SRC[i:SRC.index("auto period = [&]", i)]
+    pa, pb = _ints(r"constexpr int PA\[6\]", body)[:6], _ints(r"PB\[6\]", body)[:6]
+    sa = [int(x) for x in re.findall(r"\d+", re.search(r"SLOT_A\[2\]\[3\]\s*=\s*\{(.*?)\}\};", body).group(1))]
+    slot_a = [sa[:3], sa[3:6]]
+    assert len(sa) == 6
+    vm = _ints(r"constexpr int VM\[12\]", body)
+    assert len(vm) == 12
+    issue = {}
+    for m in re.finditer(r"if constexpr \(PH == (\d+)\) issue\((\d), (\d), (\d), ([^,]+), (kw[ab]_[cn])\);", body):
+        issue[int(m.group(1))] = (int(m.group(2)), int(m.group(3)), int(m.group(4)), m.group(5).strip(), m.group(6)[-1] == "n")
+    assert sorted(issue) == list(range(12))
+    sb = re.search(r"constexpr int sb = (.+?);", body).group(1)          # B slot of the plane read at this phase
+    rdb = re.search(r"constexpr bool rdB = HALF == 0 && \((.+?)\);", body).group(1)
+    rdb_steps = [int(x) for x in re.findall(r"S == (\d)", rdb)]
+    j = SRC.index("// prologue: the steady state at phase 0 of the first K-tile")
+    pro = [(int(a), int(b), int(c), int(d)) for a, b, c, d in
+           re.findall(r"issue\((\d), (\d), (\d), (\d), k[ab]_?\);", SRC[j:SRC.index("CDML_BARRIER();", j)])]
+    pro_vm = int(re.search(r"vmcnt\((\d+)\)", SRC[j:SRC.index("CDML_BARRIER();", j)]).group(1))
+    return pa, pb, slot_a, vm, issue, sb, rdb_steps, pro, pro_vm
+
+
+def test_r6_schedule_hazards():
+    PA, PB, SLOT_A, VM, ISSUE, SB, RDB, PRO, PRO_VM = _schedule()
+    assert sorted(zip(PA, PB)) == sorted([(0, 0), (0, 1), (1, 0), (0, 2), (2, 0), (1, 1)]), "the six plane products"
+    n_per = 7
+    seq = []                                                        # (time, (operand, slot, half), (operand, plane, half, K-tile))
+    for n, (img, pl, hh, slot) in enumerate(PRO):
+        seq.append((n - len(PRO), (img, slot, hh), (img, pl, hh, 0)))
+    for w in range(n_per):
+        PAR = w & 1
+        for ph in range(12):
+            img, pl, hh, slot_expr, nxt = ISSUE[ph]
+            slot = eval(slot_expr, {"SLOT_A": SLOT_A, "PAR": PAR})
+            seq.append((w * 12 + ph, (img, slot, hh), (img, pl, hh, w + (1 if nxt else 0))))
+    reads = []
+    for w in range(n_per):
+        PAR = w & 1
+        for ph in range(12):
+            S, HALF = ph >> 1, ph & 1
+            reads.append((w * 12 + ph, (0, SLOT_A[PAR][PA[S]], HALF), (0, PA[S], HALF, w)))
+            if HALF == 0 and S in RDB:
+                slot = eval(SB, {"PB": PB, "S": S, "PAR": PAR})
+                reads += [(w * 12 + ph, (1, slot, hh), (1, PB[S], hh, w)) for hh in (0, 1)]
+    assert sum(1 for r in reads if r[1][0] == 1) == n_per * 6, "B fragments are read on three of the six steps"
+
+    def landed_by(idx):                                             # the earliest wait after which load #idx is guaranteed done
+        for T in range(-1, n_per * 12):
+            issued = sum(1 for tt, _, _ in seq if tt <= T)
+            in_flight = (PRO_VM if T == -1 else VM[T % 12]) // 2    # half images allowed to stay in flight
+            if idx < issued - in_flight:
+                return T
+        return None
+
+    for T, key, want in reads:
+        last = [(i, tt, tag) for i, (tt, k, tag) in enumerate(seq) if k == key and tt < T][-1]
+        assert last[2] == want, "phase %d reads %s: the slot holds %s, not %s" % (T, key, last[2], want)
+        lt = landed_by(last[0])
+        assert lt is not None and lt <= T - 1, "RAW: %s read at phase %d, guaranteed landed only by the wait of phase %s" % (want, T, lt)
+    for tt, key, tag in seq:
+        assert not [T for T, k, _ in reads if k == key and T == tt], "WAR: %s overwritten in the phase that still reads it (%d)" % (key, tt)
+    # every phase issues exactly one half image, 6 plane images per K-tile
+    assert len(seq) == len(PRO) + 12 * n_per
