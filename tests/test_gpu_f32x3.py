@@ -50,6 +50,8 @@ def test_split_planes_are_exact(rows, cols, transpose):
                                    (8192, 5120, 1536)])
 @pytest.mark.parametrize("products", [6, 3])
 def test_gemm_x3_nt_matches_fp64_like_fp32(M, N, K, products):
+    if (products * K // 64) % 2:
+        pytest.skip("the general loop (three products) walks K-tiles in pairs: products * K / 64 must be even")
     torch.manual_seed(1)
     dev = _dev()
     A = torch.rand(M, K, device=dev)
@@ -401,3 +403,39 @@ def test_sign_bitmask_epilogues_equal_the_value_mask():
     v7 = d7[:, :N].float() + d7[:, N:2 * N].float() + d7[:, 2 * N:].float()
     v10 = d10[:, :N].float() + d10[:, N:2 * N].float() + d10[:, 2 * N:].float()
     assert torch.equal(v7[same], v10[same])
+
+
+def test_resident_plane_walk_race_screen():
+    """The resident-plane walk (R6) orders its LDS-DMA against the fragment reads by counted waits and barriers only (the
+    schedule itself is replayed on the CPU in tests/test_r6_schedule.py); a misplaced wait would show up as rare wrong
+    tiles.  Both forms, the full chip, many launches back to back with other launches' traffic in between, every result
+    compared bit for bit with the first (which is checked against fp64)."""
+    torch.manual_seed(9)
+    dev = _dev()
+    # k-contiguous form: 256 tiles (one per CU), 16 K-tiles = 16 periods each; odd period count in the second shape
+    for (M, N, K) in ((4096, 4096, 1024), (2048, 2048, 448)):
+        A = torch.randn(M, K, device=dev) / 32
+        B = torch.randn(N, K, device=dev)
+        A3, B3 = _planes(A, K), _planes(B, K)
+        out = torch.empty(M, N, device=dev)
+        ops.gemm_bf16x3_nt(ops.BE_F32, A3, K, B3, K, out, M, N, K)
+        ref = A.double() @ B.double().t()
+        assert (out.double() - ref).abs().max().item() <= 5e-6 * ref.abs().max().item()
+        first = out.clone()
+        for _ in range(40):
+            ops.gemm_bf16x3_nt(ops.BE_F32, A3, K, B3, K, out, M, N, K)
+            assert torch.equal(out, first)
+    # k-strided form with the bias gradient riding along: 6 x 20 tiles x 2 K-halves (the weight gradient's launch shape)
+    M, N, K = 1536, 5120, 2048
+    X = torch.randn(K, M, device=dev) / 16
+    dY = torch.randn(K, N, device=dev) * 1e-2
+    X3, dY3 = _planes(X, M), _planes(dY, N)
+    C, db = torch.empty(M, N, device=dev), torch.empty(N, device=dev)
+    ws = _ws(True, M, N, K)
+    ops.gemm_bf16x3_tn(X3, M, dY3, N, C, M, N, K, workspace=ws, colsum=db)
+    ref = X.double().t() @ dY.double()
+    assert (C.double() - ref).abs().max().item() <= 5e-6 * ref.abs().max().item()
+    c0, d0 = C.clone(), db.clone()
+    for _ in range(40):
+        ops.gemm_bf16x3_tn(X3, M, dY3, N, C, M, N, K, workspace=ws, colsum=db)
+        assert torch.equal(C, c0) and torch.equal(db, d0)
