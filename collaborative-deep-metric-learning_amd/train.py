@@ -215,15 +215,7 @@ class TrainStep:
                 logging.getLogger("cdml.train").warning(
                     "use_graph ignored: host-staged (gloo) collectives cannot be captured; RCCL ones can")
             else:
-                # captured collectives go through process groups of their own, which never carry an eager one: the RCCL
-                # watchdog's work list of a captured communicator is then empty by construction (dist.new_capture_group
-                # says why that matters -- round 3 slept 0.25 s before a capture instead).  Created here, in the same
-                # order on every rank (constructing a TrainStep is a collective call when it is to replay RCCL from graphs).
-                for h in (exchange, grad_sync):
-                    if h is not None and getattr(h, "capture_group", None) is None and \
-                            torch.distributed.get_backend(h.group) == "nccl" and (h.world > 1 or not getattr(h, "skip_self", True)
-                                                                                 or getattr(h, "active", False)):
-                        h.capture_group = _cdist.new_capture_group(h.group)
+                self._ensure_capture_groups()
         # row-sharded catalogue: the exchange of step t+1 runs ahead on a side stream
         # into the second x_hat / idx buffer while step t computes
         self.prefetch = None
@@ -236,6 +228,23 @@ class TrainStep:
             self._shift = [self.shift, torch.zeros_like(self.shift)]
         if self.use_graph == "split" and self.prefetch is None:
             self.use_graph = True                        # nothing to overlap: one graph per step
+
+    def _ensure_capture_groups(self):
+        """Captured collectives go through process groups of their own, which never carry an eager one: the RCCL watchdog's
+        work list of a captured communicator is then empty by construction (dist.new_capture_group says why that matters
+        -- round 3 slept 0.25 s before a capture instead).  Created at construction when the step is to replay RCCL from
+        graphs, and again checked right before any capture (a step switched to graph replay later): a collective call,
+        reached by every rank at the same point in the same order."""
+        from . import dist as _cdist
+        for h in (self.exchange, self.grad_sync):
+            if h is None or getattr(h, "capture_group", None) is not None:
+                continue
+            if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+                continue
+            if torch.distributed.get_backend(h.group) != "nccl":
+                continue
+            if h.world > 1 or not getattr(h, "skip_self", True) or getattr(h, "active", False):
+                h.capture_group = _cdist.new_capture_group(h.group)
 
     @property
     def grad_sync_mode(self):
@@ -591,6 +600,7 @@ class TrainStep:
         """Record ``fn`` (default: the whole step) into a hipGraph.  ``origin``: the stream the capture
         starts on (default: a fresh one) -- RCCL's communicator stream is then one fork from it."""
         torch.cuda.synchronize(self.device)
+        self._ensure_capture_groups()
         # (RCCL collectives recorded below go through the hooks' capture-only process groups -- dist.new_capture_group:
         # no eager collective is ever issued on them, so the watchdog thread has nothing of theirs to poll while their
         # communicator streams are inside this capture; the eager steps' groups are never captured)
