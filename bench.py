@@ -292,8 +292,10 @@ def settle_gpu(dev, seconds=0.3, precision="f32"):
     """GEMM launches on scratch buffers for ~`seconds`: the first ~100 ms of MFMA work after an idle spell run
     ~2 % slower on this part (clock ramp).  Not a step of the measured job: no state of the TrainStep is touched;
     disclosed in `order` / `warmup_effective`.  The launches are of the measured step's KIND of matrix work -- fp32 MFMA
-    for precision "f32", bf16 MFMA for "f32x3" / "bf16" (the chip settles at a different clock under each) -- but of a
-    kernel instantiation the step itself does not use, so a rocprofv3 run of this bench keeps clean per-kernel averages."""
+    for precision "f32", bf16 MFMA for "f32x3" / "bf16" -- but of a kernel instantiation the step itself does not use, so a
+    rocprofv3 run of this bench keeps clean per-kernel averages.  (Either kind leaves a 20-step run 3-4 % above the
+    200-step rate, profiles/r04_settle_kinds.txt: the N = 1 lines settle on steps of a second TrainStep instead, main();
+    this loop remains for N > 1, --mode predict, --only and CDML_SETTLE=gemm.)"""
     from cdml_amd import ops
     if precision == "f32":
         M, K, N = 4096, 1536, 5120

@@ -43,7 +43,7 @@ def _host_staged(group):
     return dist.get_backend(group) != "nccl"
 
 
-def _capturing(t=None):
+def _capturing():
     return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
