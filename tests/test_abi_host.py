@@ -176,3 +176,21 @@ def test_bench_self_launch_reports_failed_rank():
     assert r.returncode == 1
     assert "2-rank run failed: rank" in r.stderr and "exited with code" in r.stderr and "rank 1:" in r.stderr
     assert "needs an MI355X" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_train_config_carries_the_reference_defaults_and_round_trips(tmp_path):
+    """SURVEY section 5 'Config / flags': one object with the reference's names and its hard-coded values
+    (train.py:358-373, 212-222)."""
+    from cdml_amd.config import TrainConfig
+    c = TrainConfig()
+    assert (c.num_epochs, c.batch_size, c.learning_rate, c.margin, c.optimizer) == (8, 1024, 1.0, 0.8, "lars")
+    assert (c.check_stop_epoch, c.best_eval_dist, c.eval_per_epoch, c.require_improve_num) == (3, 1.0, 100, 40)
+    assert (c.output_size, c.learning_rate_decay_examples, c.learning_rate_decay) == (256, 1000000, 0.96)
+    assert (c.clip_gradient_norm, c.regularization_penalty, c.model, c.hidden_size) == (0.0, 0.0, "VNet", 5000)
+    p = tmp_path / "cfg.json"
+    c2 = TrainConfig(batch_size=4096, mode="inbatch", optimizer="adam", learning_rate=0.01)
+    c2.to_json(str(p))
+    assert TrainConfig.from_json(str(p)) == c2 and TrainConfig.from_json(c2.to_json()) == c2
+    import pytest
+    with pytest.raises(ValueError):
+        TrainConfig.from_json('{"batchsize": 3}')

@@ -802,6 +802,28 @@ def test_graph_replay_equals_eager(cd, precision):
     assert torch.equal(a.idx, b.idx) and int(b.step_dev.item()) == 4
 
 
+def test_train_config_builds_the_same_step(cd):
+    """config.TrainConfig (the reference's scattered hyper-parameters, train.py:358-373 / 212-222, as one object)
+    builds the step and the loop the explicit arguments build."""
+    from cdml_amd.config import TrainConfig
+    N, F, B = 4000, 200, 128
+    table = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev)
+    pairs = dt(osynth.cowatch_pairs(N, 500, 0), cd.dev, torch.int32)
+    cfg = TrainConfig(batch_size=B, hidden_size=300, output_size=64, num_epochs=2)
+    a = cfg.train_step(table, pairs, device=cd.dev)
+    b = cd.train.TrainStep(table, pairs, B, hidden_size=300, output_size=64, mode="uniform", optimizer="lars",
+                           base_learning_rate=1.0, margin=0.8, precision="f32x3", device=cd.dev)
+    for _ in range(3):
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.params.flat, b.params.flat) and a.loss() == b.loss()
+    tr = cfg.trainer(a, 500)
+    assert tr.num_batches == (500 * 2) // B and tr.require_improve_num == 40 and tr.best_eval_dist == 1.0
+    with pytest.raises(ValueError):
+        TrainConfig(model="VENet").train_step(table, pairs, device=cd.dev)
+
+
 # --------------------------------------------------------------------- facade --
 def test_facade_matches_train_step(cd):
     """models.VNet / losses.HingeLoss / inputs.MPTripletPipe used the way
