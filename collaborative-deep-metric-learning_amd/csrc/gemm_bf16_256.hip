@@ -51,6 +51,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
 constexpr int kT = 512;
@@ -81,6 +82,17 @@ __device__ __forceinline__ void dma_s(i32x4 srd, uint32_t voff, uint32_t soff, u
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory", "m0");
 }
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+// two fp32 -> one dword of two bf16 (round to nearest even; element 0 in the low half), and the halves back as fp32
+// (the dword is made opaque: hipcc otherwise sees through `pack << 16` and converts the low element a second time on its own)
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  uint32_t w = __builtin_bit_cast(uint32_t, bf16x2{(__bf16)a, (__bf16)b});
+  asm("" : "+v"(w));
+  return w;
+}
+__device__ __forceinline__ float lo_of(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float hi_of(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
   const uint64_t a = (uint64_t)(uintptr_t)base;
   i32x4 r;
@@ -853,107 +865,154 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     // bf16 outputs of the k-contiguous form: 16 B per lane and store (8 rows x 128 B per instruction) instead of
     // 8 B -- half the store instructions of the tile's tail (cdna guide T21: such a tail is issue-bound)
     const int c8 = lane & 7, lcol8 = wc * 64 + c8 * 8;
-    f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    f32x2 bb2[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
     if (kBiasEpi && !kRowBias) {
-      b0 = *reinterpret_cast<const f32x4 *>(g.bias + n0 + lcol8);
-      b1 = *reinterpret_cast<const f32x4 *>(g.bias + n0 + lcol8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(g.bias + n0 + lcol8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(g.bias + n0 + lcol8 + 4);
+      bb2[0] = f32x2{b0.x, b0.y}; bb2[1] = f32x2{b0.z, b0.w}; bb2[2] = f32x2{b1.x, b1.y}; bb2[3] = f32x2{b1.z, b1.w};
     }
-    auto row8 = [&](int rt, int p) { return m0 + grp * 128 + rt * 32 + p * 8 + (lane >> 3); };
-    bf16x8 mk8[4][4];
-    unsigned mb8[4][4];
-    // the leaky-relu' mask operand: bf16 values (sign of the hi plane) or, split-fp32 form with g.aux_bits, ONE BIT per
-    // element written by the forward layer's epilogue below (this lane's 8 columns = one byte; ldaux in bytes) -- the
-    // value form reads 84 MB of h1's hi plane from HBM inside the store-bound epilogue (30 us of the data gradient's 151)
-    const bool mask_bits = X3 && kMaskEpi && has_aux && g.aux_bits;
-    if (kMaskEpi && has_aux) {                               // all 16 mask loads of the wave go out together
-      if (mask_bits) {
+    // Round 4 (late): this tail was 2700 vector + 1500 scalar instructions per wave in the data gradient -- a branch per
+    // ELEMENT on the runtime-uniform "which mask form" switches, 64-bit address arithmetic per store.  Now every such switch
+    // is resolved ONCE per tile (MM: 0 = no mask operand, 1 = bf16 values, 2 = one bit per element; WB = also write the
+    // sign bitmask), a store's address is a wave-uniform base (SGPRs, scalar adds) plus one 32-bit lane offset that never
+    // changes, the bias / leaky-relu / residual arithmetic is written on float pairs (v_pk_*), a sign bit costs a compare
+    // and an add-with-carry, a bit-masked element a bit-field extract and a bit-field insert.
+    auto tail16 = [&](auto mm_c, auto wb_c) {
+      constexpr int MM = decltype(mm_c)::value;
+      constexpr bool WB = decltype(wb_c)::value;
+      const int lrow = lane >> 3;                                  // the lane's row inside an 8-row store
+      const int rows_left = g.M - m0 - grp * 128 - lrow;          // rows rt*32 + p*8 + lrow < ... are inside the matrix
+      const uint32_t lane_c = (uint32_t)(((int64_t)lrow * c_ld + lcol8) * 2);
+      const uint32_t lane_m = (uint32_t)((int64_t)lrow * g.ldmask + (lcol8 >> 3));
+      const uint32_t plane_bytes = (uint32_t)(g.x3_plane_c * 2);
+      bf16x8 mk8[MM == 1 ? 4 : 1][MM == 1 ? 4 : 1];
+      int mb8[MM == 2 ? 4 : 1][MM == 2 ? 4 : 1];
+      // the leaky-relu' mask operand: bf16 values (sign of the hi plane) or, split-fp32 form with g.aux_bits, ONE BIT per
+      // element written by the forward layer's epilogue below (this lane's 8 columns = one byte; ldaux in bytes) -- the
+      // value form reads 84 MB of h1's hi plane from HBM inside the store-bound epilogue (30 us of the data gradient's 151).
+      // All 16 mask loads of the wave go out together (rows clamped, not branched around)
+      if constexpr (MM != 0) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-          for (int p = 0; p < 4; ++p)
-            mb8[rt][p] = reinterpret_cast<const uint8_t *>(g.aux)[(int64_t)min(row8(rt, p), g.M - 1) * g.ldaux + ((n0 + lcol8) >> 3)];
-      } else {
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-          for (int p = 0; p < 4; ++p)
-            mk8[rt][p] = *reinterpret_cast<const bf16x8 *>(g.aux + (int64_t)min(row8(rt, p), g.M - 1) * g.ldaux + n0 + lcol8);
-      }
-    }
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      float *strip = sC + (rt & 1) * 2048;                 // alternate halves: no wait for the readers
-      if constexpr (S16) {
-#pragma unroll
-        for (int rbb = 0; rbb < 2; ++rbb)
-#pragma unroll
-          for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              strip[(rbb * 16 + q16 * 4 + r) * 64 + ((cb * 16 + l15) ^ ((q16 & 1) << 4))] = acc16[2 * rt + rbb][cb][r];
-      } else {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            strip[row * 64 + ct * 32 + l31] = acc[rt][ct][r];
+          for (int p = 0; p < 4; ++p) {
+            const int64_t rowc = m0 + grp * 128 + min(rt * 32 + p * 8 + lrow, g.M - 1 - m0 - grp * 128);
+            if constexpr (MM == 2) mb8[rt][p] = reinterpret_cast<const uint8_t *>(g.aux)[rowc * g.ldaux + ((n0 + lcol8) >> 3)];
+            else mk8[rt][p] = *reinterpret_cast<const bf16x8 *>(g.aux + rowc * g.ldaux + n0 + lcol8);
           }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      const f32x2 alpha2 = f32x2{g.alpha, g.alpha};
+      char *ub_c = static_cast<char *>(c_base) + ((int64_t)(grp * 128 + c_row0) * c_ld + c_col0) * 2;   // 8 rows further per store group
+      uint8_t *ub_m = WB ? g.mask_out + (int64_t)(m0 + grp * 128) * g.ldmask + (n0 >> 3) : nullptr;
+      const int64_t row8_c = c_ld * 16, row8_m = g.ldmask * 8;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int lr = p * 8 + (lane >> 3);
-        const int row = row8(rt, p);
-        const int sw = S16 ? (((lr >> 2) & 1) << 4) : 0;
-        f32x4 v0 = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c8 * 8) ^ sw));
-        f32x4 v1 = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c8 * 8 + 4) ^ sw));
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        if constexpr (kRowBias) {
-          const float br = g.bias[min(row, g.M - 1)];
+      for (int rt = 0; rt < 4; ++rt) {
+        float *strip = sC + (rt & 1) * 2048;                 // alternate halves: no wait for the readers
+        if constexpr (S16) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) bb[j] = br;
-        }
-        bf16x8 o;
-        unsigned bits = 0;
+          for (int rbb = 0; rbb < 2; ++rbb)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (kBiasEpi) {
-            v[j] += bb[j];
-            v[j] = fmaxf(v[j], v[j] * g.alpha);
-          } else if (has_aux) {
-            if (mask_bits) v[j] *= ((mb8[rt][p] >> j) & 1u) ? 1.f : g.alpha;
-            else v[j] *= ((float)mk8[rt][p][j] > 0.f) ? 1.f : g.alpha;
-          }
-          if constexpr (kPlanes) asm volatile("" : "+v"(v[j]));   // the planes are those of the ROUNDED value
-          o[j] = (bf16)v[j];
-          if (EPI == BE_BIAS_LRELU_BF16 && (float)o[j] > 0.f) bits |= 1u << j;
-          if (X3 && kBiasEpi && v[j] > 0.f) bits |= 1u << j;   // sign of the fp32 activation itself
-        }
-        if (row >= g.M) continue;                            // stores only below this line
-        if constexpr (kPlanes) {
-          if (kBiasEpi && g.mask_out)                        // this lane's 8 columns = one byte of the sign bitmask
-            g.mask_out[(int64_t)row * g.ldmask + ((n0 + lcol8) >> 3)] = (uint8_t)bits;
-          // three roundings to nearest hold the 24 significant bits: hi + mid + lo == v exactly
-          bf16 *dst = static_cast<bf16 *>(c_base) + (int64_t)(row - m0 + c_row0) * c_ld + c_col0 + lcol8;
-          *reinterpret_cast<bf16x8 *>(dst) = o;
+            for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-          for (int pl = 1; pl < 3; ++pl) {
+              for (int r = 0; r < 4; ++r)
+                strip[(rbb * 16 + q16 * 4 + r) * 64 + ((cb * 16 + l15) ^ ((q16 & 1) << 4))] = acc16[2 * rt + rbb][cb][r];
+        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              v[j] -= (float)o[j];
-              o[j] = (bf16)v[j];
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+              strip[row * 64 + ct * 32 + l31] = acc[rt][ct][r];
             }
-            *reinterpret_cast<bf16x8 *>(dst + pl * g.x3_plane_c) = o;
-          }
-          continue;
         }
-        if (EPI == BE_BIAS_LRELU_BF16 && g.mask_out)         // this lane's 8 columns = one byte of the sign bitmask
-          g.mask_out[(int64_t)row * g.ldmask + ((n0 + lcol8) >> 3)] = (uint8_t)bits;
-        *reinterpret_cast<bf16x8 *>(static_cast<bf16 *>(c_base) + (int64_t)(row - m0 + c_row0) * c_ld + c_col0 + lcol8) = o;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int lr = p * 8 + lrow;
+          const int sw = S16 ? (((lr >> 2) & 1) << 4) : 0;
+          const f32x4 v0 = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c8 * 8) ^ sw));
+          const f32x4 v1 = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c8 * 8 + 4) ^ sw));
+          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          if constexpr (kBiasEpi) {
+            f32x2 bq[4] = {bb2[0], bb2[1], bb2[2], bb2[3]};
+            if constexpr (kRowBias) {
+              const float br = g.bias[m0 + grp * 128 + min(rt * 32 + lr, g.M - 1 - m0 - grp * 128)];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) bq[k] = f32x2{br, br};
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const f32x2 x = f32x2{v[2 * k], v[2 * k + 1]} + bq[k];
+              const f32x2 t = x * alpha2;
+              v[2 * k] = fmaxf(x.x, t.x);
+              v[2 * k + 1] = fmaxf(x.y, t.y);
+            }
+          } else if constexpr (MM == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const f32x2 t = f32x2{v[2 * k], v[2 * k + 1]} * alpha2;   // bit set: the value; clear: alpha times it
+              const float te[2] = {t.x, t.y};
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                int keep;                                    // 0 or all ones (in asm: hipcc turns the C form back into and / cmp / cndmask)
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(mb8[rt][p]), "n"(2 * k + e));
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(v[2 * k + e]) : "v"(keep), "v"(v[2 * k + e]), "v"(te[e]));
+              }
+            }
+          } else if constexpr (MM == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= ((float)mk8[rt][p][j] > 0.f) ? 1.f : g.alpha;
+          }
+          if constexpr (kPlanes) {                            // the planes are those of the ROUNDED value
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j]));
+          }
+          // a pair of values -> one dword of two bf16 (v_cvt_pk_bf16_f32), and back by a shift / a mask (written out: hipcc
+          // converted every element a second time on its own to get its rounded value back -- 256 extra conversions per wave)
+          u32x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = pack2(v[2 * k], v[2 * k + 1]);
+          unsigned bits = 0;
+          if constexpr (WB) {                                 // bit j = (value j > 0), most significant first:
+#pragma unroll
+            for (int j = 7; j >= 0; --j) {                    // bits = 2 bits + carry, the carry being the compare
+              const float f = X3 ? v[j] : ((j & 1) ? hi_of(o[j >> 1]) : lo_of(o[j >> 1]));   // X3: sign of the fp32 activation itself; else of the stored bf16
+              asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(f) : "vcc");
+            }
+          }
+          char *const ub = ub_c;                               // (running uniform bases: two scalar adds per store group)
+          uint8_t *const um = ub_m;
+          ub_c += row8_c;
+          if constexpr (WB) ub_m += row8_m;
+          if (rt * 32 + p * 8 >= rows_left) continue;         // stores only below this line
+          if constexpr (WB) um[lane_m] = (uint8_t)bits;       // this lane's 8 columns = one byte of the sign bitmask
+          *reinterpret_cast<u32x4 *>(ub + lane_c) = o;
+          if constexpr (kPlanes) {
+            // three roundings to nearest hold the 24 significant bits: hi + mid + lo == v exactly
+#pragma unroll
+            for (int pl = 1; pl < 3; ++pl) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const f32x2 r = f32x2{v[2 * k], v[2 * k + 1]} - f32x2{lo_of(o[k]), hi_of(o[k])};
+                v[2 * k] = r.x;
+                v[2 * k + 1] = r.y;
+                o[k] = pack2(r.x, r.y);
+              }
+              *reinterpret_cast<u32x4 *>(ub + (size_t)pl * plane_bytes + lane_c) = o;
+            }
+          }
+        }
       }
+    };
+    using std::integral_constant;
+    if constexpr (kMaskEpi) {
+      if (!has_aux) tail16(integral_constant<int, 0>{}, integral_constant<bool, false>{});
+      else if (X3 && g.aux_bits) tail16(integral_constant<int, X3 ? 2 : 1>{}, integral_constant<bool, false>{});
+      else tail16(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+    } else {
+      if (g.mask_out) tail16(integral_constant<int, 0>{}, integral_constant<bool, true>{});
+      else tail16(integral_constant<int, 0>{}, integral_constant<bool, false>{});
     }
     return;
   }

@@ -4,7 +4,7 @@ shapes, one by one: timed with event pairs in interleaved rounds (one process, o
 of times under `rocprofv3 --pmc ...` (tools/pmc_passes.sh) so that every counter row belongs to a known product.
 
 usage: python tools/x3_gemm_probe.py [--cases fc1,dw1,...] [--iters N] [--rounds M] [--rows R] [--rows4 R4]
-cases: x3 step (R rows, default 8192 = config 1): fc1 fc2 dh1 dw1 dw2;  config 4 (R4 rows, default 24576): c4fc1 c4fc2 c4dh1 c4dw1 c4dw2
+cases: x3 step (R rows, default 8192 = config 1): fc1 fc1m fc2 dh1 dh1m dw1 dw2;  config 4 (R4 rows, default 24576): c4fc1 c4fc2 c4dh1 c4dw1 c4dw2
 """
 import argparse
 import os
@@ -43,7 +43,7 @@ def unit_rows(r, c):
 
 cases = {}
 want = args.cases.split(",")
-if any(c in want for c in ("fc1", "fc1a", "fc1b", "fc2", "dh1", "dw1", "dw2")):
+if any(c in want for c in ("fc1", "fc1a", "fc1b", "fc1m", "fc2", "dh1", "dh1m", "dw1", "dw1n", "dw2", "dw2n")):
     x3 = planes(unit_rows(R, F))
     W1T = planes((torch.rand(H, F, device=dev) * 2 - 1) * (6.0 / 6500) ** 0.5)
     W2T = planes((torch.rand(D, H, device=dev) * 2 - 1) * (6.0 / 5256) ** 0.5)
@@ -72,7 +72,16 @@ if any(c in want for c in ("fc1", "fc1a", "fc1b", "fc2", "dh1", "dw1", "dw2")):
                                                                     bias=b2, workspace=ws))
     cases["dh1"] = (2.0 * R * H * D, 6, lambda: ops.gemm_bf16x3_nt(ops.BE_MASK_X3, dz2, D, W2, D, dz1o, R, H, D,
                                                                     plane_c=H, aux=h1))
+    # the forms the step runs: FC1 also writes the sign bitmask of h1, the data gradient reads it as its leaky-relu' mask
+    bits = torch.zeros(R, H // 8, dtype=torch.uint8, device=dev)
+    cases["fc1m"] = (2.0 * R * F * H, 6, lambda: ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3_BITS, x3, F, W1T, F, h1o, R, H, F,
+                                                                     plane_c=H, bias=b1, aux=bits))
+    cases["dh1m"] = (2.0 * R * H * D, 6, lambda: ops.gemm_bf16x3_nt(ops.BE_MASKBITS_X3, dz2, D, W2, D, dz1o, R, H, D,
+                                                                     plane_c=H, aux=bits))
     cases["dw1"] = (2.0 * R * F * H, 6, lambda: ops.gemm_bf16x3_tn(x3, F, dz1, H, gW1, F, H, R, workspace=ws, colsum=gb1))
+    # (without the bias-gradient column sums riding along)
+    cases["dw1n"] = (2.0 * R * F * H, 6, lambda: ops.gemm_bf16x3_tn(x3, F, dz1, H, gW1, F, H, R, workspace=ws))
+    cases["dw2n"] = (2.0 * R * H * D, 6, lambda: ops.gemm_bf16x3_tn(h1, H, dz2, D, gW2, H, D, R, workspace=ws))
     cases["dw2"] = (2.0 * R * H * D, 6, lambda: ops.gemm_bf16x3_tn(h1, H, dz2, D, gW2, H, D, R, workspace=ws, colsum=gb2))
 if any(c.startswith("c4") for c in want):
     xb = unit_rows(R4, F).bfloat16()
