@@ -425,9 +425,16 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0):
     ach1 = flops_gemm / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
     k1 = "k_gemm_bf16_256<false, 0>" if bf16 else "k_gemm_f32<true, false, 2, 2, 1,"
     if x3_products:
-        k1 = "k_gemm_bf16_256<false, 6, true, true>"
+        # (full tiles + the last round's half tiles in one launch where the tile count leaves half a round or less;
+        # k_gemm_bf16_256<false, 6, ..., R6> otherwise)
+        k1 = "k_gemm_x3_rounds<6> / k_gemm_bf16_256<false, 6, true, true, false, false, true>"
     if x3_products:
-        tr1, src1 = pmc_traffic("k_gemm_bf16_256<false, 6, true, true, true", name="latest_pmc_x3") if single_gpu else (None, None)
+        tr1, src1 = (None, None)
+        if single_gpu:
+            for kn in ("k_gemm_x3_rounds<6>", "k_gemm_bf16_256<false, 6, true, true, false, false, true>"):
+                tr1, src1 = pmc_traffic(kn, name="latest_pmc_x3")
+                if src1 is not None:
+                    break
     else:
         tr1, src1 = pmc_traffic(k1, bf16) if single_gpu else (None, None)
     out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": k1 + ("" if (bf16 or x3_products) else " ...>"),

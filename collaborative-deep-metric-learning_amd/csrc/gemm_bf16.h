@@ -43,6 +43,10 @@ struct BArgs {
   int x3_tpp;
   int x3_products;         // K-major walk (> 0): K-tile v = product v % x3_products of K-tile v / x3_products (0: product-major)
   int64_t x3_plane_a, x3_plane_b, x3_plane_c;
+  // A launch over a SUBSET of the tile grid (gemm_bf16_256.hip, "the last round in half tiles"): grid_tiles = the tile
+  // count the block -> tile map is computed for (0: the launch's own grid), narrow_first = the first block index (in
+  // that map) of the tiles a NARROW launch computes as two 128 x 256 halves each
+  int grid_tiles, narrow_first;
 };
 
 // 256x256x64 kernel: true if the shape can use it (N % 256 == 0, K per split a

@@ -136,12 +136,14 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
 // the unrolled period with its compile-time DMA skipping, and the general loop is not compiled in.
 // NTCS (X3, k-contiguous form): also sum B over k per column (its own instantiation: compiled into the plain kernels the
 // four sums and their branch cost FC1 25 % -- 514 -> 642 us, measured).
-template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false>
+template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false, bool NARROW = false>
 __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int m0, const int n0, const int k_begin,
                                          const int n_ktiles, void *c_base, const int64_t c_ld, const int c_row0,
                                          const int c_col0, float *cs_row, const int64_t cs_grp_stride,
                                          unsigned char *smem) {
   static_assert(!TN || EPI == BE_F32, "the k-strided form only serves the weight gradients");
+  static_assert(!NARROW || (X3 && S16 && R6 && !TN && (EPI == BE_BIAS_LRELU_X3 || EPI == BE_MASK_X3 || EPI == BE_ROWBIAS_LRELU_X3)),
+                "the 128 x 256 half tile exists for the plane-output products of the resident-plane walk");
   static_assert(X3 || (EPI != BE_BIAS_LRELU_X3 && EPI != BE_MASK_X3 && EPI != BE_ROWBIAS_LRELU_X3),
                 "plane outputs belong to the split-fp32 form");
   const int t = threadIdx.x;
@@ -162,7 +164,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     if constexpr (!TN) {
       const int r = (wave * 2 + i) * 8 + (lane >> 3);
       const int sc = (lane & 7) ^ ((r >> 1) & 7);            // swizzle on the SOURCE chunk
-      const int row_a = (r >> 6) * 128 + (r & 63);           // A-h0 (A-h1: + 64 rows)
+      const int row_a = NARROW ? r : (r >> 6) * 128 + (r & 63);   // A-h0 (A-h1: + 64 rows); half tile: 64 rows per row group
       const int col_b = (r >> 5) * 64 + (r & 31);            // B-h0 (B-h1: + 32 columns)
       va[i] = (uint32_t)(((int64_t)(m0 + row_a) * g.lda + sc * 8) * 2);
       vb[i] = (uint32_t)(((int64_t)(n0 + col_b) * g.ldb + sc * 8) * 2);
@@ -670,6 +672,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
         dma_s(img == 0 ? srd_a : srd_b, img == 0 ? (h1 ? va_h1[0] : va[0]) : (h1 ? vb_h1[0] : vb[0]), so, dst);
         dma_s(img == 0 ? srd_a : srd_b, img == 0 ? (h1 ? va_h1[1] : va[1]) : (h1 ? vb_h1[1] : vb[1]), so, dst + 1024);
       };
+      if constexpr (!NARROW) {
       // the phase: PH = 2 S + half (compile time), PAR = parity of the K-tile; kw_* = byte offsets of this / the next K-tile
       auto phase = [&](auto phc, auto parc, const uint32_t kwa_c, const uint32_t kwb_c, const uint32_t kwa_n,
                        const uint32_t kwb_n, const bool own) {
@@ -778,6 +781,108 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
         period(std::integral_constant<int, 1>{}, w, own);
         if (++w > w_last) break;
       }
+      } else {
+      // ---- the HALF TILE (NARROW): 128 rows x 256 columns, row groups of 64 rows -----------------------------------
+      // For the last, partly filled round of a launch (FC1 at config 1: 640 tiles = 2.5 rounds of 256 CUs): its tiles are
+      // computed as two half tiles each, on twice the CUs.  Halving the ROWS keeps every phase at 32 MFMAs per wave (a
+      // phase is bound by its read part: halving the columns would halve the MFMAs of a phase and not its length); a K-tile
+      // is the six steps themselves, one phase each.  Per K-tile 3 A half images (the only half there is) + 6 B half
+      // images = 9 in 6 phases.  LDS: four A slots of 16 KiB (A0 alternates between slots 0 and 3, A1 / A2 swap slots 1 / 2
+      // on odd K-tiles) + three B slots of 32 KiB (plane p in slot p) = the same 160 KiB.
+      //   step S:   0            1            2        3     4            5
+      //   reads:    A0 B0        A1           A2       A0 B1 A1           A0 B2
+      //   issues:   B2.h0 B2.h1  B0'.h0 A0'   B0'.h1   A1'   B1'.h0 B1'.h1  A2'           (' = next K-tile)
+      //   vmcnt:    10           8            10       12    12           8
+      //   Every overwrite comes at least one step after the last read of what it replaces (B2 after step 5 of the K-tile
+      //   before, B0' after step 0, A1' -> A2's slot after step 2, B1' after step 3, A2' -> A1's slot after step 4, A0' ->
+      //   the other A0 slot), every image is waited for one step before its first read (replayed from this source by
+      //   tests/test_r6_schedule.py).
+      auto rd_an = [&](int slot, int rb, int ks2) {
+        return *reinterpret_cast<const bf16x8 *>(a16_rd + slot * IMG + rb * 2048 + sw16[ks2]);
+      };
+      const unsigned char *b16n = smem + 4 * IMG + (wc * 32 + l15) * 128;
+      auto rd_bn = [&](int slot, int hh, int cb, int ks2) {
+        return *reinterpret_cast<const bf16x8 *>(b16n + slot * 2 * IMG + hh * IMG + cb * 2048 + sw16[ks2]);
+      };
+      auto issue_n = [&](int img, int pl, int hh, int slot, uint32_t kw) {
+        const uint32_t so = (img == 0 ? pl * ps_a : pl * ps_b) + kw;
+        const uint32_t dst = lds_piece + (img == 0 ? slot * IMG : 4 * IMG + slot * 2 * IMG + hh * IMG);
+        const bool h1 = hh == 1;
+        dma_s(img == 0 ? srd_a : srd_b, img == 0 ? va[0] : (h1 ? vb_h1[0] : vb[0]), so, dst);
+        dma_s(img == 0 ? srd_a : srd_b, img == 0 ? va[1] : (h1 ? vb_h1[1] : vb[1]), so, dst + 1024);
+      };
+      auto phase_n = [&](auto sc, auto parc, const uint32_t kwb_c, const uint32_t kwa_n, const uint32_t kwb_n) {
+        constexpr int S = decltype(sc)::value, PAR = decltype(parc)::value;
+        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {0, 0, 0, 1, 1, 2};
+        constexpr int NSLOT_A[2][3] = {{0, 1, 2}, {3, 2, 1}};    // [parity][plane]
+        constexpr bool rdB = S == 0 || S == 3 || S == 5;
+        if constexpr (rdB) {
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+              fb0[2 * cb + ks2] = rd_bn(PB[S], 0, cb, ks2);
+              fb1[2 * cb + ks2] = rd_bn(PB[S], 1, cb, ks2);
+            }
+        }
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) fa[ks2][rb] = rd_an(NSLOT_A[PAR][PA[S]], rb, ks2);
+        if constexpr (S == 0) { issue_n(1, 2, 0, 2, kwb_c); issue_n(1, 2, 1, 2, kwb_c); }
+        if constexpr (S == 1) { issue_n(1, 0, 0, 0, kwb_n); issue_n(0, 0, 0, NSLOT_A[PAR ^ 1][0], kwa_n); }
+        if constexpr (S == 2) { issue_n(1, 0, 1, 0, kwb_n); }
+        if constexpr (S == 3) { issue_n(0, 1, 0, NSLOT_A[PAR ^ 1][1], kwa_n); }
+        if constexpr (S == 4) { issue_n(1, 1, 0, 1, kwb_n); issue_n(1, 1, 1, 1, kwb_n); }
+        if constexpr (S == 5) { issue_n(0, 2, 0, NSLOT_A[PAR ^ 1][2], kwa_n); }
+        constexpr int NVM[6] = {10, 8, 10, 12, 12, 8};
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NVM[S]) : "memory");
+        if constexpr (rdB) pin_b();
+        pin_a();
+        CDML_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              acc16[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[rb][cb], 0, 0, 0);
+              acc16[rb][2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[rb][2 + cb], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        CDML_BARRIER();
+      };
+      auto period_n = [&](auto parc, const int w) {
+        const int wn = min(w + 1, w_last);                 // past the end: a valid K-tile again (its images are never read)
+        const uint32_t kwb_c = (uint32_t)w * ws_b, kwa_n = (uint32_t)wn * ws_a, kwb_n = (uint32_t)wn * ws_b;
+        phase_n(std::integral_constant<int, 0>{}, parc, kwb_c, kwa_n, kwb_n);
+        phase_n(std::integral_constant<int, 1>{}, parc, kwb_c, kwa_n, kwb_n);
+        phase_n(std::integral_constant<int, 2>{}, parc, kwb_c, kwa_n, kwb_n);
+        phase_n(std::integral_constant<int, 3>{}, parc, kwb_c, kwa_n, kwb_n);
+        phase_n(std::integral_constant<int, 4>{}, parc, kwb_c, kwa_n, kwb_n);
+        phase_n(std::integral_constant<int, 5>{}, parc, kwb_c, kwa_n, kwb_n);
+      };
+      // narrow prologue: the steady state at step 0 of the first K-tile (parity 0): what steps 1 .. 5 of a previous
+      // period would have issued, in their order, then the wait of its step 5
+      {
+        const uint32_t ka = (uint32_t)w_first * ws_a, kb_ = (uint32_t)w_first * ws_b;
+        issue_n(1, 0, 0, 0, kb_); issue_n(0, 0, 0, 0, ka);
+        issue_n(1, 0, 1, 0, kb_);
+        issue_n(0, 1, 0, 1, ka);
+        issue_n(1, 1, 0, 1, kb_); issue_n(1, 1, 1, 1, kb_);
+        issue_n(0, 2, 0, 2, ka);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+      CDML_BARRIER();
+      if (grp == 1) CDML_BARRIER();                        // group 1 runs one barrier behind
+      for (int w = w_first;;) {
+        period_n(std::integral_constant<int, 0>{}, w);
+        if (++w > w_last) break;
+        period_n(std::integral_constant<int, 1>{}, w);
+        if (++w > w_last) break;
+      }
+      }
       if (grp == 0) CDML_BARRIER();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the run-ahead loads of the last K-tile
       CDML_BARRIER();
@@ -880,8 +985,9 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     auto tail16 = [&](auto mm_c, auto wb_c) {
       constexpr int MM = decltype(mm_c)::value;
       constexpr bool WB = decltype(wb_c)::value;
+      constexpr int GR = NARROW ? 64 : 128, RT = GR / 32;     // rows per row group (half tile: 64), 32-row strips of it
       const int lrow = lane >> 3;                                  // the lane's row inside an 8-row store
-      const int rows_left = g.M - m0 - grp * 128 - lrow;          // rows rt*32 + p*8 + lrow < ... are inside the matrix
+      const int rows_left = g.M - m0 - grp * GR - lrow;          // rows rt*32 + p*8 + lrow < ... are inside the matrix
       const uint32_t lane_c = (uint32_t)(((int64_t)lrow * c_ld + lcol8) * 2);
       const uint32_t lane_m = (uint32_t)((int64_t)lrow * g.ldmask + (lcol8 >> 3));
       const uint32_t plane_bytes = (uint32_t)(g.x3_plane_c * 2);
@@ -893,20 +999,20 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       // All 16 mask loads of the wave go out together (rows clamped, not branched around)
       if constexpr (MM != 0) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
-            const int64_t rowc = m0 + grp * 128 + min(rt * 32 + p * 8 + lrow, g.M - 1 - m0 - grp * 128);
+            const int64_t rowc = m0 + grp * GR + min(rt * 32 + p * 8 + lrow, g.M - 1 - m0 - grp * GR);
             if constexpr (MM == 2) mb8[rt][p] = reinterpret_cast<const uint8_t *>(g.aux)[rowc * g.ldaux + ((n0 + lcol8) >> 3)];
             else mk8[rt][p] = *reinterpret_cast<const bf16x8 *>(g.aux + rowc * g.ldaux + n0 + lcol8);
           }
       }
       const f32x2 alpha2 = f32x2{g.alpha, g.alpha};
-      char *ub_c = static_cast<char *>(c_base) + ((int64_t)(grp * 128 + c_row0) * c_ld + c_col0) * 2;   // 8 rows further per store group
-      uint8_t *ub_m = WB ? g.mask_out + (int64_t)(m0 + grp * 128) * g.ldmask + (n0 >> 3) : nullptr;
+      char *ub_c = static_cast<char *>(c_base) + ((int64_t)(grp * GR + c_row0) * c_ld + c_col0) * 2;   // 8 rows further per store group
+      uint8_t *ub_m = WB ? g.mask_out + (int64_t)(m0 + grp * GR) * g.ldmask + (n0 >> 3) : nullptr;
       const int64_t row8_c = c_ld * 16, row8_m = g.ldmask * 8;
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         float *strip = sC + (rt & 1) * 2048;                 // alternate halves: no wait for the readers
         if constexpr (S16) {
 #pragma unroll
@@ -937,7 +1043,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
           if constexpr (kBiasEpi) {
             f32x2 bq[4] = {bb2[0], bb2[1], bb2[2], bb2[3]};
             if constexpr (kRowBias) {
-              const float br = g.bias[m0 + grp * 128 + min(rt * 32 + lr, g.M - 1 - m0 - grp * 128)];
+              const float br = g.bias[m0 + grp * GR + min(rt * 32 + lr, g.M - 1 - m0 - grp * GR)];
 #pragma unroll
               for (int k = 0; k < 4; ++k) bq[k] = f32x2{br, br};
             }
@@ -1102,20 +1208,45 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   }
 }
 
-template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false>
-__global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+// one block of a launch: block index `bid` of this launch -> (half) tile -> run_tile
+template <bool TN, int EPI, bool S16, bool X3, bool F6, bool NTCS, bool R6, bool NARROW>
+__device__ __forceinline__ void block_of_launch(const BArgs &g, int bid, unsigned char *smem) {
   int tm, tn;
-  if (g.K <= (X3 ? 3072 : 512)) tile_of_block_rowmajor(blockIdx.x, gridDim.x, g.tiles_n, tm, tn);   // output-bound
-  else tile_of_block(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, tm, tn);
-  const int m0 = tm * kTileM, n0 = tn * kTileN;
+  // the block -> tile map of the WHOLE tile grid, of which this launch may cover the first blocks only (grid_tiles) or,
+  // NARROW, the rest as two half tiles each: block (xcd, local) -> half local / per of the tile of block (narrow_first / 8
+  // + local % per, xcd) -- both halves of a tile and its neighbours on the XCD whose L2 holds their operand panels
+  const int nwg = g.grid_tiles > 0 ? g.grid_tiles : (int)gridDim.x;
+  int half = 0;
+  if constexpr (NARROW) {
+    const int per = (nwg - g.narrow_first) >> 3, xcd = bid & 7, loc = bid >> 3;
+    half = loc / per;
+    bid = (((g.narrow_first >> 3) + (loc - half * per)) << 3) | xcd;
+  }
+  if (g.K <= (X3 ? 3072 : 512)) tile_of_block_rowmajor(bid, nwg, g.tiles_n, tm, tn);   // output-bound
+  else tile_of_block(bid, nwg, g.tiles_m, g.tiles_n, tm, tn);
+  const int m0 = tm * kTileM + half * (kTileM / 2), n0 = tn * kTileN;
   const int split = blockIdx.y;
   const int k_begin = split * g.k_per_split;
   const int k_end = min(g.K, k_begin + g.k_per_split);
   const int n_ktiles = k_end > k_begin ? (k_end - k_begin) / kTileK : 0;   // even (host)
   void *c_base = EPI == BE_F32 ? static_cast<void *>(static_cast<float *>(g.C) + (int64_t)split * g.slab_stride) : g.C;
   float *cs_row = ((TN || NTCS) && g.colsum_partial) ? g.colsum_partial + (int64_t)((split * g.tiles_m + tm) * 2) * g.N + n0 : nullptr;
-  run_tile<TN, EPI, S16, X3, F6, NTCS, R6>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
+  run_tile<TN, EPI, S16, X3, F6, NTCS, R6, NARROW>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
+}
+
+template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false, bool NARROW = false>
+__global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  block_of_launch<TN, EPI, S16, X3, F6, NTCS, R6, NARROW>(g, blockIdx.x, smem);
+}
+
+// full tiles and the last round's half tiles in ONE launch (blocks [0, narrow_first): full tiles; the rest: half tiles):
+// a half tile starts on whichever CU finishes its last full tile first, not after the whole launch of full tiles has drained
+template <int EPI>
+__global__ void __launch_bounds__(kT, 1) k_gemm_x3_rounds(BArgs g) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  if ((int)blockIdx.x < g.narrow_first) block_of_launch<false, EPI, true, true, false, false, true, false>(g, blockIdx.x, smem);
+  else block_of_launch<false, EPI, true, true, false, false, true, true>(g, (int)blockIdx.x - g.narrow_first, smem);
 }
 
 // ---- both weight gradients of the tower in ONE launch (k-strided form; dW1 = x_hat^T dz1, dW2 = h1^T dz2) ----
@@ -1272,18 +1403,32 @@ int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t s
 }
 
 namespace {
-template <bool TN, int EPI, bool F6, bool NTCS = false, bool R6 = false>
-int launch_x3_1(const BArgs &g, int splits, hipStream_t s) {
+template <bool TN, int EPI, bool F6, bool NTCS = false, bool R6 = false, bool NARROW = false>
+int launch_x3_1(const BArgs &g, int blocks, int splits, hipStream_t s) {
   static bool configured = false;
   constexpr int smem = R6 ? SMEM_R6 : SMEM;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS, R6>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS, R6, NARROW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3: cannot reserve %d B of LDS: %s", smem, hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS, R6>), dim3(g.tiles_m * g.tiles_n, splits), dim3(kT), smem, s, g);
+  hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS, R6, NARROW>), dim3(blocks, splits), dim3(kT), smem, s, g);
   return check_launch("gemm_bf16x3");
+}
+// The last round of a plane-output product in HALF TILES: a launch of T tiles runs T / 256 full rounds of the 256 CUs and
+// then a round with T % 256 of them busy (FC1 and the data gradient at config 1: 640 tiles, the third round on half the
+// chip).  When that remainder fits the chip twice, its tiles are computed by a second launch as two 128 x 256 halves
+// each -- same operands, same K order per output element (bit-identical results), twice the CUs at a little over half a
+// tile's time each.  CDML_X3_HALFTILES=0 turns it off (A/B timing); read per call.
+bool x3_half_tiles() {
+  const char *e = getenv("CDML_X3_HALFTILES");
+  return !e || atoi(e) != 0;
+}
+// CDML_X3_HALFTILES=2: the half tiles as a launch of their own behind the full tiles' (A/B timing)
+bool x3_one_launch() {
+  const char *e = getenv("CDML_X3_HALFTILES");
+  return !e || atoi(e) != 2;
 }
 // which K loop walks the six plane products: CDML_X3_WALK = "r6" (default: the resident-plane walk, both forms),
 // "f6" (round 3's unrolled six-step period with DMA skipping; k-contiguous form only), "general" (round 3's general loop);
@@ -1300,14 +1445,39 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
   const int walk = whole ? x3_walk() : 0;
   if constexpr (!TN && EPI == BE_F32) {   // the weight gradients of the transposed activation layout: with the column sums
     // (the general loop: round 3's unrolled period plus the sums was 14 VGPRs over the budget)
-    if (g.colsum_partial) return launch_x3_1<TN, EPI, false, true>(g, splits, s);
+    if (g.colsum_partial) return launch_x3_1<TN, EPI, false, true>(g, g.tiles_m * g.tiles_n, splits, s);
   }
-  if (walk == 2) return launch_x3_1<TN, EPI, false, false, true>(g, splits, s);
+  const int tiles = g.tiles_m * g.tiles_n;
+  if constexpr (!TN && (EPI == BE_BIAS_LRELU_X3 || EPI == BE_MASK_X3 || EPI == BE_ROWBIAS_LRELU_X3)) {
+    const int full = tiles / kNumCU * kNumCU, rem = tiles - full;
+    if (walk == 2 && splits == 1 && rem > 0 && 2 * rem <= kNumCU && rem % 8 == 0 && full % 8 == 0 && x3_half_tiles()) {
+      BArgs h = g;
+      h.grid_tiles = tiles;
+      h.narrow_first = full;
+      if (full > 0 && x3_one_launch()) {
+        static bool configured = false;
+        if (!configured) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_x3_rounds<EPI>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_R6);
+          if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3: cannot reserve %d B of LDS: %s", SMEM_R6, hipGetErrorString(e));
+          configured = true;
+        }
+        hipLaunchKernelGGL((k_gemm_x3_rounds<EPI>), dim3(full + 2 * rem), dim3(kT), SMEM_R6, s, h);
+        return check_launch("gemm_bf16x3");
+      }
+      if (full > 0) {
+        const int rc = launch_x3_1<TN, EPI, false, false, true>(h, full, 1, s);
+        if (rc) return rc;
+      }
+      return launch_x3_1<TN, EPI, false, false, true, true>(h, 2 * rem, 1, s);
+    }
+  }
+  if (walk == 2) return launch_x3_1<TN, EPI, false, false, true>(g, tiles, splits, s);
   if constexpr (!TN) {
     // (round 3: the k-strided form did not fit the F6 period into 256 VGPRs -- 58 spilled, 2.4 x slower)
-    if (walk == 1) return launch_x3_1<TN, EPI, true>(g, splits, s);
+    if (walk == 1) return launch_x3_1<TN, EPI, true>(g, tiles, splits, s);
   }
-  return launch_x3_1<TN, EPI, false>(g, splits, s);
+  return launch_x3_1<TN, EPI, false>(g, tiles, splits, s);
 }
 }  // namespace
 

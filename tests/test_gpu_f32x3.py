@@ -439,3 +439,43 @@ def test_resident_plane_walk_race_screen():
     for _ in range(40):
         ops.gemm_bf16x3_tn(X3, M, dY3, N, C, M, N, K, workspace=ws, colsum=db)
         assert torch.equal(C, c0) and torch.equal(db, d0)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 192),       # 8 tiles: half tiles only, a ragged last row tile, three K-tiles (odd)
+                                   (2816, 6144, 256),      # 264 tiles: one full round + 8 tiles as 16 halves
+                                   (2700, 6144, 128),      # the same grid with rows ending inside the second half of a tile
+                                   (8192, 5120, 1536)])    # FC1 at config 1: 640 tiles = 2 rounds + 128 tiles as 256 halves
+def test_half_tiles_of_the_last_round_are_bit_identical(M, N, K, monkeypatch):
+    """The last, partly filled round of a plane-output product runs as 128 x 256 half tiles on twice the CUs
+    (csrc/gemm_bf16_256.hip, NARROW): same operands and the same K order per output element, so the planes, the sign bits and
+    the masked gradient are those of the full-tile launch bit for bit; launched back to back many times (a misplaced wait of
+    the half tile's own DMA schedule would show as rare wrong tiles; the schedule itself: tests/test_r6_schedule.py)."""
+    torch.manual_seed(11)
+    dev = _dev()
+    A = torch.randn(M, K, device=dev) * 0.1
+    B = torch.randn(N, K, device=dev) * 0.1
+    bias = torch.randn(N, device=dev) * 0.05
+    A3, B3 = _planes(A, K), _planes(B, K)
+
+    def run(half):
+        monkeypatch.setenv("CDML_X3_HALFTILES", "1" if half else "0")
+        o = torch.zeros(M, 3 * N, dtype=torch.bfloat16, device=dev)
+        bits = torch.zeros(M, N // 8, dtype=torch.uint8, device=dev)
+        ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3_BITS, A3, K, B3, K, o, M, N, K, plane_c=N, bias=bias, alpha=0.2, aux=bits)
+        d = torch.zeros(M, 3 * N, dtype=torch.bfloat16, device=dev)
+        ops.gemm_bf16x3_nt(ops.BE_MASKBITS_X3, A3, K, B3, K, d, M, N, K, plane_c=N, aux=bits, alpha=0.2)
+        dv = torch.zeros(M, 3 * N, dtype=torch.bfloat16, device=dev)
+        ops.gemm_bf16x3_nt(ops.BE_MASK_X3, A3, K, B3, K, dv, M, N, K, plane_c=N, aux=o, alpha=0.2)
+        return o, bits, d, dv
+
+    full = run(False)
+    half = run(True)
+    for f, h in zip(full, half):
+        assert torch.equal(f, h)
+    got = half[0][:, :N].float() + half[0][:, N:2 * N].float() + half[0][:, 2 * N:].float()
+    ref = A.double() @ B.double().t() + bias.double()
+    ref = torch.maximum(ref, 0.2 * ref)
+    assert (got.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    for _ in range(10 if M * N > 2 ** 24 else 30):
+        again = run(True)
+        assert torch.equal(again[0], half[0]) and torch.equal(again[2], half[2])

@@ -83,3 +83,72 @@ def test_r6_schedule_hazards():
         assert not [T for T, k, _ in reads if k == key and T == tt], "WAR: %s overwritten in the phase that still reads it (%d)" % (key, tt)
     # every phase issues exactly one half image, 6 plane images per K-tile
     assert len(seq) == len(PRO) + 12 * n_per
+
+
+def _narrow_schedule():
+    i = SRC.index("auto phase_n = [&](auto sc, auto parc")
+    body = SRC[i:SRC.index("auto period_n = [&]", i)]
+    pa, pb = _ints(r"constexpr int PA\[6\]", body)[:6], _ints(r"PB\[6\]", body)[:6]
+    sa = [int(x) for x in re.findall(r"\d+", re.search(r"NSLOT_A\[2\]\[3\]\s*=\s*\{(.*?)\}\};", body).group(1))]
+    assert len(sa) == 6
+    slot_a = [sa[:3], sa[3:6]]
+    vm = _ints(r"constexpr int NVM\[6\]", body)
+    assert len(vm) == 6
+    rdb_steps = [int(x) for x in re.findall(r"S == (\d)", re.search(r"constexpr bool rdB = (.+?);", body).group(1))]
+    issue = {}
+    for m in re.finditer(r"if constexpr \(S == (\d)\) \{(.*?)\}\n", body):
+        issue[int(m.group(1))] = [(int(a), int(b), int(c), d.strip(), e[-1] == "n") for a, b, c, d, e in
+                                  re.findall(r"issue_n\((\d), (\d), (\d), ([^,]+), (kw[ab]_[cn])\);", m.group(2))]
+    assert sorted(issue) == list(range(6))
+    j = SRC.index("// narrow prologue: the steady state at step 0 of the first K-tile")
+    seg = SRC[j:SRC.index("CDML_BARRIER();", j)]
+    pro = [(int(a), int(b), int(c), int(d)) for a, b, c, d in re.findall(r"issue_n\((\d), (\d), (\d), (\d), k[ab]_?\);", seg)]
+    pro_vm = int(re.search(r"vmcnt\((\d+)\)", seg).group(1))
+    return pa, pb, slot_a, vm, issue, rdb_steps, pro, pro_vm
+
+
+def test_half_tile_schedule_hazards():
+    """The 128 x 256 half tile of the same walk (one phase per step, A rows in ONE half image per plane: four 16-KiB A slots,
+    three B slots): content, RAW and WAR replayed from the source like the full tile's schedule."""
+    PA, PB, SLOT_A, VM, ISSUE, RDB, PRO, PRO_VM = _narrow_schedule()
+    assert sorted(zip(PA, PB)) == sorted([(0, 0), (0, 1), (1, 0), (0, 2), (2, 0), (1, 1)]), "the six plane products"
+    assert RDB == [0, 3, 5]
+    n_per = 7
+    # a slot: A = (0, slot) one half image (hh always 0); B = (1, slot, hh).  LDS: A slots 0..3 at slot * IMG, B slots at
+    # 4 IMG + slot * 2 IMG + hh * IMG -- disjoint by construction for slots 0..3 / 0..2
+    seq = []                                                        # (time, key, content)
+    for n, (img, pl, hh, slot) in enumerate(PRO):
+        assert img == 1 or hh == 0
+        seq.append((n - len(PRO), (img, slot, hh), (img, pl, hh, 0)))
+    for w in range(n_per):
+        PAR = w & 1
+        for S in range(6):
+            for img, pl, hh, slot_expr, nxt in ISSUE[S]:
+                slot = eval(slot_expr, {"NSLOT_A": SLOT_A, "PAR": PAR})
+                assert (img == 0 and hh == 0 and 0 <= slot <= 3) or (img == 1 and 0 <= slot <= 2)
+                seq.append((w * 6 + S, (img, slot, hh), (img, pl, hh, w + (1 if nxt else 0))))
+    assert len(seq) == len(PRO) + 9 * n_per, "nine half images per K-tile: three A, six B"
+    reads = []
+    for w in range(n_per):
+        PAR = w & 1
+        for S in range(6):
+            reads.append((w * 6 + S, (0, SLOT_A[PAR][PA[S]], 0), (0, PA[S], 0, w)))
+            if S in RDB:
+                reads += [(w * 6 + S, (1, PB[S], hh), (1, PB[S], hh, w)) for hh in (0, 1)]   # plane p lives in B slot p
+
+    def landed_by(idx):
+        for T in range(-1, n_per * 6):
+            issued = sum(1 for tt, _, _ in seq if tt <= T)
+            in_flight = (PRO_VM if T == -1 else VM[T % 6]) // 2
+            if idx < issued - in_flight:
+                return T
+        return None
+
+    for T, key, want in reads:
+        last = [(i, tt, tag) for i, (tt, k, tag) in enumerate(seq) if k == key and tt < T][-1]
+        assert last[2] == want, "step %d reads %s: the slot holds %s, not %s" % (T, key, last[2], want)
+        lt = landed_by(last[0])
+        assert lt is not None and lt <= T - 1, "RAW: %s read at step %d, guaranteed landed only by the wait of step %s" % (want, T, lt)
+    for tt, key, tag in seq:
+        assert not [T for T, k, _ in reads if k == key and T == tt], "WAR: %s overwritten in the step that still reads it (%d)" % (key, tt)
+    # (the in-order issue sequence inside a step is the source order: the vmcnt table counts on it)
