@@ -5,8 +5,13 @@ hinge loss + backward + Adam) on synthetic imitation_data-shaped input.
     python bench.py --gpus N --steps K --warmup W
 
 Workloads (BASELINE.json `configs`, 0-based):
-  N = 1 (default)   config 1: 1 M videos x 1500-d fp32 in HBM, 5000 hidden, 256-d embedding,
-                    batch 4096 triplets, in-batch negatives, margin 0.8, Adam.
+  N = 1 (default)   the 1-GPU point of the scaling curve north_star quotes ("triplets/s at 8 GPUs vs 1 GPU on a
+                    10M-video / 1500-d synthetic catalogue"): config 3's per-GPU workload on ONE GPU holding the whole
+                    catalogue -- 10 M videos x 1500-d fp32 (61 GB) in HBM, 5000 hidden, 256-d embedding, batch 8192
+                    triplets, in-batch negatives, margin 0.8, Adam -- so value(N) / value(1) of the bare driver commands
+                    compares one workload (since round 5; rounds 1-4 timed config 1 here, which stays in the line as
+                    the full `config1` record: 1 M videos, batch 4096).  --rows 1000000 --batch 4096 = config 1 as
+                    the job.
   --precision       how the step's fp32 projection products are computed.  "f32x3" (the default since round 4,
                     by the round-3 ruling): every fp32 operand held as three exact bf16 planes hi | mid | lo
                     (hi + mid + lo == the fp32 value), every fp32 product as six bf16 plane products on the bf16
@@ -42,16 +47,19 @@ Prints ONE JSON line (rank 0).  Beside the contract's fields:
                  W warm-up steps; DESIGN.md section 8 says why bare GEMM launches were not enough)
 Secondary records of the default N = 1 line (measured AFTER the headline; each in its own try; those that
 train run at the headline's precision):
-  f32_mfma           the headline workload on the fp32 MFMA (precision "f32": the headline of rounds 1-3), full
+  config1            BASELINE config 1 (1 M videos, batch 4096, in-batch negatives): the headline of rounds 1-4, a full
+                     record (value, roofline, FC1 roofline, kernel breakdown, gather) so the round-to-round series continues
+  config2_semihard   BASELINE config 2 (the same 1 M catalogue, semi-hard mining over all pairs of the batch, batch 8192)
+                     with its kernel breakdown
+  f32_mfma           config 1 on the fp32 MFMA (precision "f32": the headline path of rounds 1-3), full
                      record with roofline, after one step of each path from identical weights on identical
                      triplets compared on the device
-  like_for_like      the per-GPU workload of the N > 1 line on ONE GPU holding the whole 10 M-row
-                     catalogue, so that 8-vs-1 compares one workload (the N > 1 lines name it as `scaling_base`)
-  dp_form_one_gpu    that workload through the N > 1 step FORM (row exchange + gradient sync hooks
+  dp_form_one_gpu    the headline workload through the N > 1 step FORM (row exchange + gradient sync hooks
                      over RCCL at world size 1, nothing skipped): each rank's compute floor at N = 8,
                      for both gradient-sync forms
   config4_per_gpu    BASELINE config 4's per-GPU workload (10 M-row fp16 table, bf16 MFMA, B = 8192
-                     uniform) with its own kernel timers, roofline and gather records
+                     uniform) replayed from a hipGraph (the form config 4 names; `hipgraph`: true), the eager
+                     step beside it (`eager`), with kernel timers, roofline and gather records
   reference_recipe   the reference's own run (train.py:354-364): B = 1024, uniform negatives, LARS
                      lr 1.0, margin 0.8 on the 1 M-row table
   fusion_resnet      the reference's production tower (models.py:125-157) at feature_size 1628
@@ -177,7 +185,15 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel, bf16=False, name=None):
+PMC_DEFAULT_WORKLOAD = {"latest_pmc": "rows=1000000 batch=4096 mode=inbatch", "latest_pmc_x3_config1": "rows=1000000 batch=4096 mode=inbatch",
+                        "latest_pmc_x3": "rows=1000000 batch=4096 mode=inbatch", "latest_pmc_bf16": "rows=10000000 batch=8192 mode=uniform"}
+
+
+def workload_key(n_rows, batch, mode):
+    return "rows=%d batch=%d mode=%s" % (n_rows, batch, mode)
+
+
+def pmc_traffic(kernel, bf16=False, name=None, workload=None):
     """(bytes, source): HBM-side bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC summary
     (profiles/latest_pmc.csv, latest_pmc_bf16.csv for the config-4 path: separate FETCH_SIZE /
     WRITE_SIZE passes of this bench, KiB; FETCH_SIZE doubled per the gfx950 correction) -- an earlier
@@ -204,6 +220,10 @@ def pmc_traffic(kernel, bf16=False, name=None):
     if meta.get("csrc_sha16") != csrc_hash():
         # the kernels changed since that pass (or it predates the stamp): a byte count of other code is not evidence
         return None, src + "; STALE: csrc/ differs from the sources that pass profiled, traffic withheld)"
+    took = meta.get("workload", PMC_DEFAULT_WORKLOAD.get(name))
+    if workload is not None and took != workload:
+        # bytes per launch are those of the shapes that pass ran (stamps of rounds 3-4 carry none: config 1's)
+        return None, src + "; OTHER WORKLOAD: that pass ran '%s', this record '%s', traffic withheld)" % (took, workload)
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, src + ")"
 
 
@@ -378,6 +398,15 @@ def install_timers(kt, L, bf16):
         patch("lars_step", "lars")
         patch("lars_multi", "lars")
     patch("vnet_tail", "tail")
+    # semi-hard mining (config 2): the B x 2B score product, the select, the indexed hinge, the separate l2norm kernels
+    if not bf16:
+        if bf16 is None:
+            patch("fc_bwd_data", "score_gemm")           # (precision f32x3: its only fp32-MFMA launch, when not fused)
+        patch("semihard_select", "semihard_select")
+        patch("semihard_mine_x3", "semihard_mine")
+        patch("triplet_hinge_indexed", "hinge_indexed")
+        patch("l2norm_fwd", "l2norm_fwd")
+        patch("l2norm_bwd", "l2norm_bwd")
 
     def restore():
         for name, fn in real.items():
@@ -385,7 +414,7 @@ def install_timers(kt, L, bf16):
     return restore
 
 
-def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0):
+def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0, pmc_name=None, workload=None):
     """roofline (dominant kernel: the weight-gradient GEMM), roofline_fc1_fwd, kernels -- from the
     event-timed launches.  Algorithmic (unpadded) flop: dW1 2*R*F*H, dW2 2*R*H*D.
     x3_products (precision f32x3): every algorithmic fp32 flop is that many bf16 MFMA flops, so the peak the
@@ -415,9 +444,10 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0):
     flop_launch = sampled * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
     ach = flop_launch / (t_ms * 1e-3) / 1e12
     if x3_products:
-        tr, src = pmc_traffic("k_gemm_bf16_256<true, 3, true, true", name="latest_pmc_x3") if single_gpu else (None, None)
+        tr, src = (pmc_traffic("k_gemm_bf16_256<true, 3, true, true", name=pmc_name or "latest_pmc_x3", workload=workload)
+                   if single_gpu else (None, None))
     else:
-        tr, src = pmc_traffic(kname, bf16) if single_gpu else (None, None)
+        tr, src = pmc_traffic(kname, bf16, name=pmc_name, workload=workload) if single_gpu else (None, None)
     out["roofline"] = {"bound": "mfma", "kernel": klabel, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                        "frac": round(ach / peak, 4), "traffic": tr, "traffic_source": src,
                        "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch,
@@ -432,18 +462,19 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0):
         tr1, src1 = (None, None)
         if single_gpu:
             for kn in ("k_gemm_x3_rounds<6>", "k_gemm_bf16_256<false, 6, true, true, false, false, true>"):
-                tr1, src1 = pmc_traffic(kn, name="latest_pmc_x3")
+                tr1, src1 = pmc_traffic(kn, name=pmc_name or "latest_pmc_x3", workload=workload)
                 if src1 is not None:
                     break
     else:
-        tr1, src1 = pmc_traffic(k1, bf16) if single_gpu else (None, None)
+        tr1, src1 = pmc_traffic(k1, bf16, name=pmc_name, workload=workload) if single_gpu else (None, None)
     out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": k1 + ("" if (bf16 or x3_products) else " ...>"),
                                "achieved": round(ach1, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach1 / peak, 4), "traffic": tr1, "traffic_source": src1,
                                "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": flops_gemm}
     kern = {}
     for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "adam", "adam_w1", "adam_w2", "adam_bias", "lars",
-              "split_planes", "transpose_planes"):
+              "split_planes", "transpose_planes", "score_gemm", "semihard_select", "semihard_mine", "hinge_indexed", "l2norm_fwd",
+              "l2norm_bwd"):
         if kt.mean_ms(k) is not None:
             kern[k + "_ms"] = round(kt.mean_ms(k), 4)
             if kt.count(k) != sampled:
@@ -453,7 +484,7 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0):
     return out
 
 
-def gather_record(ts, mode, bf16, dev):
+def gather_record(ts, mode, bf16, dev, pmc_name=None, workload=None):
     """The HBM-bound kernel the metric also names: the fused sampler+gather (fp32 rows, or fp16 -> bf16
     rows on the config-4 path), 10 back-to-back launches per event pair, fresh steps every launch."""
     from cdml_amd import ops, train
@@ -490,7 +521,8 @@ def gather_record(ts, mode, bf16, dev):
     torch.cuda.synchronize(dev)
     t_g = float(np.median([s.elapsed_time(e) for s, e in evs])) / per
     g_ach = gbytes / (t_g * 1e-3) / 1e9
-    tr, src = pmc_traffic("k_sample_gather<%d," % (1 if rpt == 2 else 0), name="latest_pmc_x3") if x3 else pmc_traffic(gk, bf16)
+    tr, src = (pmc_traffic("k_sample_gather<%d," % (1 if rpt == 2 else 0), name=pmc_name or "latest_pmc_x3", workload=workload) if x3
+               else pmc_traffic(gk, bf16, name=pmc_name, workload=workload))
     return {"bound": "hbm", "kernel": gk + ("<6>>" if x3 else " RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": tr,
             "traffic_source": src, "bytes_per_launch": gbytes, "launch_ms": round(t_g, 4), "steps_per_launch": n_st,
@@ -622,7 +654,7 @@ LIKE_FOR_LIKE_WORKLOAD = ("config3 per-GPU batch on ONE GPU: 10000000 videos x 1
 
 
 def table_10m(keep, dev):
-    """The 10 M-row fp32 catalogue (61 GB), shared by like_for_like and dp_form_one_gpu."""
+    """The 10 M-row fp32 catalogue (61 GB): the headline's own table at N = 1, shared with dp_form_one_gpu."""
     from cdml_amd import engine
     if "t10" not in keep:
         keep["t10"] = engine.FeatureTable.synthetic(10000000, F, seed=0, device=dev)
@@ -630,16 +662,50 @@ def table_10m(keep, dev):
     return keep["t10"], keep["p10"]
 
 
-def rec_like_for_like(dev, args, n_s, n_w, keep):
+def rec_config1(dev, args, n_s, n_w, table, pairs):
+    """BASELINE config 1 -- 1 M videos x 1500-d fp32, batch 4096, in-batch negatives -- the headline of rounds 1-4, as
+    a full record at the headline's precision: its own warm-up, >= 100 timed steps (a 1.4-ms step: fewer would time
+    the clock ramp), kernel timers, rooflines and the gather record."""
     from cdml_amd import train
-    t10, p10 = table_10m(keep, dev)
-    ts10 = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch",
-                           optimizer="adam", base_learning_rate=0.01, device=dev, gather_ahead=args.gather_ahead,
-                           precision=args.precision)
-    el = timed_steps(ts10, n_s, n_w, dev)
-    return {"workload": LIKE_FOR_LIKE_WORKLOAD, "precision": args.precision,
-            "value": round(8192 * n_s / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n_s * 1e3, 4),
-            "steps": n_s, "warmup": n_w}
+    x3 = 6 if args.precision == "f32x3" else 0
+    ts = train.TrainStep(table, pairs, 4096, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch", optimizer="adam",
+                         base_learning_rate=0.01, seed=1234, weight_seed=42, device=dev, precision=args.precision,
+                         gather_ahead=args.gather_ahead)
+    n, w = max(n_s, 100), max(n_w, 10)
+    el, kt, sampled, how = measure_job(ts, n, w, dev, None if x3 else False)
+    wk = workload_key(table.n_rows, 4096, "inbatch")
+    out = {"workload": "config1: %d videos x 1500-d fp32 in HBM, 5000 hidden, 256-d embed, batch 4096 triplets, in-batch "
+                       "negatives, margin 0.8, Adam, full step (the N = 1 headline of rounds 1-4)" % table.n_rows,
+           "precision": args.precision, "value": round(4096 * n / el, 1), "unit": "triplets/s",
+           "ms_per_step": round(el / n * 1e3, 4), "steps": n, "warmup": w, "loss": round(ts.loss(), 6)}
+    out.update(gemm_records(kt, ts.R, False, sampled, how, True, x3_products=x3,
+                            pmc_name="latest_pmc_x3_config1" if x3 else "latest_pmc", workload=wk))
+    out["gather"] = gather_record(ts, "inbatch", False, dev, pmc_name="latest_pmc_x3_config1" if x3 else "latest_pmc",
+                                  workload=wk)
+    return out
+
+
+def rec_config2(dev, args, n_s, n_w, table, pairs):
+    """BASELINE config 2: the same 1 M catalogue, semi-hard negative mining over all pairs of the batch (every anchor
+    against every embedded row: a B x 2B score product), batch 8192 -- at the headline's precision, >= 20 timed steps
+    after its own warm-up, with the kernel breakdown (event pairs on sampled steps)."""
+    from cdml_amd import train
+    x3 = 6 if args.precision == "f32x3" else 0
+    B2 = 8192
+    ts = train.TrainStep(table, pairs, B2, output_size=D, hidden_size=H, margin=MARGIN, mode="semihard", optimizer="adam",
+                         base_learning_rate=0.01, seed=1234, weight_seed=42, device=dev, precision=args.precision,
+                         gather_ahead=args.gather_ahead)
+    n, w = max(n_s, 40), max(n_w, 5)
+    el, kt, sampled, how = measure_job(ts, n, w, dev, None if x3 else False)
+    out = {"workload": "config2: %d videos x 1500-d fp32 in HBM, batch %d triplets, semi-hard negatives mined over all "
+                       "pairs of the batch (%d anchors x %d embedded rows), margin 0.8, Adam, full step"
+                       % (table.n_rows, B2, B2, 2 * B2),
+           "precision": args.precision, "value": round(B2 * n / el, 1), "unit": "triplets/s",
+           "ms_per_step": round(el / n * 1e3, 4), "steps": n, "warmup": w, "loss": round(ts.loss(), 6),
+           "mining": "fused into the score product's epilogue (no B x 2B score matrix in HBM)" if getattr(ts, "mine_fused", False)
+                     else "score matrix S (B x 2B fp32, %d MB) written by the GEMM, scanned by k_semihard_select" % (B2 * 2 * B2 * 4 // 1000000)}
+    out.update(gemm_records(kt, ts.R, False, sampled, how, False, x3_products=x3))
+    return out
 
 
 def rec_dp_form(dev, args, n_s, n_w, keep):
@@ -685,17 +751,39 @@ def rec_config4(dev, args, n_s, n_w):
     from cdml_amd import engine_bf16, train
     t = engine_bf16.FeatureTableF16.synthetic(10000000, F, seed=0, device=dev)
     p = torch.from_numpy(synth_pairs(10000000, 600000, seed=0)).to(dev)
-    ts = train.TrainStep(t, p, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="uniform", optimizer="adam",
-                         base_learning_rate=0.01, device=dev, precision="bf16", gather_ahead=args.gather_ahead)
-    n_s, n_w = max(n_s, 100), max(n_w, 10)           # a 1.1-ms step: 20 of them would time the clock ramp
-    el, kt, sampled, how = measure_job(ts, n_s, n_w, dev, True)
-    ts.check_inputs()
+    mk = lambda g: train.TrainStep(t, p, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="uniform", optimizer="adam",
+                                   base_learning_rate=0.01, device=dev, precision="bf16", gather_ahead=args.gather_ahead,
+                                   use_graph=g)
+    n_s, n_w = max(n_s, 100), max(n_w, 10)           # a 1-ms step: 20 of them would time the clock ramp
+    wk = workload_key(10000000, 8192, "uniform")
+    # BASELINE config 4 names a hipGraph-captured step: THAT form is the record's value; the eager step is timed beside
+    # it on the same box, in the same process, in alternating blocks (graph, eager, graph, eager) so that neither form
+    # owns the warmer half of the run (profiles/r05_graph_vs_eager.txt has the longer A/B and the kernel traces)
+    tg, te = mk(True), mk(False)
+    for ts_ in (tg, te):
+        timed_steps(ts_, 0, n_w + 4, dev)              # (the replayed step: first step eager, then one capture per gather slot)
+    half = max(n_s // 2, 50)
+    blocks = {"graph": [], "eager": []}
+    for _ in range(2):
+        blocks["graph"].append(timed_steps(tg, half, 0, dev))
+        blocks["eager"].append(timed_steps(te, half, 0, dev))
+    ms_g, ms_e = (sum(blocks[k]) / (2 * half) * 1e3 for k in ("graph", "eager"))
+    # kernel timers, roofline, gather: from the eager twin (same kernels, same shapes; a replay has no host-side launches
+    # to bracket)
+    el, kt, sampled, how = measure_job(te, 40, 0, dev, True)
+    tg.check_inputs()
+    te.check_inputs()
     out = {"workload": "config4 per-GPU shape on ONE GPU: 10000000 videos x 1500-d fp16 (30.7 GB) in HBM, bf16 MFMA "
-                       "tower (f32 accumulate, fp32 master weights), batch 8192 triplets, uniform (global) negatives, Adam",
-           "value": round(8192 * n_s / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n_s * 1e3, 4),
-           "steps": n_s, "warmup": n_w, "dtype": "bf16 (fp16 table, f32 accumulate)", "loss": round(ts.loss(), 6)}
-    out.update(gemm_records(kt, ts.R, True, sampled, how, True))
-    out["gather"] = gather_record(ts, "uniform", True, dev)
+                       "tower (f32 accumulate, fp32 master weights), batch 8192 triplets, uniform (global) negatives, Adam, "
+                       "step replayed from a hipGraph",
+           "hipgraph": True, "value": round(8192 / (ms_g * 1e-3), 1), "unit": "triplets/s", "ms_per_step": round(ms_g, 4),
+           "steps": 2 * half, "warmup": n_w + 4, "dtype": "bf16 (fp16 table, f32 accumulate)", "loss": round(tg.loss(), 6),
+           "eager": {"hipgraph": False, "value": round(8192 / (ms_e * 1e-3), 1), "ms_per_step": round(ms_e, 4), "steps": 2 * half,
+                     "loss": round(te.loss(), 6)},
+           "timed_how": "alternating blocks of %d steps: graph, eager, graph, eager (ms per block: graph %s, eager %s)"
+                        % (half, [round(b * 1e3 / half, 4) for b in blocks["graph"]], [round(b * 1e3 / half, 4) for b in blocks["eager"]])}
+    out.update(gemm_records(kt, te.R, True, sampled, how + " (the eager twin)", True, workload=wk))
+    out["gather"] = gather_record(te, "uniform", True, dev, workload=wk)
     return out
 
 
@@ -724,7 +812,7 @@ X3_DTYPE = ("f32 values as 3 exact bf16 planes (hi + mid + lo == the f32 value),
 
 
 def rec_other_fp32_path(dev, args, n_s, n_w, table, pairs, B, mode, other):
-    """The headline workload on the OTHER fp32 path -- `other` = "f32" (v_mfma_f32_32x32x2_f32: the headline of rounds
+    """Config 1 (`table`, `B`, `mode` of the caller) on the OTHER fp32 path -- `other` = "f32" (v_mfma_f32_32x32x2_f32: the headline of rounds
     1-3, record `f32_mfma`) when the headline runs precision "f32x3", and the reverse -- same table, batch, sampler and
     optimizer, with its own kernel timers and roofline.  Before timing, one step of each path is taken from the same
     weights on the same triplets and compared on the device."""
@@ -752,13 +840,14 @@ def rec_other_fp32_path(dev, args, n_s, n_w, table, pairs, B, mode, other):
     x3 = 6 if other == "f32x3" else 0
     n = max(n_s, 60)
     el, kt, sampled, how = measure_job(ts, n, max(n_w, 10), dev, None if x3 else False)
-    out = {"workload": "the headline workload (%d videos, batch %d, %s negatives, Adam) with precision %s"
+    out = {"workload": "config 1 (%d videos, batch %d, %s negatives, Adam) with precision %s"
                        % (table.n_rows, B, mode, "f32x3" if x3 else "f32: the projection products on the fp32 MFMA "
                                                                     "(v_mfma_f32_32x32x2_f32), the headline path of rounds 1-3"),
            "value": round(B * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4), "steps": n,
            "dtype": X3_DTYPE if x3 else "f32 (fp32 MFMA)",
            "loss": round(ts.loss(), 6), "f32_mfma_against_f32x3": check}
-    out.update(gemm_records(kt, ts.R, False, sampled, how, True, x3_products=x3))
+    out.update(gemm_records(kt, ts.R, False, sampled, how, True, x3_products=x3,
+                            workload=workload_key(table.n_rows, B, mode)))
     del ts
     torch.cuda.empty_cache()
     # a run that LEARNS (data_learnable's catalogue): both paths from the same seeds, the loss along the way
@@ -848,9 +937,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--rows", type=int, default=None, help="catalogue rows (default: 1M at N=1 fp32, else 10M)")
+    ap.add_argument("--rows", type=int, default=None, help="catalogue rows (default 10M; 1000000 with --batch 4096 = config 1 as the job)")
     ap.add_argument("--mode", default=None, choices=["inbatch", "uniform", "semihard", "predict"])
-    ap.add_argument("--batch", type=int, default=None, help="triplets per GPU per step (default 4096 for config 1, else 8192)")
+    ap.add_argument("--batch", type=int, default=None, help="triplets per GPU per step (default 8192)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
     ap.add_argument("--precision", default="f32x3", choices=["f32x3", "f32", "bf16", "f32x3-3"],
                     help="f32x3 (default): fp32 operands as three exact bf16 planes, six plane products per fp32 product on "
@@ -869,7 +958,7 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary records of the default N=1 line")
     ap.add_argument("--extras", default=None,
-                    help="comma list of secondary records to run (default: all): like_for_like,dp_form_one_gpu,"
+                    help="comma list of secondary records to run (default: all): config1,config2_semihard,dp_form_one_gpu,"
                          "config4_per_gpu,reference_recipe,fusion_resnet,predict,data_learnable,f32_mfma")
     ap.add_argument("--only", default=None, choices=["reference_recipe", "fusion_resnet", "data_learnable"],
                     help="run ONE secondary record as the job (its JSON line; for rocprofv3 runs of that workload)")
@@ -949,10 +1038,13 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
-    config1 = world == 1 and not bf16
-    n_rows = args.rows or (1000000 if config1 else 10000000)
-    B = args.batch or (4096 if config1 else 8192)
     mode = args.mode or ("uniform" if bf16 else "inbatch")
+    n_rows = args.rows or (1000000 if mode == "semihard" else 10000000)      # --mode semihard alone = BASELINE config 2
+    B = args.batch or 8192
+    # the default N = 1 job: config 3's per-GPU workload on one GPU (10 M rows, batch 8192, in-batch) -- the 1-GPU point
+    # of the curve the N > 1 commands continue; it carries the secondary records
+    default_job = world == 1 and not bf16 and args.rows is None and args.batch is None and mode == "inbatch"
+    wkey = workload_key(n_rows, B, mode)
     set_phase("setup")
     probe = None
     try:
@@ -1068,6 +1160,8 @@ def main():
             cfg_name = "config4" + (" per-GPU shape on 1 GPU" if world == 1 else "")
         elif world > 1:
             cfg_name = "config3"
+        elif n_rows == 10000000 and B == 8192 and mode == "inbatch":
+            cfg_name = "config3 per-GPU workload on 1 GPU (the whole 10 M-row catalogue in one HBM: the 1-GPU point of the scaling curve)"
         else:
             cfg_name = {"inbatch": "config1", "semihard": "config2", "uniform": "config1 size, reference negative rule"}[mode]
         out = {
@@ -1095,17 +1189,18 @@ def main():
             # 1 -> N compares ONE workload only against this base: the bare N = 1 command times BASELINE config 1 (1 M rows,
             # batch 4096), the N > 1 commands config 3's per-GPU shape (10 M rows row-sharded, batch 8192 per GPU)
             out["scaling_base"] = {"workload": LIKE_FOR_LIKE_WORKLOAD, "precision": args.precision,
-                                   "where": "the `like_for_like` record of the N = 1 line (python bench.py --gpus 1): its value "
-                                            "is the 1-GPU triplets/s of the workload every rank of this line runs",
+                                   "where": "the headline `value` of the N = 1 line (python bench.py --gpus 1; rounds 1-4: its "
+                                            "`like_for_like` record): the 1-GPU triplets/s of the workload every rank of this "
+                                            "line runs",
                                    "per_gpu_batch": B, "rows_global": n_rows}
             out["ranks_seen"] = dist.get_world_size()
             out["comm_backend"] = {"backend": dist.get_backend(), "launcher": "self" if os.environ.get("CDML_BENCH_PHASE_DIR") else "external",
                                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
         if timers_on:
-            out.update(gemm_records(kt, R, bf16, sampled, how, world == 1, x3_products=x3))
+            out.update(gemm_records(kt, R, bf16, sampled, how, world == 1, x3_products=x3, workload=wkey))
         if world == 1 and not args.train_table:
             set_phase("gather record")
-            out["gather"] = gather_record(ts, mode, bf16, dev)
+            out["gather"] = gather_record(ts, mode, bf16, dev, workload=wkey)
         if world > 1:
             ar, exw = comm_kt.mean_ms("allreduce_wait"), comm_kt.mean_ms("exchange_wait")
             out["comm"] = {"allreduce_exposed_ms": None if ar is None else round(ar, 4),
@@ -1132,16 +1227,20 @@ def main():
                         % ("" if args.no_settle else "0.3 s settle loop (%s), " % settle_how))
 
         # ---- secondary records (after the headline; the failure of one must not cost the line) ----
-        run_extras = config1 and mode == "inbatch" and not args.no_extras and not args.train_table and x3 in (0, 6)
+        run_extras = default_job and not args.no_extras and not args.train_table and x3 in (0, 6)
         if run_extras:
             del ts
             torch.cuda.empty_cache()
             other = "f32" if x3 else "f32x3"
             other_name = "f32_mfma" if x3 else "f32x3"
-            want = set((args.extras or "like_for_like,dp_form_one_gpu,config4_per_gpu,reference_recipe,fusion_resnet,"
+            want = set((args.extras or "config1,config2_semihard,dp_form_one_gpu,config4_per_gpu,reference_recipe,fusion_resnet,"
                                        "predict,data_learnable," + other_name).split(","))
             n_s, n_w = min(args.steps, 30), min(max(args.warmup, 3), 5)
-            keep = {}
+            keep = {"t10": table, "p10": pairs}            # the headline's own catalogue serves dp_form_one_gpu
+            del table, pairs
+            # rounds 1-4 reported this workload as the `like_for_like` record beside a config-1 headline
+            out["like_for_like"] = {"see": "the headline of this line IS that workload since round 5", "value": out["value"],
+                                    "ms_per_step": out["ms_per_step"], "workload": LIKE_FOR_LIKE_WORKLOAD}
 
             def attempt(name, fn):
                 if name not in want:
@@ -1152,16 +1251,20 @@ def main():
                 except Exception as e:                   # noqa: BLE001
                     out[name] = {"error": repr(e)[:300]}
                 torch.cuda.empty_cache()
-            attempt(other_name, lambda: rec_other_fp32_path(dev, args, n_s, n_w, table, pairs, B, mode, other))
-            attempt("reference_recipe", lambda: rec_reference_recipe(dev, args, n_s, n_w, table))
-            attempt("data_learnable", lambda: rec_learnable(dev, args, n_s, n_w, B))
-            del table, pairs
-            torch.cuda.empty_cache()
-            attempt("fusion_resnet", lambda: rec_fusion(dev, args, n_s, n_w))
-            attempt("like_for_like", lambda: rec_like_for_like(dev, args, n_s, n_w, keep))
             attempt("dp_form_one_gpu", lambda: rec_dp_form(dev, args, n_s, n_w, keep))
             keep.clear()
             torch.cuda.empty_cache()
+            # the 1 M-row catalogue of configs 1 and 2 (and of the reference's own recipe)
+            t1 = engine.FeatureTable.synthetic(1000000, F, seed=0, device=dev)
+            p1 = torch.from_numpy(synth_pairs(1000000, 333333, seed=0)).to(dev)
+            attempt("config1", lambda: rec_config1(dev, args, n_s, n_w, t1, p1))
+            attempt("config2_semihard", lambda: rec_config2(dev, args, n_s, n_w, t1, p1))
+            attempt(other_name, lambda: rec_other_fp32_path(dev, args, n_s, n_w, t1, p1, 4096, "inbatch", other))
+            attempt("reference_recipe", lambda: rec_reference_recipe(dev, args, n_s, n_w, t1))
+            attempt("data_learnable", lambda: rec_learnable(dev, args, n_s, n_w, 4096))
+            del t1, p1
+            torch.cuda.empty_cache()
+            attempt("fusion_resnet", lambda: rec_fusion(dev, args, n_s, n_w))
             attempt("config4_per_gpu", lambda: rec_config4(dev, args, n_s, n_w))
             attempt("predict", lambda: {"f32": rec_predict(dev, "f32"), "f32x3": rec_predict(dev, "f32x3"),
                                         "bf16": rec_predict(dev, "bf16")})

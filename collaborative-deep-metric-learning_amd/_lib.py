@@ -23,6 +23,35 @@ def lib_path():
     return os.environ.get("CDML_LIB_PATH") or os.path.join(_HERE, "lib", _LIB_NAME)
 
 
+def source_id(csrc=None, header=None):
+    """sha256[:16] over the sources the library is built from -- csrc/*.hip, csrc/*.h (sorted by name) and
+    include/cdml.h.  __graft_entry__.build() compiles it into the library (``cdml_build_id()``); ``load_library``
+    compares the two, so a prebuilt .so that travelled with a tree it was not built from is refused instead of
+    silently passing for it (file times say nothing after a copy).  None when the tree has no sources."""
+    import glob
+    import hashlib
+    csrc = csrc or os.path.join(_HERE, "csrc")
+    header = header or os.path.join(os.path.dirname(_HERE), "include", "cdml.h")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))
+    if not files or not os.path.exists(header):
+        return None
+    h = hashlib.sha256()
+    for f in files + [header]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def embedded_id(path):
+    """The build id compiled into the library file at ``path`` (read from the file, nothing is loaded), or None."""
+    import re
+    try:
+        m = re.search(rb"CDML_BUILD_ID=([0-9a-f]{16})", open(path, "rb").read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
 _p = C.c_void_p
 _i = C.c_int
 _i64 = C.c_int64
@@ -33,6 +62,7 @@ _sz = C.c_size_t
 # name -> (restype, argtypes); must list every symbol include/cdml.h declares
 SIGNATURES = {
     "cdml_version": (_i, []),
+    "cdml_build_id": (C.c_char_p, []),
     "cdml_last_error": (C.c_char_p, []),
     "cdml_fill_uniform_table": (_i, [_p, _i64, _i64, _i, _i64, _u64, _p]),
     "cdml_sample_uniform": (_i, [_p, _i64, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _p]),
@@ -138,6 +168,14 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
         fn.restype = res
         fn.argtypes = args
+    # the library must be the one THIS tree builds (a variant library named by CDML_LIB_PATH is built from a scratch
+    # copy of the sources on purpose and is exempt; CDML_ALLOW_STALE_LIB=1 for a deliberate mismatch)
+    want = source_id()
+    if want is not None and not os.environ.get("CDML_LIB_PATH") and os.environ.get("CDML_ALLOW_STALE_LIB") != "1":
+        have = lib.cdml_build_id().decode()
+        if have != "CDML_BUILD_ID=" + want:
+            raise CdmlError(-2, f"{path} was built from other sources ({have}; this tree is {want}): rebuild it with "
+                                f"`python -c 'import __graft_entry__ as g; g.build()'`")
     _lib = lib
     return lib
 

@@ -376,7 +376,11 @@ struct RowF16 {
         bf16x8v o;
 #pragma unroll
         for (int u = 0; u < 8; ++u) o[u] = (__bf16)((float)R.v[c][u] * inv);
+#if CDML_GATHER_NT_STORE
+        __builtin_nontemporal_store(o, d + q);
+#else
         d[q] = o;
+#endif
       }
     }
     const bf16x8v z8 = {0, 0, 0, 0, 0, 0, 0, 0};

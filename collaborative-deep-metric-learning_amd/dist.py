@@ -309,16 +309,21 @@ class GradSync:
         return flat_grad
 
 
-def reduce_input_flags(oob, overflow, group=None, world=None):
+def reduce_input_flags(oob, overflow, group=None, world=None, extra=None):
     """The device-side input flags of ONE rank -- ``oob`` (int32[1]: a pair id outside the catalogue) and ``overflow``
     (RowExchange.overflow, int32[1] bit field: 1 = a peer segment overflowed, 2 = a requested id outside the catalogue;
     None = no exchange) -- as (oob, overflowed, bad_id) over EVERY rank of ``group`` (maximum; a host read, a sync).
     Collective: an overflow on one rank poisons every rank's weights through the gradient all-reduce (its rows come back
     NaN), so every rank has to learn of it -- and raise -- at the same point; a rank that read only its own flag would
-    save a NaN checkpoint while the overflowing rank raised alone and left the others waiting in their next collective."""
+    save a NaN checkpoint while the overflowing rank raised alone and left the others waiting in their next collective.
+    ``extra`` (int32[1] or None): one more per-rank flag carried by the SAME all-reduce (the trainer's "my weights are
+    not finite"); with it the result has a fourth element, its maximum over the ranks."""
     dev = oob.device
     ov = overflow.to(torch.int32).view(1) if overflow is not None else torch.zeros(1, dtype=torch.int32, device=dev)
-    f = torch.cat([oob.to(torch.int32).view(1), ov & 1, (ov >> 1) & 1])
+    parts = [oob.to(torch.int32).view(1), ov & 1, (ov >> 1) & 1]
+    if extra is not None:
+        parts.append(extra.to(torch.int32).view(1))
+    f = torch.cat(parts)
     world = dist.get_world_size(group) if (world is None and dist.is_available() and dist.is_initialized()) else (world or 1)
     if world > 1:
         if f.is_cuda and _host_staged(group):

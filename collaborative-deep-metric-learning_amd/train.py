@@ -644,35 +644,55 @@ class TrainStep:
         G[("B", b)].replay()
         pf.release(b)
 
-    def check_inputs(self):
+    def check_inputs(self, extra=None):
         """Host check of the device-side input flags (synchronises; called by ``loss()``, by the
         trainer before it saves or evaluates, by bench.py after the timed region): a pair id
         outside the catalogue (the reference's IndexError, inputs.py:158) and, on a row-sharded
         catalogue, an exchange segment that overflowed (the step then trained on NaN rows).
         Data-parallel runs: a COLLECTIVE call -- the flags are reduced (maximum) over the gradient
         all-reduce's group first, because one rank's overflow reaches every rank's weights through
-        the gradient average: every rank raises, at the same point, whichever rank overflowed."""
+        the gradient average: every rank raises, at the same point, whichever rank overflowed.  So
+        every rank has to call it at the same point of its program, whatever its own arguments are
+        (``Trainer.save`` calls it before it looks at its rank-local ``checkpoint_dir``).
+        ``extra`` (int32[1] device flag or None): one more per-rank flag reduced by the same
+        collective; its maximum over the ranks is returned (None -> 0)."""
         ex = self.exchange
         if self.grad_sync is not None and self.grad_sync.world > 1:
             from .dist import reduce_input_flags
-            oob, over, bad = reduce_input_flags(self.oob, None if ex is None else ex.overflow, self.grad_sync.group,
-                                                self.grad_sync.world)
+            r = reduce_input_flags(self.oob, None if ex is None else ex.overflow, self.grad_sync.group,
+                                   self.grad_sync.world, extra=extra)
+            oob, over, bad = r[:3]
+            extra_max = r[3] if extra is not None else 0
             where = " (on at least one rank)"
         else:
             oob = int(self.oob.item())
             f = 0 if (ex is None or ex.overflow is None) else int(ex.overflow.item())
             over, bad, where = f & 1, (f >> 1) & 1, ""
+            extra_max = int(extra.item()) if extra is not None else 0
         if oob or bad:
             raise IndexError("a co-watch pair id lies outside the %d-row catalogue%s" % (self.table.n_rows_global, where))
         if over:
             raise RuntimeError("row exchange: a peer segment overflowed%s (requests are skewed towards one shard): the step "
                                "trained on NaN rows; raise RowExchange(capacity_factor=%.2f)" % (where, ex.capacity_factor))
+        return extra_max
 
-    def loss(self):
+    def weights_nonfinite_flag(self):
+        """int32[1] on the device: 1 when a weight (or, with a trainable table, a row of this rank's shard) is not
+        finite -- what a checkpoint would WRITE, as opposed to the loss of the batch before the update."""
+        bad = ~torch.isfinite(self.params.flat).all()
+        if self.train_table:
+            bad = bad | ~torch.isfinite(self.table.data).all()
+        return bad.to(torch.int32).view(1)
+
+    def loss(self, check=True):
         """Host value of the last step's mean hinge loss (synchronises; also reads the input
-        flags, so an exchange overflow raises here instead of returning NaN)."""
+        flags, so an exchange overflow raises here instead of returning NaN).
+        Data-parallel runs (``grad_sync.world > 1``): with ``check`` this is a COLLECTIVE call
+        (``check_inputs`` reduces the flags over the ranks) -- every rank must make it at the same
+        point; ``loss(check=False)`` is the rank-local read for logging on one rank only."""
         v = float(self.stats[0].item())
-        self.check_inputs()
+        if check:
+            self.check_inputs()
         return v
 
     # ------------------------------------------------------------ checkpoint --
@@ -777,14 +797,18 @@ class Trainer:
 
     # ---- checkpoints --------------------------------------------------------
     def save(self, step):
-        if not self.checkpoint_dir:
-            return None
         # never checkpoint weights that were stepped on overflowed (NaN) rows: the check is collective (every rank
-        # learns of any rank's overflow and raises here), and a state whose last loss is not finite is not written --
-        # the previous checkpoint (max_to_keep = 1 deletes it below) stays the last good one
-        self.ts.check_inputs()
-        if not torch.isfinite(self.ts.stats[0]).item():
-            self.log.warning("step %d: loss is not finite -- checkpoint NOT written, the previous one is kept", step)
+        # learns of any rank's overflow and raises here) -- so it comes BEFORE anything that depends on a per-rank
+        # argument such as checkpoint_dir (a rank that returned early would leave the others alone in the all-reduce).
+        # What is tested is what would be WRITTEN: the weights (and this rank's shard of a trainable table), not the
+        # loss of the batch before the update; the verdict rides in the same collective (maximum over the ranks), so
+        # every rank takes the same write-or-skip decision and the shard files of one step are all there or none is.
+        # The previous checkpoint (max_to_keep = 1 deletes it below) stays the last good one.
+        if self.ts.check_inputs(extra=self.ts.weights_nonfinite_flag()):
+            self.log.warning("step %d: a weight is not finite (on at least one rank) -- checkpoint NOT written, the "
+                             "previous one is kept", step)
+            return None
+        if not self.checkpoint_dir:
             return None
         # data-parallel runs: the dense state is replicated -> rank 0 writes it; a trainable
         # table is sharded -> every rank writes its own shard file

@@ -51,6 +51,11 @@ enum cdml_status {
  * thread ("" if none). */
 int cdml_version(void);
 const char *cdml_last_error(void);
+/* "CDML_BUILD_ID=<16 hex digits>": sha256[:16] over the sources this library was compiled from (csrc/ .hip and .h
+ * files by name, then this header) -- compiled in by __graft_entry__.build(); the host side
+ * (_lib.load_library) compares it with the tree it runs from and refuses a library built from other sources.
+ * The reference has no counterpart (pure Python, nothing prebuilt). */
+const char *cdml_build_id(void);
 
 /* ---- synthetic catalogue (bench/test data, imitation_data.py:41-53 shape) --
  * table[r][j] for r in [row0,row0+n_rows), j < feature_size: U[0,1) on the fp32

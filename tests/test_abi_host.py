@@ -36,6 +36,30 @@ def test_library_exports_every_declared_symbol(built):
     assert lib.cdml_last_error() is not None
 
 
+def test_build_id_ties_the_library_to_the_tree(built, tmp_path):
+    """the loaded library says which sources it was built from, and a library built from other
+    sources is refused by the loader (file times cannot tell after a copy)."""
+    import shutil
+    import subprocess
+    import sys
+    lib = built.load_library()
+    sid = built.source_id()
+    assert sid and lib.cdml_build_id().decode() == "CDML_BUILD_ID=" + sid == "CDML_BUILD_ID=" + built.embedded_id(built.lib_path())
+    # a tree whose kernel sources differ from the ones the prebuilt library came from: same .so, one byte more in a source
+    pkg = tmp_path / "collaborative-deep-metric-learning_amd"
+    shutil.copytree(os.path.join(ROOT, "collaborative-deep-metric-learning_amd"), pkg,
+                    ignore=shutil.ignore_patterns("__pycache__"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")
+    shutil.copytree(os.path.join(ROOT, "cdml_amd"), tmp_path / "cdml_amd", ignore=shutil.ignore_patterns("__pycache__"))
+    with open(pkg / "csrc" / "common.h", "a") as f:
+        f.write("\n// edited after the library was built\n")
+    code = ("import sys; sys.path.insert(0, %r); from cdml_amd import _lib\n"
+            "try:\n    _lib.load_library()\nexcept _lib.CdmlError as e:\n    print('REFUSED', e)\n" % str(tmp_path))
+    env = {k: v for k, v in os.environ.items() if k not in ("CDML_LIB_PATH", "CDML_ALLOW_STALE_LIB")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert "REFUSED" in r.stdout and "built from other sources" in r.stdout, r.stdout + r.stderr
+
+
 def test_argument_errors_need_no_gpu(built):
     """Validation happens before any HIP call, so the status/message contract is
     testable on CPU: null pointers -> CDML_E_BADARG with a message."""

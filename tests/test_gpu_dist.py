@@ -211,7 +211,8 @@ def _trainer_worker(rank, world, port, q, ckdir):
         n_pairs = ts.pairs.shape[0]
         feats = ts.table.data[:, :CFG["F"]].cpu().numpy()
         ev = [[0, 1], [2, 3], [4, 5]]                       # local rows of this shard: any pairs do
-        tr = train.Trainer(ts, num_epochs=1, n_pairs=n_pairs, checkpoint_dir=ckdir, eval_features=feats,
+        # only rank 0 is GIVEN a checkpoint directory: the collective input check of save() must not depend on it
+        tr = train.Trainer(ts, num_epochs=1, n_pairs=n_pairs, checkpoint_dir=ckdir if rank == 0 else None, eval_features=feats,
                            eval_cowatches=ev, check_stop_epoch=0.0, best_eval_dist=1e9, eval_per_epoch=2,
                            require_improve_num=1000)
         tr.run(max_steps=8)

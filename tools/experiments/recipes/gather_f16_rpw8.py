@@ -1,0 +1,2 @@
+# A/B: the fp16 fused gather with eight rows in flight per wave instead of four
+EDITS = [("sampler_gather.hip", "#define CDML_GATHER_ROWS_PER_WAVE_F16 4", "#define CDML_GATHER_ROWS_PER_WAVE_F16 8")]
