@@ -20,7 +20,15 @@ enum { BE_BIAS_LRELU_BF16 = 0, BE_BIAS_LRELU_F32 = 1, BE_MASK_BF16 = 2, BE_F32 =
        BE_ROWBIAS_LRELU_X3 = 8,
        // ABI-level ids of cdml_gemm_bf16x3_nt (mapped to 6 / 7 with BArgs::mask_out / aux_bits set): 6 that also writes the
        // sign bitmask of its result to `aux`, 7 reading that bitmask
-       BE_BIAS_LRELU_X3_BITS = 9, BE_MASKBITS_X3 = 10 };
+       BE_BIAS_LRELU_X3_BITS = 9, BE_MASKBITS_X3 = 10,
+       // semi-hard negative mining (BASELINE config 2) as the epilogue of the B x 2B score product S = E_anchor . E^T:
+       // nothing of S is written -- every (tile, column strip) hands back, per anchor row, its best candidates
+       // (BArgs::mine_*; gemm_bf16_256.hip "mine tail", loss.hip cdml_semihard_mine_x3)
+       BE_MINE_X3 = 11 };
+
+// one candidate pair of an anchor over some set of columns: the closest eligible column with d > d_p ("outside"; ties ->
+// smaller column) and the farthest eligible one; c = 0x7fffffff: none
+struct alignas(16) MineCand { float out_d; int out_c; float in_d; int in_c; };
 
 struct BArgs {
   const bf16 *A; int64_t lda;
@@ -47,6 +55,14 @@ struct BArgs {
   // count the block -> tile map is computed for (0: the launch's own grid), narrow_first = the first block index (in
   // that map) of the tiles a NARROW launch computes as two 128 x 256 halves each
   int grid_tiles, narrow_first;
+  // k_gemm_x3_rounds: this many of the half-tile blocks are dispatched FIRST (before the full tiles), the rest last: the CUs
+  // that start with a half tile then run half a tile out of phase with the others for the whole launch, so the tiles'
+  // plane stores (393 KB each) reach HBM in two bursts of half the chip instead of one of the whole chip (0: all last)
+  int stagger_lead;
+  // BE_MINE_X3: A = the anchors' planes (row i = embedded row 2 i), B = every embedded row's planes, C unused.
+  // mine_sqn[c] = |e_c|^2, mine_ids[c] = the video id of row c, mine_dp[i] = d(anchor i, its positive);
+  // mine_out[(tn * 4 + strip) * mine_ld + i] = anchor i's candidates over the 64 columns of strip `strip` of tile column tn
+  const float *mine_sqn; const int32_t *mine_ids; const float *mine_dp; MineCand *mine_out; int64_t mine_ld;
 };
 
 // 256x256x64 kernel: true if the shape can use it (N % 256 == 0, K per split a
@@ -57,6 +73,8 @@ int gemm_bf16_256_splits(int M, int N, int K);
 int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t stream);
 // the split-fp32 forms (g.x3_* set; epilogues 1, 3, 6, 7 k-contiguous, 3 k-strided)
 int launch_gemm_bf16_256_x3(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t stream);
+// the score product of semi-hard mining with the selection as its epilogue (BE_MINE_X3; six products, resident-plane walk)
+int launch_gemm_x3_mine(const BArgs &g, hipStream_t stream);
 
 // streaming kernel for the mask / plain-bf16 epilogue (BE_MASK_BF16) at K == 256: N % 256 == 0,
 // lda / ldb / ldc / ldaux multiples of 8, A inside the 2 GiB buffer-descriptor window

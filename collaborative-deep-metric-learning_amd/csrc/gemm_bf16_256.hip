@@ -146,6 +146,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
                 "the 128 x 256 half tile exists for the plane-output products of the resident-plane walk");
   static_assert(X3 || (EPI != BE_BIAS_LRELU_X3 && EPI != BE_MASK_X3 && EPI != BE_ROWBIAS_LRELU_X3),
                 "plane outputs belong to the split-fp32 form");
+  static_assert(EPI != BE_MINE_X3 || (X3 && S16 && R6 && !TN && !NARROW), "the mining epilogue rides on the resident-plane walk");
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -948,6 +949,71 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     }
   }
 
+  // ---- semi-hard mining as the epilogue of the score product (BASELINE config 2; spec: oracle/tower.py semihard_select,
+  // the rule of k_semihard_select in loss.hip) -------------------------------------------------------------------------
+  // The tile holds S[i][c] = <anchor i, row c> for 256 anchors x 256 embedded rows and writes none of it.  Lane (l15, q)
+  // holds, per 16 x 16 block (rbb, cb), column cb*16 + l15 and rows rbb*16 + 4q .. +3.  Per element: d = |a|^2 + |c|^2 - 2 S,
+  // eligible = the row's video is neither the anchor's nor its positive's; the lane keeps, per ROW, its best "outside"
+  // candidate (closest d > d_p) and its farthest eligible one over its four columns.  The 16 lanes that share a row then
+  // meet through the wave's private 16 KiB of LDS (64 rows at a time, slots XOR-swizzled by the row: conflict-free both
+  // ways): lane L merges the 16 slots of row L and stores ONE 16-B record -- rows contiguous, 1 KiB per wave store --
+  // into the strip's plane of `mine_out`.  k_semihard_finish merges an anchor's 4 tiles_n strips.  (d, c) orders are total
+  // (ties -> smaller column), so no merge order can change the result.
+  if constexpr (EPI == BE_MINE_X3) {
+    const float inf = __builtin_huge_valf();
+    MineCand *sW = reinterpret_cast<MineCand *>(smem + wave * 16384);
+    float nc[4];
+    int idc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int c = n0 + wc * 64 + cb * 16 + l15;            // < N (N is a multiple of 256)
+      nc[cb] = g.mine_sqn[c];
+      idc[cb] = g.mine_ids[c];
+    }
+    auto closer = [](float d, int c, float bd, int bc) { return d < bd || (d == bd && c < bc); };
+    auto farther = [](float d, int c, float bd, int bc) { return d > bd || (d == bd && c < bc); };
+    const int row_base = m0 + grp * 128;
+    MineCand *dst = g.mine_out + (int64_t)((n0 / kTileN) * 4 + wc) * g.mine_ld;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                     // 64 rows of the wave's 128 at a time
+#pragma unroll
+      for (int rb4 = 0; rb4 < 4; ++rb4) {
+        const int rbb = half * 4 + rb4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lrow = rb4 * 16 + q16 * 4 + r;             // 0 .. 63 within this half
+          const int i = min(row_base + half * 64 + lrow, g.M - 1);
+          const float sa = g.mine_sqn[2 * i], dpv = g.mine_dp[i];
+          const int va = g.mine_ids[2 * i], vp = g.mine_ids[2 * i + 1];
+          MineCand m{inf, 0x7fffffff, -inf, 0x7fffffff};
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) {
+            const int c = n0 + wc * 64 + cb * 16 + l15;
+            const float d = (sa + nc[cb]) - 2.0f * acc16[rbb][cb][r];
+            const bool elig = idc[cb] != va && idc[cb] != vp;
+            if (elig && d > dpv && closer(d, c, m.out_d, m.out_c)) { m.out_d = d; m.out_c = c; }
+            if (elig && farther(d, c, m.in_d, m.in_c)) { m.in_d = d; m.in_c = c; }
+          }
+          sW[lrow * 16 + (l15 ^ (lrow & 15))] = m;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      MineCand best = sW[lane * 16 + (0 ^ (lane & 15))];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) {
+        const MineCand o = sW[lane * 16 + (j ^ (lane & 15))];
+        if (closer(o.out_d, o.out_c, best.out_d, best.out_c)) { best.out_d = o.out_d; best.out_c = o.out_c; }
+        if (farther(o.in_d, o.in_c, best.in_d, best.in_c)) { best.in_d = o.in_d; best.in_c = o.in_c; }
+      }
+      const int i = row_base + half * 64 + lane;
+      if (i < g.M) dst[i] = best;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+
   // ---- epilogue: per wave, 32x64 strips through its private 16 KiB of LDS ----
   float *sC = reinterpret_cast<float *>(smem + wave * 16384);
   const int c4 = lane & 15;
@@ -1222,7 +1288,7 @@ __device__ __forceinline__ void block_of_launch(const BArgs &g, int bid, unsigne
     half = loc / per;
     bid = (((g.narrow_first >> 3) + (loc - half * per)) << 3) | xcd;
   }
-  if (g.K <= (X3 ? 3072 : 512)) tile_of_block_rowmajor(bid, nwg, g.tiles_n, tm, tn);   // output-bound
+  if (EPI != BE_MINE_X3 && g.K <= (X3 ? 3072 : 512)) tile_of_block_rowmajor(bid, nwg, g.tiles_n, tm, tn);   // output-bound
   else tile_of_block(bid, nwg, g.tiles_m, g.tiles_n, tm, tn);
   const int m0 = tm * kTileM + half * (kTileM / 2), n0 = tn * kTileN;
   const int split = blockIdx.y;
@@ -1245,8 +1311,10 @@ __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
 template <int EPI>
 __global__ void __launch_bounds__(kT, 1) k_gemm_x3_rounds(BArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  if ((int)blockIdx.x < g.narrow_first) block_of_launch<false, EPI, true, true, false, false, true, false>(g, blockIdx.x, smem);
-  else block_of_launch<false, EPI, true, true, false, false, true, true>(g, (int)blockIdx.x - g.narrow_first, smem);
+  // dispatch order (blocks start in index order): [stagger_lead half-tile blocks][the full tiles][the other half-tile blocks]
+  const int b = blockIdx.x, lead = g.stagger_lead;
+  if (b >= lead && b < lead + g.narrow_first) block_of_launch<false, EPI, true, true, false, false, true, false>(g, b - lead, smem);
+  else block_of_launch<false, EPI, true, true, false, false, true, true>(g, b < lead ? b : b - g.narrow_first, smem);
 }
 
 // ---- both weight gradients of the tower in ONE launch (k-strided form; dW1 = x_hat^T dz1, dW2 = h1^T dz2) ----
@@ -1455,6 +1523,9 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
       h.grid_tiles = tiles;
       h.narrow_first = full;
       if (full > 0 && x3_one_launch()) {
+        // CDML_X3_STAGGER=1 (A/B, read per call): half of the half-tile blocks go first
+        const char *st = getenv("CDML_X3_STAGGER");
+        if (st && atoi(st) != 0 && full + rem >= kNumCU && rem % 8 == 0) h.stagger_lead = rem;
         static bool configured = false;
         if (!configured) {
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_x3_rounds<EPI>),
@@ -1480,6 +1551,10 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
   return launch_x3_1<TN, EPI, false>(g, tiles, splits, s);
 }
 }  // namespace
+
+int launch_gemm_x3_mine(const BArgs &g, hipStream_t s) {
+  return launch_x3_1<false, BE_MINE_X3, false, false, true>(g, g.tiles_m * g.tiles_n, 1, s);
+}
 
 int launch_gemm_bf16_256_x3(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t s) {
   if (tn) return launch_x3<true, BE_F32>(g, splits, s);

@@ -330,3 +330,129 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
   }
   return rc;
 }
+
+// ---- semi-hard negative mining fused with its score product (BASELINE config 2; build-defined, spec oracle/tower.py
+// semihard_select) ------------------------------------------------------------------------------------------------------
+// Round 2 wrote S = E_anchor . E^T (B x 2B fp32: 537 MB at B = 8192) with the fp32-MFMA data-gradient kernel and scanned it
+// with k_semihard_select (0.54 + 0.14 ms of a 3.66-ms step).  Here the product runs on the plane kernels (six bf16 plane
+// products per fp32 product) and the selection is its EPILOGUE (gemm_bf16_256.hip, BE_MINE_X3): S never exists in memory.
+//   1. k_mine_prep: one wave per triplet -- |e|^2 of the anchor and the positive row, d_p = |a|^2 + |p|^2 - 2 <a, p>, both
+//      rows as planes hi | mid | lo;
+//   2. the score product, 256 anchors x 256 rows per tile: per (tile column, 64-column strip) and anchor the closest
+//      eligible row with d > d_p and the farthest eligible row (16 B);
+//   3. k_semihard_finish: per anchor the merge of its 4 tiles_n records -> neg_row.
+namespace cdml {
+namespace {
+
+__global__ void __launch_bounds__(kThreads)
+k_mine_prep(const float *__restrict__ e, int64_t lde, int B, int D, bf16 *__restrict__ e3, int64_t ld3, int64_t plane,
+            float *__restrict__ sqn, float *__restrict__ dp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nq = D >> 2;
+  for (int i = blockIdx.x * (kThreads / 64) + wave; i < B; i += gridDim.x * (kThreads / 64)) {
+    const float *a = e + (int64_t)(2 * i) * lde, *p = a + lde;
+    float sa = 0.f, sp = 0.f, ap = 0.f;
+    for (int q = lane; q < nq; q += 64) {
+      const f32x4 x = reinterpret_cast<const f32x4 *>(a)[q], y = reinterpret_cast<const f32x4 *>(p)[q];
+      sa += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+      sp += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+      ap += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      bf16x4 h, m, l;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const f32x4 v = r ? y : x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16 b0, b1, b2;
+          split3(v[j], b0, b1, b2);
+          h[j] = b0; m[j] = b1; l[j] = b2;
+        }
+        bf16 *d = e3 + (int64_t)(2 * i + r) * ld3 + 4 * q;
+        *reinterpret_cast<bf16x4 *>(d) = h;
+        *reinterpret_cast<bf16x4 *>(d + plane) = m;
+        *reinterpret_cast<bf16x4 *>(d + 2 * plane) = l;
+      }
+    }
+    sa = wave_sum(sa); sp = wave_sum(sp); ap = wave_sum(ap);
+    if (lane == 0) {
+      sqn[2 * i] = sa;
+      sqn[2 * i + 1] = sp;
+      dp[i] = (sa + sp) - 2.0f * ap;
+    }
+  }
+}
+
+// neg_row[i] = the closest "outside" candidate over all strips, else the farthest eligible one, else -1 (masked).
+// 256 threads = 64 anchors x 4 groups of strips; records of one strip are contiguous over the anchors (coalesced).
+__global__ void __launch_bounds__(kThreads)
+k_semihard_finish(const MineCand *__restrict__ part, int64_t ld, int n_strips, int B, int32_t *__restrict__ neg_row) {
+  __shared__ MineCand red[4][64];
+  const int a = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const float inf = __builtin_huge_valf();
+  MineCand best{inf, 0x7fffffff, -inf, 0x7fffffff};
+  auto merge = [&](const MineCand &o) {
+    if (o.out_d < best.out_d || (o.out_d == best.out_d && o.out_c < best.out_c)) { best.out_d = o.out_d; best.out_c = o.out_c; }
+    if (o.in_d > best.in_d || (o.in_d == best.in_d && o.in_c < best.in_c)) { best.in_d = o.in_d; best.in_c = o.in_c; }
+  };
+  if (a < B) {
+    int s = grp;
+    for (; s + 12 < n_strips; s += 16) {             // four records in flight
+      const MineCand c0 = part[(int64_t)s * ld + a], c1 = part[(int64_t)(s + 4) * ld + a];
+      const MineCand c2 = part[(int64_t)(s + 8) * ld + a], c3 = part[(int64_t)(s + 12) * ld + a];
+      merge(c0); merge(c1); merge(c2); merge(c3);
+    }
+    for (; s < n_strips; s += 4) merge(part[(int64_t)s * ld + a]);
+  }
+  red[grp][threadIdx.x & 63] = best;
+  __syncthreads();
+  if (grp == 0 && a < B) {
+    merge(red[1][threadIdx.x]); merge(red[2][threadIdx.x]); merge(red[3][threadIdx.x]);
+    neg_row[a] = best.out_c != 0x7fffffff ? best.out_c : (best.in_c != 0x7fffffff ? best.in_c : -1);
+  }
+}
+
+}  // namespace
+}  // namespace cdml
+
+extern "C" size_t cdml_semihard_mine_x3_workspace(int B) {
+  if (B < 1 || (2 * (int64_t)B) % 256) return 0;
+  return (size_t)(2 * B / 256) * 4 * (size_t)B * sizeof(MineCand);
+}
+
+// e[2B][lde] fp32 (row 2i = anchor i, 2i+1 = its positive; l2-normalised or not), rows[2B] = video ids.  Scratch the
+// caller owns: e_planes bf16 [2B][ldp] (planes `plane` apart), sqn float[2B], dp float[B], workspace
+// (cdml_semihard_mine_x3_workspace).  neg_row_out[i] as cdml_semihard_select.  2B % 256 == 0, D % 64 == 0.
+extern "C" int cdml_semihard_mine_x3(const float *e, int64_t lde, const int32_t *rows, int B, int D, uint16_t *e_planes,
+                                     int64_t ldp, int64_t plane, float *sqn, float *dp, void *workspace,
+                                     size_t workspace_bytes, int32_t *neg_row_out, cdml_stream_t stream) {
+  CDML_REQUIRE(e && rows && e_planes && sqn && dp && workspace && neg_row_out && B >= 1 && D > 0, CDML_E_BADARG,
+               "semihard_mine_x3: bad argument");
+  CDML_REQUIRE((2 * (int64_t)B) % 256 == 0 && D % 64 == 0, CDML_E_UNSUPPORTED,
+               "semihard_mine_x3: 2 B must be a multiple of 256 and D of 64, got B=%d D=%d", B, D);
+  CDML_REQUIRE(aligned16(e) && !(lde & 3) && lde >= D && aligned16(e_planes) && !(ldp & 7) && !(plane & 7) && plane >= D &&
+                   ldp >= 2 * plane + D && aligned16(workspace) && aligned16(rows) && aligned16(sqn),
+               CDML_E_ALIGN, "semihard_mine_x3: 16-B aligned bases, lde a multiple of 4, ldp / plane multiples of 8, ldp >= 2 plane + D");
+  CDML_REQUIRE(workspace_bytes >= cdml_semihard_mine_x3_workspace(B), CDML_E_BADARG,
+               "semihard_mine_x3: workspace of %zu bytes required", cdml_semihard_mine_x3_workspace(B));
+  CDML_REQUIRE(((int64_t)B + 256) * 2 * ldp * 2 < ((int64_t)1 << 31), CDML_E_UNSUPPORTED,
+               "semihard_mine_x3: the embedded rows exceed the 2 GiB buffer-descriptor range");
+  hipStream_t s = (hipStream_t)stream;
+  bf16 *e3 = reinterpret_cast<bf16 *>(e_planes);
+  hipLaunchKernelGGL(k_mine_prep, dim3(grid1d((int64_t)B * 64)), dim3(kThreads), 0, s, e, lde, B, D, e3, ldp, plane, sqn, dp);
+  int rc = check_launch("semihard_mine_x3 prep");
+  if (rc) return rc;
+  BArgs g{};
+  g.A = e3; g.lda = 2 * ldp;                                // anchors = even rows
+  g.B = e3; g.ldb = ldp;
+  g.M = B; g.N = 2 * B;
+  g.x3_tpp = D / 64; g.x3_plane_a = plane; g.x3_plane_b = plane; g.x3_products = 6;
+  g.K = 6 * g.x3_tpp * 64; g.k_per_split = g.K;
+  g.tiles_m = (B + 255) / 256; g.tiles_n = 2 * B / 256;
+  g.mine_sqn = sqn; g.mine_ids = rows; g.mine_dp = dp;
+  g.mine_out = static_cast<MineCand *>(workspace); g.mine_ld = B;
+  rc = launch_gemm_x3_mine(g, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_semihard_finish, dim3((B + 63) / 64), dim3(kThreads), 0, s, static_cast<const MineCand *>(workspace),
+                     (int64_t)B, g.tiles_n * 4, B, neg_row_out);
+  return check_launch("semihard_mine_x3 finish");
+}

@@ -314,7 +314,11 @@ struct RowF32X3 {
             o[u] = (__bf16)r[u];
             r[u] -= (float)o[u];
           }
+#if CDML_GATHER_NT_STORE
+          __builtin_nontemporal_store(o, reinterpret_cast<bf16x4v *>(dst + pl * plane + 4 * q));
+#else
           *reinterpret_cast<bf16x4v *>(dst + pl * plane + 4 * q) = o;
+#endif
         }
       }
     }

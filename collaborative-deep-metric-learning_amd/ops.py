@@ -240,6 +240,20 @@ def semihard_select(S, e, rows, B, D, sqn_scratch, neg_row_out):
     return neg_row_out
 
 
+def semihard_mine_x3_workspace(B):
+    return int(load_library().cdml_semihard_mine_x3_workspace(B))
+
+
+def semihard_mine_x3(e, rows, B, D, e_planes, plane, sqn, dp, workspace, neg_row_out):
+    """cdml_semihard_select's result without the score matrix: the B x 2B product on the plane kernels, the selection
+    as its epilogue (csrc/gemm_bf16x3.hip).  e_planes bf16 [2B, >= 3 plane], sqn f32[2B], dp f32[B], workspace f32."""
+    ep, eld = _mat(e)
+    pp, pld = _mat16(e_planes)
+    call("cdml_semihard_mine_x3", ep, eld, _p(rows, torch.int32), B, D, pp, pld, plane, _p(sqn), _p(dp),
+         _p(workspace), workspace.numel() * workspace.element_size(), _p(neg_row_out, torch.int32), _stream())
+    return neg_row_out
+
+
 def triplet_hinge_indexed(e, neg_row, B, D, margin, pos, neg, hinge, scale_scratch, stats=None, de=None):
     ep, eld = _mat(e)
     dep, deld = (C.c_void_p(0), 0) if de is None else _mat(de)

@@ -148,7 +148,18 @@ class TrainStep:
         if mode == "semihard":
             if self.B % 32:
                 raise ValueError("semi-hard mining needs a batch that is a multiple of 32")
-            self.S = torch.zeros((self.B, 2 * self.B), dtype=f32, device=dev)   # anchor x row dot products
+            # precision f32x3: the score product on the plane kernels with the selection as its epilogue -- no B x 2B
+            # score matrix (537 MB at B = 8192) is written or scanned (csrc/gemm_bf16x3.hip; CDML_MINE_FUSED=0: the
+            # round-2 form, for A/B runs); the fp32-MFMA and bf16 paths keep the score matrix
+            self.mine_fused = (self.x3 and precision == "f32x3" and (2 * self.B) % 256 == 0 and self.layout.Dp % 64 == 0
+                               and os.environ.get("CDML_MINE_FUSED", "1") != "0")
+            if self.mine_fused:
+                Dp = self.layout.Dp
+                self.e3 = torch.zeros((2 * self.B, 3 * Dp), dtype=torch.bfloat16, device=dev)
+                self.dp = torch.zeros(self.B, dtype=f32, device=dev)
+                self.mine_ws = torch.zeros(ops.semihard_mine_x3_workspace(self.B) // 4, dtype=f32, device=dev)
+            else:
+                self.S = torch.zeros((self.B, 2 * self.B), dtype=f32, device=dev)   # anchor x row dot products
             self.sqn = torch.zeros(2 * self.B, dtype=f32, device=dev)
             self.neg_row = torch.zeros(self.B, dtype=i32, device=dev)
             self.scale = torch.zeros(self.B, dtype=f32, device=dev)
@@ -368,9 +379,12 @@ class TrainStep:
                               self.stats, de)
         elif self.mode == "semihard":
             e = self.ws.e
-            # S[i][c] = <anchor_i, row_c>: the data-gradient GEMM (x @ W^T) with no mask
-            ops.fc_bwd_data(e[0::2], e, None, self.S, self.B, 2 * self.B, L.Dp)
-            ops.semihard_select(self.S, e, self.idx, self.B, L.Dp, self.sqn, self.neg_row)
+            if self.mine_fused:
+                ops.semihard_mine_x3(e, self.idx, self.B, L.Dp, self.e3, L.Dp, self.sqn, self.dp, self.mine_ws, self.neg_row)
+            else:
+                # S[i][c] = <anchor_i, row_c>: the data-gradient GEMM (x @ W^T) with no mask
+                ops.fc_bwd_data(e[0::2], e, None, self.S, self.B, 2 * self.B, L.Dp)
+                ops.semihard_select(self.S, e, self.idx, self.B, L.Dp, self.sqn, self.neg_row)
             ops.triplet_hinge_indexed(e, self.neg_row, self.B, L.Dp, self.margin, self.pos, self.neg,
                                       self.hinge, self.scale, self.stats, de)
         else:

@@ -257,6 +257,18 @@ int cdml_semihard_select(const float *S, int64_t ldS, const float *e,
                          float *sqn_scratch, int32_t *neg_row_out,
                          cdml_stream_t stream);
 
+/* The same selection with the score product on the bf16 matrix cores (fp32 operands as three exact bf16 planes, six
+ * plane products: precision "f32x3") and the selection as that product's EPILOGUE: S is never written (537 MB at
+ * B = 8192).  Scratch owned by the caller: e_planes = bf16 [2B][ldp] (planes `plane` >= D apart, ldp >= 2 plane + D),
+ * sqn float[2B], dp float[B] (receives d(anchor, positive)), workspace of cdml_semihard_mine_x3_workspace(B) bytes.
+ * 2B % 256 == 0, D % 64 == 0.  Same rule and tie-breaks as cdml_semihard_select; the distances differ from its by
+ * rounding, so a candidate within ~1e-6 of d_p may fall on either side (the test's tolerance). */
+size_t cdml_semihard_mine_x3_workspace(int B);
+int cdml_semihard_mine_x3(const float *e, int64_t lde, const int32_t *rows, int B, int D,
+                          uint16_t *e_planes, int64_t ldp, int64_t plane, float *sqn, float *dp,
+                          void *workspace, size_t workspace_bytes, int32_t *neg_row_out,
+                          cdml_stream_t stream);
+
 /* Hinge loss + gradient over triplets (row 2i, row 2i+1, row neg_row[i]);
  * neg_row[i] = -1 masks a triplet (hinge 0, still counted in the mean).  Rows
  * mined by several anchors accumulate their gradients in ascending triplet

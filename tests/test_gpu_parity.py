@@ -1026,14 +1026,77 @@ def test_semihard_select_and_indexed_loss(cd):
         assert torch.equal(dE, dE2)                   # deterministic accumulation
 
 
-def test_train_step_semihard_config2_shape(cd):
+def _check_semihard_choice(got, want, dist, rows, B, tol=2e-6):
+    """The device's negatives against the oracle's, tolerance-aware (a candidate within tol of d_p may fall on either side)."""
+    d_p = dist[np.arange(B), 2 * np.arange(B) + 1]
+    for i in range(B):
+        if want[i] < 0:
+            assert got[i] == -1
+            continue
+        assert got[i] >= 0 and rows[got[i]] not in (rows[2 * i], rows[2 * i + 1])
+        elig = (rows != rows[2 * i]) & (rows != rows[2 * i + 1])
+        strict = elig & (dist[i] > d_p[i] + tol)
+        if dist[i, got[i]] > d_p[i] - tol and (strict.any() or dist[i, want[i]] > d_p[i]):
+            if strict.any():
+                assert dist[i, got[i]] <= dist[i][strict].min() + tol
+        else:
+            assert dist[i, got[i]] >= dist[i][elig].max() - tol
+
+
+@pytest.mark.parametrize("B,D", [(128, 64), (384, 256), (640, 128)])
+def test_semihard_mine_fused_into_the_score_product(cd, B, D):
+    """BASELINE config 2 on the plane kernels: cdml_semihard_mine_x3 computes the B x 2B score product as six bf16 plane
+    products per fp32 product and selects in its epilogue -- no score matrix.  Spec = oracle.tower.semihard_select, checked
+    with the tolerance of the unfused kernel's test; B = 384 / 640: a last row tile of 128 anchors; few videos: rows with
+    nothing eligible (-1) and the farthest-eligible fallback."""
+    rng = np.random.RandomState(B + D)
+    for trial, n_videos in enumerate((5000, 12)):
+        E = otower.l2_normalize(rng.randn(2 * B, D) + (0.0 if trial else 2.0), np.float64)[0].astype(np.float32)
+        rows = rng.randint(0, n_videos, size=2 * B).astype(np.int32)
+        if trial:
+            rows[:8] = 0; rows[8:] = rng.randint(0, 2, size=2 * B - 8)
+        de_, dr = dt(E, cd.dev), dt(rows, cd.dev, torch.int32)
+        e3 = torch.zeros((2 * B, 3 * D), dtype=torch.bfloat16, device=cd.dev)
+        sqn, dpd = torch.zeros(2 * B, device=cd.dev), torch.zeros(B, device=cd.dev)
+        wsb = cd.ops.semihard_mine_x3_workspace(B)
+        assert wsb == (2 * B // 256) * 4 * B * 16
+        wsp = torch.full((wsb // 4,), float("nan"), device=cd.dev)
+        neg_row = torch.full((B,), -7, dtype=torch.int32, device=cd.dev)
+        cd.ops.semihard_mine_x3(de_, dr, B, D, e3, D, sqn, dpd, wsp, neg_row)
+        got = neg_row.cpu().numpy()
+        want, dist = otower.semihard_select(E.astype(np.float64), rows)
+        # the prep pass: exact planes, squared norms and positive distances
+        assert torch.equal(e3[:, :D].float() + e3[:, D:2 * D].float() + e3[:, 2 * D:].float(), de_)
+        np.testing.assert_allclose(sqn.cpu().numpy(), (E.astype(np.float64) ** 2).sum(1), atol=1e-6)
+        np.testing.assert_allclose(dpd.cpu().numpy(), dist[np.arange(B), 2 * np.arange(B) + 1], atol=2e-6)
+        _check_semihard_choice(got, want, dist, rows, B)
+        assert (got == want).mean() > 0.95
+        if trial:
+            assert (want < 0).any()
+        # and the unfused kernels on the same input agree (both within rounding of the oracle)
+        S = torch.empty((B, 2 * B), device=cd.dev)
+        if D % 32 == 0:
+            cd.ops.fc_bwd_data(de_[0::2], de_, None, S, B, 2 * B, D)
+            old = torch.empty(B, dtype=torch.int32, device=cd.dev)
+            cd.ops.semihard_select(S, de_, dr, B, D, torch.empty(2 * B, device=cd.dev), old)
+            assert (old.cpu().numpy() == got).mean() > 0.95
+        # deterministic
+        again = torch.empty_like(neg_row)
+        cd.ops.semihard_mine_x3(de_, dr, B, D, e3, D, sqn, dpd, wsp, again)
+        assert torch.equal(again, neg_row)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+def test_train_step_semihard_config2_shape(cd, precision):
     """BASELINE config 2 shape (batch 8192, all-pairs mining) on a 200k-row table:
     the mined negatives satisfy the semi-hard rule under the fp64 oracle distances
-    of the device's own embeddings, and loss / gradients match the oracle."""
+    of the device's own embeddings, and loss / gradients match the oracle.  f32: the score matrix S written by
+    the fp32-MFMA GEMM and scanned; f32x3: the score product on the plane kernels, the selection in its epilogue."""
     N, F, B = 200000, 1500, 8192
     table = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev)
     pairs_np = osynth.cowatch_pairs(N, 40000, 0)
-    ts = cd.train.TrainStep(table, dt(pairs_np, cd.dev, torch.int32), B, mode="semihard", device=cd.dev)
+    ts = cd.train.TrainStep(table, dt(pairs_np, cd.dev, torch.int32), B, mode="semihard", device=cd.dev, precision=precision)
+    assert ts.mine_fused == (precision == "f32x3")
     ts.fetch(); ts.forward_loss(); ts.backward()
     torch.cuda.synchronize()
     E = ts.ws.e.cpu().numpy().astype(np.float64)
