@@ -947,7 +947,8 @@ def main():
                          "bf16 MFMA), not the headline metric; f32x3-3: three products (16-bit operands), measurement only")
     ap.add_argument("--train-table", action="store_true",
                     help="also train the catalogue rows (lazy Adam; build-defined, not the headline metric)")
-    ap.add_argument("--gather-ahead", type=int, default=4, help="steps fetched per sampler+gather launch (1 GPU)")
+    ap.add_argument("--gather-ahead", type=int, default=0,
+                    help="steps fetched per sampler+gather launch (1 GPU); 0 = TrainStep's rule (1 .. 4 by the bytes a launch writes)")
     ap.add_argument("--grad-sync", default="auto", choices=["auto", "bucketed", "two", "single"],
                     help="N>1: how the gradient all-reduce is issued (auto: both forms are timed for 5 steps "
                          "before the warm-up, the faster one is kept)")

@@ -974,6 +974,19 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     auto farther = [](float d, int c, float bd, int bc) { return d > bd || (d == bd && c < bc); };
     const int row_base = m0 + grp * 128;
     MineCand *dst = g.mine_out + (int64_t)((n0 / kTileN) * 4 + wc) * g.mine_ld;
+    // the per-ROW constants of the wave's 128 anchors -- |a|^2, d_p, the two video ids -- loaded ONCE, two rows per lane,
+    // into 2 KiB of the 32 KiB of LDS the transposes leave free, and read back as one broadcast 16-B read per row (first
+    // version: four dependent global loads per row and lane inside the loop -- 128 round trips per lane and tile; the
+    // epilogue took 35 us of a 51-us tile)
+    f32x4 *rowc = reinterpret_cast<f32x4 *>(smem + 8 * 16384 + wave * 2048);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = min(row_base + u * 64 + lane, g.M - 1);
+      rowc[u * 64 + lane] = f32x4{g.mine_sqn[2 * i], g.mine_dp[i], __builtin_bit_cast(float, g.mine_ids[2 * i]),
+                                  __builtin_bit_cast(float, g.mine_ids[2 * i + 1])};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int half = 0; half < 2; ++half) {                     // 64 rows of the wave's 128 at a time
 #pragma unroll
@@ -982,9 +995,9 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int lrow = rb4 * 16 + q16 * 4 + r;             // 0 .. 63 within this half
-          const int i = min(row_base + half * 64 + lrow, g.M - 1);
-          const float sa = g.mine_sqn[2 * i], dpv = g.mine_dp[i];
-          const int va = g.mine_ids[2 * i], vp = g.mine_ids[2 * i + 1];
+          const f32x4 rc = rowc[half * 64 + lrow];
+          const float sa = rc.x, dpv = rc.y;
+          const int va = __builtin_bit_cast(int, rc.z), vp = __builtin_bit_cast(int, rc.w);
           MineCand m{inf, 0x7fffffff, -inf, 0x7fffffff};
 #pragma unroll
           for (int cb = 0; cb < 4; ++cb) {

@@ -103,6 +103,16 @@ int x3_nt_splits(int N, int ktiles) {
   return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 
+// K-tile steps per split, rounded up to whole walk periods (`period` = 6 for the six-product K-major walk, else 2), and
+// the number of splits that then actually carry K-tiles: rounding `per` up can leave the last of the requested splits
+// empty (ktiles = 288 in 11 splits: per = 30, ten splits cover it) -- an empty split would still launch its blocks, write
+// a zero slab and be read back by the combine pass
+void x3_split_geometry(int ktiles, int requested, int period, int &per, int &splits) {
+  per = (ktiles + requested - 1) / requested;
+  per = (per + period - 1) / period * period;
+  splits = (ktiles + per - 1) / per;
+}
+
 }  // namespace
 }  // namespace cdml
 
@@ -131,7 +141,11 @@ extern "C" int cdml_split_f32_bf16x3(const float *src, int64_t ld_src, int rows,
 extern "C" size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int products) {
   if (M <= 0 || N <= 0 || K <= 0 || (products != 3 && products != 6) || K % 64) return 0;
   const int ktiles = products * (K / 64);
-  const int splits = tn ? gemm_bf16_256_splits(M, N, ktiles * 64) : x3_nt_splits(N, ktiles);
+  const int requested = tn ? gemm_bf16_256_splits(M, N, ktiles * 64) : x3_nt_splits(N, ktiles);
+  int splits = requested, per = 0, s2 = requested;
+  x3_split_geometry(ktiles, requested, products == 6 ? 6 : 2, per, splits);
+  x3_split_geometry(ktiles, requested, 2, per, s2);          // (the product-major A/B walk rounds to pairs: never fewer slabs)
+  if (s2 > splits) splits = s2;
   const size_t cs = (size_t)splits * ((M + 255) / 256) * 2 * N * sizeof(float) + (size_t)N * sizeof(float);   // bias-gradient partials
   return (size_t)splits * M * N * sizeof(float) + cs;       // (a slab even unsplit: the k-strided form's bias pass reads one)
 }
@@ -245,10 +259,21 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   g.K = ktiles * 64; g.k_per_split = g.K;
   g.tiles_m = (M + 255) / 256; g.tiles_n = N / 256;
   hipStream_t s = (hipStream_t)stream;
-  int splits = planes_out ? 1 : x3_nt_splits(N, ktiles);
+  int splits = planes_out ? 1 : x3_nt_splits(N, ktiles), per = ktiles;
+  if (splits > 1) x3_split_geometry(ktiles, splits, 6, per, splits);   // whole six-step periods of the K-major walk (and an even count)
   if (splits > 1) {
-    const size_t need = (size_t)splits * M * N * sizeof(float) + (colsum ? (size_t)splits * g.tiles_m * 2 * N * sizeof(float) : 0);
-    if (!workspace || workspace_bytes < need || !aligned16(workspace)) splits = 1;     // one pass, fewer blocks
+    // The slab form needs the workspace.  workspace == NULL is the caller's explicit choice of ONE pass over K (fewer,
+    // longer blocks; no slab round trip) -- its sums are associated differently, so the result's last bits differ from
+    // the slab form's and the "same bits whole or in row blocks" property holds only among calls that all pass a workspace.
+    // A workspace that is given but too small is an error, not a silent change of arithmetic.
+    if (!workspace) {
+      splits = 1;
+    } else {
+      const size_t need = (size_t)splits * M * N * sizeof(float) + (colsum ? (size_t)splits * g.tiles_m * 2 * N * sizeof(float) : 0);
+      CDML_REQUIRE(workspace_bytes >= need && aligned16(workspace), CDML_E_BADARG,
+                   "gemm_bf16x3_nt: the slab form needs a 16-B aligned workspace of %zu bytes (cdml_gemm_bf16x3_workspace); pass "
+                   "NULL for the single-pass form", need);
+    }
   }
   const size_t slab_bytes = splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
   const size_t cs_rows = (size_t)splits * g.tiles_m * 2;
@@ -261,8 +286,7 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   if (splits == 1) {
     rc = launch_gemm_bf16_256_x3(g, false, epilogue, 1, s);
   } else {
-    const int per = (ktiles + splits - 1) / splits;
-    g.k_per_split = (per + 5) / 6 * 6 * 64;                // whole six-step periods of the K-major walk (and an even count)
+    g.k_per_split = per * 64;
     g.slab_stride = (int64_t)M * N;
     g.C = workspace; g.ldc = N;
     rc = launch_gemm_bf16_256_x3(g, false, BE_F32, splits, s);
@@ -305,7 +329,9 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
   const int ktiles = products * g.x3_tpp;
   g.K = ktiles * 64;
   g.tiles_m = M / 256; g.tiles_n = N / 256;
-  const int splits = gemm_bf16_256_splits(M, N, g.K);
+  int splits = gemm_bf16_256_splits(M, N, g.K), per = 0;
+  // whole six-step periods of the K-major walk per block (the unrolled loops need them); three products: an even count
+  x3_split_geometry(ktiles, splits, (products == 6 && g.x3_products == 6) ? 6 : 2, per, splits);
   const bool slabs = splits > 1 || bias != nullptr;       // (bias + leaky-relu are applied by the combine pass)
   const size_t slab_bytes = slabs ? (size_t)splits * M * N * sizeof(float) : 0;
   const size_t cs_rows = (size_t)splits * g.tiles_m * 2;
@@ -313,9 +339,7 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
   CDML_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && aligned16(workspace)), CDML_E_BADARG,
                "gemm_bf16x3_tn: workspace of %zu bytes required (cdml_gemm_bf16x3_workspace)", need);
   hipStream_t s = (hipStream_t)stream;
-  const int per = (ktiles + splits - 1) / splits;
-  // whole six-step periods of the K-major walk per block (the unrolled loops need them); three products: an even count
-  g.k_per_split = (products == 6 && g.x3_products == 6 ? (per + 5) / 6 * 6 : (per + 1) / 2 * 2) * 64;
+  g.k_per_split = per * 64;
   g.slab_stride = (int64_t)M * N;
   g.C = slabs ? workspace : static_cast<void *>(C);
   g.ldc = slabs ? N : ldc;

@@ -65,12 +65,28 @@ def new_capture_group(like=None):
     device_id=torch.device("cuda", i)) -- torch connects a new group's communicator eagerly at creation
     (distributed_c10d._new_process_group_helper -> eager_connect_single_device / ncclCommSplit).  Without that binding
     this raises.  Collective call: every rank of ``like`` creates the group at the same point."""
-    default = dist.distributed_c10d._get_default_group()
-    if getattr(default, "bound_device_id", None) is None:
+    default = capture_groups_supported()
+    if default is None:
         raise RuntimeError("capturing RCCL collectives into a hipGraph needs a process group bound to its device: "
                            "init_process_group(..., device_id=torch.device('cuda', local_rank))")
     ranks = None if like is None or like is default else dist.get_process_group_ranks(like)
     return dist.new_group(ranks=ranks, backend="nccl")
+
+
+def capture_groups_supported():
+    """The default process group when ``new_capture_group`` can work with it -- it is bound to its device, so torch
+    connects a new group's communicator eagerly at creation -- else None.  Reads two private names of
+    torch.distributed (``distributed_c10d._get_default_group``, ``ProcessGroup.bound_device_id``; present in torch
+    2.3 .. 2.10): where either is missing the answer is None, and ``TrainStep`` then steps eagerly with a warning instead
+    of failing at construction."""
+    get = getattr(getattr(dist, "distributed_c10d", None), "_get_default_group", None)
+    if get is None or not dist.is_initialized():
+        return None
+    try:
+        default = get()
+    except Exception:                                     # noqa: BLE001 -- no default group
+        return None
+    return default if getattr(default, "bound_device_id", None) is not None else None
 
 
 def all_to_all(out, inp, group=None):

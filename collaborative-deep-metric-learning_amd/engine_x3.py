@@ -35,9 +35,15 @@ def layout_x3(feature_size, hidden=5000, output_size=256):
 
 
 class TowerWorkspaceX3:
-    def __init__(self, layout, n_rows, device, products=6, planes_in=True, backward=True, transposed=None):
+    def __init__(self, layout, n_rows, device, products=6, planes_in=True, backward=True, transposed=None,
+                 fc2_single_pass=False):
         """planes_in: ``x_hat`` IS the plane buffer (the fused sampler + gather writes planes); False: ``x_hat`` is
-        fp32 (rows arriving through the exchange) and the forward pass splits it."""
+        fp32 (rows arriving through the exchange) and the forward pass splits it.
+        fc2_single_pass: the narrow second layer normally splits its contraction into slabs whose partition depends on
+        K alone, so an embedding has the same bits whatever batch or chunk it was computed in (whole batch or row
+        blocks, 10 000-row evaluation chunks or 65 536-row inference chunks).  True = the explicit opt-out for forward-only
+        workspaces of >= 192 row tiles: ONE pass over K, no slab round trip (about 5 % of an inference chunk), last bits
+        that differ from the slab form's."""
         L, R = layout, int(n_rows)
         if R % 128:
             raise ValueError("precision 'f32x3' needs a row count that is a multiple of 128 (got %d)" % R)
@@ -69,9 +75,10 @@ class TowerWorkspaceX3:
         self.W1T, self.W2T, self.W2 = bf(L.Hp, 3 * L.Fp), bf(L.Dp, 3 * L.Hp), bf(L.Hp, 3 * L.Dp)
         q = products
         # FC2 (one tile column) splits its contraction into slabs -- a partition that depends on K alone, so a batch gives
-        # the same bits whole or in row blocks -- when it is handed the slab workspace; without one it runs in a single
-        # pass.  Catalogue inference in big chunks (>= 192 row tiles fill the chip unsplit) skips the slabs' round trip.
-        nb = max(ops.gemm_bf16x3_workspace(False, R, L.Dp, L.Hp, q), 16) if (backward or R // 256 < 192) else 16
+        # the same bits whole or in row blocks, in small chunks or large (test_embedding_bits_do_not_depend_on_the_chunk);
+        # the single pass (workspace NULL at the C ABI) is an explicit opt-out, fc2_single_pass.
+        self.fc2_single_pass = bool(fc2_single_pass) and not backward and R // 256 >= 192
+        nb = 16 if self.fc2_single_pass else max(ops.gemm_bf16x3_workspace(False, R, L.Dp, L.Hp, q), 16)
         # leaky-relu' of the hidden layer as ONE BIT per element (round 4): FC1's epilogue writes the sign bitmask of h1
         # (this lane's 8 columns = one byte), the data gradient's epilogue reads 5 MB of bits instead of the 84 MB of
         # h1's hi plane -- that read sat in its store-bound epilogue and cost 30 us of its 151 (profiles/r04_stagger_and_
@@ -145,7 +152,7 @@ def tower_forward(p, ws, normalize=True):
             ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, ws.x3, L.Fp, ws.W1T, L.Fp, ws.h1, R, L.Hp, L.Fp, products=q,
                                plane_c=L.Hp, bias=p.b1)
         ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, ws.h1, L.Hp, ws.W2T, L.Hp, ws.z, R, L.Dp, L.Hp, products=q,
-                           bias=p.b2, workspace=ws.gemm_ws)
+                           bias=p.b2, workspace=None if getattr(ws, "fc2_single_pass", False) else ws.gemm_ws)
     ws.tail_done = False
     ws.dz2_planes_done = False
     if normalize:

@@ -15,11 +15,12 @@ from . import engine, engine_bf16, engine_x3, ops
 
 
 class Prediction():
-    def __init__(self, params=None, ckpt=None, device="cuda:0", precision="f32"):
+    def __init__(self, params=None, ckpt=None, device="cuda:0", precision="f32", fc2_single_pass=False):
         """``precision``: "f32" (the reference's arithmetic) or "bf16" -- BASELINE config 4's
         precision for catalogue inference: an fp16 ``FeatureTableF16`` in, bf16 MFMA projection,
         fp32 accumulation and output normalisation (build-defined; tolerance 5e-3 on the unit-norm
-        embeddings, tests/test_gpu_bf16.py)."""
+        embeddings, tests/test_gpu_bf16.py).  ``fc2_single_pass`` (precision "f32x3"): see
+        engine_x3.TowerWorkspaceX3 -- off, an embedding's bits do not depend on the chunk size."""
         if params is None:
             if ckpt is None or not os.path.exists(ckpt):
                 raise IOError("Prediction __init__ Cannot find %s" % ckpt)      # predict.py:54-55
@@ -39,6 +40,7 @@ class Prediction():
         self.params = params
         self.device = params.device
         self.precision = precision
+        self.fc2_single_pass = bool(fc2_single_pass)
         self._ws = None
 
     X3_MAX_ROWS = 65536
@@ -50,7 +52,8 @@ class Prediction():
             n_rows = engine.round_up(n_rows, 128)
         if self._ws is None or self._ws.R < n_rows:
             if self.precision == "f32x3":
-                self._ws = engine_x3.TowerWorkspaceX3(self.params.layout, n_rows, self.device, planes_in=False, backward=False)
+                self._ws = engine_x3.TowerWorkspaceX3(self.params.layout, n_rows, self.device, planes_in=False, backward=False,
+                                                      fc2_single_pass=self.fc2_single_pass)
             elif self.precision == "bf16":
                 self._ws = engine_bf16.TowerWorkspaceBF16(self.params.layout, n_rows, self.device, backward=False)
                 self._ids = torch.arange(n_rows, dtype=torch.int32, device=self.device)

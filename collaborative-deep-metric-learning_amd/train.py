@@ -44,7 +44,7 @@ class TrainStep:
                  base_learning_rate=0.01, learning_rate_decay_examples=1000000,
                  learning_rate_decay=0.96, seed=1234, weight_seed=42, device="cuda:0",
                  exchange=None, grad_sync=None, slot0=0, batch_global=None, use_graph=False,
-                 prefetch=True, precision="f32", train_table=False, gather_ahead=4,
+                 prefetch=True, precision="f32", train_table=False, gather_ahead="auto",
                  clip_gradient_norm=0.0, regularization_penalty=0.0, l2_penalty=1e-8,
                  grad_sync_mode="bucketed"):
         """table: FeatureTable (whole catalogue, or this rank's shard when
@@ -60,9 +60,13 @@ class TrainStep:
         their own streams and ordered by events recorded eagerly between the replays, so the exchange
         of step t+1 runs UNDER step t's forward GEMMs as in the eager step and every RCCL stream is one
         fork from its capture origin (two deep hangs on this stack: dist.Prefetcher).
-        ``gather_ahead``: steps fetched per launch of the fused sampler+gather (single-GPU fp32
+        ``gather_ahead``: steps fetched per launch of the fused sampler+gather (single-GPU
         path): the sampler is counter-based, so one launch samples and gathers the rows of
-        this step and the next gather_ahead-1 into their own buffers.
+        this step and the next gather_ahead-1 into their own buffers.  "auto" (default): as many
+        steps (1 .. 4) as keep the bytes one launch WRITES near the 256 MB Infinity Cache -- more
+        steps amortise the launch's fixed cost, but rows written past what the cache absorbs
+        cost HBM bandwidth twice (round 5, profiles/r05_gather_sweep.txt: three-plane rows at
+        16 384 rows a step read+write 0.70-0.72 of 8 TB/s at two steps per launch, 0.63 at four).
         ``clip_gradient_norm`` / ``regularization_penalty``: build_graph's switches
         (train.py:133-145; the reference's run passes 0 for both, train.py:221-222): per-variable
         tf.clip_by_norm, and penalty * sum_W l2_penalty*|W|^2/2 added to the loss (models.py:28).
@@ -194,6 +198,10 @@ class TrainStep:
                                  "replicated trainable tables would diverge between ranks")
         # several steps' rows per gather launch (the frozen catalogue cannot change in between;
         # a trainable one can, and the sharded path has its own prefetcher)
+        if gather_ahead in ("auto", None, 0):
+            row_bytes = self.ws.x_hat.shape[-1] * self.ws.x_hat.element_size()       # what one gathered row writes
+            target = 230e6 if self.bf16 else 300e6                                  # (fp16 -> bf16 rows: half the bytes read per byte written)
+            gather_ahead = min(4, max(1, int(round(target / (self.R * row_bytes)))))
         self.gather_ahead = max(1, int(gather_ahead))
         if exchange is not None or self.train_table:
             self.gather_ahead = 1
@@ -225,6 +233,12 @@ class TrainStep:
                 self.use_graph = False
                 logging.getLogger("cdml.train").warning(
                     "use_graph ignored: host-staged (gloo) collectives cannot be captured; RCCL ones can")
+            elif self._needs_capture_groups() and _cdist.capture_groups_supported() is None:
+                # the capture-only groups need a default group bound to its device (dist.new_capture_group); a caller
+                # that initialised torch.distributed without device_id= (what worked through round 3) steps eagerly
+                self.use_graph = False
+                logging.getLogger("cdml.train").warning(
+                    "use_graph ignored: capturing RCCL collectives needs init_process_group(..., device_id=...); stepping eagerly")
             else:
                 self._ensure_capture_groups()
         # row-sharded catalogue: the exchange of step t+1 runs ahead on a side stream
@@ -239,6 +253,18 @@ class TrainStep:
             self._shift = [self.shift, torch.zeros_like(self.shift)]
         if self.use_graph == "split" and self.prefetch is None:
             self.use_graph = True                        # nothing to overlap: one graph per step
+
+    def _needs_capture_groups(self):
+        """True when a captured step of this job would issue an RCCL collective (a hook over the nccl backend that is
+        not skipped at world size 1)."""
+        for h in (self.exchange, self.grad_sync):
+            if h is None or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+                continue
+            if torch.distributed.get_backend(h.group) != "nccl":
+                continue
+            if h.world > 1 or not getattr(h, "skip_self", True) or getattr(h, "active", False):
+                return True
+        return False
 
     def _ensure_capture_groups(self):
         """Captured collectives go through process groups of their own, which never carry an eager one: the RCCL watchdog's

@@ -35,6 +35,14 @@ def _worker(rank, world, port, n_rows, F, q):
 
         full = osynth.features_philox(0, n_rows, F, seed=3)            # the global catalogue
         lo, hi, per = cdist.shard_bounds(n_rows, world, rank)
+        # a default group that is not bound to a device cannot host capture-only RCCL groups: the probe says so (and
+        # TrainStep then steps eagerly with a warning instead of raising); asking for one anyway raises
+        assert cdist.capture_groups_supported() is None
+        try:
+            cdist.new_capture_group()
+            raise AssertionError("new_capture_group() on an unbound default group must raise")
+        except RuntimeError as e:
+            assert "device_id" in str(e)
 
         class Shard:                                                   # stand-in for FeatureTable
             data = torch.from_numpy(full[lo:hi].copy())

@@ -479,3 +479,56 @@ def test_half_tiles_of_the_last_round_are_bit_identical(M, N, K, monkeypatch):
     for _ in range(10 if M * N > 2 ** 24 else 30):
         again = run(True)
         assert torch.equal(again[0], half[0]) and torch.equal(again[2], half[2])
+
+
+def test_embedding_bits_do_not_depend_on_the_chunk():
+    """the narrow second layer's K partition is a function of K alone, so an embedding has the same bits in a
+    49 152-row inference chunk (192 row tiles: round 4 skipped the slabs there) and in 4 096-row chunks; the single pass
+    over K is an explicit opt-out (fc2_single_pass) whose results agree to rounding, and a workspace that is given but too
+    small is an error at the C ABI, not a silent change of arithmetic."""
+    from cdml_amd import _lib, engine, engine_x3, predict
+    dev = _dev()
+    F, H, D, N = 64, 1280, 32, 49152                       # Hp = 1280: 120 K-tile steps = two slabs of 60
+    L = engine_x3.layout_x3(F, H, D)
+    params = engine.VNetParams(L, dev, 42)
+    table = engine.FeatureTable.synthetic(N, F, seed=0, device=dev)
+    pr = predict.Prediction(params=params, precision="f32x3")
+    big = pr.embed_table(table, N).clone()
+    assert pr._ws.R // 256 >= 192 and not pr._ws.fc2_single_pass
+    small = predict.Prediction(params=params, precision="f32x3").embed_table(table, 4096)
+    torch.cuda.synchronize()
+    assert torch.equal(big, small)
+    one = predict.Prediction(params=params, precision="f32x3", fc2_single_pass=True)
+    single = one.embed_table(table, N)
+    assert one._ws.fc2_single_pass
+    assert (single - big).abs().max().item() < 1e-6
+    # the C ABI: NULL workspace = the single pass; a workspace that is too small is refused
+    M, K = 512, 1280
+    A3 = _planes(torch.randn(M, K, device=dev) * 0.1, K)
+    B3 = _planes(torch.randn(256, K, device=dev) * 0.1, K)
+    C = torch.empty((M, 256), device=dev)
+    bias = torch.zeros(256, device=dev)
+    ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, A3, K, B3, K, C, M, 256, K, bias=bias, alpha=0.2)           # single pass
+    with pytest.raises(_lib.CdmlError, match="slab form needs"):
+        ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, A3, K, B3, K, C, M, 256, K, bias=bias, alpha=0.2,
+                           workspace=torch.empty(1024, device=dev))
+
+
+def test_split_k_geometry_has_no_empty_split():
+    """rounding the K-tiles per split up to whole walk periods can leave the last requested split empty; the
+    launch, the slab sizes and the workspace query now use the splits that carry K-tiles (x3_split_geometry).  A one-tile
+    product over K = 3 072 rows (288 K-tile steps, split for occupancy) against fp64, with the bias-gradient sums."""
+    dev = _dev()
+    M, N, K = 256, 256, 3072
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    A = torch.randn(K, M, device=dev, generator=g) * 0.1
+    B = torch.randn(K, N, device=dev, generator=g) * 0.1
+    A3, B3 = _planes(A, M), _planes(B, N)
+    nbytes = ops.gemm_bf16x3_workspace(True, M, N, K, 6)
+    C = torch.empty((M, N), device=dev)
+    cs = torch.empty(N, device=dev)
+    ops.gemm_bf16x3_tn(A3, M, B3, N, C, M, N, K, workspace=torch.empty(max(nbytes, 16) // 4, device=dev), colsum=cs)
+    torch.cuda.synchronize()
+    want = (A.double().t() @ B.double())
+    assert ((C.double() - want).abs().max() / want.abs().max()).item() < 5e-6
+    assert (cs.double() - B.double().sum(0)).abs().max().item() < 1e-4
