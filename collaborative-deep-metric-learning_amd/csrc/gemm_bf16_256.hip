@@ -142,8 +142,8 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
                                          const int c_col0, float *cs_row, const int64_t cs_grp_stride,
                                          unsigned char *smem) {
   static_assert(!TN || EPI == BE_F32, "the k-strided form only serves the weight gradients");
-  static_assert(!NARROW || (X3 && S16 && R6 && !TN && (EPI == BE_BIAS_LRELU_X3 || EPI == BE_MASK_X3 || EPI == BE_ROWBIAS_LRELU_X3)),
-                "the 128 x 256 half tile exists for the plane-output products of the resident-plane walk");
+  static_assert(!NARROW || (X3 && S16 && R6 && !TN && (EPI == BE_BIAS_LRELU_X3 || EPI == BE_MASK_X3 || EPI == BE_ROWBIAS_LRELU_X3 || EPI == BE_F32)),
+                "the 128 x 256 half tile exists for the plane-output products of the resident-plane walk and for the fp32 slabs of the narrow layer");
   static_assert(X3 || (EPI != BE_BIAS_LRELU_X3 && EPI != BE_MASK_X3 && EPI != BE_ROWBIAS_LRELU_X3),
                 "plane outputs belong to the split-fp32 form");
   static_assert(EPI != BE_MINE_X3 || (X3 && S16 && R6 && !TN && !NARROW), "the mining epilogue rides on the resident-plane walk");
@@ -1037,9 +1037,10 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32 || EPI == BE_BIAS_LRELU_X3)
     bias4 = *reinterpret_cast<const f32x4 *>(g.bias + gcol);
   const bool has_aux = (EPI == BE_MASK_BF16 || EPI == BE_MASK_X3) && g.aux != nullptr;
+  constexpr int GRg = NARROW ? 64 : 128, RTg = GRg / 32;     // rows per row group (half tile: 64), its 32-row strips
   auto out_row = [&](int rt, int p) {
     const int lr = p * 4 + (lane >> 4);
-    return TN ? m0 + (rt >> 1) * 128 + grp * 64 + (rt & 1) * 32 + lr : m0 + grp * 128 + rt * 32 + lr;
+    return TN ? m0 + (rt >> 1) * 128 + grp * 64 + (rt & 1) * 32 + lr : m0 + grp * GRg + rt * 32 + lr;
   };
   constexpr bool kRowBias = EPI == BE_ROWBIAS_LRELU_X3;
   constexpr bool kBiasEpi = EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_X3 || kRowBias;
@@ -1206,13 +1207,13 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   bf16x4 mk[4][8];
   if ((EPI == BE_MASK_BF16 || EPI == BE_MASK_X3) && has_aux) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RTg; ++rt)
 #pragma unroll
       for (int p = 0; p < 8; ++p)
         mk[rt][p] = *reinterpret_cast<const bf16x4 *>(g.aux + (int64_t)min(out_row(rt, p), g.M - 1) * g.ldaux + gcol);
   }
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
+  for (int rt = 0; rt < RTg; ++rt) {
     float *strip = sC + (rt & 1) * 2048;                 // alternate halves: no wait for the readers
     if constexpr (S16) {
       // 16x16 blocks: lane (l15, q) holds column l15, rows 4q .. 4q+3.  Rows 4 apart share their banks
@@ -1554,6 +1555,17 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
         if (rc) return rc;
       }
       return launch_x3_1<TN, EPI, false, false, true, true>(h, 2 * rem, 1, s);
+    }
+  }
+  if constexpr (!TN && EPI == BE_F32) {
+    // The narrow layer's fp32 slabs (N = one tile column, K split into slabs): when the full tiles leave a third of the
+    // chip or more idle, the same slabs are computed as 128 x 256 HALF tiles on twice the blocks -- same operands, same K
+    // order per output element: bit-identical (BASELINE config 1: 32 row tiles x 4 slabs = 128 blocks -> 256)
+    if (walk == 2 && splits > 1 && !g.colsum_partial && tiles % 8 == 0 && 3 * tiles * splits <= 2 * kNumCU && x3_half_tiles()) {
+      BArgs h = g;
+      h.grid_tiles = tiles;
+      h.narrow_first = 0;
+      return launch_x3_1<TN, EPI, false, false, true, true>(h, 2 * tiles, splits, s);
     }
   }
   if (walk == 2) return launch_x3_1<TN, EPI, false, false, true>(g, tiles, splits, s);

@@ -92,14 +92,20 @@ bool x3_kmajor() {
 
 // split-K for the k-contiguous forms whose output is ONE tile column wide (N = 256: the narrow forward layer, whose
 // M / 256 tiles alone would leave most of the chip idle; fp32 slab output only).  The K partition is a function of K
-// ALONE -- slabs of ten six-step periods (60 K-tile steps), at most 16 of them, summed in slab order by k_x3_sum_slabs --
-// so the result does not depend on how many rows the call carries: a batch computed whole and the same batch computed
+// ALONE -- slabs of twenty six-step periods (120 K-tile steps), at most 16 of them, summed in slab order by k_x3_sum_slabs
+// -- so the result does not depend on how many rows the call carries: a batch computed whole and the same batch computed
 // in row blocks (two ranks against one) give the same bits.  (Round 3 chose the slab count from the tile count: 8
 // slabs at 8 192 rows, none at 49 152, and leaky-relu' flips near zero then loosened the two-rank gradient bound.)
+// Round 5: 120 steps instead of 60 -- four slabs at K = 5 120 -- which halves the slab round trip (the forward layer at
+// 16 384 rows: 64 tiles x 4 slabs = one round of the chip instead of two rounds of half-length blocks); where four slabs
+// leave the chip under-filled (8 192 rows: 128 blocks) the SAME slabs run as 128 x 256 half tiles (gemm_bf16_256.hip),
+// so the partition stays a function of K alone.
 // Wider outputs are never split: their tiles fill the chip at every batch size the step uses.
 int x3_nt_splits(int N, int ktiles) {
   if (N / 256 != 1) return 1;
-  const int s = ktiles / 60;
+  const char *e = getenv("CDML_X3_SLAB_STEPS");            // (A/B: 60 = the partition of rounds 4)
+  const int steps = e && atoi(e) >= 12 ? atoi(e) / 6 * 6 : 120;
+  const int s = ktiles / steps;
   return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 

@@ -171,12 +171,39 @@ def test_train_step_matches_the_fp32_mfma_step(mode, optimizer, transposed, monk
     D = 256
     assert torch.equal(a.idx, b.idx)
     assert (a.ws.e[:, :D] - b.ws.e[:, :D]).abs().max().item() < 1e-5
-    assert abs(a.loss() - b.loss()) < 1e-5
     if mode == "semihard":
-        assert torch.equal(a.neg_row, b.neg_row)
+        # round 5: the f32x3 step mines in the epilogue of its own score product (plane kernels), the fp32 step scans the
+        # score matrix of the fp32-MFMA GEMM: the two sets of distances differ by rounding, and on this iid catalogue the
+        # untrained embeddings lie within ~1e-3 of each other, so near-ties may break differently.  Each path's choice is
+        # held to the rule under fp64 distances of ITS OWN embeddings (2e-6, as tests/test_gpu_parity.py), and its loss to
+        # the oracle's on its own triplets.
+        from oracle import tower as otower
+        assert b.mine_fused and not a.mine_fused
+        for t in (a, b):
+            E = t.ws.e[:, :D].double().cpu().numpy()
+            rows = t.idx.cpu().numpy()
+            got = t.neg_row.cpu().numpy()
+            want, dist = otower.semihard_select(E, rows)
+            d_p = dist[np.arange(B), 2 * np.arange(B) + 1]
+            for i in range(B):
+                if want[i] < 0:
+                    assert got[i] == -1
+                    continue
+                elig = (rows != rows[2 * i]) & (rows != rows[2 * i + 1])
+                assert got[i] >= 0 and elig[got[i]]
+                strict = elig & (dist[i] > d_p[i] + 2e-6)
+                if dist[i, got[i]] > d_p[i] - 2e-6 and (strict.any() or dist[i, want[i]] > d_p[i]):
+                    if strict.any():
+                        assert dist[i, got[i]] <= dist[i][strict].min() + 2e-6
+                else:
+                    assert dist[i, got[i]] >= dist[i][elig].max() - 2e-6
+            tri, valid = otower.semihard_triplets(got)
+            assert abs(t.loss() - float(otower.hinge_loss_indexed(E, tri, valid, 0.8, np.float64)["hinge_loss"])) < 1e-5
+    else:
+        assert abs(a.loss() - b.loss()) < 1e-5
     for _ in range(3):                                   # keeps stepping: the plane copies follow the optimizer
         a.step(); b.step()
-    assert abs(a.loss() - b.loss()) < 2e-3
+    assert abs(a.loss() - b.loss()) < (5e-3 if mode == "semihard" else 2e-3)
     # the planes the GEMMs read ARE the master weights
     L = b.layout
     w1t = b.ws.W1T[:, :L.Fp].float() + b.ws.W1T[:, L.Fp:2 * L.Fp].float() + b.ws.W1T[:, 2 * L.Fp:].float()
@@ -488,7 +515,7 @@ def test_embedding_bits_do_not_depend_on_the_chunk():
     small is an error at the C ABI, not a silent change of arithmetic."""
     from cdml_amd import _lib, engine, engine_x3, predict
     dev = _dev()
-    F, H, D, N = 64, 1280, 32, 49152                       # Hp = 1280: 120 K-tile steps = two slabs of 60
+    F, H, D, N = 64, 2560, 32, 49152                       # Hp = 2560: 240 K-tile steps = two slabs of 120
     L = engine_x3.layout_x3(F, H, D)
     params = engine.VNetParams(L, dev, 42)
     table = engine.FeatureTable.synthetic(N, F, seed=0, device=dev)
@@ -503,7 +530,7 @@ def test_embedding_bits_do_not_depend_on_the_chunk():
     assert one._ws.fc2_single_pass
     assert (single - big).abs().max().item() < 1e-6
     # the C ABI: NULL workspace = the single pass; a workspace that is too small is refused
-    M, K = 512, 1280
+    M, K = 512, 2560
     A3 = _planes(torch.randn(M, K, device=dev) * 0.1, K)
     B3 = _planes(torch.randn(256, K, device=dev) * 0.1, K)
     C = torch.empty((M, 256), device=dev)
