@@ -978,12 +978,13 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     // into 2 KiB of the 32 KiB of LDS the transposes leave free, and read back as one broadcast 16-B read per row (first
     // version: four dependent global loads per row and lane inside the loop -- 128 round trips per lane and tile; the
     // epilogue took 35 us of a 51-us tile)
-    f32x4 *rowc = reinterpret_cast<f32x4 *>(smem + 8 * 16384 + wave * 2048);
+    // (as INTEGER words: video ids carried as float bit patterns are denormals, and a float move may flush them)
+    i32x4 *rowc = reinterpret_cast<i32x4 *>(smem + 8 * 16384 + wave * 2048);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int i = min(row_base + u * 64 + lane, g.M - 1);
-      rowc[u * 64 + lane] = f32x4{g.mine_sqn[2 * i], g.mine_dp[i], __builtin_bit_cast(float, g.mine_ids[2 * i]),
-                                  __builtin_bit_cast(float, g.mine_ids[2 * i + 1])};
+      rowc[u * 64 + lane] = i32x4{__builtin_bit_cast(int, g.mine_sqn[2 * i]), __builtin_bit_cast(int, g.mine_dp[i]),
+                                  g.mine_ids[2 * i], g.mine_ids[2 * i + 1]};
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -995,9 +996,9 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int lrow = rb4 * 16 + q16 * 4 + r;             // 0 .. 63 within this half
-          const f32x4 rc = rowc[half * 64 + lrow];
-          const float sa = rc.x, dpv = rc.y;
-          const int va = __builtin_bit_cast(int, rc.z), vp = __builtin_bit_cast(int, rc.w);
+          const i32x4 rc = rowc[half * 64 + lrow];
+          const float sa = __builtin_bit_cast(float, rc.x), dpv = __builtin_bit_cast(float, rc.y);
+          const int va = rc.z, vp = rc.w;
           MineCand m{inf, 0x7fffffff, -inf, 0x7fffffff};
 #pragma unroll
           for (int cb = 0; cb < 4; ++cb) {
@@ -1295,7 +1296,7 @@ __device__ __forceinline__ void block_of_launch(const BArgs &g, int bid, unsigne
   // the block -> tile map of the WHOLE tile grid, of which this launch may cover the first blocks only (grid_tiles) or,
   // NARROW, the rest as two half tiles each: block (xcd, local) -> half local / per of the tile of block (narrow_first / 8
   // + local % per, xcd) -- both halves of a tile and its neighbours on the XCD whose L2 holds their operand panels
-  const int nwg = g.grid_tiles > 0 ? g.grid_tiles : (int)gridDim.x;
+  const int nwg = g.grid_tiles > 0 ? g.grid_tiles : (g.persist_blocks > 0 ? g.persist_blocks : (int)gridDim.x);
   int half = 0;
   if constexpr (NARROW) {
     const int per = (nwg - g.narrow_first) >> 3, xcd = bid & 7, loc = bid >> 3;
@@ -1317,6 +1318,18 @@ __device__ __forceinline__ void block_of_launch(const BArgs &g, int bid, unsigne
 template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false, bool NARROW = false>
 __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  if (g.persist_blocks > 0) {
+    for (int b = blockIdx.x; b < g.persist_blocks; b += gridDim.x) {
+      if (b != (int)blockIdx.x) {
+        // the previous tile's stores are retired before this tile's DMA is counted in vmcnt (one counter for loads and
+        // stores), and its epilogue strips are LDS images again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CDML_BARRIER();
+      }
+      block_of_launch<TN, EPI, S16, X3, F6, NTCS, R6, NARROW>(g, b, smem);
+    }
+    return;
+  }
   block_of_launch<TN, EPI, S16, X3, F6, NTCS, R6, NARROW>(g, blockIdx.x, smem);
 }
 
@@ -1326,9 +1339,16 @@ template <int EPI>
 __global__ void __launch_bounds__(kT, 1) k_gemm_x3_rounds(BArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   // dispatch order (blocks start in index order): [stagger_lead half-tile blocks][the full tiles][the other half-tile blocks]
-  const int b = blockIdx.x, lead = g.stagger_lead;
-  if (b >= lead && b < lead + g.narrow_first) block_of_launch<false, EPI, true, true, false, false, true, false>(g, b - lead, smem);
-  else block_of_launch<false, EPI, true, true, false, false, true, true>(g, b < lead ? b : b - g.narrow_first, smem);
+  const int lead = g.stagger_lead;
+  const int n_logical = g.persist_blocks > 0 ? g.persist_blocks : (int)gridDim.x;
+  for (int b = blockIdx.x; b < n_logical; b += gridDim.x) {
+    if (b != (int)blockIdx.x) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      CDML_BARRIER();
+    }
+    if (b >= lead && b < lead + g.narrow_first) block_of_launch<false, EPI, true, true, false, false, true, false>(g, b - lead, smem);
+    else block_of_launch<false, EPI, true, true, false, false, true, true>(g, b < lead ? b : b - g.narrow_first, smem);
+  }
 }
 
 // ---- both weight gradients of the tower in ONE launch (k-strided form; dW1 = x_hat^T dz1, dW2 = h1^T dz2) ----
@@ -1495,6 +1515,14 @@ int launch_x3_1(const BArgs &g, int blocks, int splits, hipStream_t s) {
     if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3: cannot reserve %d B of LDS: %s", smem, hipGetErrorString(e));
     configured = true;
   }
+  // CDML_X3_PERSIST=1 (A/B, read per call): one resident block per CU walks the launch's tiles
+  const char *pe = getenv("CDML_X3_PERSIST");
+  if (pe && atoi(pe) != 0 && splits == 1 && blocks > kNumCU && blocks % 8 == 0) {
+    BArgs h = g;
+    h.persist_blocks = blocks;
+    hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS, R6, NARROW>), dim3(kNumCU, 1), dim3(kT), smem, s, h);
+    return check_launch("gemm_bf16x3");
+  }
   hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS, R6, NARROW>), dim3(blocks, splits), dim3(kT), smem, s, g);
   return check_launch("gemm_bf16x3");
 }
@@ -1546,6 +1574,12 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
                                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_R6);
           if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3: cannot reserve %d B of LDS: %s", SMEM_R6, hipGetErrorString(e));
           configured = true;
+        }
+        const char *pe = getenv("CDML_X3_PERSIST");
+        if (pe && atoi(pe) != 0) {
+          h.persist_blocks = full + 2 * rem;
+          hipLaunchKernelGGL((k_gemm_x3_rounds<EPI>), dim3(kNumCU), dim3(kT), SMEM_R6, s, h);
+          return check_launch("gemm_bf16x3");
         }
         hipLaunchKernelGGL((k_gemm_x3_rounds<EPI>), dim3(full + 2 * rem), dim3(kT), SMEM_R6, s, h);
         return check_launch("gemm_bf16x3");

@@ -549,17 +549,9 @@ int grid_for(int64_t work_items, int per_block) {
   return (int)b;
 }
 
-// grid of the PERSISTENT fused kernels (a block walks chunks c, c + grid, ...): at most 8 blocks per CU, and every block
-// the same number of chunks -- 4 608 chunks on 2 048 blocks leave the last pass a quarter full, on 1 536 blocks every
-// block walks exactly three (round 5: the launch's fixed costs are what keeps the fp16 gather under 0.70 of HBM)
-int grid_balanced(int64_t work_items, int per_block) {
-  const int64_t chunks = (work_items + per_block - 1) / per_block;
-  const int64_t cap = (int64_t)kNumCU * 8;
-  if (chunks <= cap) return (int)(chunks < 1 ? 1 : chunks);
-  const int64_t passes = (chunks + cap - 1) / cap;
-  return (int)((chunks + passes - 1) / passes);
-}
-
+// (round 5: a grid with every block walking the same number of chunks -- 1 536 blocks x 3 chunks instead of 2 048 blocks x
+// 2.25 -- was measured SLOWER for the fp16 gather, 0.600 against 0.675 of 8 TB/s: what counts is 8 resident blocks per CU,
+// not an even chunk count)
 }  // namespace
 }  // namespace cdml
 
@@ -666,7 +658,7 @@ extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pair
                "sample_gather: batch_global < slot0 + batch");
   int rc = check_gather_layout("sample_gather", table, row_stride, F, x_out, out_stride);
   if (rc) return rc;
-  const int grid = grid_balanced((int64_t)batch * (mode == 0 ? 3 : 2) * n_steps, RowF32<6>::kRows * kWavesPerBlock);
+  const int grid = grid_for((int64_t)batch * (mode == 0 ? 3 : 2) * n_steps, RowF32<6>::kRows * kWavesPerBlock);
   const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
 #define CDML_LAUNCH_SG(M, N)                                                                      \
   hipLaunchKernelGGL((k_sample_gather<M, RowF32<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
@@ -710,7 +702,7 @@ extern "C" int cdml_sample_gather_x3(int mode, const int32_t *pairs, int64_t n_p
   CDML_REQUIRE(row_stride >= F && (row_stride & 3) == 0 && out_stride % 3 == 0 && out_stride / 3 >= F &&
                    ((out_stride / 3) & 3) == 0 && aligned16(table) && (reinterpret_cast<uintptr_t>(x_out_planes) & 7) == 0,
                CDML_E_ALIGN, "sample_gather_x3: out_stride must be 3 planes of >= F columns (multiples of 4)");
-  const int grid = grid_balanced((int64_t)batch * rpt * n_steps, RowF32X3<6>::kRows * kWavesPerBlock);
+  const int grid = grid_for((int64_t)batch * rpt * n_steps, RowF32X3<6>::kRows * kWavesPerBlock);
   const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
 #define CDML_LAUNCH_SGX(M, N)                                                                              \
   hipLaunchKernelGGL((k_sample_gather<M, RowF32X3<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
@@ -772,7 +764,7 @@ extern "C" int cdml_sample_gather_f16(int mode, const int32_t *pairs, int64_t n_
   CDML_REQUIRE(row_stride >= F && (row_stride & 7) == 0 && out_stride >= F && (out_stride & 7) == 0 &&
                    aligned16(table) && aligned16(x_out_bf16),
                CDML_E_ALIGN, "sample_gather_f16: strides must be >= F and multiples of 8, bases 16-B aligned");
-  const int grid = grid_balanced((int64_t)batch * rpt * n_steps, RowF16<3>::kRows * kWavesPerBlock);
+  const int grid = grid_for((int64_t)batch * rpt * n_steps, RowF16<3>::kRows * kWavesPerBlock);
   const int nch = ((F + 7) / 8 + kWave - 1) / kWave;
 #define CDML_LAUNCH_SGH(M, N)                                                                               \
   hipLaunchKernelGGL((k_sample_gather<M, RowF16<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream,   \

@@ -528,7 +528,7 @@ def test_embedding_bits_do_not_depend_on_the_chunk():
     one = predict.Prediction(params=params, precision="f32x3", fc2_single_pass=True)
     single = one.embed_table(table, N)
     assert one._ws.fc2_single_pass
-    assert (single - big).abs().max().item() < 1e-6
+    assert 0 < (single - big).abs().max().item() < 5e-6     # (another association of the same sums: close, not equal)
     # the C ABI: NULL workspace = the single pass; a workspace that is too small is refused
     M, K = 512, 2560
     A3 = _planes(torch.randn(M, K, device=dev) * 0.1, K)
