@@ -59,9 +59,6 @@ struct BArgs {
   // that start with a half tile then run half a tile out of phase with the others for the whole launch, so the tiles'
   // plane stores (393 KB each) reach HBM in two bursts of half the chip instead of one of the whole chip (0: all last)
   int stagger_lead;
-  // > 0: the launch has this many LOGICAL blocks but only gridDim.x resident ones (one per CU), each walking logical blocks
-  // b, b + gridDim.x, ... (splits == 1 only): no block dispatch between a CU's tiles (A/B: CDML_X3_PERSIST)
-  int persist_blocks;
   // BE_MINE_X3: A = the anchors' planes (row i = embedded row 2 i), B = every embedded row's planes, C unused.
   // mine_sqn[c] = |e_c|^2, mine_ids[c] = the video id of row c, mine_dp[i] = d(anchor i, its positive);
   // mine_out[(tn * 4 + strip) * mine_ld + i] = anchor i's candidates over the 64 columns of strip `strip` of tile column tn

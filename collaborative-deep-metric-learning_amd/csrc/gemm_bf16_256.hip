@@ -960,6 +960,15 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   // into the strip's plane of `mine_out`.  k_semihard_finish merges an anchor's 4 tiles_n strips.  (d, c) orders are total
   // (ties -> smaller column), so no merge order can change the result.
   if constexpr (EPI == BE_MINE_X3) {
+    // Everything below is computed from a lane id the optimizer cannot see through: derived from the function's own
+    // `lane`, the epilogue's addresses were hoisted ABOVE the K loop and kept live across it -- 17 VGPRs spilled to
+    // scratch inside the loop, and a scratch store is a vector-memory operation: it is counted by the loop's hand-counted
+    // s_waitcnt vmcnt(N), which then lets fragments be read before their DMA has landed (round 5: every negative wrong,
+    // on one build and not on the one before).  __graft_entry__.build() now refuses a build in which a kernel of this file
+    // has a scratch frame.
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int l15 = lane_e & 15, q16 = lane_e >> 4, lane = lane_e;
     const float inf = __builtin_huge_valf();
     MineCand *sW = reinterpret_cast<MineCand *>(smem + wave * 16384);
     float nc[4];
@@ -1296,7 +1305,7 @@ __device__ __forceinline__ void block_of_launch(const BArgs &g, int bid, unsigne
   // the block -> tile map of the WHOLE tile grid, of which this launch may cover the first blocks only (grid_tiles) or,
   // NARROW, the rest as two half tiles each: block (xcd, local) -> half local / per of the tile of block (narrow_first / 8
   // + local % per, xcd) -- both halves of a tile and its neighbours on the XCD whose L2 holds their operand panels
-  const int nwg = g.grid_tiles > 0 ? g.grid_tiles : (g.persist_blocks > 0 ? g.persist_blocks : (int)gridDim.x);
+  const int nwg = g.grid_tiles > 0 ? g.grid_tiles : (int)gridDim.x;
   int half = 0;
   if constexpr (NARROW) {
     const int per = (nwg - g.narrow_first) >> 3, xcd = bid & 7, loc = bid >> 3;
@@ -1318,18 +1327,10 @@ __device__ __forceinline__ void block_of_launch(const BArgs &g, int bid, unsigne
 template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false, bool NARROW = false>
 __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  if (g.persist_blocks > 0) {
-    for (int b = blockIdx.x; b < g.persist_blocks; b += gridDim.x) {
-      if (b != (int)blockIdx.x) {
-        // the previous tile's stores are retired before this tile's DMA is counted in vmcnt (one counter for loads and
-        // stores), and its epilogue strips are LDS images again
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        CDML_BARRIER();
-      }
-      block_of_launch<TN, EPI, S16, X3, F6, NTCS, R6, NARROW>(g, b, smem);
-    }
-    return;
-  }
+  // (round 5: ONE resident block per CU walking the launch's tiles -- no block dispatch between a CU's tiles -- was built
+  // and measured: miner 0.437-0.442 against 0.429-0.430 ms, headline step 2.629-2.633 against 2.621-2.623 ms,
+  // profiles/r05_persistent_tiles_ab.txt; the loop around run_tile also cost the k-strided kernel its last free VGPRs --
+  // 72 B of scratch.  Removed.)
   block_of_launch<TN, EPI, S16, X3, F6, NTCS, R6, NARROW>(g, blockIdx.x, smem);
 }
 
@@ -1339,16 +1340,9 @@ template <int EPI>
 __global__ void __launch_bounds__(kT, 1) k_gemm_x3_rounds(BArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   // dispatch order (blocks start in index order): [stagger_lead half-tile blocks][the full tiles][the other half-tile blocks]
-  const int lead = g.stagger_lead;
-  const int n_logical = g.persist_blocks > 0 ? g.persist_blocks : (int)gridDim.x;
-  for (int b = blockIdx.x; b < n_logical; b += gridDim.x) {
-    if (b != (int)blockIdx.x) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      CDML_BARRIER();
-    }
-    if (b >= lead && b < lead + g.narrow_first) block_of_launch<false, EPI, true, true, false, false, true, false>(g, b - lead, smem);
-    else block_of_launch<false, EPI, true, true, false, false, true, true>(g, b < lead ? b : b - g.narrow_first, smem);
-  }
+  const int b = blockIdx.x, lead = g.stagger_lead;
+  if (b >= lead && b < lead + g.narrow_first) block_of_launch<false, EPI, true, true, false, false, true, false>(g, b - lead, smem);
+  else block_of_launch<false, EPI, true, true, false, false, true, true>(g, b < lead ? b : b - g.narrow_first, smem);
 }
 
 // ---- both weight gradients of the tower in ONE launch (k-strided form; dW1 = x_hat^T dz1, dW2 = h1^T dz2) ----
@@ -1515,14 +1509,6 @@ int launch_x3_1(const BArgs &g, int blocks, int splits, hipStream_t s) {
     if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3: cannot reserve %d B of LDS: %s", smem, hipGetErrorString(e));
     configured = true;
   }
-  // CDML_X3_PERSIST=1 (A/B, read per call): one resident block per CU walks the launch's tiles
-  const char *pe = getenv("CDML_X3_PERSIST");
-  if (pe && atoi(pe) != 0 && splits == 1 && blocks > kNumCU && blocks % 8 == 0) {
-    BArgs h = g;
-    h.persist_blocks = blocks;
-    hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS, R6, NARROW>), dim3(kNumCU, 1), dim3(kT), smem, s, h);
-    return check_launch("gemm_bf16x3");
-  }
   hipLaunchKernelGGL((k_gemm_bf16_256<TN, EPI, true, true, F6, NTCS, R6, NARROW>), dim3(blocks, splits), dim3(kT), smem, s, g);
   return check_launch("gemm_bf16x3");
 }
@@ -1574,12 +1560,6 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
                                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_R6);
           if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3: cannot reserve %d B of LDS: %s", SMEM_R6, hipGetErrorString(e));
           configured = true;
-        }
-        const char *pe = getenv("CDML_X3_PERSIST");
-        if (pe && atoi(pe) != 0) {
-          h.persist_blocks = full + 2 * rem;
-          hipLaunchKernelGGL((k_gemm_x3_rounds<EPI>), dim3(kNumCU), dim3(kT), SMEM_R6, s, h);
-          return check_launch("gemm_bf16x3");
         }
         hipLaunchKernelGGL((k_gemm_x3_rounds<EPI>), dim3(full + 2 * rem), dim3(kT), SMEM_R6, s, h);
         return check_launch("gemm_bf16x3");

@@ -60,6 +60,30 @@ def test_build_id_ties_the_library_to_the_tree(built, tmp_path):
     assert "REFUSED" in r.stdout and "built from other sources" in r.stdout, r.stdout + r.stderr
 
 
+def test_no_gemm_kernel_has_a_scratch_frame(built):
+    """The GEMMs count their LDS-DMA loads by hand (s_waitcnt vmcnt(N)); a register spill is a vector-memory operation on
+    the same counter, so a spill inside such a loop reads LDS images before they have landed.  build() keeps the compiler's
+    resource remarks beside every object and refuses a build with a spilling GEMM kernel; this test reads them again."""
+    import glob
+    import re
+    import __graft_entry__ as g
+    rem = sorted(glob.glob(os.path.join(ROOT, "build", "obj", "gemm_*.remarks")))
+    assert len(rem) >= 4, "build() writes <object>.remarks for every source"
+    seen = 0
+    for f in rem:
+        name = None
+        for ln in open(f):
+            m = re.search(r"Function Name: (\S+)", ln)
+            if m:
+                name = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", ln)
+            if m and name and "k_gemm" in name:
+                seen += 1
+                assert int(m.group(1)) == 0, (name, ln)
+    assert seen >= 40                                  # every instantiation of the tile kernels reports
+    g._check_no_scratch([f[:-8] + ".o" for f in rem])
+
+
 def test_argument_errors_need_no_gpu(built):
     """Validation happens before any HIP call, so the status/message contract is
     testable on CPU: null pointers -> CDML_E_BADARG with a message."""
