@@ -961,11 +961,10 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   // (ties -> smaller column), so no merge order can change the result.
   if constexpr (EPI == BE_MINE_X3) {
     // Everything below is computed from a lane id the optimizer cannot see through: derived from the function's own
-    // `lane`, the epilogue's addresses were hoisted ABOVE the K loop and kept live across it -- 17 VGPRs spilled to
-    // scratch inside the loop, and a scratch store is a vector-memory operation: it is counted by the loop's hand-counted
-    // s_waitcnt vmcnt(N), which then lets fragments be read before their DMA has landed (round 5: every negative wrong,
-    // on one build and not on the one before).  __graft_entry__.build() now refuses a build in which a kernel of this file
-    // has a scratch frame.
+    // `lane`, the epilogue's addresses were hoisted ABOVE the K loop and kept live across it (256 VGPRs and 17 of them
+    // spilled to scratch inside the loop, against 222 and none this way).  A scratch store is a vector-memory operation:
+    // it is counted by the loop's hand-counted s_waitcnt vmcnt(N), which would then let fragments be read before their DMA
+    // has landed -- __graft_entry__.build() refuses a build in which a GEMM kernel has a scratch frame.
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int l15 = lane_e & 15, q16 = lane_e >> 4, lane = lane_e;
@@ -992,8 +991,8 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int i = min(row_base + u * 64 + lane, g.M - 1);
-      rowc[u * 64 + lane] = i32x4{__builtin_bit_cast(int, g.mine_sqn[2 * i]), __builtin_bit_cast(int, g.mine_dp[i]),
-                                  g.mine_ids[2 * i], g.mine_ids[2 * i + 1]};
+      rowc[u * 64 + lane] = i32x4{__float_as_int(g.mine_sqn[2 * i]), __float_as_int(g.mine_dp[i]), g.mine_ids[2 * i],
+                                  g.mine_ids[2 * i + 1]};
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1006,7 +1005,10 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
         for (int r = 0; r < 4; ++r) {
           const int lrow = rb4 * 16 + q16 * 4 + r;             // 0 .. 63 within this half
           const i32x4 rc = rowc[half * 64 + lrow];
-          const float sa = __builtin_bit_cast(float, rc.x), dpv = __builtin_bit_cast(float, rc.y);
+          // (through scalar copies: __builtin_bit_cast applied to a vector ELEMENT read element 0 for every element with
+          // this hipcc -- ROCm 7.2 -- so d_p came back as |a|^2 and, in the float-vector form, both ids as its bits)
+          const int w0 = rc.x, w1 = rc.y;
+          const float sa = __int_as_float(w0), dpv = __int_as_float(w1);
           const int va = rc.z, vp = rc.w;
           MineCand m{inf, 0x7fffffff, -inf, 0x7fffffff};
 #pragma unroll

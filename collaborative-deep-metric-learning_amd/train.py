@@ -667,7 +667,15 @@ class TrainStep:
             raise RuntimeError("graph replay needs the previous step's prefetch (step %d)" % t)
         G = self._graphs
         if ("E", 1 - b) not in G:
-            G[("E", 1 - b)] = self._capture(lambda: self._fill(1 - b, None), origin=pf.stream)
+            # Capture origin: a stream of its OWN, never the prefetch stream (rounds 3-4).  torch runs a synchronous eager
+            # collective on the CURRENT stream and records its work's end event there, so the eager exchange of the first
+            # step left such an event on pf.stream; a capture that starts on pf.stream within the RCCL watchdog's poll
+            # period (100 ms) then makes the watchdog query an event "last recorded in a capturing stream" and the process
+            # ends (round 5: test_data_parallel_step_replays_from_hipgraph_over_rccl failed once in four suite runs).  The
+            # graph is still REPLAYED on pf.stream; RCCL's communicator stream is one fork from the origin either way.
+            if getattr(self, "_ex_origin", None) is None:
+                self._ex_origin = torch.cuda.Stream(self.device)
+            G[("E", 1 - b)] = self._capture(lambda: self._fill(1 - b, None), origin=self._ex_origin)
         self.ws.x_hat, self.idx, self.shift = self._x[b], self._idx[b], self._shift[b]
         if ("F", b) not in G:
             G[("F", b)] = self._capture(self.forward_loss)

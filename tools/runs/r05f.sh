@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, GPU call F: the whole -m gpu suite on the spill-free build, the miner probe, config 2
+# round 5, GPU call F: the whole -m gpu suite, the miner probe, config 2 and the headline (re-run after the bit_cast fix)
 set -o pipefail
 ROOT=$(pwd); O=$ROOT/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 python -m pytest tests -m gpu -q > $O/r05f_gpu_tests.txt 2>&1
