@@ -1310,9 +1310,14 @@ __device__ __forceinline__ void block_of_launch(const BArgs &g, int bid, unsigne
   const int nwg = g.grid_tiles > 0 ? g.grid_tiles : (int)gridDim.x;
   int half = 0;
   if constexpr (NARROW) {
-    const int per = (nwg - g.narrow_first) >> 3, xcd = bid & 7, loc = bid >> 3;
-    half = loc / per;
-    bid = (((g.narrow_first >> 3) + (loc - half * per)) << 3) | xcd;
+    if (((nwg - g.narrow_first) & 7) == 0) {
+      const int per = (nwg - g.narrow_first) >> 3, xcd = bid & 7, loc = bid >> 3;
+      half = loc / per;
+      bid = (((g.narrow_first >> 3) + (loc - half * per)) << 3) | xcd;
+    } else {                      // a tile count that is no multiple of 8 (the narrow layer at 3 072 rows: 12 tiles): halves side by side
+      half = bid & 1;
+      bid = g.narrow_first + (bid >> 1);
+    }
   }
   if (EPI != BE_MINE_X3 && g.K <= (X3 ? 3072 : 512)) tile_of_block_rowmajor(bid, nwg, g.tiles_n, tm, tn);   // output-bound
   else tile_of_block(bid, nwg, g.tiles_m, g.tiles_n, tm, tn);
@@ -1577,7 +1582,7 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
     // The narrow layer's fp32 slabs (N = one tile column, K split into slabs): when the full tiles leave a third of the
     // chip or more idle, the same slabs are computed as 128 x 256 HALF tiles on twice the blocks -- same operands, same K
     // order per output element: bit-identical (BASELINE config 1: 32 row tiles x 4 slabs = 128 blocks -> 256)
-    if (walk == 2 && splits > 1 && !g.colsum_partial && tiles % 8 == 0 && 3 * tiles * splits <= 2 * kNumCU && x3_half_tiles()) {
+    if (walk == 2 && splits > 1 && !g.colsum_partial && 3 * tiles * splits <= 2 * kNumCU && x3_half_tiles()) {
       BArgs h = g;
       h.grid_tiles = tiles;
       h.narrow_first = 0;
