@@ -204,11 +204,12 @@ def pmc_traffic(kernel, bf16=False, name=None, workload=None):
     if not os.path.exists(path):
         return None, None
     import csv
-    vals = {}
-    for r in csv.DictReader(open(path)):
-        # `kernel` may leave trailing template arguments (tile-depth / stage tuning) open
-        if r["kernel"] == kernel or (not kernel.endswith(">") and r["kernel"].startswith(kernel)):
-            vals[r["counter"]] = float(r["mean_per_launch"])
+    rows = list(csv.DictReader(open(path)))
+    # `kernel` may leave trailing template arguments (tile-depth / stage tuning) open: an exact name wins, else the FIRST
+    # kernel whose name starts with it (k_gemm_f32_sk must not pick up k_gemm_f32_sk_fixup's bytes)
+    names = [r["kernel"] for r in rows]
+    pick = kernel if kernel in names else next((n for n in names if not kernel.endswith(">") and n.startswith(kernel)), None)
+    vals = {r["counter"]: float(r["mean_per_launch"]) for r in rows if r["kernel"] == pick}
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None, None
     src = "profiles/%s.csv (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run" % name
@@ -434,7 +435,7 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0, pmc_name=
         else:
             kname, klabel = "k_gemm_f32_sk", "k_gemm_f32_sk (dW1+dW2 in one stream-K launch, fix-up pass included)"
     else:
-        kname = "k_gemm_bf16_256<true, 3>" if (bf16 or x3_products) else "k_gemm_f32<false, false, 2, 2, 3,"
+        kname = "k_gemm_bf16_256<true, 3, true, false" if (bf16 or x3_products) else "k_gemm_f32<false, false, 2, 2, 3,"
         n_launch = kt.count("dW1") + kt.count("dW2")
         t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
         klabel = kname + (" ...> (dW1+dW2 launches)" if not (bf16 or x3_products) else " (dW1+dW2 launches)")
@@ -453,7 +454,7 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0, pmc_name=
                        "launch_ms": round(t_ms, 4), "flop_per_launch": flop_launch,
                        "launches_per_step": n_launch / sampled, "timed_steps": sampled, "timed_how": how}
     ach1 = flops_gemm / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
-    k1 = "k_gemm_bf16_256<false, 0>" if bf16 else "k_gemm_f32<true, false, 2, 2, 1,"
+    k1 = "k_gemm_bf16_256<false, 0," if bf16 else "k_gemm_f32<true, false, 2, 2, 1,"
     if x3_products:
         # (full tiles + the last round's half tiles in one launch where the tile count leaves half a round or less;
         # k_gemm_bf16_256<false, 6, ..., R6> otherwise)
@@ -461,7 +462,7 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0, pmc_name=
     if x3_products:
         tr1, src1 = (None, None)
         if single_gpu:
-            for kn in ("k_gemm_x3_rounds<6>", "k_gemm_bf16_256<false, 6, true, true, false, false, true>"):
+            for kn in ("k_gemm_x3_rounds<6>", "k_gemm_bf16_256<false, 6, true, true, false, false, true"):
                 tr1, src1 = pmc_traffic(kn, name=pmc_name or "latest_pmc_x3", workload=workload)
                 if src1 is not None:
                     break
