@@ -75,6 +75,9 @@ int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t s
 int launch_gemm_bf16_256_x3(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t stream);
 // the score product of semi-hard mining with the selection as its epilogue (BE_MINE_X3; six products, resident-plane walk)
 int launch_gemm_x3_mine(const BArgs &g, hipStream_t stream);
+// the k-strided product on k8-INTERLEAVED operands ([plane][k / 8][column][8 k]; g.lda / g.ldb = elements per k-group,
+// g.x3_plane_* = elements per plane): the resident-plane walk with one 16-B LDS read per fragment
+int launch_gemm_x3_tnk(const BArgs &g, int splits, hipStream_t stream);
 
 // streaming kernel for the mask / plain-bf16 epilogue (BE_MASK_BF16) at K == 256: N % 256 == 0,
 // lda / ldb / ldc / ldaux multiples of 8, A inside the 2 GiB buffer-descriptor window

@@ -136,7 +136,13 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
 // the unrolled period with its compile-time DMA skipping, and the general loop is not compiled in.
 // NTCS (X3, k-contiguous form): also sum B over k per column (its own instantiation: compiled into the plain kernels the
 // four sums and their branch cost FC1 25 % -- 514 -> 642 us, measured).
-template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false, bool NARROW = false>
+// KI (k-strided form of the resident-plane walk only): the operands are stored k8-INTERLEAVED -- [plane][k / 8][column][8 k]
+// bf16, lda / ldb = elements per k-group (8 x the operand's columns), x3_plane_* = elements per plane -- so that a fragment (8
+// consecutive k of one column) is ONE aligned 16-B LDS read instead of two transposed 8-B reads, and a half image
+// [8 k-groups][128 columns][16 B] is filled by 1-KiB pieces that are contiguous in memory.  Same images, slots, DMA schedule,
+// accumulation order and results as the k-strided form (test_gemm_x3_tnk_equals_tn: bit for bit).
+template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false, bool NARROW = false,
+          bool KI = false>
 __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int m0, const int n0, const int k_begin,
                                          const int n_ktiles, void *c_base, const int64_t c_ld, const int c_row0,
                                          const int c_col0, float *cs_row, const int64_t cs_grp_stride,
@@ -147,6 +153,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   static_assert(X3 || (EPI != BE_BIAS_LRELU_X3 && EPI != BE_MASK_X3 && EPI != BE_ROWBIAS_LRELU_X3),
                 "plane outputs belong to the split-fp32 form");
   static_assert(EPI != BE_MINE_X3 || (X3 && S16 && R6 && !TN && !NARROW), "the mining epilogue rides on the resident-plane walk");
+  static_assert(!KI || (TN && X3 && S16 && R6), "the k8-interleaved operands exist for the k-strided resident-plane walk");
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -154,8 +161,8 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   const int l31 = lane & 31, h = lane >> 5;
 
   const int k_rows = X3 ? g.x3_tpp * kTileK : g.K;              // k-strided form: rows of the operands in memory
-  const i32x4 srd_a = make_srd(g.A, (int64_t)(TN ? k_rows : g.M) * g.lda * 2);
-  const i32x4 srd_b = make_srd(g.B, (int64_t)(TN ? k_rows : g.N) * g.ldb * 2);
+  const i32x4 srd_a = make_srd(g.A, KI ? 3 * g.x3_plane_a * 2 : (int64_t)(TN ? k_rows : g.M) * g.lda * 2);
+  const i32x4 srd_b = make_srd(g.B, KI ? 3 * g.x3_plane_b * 2 : (int64_t)(TN ? k_rows : g.N) * g.ldb * 2);
 
   // ---- DMA lane constants.  NT: piece pc = wave*2+i covers image rows pc*8 .. pc*8+7
   //      (128-B rows); TN: k-rows pc*4 .. pc*4+3 (256-B rows) ----
@@ -169,6 +176,11 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       const int col_b = (r >> 5) * 64 + (r & 31);            // B-h0 (B-h1: + 32 columns)
       va[i] = (uint32_t)(((int64_t)(m0 + row_a) * g.lda + sc * 8) * 2);
       vb[i] = (uint32_t)(((int64_t)(n0 + col_b) * g.ldb + sc * 8) * 2);
+    } else if constexpr (KI) {
+      // piece pc = k-group pc >> 1, columns (pc & 1) * 64 + lane of the half image: 64 x 16 B contiguous in memory
+      const int pc = wave * 2 + i;
+      va[i] = (uint32_t)(((int64_t)(pc >> 1) * g.lda + (int64_t)(m0 + (pc & 1) * 64 + lane) * 8) * 2);   // A-h1: + 128 columns
+      vb[i] = (uint32_t)(((int64_t)(pc >> 1) * g.ldb + (int64_t)(n0 + (pc & 1) * 64 + lane) * 8) * 2);
     } else {
       const int r = (wave * 2 + i) * 4 + (lane >> 4);
       const int sc = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
@@ -622,8 +634,8 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     const int n_per = n_ktiles / 6;                        // whole periods (host)
     if (n_per > 0) {                                       // (an empty split writes zeros)
       const int w_first = x3_t0 / 6, w_last = w_first + n_per - 1;
-      const uint32_t ws_a = TN ? (uint32_t)(kTileK * g.lda * 2) : (uint32_t)(kTileK * 2);   // bytes per K-tile of a plane
-      const uint32_t ws_b = TN ? (uint32_t)(kTileK * g.ldb * 2) : (uint32_t)(kTileK * 2);
+      const uint32_t ws_a = KI ? (uint32_t)(8 * g.lda * 2) : TN ? (uint32_t)(kTileK * g.lda * 2) : (uint32_t)(kTileK * 2);   // bytes per K-tile of a plane
+      const uint32_t ws_b = KI ? (uint32_t)(8 * g.ldb * 2) : TN ? (uint32_t)(kTileK * g.ldb * 2) : (uint32_t)(kTileK * 2);
       const uint32_t ps_a = (uint32_t)(g.x3_plane_a * 2), ps_b = (uint32_t)(g.x3_plane_b * 2);
       const unsigned char *b16r = smem + 6 * IMG + (wc * 32 + l15) * 128;
       // k-strided form: the transposed reads address LDS as (lane offset register) + (16-bit immediate).  160 KiB need
@@ -631,7 +643,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       // by 64 / 96 KiB -- made opaque to the optimizer, which otherwise forms one hoisted register per DISTINCT large
       // constant (dozens over the 24 unrolled phases: 61 spilled VGPRs, measured)
       int ta_w2[4][2], tb_w[2][2];
-      if constexpr (TN) {
+      if constexpr (TN && !KI) {
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh) {
 #pragma unroll
@@ -646,9 +658,14 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
           }
         }
       }
+      // k8-interleaved images [8 k-groups][128 columns][16 B]: lane (l15, q) reads k-group 4 ks2 + q of its column
+      const unsigned char *ka_rd = smem + (q16 * 128 + grp * 64 + l15) * 16;
+      const unsigned char *kb_rd = smem + 6 * IMG + (q16 * 128 + wc * 32 + l15) * 16;
       auto rd_a = [&](int slot, int hh, int rb, int ks2) {
         if constexpr (!TN)
           return *reinterpret_cast<const bf16x8 *>(a16_rd + slot * 2 * IMG + hh * IMG + rb * 2048 + sw16[ks2]);
+        else if constexpr (KI)
+          return *reinterpret_cast<const bf16x8 *>(ka_rd + slot * 2 * IMG + hh * IMG + ks2 * 8192 + rb * 256);
         else if (slot < 2)
           return tr_read(smem + slot * 2 * IMG + hh * IMG + ks2 * 8192, ta16[rb][0], ta16[rb][1]);
         else
@@ -657,6 +674,8 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       auto rd_b = [&](int slot, int hh, int cb, int ks2) {
         if constexpr (!TN)
           return *reinterpret_cast<const bf16x8 *>(b16r + slot * 2 * IMG + hh * IMG + cb * 2048 + sw16[ks2]);
+        else if constexpr (KI)
+          return *reinterpret_cast<const bf16x8 *>(kb_rd + slot * 2 * IMG + hh * IMG + ks2 * 8192 + cb * 256);
         else
           return tr_read(smem + slot * 2 * IMG + hh * IMG + ks2 * 8192, tb_w[cb][0], tb_w[cb][1]);
       };
@@ -667,7 +686,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       // (whether the check also sees the scalar offset is not something to depend on)
       uint32_t va_h1[2] = {va[0] + d_a, va[1] + d_a}, vb_h1[2] = {vb[0] + d_b, vb[1] + d_b};
       auto issue = [&](int img, int pl, int hh, int slot, uint32_t kw) {
-        const uint32_t so = (img == 0 ? pl * ps_a : pl * ps_b) + kw + (TN ? hh * 256u : 0u);
+        const uint32_t so = (img == 0 ? pl * ps_a : pl * ps_b) + kw + (KI ? hh * 2048u : TN ? hh * 256u : 0u);
         const uint32_t dst = lds_piece + (img == 0 ? 0 : 6 * IMG) + slot * 2 * IMG + hh * IMG;
         const bool h1 = !TN && hh == 1;
         dma_s(img == 0 ? srd_a : srd_b, img == 0 ? (h1 ? va_h1[0] : va[0]) : (h1 ? vb_h1[0] : vb[0]), so, dst);
@@ -1301,7 +1320,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 }
 
 // one block of a launch: block index `bid` of this launch -> (half) tile -> run_tile
-template <bool TN, int EPI, bool S16, bool X3, bool F6, bool NTCS, bool R6, bool NARROW>
+template <bool TN, int EPI, bool S16, bool X3, bool F6, bool NTCS, bool R6, bool NARROW, bool KI = false>
 __device__ __forceinline__ void block_of_launch(const BArgs &g, int bid, unsigned char *smem) {
   int tm, tn;
   // the block -> tile map of the WHOLE tile grid, of which this launch may cover the first blocks only (grid_tiles) or,
@@ -1328,17 +1347,18 @@ __device__ __forceinline__ void block_of_launch(const BArgs &g, int bid, unsigne
   const int n_ktiles = k_end > k_begin ? (k_end - k_begin) / kTileK : 0;   // even (host)
   void *c_base = EPI == BE_F32 ? static_cast<void *>(static_cast<float *>(g.C) + (int64_t)split * g.slab_stride) : g.C;
   float *cs_row = ((TN || NTCS) && g.colsum_partial) ? g.colsum_partial + (int64_t)((split * g.tiles_m + tm) * 2) * g.N + n0 : nullptr;
-  run_tile<TN, EPI, S16, X3, F6, NTCS, R6, NARROW>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
+  run_tile<TN, EPI, S16, X3, F6, NTCS, R6, NARROW, KI>(g, tm, m0, n0, k_begin, n_ktiles, c_base, g.ldc, m0, n0, cs_row, g.N, smem);
 }
 
-template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false, bool NARROW = false>
+template <bool TN, int EPI, bool S16, bool X3 = false, bool F6 = false, bool NTCS = false, bool R6 = false, bool NARROW = false,
+          bool KI = false>
 __global__ void __launch_bounds__(kT, 1) k_gemm_bf16_256(BArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   // (round 5: ONE resident block per CU walking the launch's tiles -- no block dispatch between a CU's tiles -- was built
   // and measured: miner 0.437-0.442 against 0.429-0.430 ms, headline step 2.629-2.633 against 2.621-2.623 ms,
   // profiles/r05_persistent_tiles_ab.txt; the loop around run_tile also cost the k-strided kernel its last free VGPRs --
   // 72 B of scratch.  Removed.)
-  block_of_launch<TN, EPI, S16, X3, F6, NTCS, R6, NARROW>(g, blockIdx.x, smem);
+  block_of_launch<TN, EPI, S16, X3, F6, NTCS, R6, NARROW, KI>(g, blockIdx.x, smem);
 }
 
 // full tiles and the last round's half tiles in ONE launch (blocks [0, narrow_first): full tiles; the rest: half tiles):
@@ -1597,6 +1617,20 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
   return launch_x3_1<TN, EPI, false>(g, tiles, splits, s);
 }
 }  // namespace
+
+// the k-strided product on k8-interleaved operands (resident-plane walk, six products, whole periods per split)
+int launch_gemm_x3_tnk(const BArgs &g, int splits, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16_256<true, BE_F32, true, true, false, false, true, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_R6);
+    if (e != hipSuccess) return fail(CDML_E_HIP, "gemm_bf16x3_tnk: cannot reserve %d B of LDS: %s", SMEM_R6, hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL((k_gemm_bf16_256<true, BE_F32, true, true, false, false, true, false, true>), dim3(g.tiles_m * g.tiles_n, splits),
+                     dim3(kT), SMEM_R6, s, g);
+  return check_launch("gemm_bf16x3_tnk");
+}
 
 int launch_gemm_x3_mine(const BArgs &g, hipStream_t s) {
   return launch_x3_1<false, BE_MINE_X3, false, false, true>(g, g.tiles_m * g.tiles_n, 1, s);

@@ -486,3 +486,100 @@ extern "C" int cdml_semihard_mine_x3(const float *e, int64_t lde, const int32_t 
                      (int64_t)B, g.tiles_n * 4, B, neg_row_out);
   return check_launch("semihard_mine_x3 finish");
 }
+
+// ---- k8-interleaved operands for the weight gradients (round 5) ---------------------------------------------------------
+// A weight gradient contracts over the batch rows, so its operands -- stored row-major, one row per batch row -- are
+// k-STRIDED, and a fragment (8 consecutive k of one column) takes two transposed LDS reads (ds_read_b64_tr_b16): twice the LDS
+// instructions of the k-contiguous products per phase, and the k-strided kernel's phases are bound by their read part (MFMA
+// busy 0.76-0.79 against 0.84-0.85).  Stored [plane][row / 8][column][8 rows] the same fragment is ONE aligned 16-B read and an
+// LDS image is filled by contiguous 1-KiB pieces: cdml_gemm_bf16x3_tnk.  cdml_interleave8_bf16x3 converts row-major planes.
+namespace cdml {
+namespace {
+// dst[(p * (rows / 8) + r / 8) * cols * 8 + c * 8 + r % 8] = src[r][p * plane_src + c]; one thread per (k-group, 8-column run)
+__global__ void __launch_bounds__(kThreads)
+k_interleave8(const bf16 *__restrict__ src, int64_t ld_src, int64_t plane_src, int rows, int cols, bf16 *__restrict__ dst) {
+  using bf16x8v = __attribute__((ext_vector_type(8))) __bf16;
+  const int c8n = cols >> 3, kgs = rows >> 3;
+  const int64_t total = (int64_t)3 * kgs * c8n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % c8n);
+    const int64_t t = i / c8n;
+    const int kg = (int)(t % kgs), p = (int)(t / kgs);
+    bf16x8v in[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      in[r] = *reinterpret_cast<const bf16x8v *>(src + (int64_t)(kg * 8 + r) * ld_src + p * plane_src + c8 * 8);
+    bf16 *d = dst + ((int64_t)(p * kgs + kg) * cols + c8 * 8) * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      bf16x8v o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = in[r][c];
+      *reinterpret_cast<bf16x8v *>(d + c * 8) = o;
+    }
+  }
+}
+}  // namespace
+}  // namespace cdml
+
+// src: bf16 planes row-major [rows][ld_src], plane p at columns p * plane_src (what the gather / the epilogues write);
+// dst: bf16 [3][rows / 8][cols][8].  rows % 8 == 0, cols % 8 == 0.
+extern "C" int cdml_interleave8_bf16x3(const uint16_t *src, int64_t ld_src, int64_t plane_src, int rows, int cols,
+                                       uint16_t *dst, cdml_stream_t stream) {
+  CDML_REQUIRE(src && dst && rows > 0 && cols > 0, CDML_E_BADARG, "interleave8_bf16x3: bad argument");
+  CDML_REQUIRE(rows % 8 == 0 && cols % 8 == 0 && !(ld_src & 7) && !(plane_src & 7) && plane_src >= cols && ld_src >= 2 * plane_src + cols &&
+                   aligned16(src) && aligned16(dst), CDML_E_ALIGN,
+               "interleave8_bf16x3: rows, cols, ld_src, plane_src multiples of 8, 16-B aligned bases");
+  hipLaunchKernelGGL(k_interleave8, dim3(grid1d((int64_t)3 * (rows / 8) * (cols / 8))), dim3(kThreads), 0, (hipStream_t)stream,
+                     reinterpret_cast<const bf16 *>(src), ld_src, plane_src, rows, cols, reinterpret_cast<bf16 *>(dst));
+  return check_launch("interleave8_bf16x3");
+}
+
+// C[M][N] (fp32) = sum_k A[k][M] B[k][N] like cdml_gemm_bf16x3_tn, the operands k8-INTERLEAVED: A = bf16 [3][K / 8][ma][8]
+// with ma >= M columns per k-group (the product takes columns [a_col0, a_col0 + M)), B = bf16 [3][K / 8][nb][8] likewise.
+// Six products; M, N % 256 == 0, K % 128 == 0; same split-K, slab combine, colsum and workspace as the row-major form
+// (cdml_gemm_bf16x3_workspace(1, M, N, K, 6)); bit-identical results.
+extern "C" int cdml_gemm_bf16x3_tnk(const uint16_t *A, int ma, int a_col0, const uint16_t *B, int nb, int b_col0, int M, int N,
+                                    int K, float *C, int64_t ldc, float *colsum, void *workspace, size_t workspace_bytes,
+                                    cdml_stream_t stream) {
+  CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16x3_tnk: bad argument");
+  CDML_REQUIRE(M % 256 == 0 && N % 256 == 0 && K % 128 == 0, CDML_E_UNSUPPORTED,
+               "gemm_bf16x3_tnk: M, N must be multiples of 256 and K of 128, got M=%d N=%d K=%d", M, N, K);
+  CDML_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && !(ldc & 3) && ldc >= N && a_col0 >= 0 && b_col0 >= 0 &&
+                   a_col0 + M <= ma && b_col0 + N <= nb && !(ma & 7) && !(nb & 7),
+               CDML_E_ALIGN, "gemm_bf16x3_tnk: 16-B aligned bases, column windows inside the operands");
+  CDML_REQUIRE((int64_t)3 * (K / 8) * ma * 16 < ((int64_t)1 << 31) && (int64_t)3 * (K / 8) * nb * 16 < ((int64_t)1 << 31), CDML_E_UNSUPPORTED,
+               "gemm_bf16x3_tnk: an operand exceeds the 2 GiB buffer-descriptor range");
+  BArgs g{};
+  g.A = reinterpret_cast<const bf16 *>(A) + (int64_t)a_col0 * 8; g.lda = (int64_t)ma * 8;
+  g.B = reinterpret_cast<const bf16 *>(B) + (int64_t)b_col0 * 8; g.ldb = (int64_t)nb * 8;
+  g.M = M; g.N = N;
+  g.x3_tpp = K / 64; g.x3_plane_a = (int64_t)(K / 8) * ma * 8; g.x3_plane_b = (int64_t)(K / 8) * nb * 8;
+  g.x3_products = 6;
+  const int ktiles = 6 * g.x3_tpp;
+  g.K = ktiles * 64;
+  g.tiles_m = M / 256; g.tiles_n = N / 256;
+  int splits = gemm_bf16_256_splits(M, N, g.K), per = 0;
+  x3_split_geometry(ktiles, splits, 6, per, splits);
+  const bool slabs = splits > 1;
+  const size_t slab_bytes = slabs ? (size_t)splits * M * N * sizeof(float) : 0;
+  const size_t cs_rows = (size_t)splits * g.tiles_m * 2;
+  const size_t need = slab_bytes + (colsum ? cs_rows * N * sizeof(float) : 0);
+  CDML_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && aligned16(workspace)), CDML_E_BADARG,
+               "gemm_bf16x3_tnk: workspace of %zu bytes required (cdml_gemm_bf16x3_workspace)", need);
+  hipStream_t s = (hipStream_t)stream;
+  g.k_per_split = per * 64;
+  g.slab_stride = (int64_t)M * N;
+  g.C = slabs ? workspace : static_cast<void *>(C);
+  g.ldc = slabs ? N : ldc;
+  g.colsum_partial = colsum ? reinterpret_cast<float *>(static_cast<char *>(workspace) + slab_bytes) : nullptr;
+  int rc = launch_gemm_x3_tnk(g, splits, s);
+  if (rc) return rc;
+  if (slabs || colsum) {
+    const int sb = slabs ? grid1d((int64_t)M * N / 4) : 0, cb = colsum ? (N + 15) / 16 : 0;
+    hipLaunchKernelGGL(k_x3_sum_slabs, dim3(sb + cb), dim3(kThreads), 0, s, static_cast<const float *>(workspace), g.slab_stride,
+                       splits, M, N, static_cast<const float *>(nullptr), 0.f, C, ldc, sb, g.colsum_partial, (int)cs_rows, colsum);
+    rc = check_launch("gemm_bf16x3_tnk combine");
+  }
+  return rc;
+}

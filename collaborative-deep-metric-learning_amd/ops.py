@@ -430,6 +430,24 @@ def gemm_bf16x3_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, products=6, pla
     return C
 
 
+def interleave8_bf16x3(src, plane_src, rows, cols, dst):
+    """row-major planes [rows, >= 2 plane_src + cols] -> k8-interleaved [3, rows / 8, cols, 8] (csrc/gemm_bf16x3.hip)"""
+    sp, sld = _mat16(src)
+    if dst.dtype != torch.bfloat16 or not dst.is_contiguous() or dst.numel() < 3 * rows * cols:
+        raise ValueError("interleave8_bf16x3: dst must be a contiguous bf16 buffer of 3 * rows * cols elements")
+    call("cdml_interleave8_bf16x3", sp, sld, plane_src, rows, cols, C.c_void_p(dst.data_ptr()), _stream())
+    return dst
+
+
+def gemm_bf16x3_tnk(A, ma, a_col0, B, nb, b_col0, out, M, N, K, workspace=None, colsum=None):
+    """out[M][N] f32 = sum_k A[k][a_col0 + m] B[k][b_col0 + n] on k8-interleaved operands [3, K / 8, ma | nb, 8] (six products)."""
+    cp, cld = _mat(out)
+    ws, wb = (C.c_void_p(0), 0) if workspace is None else (C.c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size())
+    call("cdml_gemm_bf16x3_tnk", C.c_void_p(A.data_ptr()), ma, a_col0, C.c_void_p(B.data_ptr()), nb, b_col0, M, N, K, cp, cld,
+         _p(colsum, torch.float32), ws, wb, _stream())
+    return out
+
+
 def gemm_bf16x3_tn(A, plane_a, B, plane_b, C, M, N, K, products=6, workspace=None, colsum=None, bias=None,
                    alpha=LRELU_ALPHA):
     """C[M][N] f32 = sum_k A[k][M] B[k][N] for fp32 operands given as bf16 planes [K][hi | mid | lo]

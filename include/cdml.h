@@ -442,6 +442,17 @@ int cdml_adam_matrix_planes(float *w, const float *g, float *m, float *v, int K,
  * as one bit per element instead of a 2-byte value).  The narrow forward layer (N == 256) splits its contraction into
  * slabs of 60 K-tile steps when given the workspace -- a partition that depends on K alone. */
 size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int products);
+/* The weight gradients (train.py:141) on k8-INTERLEAVED operands, round 5: an operand whose contraction runs over the batch
+ * rows stored as bf16 [3 planes][rows / 8][columns][8 rows], so that a fragment of the k-strided product is one aligned
+ * 16-B LDS read instead of two transposed ones.  cdml_interleave8_bf16x3 converts row-major planes (src [rows][ld_src],
+ * plane p at columns p * plane_src; rows, cols % 8 == 0); cdml_gemm_bf16x3_tnk is cdml_gemm_bf16x3_tn on such operands
+ * (A: ma columns per row group, the product takes columns [a_col0, a_col0 + M); B likewise; six products; the same
+ * workspace, split-K, slab sum and colsum; bit-identical results). */
+int cdml_interleave8_bf16x3(const uint16_t *src, int64_t ld_src, int64_t plane_src, int rows, int cols,
+                            uint16_t *dst, cdml_stream_t stream);
+int cdml_gemm_bf16x3_tnk(const uint16_t *A, int ma, int a_col0, const uint16_t *B, int nb, int b_col0,
+                         int M, int N, int K, float *C, int64_t ldc, float *colsum, void *workspace,
+                         size_t workspace_bytes, cdml_stream_t stream);
 int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
                         int64_t ldb, int64_t plane_b, int M, int N, int K, int products, void *C,
                         int64_t ldc, int64_t plane_c, const float *bias, const uint16_t *aux,

@@ -559,3 +559,33 @@ def test_split_k_geometry_has_no_empty_split():
     want = (A.double().t() @ B.double())
     assert ((C.double() - want).abs().max() / want.abs().max()).item() < 5e-6
     assert (cs.double() - B.double().sum(0)).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,a0,b0", [(256, 512, 256, 0, 0), (512, 256, 1024, 256, 0), (256, 256, 3072, 0, 256)])
+def test_gemm_x3_tnk_equals_tn(M, N, K, a0, b0):
+    """The weight-gradient product on k8-interleaved operands ([plane][k / 8][column][8 k]: one aligned 16-B LDS read per
+    fragment instead of two transposed reads) is the k-strided product -- same images, slots, DMA schedule and accumulation
+    order: bit-identical results and column sums, also for a column window of wider operands (the data-parallel step's row
+    blocks of W1)."""
+    dev = _dev()
+    g = torch.Generator(device=dev); g.manual_seed(M + N + K)
+    ma, nb = M + a0 + 256, N + b0
+    A = torch.randn(K, ma, device=dev, generator=g) * 0.05
+    B = torch.randn(K, nb, device=dev, generator=g) * 0.02
+    A3, B3 = _planes(A, ma), _planes(B, nb)
+    Ai = torch.empty(3 * K * ma, dtype=torch.bfloat16, device=dev)
+    Bi = torch.empty(3 * K * nb, dtype=torch.bfloat16, device=dev)
+    ops.interleave8_bf16x3(A3, ma, K, ma, Ai)
+    ops.interleave8_bf16x3(B3, nb, K, nb, Bi)
+    # the interleave itself: element (plane p, row r, column c) at ((p * K/8 + r/8) * cols + c) * 8 + r % 8
+    v = Ai.view(3, K // 8, ma, 8)
+    assert torch.equal(v.permute(0, 1, 3, 2).reshape(3, K, ma)[1], A3[:, ma:2 * ma])
+    ws = _ws(True, M, N, K)
+    C1, C2 = torch.empty((M, N), device=dev), torch.full((M, N), float("nan"), device=dev)
+    cs1, cs2 = torch.empty(N, device=dev), torch.full((N,), float("nan"), device=dev)
+    ops.gemm_bf16x3_tn(A3[:, a0:], ma, B3[:, b0:], nb, C1, M, N, K, workspace=ws, colsum=cs1)
+    ops.gemm_bf16x3_tnk(Ai, ma, a0, Bi, nb, b0, C2, M, N, K, workspace=ws, colsum=cs2)
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C2) and torch.equal(cs1, cs2)
+    want = A[:, a0:a0 + M].double().t() @ B[:, b0:b0 + N].double()
+    assert ((C2.double() - want).abs().max() / want.abs().max()).item() < 5e-6
