@@ -24,7 +24,9 @@ enum { BE_BIAS_LRELU_BF16 = 0, BE_BIAS_LRELU_F32 = 1, BE_MASK_BF16 = 2, BE_F32 =
        // semi-hard negative mining (BASELINE config 2) as the epilogue of the B x 2B score product S = E_anchor . E^T:
        // nothing of S is written -- every (tile, column strip) hands back, per anchor row, its best candidates
        // (BArgs::mine_*; gemm_bf16_256.hip "mine tail", loss.hip cdml_semihard_mine_x3)
-       BE_MINE_X3 = 11 };
+       BE_MINE_X3 = 11,
+       // ABI-level id of cdml_gemm_bf16x3_nt: 10 (or 7 without a mask) with the planes of the result k8-interleaved
+       BE_MASKBITS_X3_KI = 12 };
 
 // one candidate pair of an anchor over some set of columns: the closest eligible column with d > d_p ("outside"; ties ->
 // smaller column) and the farthest eligible one; c = 0x7fffffff: none
@@ -59,6 +61,9 @@ struct BArgs {
   // that start with a half tile then run half a tile out of phase with the others for the whole launch, so the tiles'
   // plane stores (393 KB each) reach HBM in two bursts of half the chip instead of one of the whole chip (0: all last)
   int stagger_lead;
+  // plane-output epilogue BE_MASK_X3: write the planes k8-interleaved ([plane][row / 8][column][8 rows]; ldc = columns per
+  // row group, x3_plane_c = elements per plane) for the weight gradient that contracts over the rows
+  int c_kint;
   // BE_MINE_X3: A = the anchors' planes (row i = embedded row 2 i), B = every embedded row's planes, C unused.
   // mine_sqn[c] = |e_c|^2, mine_ids[c] = the video id of row c, mine_dp[i] = d(anchor i, its positive);
   // mine_out[(tn * 4 + strip) * mine_ld + i] = anchor i's candidates over the 64 columns of strip `strip` of tile column tn

@@ -1093,9 +1093,15 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     // sign bitmask), a store's address is a wave-uniform base (SGPRs, scalar adds) plus one 32-bit lane offset that never
     // changes, the bias / leaky-relu / residual arithmetic is written on float pairs (v_pk_*), a sign bit costs a compare
     // and an add-with-carry, a bit-masked element a bit-field extract and a bit-field insert.
-    auto tail16 = [&](auto mm_c, auto wb_c) {
+    // KO (plane outputs only; round 5): the planes are written k8-INTERLEAVED -- [plane][row / 8][column][8 rows], c_ld =
+    // columns per row group -- for a consumer that contracts over the rows (the weight gradient reads the data gradient this
+    // way: one 16-B LDS read per fragment).  The masked / activated values go back into the strip they came from, and a
+    // second pass reads it by COLUMNS: lane = column, eight rows per 16-B store, 64 lanes x 16 B contiguous per plane.
+    auto tail16 = [&](auto mm_c, auto wb_c, auto ko_c) {
       constexpr int MM = decltype(mm_c)::value;
       constexpr bool WB = decltype(wb_c)::value;
+      constexpr bool KO = decltype(ko_c)::value;
+      static_assert(!KO || (kPlanes && S16 && !WB), "interleaved plane output: a plane epilogue of the 16x16x32 form");
       constexpr int GR = NARROW ? 64 : 128, RT = GR / 32;     // rows per row group (half tile: 64), 32-row strips of it
       const int lrow = lane >> 3;                                  // the lane's row inside an 8-row store
       const int rows_left = g.M - m0 - grp * GR - lrow;          // rows rt*32 + p*8 + lrow < ... are inside the matrix
@@ -1185,6 +1191,11 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 #pragma unroll
             for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j]));
           }
+          if constexpr (KO) {                                 // back where they came from; the column pass below stores them
+            *reinterpret_cast<f32x4 *>(strip + lr * 64 + ((c8 * 8) ^ sw)) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4 *>(strip + lr * 64 + ((c8 * 8 + 4) ^ sw)) = f32x4{v[4], v[5], v[6], v[7]};
+            continue;
+          }
           // a pair of values -> one dword of two bf16 (v_cvt_pk_bf16_f32), and back by a shift / a mask (written out: hipcc
           // converted every element a second time on its own to get its rounded value back -- 256 extra conversions per wave)
           u32x4 o;
@@ -1220,16 +1231,54 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
             }
           }
         }
+        if constexpr (KO) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          // rows (c_row0 + grp GR + rt 32 + rg 8 .. + 7) of column c_col0 + wc 64 + lane: element (r, c, plane) of the output at
+          // plane * x3_plane_c + ((r / 8) * c_ld + c) * 8 + r % 8
+          char *const kb = static_cast<char *>(c_base) + ((int64_t)((c_row0 + grp * GR + rt * 32) >> 3) * c_ld + c_col0 + wc * 64 + lane) * 16;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = strip[(rg * 8 + j) * 64 + (lane ^ ((j >> 2) << 4))];
+            if (m0 + grp * GR + rt * 32 + rg * 8 >= g.M) continue;          // (M is a multiple of 8: a row group is inside or outside)
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = pack2(v[2 * k], v[2 * k + 1]);
+            char *const dstp = kb + (int64_t)rg * c_ld * 16;
+            *reinterpret_cast<u32x4 *>(dstp) = o;
+#pragma unroll
+            for (int pl = 1; pl < 3; ++pl) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const f32x2 r = f32x2{v[2 * k], v[2 * k + 1]} - f32x2{lo_of(o[k]), hi_of(o[k])};
+                v[2 * k] = r.x;
+                v[2 * k + 1] = r.y;
+                o[k] = pack2(r.x, r.y);
+              }
+              *reinterpret_cast<u32x4 *>(dstp + (size_t)pl * plane_bytes) = o;
+            }
+          }
+        }
       }
     };
     using std::integral_constant;
+    using no_t = integral_constant<bool, false>;
     if constexpr (kMaskEpi) {
-      if (!has_aux) tail16(integral_constant<int, 0>{}, integral_constant<bool, false>{});
-      else if (X3 && g.aux_bits) tail16(integral_constant<int, X3 ? 2 : 1>{}, integral_constant<bool, false>{});
-      else tail16(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+      if constexpr (X3 && S16 && EPI == BE_MASK_X3) {
+        if (g.c_kint) {                                       // (host: the bitmask form or no mask)
+          if (has_aux) tail16(integral_constant<int, 2>{}, no_t{}, integral_constant<bool, true>{});
+          else tail16(integral_constant<int, 0>{}, no_t{}, integral_constant<bool, true>{});
+          return;
+        }
+      }
+      if (!has_aux) tail16(integral_constant<int, 0>{}, no_t{}, no_t{});
+      else if (X3 && g.aux_bits) tail16(integral_constant<int, X3 ? 2 : 1>{}, no_t{}, no_t{});
+      else tail16(integral_constant<int, 1>{}, no_t{}, no_t{});
     } else {
-      if (g.mask_out) tail16(integral_constant<int, 0>{}, integral_constant<bool, true>{});
-      else tail16(integral_constant<int, 0>{}, integral_constant<bool, false>{});
+      if (g.mask_out) tail16(integral_constant<int, 0>{}, integral_constant<bool, true>{}, no_t{});
+      else tail16(integral_constant<int, 0>{}, no_t{}, no_t{});
     }
     return;
   }

@@ -225,12 +225,13 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
                                    int64_t ldaux, float alpha, float *colsum, void *workspace,
                                    size_t workspace_bytes, cdml_stream_t stream) {
   CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16x3_nt: bad argument");
-  const bool bits_out = epilogue == BE_BIAS_LRELU_X3_BITS, bits_in = epilogue == BE_MASKBITS_X3;
+  const bool kint_out = epilogue == BE_MASKBITS_X3_KI;      // 12 = 10 with the result's planes k8-interleaved
+  const bool bits_out = epilogue == BE_BIAS_LRELU_X3_BITS, bits_in = epilogue == BE_MASKBITS_X3 || (kint_out && aux);
   if (bits_out) epilogue = BE_BIAS_LRELU_X3;
-  if (bits_in) epilogue = BE_MASK_X3;
+  if (bits_in || kint_out) epilogue = BE_MASK_X3;
   CDML_REQUIRE(epilogue == BE_BIAS_LRELU_F32 || epilogue == BE_F32 || epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3 ||
                    epilogue == BE_ROWBIAS_LRELU_X3,
-               CDML_E_BADARG, "gemm_bf16x3_nt: epilogue must be 1, 3, 6, 7, 8, 9 or 10");
+               CDML_E_BADARG, "gemm_bf16x3_nt: epilogue must be 1, 3, 6, 7, 8, 9, 10 or 12");
   CDML_REQUIRE(!(bits_out || bits_in) || (aux && N % 8 == 0 && ldaux >= N / 8), CDML_E_BADARG,
                "gemm_bf16x3_nt: epilogues 9 / 10 need the bitmask in aux (ldaux >= N / 8 bytes)");
   CDML_REQUIRE(products == 3 || products == 6, CDML_E_BADARG, "gemm_bf16x3_nt: products must be 3 or 6");
@@ -240,8 +241,11 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
                    plane_a >= K && plane_b >= K && lda >= 2 * plane_a + K && ldb >= 2 * plane_b + K,
                CDML_E_ALIGN, "gemm_bf16x3_nt: 16-B aligned bases, strides multiples of 8, ld >= 2 plane + K");
   const bool planes_out = epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3 || epilogue == BE_ROWBIAS_LRELU_X3;
-  CDML_REQUIRE(planes_out ? (!(ldc & 7) && !(plane_c & 7) && plane_c >= N && ldc >= 2 * plane_c + N) : (!(ldc & 3) && ldc >= N),
-               CDML_E_ALIGN, "gemm_bf16x3_nt: ldc (plane outputs: ldc and plane_c multiples of 8, ldc >= 2 plane_c + N)");
+  CDML_REQUIRE(kint_out ? (M % 8 == 0 && !(ldc & 7) && ldc >= N && plane_c >= (int64_t)(M / 8) * ldc * 8 &&
+                           (int64_t)3 * plane_c * 2 < ((int64_t)1 << 32))
+                        : planes_out ? (!(ldc & 7) && !(plane_c & 7) && plane_c >= N && ldc >= 2 * plane_c + N) : (!(ldc & 3) && ldc >= N),
+               CDML_E_ALIGN, "gemm_bf16x3_nt: ldc (plane outputs: ldc and plane_c multiples of 8, ldc >= 2 plane_c + N; epilogue 12: M a "
+               "multiple of 8, ldc = columns per row group >= N, plane_c >= M ldc)");
   CDML_REQUIRE(epilogue != BE_MASK_X3 || !aux || bits_in || (aligned16(aux) && !(ldaux & 7) && ldaux >= N), CDML_E_ALIGN,
                "gemm_bf16x3_nt: aux must be 16-B aligned with ldaux a multiple of 8");
   CDML_REQUIRE((epilogue != BE_BIAS_LRELU_F32 && epilogue != BE_BIAS_LRELU_X3 && epilogue != BE_ROWBIAS_LRELU_X3) || bias,
@@ -257,6 +261,7 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   g.aux = reinterpret_cast<const bf16 *>(aux); g.ldaux = ldaux;
   if (bits_out) { g.mask_out = reinterpret_cast<uint8_t *>(const_cast<uint16_t *>(aux)); g.ldmask = ldaux; g.aux = nullptr; g.ldaux = 0; }
   g.aux_bits = bits_in ? 1 : 0;
+  g.c_kint = kint_out ? 1 : 0;
   g.M = M; g.N = N;
   g.x3_tpp = K / 64; g.x3_plane_a = plane_a; g.x3_plane_b = plane_b; g.x3_plane_c = plane_c;
   g.x3_products = x3_kmajor() ? products : 0;

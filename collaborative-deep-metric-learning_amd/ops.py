@@ -400,6 +400,7 @@ def gemm_bf16_tn(A, B, C, M, N, K, workspace=None, colsum=None):
 # ---- fp32 products on the bf16 MFMA: operands as three bf16 planes (csrc/gemm_bf16x3.hip) ----
 BE_BIAS_LRELU_X3, BE_MASK_X3, BE_ROWBIAS_LRELU_X3 = 6, 7, 8
 BE_BIAS_LRELU_X3_BITS, BE_MASKBITS_X3 = 9, 10         # 6 + sign bitmask out (aux, uint8 [M][N / 8]) / 7 reading that bitmask
+BE_MASKBITS_X3_KI = 12                                # 10 (7 without aux) with the result's planes k8-interleaved: [3][M / 8][ldc][8]
 
 
 def split_f32_bf16x3(src, dst, plane, transpose=False):
@@ -415,16 +416,20 @@ def gemm_bf16x3_workspace(tn, M, N, K, products=6):
 
 
 def gemm_bf16x3_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, products=6, plane_c=0, bias=None, aux=None,
-                   alpha=LRELU_ALPHA, workspace=None, colsum=None):
+                   alpha=LRELU_ALPHA, workspace=None, colsum=None, ldc=None):
     """C = epilogue(A . B^T) for fp32 operands given as bf16 planes [rows][hi K | mid K | lo K]; colsum[n] = sum_k
-    B[n][k] on request."""
+    B[n][k] on request.  Epilogue 12: C is the flat k8-interleaved buffer [3][M / 8][ldc][8] (``ldc`` = columns per row
+    group, ``plane_c`` = elements per plane)."""
     ap, ald = _mat16(A)
     bp, bld = _mat16(B)
-    if C.dim() != 2 or C.stride(1) != 1:
+    if epilogue == BE_MASKBITS_X3_KI:
+        if ldc is None or not C.is_contiguous() or C.dtype != torch.bfloat16:
+            raise ValueError("epilogue 12 writes a contiguous bf16 buffer and needs ldc (columns per row group)")
+    elif C.dim() != 2 or C.stride(1) != 1:
         raise ValueError("C must be 2-D with unit inner stride")
-    if aux is not None and (aux.dtype == torch.uint8) != (epilogue in (BE_BIAS_LRELU_X3_BITS, BE_MASKBITS_X3)):
-        raise ValueError("epilogues 9 / 10 take a uint8 bitmask as aux, epilogue 7 bf16 values")
-    call("cdml_gemm_bf16x3_nt", epilogue, ap, ald, plane_a, bp, bld, plane_b, M, N, K, products, _p(C), C.stride(0),
+    if aux is not None and (aux.dtype == torch.uint8) != (epilogue in (BE_BIAS_LRELU_X3_BITS, BE_MASKBITS_X3, BE_MASKBITS_X3_KI)):
+        raise ValueError("epilogues 9 / 10 / 12 take a uint8 bitmask as aux, epilogue 7 bf16 values")
+    call("cdml_gemm_bf16x3_nt", epilogue, ap, ald, plane_a, bp, bld, plane_b, M, N, K, products, _p(C), C.stride(0) if ldc is None else ldc,
          plane_c, _p(bias), _p(aux), aux.stride(0) if aux is not None else 0, alpha, _p(colsum, torch.float32),
          _p(workspace), 0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())
     return C

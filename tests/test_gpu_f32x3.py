@@ -589,3 +589,28 @@ def test_gemm_x3_tnk_equals_tn(M, N, K, a0, b0):
     assert torch.equal(C1, C2) and torch.equal(cs1, cs2)
     want = A[:, a0:a0 + M].double().t() @ B[:, b0:b0 + N].double()
     assert ((C2.double() - want).abs().max() / want.abs().max()).item() < 5e-6
+
+
+@pytest.mark.parametrize("M,N", [(640, 512), (6144, 4096)])
+def test_data_gradient_epilogue_writes_interleaved_planes(M, N):
+    """Epilogue 12 of cdml_gemm_bf16x3_nt = epilogue 10 (times leaky-relu' from the sign bitmask) -- or 7 without a mask --
+    with the result's planes written k8-interleaved ([plane][row / 8][column][8 rows]) for the weight gradient that
+    contracts over the rows: the same values, bit for bit, as interleaving the row-major result.  6144 x 4096: 384 tiles =
+    one round of full tiles + 128 tiles as 256 half tiles (the NARROW form of the same epilogue); 640 rows: a last row
+    tile of 128."""
+    dev = _dev()
+    K = 256
+    g = torch.Generator(device=dev); g.manual_seed(M + N)
+    A3 = _planes(torch.randn(M, K, device=dev, generator=g) * 0.1, K)
+    B3 = _planes(torch.randn(N, K, device=dev, generator=g) * 0.1, K)
+    bits = torch.randint(0, 256, (M, N // 8), device=dev, generator=g, dtype=torch.uint8)
+    for aux in (bits, None):
+        rowmajor = torch.zeros((M, 3 * N), dtype=torch.bfloat16, device=dev)
+        ops.gemm_bf16x3_nt(ops.BE_MASKBITS_X3 if aux is not None else ops.BE_MASK_X3, A3, K, B3, K, rowmajor, M, N, K, plane_c=N,
+                           aux=aux, alpha=0.2)
+        want = torch.empty(3 * M * N, dtype=torch.bfloat16, device=dev)
+        ops.interleave8_bf16x3(rowmajor, N, M, N, want)
+        got = torch.full((3 * M * N,), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm_bf16x3_nt(ops.BE_MASKBITS_X3_KI, A3, K, B3, K, got, M, N, K, plane_c=M * N, aux=aux, alpha=0.2, ldc=N)
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
