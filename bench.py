@@ -496,8 +496,11 @@ def gather_record(ts, mode, bf16, dev, pmc_name=None, workload=None):
     gk = "k_sample_gather<%d," % (1 if rpt == 2 else 0)       # <mode, RowF32<6>> / <mode, RowF16<3>>
     gbytes = n_st * R * F * (2 + 2.0) if bf16 else n_st * 2.0 * R * F * 4     # rows read + normalised rows written
     x3 = (not bf16) and ts.ws.x_hat.dtype == torch.bfloat16
+    ki = x3 and getattr(ts.ws, "xk", None) is not None
     if x3:
-        gbytes = n_st * R * F * (4 + 6.0)                                     # fp32 rows read, three bf16 planes written
+        # fp32 rows read, three bf16 planes written -- twice where the launch also writes the k8-interleaved copy the
+        # first layer's weight gradient reads (round 5)
+        gbytes = n_st * R * F * (4 + (12.0 if ki else 6.0))
         gk = "k_sample_gather<%d, RowF32X3" % (1 if rpt == 2 else 0)
     nxt = [ts.global_step + 1000]                   # fresh steps every launch: re-reading the same rows
                                                     # would be served from the 256 MB Infinity Cache
@@ -507,7 +510,7 @@ def gather_record(ts, mode, bf16, dev, pmc_name=None, workload=None):
             ts._gather_block(nxt[0])
         else:
             ops.sample_gather(m, ts.pairs, ts.seed, nxt[0], B, ts.table.data, F, ts.idx, ts.ws.x_hat,
-                              shift_out=ts.shift)
+                              shift_out=ts.shift, x_ki=ts.ws.xk if ki else None)
         nxt[0] += n_st
     for _ in range(3):
         launch()
@@ -524,7 +527,7 @@ def gather_record(ts, mode, bf16, dev, pmc_name=None, workload=None):
     g_ach = gbytes / (t_g * 1e-3) / 1e9
     tr, src = (pmc_traffic("k_sample_gather<%d," % (1 if rpt == 2 else 0), name=pmc_name or "latest_pmc_x3", workload=workload) if x3
                else pmc_traffic(gk, bf16, name=pmc_name, workload=workload))
-    return {"bound": "hbm", "kernel": gk + ("<6>>" if x3 else " RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1),
+    return {"bound": "hbm", "kernel": gk + ("<6>, true> (row-major planes + the k8-interleaved copy)" if ki else "<6>>" if x3 else " RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": tr,
             "traffic_source": src, "bytes_per_launch": gbytes, "launch_ms": round(t_g, 4), "steps_per_launch": n_st,
             "method": "%d back-to-back launches per event pair (inter-launch gaps included), median of %d" % (per, reps)}

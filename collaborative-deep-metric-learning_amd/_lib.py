@@ -114,6 +114,8 @@ SIGNATURES = {
     "cdml_gemm_bf16_tn": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _sz, _p]),
     "cdml_sample_gather_x3": (_i, [_i, _p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _i64, _i64, _i,
                                    _p, _p, _p, _i64, _i, _i64, _i64, _p, _p]),
+    "cdml_sample_gather_x3k": (_i, [_i, _p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _i64, _i64, _i,
+                                    _p, _p, _p, _i64, _i, _i64, _i64, _p, _p, _i64, _p]),
     "cdml_split_f32_bf16x3": (_i, [_p, _i64, _i, _i, _p, _i64, _i64, _i, _p]),
     "cdml_gemm_bf16x3_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "cdml_gemm_bf16x3_nt": (_i, [_i, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _p, _i64, _i64, _p, _p, _i64, _f,

@@ -275,6 +275,28 @@ struct RowF32X3 {
   using Regs = RowRegs<NCH>;
   static constexpr int kPerChunk = 4;
   static constexpr int kRows = kRowsPerWave;
+  // The k8-interleaved copy (round 5; k_sample_gather's x_ki): after finish() the registers hold the row with its pad
+  // masked; the planes of chunk c are recomputed from the SAME rounded products (same expression, no contraction).
+  __device__ static __forceinline__ float inv_norm(const Regs &R) {
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      ss += R.v[c].x * R.v[c].x + R.v[c].y * R.v[c].y + R.v[c].z * R.v[c].z + R.v[c].w * R.v[c].w;
+    ss = wave_sum(ss);
+    return 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+  }
+  template <typename V4>
+  __device__ static __forceinline__ void chunk_planes(const Regs &R, int c, float inv, V4 (&o)[3]) {
+#pragma clang fp contract(off)
+    float r[4] = {R.v[c].x * inv, R.v[c].y * inv, R.v[c].z * inv, R.v[c].w * inv};
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        o[pl][u] = (__bf16)r[u];
+        r[u] -= (float)o[pl][u];
+      }
+  }
   __device__ static __forceinline__ void issue(Regs &R, const In *table, int64_t lr, int64_t stride, int F, int lane) {
     row_issue<NCH>(R, table, lr, stride, (F + 3) >> 2, lane);
   }
@@ -392,7 +414,13 @@ struct RowF16 {
   }
 };
 
-template <int MODE, typename ROW>
+// KI (RowF32X3 only; round 5): the chunk's 8 rows = ONE row group of the k8-interleaved copy x_ki -- per step
+// [3 planes][rows_per_step / 8][plane columns][8 rows] bf16, what the weight gradient's k-strided product reads with one
+// 16-B LDS read per fragment (gemm_bf16_256.hip, KI).  After the row-major planes are stored the block walks the plane in
+// slices of 256 columns: every wave drops its two rows' planes of the slice into 12 KiB of LDS as [plane][row][column]
+// (8-B writes), then 192 threads each read one 4-column group of all 8 rows (8-B reads), transpose 8 x 4 in registers and
+// store 4 x 16 B = 64 contiguous bytes of x_ki.
+template <int MODE, typename ROW, bool KI = false>
 __global__ void __launch_bounds__(kThreads)
 k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t seed,
                 uint64_t step_imm, const uint64_t *__restrict__ step_dev, int batch,
@@ -400,10 +428,12 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
                 int64_t n_rows, int64_t row_stride, int F, int32_t *__restrict__ idx_out,
                 int32_t *__restrict__ shift_out, typename ROW::Out *__restrict__ x_out, int64_t out_stride,
                 int n_steps, int64_t x_step_stride, int64_t idx_step_stride,
-                int32_t *__restrict__ oob_flag) {
+                int32_t *__restrict__ oob_flag, __bf16 *__restrict__ x_ki = nullptr, int64_t ki_step_stride = 0) {
   constexpr int RPT = (MODE == 0) ? 3 : 2;  // rows per triplet
   constexpr int kRPW = ROW::kRows, kCR = kRPW * kWavesPerBlock;   // rows per wave / per chunk
   __shared__ int32_t s_id[2][kCR];
+  __shared__ __attribute__((aligned(16))) __bf16 s_il[KI ? 3 : 1][KI ? 8 : 1][KI ? 256 : 4];
+  static_assert(!KI || kCR == 8, "the interleaved copy takes a chunk of 8 rows = one row group");
   const uint64_t step0 = step_imm + (step_dev ? *step_dev : 0);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -459,6 +489,51 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
       if (g < total_rows) {
         const int64_t s = g / rows_per_step, r = g - s * rows_per_step;
         ROW::finish(R[u], F, x_out + s * x_step_stride + r * out_stride, out_stride, lane);
+      }
+    }
+    if constexpr (KI) {
+      using bf16x4v = __attribute__((ext_vector_type(4))) __bf16;
+      using u32x2v = __attribute__((ext_vector_type(2))) uint32_t;
+      using u32x4v = __attribute__((ext_vector_type(4))) uint32_t;
+      // (host: rows_per_step % 8 == 0, so the chunk's 8 rows are whole, of one step, and one row group of it)
+      const int64_t gc = c * kCR;
+      const int64_t sidx = gc / rows_per_step;
+      const int64_t kg = (gc - sidx * rows_per_step) >> 3, kgs = rows_per_step >> 3;
+      const int plane = (int)(out_stride / 3);
+      float inv[kRPW];
+#pragma unroll
+      for (int u = 0; u < kRPW; ++u) inv[u] = ROW::inv_norm(R[u]);      // (R[u] is masked by finish(): the same sum, the same bits)
+      __bf16 *const kbase = x_ki + sidx * ki_step_stride;
+      constexpr int kSlices = (int)(sizeof(R[0].v) / sizeof(R[0].v[0]));   // the row registers: NCH chunks of 256 columns
+#pragma unroll
+      for (int sl = 0; sl < kSlices; ++sl) {                            // chunk sl of the row registers = columns 256 sl .. + 255
+        if (sl * 256 >= plane) break;                                  // (uniform)
+#pragma unroll
+        for (int u = 0; u < kRPW; ++u) {
+          bf16x4v o[3];
+          ROW::chunk_planes(R[u], sl, inv[u], o);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x4v *>(&s_il[pl][wave * kRPW + u][4 * lane]) = o[pl];
+        }
+        __syncthreads();
+        if (threadIdx.x < 192) {
+          const int pl = threadIdx.x >> 6, fg = threadIdx.x & 63;
+          u32x2v in[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) in[j] = *reinterpret_cast<const u32x2v *>(&s_il[pl][j][4 * fg]);
+          __bf16 *dstp = kbase + (((int64_t)pl * kgs + kg) * plane + sl * 256 + 4 * fg) * 8;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            u32x4v o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const uint32_t a = in[2 * k][e >> 1], b = in[2 * k + 1][e >> 1];
+              o[k] = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+            }
+            *reinterpret_cast<u32x4v *>(dstp + e * 8) = o;
+          }
+        }
+        __syncthreads();
       }
     }
     __syncthreads();                               // ids of the next chunk are staged; this buffer is free
@@ -680,12 +755,13 @@ extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pair
 
 // The fused sampler + gather writing each row as three bf16 planes (precision "f32x3"): x_out = bf16
 // [rows][out_stride], out_stride = 3 planes of out_stride / 3 >= F columns each (a multiple of 4).
-extern "C" int cdml_sample_gather_x3(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
-                                     uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
-                                     int64_t batch_global, const float *table, int64_t n_rows,
-                                     int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
-                                     uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
-                                     int64_t idx_step_stride, int32_t *oob_flag, cdml_stream_t stream) {
+static int sample_gather_x3_impl(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                                 uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
+                                 int64_t batch_global, const float *table, int64_t n_rows,
+                                 int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
+                                 uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
+                                 int64_t idx_step_stride, int32_t *oob_flag, uint16_t *x_ki, int64_t ki_step_stride,
+                                 cdml_stream_t stream) {
   CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "sample_gather_x3: mode must be 0 or 1");
   CDML_REQUIRE(n_steps >= 1 && n_steps <= 64, CDML_E_BADARG, "sample_gather_x3: n_steps must be in [1, 64]");
   const int rpt = mode == 0 ? 3 : 2;
@@ -704,18 +780,59 @@ extern "C" int cdml_sample_gather_x3(int mode, const int32_t *pairs, int64_t n_p
                CDML_E_ALIGN, "sample_gather_x3: out_stride must be 3 planes of >= F columns (multiples of 4)");
   const int grid = grid_for((int64_t)batch * rpt * n_steps, RowF32X3<6>::kRows * kWavesPerBlock);
   const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
-#define CDML_LAUNCH_SGX(M, N)                                                                              \
-  hipLaunchKernelGGL((k_sample_gather<M, RowF32X3<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
+  const int plane = (int)(out_stride / 3);
+  if (x_ki) {
+    // the interleaved copy: [3][rows_per_step / 8][plane][8] per step; whole row groups per step, plane in 256-column slices
+    // that the row registers cover (NCH x 256 columns)
+    CDML_REQUIRE(((int64_t)batch * rpt) % 8 == 0 && plane % 256 == 0 && plane <= (nch <= 6 ? 6 : 8) * 256 && aligned16(x_ki) &&
+                     (n_steps == 1 || ki_step_stride >= (int64_t)3 * batch * rpt * plane) && RowF32X3<6>::kRows * kWavesPerBlock == 8,
+                 CDML_E_UNSUPPORTED, "sample_gather_x3k: needs 8 | rows per step, plane columns a multiple of 256 (<= %d), 16-B aligned x_ki",
+                 (nch <= 6 ? 6 : 8) * 256);
+  }
+#define CDML_LAUNCH_SGX(M, N, KI)                                                                              \
+  hipLaunchKernelGGL((k_sample_gather<M, RowF32X3<N>, KI>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
                      pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global, table,               \
                      n_rows, row_stride, F, idx_out, shift_out, reinterpret_cast<__bf16 *>(x_out_planes),   \
-                     out_stride, n_steps, x_step_stride, idx_step_stride, oob_flag)
-  if (mode == 0) {
-    if (nch <= 6) CDML_LAUNCH_SGX(0, 6); else CDML_LAUNCH_SGX(0, 8);
+                     out_stride, n_steps, x_step_stride, idx_step_stride, oob_flag, reinterpret_cast<__bf16 *>(x_ki), ki_step_stride)
+  if (x_ki) {
+    if (mode == 0) {
+      if (nch <= 6) CDML_LAUNCH_SGX(0, 6, true); else CDML_LAUNCH_SGX(0, 8, true);
+    } else {
+      if (nch <= 6) CDML_LAUNCH_SGX(1, 6, true); else CDML_LAUNCH_SGX(1, 8, true);
+    }
+  } else if (mode == 0) {
+    if (nch <= 6) CDML_LAUNCH_SGX(0, 6, false); else CDML_LAUNCH_SGX(0, 8, false);
   } else {
-    if (nch <= 6) CDML_LAUNCH_SGX(1, 6); else CDML_LAUNCH_SGX(1, 8);
+    if (nch <= 6) CDML_LAUNCH_SGX(1, 6, false); else CDML_LAUNCH_SGX(1, 8, false);
   }
 #undef CDML_LAUNCH_SGX
   return check_launch("sample_gather_x3");
+}
+
+extern "C" int cdml_sample_gather_x3(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                                     uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
+                                     int64_t batch_global, const float *table, int64_t n_rows,
+                                     int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
+                                     uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
+                                     int64_t idx_step_stride, int32_t *oob_flag, cdml_stream_t stream) {
+  return sample_gather_x3_impl(mode, pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global, table, n_rows, row_stride, F,
+                               idx_out, shift_out, x_out_planes, out_stride, n_steps, x_step_stride, idx_step_stride, oob_flag,
+                               nullptr, 0, stream);
+}
+
+// cdml_sample_gather_x3 that ALSO writes every step's rows k8-interleaved (x_ki: bf16 [3][rows per step / 8][out_stride / 3][8]
+// per step, steps ki_step_stride elements apart): the operand layout of cdml_gemm_bf16x3_tnk
+extern "C" int cdml_sample_gather_x3k(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                                      uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
+                                      int64_t batch_global, const float *table, int64_t n_rows,
+                                      int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
+                                      uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
+                                      int64_t idx_step_stride, int32_t *oob_flag, uint16_t *x_ki, int64_t ki_step_stride,
+                                      cdml_stream_t stream) {
+  CDML_REQUIRE(x_ki, CDML_E_BADARG, "sample_gather_x3k: x_ki required (cdml_sample_gather_x3 without it)");
+  return sample_gather_x3_impl(mode, pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global, table, n_rows, row_stride, F,
+                               idx_out, shift_out, x_out_planes, out_stride, n_steps, x_step_stride, idx_step_stride, oob_flag,
+                               x_ki, ki_step_stride, stream);
 }
 
 extern "C" int cdml_route_rows(const int32_t *ids, int n, int64_t rows_per_shard, int world, int capacity,

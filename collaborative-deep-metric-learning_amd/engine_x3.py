@@ -36,14 +36,22 @@ def layout_x3(feature_size, hidden=5000, output_size=256):
 
 class TowerWorkspaceX3:
     def __init__(self, layout, n_rows, device, products=6, planes_in=True, backward=True, transposed=None,
-                 fc2_single_pass=False):
+                 fc2_single_pass=False, kint=None):
         """planes_in: ``x_hat`` IS the plane buffer (the fused sampler + gather writes planes); False: ``x_hat`` is
         fp32 (rows arriving through the exchange) and the forward pass splits it.
         fc2_single_pass: the narrow second layer normally splits its contraction into slabs whose partition depends on
         K alone, so an embedding has the same bits whatever batch or chunk it was computed in (whole batch or row
         blocks, 10 000-row evaluation chunks or 65 536-row inference chunks).  True = the explicit opt-out for forward-only
         workspaces of >= 192 row tiles: ONE pass over K, no slab round trip (about 5 % of an inference chunk), last bits
-        that differ from the slab form's."""
+        that differ from the slab form's.
+        kint (training, six products, planes_in; default on, CDML_X3_KI=0 turns it off): the first layer's weight gradient
+        contracts over the batch rows, so its operands -- x_hat and dz1 -- are k-STRIDED in their row-major form and every
+        fragment costs two transposed LDS reads.  With kint they are ALSO (x_hat: the fused gather writes a second copy,
+        ``xk``) or ONLY (dz1: the data gradient's epilogue writes ``dz1k`` instead of ``dz1``) held k8-interleaved --
+        [plane][row / 8][column][8 rows] -- and dW1 runs on cdml_gemm_bf16x3_tnk: one aligned 16-B LDS read per fragment, the
+        same images, DMA schedule, accumulation order and BITS (tests/test_gpu_f32x3.py), 10-12 % faster
+        (profiles/r05_tnk_probe.txt).  ``xk`` is set by the owner of the gather buffers (TrainStep); without it the backward
+        pass falls back to the row-major product."""
         L, R = layout, int(n_rows)
         if R % 128:
             raise ValueError("precision 'f32x3' needs a row count that is a multiple of 128 (got %d)" % R)
@@ -68,6 +76,11 @@ class TowerWorkspaceX3:
         if transposed and (R % 256 or not backward):
             raise ValueError("the transposed activation layout needs a training workspace with rows % 256 == 0")
         self.transposed = bool(transposed)
+        maskbits = backward and not self.transposed and os.environ.get("CDML_X3_MASKBITS", "1") != "0"
+        if kint is None:
+            kint = os.environ.get("CDML_X3_KI", "1") != "0" and planes_in
+        self.kint = bool(kint) and maskbits and products == 6 and R % 8 == 0
+        self.xk = None                                       # [3 * R * Fp] bf16, k8-interleaved x_hat (the gather's second output)
         self.x3 = bf(R, 3 * L.Fp)
         self.x_hat = self.x3 if planes_in else f32(R, L.Fp)    # the gather's output (l2-normalised rows)
         self.h1 = bf(L.Hp, 3 * R) if self.transposed else bf(R, 3 * L.Hp)
@@ -84,10 +97,11 @@ class TowerWorkspaceX3:
         # h1's hi plane -- that read sat in its store-bound epilogue and cost 30 us of its 151 (profiles/r04_stagger_and_
         # fc1_rounds.txt, item 3).  CDML_X3_MASKBITS=0 for the value mask (A/B runs); the transposed layout keeps it.
         self.h1_bits = None
-        if backward and not self.transposed and os.environ.get("CDML_X3_MASKBITS", "1") != "0":
+        if maskbits:
             self.h1_bits = torch.zeros((R, L.Hp // 8), dtype=torch.uint8, device=device)
         if backward:                                       # (catalogue inference: forward buffers only)
-            self.dz1 = bf(L.Hp, 3 * R) if self.transposed else bf(R, 3 * L.Hp)
+            self.dz1 = bf(L.Hp, 3 * R) if self.transposed else (None if self.kint else bf(R, 3 * L.Hp))
+            self.dz1k = torch.zeros(3 * R * L.Hp, dtype=torch.bfloat16, device=device) if self.kint else None
             self.de, self.dz2 = f32(R, L.Dp), f32(R, L.Dp)
             self.dz2_3 = bf(R, 3 * L.Dp)
             nb = max(nb, ops.gemm_bf16x3_workspace(True, L.Fp, L.Hp, R, q), ops.gemm_bf16x3_workspace(True, L.Hp, L.Dp, R, q))
@@ -114,6 +128,9 @@ class TowerWorkspaceX3:
         """the hidden layer's pre-activation gradient as one fp32 tensor [R, Hp]"""
         if self.transposed:
             return self._sum_planes(self.dz1, self.R).t().contiguous()
+        if self.dz1 is None:                               # k8-interleaved: [3][R / 8][Hp][8]
+            v = self.dz1k.view(3, self.R // 8, self.layout.Hp, 8).permute(0, 1, 3, 2).reshape(3, self.R, self.layout.Hp)
+            return v[0].float() + v[1].float() + v[2].float()
         return self._sum_planes(self.dz1, self.layout.Hp)
 
     def h1_f32(self):
@@ -190,7 +207,14 @@ def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
         for pl in range(3):                                                       # the gathered planes, transposed
             ops.transpose_to_bf16(ws.x3[:, pl * L.Fp:(pl + 1) * L.Fp], ws.xT[:, pl * R:(pl + 1) * R], R, L.Fp)
     else:
-        if getattr(ws, "h1_bits", None) is not None:
+        kint = getattr(ws, "kint", False) and ws.xk is not None and getattr(ws, "h1_bits", None) is not None
+        if getattr(ws, "kint", False) and not kint:
+            raise RuntimeError("this workspace holds dz1 k8-interleaved only: it needs the gather's interleaved x_hat (ws.xk) and "
+                               "the sign bitmask of h1 (CDML_X3_MASKBITS); build it with kint=False otherwise")
+        if kint:      # dz1 written k8-interleaved by the epilogue: the only form the first layer's weight gradient reads
+            ops.gemm_bf16x3_nt(ops.BE_MASKBITS_X3_KI, ws.dz2_3, L.Dp, ws.W2, L.Dp, ws.dz1k, R, L.Hp, L.Dp, products=q,
+                               plane_c=R * L.Hp, aux=ws.h1_bits, ldc=L.Hp)
+        elif getattr(ws, "h1_bits", None) is not None:
             ops.gemm_bf16x3_nt(ops.BE_MASKBITS_X3, ws.dz2_3, L.Dp, ws.W2, L.Dp, ws.dz1, R, L.Hp, L.Dp, products=q,
                                plane_c=L.Hp, aux=ws.h1_bits)
         else:
@@ -202,6 +226,8 @@ def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
         if T:      # rows lo .. hi of x^T against all of dz1^T; db1 = the row sums of dz1^T
             ops.gemm_bf16x3_nt(ops.BE_F32, ws.xT[lo:hi], R, ws.dz1, R, p.gW1[lo:hi], hi - lo, L.Hp, R, products=q,
                                workspace=ws.gemm_ws, colsum=db)
+        elif getattr(ws, "kint", False):      # k8-interleaved operands: one 16-B LDS read per fragment (columns lo .. hi of x_hat)
+            ops.gemm_bf16x3_tnk(ws.xk, L.Fp, lo, ws.dz1k, L.Hp, 0, p.gW1[lo:hi], hi - lo, L.Hp, R, workspace=ws.gemm_ws, colsum=db)
         else:      # columns lo .. hi of every plane of x_hat: the same plane stride, the base moved by lo
             ops.gemm_bf16x3_tn(ws.x3[:, lo:], L.Fp, ws.dz1, L.Hp, p.gW1[lo:hi], hi - lo, L.Hp, R, products=q,
                                workspace=ws.gemm_ws, colsum=db)

@@ -80,10 +80,11 @@ def gather_rows(table, row0, idx, feature_size, x_out, normalize=True, inv_norm_
 
 
 def sample_gather(mode, pairs, seed, step, batch, table, feature_size, idx_out, x_out,
-                  shift_out=None, slot0=0, batch_global=None, step_dev=None, n_steps=1, oob_flag=None):
+                  shift_out=None, slot0=0, batch_global=None, step_dev=None, n_steps=1, oob_flag=None, x_ki=None):
     """n_steps > 1: x_out is [n_steps, rows, stride], idx_out [n_steps, rows], shift_out [n_steps]
     (steps step, step+1, ... in one launch).  oob_flag (int32[1]): bit 0 set when a pair id lies
-    outside the catalogue (the reference's IndexError, inputs.py:158)."""
+    outside the catalogue (the reference's IndexError, inputs.py:158).  x_ki (three-plane output only): a contiguous
+    bf16 buffer [n_steps, 3 * rows * plane] that also receives every step's rows k8-interleaved."""
     bg = batch if batch_global is None else batch_global
     f16 = table.dtype == torch.float16              # fp16 catalogue -> bf16 rows (config 4)
     x3 = not f16 and x_out.dtype == torch.bfloat16   # fp32 catalogue -> rows as three bf16 planes (precision f32x3)
@@ -98,6 +99,15 @@ def sample_gather(mode, pairs, seed, step, batch, table, feature_size, idx_out, 
     else:
         xp, xld = omat(x_out)
         xss = iss = 0
+    if x_ki is not None:
+        if not x3 or x_ki.dtype != torch.bfloat16 or not x_ki.is_contiguous():
+            raise ValueError("x_ki goes with the three-plane output and must be a contiguous bf16 buffer")
+        kss = x_ki.stride(0) if (n_steps > 1 and x_ki.dim() > 1) else 0
+        call("cdml_sample_gather_x3k", mode, _p(pairs, torch.int32), pairs.shape[0], seed,
+             0 if step is None else step, _p(step_dev, torch.int64), batch, slot0, bg, tp,
+             table.shape[0], tld, feature_size, _p(idx_out, torch.int32), _p(shift_out, torch.int32),
+             xp, xld, n_steps, xss, iss, _p(oob_flag, torch.int32), C.c_void_p(x_ki.data_ptr()), kss, _stream())
+        return x_out
     call("cdml_sample_gather_f16" if f16 else "cdml_sample_gather_x3" if x3 else "cdml_sample_gather",
          mode, _p(pairs, torch.int32), pairs.shape[0], seed,
          0 if step is None else step, _p(step_dev, torch.int64), batch, slot0, bg, tp,

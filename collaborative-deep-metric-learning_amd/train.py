@@ -127,7 +127,9 @@ class TrainStep:
             self.layout = engine_x3.layout_x3(F, hidden_size, output_size)
             self.params = engine.VNetParams(self.layout, self.device, weight_seed)
             self.ws = engine_x3.TowerWorkspaceX3(self.layout, self.R, self.device, products=3 if precision.endswith("-3") else 6,
-                                                 planes_in=exchange is None)
+                                                 planes_in=exchange is None,
+                                                 # the interleaved copy of x_hat comes from the fused sampler + gather (one GPU)
+                                                 kint=None if (exchange is None and not train_table) else False)
             engine_x3.refresh_weights(self.params, self.ws)
         elif self.bf16:
             self.layout = engine_bf16.layout_bf16(F, hidden_size, output_size)
@@ -198,8 +200,9 @@ class TrainStep:
                                  "replicated trainable tables would diverge between ranks")
         # several steps' rows per gather launch (the frozen catalogue cannot change in between;
         # a trainable one can, and the sharded path has its own prefetcher)
+        kint = self.x3 and getattr(self.ws, "kint", False)
         if gather_ahead in ("auto", None, 0):
-            row_bytes = self.ws.x_hat.shape[-1] * self.ws.x_hat.element_size()       # what one gathered row writes
+            row_bytes = self.ws.x_hat.shape[-1] * self.ws.x_hat.element_size() * (2 if kint else 1)   # what one gathered row writes
             target = 230e6 if self.bf16 else 300e6                                  # (fp16 -> bf16 rows: half the bytes read per byte written)
             gather_ahead = min(4, max(1, int(round(target / (self.R * row_bytes)))))
         self.gather_ahead = max(1, int(gather_ahead))
@@ -211,9 +214,13 @@ class TrainStep:
             # gather left the critical path, but the GEMM it ran beside lost as much -- dropped)
             K = self.gather_ahead
             self._xa = torch.zeros((K,) + tuple(self.ws.x_hat.shape), dtype=self.ws.x_hat.dtype, device=dev)
+            self._xka = torch.zeros((K, 3 * self.R * self.layout.Fp), dtype=torch.bfloat16, device=dev) if kint else None
             self._idxa = torch.zeros((K, self.R), dtype=i32, device=dev)
             self._shifta = torch.zeros(K, dtype=i32, device=dev)
             self._select_ahead(0)
+        elif kint:
+            self._xka = None
+            self.ws.xk = torch.zeros(3 * self.R * self.layout.Fp, dtype=torch.bfloat16, device=dev)
         self._graphs = {}
         self._warmed = False
         self._replayed = False                           # the previous step was a graph replay
@@ -323,6 +330,8 @@ class TrainStep:
 
     def _select_ahead(self, off):
         self.ws.x_hat, self.idx, self.shift = self._xa[off], self._idxa[off], self._shifta[off:off + 1]
+        if getattr(self, "_xka", None) is not None:
+            self.ws.xk = self._xka[off]
 
     def _gather_block(self, step=None):
         """Sample + gather the steps step .. step+gather_ahead-1 in one launch (step None: the
@@ -331,7 +340,7 @@ class TrainStep:
                           self.table.feature_size, self._idxa, self._xa, shift_out=self._shifta,
                           slot0=self.slot0, batch_global=self.batch_global,
                           step_dev=self.step_dev if step is None else None, n_steps=self.gather_ahead,
-                          oob_flag=self.oob)
+                          oob_flag=self.oob, x_ki=getattr(self, "_xka", None))
 
     def fetch(self):
         """Sampler + gather (+ input l2norm): fills ws.x_hat and self.idx."""
@@ -354,7 +363,8 @@ class TrainStep:
             ops.sample_gather(m, self.pairs, self.seed, None, self.B, self.table.data,
                               self.table.feature_size, self.idx, self.ws.x_hat,
                               shift_out=self.shift, slot0=self.slot0,
-                              batch_global=self.batch_global, step_dev=self.step_dev, oob_flag=self.oob)
+                              batch_global=self.batch_global, step_dev=self.step_dev, oob_flag=self.oob,
+                              x_ki=self.ws.xk if (self.x3 and getattr(self.ws, "kint", False)) else None)
         else:
             if m == MODE_UNIFORM:
                 ops.sample_uniform(self.pairs, self.table.n_rows_global, self.seed, None, self.B,

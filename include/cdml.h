@@ -419,6 +419,17 @@ int cdml_sample_gather_x3(int mode, const int32_t *pairs, int64_t n_pairs, uint6
                           int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
                           uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
                           int64_t idx_step_stride, int32_t *oob_flag, cdml_stream_t stream);
+/* cdml_sample_gather_x3 that ALSO writes every step's rows k8-interleaved (round 5): x_ki = bf16
+ * [3 planes][rows per step / 8][out_stride / 3][8 rows] per step, steps ki_step_stride elements apart -- the operand layout of
+ * cdml_gemm_bf16x3_tnk (the first layer's weight gradient contracts over these rows).  rows per step % 8 == 0,
+ * out_stride / 3 a multiple of 256. */
+int cdml_sample_gather_x3k(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                           uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
+                           int64_t batch_global, const float *table, int64_t n_rows,
+                           int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
+                           uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
+                           int64_t idx_step_stride, int32_t *oob_flag, uint16_t *x_ki, int64_t ki_step_stride,
+                           cdml_stream_t stream);
 /* cdml_vnet_tail (models.py:61, losses.py:32-38, train.py:141) writing dz2 also as its three planes:
  * dz2_planes = bf16 [rows][ldbf], plane p at columns p * plane_bf (plane_bf >= D, ldbf >= 2 plane_bf + D). */
 int cdml_vnet_tail_planes(int mode, const float *z, int64_t ldz, const int32_t *rows,

@@ -614,3 +614,34 @@ def test_data_gradient_epilogue_writes_interleaved_planes(M, N):
         ops.gemm_bf16x3_nt(ops.BE_MASKBITS_X3_KI, A3, K, B3, K, got, M, N, K, plane_c=M * N, aux=aux, alpha=0.2, ldc=N)
         torch.cuda.synchronize()
         assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("mode,steps", [(0, 1), (1, 2), (1, 4)])
+def test_sample_gather_writes_the_interleaved_copy(mode, steps):
+    """cdml_sample_gather_x3k: beside every step's rows as row-major planes the launch writes them k8-interleaved
+    ([plane][row / 8][column][8 rows]: the operand layout of cdml_gemm_bf16x3_tnk) -- the same bits as interleaving the
+    row-major planes, every step of a multi-step launch, both sampler modes; the row-major output and the ids are those of
+    the launch without the copy."""
+    from cdml_amd import engine
+    dev = _dev()
+    N, F, B = 5000, 500, 64
+    Fp = 512
+    table = engine.FeatureTable.synthetic(N, F, 0, dev)
+    rng = np.random.RandomState(2)
+    pairs = rng.randint(0, N, size=(2000, 2)).astype(np.int32)
+    pairs = torch.from_numpy(pairs[pairs[:, 0] != pairs[:, 1]]).to(dev)
+    R = B * (3 if mode == 0 else 2)
+    mk = lambda: (torch.zeros((steps, R, 3 * Fp), dtype=torch.bfloat16, device=dev), torch.zeros((steps, R), dtype=torch.int32, device=dev),
+                  torch.zeros(steps, dtype=torch.int32, device=dev))
+    x0, i0, s0 = mk()
+    x1, i1, s1 = mk()
+    xk = torch.full((steps, 3 * R * Fp), float("nan"), dtype=torch.bfloat16, device=dev)
+    args = lambda x, i, s: dict(idx_out=i if steps > 1 else i[0], x_out=x if steps > 1 else x[0], shift_out=s, n_steps=steps)
+    ops.sample_gather(mode, pairs, 77, 5, B, table.data, F, **args(x0, i0, s0))
+    ops.sample_gather(mode, pairs, 77, 5, B, table.data, F, x_ki=xk if steps > 1 else xk[0], **args(x1, i1, s1))
+    torch.cuda.synchronize()
+    assert torch.equal(x0.view(torch.int16), x1.view(torch.int16)) and torch.equal(i0, i1) and torch.equal(s0, s1)
+    for st in range(steps):
+        want = torch.empty(3 * R * Fp, dtype=torch.bfloat16, device=dev)
+        ops.interleave8_bf16x3(x1[st], Fp, R, Fp, want)
+        assert torch.equal(xk[st].view(torch.int16), want.view(torch.int16)), st
