@@ -383,7 +383,8 @@ def install_timers(kt, L, bf16):
         # (by epilogue: 6 / 8 / 9 = FC1 with plane output, 1 = FC2, 7 / 10 = the data gradient, 3 = a weight gradient in the
         # k-contiguous form of the transposed activation layout; the k-strided form: FC2 when it carries a bias)
         patch("gemm_bf16x3_nt", lambda e, A, pa, Bm, pb, C, M, N, K, **k:
-              {6: "fc1_fwd", 8: "fc1_fwd", 9: "fc1_fwd", 1: "fc2_fwd", 7: "dH1", 10: "dH1"}.get(e, "dW1" if N == L.Hp else "dW2"))
+              {6: "fc1_fwd", 8: "fc1_fwd", 9: "fc1_fwd", 1: "fc2_fwd", 7: "dH1", 10: "dH1", 12: "dH1"}.get(e, "dW1" if N == L.Hp else "dW2"))
+        patch("gemm_bf16x3_tnk", lambda A, ma, a0, Bm, nb, b0, out, M, N, K, **k: "dW1" if N == L.Hp else "dW2")
         patch("gemm_bf16x3_tn", lambda A, pa, Bm, pb, C, M, N, K, **k:
               "fc2_fwd" if k.get("bias") is not None else ("dW1" if N == L.Hp else "dW2"))
         patch("transpose_to_bf16", "transpose_planes")

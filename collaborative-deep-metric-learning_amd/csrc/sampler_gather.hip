@@ -276,15 +276,9 @@ struct RowF32X3 {
   static constexpr int kPerChunk = 4;
   static constexpr int kRows = kRowsPerWave;
   // The k8-interleaved copy (round 5; k_sample_gather's x_ki): after finish() the registers hold the row with its pad
-  // masked; the planes of chunk c are recomputed from the SAME rounded products (same expression, no contraction).
-  __device__ static __forceinline__ float inv_norm(const Regs &R) {
-    float ss = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-      ss += R.v[c].x * R.v[c].x + R.v[c].y * R.v[c].y + R.v[c].z * R.v[c].z + R.v[c].w * R.v[c].w;
-    ss = wave_sum(ss);
-    return 1.0f / sqrtf(fmaxf(ss, 1e-12f));
-  }
+  // masked; the planes of chunk c are recomputed from the SAME rounded products (same expression, no contraction) with the
+  // norm factor finish() RETURNS -- a second evaluation of the sum of squares in the same kernel was contracted into fmas
+  // differently from the first and moved a few rows' factor by one ulp (tests: the copy == the interleaved row-major planes).
   template <typename V4>
   __device__ static __forceinline__ void chunk_planes(const Regs &R, int c, float inv, V4 (&o)[3]) {
 #pragma clang fp contract(off)
@@ -300,7 +294,7 @@ struct RowF32X3 {
   __device__ static __forceinline__ void issue(Regs &R, const In *table, int64_t lr, int64_t stride, int F, int lane) {
     row_issue<NCH>(R, table, lr, stride, (F + 3) >> 2, lane);
   }
-  __device__ static __forceinline__ void finish(Regs &R, int F, Out *dst, int64_t out_stride, int lane) {
+  __device__ static __forceinline__ float finish(Regs &R, int F, Out *dst, int64_t out_stride, int lane) {
     using bf16x4v = __attribute__((ext_vector_type(4))) __bf16;
     if (F & 3) {
 #pragma unroll
@@ -347,6 +341,7 @@ struct RowF32X3 {
     for (int q = lane + kWave * NCH; q < oq; q += kWave)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x4v *>(dst + pl * plane + 4 * q) = z4;
+    return inv;
   }
 };
 
@@ -483,12 +478,14 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
     }
     const int64_t cn = c + gridDim.x;
     if (cn < n_chunks) stage_ids(cn, b ^ 1);       // under the row loads in flight
+    float inv[KI ? kRPW : 1];
 #pragma unroll
     for (int u = 0; u < kRPW; ++u) {
       const int64_t g = g0 + u;
       if (g < total_rows) {
         const int64_t s = g / rows_per_step, r = g - s * rows_per_step;
-        ROW::finish(R[u], F, x_out + s * x_step_stride + r * out_stride, out_stride, lane);
+        if constexpr (KI) inv[u] = ROW::finish(R[u], F, x_out + s * x_step_stride + r * out_stride, out_stride, lane);
+        else ROW::finish(R[u], F, x_out + s * x_step_stride + r * out_stride, out_stride, lane);
       }
     }
     if constexpr (KI) {
@@ -500,9 +497,6 @@ k_sample_gather(const int32_t *__restrict__ pairs, int64_t n_pairs, uint64_t see
       const int64_t sidx = gc / rows_per_step;
       const int64_t kg = (gc - sidx * rows_per_step) >> 3, kgs = rows_per_step >> 3;
       const int plane = (int)(out_stride / 3);
-      float inv[kRPW];
-#pragma unroll
-      for (int u = 0; u < kRPW; ++u) inv[u] = ROW::inv_norm(R[u]);      // (R[u] is masked by finish(): the same sum, the same bits)
       __bf16 *const kbase = x_ki + sidx * ki_step_stride;
       constexpr int kSlices = (int)(sizeof(R[0].v) / sizeof(R[0].v[0]));   // the row registers: NCH chunks of 256 columns
 #pragma unroll

@@ -44,14 +44,18 @@ class TowerWorkspaceX3:
         blocks, 10 000-row evaluation chunks or 65 536-row inference chunks).  True = the explicit opt-out for forward-only
         workspaces of >= 192 row tiles: ONE pass over K, no slab round trip (about 5 % of an inference chunk), last bits
         that differ from the slab form's.
-        kint (training, six products, planes_in; default on, CDML_X3_KI=0 turns it off): the first layer's weight gradient
+        kint (training, six products, planes_in; OFF unless CDML_X3_KI=1 -- measured, see the end): the first layer's weight gradient
         contracts over the batch rows, so its operands -- x_hat and dz1 -- are k-STRIDED in their row-major form and every
         fragment costs two transposed LDS reads.  With kint they are ALSO (x_hat: the fused gather writes a second copy,
         ``xk``) or ONLY (dz1: the data gradient's epilogue writes ``dz1k`` instead of ``dz1``) held k8-interleaved --
         [plane][row / 8][column][8 rows] -- and dW1 runs on cdml_gemm_bf16x3_tnk: one aligned 16-B LDS read per fragment, the
-        same images, DMA schedule, accumulation order and BITS (tests/test_gpu_f32x3.py), 10-12 % faster
-        (profiles/r05_tnk_probe.txt).  ``xk`` is set by the owner of the gather buffers (TrainStep); without it the backward
-        pass falls back to the row-major product."""
+        same images, DMA schedule, accumulation order and BITS (tests/test_gpu_f32x3.py).  ``xk`` is set by the owner of
+        the gather buffers (TrainStep); without it the backward pass falls back to the row-major product.
+        MEASURED (profiles/r05_tnk_probe.txt, r05_kint_in_the_step.txt): alone, back to back, dW1 runs 10-12 % faster this way
+        (0.59 -> 0.655 of the peak at 16 384 rows); IN THE STEP 4 % (999 -> 959 us: the chip answers the higher matrix-pipe
+        duty with a lower clock), the gather's second copy costs + 48 us a step (151 MB more to write and a launch per step
+        instead of per two), the epilogue's second LDS pass + 5 us: the step comes out EVEN (2.7309 against 2.7321 ms).  Kept,
+        with its tests, as the measured alternative; off by default."""
         L, R = layout, int(n_rows)
         if R % 128:
             raise ValueError("precision 'f32x3' needs a row count that is a multiple of 128 (got %d)" % R)
@@ -78,7 +82,7 @@ class TowerWorkspaceX3:
         self.transposed = bool(transposed)
         maskbits = backward and not self.transposed and os.environ.get("CDML_X3_MASKBITS", "1") != "0"
         if kint is None:
-            kint = os.environ.get("CDML_X3_KI", "1") != "0" and planes_in
+            kint = os.environ.get("CDML_X3_KI", "0") == "1" and planes_in
         self.kint = bool(kint) and maskbits and products == 6 and R % 8 == 0
         self.xk = None                                       # [3 * R * Fp] bf16, k8-interleaved x_hat (the gather's second output)
         self.x3 = bf(R, 3 * L.Fp)

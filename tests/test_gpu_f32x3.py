@@ -645,3 +645,31 @@ def test_sample_gather_writes_the_interleaved_copy(mode, steps):
         want = torch.empty(3 * R * Fp, dtype=torch.bfloat16, device=dev)
         ops.interleave8_bf16x3(x1[st], Fp, R, Fp, want)
         assert torch.equal(xk[st].view(torch.int16), want.view(torch.int16)), st
+
+
+@pytest.mark.parametrize("mode", ["inbatch", "uniform"])
+def test_train_step_on_interleaved_operands_is_the_same_step(mode, monkeypatch):
+    """CDML_X3_KI=1: the fused gather also writes x_hat k8-interleaved, the data gradient writes dz1 ONLY that way and the
+    first layer's weight gradient runs on cdml_gemm_bf16x3_tnk -- the same images, accumulation order and bits: after
+    three steps the weights are those of the default step, bit for bit (gather_ahead 1 and 2: a launch per step and a
+    launch for two steps)."""
+    dev = _dev()
+    from cdml_amd import engine, train
+    N, F, B = 6000, 500, 128
+    table = engine.FeatureTable.synthetic(N, F, 0, dev)
+    rng = np.random.RandomState(1)
+    pairs = rng.randint(0, N, size=(3000, 2)).astype(np.int32)
+    pairs = torch.from_numpy(pairs[pairs[:, 0] != pairs[:, 1]]).to(dev)
+    for ahead in (1, 2):
+        def mk(ki):
+            monkeypatch.setenv("CDML_X3_KI", "1" if ki else "0")
+            return train.TrainStep(table, pairs, B, hidden_size=700, output_size=256, mode=mode, optimizer="adam",
+                                   base_learning_rate=0.01, device=dev, precision="f32x3", gather_ahead=ahead)
+        a, b = mk(False), mk(True)
+        assert b.ws.kint and b.ws.dz1 is None and not a.ws.kint
+        for _ in range(3):
+            a.step(); b.step()
+        torch.cuda.synchronize()
+        assert torch.equal(a.idx, b.idx) and torch.equal(a.ws.x_hat.view(torch.int16), b.ws.x_hat.view(torch.int16))
+        assert torch.equal(a.ws.dz1_f32(), b.ws.dz1_f32())
+        assert torch.equal(a.params.grad, b.params.grad) and torch.equal(a.params.flat, b.params.flat)
