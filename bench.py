@@ -1211,7 +1211,7 @@ def main():
             ar, exw = comm_kt.mean_ms("allreduce_wait"), comm_kt.mean_ms("exchange_wait")
             out["comm"] = {"allreduce_exposed_ms": None if ar is None else round(ar, 4),
                            "exchange_exposed_ms": None if exw is None else round(exw, 4),
-                           "exchange_bytes": exchange.bytes_per_step(ts.R, ts.ws.x_hat),
+                           "exchange_bytes": exchange.bytes_per_step(ts.R, ts.ws.x_hat, ts.table),
                            "allreduce_bytes": int(ts.layout.numel * 4),
                            "grad_sync": ts.grad_sync_mode, "grad_sync_probe": probe,
                            "exchange_capacity_factor": args.capacity_factor,

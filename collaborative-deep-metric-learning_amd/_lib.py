@@ -114,6 +114,7 @@ SIGNATURES = {
     "cdml_gemm_bf16_tn": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _sz, _p]),
     "cdml_sample_gather_x3": (_i, [_i, _p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _i64, _i64, _i,
                                    _p, _p, _p, _i64, _i, _i64, _i64, _p, _p]),
+    "cdml_gather_rows_x3": (_i, [_p, _i64, _i64, _p, _i, _i, _i, _p, _i64, _p, _p]),
     "cdml_sample_gather_x3k": (_i, [_i, _p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _i64, _i64, _i,
                                     _p, _p, _p, _i64, _i, _i64, _i64, _p, _p, _i64, _p]),
     "cdml_split_f32_bf16x3": (_i, [_p, _i64, _i, _i, _p, _i64, _i64, _i, _p]),

@@ -178,6 +178,64 @@ k_gather_rows(const float *__restrict__ table, int64_t row0, int64_t n_rows, int
   }
 }
 
+// out planes[r] = the three bf16 planes hi | mid | lo of the fp32 row src[idx[r]] AS STORED (no normalisation): the last step
+// of the row exchange on the split-fp32 path (round 5) -- the received rows go into request order and into the GEMMs' operand
+// form in one pass on the prefetch stream, instead of fp32 rows there and a split launch on the compute stream every step.
+// idx -1 (flag bit 1): a request that found no slot -> all-ones words (NaN in every plane), as k_gather_rows.
+template <int NCH>
+__global__ void __launch_bounds__(kThreads)
+k_gather_rows_planes(const float *__restrict__ src, int64_t n_rows, int64_t row_stride, const int32_t *__restrict__ idx, int n_idx,
+                     int F, int flags, __bf16 *__restrict__ out, int64_t out_stride, int32_t *__restrict__ oob_flag) {
+  using bf16x4v = __attribute__((ext_vector_type(4))) __bf16;
+  using u32x2v = __attribute__((ext_vector_type(2))) uint32_t;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t plane = out_stride / 3;
+  const int oq = (int)(plane >> 2), nq = (F + 3) >> 2;
+  for (int r = blockIdx.x * kWavesPerBlock + wave; r < n_idx; r += gridDim.x * kWavesPerBlock) {
+    const int32_t id = idx[r];
+    __bf16 *dst = out + (int64_t)r * out_stride;
+    if (id == -1) {
+      if (flags & 2)
+        for (int q = lane; q < 3 * oq; q += kWave) *reinterpret_cast<u32x2v *>(dst + 4 * q) = u32x2v{0xFFFFFFFFu, 0xFFFFFFFFu};
+      continue;
+    }
+    const int64_t lr = clamp_row(id, 0, n_rows, oob_flag);
+    const float4 *s4 = reinterpret_cast<const float4 *>(src + lr * row_stride);
+    float4 v[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      v[c] = (q < nq) ? s4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      if (q < oq) {
+        float x[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+        if (F & 3) {                                        // the pad of the source row never leaks in
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (4 * q + u >= F) x[u] = 0.f;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          bf16x4v o;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            o[u] = (__bf16)x[u];
+            x[u] -= (float)o[u];
+          }
+          *reinterpret_cast<bf16x4v *>(dst + pl * plane + 4 * q) = o;
+        }
+      }
+    }
+    const bf16x4v z4 = {0, 0, 0, 0};
+    for (int q = lane + kWave * NCH; q < oq; q += kWave)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x4v *>(dst + pl * plane + 4 * q) = z4;
+  }
+}
+
 // Persistent fused sampler + gather + input l2-normalise, one launch for n_steps consecutive
 // training steps (the sampler is counter-based, so the triplets of step t+1 are known at step
 // t; two or more steps per launch amortise the launch ramp and the ids -> row latency chain of
@@ -704,6 +762,30 @@ extern "C" int cdml_gather_rows(const float *table, int64_t row0, int64_t n_rows
   else CDML_LAUNCH_GATHER(8);
 #undef CDML_LAUNCH_GATHER
   return check_launch("gather_rows");
+}
+
+// rows AS STORED (fp32, e.g. the receive buffer of the row exchange) -> request order AND the three bf16 planes of the split-fp32
+// GEMMs: x_out_planes[r] = planes of src[idx[r]] (out_stride = 3 planes of out_stride / 3 >= F columns); flags bit 1: idx -1 =
+// a request that found no slot -> NaN planes (else: left untouched).
+extern "C" int cdml_gather_rows_x3(const float *src, int64_t n_rows, int64_t row_stride, const int32_t *idx, int n_idx, int F,
+                                   int flags, uint16_t *x_out_planes, int64_t out_stride, int32_t *oob_flag,
+                                   cdml_stream_t stream) {
+  CDML_REQUIRE(src && idx && x_out_planes && n_rows > 0 && n_idx > 0, CDML_E_BADARG, "gather_rows_x3: bad argument");
+  CDML_REQUIRE(F > 0 && F <= 2048, CDML_E_UNSUPPORTED, "gather_rows_x3: feature size %d outside (0, 2048]", F);
+  CDML_REQUIRE(row_stride >= F && (row_stride & 3) == 0 && out_stride % 3 == 0 && out_stride / 3 >= F && ((out_stride / 3) & 3) == 0 &&
+                   aligned16(src) && (reinterpret_cast<uintptr_t>(x_out_planes) & 7) == 0,
+               CDML_E_ALIGN, "gather_rows_x3: out_stride must be 3 planes of >= F columns (multiples of 4), 16-B aligned rows");
+  const int grid = grid_for(n_idx, kWavesPerBlock);
+  const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
+#define CDML_LAUNCH_GRP(N)                                                                                          \
+  hipLaunchKernelGGL(k_gather_rows_planes<N>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, src, n_rows, row_stride, \
+                     idx, n_idx, F, flags, reinterpret_cast<__bf16 *>(x_out_planes), out_stride, oob_flag)
+  if (nch <= 2) CDML_LAUNCH_GRP(2);
+  else if (nch <= 4) CDML_LAUNCH_GRP(4);
+  else if (nch <= 6) CDML_LAUNCH_GRP(6);
+  else CDML_LAUNCH_GRP(8);
+#undef CDML_LAUNCH_GRP
+  return check_launch("gather_rows_x3");
 }
 
 extern "C" int cdml_sample_gather(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,

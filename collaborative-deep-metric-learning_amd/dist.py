@@ -197,13 +197,21 @@ class RowExchange:
         group = self.capture_group if (self.capture_group is not None and _capturing()) else self.group
         if not local_only:
             all_to_all(recv_ids, send_ids, group)
-        stride = out.shape[1]
-        rows_out = self._scratch("rows_out", (n_slots, stride), out.dtype, out.device)
+        # split-fp32 path (round 5): ``out`` is the GEMMs' plane buffer [R, 3 planes] bf16 while the table is fp32 -- the rows
+        # TRAVEL as fp32 (6 KB, not 9 KB of planes) and the un-permute pass writes the planes: request order and operand
+        # form in one launch on the prefetch stream, no fp32 x_hat and no split launch on the compute stream
+        planes = out.dtype == torch.bfloat16 and table.data.dtype == torch.float32
+        stride = out.shape[1] // 3 if planes else out.shape[1]
+        row_dtype = torch.float32 if planes else out.dtype
+        rows_out = self._scratch("rows_out", (n_slots, stride), row_dtype, out.device)
         self.local_gather(table, recv_ids, rows_out)
-        rows_in = rows_out if local_only else self._scratch("rows_in", (n_slots, stride), out.dtype, out.device)
+        rows_in = rows_out if local_only else self._scratch("rows_in", (n_slots, stride), row_dtype, out.device)
         if not local_only:
             all_to_all(rows_in, rows_out, group)
-        self.unpermute(rows_in, slot, out)
+        if planes:
+            ops.gather_rows_x3(rows_in, slot, stride, out[:slot.numel()], nan_missing=True)
+        else:
+            self.unpermute(rows_in, slot, out)
         # kept for scatter_back(): the same routing carries row gradients to their owners
         self.last = (slot, recv_ids, cap)
         return out
@@ -253,10 +261,13 @@ class RowExchange:
             raise RuntimeError("row exchange: a peer segment overflowed (requests are skewed towards one shard); "
                                "raise RowExchange(capacity_factor=%.2f)" % self.capacity_factor)
 
-    def bytes_per_step(self, n_requests, x):
-        """Bytes this rank sends per step (ids out + rows back), padding included."""
+    def bytes_per_step(self, n_requests, x, table=None):
+        """Bytes this rank sends per step (ids out + rows back), padding included.  (Split-fp32 path: ``x`` is the plane
+        buffer, the rows travel as fp32 -- a third of its columns, four bytes each.)"""
         n_slots = self.world * self.capacity(n_requests)
-        return int(n_slots * 4 + n_slots * x.shape[1] * x.element_size())
+        planes = table is not None and x.dtype == torch.bfloat16 and table.data.dtype == torch.float32
+        row_bytes = (x.shape[1] // 3) * 4 if planes else x.shape[1] * x.element_size()
+        return int(n_slots * 4 + n_slots * row_bytes)
 
 
 class GradSync:

@@ -79,6 +79,16 @@ def gather_rows(table, row0, idx, feature_size, x_out, normalize=True, inv_norm_
     return x_out
 
 
+def gather_rows_x3(src, idx, feature_size, x_out_planes, nan_missing=False, oob_flag=None):
+    """x_out_planes[r] = the three bf16 planes of the fp32 row src[idx[r]] as stored (the row exchange's last step on the
+    split-fp32 path: request order and operand form in one pass)."""
+    sp, sld = _mat(src)
+    xp, xld = _mat16(x_out_planes)
+    call("cdml_gather_rows_x3", sp, src.shape[0], sld, _p(idx, torch.int32), idx.numel(), feature_size, 2 if nan_missing else 0,
+         xp, xld, _p(oob_flag, torch.int32), _stream())
+    return x_out_planes
+
+
 def sample_gather(mode, pairs, seed, step, batch, table, feature_size, idx_out, x_out,
                   shift_out=None, slot0=0, batch_global=None, step_dev=None, n_steps=1, oob_flag=None, x_ki=None):
     """n_steps > 1: x_out is [n_steps, rows, stride], idx_out [n_steps, rows], shift_out [n_steps]

@@ -127,7 +127,10 @@ class TrainStep:
             self.layout = engine_x3.layout_x3(F, hidden_size, output_size)
             self.params = engine.VNetParams(self.layout, self.device, weight_seed)
             self.ws = engine_x3.TowerWorkspaceX3(self.layout, self.R, self.device, products=3 if precision.endswith("-3") else 6,
-                                                 planes_in=exchange is None,
+                                                 # the plane buffer IS x_hat on both paths: the fused gather writes planes, and so
+                                                 # does the un-permute pass of the row exchange (round 5; a caller's fp32 rows:
+                                                 # TowerWorkspaceX3(planes_in=False) splits them in the forward pass)
+                                                 planes_in=True,
                                                  # the interleaved copy of x_hat comes from the fused sampler + gather (one GPU)
                                                  kint=None if (exchange is None and not train_table) else False)
             engine_x3.refresh_weights(self.params, self.ws)

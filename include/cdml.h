@@ -419,6 +419,12 @@ int cdml_sample_gather_x3(int mode, const int32_t *pairs, int64_t n_pairs, uint6
                           int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
                           uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
                           int64_t idx_step_stride, int32_t *oob_flag, cdml_stream_t stream);
+/* The last step of the row exchange on the split-fp32 path (round 5; the build's data-parallel extension, no reference row):
+ * x_out_planes[r] = the three bf16 planes of the fp32 row src[idx[r]] AS STORED -- request order and operand form in one pass
+ * (flags bit 1: idx -1 = a request that found no slot -> NaN planes, else left untouched). */
+int cdml_gather_rows_x3(const float *src, int64_t n_rows, int64_t row_stride, const int32_t *idx, int n_idx, int F,
+                        int flags, uint16_t *x_out_planes, int64_t out_stride, int32_t *oob_flag,
+                        cdml_stream_t stream);
 /* cdml_sample_gather_x3 that ALSO writes every step's rows k8-interleaved (round 5): x_ki = bf16
  * [3 planes][rows per step / 8][out_stride / 3][8 rows] per step, steps ki_step_stride elements apart -- the operand layout of
  * cdml_gemm_bf16x3_tnk (the first layer's weight gradient contracts over these rows).  rows per step % 8 == 0,

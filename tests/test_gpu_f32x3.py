@@ -673,3 +673,27 @@ def test_train_step_on_interleaved_operands_is_the_same_step(mode, monkeypatch):
         assert torch.equal(a.idx, b.idx) and torch.equal(a.ws.x_hat.view(torch.int16), b.ws.x_hat.view(torch.int16))
         assert torch.equal(a.ws.dz1_f32(), b.ws.dz1_f32())
         assert torch.equal(a.params.grad, b.params.grad) and torch.equal(a.params.flat, b.params.flat)
+
+
+def test_gather_rows_x3_is_the_split_of_the_gathered_rows():
+    """cdml_gather_rows_x3 (the row exchange's last step on the split-fp32 path): request order and the GEMMs' operand form in
+    one pass -- the planes of src[idx[r]] exactly as cdml_split_f32_bf16x3 gives them for the gathered fp32 rows; padding
+    columns zero; an unanswered request (-1) a NaN row, or untouched without the flag."""
+    dev = _dev()
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    n, F, Fp, R = 700, 500, 512, 300
+    src = torch.zeros((n, Fp), device=dev)
+    src[:, :F] = torch.randn(n, F, device=dev, generator=g)
+    idx = torch.randint(0, n, (R,), device=dev, generator=g, dtype=torch.int32)
+    idx[7] = -1; idx[200] = -1
+    out = torch.full((R, 3 * Fp), 5.0, dtype=torch.bfloat16, device=dev)
+    ops.gather_rows_x3(src, idx, F, out, nan_missing=True)
+    rows = src[idx.clamp_min(0).long()]
+    want = torch.zeros((R, 3 * Fp), dtype=torch.bfloat16, device=dev)
+    ops.split_f32_bf16x3(rows, want, Fp)
+    ok = idx >= 0
+    assert torch.equal(out[ok].view(torch.int16), want[ok].view(torch.int16))
+    assert torch.isnan(out[~ok].float()).all()
+    out2 = torch.full((R, 3 * Fp), 5.0, dtype=torch.bfloat16, device=dev)
+    ops.gather_rows_x3(src, idx, F, out2)
+    assert (out2[~ok].float() == 5.0).all() and torch.equal(out2[ok].view(torch.int16), want[ok].view(torch.int16))
