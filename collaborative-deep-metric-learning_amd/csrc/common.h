@@ -30,6 +30,27 @@ constexpr int kWave = 64;
 constexpr int kNumCU = 256;
 
 // ---- device helpers -----------------------------------------------------------
+// Sum of squares of one 16-B chunk (8 halfs) of an fp16 catalogue row, elements at or past F zeroed IN the chunk (the pad is
+// never trusted): shared by the fused sampler + gather and k_gather_rows_f16, which must agree bit for bit.  Round 5: four
+// v_dot2_f32_f16 (exact fp16 products, fp32 accumulate) instead of eight conversions + eight fmas, and the pad test only in
+// the chunks that reach past F -- a timing ablation without the norm ran the fp16 gather 11 % faster: it is bound by its
+// per-row instructions as much as by HBM (profiles/r05_gather_f16_norm_ablation.txt).
+using cdml_half8 = __attribute__((ext_vector_type(8))) _Float16;
+using cdml_half2 = __attribute__((ext_vector_type(2))) _Float16;
+__device__ __forceinline__ float f16_chunk_sumsq(cdml_half8 &x, int q, int F, float ss) {
+  if (8 * q + 8 > F) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (8 * q + u >= F) x[u] = 0;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const cdml_half2 p = {x[2 * e], x[2 * e + 1]};
+    ss = __builtin_amdgcn_fdot2(p, p, ss, false);
+  }
+  return ss;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

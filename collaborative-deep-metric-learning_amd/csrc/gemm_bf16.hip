@@ -352,12 +352,7 @@ k_gather_rows_f16(const _Float16 *__restrict__ table, int64_t row0, int64_t n_ro
       const int q = lane + 64 * c;
       half8 x = {0, 0, 0, 0, 0, 0, 0, 0};
       if (q < nq) x = src[q];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (8 * q + u >= F) x[u] = 0;           // never trust the pad
-        const float f = (float)x[u];
-        ss += f * f;
-      }
+      ss = f16_chunk_sumsq(x, q, F, ss);           // (the pad zeroed in x; the same arithmetic as the fused kernel)
       v[c] = x;
     }
     ss = wave_sum(ss);

@@ -435,15 +435,7 @@ struct RowF16 {
   __device__ static __forceinline__ void finish(Regs &R, int F, Out *dst, int64_t out_stride, int lane) {
     float ss = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int q = lane + kWave * c;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (8 * q + u >= F) R.v[c][u] = 0;       // never trust the pad
-        const float f = (float)R.v[c][u];
-        ss += f * f;
-      }
-    }
+    for (int c = 0; c < NCH; ++c) ss = f16_chunk_sumsq(R.v[c], lane + kWave * c, F, ss);
     ss = wave_sum(ss);
     const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
     bf16x8v *d = reinterpret_cast<bf16x8v *>(dst);
