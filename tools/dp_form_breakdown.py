@@ -15,17 +15,18 @@ import bench  # noqa: E402
 from cdml_amd import dist as cdist, engine, train  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+precision = sys.argv[2] if len(sys.argv) > 2 else "f32x3"
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % bench.free_port(), rank=0, world_size=1, device_id=dev,
                         timeout=datetime.timedelta(seconds=120))
 table = engine.FeatureTable.synthetic(10000000, 1500, seed=0, device=dev)
 pairs = torch.from_numpy(bench.synth_pairs(10000000, 600000, seed=0)).to(dev)
-bench.settle_gpu(dev)
+bench.settle_gpu(dev, precision=precision[:5])
 
 
 def run(name, **kw):
-    ts = train.TrainStep(table, pairs, 8192, mode="inbatch", device=dev, batch_global=8192, **kw)
+    ts = train.TrainStep(table, pairs, 8192, mode="inbatch", device=dev, batch_global=8192, precision=precision, **kw)
     el = bench.timed_steps(ts, steps, 5, dev)
     print("%-58s %.4f ms/step" % (name, el / steps * 1e3), flush=True)
 
