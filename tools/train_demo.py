@@ -29,15 +29,17 @@ pairs = torch.stack([a[same], b[same]], 1).to(torch.int32)
 pairs = pairs[torch.randperm(pairs.shape[0], device=dev, generator=g)]
 eval_pairs, train_pairs = pairs[:2000], pairs[2000:].contiguous()
 print("catalogue %d x %d, %d clusters, %d training pairs, %d held-out pairs" % (N, F, C, len(train_pairs), len(eval_pairs)))
-for prec in ("f32", "bf16"):
-    if prec == "f32":
+combos = [tuple(c.split(":")) for c in (sys.argv[3].split(",") if len(sys.argv) > 3 else
+                                        ["f32:inbatch", "f32x3:inbatch", "f32x3:semihard", "bf16:inbatch"])]
+for prec, mode in combos:
+    if prec != "bf16":
         table = engine.FeatureTable(torch.zeros((N, 1536), device=dev), F)
         table.data[:, :F] = feats
     else:
         table = engine_bf16.FeatureTableF16.from_numpy(feats.cpu().numpy(), dev)
-    ts = train.TrainStep(table, train_pairs, B, mode="inbatch", optimizer="adam", base_learning_rate=2e-4,
+    ts = train.TrainStep(table, train_pairs, B, mode=mode, optimizer="adam", base_learning_rate=2e-4,
                          precision=prec, device=dev)
-    pred = predict.Prediction(params=ts.params, device=dev)
+    pred = predict.Prediction(params=ts.params, device=dev, precision="f32x3" if prec == "f32x3" else "f32")
     ev_rows = torch.unique(eval_pairs.reshape(-1).to(torch.int64))
     remap = torch.full((N,), -1, dtype=torch.int64, device=dev)
     remap[ev_rows] = torch.arange(len(ev_rows), device=dev)
@@ -49,7 +51,7 @@ for prec in ("f32", "bf16"):
     def held_out():
         return ev.mean_dist(pred.predict(ev_feats), ev_local)
 
-    print("== %s" % prec)
+    print("== %s, %s negatives%s" % (prec, mode, " (mined in the epilogue of the score product)" if getattr(ts, "mine_fused", False) else ""))
     print("step %4d  held-out mean positive distance %.4f" % (0, held_out()))
     torch.cuda.synchronize()
     import time
