@@ -513,3 +513,22 @@ def test_resume_bf16_is_bit_exact(cd, tmp_path, precision):
     torch.cuda.synchronize()
     assert c.global_step == 10 and torch.equal(a.params.flat, c.params.flat)
     assert torch.equal(a.m, c.m) and torch.equal(a.idx, c.idx)
+
+
+def test_gather_steps_per_launch_follow_the_bytes_a_launch_writes(cd):
+    """TrainStep(gather_ahead="auto"), round 5: as many steps per fused sampler + gather launch (1 .. 4) as keep the bytes the
+    launch WRITES near the 256 MB Infinity Cache (profiles/r05_gather_sweep.txt): three-plane rows at 16 384 rows a step -> 2,
+    at 8 192 -> 4; fp32 rows -> 4; config 4's bf16 rows at 24 576 rows a step -> 3; an explicit value is taken as given, and
+    the row-sharded path fetches per step."""
+    from oracle import synth as osynth
+    N, F = 20000, 1500
+    t32 = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev)
+    pairs = torch.as_tensor(osynth.cowatch_pairs(N, 6000, 0)).to(cd.dev)
+    mk = lambda table, B, mode, prec, **kw: cd.train.TrainStep(table, pairs, B, mode=mode, device=cd.dev, precision=prec, **kw)
+    assert mk(t32, 8192, "inbatch", "f32x3").gather_ahead == 2
+    assert mk(t32, 4096, "inbatch", "f32x3").gather_ahead == 4
+    assert mk(t32, 4096, "inbatch", "f32").gather_ahead == 4
+    assert mk(t32, 4096, "inbatch", "f32x3", gather_ahead=3).gather_ahead == 3
+    t16 = cd.ebf.FeatureTableF16.synthetic(N, F, 0, cd.dev) if hasattr(cd, "ebf") else None
+    if t16 is not None:
+        assert mk(t16, 8192, "uniform", "bf16").gather_ahead == 3
