@@ -528,9 +528,23 @@ def gather_record(ts, mode, bf16, dev, pmc_name=None, workload=None):
     g_ach = gbytes / (t_g * 1e-3) / 1e9
     tr, src = (pmc_traffic("k_sample_gather<%d," % (1 if rpt == 2 else 0), name=pmc_name or "latest_pmc_x3", workload=workload) if x3
                else pmc_traffic(gk, bf16, name=pmc_name, workload=workload))
+    # Which bytes.  `achieved` / `frac` divide the bytes the launch MOVES (rows read + the operand form
+    # written: three bf16 planes on the split-fp32 path) by its time -- the HBM figure, what PMC FETCH + WRITE confirms.
+    # SURVEY section 8(d) prices a gathered row at F*elt read + F*elt written (the normalised row in the table's own width):
+    # `frac_algorithmic_8d` divides THOSE bytes by the same time -- lower on the plane path, whose rows cost 9 000 B of
+    # writes for 6 000 B of algorithmic output.
+    elt = 2 if bf16 else 4
+    row_moved = gbytes / (n_st * R)
+    row_alg = 2.0 * F * elt
+    alg_ach = n_st * R * row_alg / (t_g * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": gk + ("<6>, true> (row-major planes + the k8-interleaved copy)" if ki else "<6>>" if x3 else " RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": tr,
             "traffic_source": src, "bytes_per_launch": gbytes, "launch_ms": round(t_g, 4), "steps_per_launch": n_st,
+            "bytes_per_row_moved": row_moved, "bytes_per_row_algorithmic_8d": row_alg,
+            "achieved_algorithmic_8d": round(alg_ach, 1), "frac_algorithmic_8d": round(alg_ach / PEAK_HBM_GBS, 4),
+            "frac_is": "bytes MOVED per launch (rows read + operand form written) / time / 8 TB/s; frac_algorithmic_8d: SURVEY "
+                       "8(d)'s F*elt read + F*elt written per row / the same time",
+            "rows_per_launch": n_st * R,
             "method": "%d back-to-back launches per event pair (inter-launch gaps included), median of %d" % (per, reps)}
 
 
@@ -1148,9 +1162,28 @@ def main():
                                                 barrier if world > 1 else None)
         if comm_kt is not None:
             comm_kt.on = False
+        elapsed_local = elapsed
+        per_rank = None
         if world > 1:
             set_phase("max over ranks")
             elapsed = reduce_max(elapsed)
+            # every rank's own facts in the one JSON line, so that the first real N > 1 run explains itself:
+            # the flags are read BEFORE the check below raises on them -- an overflowing run still names its rank in the
+            # failure message of check_inputs(), a clean one shows every rank's zeros here
+            set_phase("per-rank facts")
+            ov = 0 if exchange.overflow is None else int(exchange.overflow.item())
+            ar_w, ex_w = comm_kt.mean_ms("allreduce_wait"), comm_kt.mean_ms("exchange_wait")
+            mine = torch.tensor([rank, local_rank, elapsed_local / args.steps * 1e3, ov, int(ts.oob.item()),
+                                 -1.0 if ar_w is None else ar_w, -1.0 if ex_w is None else ex_w,
+                                 torch.cuda.memory_allocated(dev) / 2.0 ** 30], dtype=torch.float64,
+                                device=dev if backend == "nccl" else "cpu")
+            allv = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine)
+            per_rank = [{"rank": int(v[0]), "local_rank": int(v[1]), "ms_per_step": round(float(v[2]), 4),
+                         "exchange_overflow_flag": int(v[3]), "pair_id_out_of_range_flag": int(v[4]),
+                         "allreduce_exposed_ms": None if v[5] < 0 else round(float(v[5]), 4),
+                         "exchange_exposed_ms": None if v[6] < 0 else round(float(v[6]), 4),
+                         "hbm_allocated_gib": round(float(v[7]), 2)} for v in (t.cpu() for t in allv)]
         set_phase("checks")
         loss = ts.loss()                                 # (also reads the exchange-overflow / bad-id flags)
         assert np.isfinite(loss), "non-finite loss"
@@ -1180,12 +1213,19 @@ def main():
                       "an fp32 equivalent; measurement only)"),
             "data": "synthetic",
             "config": {"workload": "%s: %d videos x %d-d %s in HBM%s, %d hidden, %d-d embed, batch %d triplets/GPU "
-                                   "(%d global), %s negatives, margin %.1f, Adam, full step (sample+gather+fwd+loss+bwd+opt)"
+                                   "(%d global), %s negatives (%d rows per triplet), margin %.1f, Adam, full step (sample+gather+fwd+loss+bwd+opt)"
                                    % (cfg_name, n_rows, F, "fp16" if bf16 else "fp32",
                                       "" if world == 1 else " row-sharded over %d GPUs" % world, H, D, B, world * B,
                                       {"inbatch": "in-batch", "uniform": "uniform random", "semihard": "semi-hard mined"}[mode],
-                                      MARGIN),
+                                      rpt, MARGIN),
                        "global_batch": world * B, "rows_per_triplet": rpt,
+                       "rows_per_triplet_note": ("in-batch negatives: a triplet gathers and embeds 2 rows (anchor, positive; the negative "
+                                                 "is another triplet's positive).  The reference's only negative rule is uniform (3 rows per "
+                                                 "triplet, inputs.py:125-127): in rows embedded this value is value x 2/3 = %.1f "
+                                                 "three-row triplets/s; the three-row step itself is timed as `reference_recipe` "
+                                                 "(B = 1024) and `config4_per_gpu`" % (world * B * args.steps / elapsed * 2.0 / 3.0))
+                                                if rpt == 2 else "uniform negatives: 3 rows per triplet, the reference's rule",
+                       "value_three_row_equivalent": round(world * B * args.steps / elapsed * rpt / 3.0, 1),
                        "parallelism": "dp%d" % world + ("" if world == 1 else " row-sharded table, all-to-all rows + all-reduce grads"),
                        "hipgraph": ts.use_graph if ts.use_graph == "split" else bool(ts.use_graph), "trainable_table": bool(args.train_table),
                        "gather_steps_per_launch": ts.gather_ahead, "precision": args.precision},
@@ -1201,12 +1241,32 @@ def main():
                                    "per_gpu_batch": B, "rows_global": n_rows}
             out["ranks_seen"] = dist.get_world_size()
             out["comm_backend"] = {"backend": dist.get_backend(), "launcher": "self" if os.environ.get("CDML_BENCH_PHASE_DIR") else "external",
-                                   "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
+                                   "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                                   # what steers RCCL's algorithm / protocol / channel choice, as this process saw it (unset =
+                                   # RCCL's own choice for the topology: ring over the xGMI mesh unless told otherwise)
+                                   "env": {k: v for k, v in sorted(os.environ.items())
+                                           if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "HSA_FORCE_FINE", "HIP_VISIBLE", "ROCR_VISIBLE"))},
+                                   "algo": os.environ.get("NCCL_ALGO", "unset (RCCL decides)"),
+                                   "proto": os.environ.get("NCCL_PROTO", "unset (RCCL decides)"),
+                                   "channels": {"min": os.environ.get("NCCL_MIN_NCHANNELS"), "max": os.environ.get("NCCL_MAX_NCHANNELS")}}
+            out["ranks"] = per_rank
+            out["exchange"] = {"requests_per_rank": ts.R, "capacity_slots_per_peer": exchange.capacity(ts.R),
+                               "capacity_factor": args.capacity_factor, "mean_share_per_peer": ts.R / world,
+                               "overflow_flag_max": max(r["exchange_overflow_flag"] for r in per_rank),
+                               "overflow_flag_bits": "1 = a peer segment was full (rows came back NaN), 2 = an id outside the catalogue"}
         if timers_on:
             out.update(gemm_records(kt, R, bf16, sampled, how, world == 1, x3_products=x3, workload=wkey))
         if world == 1 and not args.train_table:
             set_phase("gather record")
             out["gather"] = gather_record(ts, mode, bf16, dev, workload=wkey)
+            if "roofline" in out:
+                # BASELINE's metric has an HBM half ("HBM GB/s on gather vs roofline"): carried INSIDE `roofline`, the object the
+                # driver keeps, not only as a top-level extra
+                gr = out["gather"]
+                out["roofline"]["gather"] = {k: gr[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                                "bytes_per_row_moved", "bytes_per_row_algorithmic_8d",
+                                                                "achieved_algorithmic_8d", "frac_algorithmic_8d", "launch_ms",
+                                                                "rows_per_launch", "frac_is")}
         if world > 1:
             ar, exw = comm_kt.mean_ms("allreduce_wait"), comm_kt.mean_ms("exchange_wait")
             out["comm"] = {"allreduce_exposed_ms": None if ar is None else round(ar, 4),

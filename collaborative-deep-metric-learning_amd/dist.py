@@ -47,6 +47,53 @@ def _capturing():
     return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
+class EagerCollectiveStreams:
+    """The streams that have carried an EAGER RCCL collective, so that none of them is ever used as the origin of a
+    hipGraph capture.
+
+    Why (the abort of round 5): torch runs a synchronous eager collective on the caller's current
+    stream and records the work's end event THERE; the RCCL watchdog thread polls that event (hipEventQuery, every
+    100 ms) until it has seen it complete.  A capture that begins on such a stream before the next poll makes HIP answer
+    the query with hipErrorCapturedEvent, the watchdog rethrows, the process ends.  Rounds 3-4 captured the split
+    form's exchange graph with the prefetch stream -- which carries the eager exchanges -- as its origin; round 5 moved
+    the capture to a stream of its own.  This registry turns "no stream that ever carried an eager collective enters
+    a capture" from a convention into a checked invariant: every collective entry point of this module notes the
+    stream it was issued on (``note``), and ``TrainStep._capture`` refuses an origin that ``carried`` one.
+
+    Streams are identified by (device index, native handle); objects without those attributes (the CPU tests' stand-ins)
+    by their ``id``.  Process-wide: a stream is a property of the process, not of one hook."""
+    _seen = set()
+
+    @staticmethod
+    def key(stream):
+        h = getattr(stream, "cuda_stream", None)
+        if h is None:
+            return ("obj", id(stream))
+        return (getattr(stream, "device_index", None), int(h))
+
+    @classmethod
+    def note(cls, stream=None):
+        """An eager collective is being issued on ``stream`` (None: the current stream).  No-op inside a capture (captured
+        collectives are never put on a watchdog work list) and without a GPU."""
+        if stream is None:
+            if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+                return
+            stream = torch.cuda.current_stream()
+        cls._seen.add(cls.key(stream))
+
+    @classmethod
+    def carried(cls, stream):
+        return cls.key(stream) in cls._seen
+
+    @classmethod
+    def assert_clean_origin(cls, stream, what="capture origin"):
+        if cls.carried(stream):
+            raise RuntimeError(
+                "%s %r has carried an eager RCCL collective: the RCCL watchdog still polls work events recorded on it, and "
+                "a capture that pulls it in ends the process with hipErrorCapturedEvent (DESIGN.md section 7).  Capture "
+                "from a stream that never issues eager collectives (TrainStep._ex_origin)" % (what, stream))
+
+
 def new_capture_group(like=None):
     """A process group over the ranks of ``like`` (None: the world) that is used ONLY inside hipGraph captures.
 
@@ -96,6 +143,8 @@ def all_to_all(out, inp, group=None):
         dist.all_to_all_single(o, inp.cpu(), group=group)
         out.copy_(o)
     else:
+        if inp.is_cuda:
+            EagerCollectiveStreams.note()
         dist.all_to_all_single(out, inp, group=group)
     return out
 
@@ -290,6 +339,7 @@ class GradSync:
             dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
             try:
                 t = torch.ones(1, device=dev)
+                EagerCollectiveStreams.note()
                 dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
                 self.avg = abs(float(t.item()) - 1.0) < 1e-6
             except Exception:
@@ -305,6 +355,7 @@ class GradSync:
         if self.nccl:
             op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
             group = self.capture_group if (self.capture_group is not None and _capturing()) else self.group
+            EagerCollectiveStreams.note()
             return (dist.all_reduce(seg, op=op, group=group, async_op=True), seg)
         self(seg)                                    # gloo: synchronous, host-staged
         return None
@@ -323,6 +374,7 @@ class GradSync:
             return flat_grad
         if self.nccl:
             group = self.capture_group if (self.capture_group is not None and _capturing()) else self.group
+            EagerCollectiveStreams.note()
             dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, group=group)
             if not self.avg:
                 flat_grad.div_(self.world)
@@ -358,6 +410,8 @@ def reduce_input_flags(oob, overflow, group=None, world=None, extra=None):
             dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
             f = h
         else:
+            if f.is_cuda:
+                EagerCollectiveStreams.note()
             dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)
     return tuple(int(v) for v in f.tolist())
 

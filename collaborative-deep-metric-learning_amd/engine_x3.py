@@ -151,6 +151,8 @@ def refresh_weights(p, ws):
     ops.split_f32_bf16x3(p.W1, ws.W1T, L.Fp, transpose=True)        # [Hp][3 Fp]
     ops.split_f32_bf16x3(p.W2, ws.W2T, L.Hp, transpose=True)        # [Dp][3 Hp]
     ops.split_f32_bf16x3(p.W2, ws.W2, L.Dp)                         # [Hp][3 Dp]
+    if getattr(ws, "W1n", None) is not None:                        # trainable catalogue: dx_hat = dz1 . W1^T reads W1 as it is
+        ops.split_f32_bf16x3(p.W1, ws.W1n, L.Hp)                    # [Fp][3 Hp]
 
 
 def tower_forward(p, ws, normalize=True):

@@ -190,8 +190,17 @@ class TrainStep:
         self.grad_norms = torch.zeros((4, 2), dtype=f32, device=dev)   # per variable: |g|, |w|^2
         self.train_table = bool(train_table)
         if self.train_table:
-            if self.bf16 or self.x3 or optimizer != "adam":
-                raise ValueError("train_table goes with the fp32 path and the Adam optimizer")
+            if self.bf16 or optimizer != "adam" or precision == "f32x3-3":
+                # (config 4's catalogue is fp16: it has no fp32 master rows for Adam to move by 1e-2 * 2^-11 of a value)
+                raise ValueError("train_table goes with an fp32 catalogue (precision 'f32x3' or 'f32') and the Adam optimizer")
+            if self.x3:
+                # the row gradient dLoss/dx_hat = dz1 . W1^T is one more fp32 product on the plane kernels (k-contiguous
+                # form: dz1's planes as they are, W1 in its NATURAL orientation [F][hi H | mid H | lo H] -- a third plane
+                # copy of W1 that the Adam launch writes with the update, as it does W2's two)
+                if getattr(self.ws, "transposed", False) or self.ws.dz1 is None:
+                    raise ValueError("train_table needs the row-major activation layout of the f32x3 path")
+                self.ws.W1n = torch.zeros((self.layout.Fp, 3 * self.layout.Hp), dtype=torch.bfloat16, device=dev)
+                engine_x3.refresh_weights(self.params, self.ws)
             self.tab_m = torch.zeros_like(table.data)
             self.tab_v = torch.zeros_like(table.data)
             self.tab_head = torch.full((table.n_rows,), -1, dtype=i32, device=dev)
@@ -443,7 +452,11 @@ class TrainStep:
         catalogue rows they came from (on their owners when the table is sharded).  Runs
         before the dense update: it needs this step's W1 and step counter."""
         L, p, t = self.layout, self.params, self.table
-        ops.fc_bwd_data(self.ws.dz1, p.W1, None, self.dxh, self.R, L.Fp, L.Hp)
+        if self.x3:
+            ops.gemm_bf16x3_nt(ops.BE_F32, self.ws.dz1, L.Hp, self.ws.W1n, L.Hp, self.dxh, self.R, L.Fp, L.Hp,
+                               products=self.ws.products)
+        else:
+            ops.fc_bwd_data(self.ws.dz1, p.W1, None, self.dxh, self.R, L.Fp, L.Hp)
         idx, rows = self.idx, self.dxh
         if self.exchange is not None:
             idx, rows = self.exchange.scatter_back(self.dxh)
@@ -498,8 +511,10 @@ class TrainStep:
             kw = dict(lr_dev=self.lr_dev, t_dev=self.step_dev)
             b1, b2 = slice(o[1], o[1] + L.Hp), slice(o[3], o[3] + L.Dp)
             vec = lambda sl: (p.flat[sl], p.grad[sl], self.m[sl], self.v[sl])
+            w1n = getattr(ws, "W1n", None)                 # trainable table: W1's planes in their natural orientation too
             ops.adam_matrix_bf16(p.W1, mat(p.grad, 0, L.Fp, L.Hp), mat(self.m, 0, L.Fp, L.Hp),
-                                 mat(self.v, 0, L.Fp, L.Hp), 0.0, 1, wt=ws.W1T, plane_t=L.Fp, bias=vec(b1), **kw)
+                                 mat(self.v, 0, L.Fp, L.Hp), 0.0, 1, wt=ws.W1T, plane_t=L.Fp, bias=vec(b1),
+                                 **(dict(kw, wc=w1n, plane_c=L.Hp) if w1n is not None else kw))
             ops.adam_matrix_bf16(p.W2, mat(p.grad, 2, L.Hp, L.Dp), mat(self.m, 2, L.Hp, L.Dp),
                                  mat(self.v, 2, L.Hp, L.Dp), 0.0, 1, wt=ws.W2T, plane_t=L.Hp, wc=ws.W2, plane_c=L.Dp,
                                  bias=vec(b2), advance_tickets=self.adam_tickets, **kw)
@@ -652,6 +667,12 @@ class TrainStep:
     def _capture(self, fn=None, origin=None):
         """Record ``fn`` (default: the whole step) into a hipGraph.  ``origin``: the stream the capture
         starts on (default: a fresh one) -- RCCL's communicator stream is then one fork from it."""
+        if origin is not None:
+            # the invariant the round-5 abort taught: no stream that ever carried an eager RCCL collective enters a capture
+            # (the current stream is only waited on before / after the capture, it is not part of it; a fresh origin cannot
+            # have carried anything).  Checked before anything else touches the device.
+            from .dist import EagerCollectiveStreams
+            EagerCollectiveStreams.assert_clean_origin(origin)
         torch.cuda.synchronize(self.device)
         self._ensure_capture_groups()
         # (RCCL collectives recorded below go through the hooks' capture-only process groups -- dist.new_capture_group:

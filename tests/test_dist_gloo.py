@@ -176,3 +176,24 @@ def test_shard_bounds_cover_catalogue():
         per = cdist.shard_bounds(n, w, 0)[2]
         for r in (0, n // 2, n - 1):
             assert spans[r // per][0] <= r < spans[r // per][1]
+
+
+def test_capture_origin_that_carried_an_eager_collective_is_refused():
+    """The arrangement of rounds 3-4 that ended a process in round 5: the split form's exchange graph
+    captured with the PREFETCH stream -- which carries the eager exchanges' work events -- as capture origin.  Every
+    collective entry point of cdml_amd.dist notes the stream it was issued on; TrainStep._capture refuses such an origin
+    before it touches the device (stand-in stream objects: no GPU here)."""
+    from cdml_amd import dist as cdist, train
+
+    class Stream:
+        def __init__(self, handle):
+            self.cuda_stream, self.device_index = handle, 0
+
+    prefetch, own = Stream(0x7f0000001000), Stream(0x7f0000002000)
+    cdist.EagerCollectiveStreams.note(prefetch)            # what an eager exchange on the prefetch stream leaves behind
+    ts = object.__new__(train.TrainStep)                   # (no buffers: the check comes first)
+    with pytest.raises(RuntimeError, match="hipErrorCapturedEvent"):
+        ts._capture(lambda: None, origin=prefetch)
+    assert cdist.EagerCollectiveStreams.carried(Stream(0x7f0000001000))      # identity is the native handle, not the object
+    cdist.EagerCollectiveStreams.assert_clean_origin(own)
+    assert not cdist.EagerCollectiveStreams.carried(own)

@@ -22,6 +22,8 @@ CFG = dict(n_rows=3000, F=200, H=300, D=64, B=32, steps=2, precision="f32")
 CFG_BF16 = dict(CFG, B=64, precision="bf16")
 # trainable catalogue rows: row gradients travel back to the owners (RowExchange.scatter_back)
 CFG_TABLE = dict(CFG, train_table=True)
+# the same on the headline's arithmetic (round 6): dLoss/dx_hat = dz1 . W1^T as a sixth product on the plane kernels
+CFG_TABLE_X3 = dict(CFG, F=250, H=500, D=256, B=128, precision="f32x3", train_table=True)
 # the fp32 tower on the bf16 MFMA (three exact planes per operand): rows cross the wire in fp32 and are split on arrival
 CFG_X3 = dict(CFG, F=250, H=500, D=256, B=128, precision="f32x3")
 CFG_X3_BUCKETS = dict(CFG_X3, F=500)              # F padded to 512: dW1 in two 256-row blocks, an all-reduce after each
@@ -89,9 +91,9 @@ def _worker(rank, world, port, q, CFG=CFG):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_X3, CFG_X3_BUCKETS, CFG_TABLE, CFG_W4, CFG_C3, CFG_C3_X3, CFG_C4, CFG_C3_W4, CFG_C3_TWO,
+@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_X3, CFG_X3_BUCKETS, CFG_TABLE, CFG_TABLE_X3, CFG_W4, CFG_C3, CFG_C3_X3, CFG_C4, CFG_C3_W4, CFG_C3_TWO,
                                  CFG_C3_SINGLE, CFG_C4_SINGLE],
-                         ids=["f32", "bf16", "f32x3", "f32x3-bucketed", "trainable-table", "4-ranks", "config3-full-size",
+                         ids=["f32", "bf16", "f32x3", "f32x3-bucketed", "trainable-table", "trainable-table-f32x3", "4-ranks", "config3-full-size",
                               "config3-full-size-f32x3", "config4-full-size",
                               "config3-full-size-4-ranks", "config3-full-size-sync-two", "config3-full-size-sync-single",
                               "config4-full-size-sync-single"])
@@ -318,6 +320,18 @@ def _nccl_graph_worker(port, q):
             _say("resumed")
             if not same():
                 msg = "mid-run resume differs from eager: %g" % diff()
+        if msg == "ok":
+            # the prefetch stream has carried eager exchanges by now -- as a capture origin (rounds 3-4's
+            # arrangement, the round-5 abort) it is refused before anything is captured; the stream the split form
+            # does capture from is clean
+            try:
+                s1._capture(lambda: None, origin=s1.prefetch.stream)
+                msg = "a capture from the prefetch stream was not refused"
+            except RuntimeError as e:
+                if "hipErrorCapturedEvent" not in str(e):
+                    msg = "unexpected refusal: %s" % e
+            if cdist.EagerCollectiveStreams.carried(s1._ex_origin):
+                msg = "the exchange graph's own origin stream carried an eager collective"
         g1._graphs.clear()                               # graphs go before the communicators they recorded
         s1._graphs.clear()
         torch.cuda.synchronize()
@@ -404,6 +418,14 @@ def test_bench_two_rank_rehearsal(gpu, launcher):
     assert comm["exchange_bytes"] > 2 * 256 * 1536 * 4 and comm["allreduce_bytes"] == 4 * 9180416
     assert out["warmup_effective"]["of_which_grad_sync_probe"] == 21
     assert np.isfinite(out["loss"])
+    # every rank's own facts, the exchange geometry and what steers RCCL, in the one line
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and all(r["ms_per_step"] > 0 for r in out["ranks"])
+    assert all(r["exchange_overflow_flag"] == 0 and r["pair_id_out_of_range_flag"] == 0 for r in out["ranks"])
+    ex = out["exchange"]
+    assert ex["requests_per_rank"] == 512 and ex["overflow_flag_max"] == 0 and ex["capacity_factor"] == 1.25
+    assert ex["capacity_slots_per_peer"] * 2 * (4 + 1536 * 4) == comm["exchange_bytes"]
+    assert "env" in out["comm_backend"] and "algo" in out["comm_backend"]
+    assert out["config"]["rows_per_triplet"] == 2 and abs(out["config"]["value_three_row_equivalent"] - out["value"] * 2 / 3) < 0.2
 
 
 def test_bench_four_rank_full_size_rehearsal(gpu):
@@ -435,6 +457,8 @@ def test_bench_four_rank_full_size_rehearsal(gpu):
     assert comm["exchange_bytes"] == 4 * 5512 * (4 + 1536 * 4)
     assert out["scaling_base"]["per_gpu_batch"] == 8192 and out["scaling_base"]["rows_global"] == 10000000
     assert np.isfinite(out["loss"]) and out["value"] > 0
+    assert [r["rank"] for r in out["ranks"]] == [0, 1, 2, 3] and out["exchange"]["capacity_slots_per_peer"] == 5512
+    assert out["exchange"]["overflow_flag_max"] == 0
 
 
 def _overflow_worker(rank, world, port, q, ckpt_dir):

@@ -69,21 +69,26 @@ def test_table_adam_rows_vs_oracle(cd, F, stride):
     assert not np.allclose(m3.cpu().numpy()[touched, :F], got_m[touched, :F], atol=1e-7)
 
 
-def test_train_step_with_trainable_table(cd):
-    """The step's table update = oracle update fed with the device's own dz1 and W1."""
-    N, F, H, D, B = 400, 96, 160, 32, 32
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+def test_train_step_with_trainable_table(cd, precision):
+    """The step's table update = oracle update fed with the device's own dz1 and W1 -- on both fp32 paths (round 6: on the
+    split-fp32 path the row gradient dz1 . W1^T is a sixth product on the plane kernels, W1's planes in their natural
+    orientation written by the Adam launch)."""
+    N, F, H, D, B = 400, 96, 160, 32, 128
     table = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev)
     pairs = torch.as_tensor(osynth.cowatch_pairs(N, 60, 0)).to(cd.dev)
     ts = cd.train.TrainStep(table, pairs, B, hidden_size=H, output_size=D, mode="uniform", device=cd.dev,
-                            train_table=True)
+                            train_table=True, precision=precision)
     before = table.data.clone()
     ts.fetch(); ts.forward_loss(); ts.backward()
     W1 = ts.params.unpadded()[0].cpu().numpy().astype(np.float64)
-    dz1 = ts.ws.dz1[:, :H].cpu().numpy().astype(np.float64)
+    dz1 = (ts.ws.dz1_f32() if precision == "f32x3" else ts.ws.dz1)[:, :H].cpu().numpy().astype(np.float64)
     idx = ts.idx.cpu().numpy()
     ts.update_table()
     torch.cuda.synchronize()
     G = otable.grad_xhat(dz1, W1)
+    got_G = ts.dxh[:, :F].cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(got_G - G) <= 1e-5 * np.linalg.norm(G)          # the row gradient itself, before Adam's sign amplifier
     want, _, _ = otable.table_adam_rows(before[:, :F].cpu().numpy(), np.zeros((N, F)), np.zeros((N, F)), idx, G, 1, 0.01)
     got = table.data[:, :F].cpu().numpy()
     # the first Adam step moves every touched entry by lr * sign(g): entries whose gradient is
@@ -96,10 +101,58 @@ def test_train_step_with_trainable_table(cd):
     assert np.array_equal(got[untouched], before[untouched, :F].cpu().numpy())
     # and the whole step runs, eagerly and from a captured graph, to the same bits
     mk = lambda g: cd.train.TrainStep(cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev), pairs, B, hidden_size=H,
-                                      output_size=D, mode="uniform", device=cd.dev, train_table=True, use_graph=g)
+                                      output_size=D, mode="uniform", device=cd.dev, train_table=True, use_graph=g,
+                                      precision=precision)
     a, b = mk(False), mk(True)
     for _ in range(4):
         a.step(); b.step()
     torch.cuda.synchronize()
     assert torch.equal(a.table.data, b.table.data) and torch.equal(a.params.flat, b.params.flat)
     assert not torch.equal(a.table.data, before)
+    if precision == "f32x3":                               # the natural-orientation planes ARE the updated W1
+        L = a.layout
+        w1n = a.ws.W1n[:, :L.Hp].float() + a.ws.W1n[:, L.Hp:2 * L.Hp].float() + a.ws.W1n[:, 2 * L.Hp:].float()
+        assert torch.equal(w1n, a.params.W1)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+def test_trainable_table_production_width(cd, precision):
+    """the trainable catalogue at PRODUCTION width (F = 1500, H = 5000, D = 256), 120 000 rows, batch 512
+    triplets (1 536 gathered rows, duplicates included), on both fp32 paths: the row gradient dz1 . W1^T (K = 5 000) against
+    fp64 on the device's own operands, then the lazy-Adam row update against oracle/table.py; rows nobody gathered keep
+    their bits; two steps run and move the rows again."""
+    N, F, H, D, B = 120000, 1500, 5000, 256, 512
+    table = cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev)
+    pairs = torch.as_tensor(osynth.cowatch_pairs(N, 4000, 0)).to(cd.dev)
+    ts = cd.train.TrainStep(table, pairs, B, hidden_size=H, output_size=D, mode="uniform", device=cd.dev,
+                            train_table=True, precision=precision)
+    ts.fetch(); ts.forward_loss(); ts.backward()
+    idx = ts.idx.cpu().numpy()
+    touched = np.unique(idx)
+    before = table.data[torch.as_tensor(touched).to(cd.dev).long()][:, :F].cpu().numpy()
+    probe = torch.arange(0, N, 997, device=cd.dev)                        # a sample of the whole table for the "untouched" check
+    before_probe = table.data[probe].clone()
+    W1 = ts.params.unpadded()[0].cpu().numpy().astype(np.float64)
+    dz1 = (ts.ws.dz1_f32() if precision == "f32x3" else ts.ws.dz1)[:, :H].cpu().numpy().astype(np.float64)
+    ts.update_table()
+    torch.cuda.synchronize()
+    G = otable.grad_xhat(dz1, W1)
+    got_G = ts.dxh[:, :F].cpu().numpy().astype(np.float64)
+    rel = np.linalg.norm(got_G - G) / np.linalg.norm(G)
+    assert rel <= 1e-5, rel
+    assert (ts.dxh[:, F:] == 0).all()                                     # pad columns of the row gradient
+    # oracle update on the touched rows only (ids remapped to their position among the touched rows)
+    remap = np.searchsorted(touched, idx)
+    want, _, _ = otable.table_adam_rows(before, np.zeros_like(before), np.zeros_like(before), remap, G, 1, 0.01)
+    got = table.data[torch.as_tensor(touched).to(cd.dev).long()][:, :F].cpu().numpy()
+    diff = np.abs(got - want)
+    assert np.mean(diff > 1e-5) < 0.01 and diff.max() <= 0.0201, (float(np.mean(diff > 1e-5)), float(diff.max()))
+    assert np.abs(got - before).max() > 0.005
+    mask = ~torch.isin(probe, torch.as_tensor(touched).to(cd.dev))
+    assert torch.equal(table.data[probe][mask], before_probe[mask])
+    ts.apply_gradients()
+    ts.global_step += 1
+    for _ in range(2):
+        ts.step()
+    torch.cuda.synchronize()
+    assert np.isfinite(ts.loss()) and bool(torch.isfinite(table.data[probe]).all())
