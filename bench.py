@@ -383,7 +383,9 @@ def install_timers(kt, L, bf16):
         # (by epilogue: 6 / 8 / 9 = FC1 with plane output, 1 = FC2, 7 / 10 = the data gradient, 3 = a weight gradient in the
         # k-contiguous form of the transposed activation layout; the k-strided form: FC2 when it carries a bias)
         patch("gemm_bf16x3_nt", lambda e, A, pa, Bm, pb, C, M, N, K, **k:
-              {6: "fc1_fwd", 8: "fc1_fwd", 9: "fc1_fwd", 1: "fc2_fwd", 7: "dH1", 10: "dH1", 12: "dH1"}.get(e, "dW1" if N == L.Hp else "dW2"))
+              {6: "fc1_fwd", 8: "fc1_fwd", 9: "fc1_fwd", 1: "fc2_fwd", 7: "dH1", 10: "dH1", 12: "dH1"}.get(
+                  e, "dX" if N == L.Fp else "dW1" if N == L.Hp else "dW2"))      # (dX: the trainable table's row gradient dz1 . W1^T)
+        patch("table_adam_rows", "table_adam")
         patch("gemm_bf16x3_tnk", lambda A, ma, a0, Bm, nb, b0, out, M, N, K, **k: "dW1" if N == L.Hp else "dW2")
         patch("gemm_bf16x3_tn", lambda A, pa, Bm, pb, C, M, N, K, **k:
               "fc2_fwd" if k.get("bias") is not None else ("dW1" if N == L.Hp else "dW2"))
@@ -395,7 +397,8 @@ def install_timers(kt, L, bf16):
         patch("fc_lrelu_fwd", lambda x, W, b, y, M, K, N, *a, **k: "fc1_fwd" if N == L.Hp else "fc2_fwd")
         patch("fc_bwd_weight", lambda x, dy, dW, db, ws, M, K, N: "dW1" if N == L.Hp else "dW2")
         patch("fc_bwd_weight2", "dW")             # single GPU: both products in one stream-K launch
-        patch("fc_bwd_data", "dH1")
+        patch("fc_bwd_data", lambda x, W, m, o, M, N, K, **k: "dX" if N == L.Fp else "dH1")
+        patch("table_adam_rows", "table_adam")
         patch("adam_step", "adam")
         patch("lars_step", "lars")
         patch("lars_multi", "lars")
@@ -474,7 +477,7 @@ def gemm_records(kt, R, bf16, sampled, how, single_gpu, x3_products=0, pmc_name=
                                "frac": round(ach1 / peak, 4), "traffic": tr1, "traffic_source": src1,
                                "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": flops_gemm}
     kern = {}
-    for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "adam", "adam_w1", "adam_w2", "adam_bias", "lars",
+    for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW", "dW1", "dW2", "dX", "table_adam", "adam", "adam_w1", "adam_w2", "adam_bias", "lars",
               "split_planes", "transpose_planes", "score_gemm", "semihard_select", "semihard_mine", "hinge_indexed", "l2norm_fwd",
               "l2norm_bwd"):
         if kt.mean_ms(k) is not None:
@@ -766,6 +769,44 @@ def rec_dp_form(dev, args, n_s, n_w, keep):
             dist.destroy_process_group()
 
 
+def rec_train_table(dev, args, n_s, n_w, keep):
+    """north_star's extension of the path ("the catalogue feature table and its Adam states shard row-wise"; the reference's
+    features are a frozen placeholder, train.py:265): the headline workload -- 10 M rows, batch 8192, in-batch negatives, the
+    headline's precision -- with the catalogue rows TRAINED: one more product per step (dLoss/dx_hat = dz1 . W1^T, 245.8 GFLOP
+    at these shapes, on the plane kernels since round 6), then per touched row the l2norm backward and the lazy-Adam update
+    (csrc/table_adam.hip).  Table + its two Adam states: 184 GB resident in one HBM.  Runs LAST on the shared catalogue: it
+    changes its rows."""
+    from cdml_amd import train
+    x3 = 6 if args.precision == "f32x3" else 0
+    t10, p10 = table_10m(keep, dev)
+    ts = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch", optimizer="adam",
+                         base_learning_rate=0.01, seed=1234, weight_seed=42, device=dev, precision=args.precision,
+                         train_table=True)
+    n, w = max(n_s, 30), max(n_w, 5)
+    el, kt, sampled, how = measure_job(ts, n, w, dev, None if x3 else False)
+    R = ts.R
+    out = {"workload": "the headline workload with a TRAINABLE catalogue: 10000000 videos x 1500-d fp32 + Adam m, v per row (184 GB "
+                       "in one HBM), batch 8192 triplets, in-batch negatives, Adam on weights and on the gathered rows (lazy), "
+                       "full step incl. dx_hat = dz1 . W1^T and the row update",
+           "precision": args.precision, "value": round(8192 * n / el, 1), "unit": "triplets/s",
+           "ms_per_step": round(el / n * 1e3, 4), "steps": n, "warmup": w, "loss": round(ts.loss(), 6),
+           "gather_steps_per_launch": ts.gather_ahead}
+    out.update(gemm_records(kt, R, False, sampled, how, False, x3_products=x3))
+    if kt.mean_ms("dX") is not None:
+        peak = round(PEAK_BF16_MFMA_TFLOPS / x3, 1) if x3 else PEAK_F32_MFMA_TFLOPS
+        ach = 2.0 * R * F * H / (kt.mean_ms("dX") * 1e-3) / 1e12
+        out["roofline_dx"] = {"bound": "mfma", "kernel": "k_gemm_bf16_256<false, 3, true, true, ..., R6> (dz1 planes . W1 planes^T, fp32 out)"
+                                                           if x3 else "k_gemm_f32 NT (dz1 . W1^T)",
+                              "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                              "launch_ms": round(kt.mean_ms("dX"), 4), "flop_per_launch": 2.0 * R * F * H}
+    if kt.mean_ms("table_adam") is not None:
+        # per touched row: the row, m, v read and written (6 x 6 KB) + its gathered gradient rows read (R x 6 KB in all)
+        out["table_adam"] = {"launch_ms": round(kt.mean_ms("table_adam"), 4),
+                             "bytes_bound": "<= %d rows x (6 KB gradient + 6 x 6 KB of row / m / v)" % R,
+                             "achieved_GBs_upper": round(R * 7 * F * 4 / (kt.mean_ms("table_adam") * 1e-3) / 1e9, 1)}
+    return out
+
+
 def rec_config4(dev, args, n_s, n_w):
     from cdml_amd import engine_bf16, train
     t = engine_bf16.FeatureTableF16.synthetic(10000000, F, seed=0, device=dev)
@@ -815,8 +856,8 @@ def rec_reference_recipe(dev, args, n_s, n_w, table):
     ts = train.TrainStep(table, pairs, 1024, output_size=D, hidden_size=H, margin=MARGIN, mode="uniform",
                          optimizer="lars", base_learning_rate=1.0, device=dev, gather_ahead=args.gather_ahead,
                          precision="f32x3" if x3 else "f32")
-    n = max(n_s, 60)
-    el, kt, sampled, how = measure_job(ts, n, max(n_w, 5), dev, None if x3 else False)
+    n = max(n_s, 200)                                  # a 0.6-ms step: 60 of them timed the clock ramp (0.674 against 0.643 ms as the job)
+    el, kt, sampled, how = measure_job(ts, n, max(n_w, 20), dev, None if x3 else False)
     out = {"workload": "reference recipe (train.py:354-364): %d videos x 1500-d fp32, batch 1024 triplets (3072 rows), "
                        "uniform negatives, LARS lr 1.0, margin 0.8, full step" % table.n_rows,
            "precision": "f32x3" if x3 else "f32",
@@ -934,6 +975,33 @@ def rec_predict(dev, precision, n_rows=10000000, chunk=100000, reps=2):
                       "f32 values as 3 exact bf16 planes, 6 plane products on the bf16 MFMA (peak = bf16 dense peak / 6)")}
 
 
+def rec_knn(dev, n=343455, k=51, precision="f32x3"):
+    """The kNN export (faiss_knn.py:82-131 `calc_knn`; the reference's production catalogue: doc_location = 343455,
+    faiss_knn.py:389; nearest_num = 51 = 50 neighbours + the query): EXACT self-kNN of n unit 256-d embeddings -- the
+    reference builds an approximate HNSW index on the CPU.  Algorithmic work: 2 n^2 D flop of inner products; the n^2
+    scores are produced and consumed in 128-MiB blocks that stay in the Infinity Cache."""
+    from cdml_amd import knn
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    e = torch.randn(n, D, device=dev, generator=g)
+    knn.knn_search(e[:8192], e[:8192], k, precision=precision)            # (loads the kernels)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    Dk, Ik = knn.knn_search(e, e, k, precision=precision)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    flops = 2.0 * n * n * D
+    peak = round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if precision == "f32x3" else PEAK_F32_MFMA_TFLOPS
+    self_first = bool((Ik[:, 0] == torch.arange(n, device=dev)).all())
+    return {"workload": "exact self-kNN export: %d unit embeddings x %d-d, k = %d (faiss_knn.py:82-131, :389), l2-normalise + "
+                        "inner products + per-query top-k merge, results in HBM" % (n, D, k),
+            "precision": precision, "value": round(n / el, 1), "unit": "queries/s", "seconds": round(el, 4),
+            "inner_product_tflops": round(flops / el / 1e12, 2), "frac_of_mfma_peak": round(flops / el / 1e12 / peak, 4),
+            "peak_tflops": peak, "score_bytes_through_cache": 2.0 * n * n * 4,
+            "score_stream_TBs": round(2.0 * n * n * 4 / el / 1e12, 2),
+            "query_is_its_own_first_neighbour": self_first, "mean_second_neighbour_d2": round(float(Dk[:, 1].mean()), 5)}
+
+
 def rec_learnable(dev, args, n_s, n_w, B):
     from cdml_amd import train
     tl, pl = learnable_catalogue(200000, dev)
@@ -978,7 +1046,7 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary records of the default N=1 line")
     ap.add_argument("--extras", default=None,
-                    help="comma list of secondary records to run (default: all): config1,config2_semihard,dp_form_one_gpu,"
+                    help="comma list of secondary records to run (default: all): config1,config2_semihard,dp_form_one_gpu,train_table,"
                          "config4_per_gpu,reference_recipe,fusion_resnet,predict,data_learnable,f32_mfma")
     ap.add_argument("--only", default=None, choices=["reference_recipe", "fusion_resnet", "data_learnable"],
                     help="run ONE secondary record as the job (its JSON line; for rocprofv3 runs of that workload)")
@@ -1299,8 +1367,8 @@ def main():
             torch.cuda.empty_cache()
             other = "f32" if x3 else "f32x3"
             other_name = "f32_mfma" if x3 else "f32x3"
-            want = set((args.extras or "config1,config2_semihard,dp_form_one_gpu,config4_per_gpu,reference_recipe,fusion_resnet,"
-                                       "predict,data_learnable," + other_name).split(","))
+            want = set((args.extras or "config1,config2_semihard,dp_form_one_gpu,train_table,config4_per_gpu,reference_recipe,fusion_resnet,"
+                                       "predict,knn,data_learnable," + other_name).split(","))
             n_s, n_w = min(args.steps, 30), min(max(args.warmup, 3), 5)
             keep = {"t10": table, "p10": pairs}            # the headline's own catalogue serves dp_form_one_gpu
             del table, pairs
@@ -1318,6 +1386,7 @@ def main():
                     out[name] = {"error": repr(e)[:300]}
                 torch.cuda.empty_cache()
             attempt("dp_form_one_gpu", lambda: rec_dp_form(dev, args, n_s, n_w, keep))
+            attempt("train_table", lambda: rec_train_table(dev, args, n_s, n_w, keep))     # (last user of the 10 M-row table: it trains it)
             keep.clear()
             torch.cuda.empty_cache()
             # the 1 M-row catalogue of configs 1 and 2 (and of the reference's own recipe)
@@ -1334,6 +1403,7 @@ def main():
             attempt("config4_per_gpu", lambda: rec_config4(dev, args, n_s, n_w))
             attempt("predict", lambda: {"f32": rec_predict(dev, "f32"), "f32x3": rec_predict(dev, "f32x3"),
                                         "bf16": rec_predict(dev, "bf16")})
+            attempt("knn", lambda: rec_knn(dev))
         if world == 1 and not args.no_cpu_baseline:
             set_phase("cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)

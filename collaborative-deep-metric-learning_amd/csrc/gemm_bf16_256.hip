@@ -1620,7 +1620,9 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
     if (g.colsum_partial) return launch_x3_1<TN, EPI, false, true>(g, g.tiles_m * g.tiles_n, splits, s);
   }
   const int tiles = g.tiles_m * g.tiles_n;
-  if constexpr (!TN && (EPI == BE_BIAS_LRELU_X3 || EPI == BE_MASK_X3 || EPI == BE_ROWBIAS_LRELU_X3)) {
+  // (round 6: the unsplit fp32-output product too -- the trainable table's row gradient dz1 . W1^T is 384 tiles at 16 384 rows:
+  // a full round and half a round)
+  if constexpr (!TN && (EPI == BE_BIAS_LRELU_X3 || EPI == BE_MASK_X3 || EPI == BE_ROWBIAS_LRELU_X3 || EPI == BE_F32)) {
     const int full = tiles / kNumCU * kNumCU, rem = tiles - full;
     if (walk == 2 && splits == 1 && rem > 0 && 2 * rem <= kNumCU && rem % 8 == 0 && full % 8 == 0 && x3_half_tiles()) {
       BArgs h = g;

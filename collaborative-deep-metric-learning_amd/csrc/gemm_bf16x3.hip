@@ -101,10 +101,24 @@ bool x3_kmajor() {
 // leave the chip under-filled (8 192 rows: 128 blocks) the SAME slabs run as 128 x 256 half tiles (gemm_bf16_256.hip),
 // so the partition stays a function of K alone.
 // Wider outputs are never split: their tiles fill the chip at every batch size the step uses.
-int x3_nt_splits(int N, int ktiles) {
+// Round 6: the slab length is a function of K and of the ROW-TILE CLASS.  The 120-step slabs were chosen for BASELINE's
+// batches; the reference's own recipe (B = 1 024: 3 072 rows = 12 row tiles) fills 96 half-tile blocks with them and ran
+// 0.622 against 0.643 ms/step with 60-step slabs (profiles/r05_reference_recipe_slab_steps_ab.txt).  Rule: where the
+// 120-step slabs give at most 64 full tiles (128 half-tile blocks: half the chip) the slabs are 60 steps long -- twice the
+// blocks -- else 120.  Within a class the partition is still a function of K alone (a batch whole or in row blocks of the
+// same class: the same bits); ACROSS the class boundary the last bits of z differ.  A caller that needs one partition for
+// every call size pins it: cdml_x3_slab_steps(120) (thread-local; catalogue inference does, so an embedding has the same
+// bits in 4 096- and 49 152-row chunks: test_embedding_bits_do_not_depend_on_the_chunk).
+thread_local int tl_slab_steps = 0;                        // 0 = by class
+int x3_nt_splits(int N, int ktiles, int tiles_m) {
   if (N / 256 != 1) return 1;
-  const char *e = getenv("CDML_X3_SLAB_STEPS");            // (A/B: 60 = the partition of rounds 4)
-  const int steps = e && atoi(e) >= 12 ? atoi(e) / 6 * 6 : 120;
+  const char *e = getenv("CDML_X3_SLAB_STEPS");            // (A/B runs: one length for everything)
+  int steps = e && atoi(e) >= 12 ? atoi(e) / 6 * 6 : tl_slab_steps;
+  if (steps < 12) {
+    int s120 = ktiles / 120;
+    s120 = s120 < 1 ? 1 : (s120 > 16 ? 16 : s120);
+    steps = tiles_m * s120 <= 64 ? 60 : 120;
+  }
   const int s = ktiles / steps;
   return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
@@ -144,10 +158,21 @@ extern "C" int cdml_split_f32_bf16x3(const float *src, int64_t ld_src, int rows,
   return check_launch("split_f32_bf16x3");
 }
 
+extern "C" int cdml_x3_slab_steps(int steps) {
+  const int prev = tl_slab_steps;
+  tl_slab_steps = steps >= 12 ? steps / 6 * 6 : 0;
+  return prev;
+}
+
 extern "C" size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int products) {
   if (M <= 0 || N <= 0 || K <= 0 || (products != 3 && products != 6) || K % 64) return 0;
   const int ktiles = products * (K / 64);
-  const int requested = tn ? gemm_bf16_256_splits(M, N, ktiles * 64) : x3_nt_splits(N, ktiles);
+  // (k-contiguous form: the larger of the two slab lengths' counts -- a workspace serves any pin of cdml_x3_slab_steps)
+  int requested = tn ? gemm_bf16_256_splits(M, N, ktiles * 64) : x3_nt_splits(N, ktiles, (M + 255) / 256);
+  if (!tn && N / 256 == 1) {
+    const int s60 = ktiles / 60 < 1 ? 1 : (ktiles / 60 > 16 ? 16 : ktiles / 60);
+    if (s60 > requested) requested = s60;
+  }
   int splits = requested, per = 0, s2 = requested;
   x3_split_geometry(ktiles, requested, products == 6 ? 6 : 2, per, splits);
   x3_split_geometry(ktiles, requested, 2, per, s2);          // (the product-major A/B walk rounds to pairs: never fewer slabs)
@@ -270,7 +295,7 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   g.K = ktiles * 64; g.k_per_split = g.K;
   g.tiles_m = (M + 255) / 256; g.tiles_n = N / 256;
   hipStream_t s = (hipStream_t)stream;
-  int splits = planes_out ? 1 : x3_nt_splits(N, ktiles), per = ktiles;
+  int splits = planes_out ? 1 : x3_nt_splits(N, ktiles, g.tiles_m), per = ktiles;
   if (splits > 1) x3_split_geometry(ktiles, splits, 6, per, splits);   // whole six-step periods of the K-major walk (and an even count)
   if (splits > 1) {
     // The slab form needs the workspace.  workspace == NULL is the caller's explicit choice of ONE pass over K (fewer,

@@ -533,62 +533,192 @@ k_hinge_indexed_fwd(const float *__restrict__ e, int64_t lde, const int32_t *__r
   }
 }
 
-// Backward: one wave per embedded row r sums, in ascending triplet order, its own
-// triplet's term and the terms of every triplet that mined r as its negative
-// (no atomics: bit-reproducible).
+// Backward: the gradient of every embedded row r = its own triplet's term, then the terms of every triplet that mined r
+// as its negative in ascending triplet order (no atomics: bit-reproducible).
+// Round 6: a BLOCK owns 16 consecutive rows (4 per wave) and scans neg_row / scale ONCE (1 024 triplets per pass, 16-B
+// loads), compacting the hits on its rows into an LDS list in ascending triplet order (wave prefix sums over the per-lane
+// hit counts, then the waves' bases); the wave that owns a row walks the list and adds its hits.  Rounds 2-5 gave every
+// ROW a wave that scanned all B triplets itself: 2B waves x 8 B x B = 1 GB of L2 reads at B = 8 192 -- 50 of the 62 us
+// this call took in BASELINE config 2's step; a block per 16 rows reads 64 MB.  (A first version of this round gave a
+// block 64 rows, 16 per wave in sequence: every row costs two or three dependent global round trips, and 1 024 waves
+// walking 16 rows each ran 4 x SLOWER than the scan they replaced -- rows per wave is what bounds this kernel, so it is 4,
+// unrolled, all four rows' loads in flight together.)  Same terms, same order per row: the same bits.
+// Fused tail (z != null): once a row's gradient is complete its wave runs k_l2norm_bwd's arithmetic on it (dz2 = the
+// gradient of the output layer's pre-activation, leaky-relu' included) and, on request, writes dz2's bf16 copy or its
+// three exact planes -- two more launches of config 2's step (l2norm_bwd, split) folded into this one.
+constexpr int kIdxRowsPerWave = 4;
+constexpr int kIdxRows = kIdxRowsPerWave * kWavesPerBlock;      // rows per block
+template <int NCH>
 __global__ void __launch_bounds__(kThreads)
 k_hinge_indexed_bwd(const float *__restrict__ e, int64_t lde, const int32_t *__restrict__ neg_row,
                     const float *__restrict__ scale, int B, int D, float *__restrict__ de,
-                    int64_t ldde) {
+                    int64_t ldde, const float *__restrict__ z, int64_t ldz, float alpha,
+                    float *__restrict__ dz2, int64_t lddz, uint16_t *__restrict__ dz2_bf, int64_t ldbf,
+                    int64_t plane_bf) {
+  __shared__ int s_hit[4 * kThreads];                // (triplet << 4) | row within the block
+  __shared__ int s_cnt[kWavesPerBlock];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int nq = D >> 2;
   const int R = 2 * B;
-  for (int r = blockIdx.x * kWavesPerBlock + wave; r < R; r += gridDim.x * kWavesPerBlock) {
+  const int r0 = blockIdx.x * kIdxRows;
+  const int rw0 = r0 + wave * kIdxRowsPerWave;       // this wave's rows: rw0 .. rw0 + 3
+  // the rows' gradients live in REGISTERS (NCH float4 per lane and row) until they are complete
+  float4 acc[kIdxRowsPerWave][NCH];
+#pragma unroll
+  for (int u = 0; u < kIdxRowsPerWave; ++u) {        // own triplet: anchor or positive role
+    const int r = min(rw0 + u, R - 1);
     const int i = r >> 1;
     const float si = scale[i];
-    const float *er = e + (int64_t)r * lde;
-    float *dr = de + (int64_t)r * ldde;
     const float *a = e + (int64_t)(2 * i) * lde, *p = a + lde;
     const int nr = neg_row[i];
     const float *n = e + (int64_t)(nr >= 0 ? nr : 2 * i) * lde;
-    for (int q = lane; q < nq; q += kWave) {   // own triplet: anchor or positive role
-      const float4 va = ld4(a, q), vp = ld4(p, q), vn = ld4(n, q);
-      st4(dr, q, (r & 1) ? mul4(sub4(vp, va), si) : mul4(sub4(vn, vp), si));
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      if (q < nq) {
+        const float4 va = ld4(a, q), vp = ld4(p, q), vn = ld4(n, q);
+        acc[u][c] = (r & 1) ? mul4(sub4(vp, va), si) : mul4(sub4(vn, vp), si);
+      } else {
+        acc[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
-    // triplets that mined row r as negative, in ascending triplet order: each lane checks four
-    // consecutive triplets per pass (16-B loads of neg_row / scale), hits are rare
-    auto add_term = [&](int jj) {
+  }
+  for (int j0 = 0; j0 < B; j0 += 4 * kThreads) {
+    const int j = j0 + 4 * (int)threadIdx.x;
+    unsigned hits = 0;                               // bit u: triplet j + u mined a row of this block and is active
+    int rl[4] = {0, 0, 0, 0};
+    if (j + 3 < B) {
+      const int4 n4 = *reinterpret_cast<const int4 *>(neg_row + j);
+      const float4 s4 = *reinterpret_cast<const float4 *>(scale + j);
+      rl[0] = n4.x - r0; rl[1] = n4.y - r0; rl[2] = n4.z - r0; rl[3] = n4.w - r0;
+      hits = (unsigned)((unsigned)rl[0] < (unsigned)kIdxRows && s4.x != 0.f) |
+             ((unsigned)((unsigned)rl[1] < (unsigned)kIdxRows && s4.y != 0.f) << 1) |
+             ((unsigned)((unsigned)rl[2] < (unsigned)kIdxRows && s4.z != 0.f) << 2) |
+             ((unsigned)((unsigned)rl[3] < (unsigned)kIdxRows && s4.w != 0.f) << 3);
+    } else {
+      for (int u = 0; u < 4 && j + u < B; ++u) {
+        rl[u] = neg_row[j + u] - r0;
+        hits |= (unsigned)((unsigned)rl[u] < (unsigned)kIdxRows && scale[j + u] != 0.f) << u;
+      }
+    }
+    const int cnt = __popc(hits);
+    int incl = cnt;                                  // inclusive prefix sum over the wave's lanes
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int t = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += t;
+    }
+    if (lane == kWave - 1) s_cnt[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+      const int c = s_cnt[w];
+      base += (w < wave) ? c : 0;
+      total += c;
+    }
+    int pos = base + incl - cnt;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (hits & (1u << u)) s_hit[pos++] = ((j + u) << 4) | rl[u];
+    __syncthreads();
+    for (int h = 0; h < total; ++h) {                // ascending triplets; each wave takes the hits on its own rows
+      const int hv = s_hit[h];
+      const int rloc = hv & 15;
+      if ((rloc >> 2) != wave) continue;
+      const int jj = hv >> 4, u = rloc & 3;
       const float sj = scale[jj];
       const float *aj = e + (int64_t)(2 * jj) * lde;
-      for (int q = lane; q < nq; q += kWave) {
-        const float4 g = mul4(sub4(ld4(aj, q), ld4(er, q)), sj);
-        const float4 cur = ld4(dr, q);
-        st4(dr, q, make_float4(cur.x + g.x, cur.y + g.y, cur.z + g.z, cur.w + g.w));
-      }
-    };
-    const int B4 = B & ~3;
-    for (int j0 = 0; j0 < B4; j0 += 4 * kWave) {
-      const int j = j0 + 4 * lane;
-      unsigned hits = 0;                         // bit u: triplet j + u mined r and is active
-      if (j < B4) {
-        const int4 n4 = *reinterpret_cast<const int4 *>(neg_row + j);
-        const float4 s4 = *reinterpret_cast<const float4 *>(scale + j);
-        hits = (unsigned)(n4.x == r && s4.x != 0.f) | ((unsigned)(n4.y == r && s4.y != 0.f) << 1) |
-               ((unsigned)(n4.z == r && s4.z != 0.f) << 2) | ((unsigned)(n4.w == r && s4.w != 0.f) << 3);
-      }
-      unsigned long long m = __ballot(hits != 0);
-      while (m) {                                // lanes ascending = triplets ascending
-        const int l = __builtin_ctzll(m);
-        m &= m - 1;
-        const unsigned h = (unsigned)__shfl((int)hits, l, 64);
+      const float *er = e + (int64_t)(r0 + rloc) * lde;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (h & (1u << u)) add_term(j0 + 4 * l + u);
+      for (int c = 0; c < NCH; ++c) {
+        const int q = lane + kWave * c;
+        if (q >= nq) continue;
+        const float4 g = mul4(sub4(ld4(aj, q), ld4(er, q)), sj);
+#pragma unroll
+        for (int uu = 0; uu < kIdxRowsPerWave; ++uu)   // (u is wave-uniform: a select, not a dynamic register index)
+          if (uu == u) acc[uu][c] = make_float4(acc[uu][c].x + g.x, acc[uu][c].y + g.y, acc[uu][c].z + g.z, acc[uu][c].w + g.w);
       }
     }
-    for (int jj = B4; jj < B; ++jj)              // B not a multiple of 4: the last few, one by one
-      if (neg_row[jj] == r && scale[jj] != 0.f) add_term(jj);
+    __syncthreads();                                 // the list is reused by the next pass
+  }
+#pragma unroll
+  for (int u = 0; u < kIdxRowsPerWave; ++u) {
+    const int r = rw0 + u;
+    if (r >= R) break;
+    float *dr = de + (int64_t)r * ldde;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      if (q < nq) st4(dr, q, acc[u][c]);
+    }
+  }
+  if (!z) return;
+  // k_l2norm_bwd on the finished rows, operation for operation (its sums run over q = lane, lane + 64, ...: the order
+  // of the register chunks)
+  float4 zr[kIdxRowsPerWave][NCH];
+  float inv[kIdxRowsPerWave], cc[kIdxRowsPerWave];
+#pragma unroll
+  for (int u = 0; u < kIdxRowsPerWave; ++u) {
+    const int r = min(rw0 + u, R - 1);
+    const float *zp = z + (int64_t)r * ldz;
+    float ss = 0.f, zg = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      zr[u][c] = (q < nq) ? ld4(zp, q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < nq) {
+        ss += sq4(zr[u][c]);
+        zg += dot4(zr[u][c], acc[u][c]);
+      }
+    }
+    ss = wave_sum(ss);
+    zg = wave_sum(zg);
+    inv[u] = 1.0f / sqrtf(fmaxf(ss, kL2Eps));
+    cc[u] = (ss > kL2Eps) ? inv[u] * inv[u] * zg : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < kIdxRowsPerWave; ++u) {
+    const int r = rw0 + u;
+    if (r >= R) break;
+    float *dr = dz2 + (int64_t)r * lddz;
+    uint16_t *br = dz2_bf ? dz2_bf + (int64_t)r * ldbf : nullptr;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      if (q >= nq) continue;
+      const float4 a = zr[u][c], b = acc[u][c];
+      const float iv = inv[u], cv = cc[u];
+      float4 d = make_float4(iv * (b.x - a.x * cv), iv * (b.y - a.y * cv), iv * (b.z - a.z * cv), iv * (b.w - a.w * cv));
+      if (alpha >= 0.f) {
+        d.x *= (a.x > 0.f) ? 1.f : alpha;
+        d.y *= (a.y > 0.f) ? 1.f : alpha;
+        d.z *= (a.z > 0.f) ? 1.f : alpha;
+        d.w *= (a.w > 0.f) ? 1.f : alpha;
+      }
+      st4(dr, q, d);
+      if (br) {                                      // bf16 copy (round to nearest even); plane_bf: the mid and lo planes too
+        auto rn = [](float x) -> uint32_t {
+          const uint32_t u32 = __float_as_uint(x);
+          return (u32 + 0x7fffu + ((u32 >> 16) & 1u)) >> 16;
+        };
+        float rr[4] = {d.x, d.y, d.z, d.w};
+        uint32_t hb[4] = {rn(d.x), rn(d.y), rn(d.z), rn(d.w)};
+        reinterpret_cast<uint2 *>(br)[q] = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+        if (plane_bf) {
+#pragma unroll
+          for (int pl = 1; pl < 3; ++pl) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              rr[t] -= __uint_as_float(hb[t] << 16);
+              hb[t] = rn(rr[t]);
+            }
+            reinterpret_cast<uint2 *>(br + pl * plane_bf)[q] = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+          }
+        }
+      }
+    }
   }
 }
 
@@ -880,10 +1010,12 @@ extern "C" int cdml_semihard_select(const float *S, int64_t ldS, const float *e,
   return check_launch("semihard_select");
 }
 
-extern "C" int cdml_triplet_hinge_indexed(const float *e, int64_t lde, const int32_t *neg_row, int B,
-                                          int D, float margin, float *pos, float *neg, float *hinge,
-                                          float *stats, float *scale_scratch, float *de, int64_t ldde,
-                                          cdml_stream_t stream) {
+extern "C" int cdml_triplet_hinge_indexed_tail(const float *e, int64_t lde, const int32_t *neg_row, int B, int D,
+                                               float margin, float *pos, float *neg, float *hinge, float *stats,
+                                               float *scale_scratch, float *de, int64_t ldde, const float *z,
+                                               int64_t ldz, float lrelu_alpha, float *dz2, int64_t lddz,
+                                               uint16_t *dz2_bf16, int64_t ldbf, int64_t plane_bf,
+                                               cdml_stream_t stream) {
   CDML_REQUIRE(B >= 1 && D > 0 && neg_row && pos && neg && hinge && scale_scratch, CDML_E_BADARG,
                "triplet_hinge_indexed: bad argument");
   int rc;
@@ -891,18 +1023,43 @@ extern "C" int cdml_triplet_hinge_indexed(const float *e, int64_t lde, const int
   if (de && (rc = check_rows("triplet_hinge_indexed", de, ldde, D))) return rc;
   CDML_REQUIRE(!de || (aligned16(neg_row) && aligned16(scale_scratch)), CDML_E_ALIGN,
                "triplet_hinge_indexed: neg_row and scale_scratch must be 16-B aligned");
+  if (z) {
+    CDML_REQUIRE(de && dz2, CDML_E_BADARG, "triplet_hinge_indexed_tail: the fused tail needs de and dz2");
+    if ((rc = check_rows("triplet_hinge_indexed_tail z", z, ldz, D))) return rc;
+    if ((rc = check_rows("triplet_hinge_indexed_tail dz2", dz2, lddz, D))) return rc;
+    CDML_REQUIRE(!dz2_bf16 || ((reinterpret_cast<uintptr_t>(dz2_bf16) & 7) == 0 && (ldbf & 3) == 0 && (plane_bf & 3) == 0 &&
+                               ldbf >= (plane_bf ? 2 * plane_bf + D : D) && plane_bf >= 0),
+                 CDML_E_ALIGN, "triplet_hinge_indexed_tail: dz2_bf16 8-B aligned, ldbf and plane_bf multiples of 4, ldbf >= 2 plane_bf + D");
+  }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_hinge_indexed_fwd, dim3(grid_rows(B)), dim3(kThreads), 0, s, e, lde, neg_row, B,
                      D, margin, pos, neg, hinge, scale_scratch);
-  if (de)
-    hipLaunchKernelGGL(k_hinge_indexed_bwd, dim3(grid_rows(2 * B)), dim3(kThreads), 0, s, e, lde,
-                       neg_row, scale_scratch, B, D, de, ldde);
+  if (de) {
+    const int nch = ((D >> 2) + kWave - 1) / kWave;   // float4 chunks per lane and row (D <= 256: 1)
+    CDML_REQUIRE(nch <= 4, CDML_E_UNSUPPORTED, "triplet_hinge_indexed: embeddings of at most 1024 dimensions (got %d)", D);
+    const dim3 grid((2 * B + kIdxRows - 1) / kIdxRows);
+#define CDML_LAUNCH_HIB(N)                                                                                          \
+    hipLaunchKernelGGL((k_hinge_indexed_bwd<N>), grid, dim3(kThreads), 0, s, e, lde, neg_row, scale_scratch, B, D, de, \
+                       ldde, z, ldz, lrelu_alpha, dz2, lddz, dz2_bf16, ldbf, plane_bf)
+    if (nch <= 1) CDML_LAUNCH_HIB(1);
+    else if (nch == 2) CDML_LAUNCH_HIB(2);
+    else CDML_LAUNCH_HIB(4);
+#undef CDML_LAUNCH_HIB
+  }
   if ((rc = check_launch("triplet_hinge_indexed"))) return rc;
   if (stats) {
     hipLaunchKernelGGL(k_loss_stats, dim3(1), dim3(1024), 0, s, pos, neg, hinge, B, stats);
     rc = check_launch("triplet_hinge_indexed stats");
   }
   return rc;
+}
+
+extern "C" int cdml_triplet_hinge_indexed(const float *e, int64_t lde, const int32_t *neg_row, int B,
+                                          int D, float margin, float *pos, float *neg, float *hinge,
+                                          float *stats, float *scale_scratch, float *de, int64_t ldde,
+                                          cdml_stream_t stream) {
+  return cdml_triplet_hinge_indexed_tail(e, lde, neg_row, B, D, margin, pos, neg, hinge, stats, scale_scratch, de, ldde,
+                                         nullptr, 0, -1.0f, nullptr, 0, nullptr, 0, 0, stream);
 }
 
 extern "C" int cdml_pair_dist(const float *e, int64_t lde, int n_rows, const int32_t *pairs, int P,

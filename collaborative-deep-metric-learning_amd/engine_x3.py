@@ -95,6 +95,11 @@ class TowerWorkspaceX3:
         # the same bits whole or in row blocks, in small chunks or large (test_embedding_bits_do_not_depend_on_the_chunk);
         # the single pass (workspace NULL at the C ABI) is an explicit opt-out, fc2_single_pass.
         self.fc2_single_pass = bool(fc2_single_pass) and not backward and R // 256 >= 192
+        # round 6: the slab LENGTH follows the row-tile class of a call (60 K-tile steps for small batches such as the
+        # reference's own B = 1 024, 120 otherwise: csrc/gemm_bf16x3.hip x3_nt_splits).  A forward-only workspace -- catalogue
+        # inference, evaluation -- pins 120 whatever its chunk size, so an embedding keeps its bits from chunk to chunk; a
+        # training workspace follows the rule (its batch size is what it is: one class per job)
+        self.slab_steps = None if backward else 120
         nb = 16 if self.fc2_single_pass else max(ops.gemm_bf16x3_workspace(False, R, L.Dp, L.Hp, q), 16)
         # leaky-relu' of the hidden layer as ONE BIT per element (round 4): FC1's epilogue writes the sign bitmask of h1
         # (this lane's 8 columns = one byte), the data gradient's epilogue reads 5 MB of bits instead of the 84 MB of
@@ -175,7 +180,8 @@ def tower_forward(p, ws, normalize=True):
             ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_X3, ws.x3, L.Fp, ws.W1T, L.Fp, ws.h1, R, L.Hp, L.Fp, products=q,
                                plane_c=L.Hp, bias=p.b1)
         ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, ws.h1, L.Hp, ws.W2T, L.Hp, ws.z, R, L.Dp, L.Hp, products=q,
-                           bias=p.b2, workspace=None if getattr(ws, "fc2_single_pass", False) else ws.gemm_ws)
+                           bias=p.b2, workspace=None if getattr(ws, "fc2_single_pass", False) else ws.gemm_ws,
+                           slab_steps=getattr(ws, "slab_steps", None))
     ws.tail_done = False
     ws.dz2_planes_done = False
     if normalize:

@@ -5,9 +5,10 @@ The reference l2-normalises the embeddings, builds a faiss ``IndexHNSWFlat`` and
 returns ``D`` (squared L2 distances, ascending) and ``I`` (int64 ids; the query
 itself is its own first neighbour -- "51 = 50 neighbours + the query").  HNSW is an
 approximation of the exact answer; this module computes the exact one by brute
-force on the GPU: blocks of inner products from the fp32 MFMA GEMM
-(``ops.fc_bwd_data`` without a mask = ``Q @ Bᵀ``), folded into per-query
-candidate lists by ``ops.knn_merge``.  Ties are ordered by id.  ``M``,
+force on the GPU: blocks of inner products ``Q @ Bᵀ`` from the plane kernels
+(the headline path's arithmetic, ``ops.gemm_bf16x3_nt``; or the fp32 MFMA GEMM,
+``ops.fc_bwd_data`` without a mask), folded into per-query candidate lists by
+``ops.knn_merge`` while the 128-MiB score block is still in the Infinity Cache.  Ties are ordered by id.  ``M``,
 ``efConstruction`` and ``efSearch`` are accepted for call compatibility and ignored.
 """
 import numpy as np
@@ -23,19 +24,30 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def _device_matrix(a, device, row_multiple):
-    """[n, D] -> zero-padded fp32 device matrix [n_pad, Dp] (Dp % 32 == 0)."""
+def _device_matrix(a, device, row_multiple, col_multiple=32):
+    """[n, D] -> zero-padded fp32 device matrix [n_pad, Dp] (Dp % col_multiple == 0)."""
     t = a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a, dtype=np.float32))
     t = t.to(device=device, dtype=torch.float32)
     n, D = t.shape
-    out = torch.zeros((_round_up(n, row_multiple), _round_up(D, 32)), dtype=torch.float32, device=device)
+    out = torch.zeros((_round_up(n, row_multiple), _round_up(D, col_multiple)), dtype=torch.float32, device=device)
     out[:n, :D] = t
     return out
 
 
-def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK, b_block=B_BLOCK):
+def _planes(x, Dp):
+    out = torch.empty((x.shape[0], 3 * Dp), dtype=torch.bfloat16, device=x.device)
+    ops.split_f32_bf16x3(x, out, Dp)
+    return out
+
+
+def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK, b_block=B_BLOCK, precision="f32x3"):
     """Device tensors (D [nq,k] fp32 squared L2 ascending, I [nq,k] int64; -1 where
-    the catalogue has fewer than k rows)."""
+    the catalogue has fewer than k rows).  ``precision``: "f32x3" (default; round 6) = the inner products on the plane
+    kernels -- the headline path's arithmetic: every fp32 operand as three exact bf16 planes, six plane products per fp32
+    product on the bf16 MFMA (csrc/gemm_bf16x3.hip), errors those of the fp32 kernels -- or "f32" = the fp32 MFMA."""
+    if precision not in ("f32x3", "f32"):
+        raise ValueError("precision must be 'f32x3' or 'f32'")
+    x3 = precision == "f32x3"
     cap = ops.knn_list_capacity()
     if not 1 <= k <= cap:
         raise ValueError("nearest_num must be in [1, %d]" % cap)
@@ -43,10 +55,10 @@ def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK,
     nq = queries.shape[0]
     if queries.shape[1] != D:
         raise ValueError("query / catalogue dimension mismatch")
-    b_block = _round_up(min(b_block, _round_up(nb, 64)), 64)
-    B = _device_matrix(base, device, b_block)
+    b_block = _round_up(min(b_block, _round_up(nb, 64)), 256 if x3 else 64)
+    B = _device_matrix(base, device, b_block, 64 if x3 else 32)
     same = queries is base
-    Q = B if same else _device_matrix(queries, device, 1)
+    Q = B if same else _device_matrix(queries, device, 1, 64 if x3 else 32)
     Dp = B.shape[1]
     if l2_norm:                                              # faiss_knn.py:99-104
         ops.l2norm_fwd(B[:nb], Dp, B)
@@ -63,11 +75,17 @@ def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK,
     best_i = torch.empty((nq, cap), dtype=torch.int32, device=device)
     q_block = min(q_block, nq)
     scores = torch.empty((q_block, b_block), dtype=torch.float32, device=device)
+    if x3:
+        B3 = _planes(B, Dp)
+        Q3 = B3 if same else _planes(Q, Dp)
     for q0 in range(0, nq, q_block):
         m = min(q_block, nq - q0)
         for c0 in range(0, B.shape[0], b_block):
-            # scores[m, b_block] = Q[q0:q0+m] @ B[c0:c0+b_block]^T   (exact fp32 MFMA)
-            ops.fc_bwd_data(Q[q0:q0 + m], B[c0:c0 + b_block], None, scores, m, b_block, Dp)
+            # scores[m, b_block] = Q[q0:q0+m] @ B[c0:c0+b_block]^T
+            if x3:
+                ops.gemm_bf16x3_nt(ops.BE_F32, Q3[q0:q0 + m], Dp, B3[c0:c0 + b_block], Dp, scores, m, b_block, Dp)
+            else:
+                ops.fc_bwd_data(Q[q0:q0 + m], B[c0:c0 + b_block], None, scores, m, b_block, Dp)
             ops.knn_merge(scores, m, b_block, c0, nb, q_sq[q0:q0 + m], b_sq[c0:c0 + b_block], k,
                           best_d[q0:q0 + m], best_i[q0:q0 + m], first=(c0 == 0))
     I = best_i[:, :k].to(torch.int64)
@@ -76,10 +94,10 @@ def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK,
 
 
 def calc_knn(embeddings, q_embeddings=None, nearest_num=51, l2_norm=True, M=80, efConstruction=64,
-             efSearch=32, device="cuda:0"):
+             efSearch=32, device="cuda:0", precision="f32x3"):
     """(D, I) ndarrays as faiss ``index.search(q, nearest_num)`` returns them
     (faiss_knn.py:128).  Like the reference, queries default to the catalogue."""
     emb = embeddings if torch.is_tensor(embeddings) else np.asarray(embeddings, dtype=np.float32)
     q = emb if q_embeddings is None else q_embeddings
-    D, I = knn_search(emb, q, int(nearest_num), l2_norm=l2_norm, device=device)
+    D, I = knn_search(emb, q, int(nearest_num), l2_norm=l2_norm, device=device, precision=precision)
     return D.cpu().numpy(), I.cpu().numpy()

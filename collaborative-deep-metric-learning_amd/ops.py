@@ -274,11 +274,22 @@ def semihard_mine_x3(e, rows, B, D, e_planes, plane, sqn, dp, workspace, neg_row
     return neg_row_out
 
 
-def triplet_hinge_indexed(e, neg_row, B, D, margin, pos, neg, hinge, scale_scratch, stats=None, de=None):
+def triplet_hinge_indexed(e, neg_row, B, D, margin, pos, neg, hinge, scale_scratch, stats=None, de=None, z=None, dz2=None,
+                          dz2_bf16=None, plane_bf=0, lrelu_alpha=LRELU_ALPHA):
+    """Hinge loss + gradient over (row 2i, row 2i+1, row neg_row[i]).  ``z`` and ``dz2`` given: the finished row gradients
+    also go through l2norm_bwd (+ leaky-relu') into dz2 -- and into its bf16 copy / three planes (``dz2_bf16``,
+    ``plane_bf``) -- inside the same launch (cdml_triplet_hinge_indexed_tail)."""
     ep, eld = _mat(e)
     dep, deld = (C.c_void_p(0), 0) if de is None else _mat(de)
-    call("cdml_triplet_hinge_indexed", ep, eld, _p(neg_row, torch.int32), B, D, margin, _p(pos), _p(neg),
-         _p(hinge), _p(stats), _p(scale_scratch), dep, deld, _stream())
+    if z is None:
+        call("cdml_triplet_hinge_indexed", ep, eld, _p(neg_row, torch.int32), B, D, margin, _p(pos), _p(neg),
+             _p(hinge), _p(stats), _p(scale_scratch), dep, deld, _stream())
+        return
+    zp, zld = _mat(z)
+    dzp, dzld = _mat(dz2)
+    bp, bld = (C.c_void_p(0), 0) if dz2_bf16 is None else _mat16(dz2_bf16)
+    call("cdml_triplet_hinge_indexed_tail", ep, eld, _p(neg_row, torch.int32), B, D, margin, _p(pos), _p(neg),
+         _p(hinge), _p(stats), _p(scale_scratch), dep, deld, zp, zld, lrelu_alpha, dzp, dzld, bp, bld, plane_bf, _stream())
 
 
 def pair_dist(e, pairs, D, sqdist, dot, means=None):
@@ -436,10 +447,19 @@ def gemm_bf16x3_workspace(tn, M, N, K, products=6):
 
 
 def gemm_bf16x3_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, products=6, plane_c=0, bias=None, aux=None,
-                   alpha=LRELU_ALPHA, workspace=None, colsum=None, ldc=None):
+                   alpha=LRELU_ALPHA, workspace=None, colsum=None, ldc=None, slab_steps=None):
     """C = epilogue(A . B^T) for fp32 operands given as bf16 planes [rows][hi K | mid K | lo K]; colsum[n] = sum_k
     B[n][k] on request.  Epilogue 12: C is the flat k8-interleaved buffer [3][M / 8][ldc][8] (``ldc`` = columns per row
-    group, ``plane_c`` = elements per plane)."""
+    group, ``plane_c`` = elements per plane).  ``slab_steps`` (the narrow layer, N = 256): pin the K-slab length for this
+    call (cdml_x3_slab_steps) instead of the rule by row-tile class."""
+    if slab_steps:
+        lib = load_library()
+        prev = lib.cdml_x3_slab_steps(int(slab_steps))
+        try:
+            return gemm_bf16x3_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, products=products, plane_c=plane_c, bias=bias,
+                                  aux=aux, alpha=alpha, workspace=workspace, colsum=colsum, ldc=ldc)
+        finally:
+            lib.cdml_x3_slab_steps(prev)
     ap, ald = _mat16(A)
     bp, bld = _mat16(B)
     if epilogue == BE_MASKBITS_X3_KI:

@@ -433,8 +433,19 @@ class TrainStep:
                 # S[i][c] = <anchor_i, row_c>: the data-gradient GEMM (x @ W^T) with no mask
                 ops.fc_bwd_data(e[0::2], e, None, self.S, self.B, 2 * self.B, L.Dp)
                 ops.semihard_select(self.S, e, self.idx, self.B, L.Dp, self.sqn, self.neg_row)
-            ops.triplet_hinge_indexed(e, self.neg_row, self.B, L.Dp, self.margin, self.pos, self.neg,
-                                      self.hinge, self.scale, self.stats, de)
+            if with_grad and os.environ.get("CDML_INDEXED_TAIL", "1") != "0":
+                # round 6: the rest of the tail rides in the gradient launch -- every finished row gradient goes through the
+                # l2norm backward (+ leaky-relu') into dz2 and its operand copy (bf16 / three planes) on the spot: two
+                # launches fewer per step, bit-identical (CDML_INDEXED_TAIL=0: the separate launches, for A/B runs)
+                ops.triplet_hinge_indexed(e, self.neg_row, self.B, L.Dp, self.margin, self.pos, self.neg, self.hinge,
+                                          self.scale, self.stats, de, z=self.ws.z, dz2=self.ws.dz2,
+                                          dz2_bf16=self.ws.dz2_bf if self.bf16 else self.ws.dz2_3 if self.x3 else None,
+                                          plane_bf=L.Dp if self.x3 else 0)
+                self.ws.tail_done = True
+                self.ws.dz2_planes_done = self.x3
+            else:
+                ops.triplet_hinge_indexed(e, self.neg_row, self.B, L.Dp, self.margin, self.pos, self.neg,
+                                          self.hinge, self.scale, self.stats, de)
         else:
             ops.triplet_hinge_inbatch(self.ws.e, self.idx, self.shift, self.B, L.Dp, self.margin,
                                       self.pos, self.neg, self.hinge, self.valid, self.stats, de)

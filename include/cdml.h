@@ -278,6 +278,18 @@ int cdml_triplet_hinge_indexed(const float *e, int64_t lde,
                                float *pos, float *neg, float *hinge, float *stats,
                                float *scale_scratch, float *de, int64_t ldde,
                                cdml_stream_t stream);
+/* The same with the rest of the step's tail folded into the gradient launch (round 6; BASELINE config 2's step):
+ * z (pre-normalisation output rows, e = l2norm(z)) given, every row's finished gradient de goes straight through
+ * cdml_l2norm_bwd's arithmetic -- dz2 = l2norm-backward(z, de) times leaky-relu'(z) (lrelu_alpha < 0: none) -- and,
+ * dz2_bf16 given, its bf16 copy (plane_bf = 0) or its three exact bf16 planes hi | mid | lo, plane_bf elements apart
+ * (what cdml_split_f32_bf16x3 writes).  Bit-identical to the separate launches (losses.py:32-38, models.py:61,
+ * train.py:141).  z = NULL: cdml_triplet_hinge_indexed. */
+int cdml_triplet_hinge_indexed_tail(const float *e, int64_t lde, const int32_t *neg_row, int B, int D,
+                                    float margin, float *pos, float *neg, float *hinge, float *stats,
+                                    float *scale_scratch, float *de, int64_t ldde, const float *z,
+                                    int64_t ldz, float lrelu_alpha, float *dz2, int64_t lddz,
+                                    uint16_t *dz2_bf16, int64_t ldbf, int64_t plane_bf,
+                                    cdml_stream_t stream);
 
 /* ---- evaluation metric: Evaluation.mean_dist / mean_cos_dist (evaluate.py:57-90)
  * e[n_rows][lde] embeddings; pairs int32[P][2] row indices (must be < n_rows).
@@ -452,6 +464,14 @@ int cdml_adam_matrix_planes(float *w, const float *g, float *m, float *v, int K,
                             uint16_t *wc_planes, int64_t ldc, int64_t plane_c, float *bias_w,
                             const float *bias_g, float *bias_m, float *bias_v, int bias_n,
                             int advance_step, uint32_t *tickets, cdml_stream_t stream);
+/* The narrow forward layer (N = 256) of cdml_gemm_bf16x3_nt splits its contraction into slabs.  Their length follows K
+ * and the row-tile class of the call (round 6): 60 K-tile steps where 120-step slabs would give at most 64 tiles (small
+ * batches: the reference's own B = 1 024), else 120 -- within a class the partition depends on K alone (a batch whole or
+ * in row blocks: the same bits).  cdml_x3_slab_steps(steps) pins ONE length (a multiple of 6, >= 12) for the calling
+ * thread's later calls whatever their size -- catalogue inference pins 120, so an embedding does not depend on the
+ * chunk it was computed in; 0 = back to the rule.  Returns the previous pin.  Needs no GPU. */
+int cdml_x3_slab_steps(int steps);
+
 /* cdml_gemm_bf16x3_nt epilogues: 1 fp32 C = lrelu(. + bias); 3 fp32 C; 6 C = the three planes of lrelu(. + bias);
  * 7 C = planes of (. times (aux > 0 ? 1 : alpha)), aux = bf16 values [M][ldaux]; 8 = 6 with the bias indexed by the
  * output row; 9 = 6 that ALSO writes the sign bitmask of its result to aux (as uint8 [M][ldaux BYTES], bit j of byte b of

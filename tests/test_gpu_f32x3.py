@@ -493,7 +493,10 @@ def test_half_tiles_of_the_last_round_are_bit_identical(M, N, K, monkeypatch):
         ops.gemm_bf16x3_nt(ops.BE_MASKBITS_X3, A3, K, B3, K, d, M, N, K, plane_c=N, aux=bits, alpha=0.2)
         dv = torch.zeros(M, 3 * N, dtype=torch.bfloat16, device=dev)
         ops.gemm_bf16x3_nt(ops.BE_MASK_X3, A3, K, B3, K, dv, M, N, K, plane_c=N, aux=o, alpha=0.2)
-        return o, bits, d, dv
+        # round 6: the unsplit fp32-output product too (the trainable table's row gradient dz1 . W1^T)
+        c = torch.zeros(M, N, device=dev)
+        ops.gemm_bf16x3_nt(ops.BE_F32, A3, K, B3, K, c, M, N, K)
+        return o, bits, d, dv, c
 
     full = run(False)
     half = run(True)
@@ -539,6 +542,20 @@ def test_embedding_bits_do_not_depend_on_the_chunk():
     with pytest.raises(_lib.CdmlError, match="slab form needs"):
         ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, A3, K, B3, K, C, M, 256, K, bias=bias, alpha=0.2,
                            workspace=torch.empty(1024, device=dev))
+    # round 6: the slab LENGTH follows the row-tile class -- within a class a batch gives the same bits whole or in row
+    # blocks; a pin (what the inference workspaces above use) holds ONE length across classes
+    ws = torch.empty(max(ops.gemm_bf16x3_workspace(False, 16640, 256, K, 6), 16) // 4, device=dev)
+    run = lambda A_, M_, **kw: ops.gemm_bf16x3_nt(ops.BE_BIAS_LRELU_F32, A_, K, B3, K, torch.empty((M_, 256), device=dev), M_, 256,
+                                                  K, bias=bias, alpha=0.2, workspace=ws, **kw)
+    whole = run(A3, M)                                       # 2 row tiles x 2 slabs of 120 <= 64 tiles: the 60-step class
+    halves = torch.cat([run(A3[:256], 256), run(A3[256:], 256)])
+    assert torch.equal(whole, halves)
+    pinned = run(A3, M, slab_steps=120)
+    assert 0 < (pinned - whole).abs().max().item() < 5e-6    # two slabs against four: another association of the same sums
+    assert torch.equal(run(A3, M, slab_steps=60), whole)     # the class's own length, pinned
+    Abig = _planes(torch.randn(16640, K, device=dev) * 0.1, K)      # 65 row tiles x 2 slabs > 64: the 120-step class
+    assert torch.equal(run(Abig, 16640), run(Abig, 16640, slab_steps=120))
+    assert _lib.load_library().cdml_x3_slab_steps(0) == 0    # no pin is left behind
 
 
 def test_split_k_geometry_has_no_empty_split():

@@ -69,3 +69,42 @@ def test_bad_k_is_refused():
     from cdml_amd import knn
     with pytest.raises(ValueError):
         knn.calc_knn(embeddings(10, 32, 0), nearest_num=129)
+
+
+def test_self_knn_at_the_reference_catalogue_size():
+    """the export at the reference's own scale -- doc_location = 343455 embeddings (faiss_knn.py:389), 256-d,
+    nearest_num = 51 -- against a blocked EXACT search in fp64 on the device (torch: 2 048 queries x the whole catalogue
+    per block).  Every returned neighbour's true distance lies within tolerance of the exact k-th distance (ids may swap
+    only between candidates the fp32 arithmetic cannot tell apart), distances ascending and equal to the exact ones to
+    TOL, the query its own first neighbour."""
+    from cdml_amd import knn
+    dev = torch.device("cuda:0")
+    n, D, k = 343455, 256, 51
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    e = torch.randn(n, D, device=dev, generator=g)
+    Dg, Ig = knn.knn_search(e, e, k)
+    torch.cuda.synchronize()
+    assert Dg.shape == (n, k) and Ig.dtype == torch.int64
+    assert bool((Ig[:, 0] == torch.arange(n, device=dev)).all())
+    assert bool((Dg[:, 1:] >= Dg[:, :-1]).all())
+    b = e.double()
+    b = b / b.norm(dim=1, keepdim=True).clamp_min(1e-6)
+    bsq = (b * b).sum(1)
+    worst_d = worst_set = 0.0
+    exact_ids = 0
+    for q0 in range(0, n, 2048):
+        q = b[q0:q0 + 2048]
+        d = (bsq[q0:q0 + 2048, None] + bsq[None, :] - 2.0 * (q @ b.t())).clamp_min(0.0)
+        Dr, Ir = torch.topk(d, k, dim=1, largest=False, sorted=True)
+        got_d, got_i = Dg[q0:q0 + 2048].double(), Ig[q0:q0 + 2048]
+        worst_d = max(worst_d, float((got_d - Dr).abs().max()))
+        true_d = d.gather(1, got_i)                                    # the exact distance of what was returned
+        worst_set = max(worst_set, float((true_d - Dr[:, -1:]).max()))
+        srt = got_i.sort(dim=1).values
+        assert bool((srt[:, 1:] != srt[:, :-1]).all())                # no neighbour twice
+        exact_ids += int((got_i == Ir).all(dim=1).sum())
+        del d
+    assert worst_d <= TOL, worst_d
+    assert worst_set <= 2 * TOL, worst_set
+    assert exact_ids >= 0.98 * n, exact_ids / n                       # (swaps only among near-ties)

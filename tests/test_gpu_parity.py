@@ -1026,6 +1026,61 @@ def test_semihard_select_and_indexed_loss(cd):
         assert torch.equal(dE, dE2)                   # deterministic accumulation
 
 
+@pytest.mark.parametrize("B,D,skew", [(1500, 256, "uniform"), (1500, 256, "one-row"), (2051, 64, "few-rows"), (96, 128, "masked")])
+def test_indexed_hinge_backward_block_scan_and_fused_tail(cd, B, D, skew):
+    """Round 6: the indexed hinge's backward as a block-cooperative scan (a block of 64 rows scans neg_row once and walks
+    its hits in ascending triplet order) with the rest of config 2's tail folded in.  Against the fp64 oracle on any
+    distribution of mined rows -- uniform, EVERY anchor mining one row (one wave adds B terms in order), a handful of
+    rows, masked triplets; batch sizes that are no multiple of 4 or of the 1 024-triplet pass -- and the fused tail
+    (l2norm backward + leaky-relu' + bf16 copy / three planes) bit-identical to the separate launches
+    (losses.py:32-38, models.py:61, train.py:141)."""
+    rng = np.random.RandomState(B + D)
+    Z = (rng.randn(2 * B, D) * 0.3).astype(np.float32)
+    E = otower.l2_normalize(Z.astype(np.float64), np.float64)[0].astype(np.float32)
+    if skew == "uniform":
+        nr = rng.randint(0, 2 * B, size=B)
+    elif skew == "one-row":
+        nr = np.full(B, 77)
+    elif skew == "few-rows":
+        nr = rng.choice([3, 64, 65, 1000, 2 * B - 1], size=B)
+    else:
+        nr = rng.randint(0, 2 * B, size=B)
+        nr[rng.rand(B) < 0.4] = -1
+    nr = nr.astype(np.int32)
+    dz_, de_, dn = dt(Z, cd.dev), dt(E, cd.dev), dt(nr, cd.dev, torch.int32)
+    pos, neg, hinge, scale = (torch.empty(B, device=cd.dev) for _ in range(4))
+    stats = torch.empty(4, device=cd.dev)
+    dE = torch.empty((2 * B, D), device=cd.dev)
+    cd.ops.triplet_hinge_indexed(de_, dn, B, D, 0.8, pos, neg, hinge, scale, stats, dE)
+    tri, valid = otower.semihard_triplets(nr)
+    w = otower.hinge_loss_indexed(E.astype(np.float64), tri, valid, 0.8, np.float64)
+    np.testing.assert_allclose(hinge.cpu().numpy(), w["hinge_dist"], atol=TOL)
+    wd = otower.hinge_loss_indexed_backward(E.astype(np.float64), tri, valid, 0.8, np.float64)
+    # (a triplet within rounding of the hinge's corner may be active on one side only: compare where the oracle is clear)
+    t = w["pos_dist"] - w["neg_dist"] + 0.8 if "pos_dist" in w else None
+    got = dE.cpu().numpy()
+    if t is not None and (np.abs(np.ravel(t)) < 1e-5).any():
+        pytest.skip("a triplet sits on the hinge's corner in this draw")
+    np.testing.assert_allclose(got, wd, atol=5e-5 if skew == "one-row" else TOL)     # (one row sums B terms: fp32 accumulation)
+    # the separate launches of the tail ...
+    dz2_a = torch.empty((2 * B, D), device=cd.dev)
+    cd.ops.l2norm_bwd(dz_, dE, D, dz2_a, lrelu_alpha=cd.ops.LRELU_ALPHA)
+    pl_a = torch.zeros((2 * B, 3 * D), dtype=torch.bfloat16, device=cd.dev)
+    cd.ops.split_f32_bf16x3(dz2_a, pl_a, D)
+    # ... against the fused form, three planes and plain bf16
+    for planes in (True, False):
+        dE_b, dz2_b = torch.empty_like(dE), torch.empty_like(dz2_a)
+        bf = torch.zeros((2 * B, 3 * D if planes else D), dtype=torch.bfloat16, device=cd.dev)
+        cd.ops.triplet_hinge_indexed(de_, dn, B, D, 0.8, pos, neg, hinge, scale, stats, dE_b, z=dz_, dz2=dz2_b, dz2_bf16=bf,
+                                     plane_bf=D if planes else 0)
+        assert torch.equal(dE_b, dE) and torch.equal(dz2_b, dz2_a)
+        if planes:
+            assert torch.equal(bf, pl_a)
+            assert torch.equal(bf[:, :D].float() + bf[:, D:2 * D].float() + bf[:, 2 * D:].float(), dz2_a)
+        else:
+            assert torch.equal(bf, dz2_a.to(torch.bfloat16))
+
+
 def _check_semihard_choice(got, want, dist, rows, B, tol=2e-6):
     """The device's negatives against the oracle's, tolerance-aware (a candidate within tol of d_p may fall on either side)."""
     d_p = dist[np.arange(B), 2 * np.arange(B) + 1]

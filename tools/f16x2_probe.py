@@ -56,18 +56,27 @@ def split16(x, L):
     return hi.contiguous(), lo.contiguous(), s
 
 
-def f16x2_nt(A, B, mode):
-    """C = A . B^T (fp32 [M][K], [N][K]) through the two-plane fp16 form"""
+def f16x2_nt(A, B, mode, slabs=1):
+    """C = A . B^T (fp32 [M][K], [N][K]) through the two-plane fp16 form; ``slabs`` > 1: the contraction in that many
+    K-slabs, each in its own accumulator, summed in fp32 in slab order -- the partition the production weight-gradient
+    kernels use (split-K slabs + k_x3_sum_slabs): what bounds a long contraction's error is the number of MFMA
+    accumulation steps into ONE accumulator."""
     L = 11 if mode == 0 else 0
     ah, al, sa = split16(A, L)
     bh, bl, sb = split16(B, L)
     M, K = A.shape
     N = B.shape[0]
     out = torch.empty(M, N, device=dev)
-    rc = lib.f16x2_gemm_nt(mode, ah.data_ptr(), al.data_ptr(), bh.data_ptr(), bl.data_ptr(), K, K, out.data_ptr(), N, M, N, K,
-                           2.0 ** -11, 2.0 ** -(sa + sb), torch.cuda.current_stream().cuda_stream)
-    assert rc == 0, rc
-    return out
+    per = (K // slabs + 31) // 32 * 32
+    total = None
+    for k0 in range(0, K, per):
+        kk = min(per, K - k0)
+        off = k0 * 2                                           # bytes into a row of an fp16 plane
+        rc = lib.f16x2_gemm_nt(mode, ah.data_ptr() + off, al.data_ptr() + off, bh.data_ptr() + off, bl.data_ptr() + off, K, K,
+                               out.data_ptr(), N, M, N, kk, 2.0 ** -11, 2.0 ** -(sa + sb), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+        total = out.clone() if total is None else total + out
+    return total
 
 
 def planes(x, w=None):
@@ -106,16 +115,28 @@ fmt = lambda e: "%.2e (%.2e)" % e
 gate_ok = True
 
 
-def row(name, ref, c32, c6, A, B):
-    """A [M][K], B [N][K]: the NT operands of the product (k-strided products pass their transposes)"""
-    global gate_ok
+gate_one_slabs = True
+
+
+def row(name, ref, c32, c6, A, B, slabs=1):
+    """A [M][K], B [N][K]: the NT operands of the product (k-strided products pass their transposes).  ``slabs``: the K
+    partition of the production kernel for this product (the weight gradients are split-K launches)."""
+    global gate_ok, gate_one_slabs
     e32, e6 = errs(c32, ref), errs(c6, ref)
     e0, e1, e2 = errs(f16x2_nt(A, B, 0), ref), errs(f16x2_nt(A, B, 1), ref), errs(f16x2_nt(A, B, 2), ref)
     ok0, ok1 = e0[0] <= 1.5 * e32[0] + 2e-8, e1[0] <= 1.5 * e32[0] + 2e-8
     gate_ok = gate_ok and ok0
-    print("%-26s %-22s %-22s %-22s %-22s %-12.2e own-acc %s (%.2f x), one-acc %s (%.2f x)"
+    extra = ""
+    if slabs > 1:
+        e1s = errs(f16x2_nt(A, B, 1, slabs), ref)
+        ok1s = e1s[0] <= 1.5 * e32[0] + 2e-8
+        gate_one_slabs = gate_one_slabs and ok1s
+        extra = "; one-acc in the production's %d K-slabs: %s %s (%.2f x)" % (slabs, fmt(e1s), "PASS" if ok1s else "FAIL", e1s[0] / e32[0])
+    else:
+        gate_one_slabs = gate_one_slabs and ok1
+    print("%-26s %-22s %-22s %-22s %-22s %-12.2e own-acc %s (%.2f x), one-acc %s (%.2f x)%s"
           % (name, fmt(e32), fmt(e6), fmt(e0), fmt(e1), e2[0], "PASS" if ok0 else "FAIL", e0[0] / e32[0], "PASS" if ok1 else "FAIL",
-             e1[0] / e32[0]))
+             e1[0] / e32[0], extra))
 
 
 for tag, dz2 in (("|dz2| ~ 1e-3 (the test's)", torch.randn(R, D, device=dev) * 1e-3),
@@ -151,15 +172,17 @@ for tag, dz2 in (("|dz2| ~ 1e-3 (the test's)", torch.randn(R, D, device=dev) * 1
         ops.fc_bwd_weight(a, g, c32, db32, ws32, R, M, N)
         c6 = torch.empty(M, N, device=dev)
         ops.gemm_bf16x3_tn(a3, pa, g3, pg, c6, M, N, R, workspace=ws_x3(True, M, N, R))
-        row(name, ref, c32, c6, a.t().contiguous(), g.t().contiguous())
+        # (split-K of the production launch at these shapes: dW1 120 tiles x 2 slabs, dW2 20 tiles x 12 slabs = 240 blocks)
+        row(name, ref, c32, c6, a.t().contiguous(), g.t().contiguous(), slabs=2 if N == H else 12)
     del x3, h13, dz13, dz23, W1T3, W2T3, W23
 print("# GATE (own-accumulator form, every row above): %s" % ("PASS" if gate_ok else "FAIL"))
+print("# GATE (ONE accumulator, lo unscaled, the weight gradients in the production kernels' K-slabs): %s" % ("PASS" if gate_one_slabs else "FAIL"))
 
 # subnormal handling of the fp16 MFMA (the one-accumulator form leans on it): a product of two subnormal-scaled planes
-t = torch.full((64, 32), 2.0 ** -20, device=dev)            # fp16 subnormal (min normal 2^-14)
-u = torch.full((64, 32), 1.0, device=dev)
+t = torch.full((64, 32), 2.0 ** -20, device=dev).half()     # fp16 subnormal (min normal 2^-14); held: the kernel reads raw pointers
+u = torch.full((64, 32), 1.0, device=dev).half()
 o = torch.empty(64, 64, device=dev)
-lib.f16x2_gemm_nt(2, t.half().data_ptr(), t.half().data_ptr(), u.half().data_ptr(), u.half().data_ptr(), 32, 32, o.data_ptr(), 64, 64, 64, 32,
+lib.f16x2_gemm_nt(2, t.data_ptr(), t.data_ptr(), u.data_ptr(), u.data_ptr(), 32, 32, o.data_ptr(), 64, 64, 64, 32,
                   0.0, 1.0, torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 print("# fp16 subnormal inputs to v_mfma_f32_16x16x32_f16: sum of 32 x (2^-20 x 1) = %.6e (exact: %.6e) -> subnormals are %s"
