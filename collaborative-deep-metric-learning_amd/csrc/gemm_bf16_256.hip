@@ -159,6 +159,13 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int grp = wave >> 2, wc = wave & 3;
   const int l31 = lane & 31, h = lane >> 5;
+  // Round 6: the MFMA's two operands SWAPPED -- a fragment of the row operand and one of the column operand have the same
+  // register layout (16 rows x 32 k, lane -> (row l & 15, k-chunk l >> 4)), so mfma(b, a) instead of mfma(a, b) costs
+  // nothing and leaves the TRANSPOSED 16 x 16 block in the accumulator: lane (l15, q) then holds output ROW l15 and the
+  // four consecutive COLUMNS 4q .. 4q + 3 of the block instead of column l15 and four rows.  An epilogue that works along
+  // rows (the miner: the best column per row) then needs no trip through LDS: a lane reduces its own 16 columns of a row,
+  // the four lanes that share the row meet in two cross-lane steps.
+  constexpr bool kSwap = EPI == BE_MINE_X3;
 
   const int k_rows = X3 ? g.x3_tpp * kTileK : g.K;              // k-strided form: rows of the operands in memory
   const i32x4 srd_a = make_srd(g.A, KI ? 3 * g.x3_plane_a * 2 : (int64_t)(TN ? k_rows : g.M) * g.lda * 2);
@@ -751,14 +758,25 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
           for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
+              if constexpr (kSwap) {
+                acc16[4 * HALF + rb][cb] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[2 * cb + ks2], fa[ks2][rb], acc16[4 * HALF + rb][cb], 0, 0, 0);
+                acc16[4 * HALF + rb][2 + cb] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[2 * cb + ks2], fa[ks2][rb], acc16[4 * HALF + rb][2 + cb], 0, 0, 0);
+              } else {
               acc16[4 * HALF + rb][cb] =
                   __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 * HALF + rb][cb], 0, 0, 0);
               acc16[4 * HALF + rb][2 + cb] =
                   __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 * HALF + rb][2 + cb], 0, 0, 0);
+              }
             }
         __builtin_amdgcn_s_setprio(0);
         CDML_BARRIER();
       };
+      // (round 6 pointed the last period's run-ahead loads -- seven half images "for the next K-tile" that nobody reads -- at the
+      // NEXT tile's first K-tile, one resident block per CU walking its tiles: the next tile then starts without a prologue.
+      // Measured on the K = 256 miner, with and without its epilogue: nothing, profiles/r06_miner_runahead_and_lds_free_
+      // epilogue_ab.txt -- a prologue out of L2 is not what a short tile waits for.  Removed.)
       auto period = [&](auto parc, const int w, const bool own) {
         const int wn = min(w + 1, w_last);                 // past the end: a valid K-tile again (its images are never read)
         const uint32_t kwa_c = (uint32_t)w * ws_a, kwb_c = (uint32_t)w * ws_b;
@@ -979,81 +997,93 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   // into the strip's plane of `mine_out`.  k_semihard_finish merges an anchor's 4 tiles_n strips.  (d, c) orders are total
   // (ties -> smaller column), so no merge order can change the result.
   if constexpr (EPI == BE_MINE_X3) {
+    // Round 6: no LDS.  With the operands swapped (kSwap) lane (l15, q) holds, per 16 x 16 block (rbb, cb), ROW rbb*16 + l15
+    // and the four consecutive columns cb*16 + 4q .. + 3: a lane's 16 columns of a row (four blocks x four) are reduced in
+    // registers, the four lanes that share the row (q = 0 .. 3: lanes l15, l15 + 16, + 32, + 48) meet in two cross-lane
+    // steps, lane q = 0 stores the row's 16-B record -- 16 rows x 16 B contiguous per store.  (Rounds 5's form: column per
+    // lane, a 16-B record per (row, lane) written to the wave's 16 KiB of LDS, read back transposed, merged 16-way: 2 246
+    // vector + 1 868 scalar instructions per wave and tile, ~12 us of a 49-us tile.)
     // Everything below is computed from a lane id the optimizer cannot see through: derived from the function's own
     // `lane`, the epilogue's addresses were hoisted ABOVE the K loop and kept live across it (256 VGPRs and 17 of them
-    // spilled to scratch inside the loop, against 222 and none this way).  A scratch store is a vector-memory operation:
-    // it is counted by the loop's hand-counted s_waitcnt vmcnt(N), which would then let fragments be read before their DMA
-    // has landed -- __graft_entry__.build() refuses a build in which a GEMM kernel has a scratch frame.
+    // spilled to scratch inside the loop).  A scratch store is a vector-memory operation: it is counted by the loop's
+    // hand-counted s_waitcnt vmcnt(N), which would then let fragments be read before their DMA has landed --
+    // __graft_entry__.build() refuses a build in which a GEMM kernel has a scratch frame.
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
-    const int l15 = lane_e & 15, q16 = lane_e >> 4, lane = lane_e;
+    const int l15 = lane_e & 15, q16 = lane_e >> 4;
     const float inf = __builtin_huge_valf();
-    MineCand *sW = reinterpret_cast<MineCand *>(smem + wave * 16384);
-    float nc[4];
-    int idc[4];
+    // the lane's 16 columns: c(cb, r) = cbase + cb*16 + r -- their |c|^2 and video ids as four 16-B loads each
+    const int cbase = n0 + wc * 64 + 4 * q16;                 // < N (N is a multiple of 256)
+    f32x4 ncv[4];
+    i32x4 idv[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-      const int c = n0 + wc * 64 + cb * 16 + l15;            // < N (N is a multiple of 256)
-      nc[cb] = g.mine_sqn[c];
-      idc[cb] = g.mine_ids[c];
+      ncv[cb] = *reinterpret_cast<const f32x4 *>(g.mine_sqn + cbase + cb * 16);
+      idv[cb] = *reinterpret_cast<const i32x4 *>(g.mine_ids + cbase + cb * 16);
+    }
+    // the lane's 8 rows: |a|^2, d_p and the anchor's / the positive's video id, all loads in flight together
+    const int row_base = m0 + grp * 128 + l15;
+    float sa8[8], dp8[8];
+    int va8[8], vp8[8];
+#pragma unroll
+    for (int rbb = 0; rbb < 8; ++rbb) {
+      const int i = min(row_base + rbb * 16, g.M - 1);
+      sa8[rbb] = g.mine_sqn[2 * i];
+      dp8[rbb] = g.mine_dp[i];
+      va8[rbb] = g.mine_ids[2 * i];
+      vp8[rbb] = g.mine_ids[2 * i + 1];
     }
     auto closer = [](float d, int c, float bd, int bc) { return d < bd || (d == bd && c < bc); };
     auto farther = [](float d, int c, float bd, int bc) { return d > bd || (d == bd && c < bc); };
-    const int row_base = m0 + grp * 128;
     MineCand *dst = g.mine_out + (int64_t)((n0 / kTileN) * 4 + wc) * g.mine_ld;
-    // the per-ROW constants of the wave's 128 anchors -- |a|^2, d_p, the two video ids -- loaded ONCE, two rows per lane,
-    // into 2 KiB of the 32 KiB of LDS the transposes leave free, and read back as one broadcast 16-B read per row (first
-    // version: four dependent global loads per row and lane inside the loop -- 128 round trips per lane and tile; the
-    // epilogue took 35 us of a 51-us tile)
-    // (as INTEGER words: video ids carried as float bit patterns are denormals, and a float move may flush them)
-    i32x4 *rowc = reinterpret_cast<i32x4 *>(smem + 8 * 16384 + wave * 2048);
+    // The "farthest eligible" candidate is the rule's FALLBACK -- taken only when an anchor has no outside candidate in any
+    // strip.  A strip that has found an outside candidate for a row therefore never needs to report a farthest one for it
+    // (the anchor has an outside candidate, full stop); a strip that has not reports its farthest as before -- if NO strip
+    // has an outside candidate, every strip reported its farthest, and k_semihard_finish's merge is what it was.  So the
+    // second scan runs only for the 16-row blocks in which some row's strip came up empty (wave-uniform test; rare: 64
+    // columns, about half of them outside): the epilogue is bound by exactly these compare-and-select chains
+    // (profiles/r06_miner_runahead_and_lds_free_epilogue_ab.txt), and this removes a third of them.
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = min(row_base + u * 64 + lane, g.M - 1);
-      rowc[u * 64 + lane] = i32x4{__float_as_int(g.mine_sqn[2 * i]), __float_as_int(g.mine_dp[i]), g.mine_ids[2 * i],
-                                  g.mine_ids[2 * i + 1]};
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    for (int rbb = 0; rbb < 8; ++rbb) {
+      const float sa = sa8[rbb], dpv = dp8[rbb];
+      const int va = va8[rbb], vp = vp8[rbb];
+      float od = inf, id_ = -inf;
+      int oc = 0x7fffffff, ic = 0x7fffffff;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {                     // 64 rows of the wave's 128 at a time
+      for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-      for (int rb4 = 0; rb4 < 4; ++rb4) {
-        const int rbb = half * 4 + rb4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int lrow = rb4 * 16 + q16 * 4 + r;             // 0 .. 63 within this half
-          const i32x4 rc = rowc[half * 64 + lrow];
-          // (through scalar copies: __builtin_bit_cast applied to a vector ELEMENT read element 0 for every element with
-          // this hipcc -- ROCm 7.2 -- so d_p came back as |a|^2 and, in the float-vector form, both ids as its bits)
-          const int w0 = rc.x, w1 = rc.y;
-          const float sa = __int_as_float(w0), dpv = __int_as_float(w1);
-          const int va = rc.z, vp = rc.w;
-          MineCand m{inf, 0x7fffffff, -inf, 0x7fffffff};
-#pragma unroll
-          for (int cb = 0; cb < 4; ++cb) {
-            const int c = n0 + wc * 64 + cb * 16 + l15;
-            const float d = (sa + nc[cb]) - 2.0f * acc16[rbb][cb][r];
-            const bool elig = idc[cb] != va && idc[cb] != vp;
-            if (elig && d > dpv && closer(d, c, m.out_d, m.out_c)) { m.out_d = d; m.out_c = c; }
-            if (elig && farther(d, c, m.in_d, m.in_c)) { m.in_d = d; m.in_c = c; }
-          }
-          sW[lrow * 16 + (l15 ^ (lrow & 15))] = m;
+        for (int r = 0; r < 4; ++r) {                        // columns ascending: a tie keeps the smaller column without a test
+          const int c = cbase + cb * 16 + r;
+          const float d = (sa + ncv[cb][r]) - 2.0f * acc16[rbb][cb][r];
+          const int vid = idv[cb][r];
+          if (vid != va && vid != vp && d > dpv && d < od) { od = d; oc = c; }
         }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      MineCand best = sW[lane * 16 + (0 ^ (lane & 15))];
 #pragma unroll
-      for (int j = 1; j < 16; ++j) {
-        const MineCand o = sW[lane * 16 + (j ^ (lane & 15))];
-        if (closer(o.out_d, o.out_c, best.out_d, best.out_c)) { best.out_d = o.out_d; best.out_c = o.out_c; }
-        if (farther(o.in_d, o.in_c, best.in_d, best.in_c)) { best.in_d = o.in_d; best.in_c = o.in_c; }
+      for (int off = 16; off < 64; off <<= 1) {              // the four lanes of a row: (d, c) orders are total, any merge order
+        const float od2 = __shfl_xor(od, off, 64);
+        const int oc2 = __shfl_xor(oc, off, 64);
+        if (closer(od2, oc2, od, oc)) { od = od2; oc = oc2; }
       }
-      const int i = row_base + half * 64 + lane;
-      if (i < g.M) dst[i] = best;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      if (__ballot(oc == 0x7fffffff) != 0ull) {              // some row of this block has no outside candidate in this strip
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = cbase + cb * 16 + r;
+            const float d = (sa + ncv[cb][r]) - 2.0f * acc16[rbb][cb][r];
+            const int vid = idv[cb][r];
+            if (vid != va && vid != vp && d > id_) { id_ = d; ic = c; }
+          }
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+          const float id2 = __shfl_xor(id_, off, 64);
+          const int ic2 = __shfl_xor(ic, off, 64);
+          if (farther(id2, ic2, id_, ic)) { id_ = id2; ic = ic2; }
+        }
+        if (oc != 0x7fffffff) { id_ = -inf; ic = 0x7fffffff; }   // (a row that HAS an outside candidate reports none: one rule per row)
+      }
+      const int i = row_base + rbb * 16;
+      if (q16 == 0 && i < g.M) dst[i] = MineCand{od, oc, id_, ic};
     }
     return;
   }

@@ -528,26 +528,33 @@ k_hinge_indexed_fwd(const float *__restrict__ e, int64_t lde, const int32_t *__r
       pos_o[i] = pos;
       neg_o[i] = neg;
       hinge_o[i] = valid ? fmaxf(t, 0.f) : 0.f;
-      scale[i] = (valid && t >= 0.f) ? two_over_b : 0.f;
+      // round 6: the scratch word of a triplet is its KEY for the backward scan -- the mined row when the triplet is
+      // active (its gradient scale is then 2 / B), -1 when it is not (scale 0): one int per triplet to scan instead of two
+      reinterpret_cast<int32_t *>(scale)[i] = (valid && t >= 0.f) ? nr : -1;
     }
   }
 }
 
 // Backward: the gradient of every embedded row r = its own triplet's term, then the terms of every triplet that mined r
 // as its negative in ascending triplet order (no atomics: bit-reproducible).
-// Round 6: a BLOCK owns 16 consecutive rows (4 per wave) and scans neg_row / scale ONCE (1 024 triplets per pass, 16-B
-// loads), compacting the hits on its rows into an LDS list in ascending triplet order (wave prefix sums over the per-lane
-// hit counts, then the waves' bases); the wave that owns a row walks the list and adds its hits.  Rounds 2-5 gave every
-// ROW a wave that scanned all B triplets itself: 2B waves x 8 B x B = 1 GB of L2 reads at B = 8 192 -- 50 of the 62 us
-// this call took in BASELINE config 2's step; a block per 16 rows reads 64 MB.  (A first version of this round gave a
-// block 64 rows, 16 per wave in sequence: every row costs two or three dependent global round trips, and 1 024 waves
-// walking 16 rows each ran 4 x SLOWER than the scan they replaced -- rows per wave is what bounds this kernel, so it is 4,
-// unrolled, all four rows' loads in flight together.)  Same terms, same order per row: the same bits.
+// Round 6.  Rounds 2-5 gave every ROW a wave that scanned all B triplets for its row in global memory (2B waves x 8 B x B =
+// 1 GB of L2 reads at B = 8 192) and added its hits one dependent round trip after the other: 62 us of BASELINE config
+// 2's step.  Now: the forward pass leaves ONE word per triplet, its key (the mined row if the triplet is active, else
+// -1); a block copies the keys into LDS once (32 KB at B = 8 192; longer batches in chunks) and each of its waves -- four
+// consecutive rows to a wave, their gradients in registers -- scans them THERE (ds_read_b128, no global latency in the
+// loop), appends its hits in ascending triplet order to a list of its own and adds them in that order with the loads of
+// kBatch hits in flight together (semi-hard mining sends many anchors to the same few "hub" rows: 27 on one row after 30
+// steps of config 2; a hub is a chain on one wave).  Intermediate forms of this round, measured and replaced: hits of a
+// 16- / 64-row block compacted through LDS with __syncthreads per 1 024 triplets (bound by that chain of barriers and
+// global round trips: 30 us without any hub); 16 rows to a wave (4 x slower than the scan it replaced: the rows' own
+// dependent loads); the wave scanning global memory itself (8 iterations x ~2 us of load latency).  Same terms, same
+// order per row as ever: the same bits.
 // Fused tail (z != null): once a row's gradient is complete its wave runs k_l2norm_bwd's arithmetic on it (dz2 = the
 // gradient of the output layer's pre-activation, leaky-relu' included) and, on request, writes dz2's bf16 copy or its
 // three exact planes -- two more launches of config 2's step (l2norm_bwd, split) folded into this one.
 constexpr int kIdxRowsPerWave = 4;
 constexpr int kIdxRows = kIdxRowsPerWave * kWavesPerBlock;      // rows per block
+constexpr int kIdxKeyChunk = 8192;                              // keys held in LDS at a time
 template <int NCH>
 __global__ void __launch_bounds__(kThreads)
 k_hinge_indexed_bwd(const float *__restrict__ e, int64_t lde, const int32_t *__restrict__ neg_row,
@@ -555,21 +562,24 @@ k_hinge_indexed_bwd(const float *__restrict__ e, int64_t lde, const int32_t *__r
                     int64_t ldde, const float *__restrict__ z, int64_t ldz, float alpha,
                     float *__restrict__ dz2, int64_t lddz, uint16_t *__restrict__ dz2_bf, int64_t ldbf,
                     int64_t plane_bf) {
-  __shared__ int s_hit[4 * kThreads];                // (triplet << 4) | row within the block
-  __shared__ int s_cnt[kWavesPerBlock];
+  constexpr int kListCap = 512;
+  __shared__ __attribute__((aligned(16))) int s_key[kIdxKeyChunk];
+  __shared__ int s_mine[kWavesPerBlock][kListCap];   // per wave: (triplet << 2) | row within the wave's four
+  const int32_t *__restrict__ key = reinterpret_cast<const int32_t *>(scale);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int nq = D >> 2;
   const int R = 2 * B;
-  const int r0 = blockIdx.x * kIdxRows;
-  const int rw0 = r0 + wave * kIdxRowsPerWave;       // this wave's rows: rw0 .. rw0 + 3
+  const int rw0 = (blockIdx.x * kWavesPerBlock + wave) * kIdxRowsPerWave;       // this wave's rows: rw0 .. rw0 + 3
+  const bool live = rw0 < R;                         // (a wave past the last row still helps to copy the keys)
+  const float two_over_b = 2.0f / (float)B;          // the forward pass's scale of an active triplet
   // the rows' gradients live in REGISTERS (NCH float4 per lane and row) until they are complete
   float4 acc[kIdxRowsPerWave][NCH];
 #pragma unroll
   for (int u = 0; u < kIdxRowsPerWave; ++u) {        // own triplet: anchor or positive role
     const int r = min(rw0 + u, R - 1);
     const int i = r >> 1;
-    const float si = scale[i];
+    const float si = key[i] >= 0 ? two_over_b : 0.f;
     const float *a = e + (int64_t)(2 * i) * lde, *p = a + lde;
     const int nr = neg_row[i];
     const float *n = e + (int64_t)(nr >= 0 ? nr : 2 * i) * lde;
@@ -584,65 +594,91 @@ k_hinge_indexed_bwd(const float *__restrict__ e, int64_t lde, const int32_t *__r
       }
     }
   }
-  for (int j0 = 0; j0 < B; j0 += 4 * kThreads) {
-    const int j = j0 + 4 * (int)threadIdx.x;
-    unsigned hits = 0;                               // bit u: triplet j + u mined a row of this block and is active
-    int rl[4] = {0, 0, 0, 0};
-    if (j + 3 < B) {
-      const int4 n4 = *reinterpret_cast<const int4 *>(neg_row + j);
-      const float4 s4 = *reinterpret_cast<const float4 *>(scale + j);
-      rl[0] = n4.x - r0; rl[1] = n4.y - r0; rl[2] = n4.z - r0; rl[3] = n4.w - r0;
-      hits = (unsigned)((unsigned)rl[0] < (unsigned)kIdxRows && s4.x != 0.f) |
-             ((unsigned)((unsigned)rl[1] < (unsigned)kIdxRows && s4.y != 0.f) << 1) |
-             ((unsigned)((unsigned)rl[2] < (unsigned)kIdxRows && s4.z != 0.f) << 2) |
-             ((unsigned)((unsigned)rl[3] < (unsigned)kIdxRows && s4.w != 0.f) << 3);
-    } else {
-      for (int u = 0; u < 4 && j + u < B; ++u) {
-        rl[u] = neg_row[j + u] - r0;
-        hits |= (unsigned)((unsigned)rl[u] < (unsigned)kIdxRows && scale[j + u] != 0.f) << u;
+  constexpr int kBatch = NCH == 1 ? 16 : (NCH == 2 ? 4 : 2);
+  int n_mine = 0;                                    // wave-uniform
+  auto flush = [&]() {                               // add the listed hits, in list order, kBatch loads in flight
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int h0 = 0; h0 < n_mine; h0 += kBatch) {
+      float4 ga[kBatch][NCH], ge[kBatch][NCH];
+      int ub[kBatch];
+#pragma unroll
+      for (int b = 0; b < kBatch; ++b) {
+        const bool on = h0 + b < n_mine;
+        const int hv = on ? s_mine[wave][h0 + b] : 0;
+        const int jj = hv >> 2, u = hv & 3;
+        ub[b] = on ? u : -1;
+        const float *aj = e + (int64_t)(2 * jj) * lde;
+        const float *er = e + (int64_t)min(rw0 + u, R - 1) * lde;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int q = lane + kWave * c;
+          const bool ld = on && q < nq;
+          ga[b][c] = ld ? ld4(aj, q) : make_float4(0.f, 0.f, 0.f, 0.f);
+          ge[b][c] = ld ? ld4(er, q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < kBatch; ++b) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const float4 g = mul4(sub4(ga[b][c], ge[b][c]), two_over_b);
+#pragma unroll
+          for (int uu = 0; uu < kIdxRowsPerWave; ++uu)   // (ub is wave-uniform: a select, not a dynamic register index)
+            if (uu == ub[b]) acc[uu][c] = make_float4(acc[uu][c].x + g.x, acc[uu][c].y + g.y, acc[uu][c].z + g.z, acc[uu][c].w + g.w);
+        }
       }
     }
-    const int cnt = __popc(hits);
-    int incl = cnt;                                  // inclusive prefix sum over the wave's lanes
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const int t = __shfl_up(incl, off, kWave);
-      if (lane >= off) incl += t;
-    }
-    if (lane == kWave - 1) s_cnt[wave] = incl;
-    __syncthreads();
-    int base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) {
-      const int c = s_cnt[w];
-      base += (w < wave) ? c : 0;
-      total += c;
-    }
-    int pos = base + incl - cnt;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (hits & (1u << u)) s_hit[pos++] = ((j + u) << 4) | rl[u];
-    __syncthreads();
-    for (int h = 0; h < total; ++h) {                // ascending triplets; each wave takes the hits on its own rows
-      const int hv = s_hit[h];
-      const int rloc = hv & 15;
-      if ((rloc >> 2) != wave) continue;
-      const int jj = hv >> 4, u = rloc & 3;
-      const float sj = scale[jj];
-      const float *aj = e + (int64_t)(2 * jj) * lde;
-      const float *er = e + (int64_t)(r0 + rloc) * lde;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int q = lane + kWave * c;
-        if (q >= nq) continue;
-        const float4 g = mul4(sub4(ld4(aj, q), ld4(er, q)), sj);
-#pragma unroll
-        for (int uu = 0; uu < kIdxRowsPerWave; ++uu)   // (u is wave-uniform: a select, not a dynamic register index)
-          if (uu == u) acc[uu][c] = make_float4(acc[uu][c].x + g.x, acc[uu][c].y + g.y, acc[uu][c].z + g.z, acc[uu][c].w + g.w);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    n_mine = 0;
+  };
+  for (int k0 = 0; k0 < B; k0 += kIdxKeyChunk) {
+    const int nk = min(kIdxKeyChunk, B - k0);        // keys of this chunk (the whole batch up to 8 192 triplets)
+    if (k0) __syncthreads();                         // every wave is done with the previous chunk
+    for (int t = (int)threadIdx.x * 4; t < nk; t += kThreads * 4) {
+      if (t + 3 < nk) {
+        *reinterpret_cast<int4 *>(s_key + t) = *reinterpret_cast<const int4 *>(key + k0 + t);
+      } else {
+        for (int u = 0; u < 4 && t + u < nk; ++u) s_key[t + u] = key[k0 + t + u];
       }
     }
-    __syncthreads();                                 // the list is reused by the next pass
+    __syncthreads();
+    if (!live) continue;
+    // the scan: lane l of a step looks at keys j .. j + 3, j = step * 256 + 4 l
+    for (int j0 = 0; j0 < nk; j0 += 4 * kWave) {
+      const int j = j0 + 4 * lane;
+      int4 k4 = make_int4(-1, -1, -1, -1);
+      if (j + 3 < nk) {
+        k4 = *reinterpret_cast<const int4 *>(s_key + j);
+      } else if (j < nk) {
+        k4.x = s_key[j];
+        if (j + 1 < nk) k4.y = s_key[j + 1];
+        if (j + 2 < nk) k4.z = s_key[j + 2];
+      }
+      const unsigned r0_ = (unsigned)(k4.x - rw0), r1_ = (unsigned)(k4.y - rw0), r2_ = (unsigned)(k4.z - rw0), r3_ = (unsigned)(k4.w - rw0);
+      const unsigned h = (unsigned)(r0_ < (unsigned)kIdxRowsPerWave) | ((unsigned)(r1_ < (unsigned)kIdxRowsPerWave) << 1) |
+                         ((unsigned)(r2_ < (unsigned)kIdxRowsPerWave) << 2) | ((unsigned)(r3_ < (unsigned)kIdxRowsPerWave) << 3);
+      if (__ballot(h != 0) == 0ull) continue;        // (wave-uniform; the usual case)
+      // position of a lane's hits in the list: the hits of the lanes below it, then its own in triplet order
+      int below = 0, total = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned long long bl = __ballot((h >> u) & 1u);
+        below += __popcll(bl & ((1ull << lane) - 1ull));
+        total += __popcll(bl);
+      }
+      if (n_mine + total > kListCap) flush();        // (total <= 256 <= kListCap)
+      int pos = n_mine + below;
+      const unsigned rl[4] = {r0_, r1_, r2_, r3_};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if ((h >> u) & 1u) s_mine[wave][pos++] = ((k0 + j + u) << 2) | (int)rl[u];
+      n_mine += total;
+    }
   }
+  if (!live) return;
+  flush();
 #pragma unroll
   for (int u = 0; u < kIdxRowsPerWave; ++u) {
     const int r = rw0 + u;

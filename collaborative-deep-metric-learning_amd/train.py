@@ -44,7 +44,7 @@ class TrainStep:
                  base_learning_rate=0.01, learning_rate_decay_examples=1000000,
                  learning_rate_decay=0.96, seed=1234, weight_seed=42, device="cuda:0",
                  exchange=None, grad_sync=None, slot0=0, batch_global=None, use_graph=False,
-                 prefetch=True, precision="f32", train_table=False, gather_ahead="auto",
+                 prefetch=True, precision="auto", train_table=False, gather_ahead="auto",
                  clip_gradient_norm=0.0, regularization_penalty=0.0, l2_penalty=1e-8,
                  grad_sync_mode="bucketed"):
         """table: FeatureTable (whole catalogue, or this rank's shard when
@@ -52,6 +52,9 @@ class TrainStep:
         ``grad_sync``: the multi-GPU hooks of cdml_amd.dist (None on one GPU).
         ``train_table``: also train the catalogue rows (lazy Adam, states stored beside the
         shard; build-defined -- the reference keeps the features frozen, train.py:265).
+        ``precision``: "auto" (default) = "bf16" for an fp16 catalogue (BASELINE config 4), else "f32x3" -- fp32 operands as
+        three exact bf16 planes, six plane products per fp32 product on the bf16 MFMA, held to the fp32 path's bounds; what
+        bench.py times -- when the step's rows are a multiple of 128, else "f32" (the fp32 MFMA).
         ``use_graph``: False = eager; True = the whole step replayed from ONE hipGraph (single GPU: the
         fast form; data-parallel: the exchange of step t+1 is then recorded on the capturing stream,
         ahead of the forward pass, not under it); "split" (data-parallel with the prefetcher) = three
@@ -114,8 +117,17 @@ class TrainStep:
         self.slot0 = int(slot0)
         self.batch_global = self.B if batch_global is None else int(batch_global)
         F = table.feature_size if feature_size is None else feature_size
+        if precision in ("auto", None):
+            # round 6: the default is the path bench.py times.  An fp16 catalogue is config 4's path; an fp32
+            # catalogue takes the split-fp32 products on the bf16 MFMA ("f32x3": fp32 results, 1.7 x the fp32 MFMA's rate)
+            # whenever the step's row count allows it (a multiple of 128: the plane kernels' row tiles), else the fp32 MFMA.
+            # Say precision="f32" / "f32x3" to pin one.
+            if table.data.dtype == torch.float16:
+                precision = "bf16"
+            else:
+                precision = "f32x3" if (self.B * self.rows_per_triplet) % 128 == 0 else "f32"
         if precision not in ("f32", "bf16", "f32x3", "f32x3-3"):
-            raise ValueError("precision must be 'f32', 'f32x3' or 'bf16'")
+            raise ValueError("precision must be 'auto', 'f32', 'f32x3' or 'bf16'")
         self.precision = precision
         self.bf16 = precision == "bf16"          # BASELINE config 4: fp16 table + bf16 MFMA
         # fp32 products on the bf16 MFMA: operands as three exact bf16 planes, six plane products (engine_x3;

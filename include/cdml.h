@@ -272,7 +272,8 @@ int cdml_semihard_mine_x3(const float *e, int64_t lde, const int32_t *rows, int 
 /* Hinge loss + gradient over triplets (row 2i, row 2i+1, row neg_row[i]);
  * neg_row[i] = -1 masks a triplet (hinge 0, still counted in the mean).  Rows
  * mined by several anchors accumulate their gradients in ascending triplet
- * order (deterministic).  scale_scratch: float[B]. */
+ * order (deterministic).  scale_scratch: B 32-bit words of scratch (the forward launch leaves every triplet's key
+ * for the gradient launch there: the mined row if the triplet is active, -1 if not). */
 int cdml_triplet_hinge_indexed(const float *e, int64_t lde,
                                const int32_t *neg_row, int B, int D, float margin,
                                float *pos, float *neg, float *hinge, float *stats,
@@ -282,8 +283,9 @@ int cdml_triplet_hinge_indexed(const float *e, int64_t lde,
  * z (pre-normalisation output rows, e = l2norm(z)) given, every row's finished gradient de goes straight through
  * cdml_l2norm_bwd's arithmetic -- dz2 = l2norm-backward(z, de) times leaky-relu'(z) (lrelu_alpha < 0: none) -- and,
  * dz2_bf16 given, its bf16 copy (plane_bf = 0) or its three exact bf16 planes hi | mid | lo, plane_bf elements apart
- * (what cdml_split_f32_bf16x3 writes).  Bit-identical to the separate launches (losses.py:32-38, models.py:61,
- * train.py:141).  z = NULL: cdml_triplet_hinge_indexed. */
+ * (what cdml_split_f32_bf16x3 writes).  Equal to the separate launches: de bit for bit, dz2 to a few ulp (which
+ * multiply-adds become fmas differs between kernels), the planes exactly those of the dz2 written here
+ * (losses.py:32-38, models.py:61, train.py:141).  z = NULL: cdml_triplet_hinge_indexed. */
 int cdml_triplet_hinge_indexed_tail(const float *e, int64_t lde, const int32_t *neg_row, int B, int D,
                                     float margin, float *pos, float *neg, float *hinge, float *stats,
                                     float *scale_scratch, float *de, int64_t ldde, const float *z,

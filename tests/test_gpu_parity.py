@@ -1032,7 +1032,8 @@ def test_indexed_hinge_backward_block_scan_and_fused_tail(cd, B, D, skew):
     its hits in ascending triplet order) with the rest of config 2's tail folded in.  Against the fp64 oracle on any
     distribution of mined rows -- uniform, EVERY anchor mining one row (one wave adds B terms in order), a handful of
     rows, masked triplets; batch sizes that are no multiple of 4 or of the 1 024-triplet pass -- and the fused tail
-    (l2norm backward + leaky-relu' + bf16 copy / three planes) bit-identical to the separate launches
+    (l2norm backward + leaky-relu' + bf16 copy / three planes) equal to the separate launches -- the row gradients bit for
+    bit, dz2 to a few ulp (fma contraction differs between kernels), its planes exactly those of the dz2 it wrote
     (losses.py:32-38, models.py:61, train.py:141)."""
     rng = np.random.RandomState(B + D)
     Z = (rng.randn(2 * B, D) * 0.3).astype(np.float32)
@@ -1073,12 +1074,19 @@ def test_indexed_hinge_backward_block_scan_and_fused_tail(cd, B, D, skew):
         bf = torch.zeros((2 * B, 3 * D if planes else D), dtype=torch.bfloat16, device=cd.dev)
         cd.ops.triplet_hinge_indexed(de_, dn, B, D, 0.8, pos, neg, hinge, scale, stats, dE_b, z=dz_, dz2=dz2_b, dz2_bf16=bf,
                                      plane_bf=D if planes else 0)
-        assert torch.equal(dE_b, dE) and torch.equal(dz2_b, dz2_a)
-        if planes:
-            assert torch.equal(bf, pl_a)
-            assert torch.equal(bf[:, :D].float() + bf[:, D:2 * D].float() + bf[:, 2 * D:].float(), dz2_a)
+        assert torch.equal(dE_b, dE)
+        # the l2norm backward inside another kernel: the same operations, but which multiply-adds the compiler contracts
+        # into fmas differs from kernel to kernel -- a few ulp, as between k_vnet_tail and its separate kernels
+        # (per row, against the size of what is subtracted there: dz2 = (g - z <z,g> / |z|^2) / |z| cancels on hub rows)
+        row_scale = dE.abs().max(dim=1).values / dz_.norm(dim=1)
+        assert bool(((dz2_b - dz2_a).abs().max(dim=1).values <= 1e-6 * row_scale + 1e-12).all())
+        if planes:                                               # the planes are those of THIS launch's dz2, exactly
+            assert torch.equal(bf[:, :D].float() + bf[:, D:2 * D].float() + bf[:, 2 * D:].float(), dz2_b)
+            chk = torch.zeros_like(bf)
+            cd.ops.split_f32_bf16x3(dz2_b, chk, D)
+            assert torch.equal(bf, chk)
         else:
-            assert torch.equal(bf, dz2_a.to(torch.bfloat16))
+            assert torch.equal(bf, dz2_b.to(torch.bfloat16))
 
 
 def _check_semihard_choice(got, want, dist, rows, B, tol=2e-6):

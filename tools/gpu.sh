@@ -12,7 +12,11 @@ python __graft_entry__.py | tail -1
 START=$(date +%s)
 /usr/local/graft/bin/gpurun --timeout "$1" -- "$2" 2>&1 | tee gpurun_out/${TAG}.gpurun.log
 RC=${PIPESTATUS[0]}
-if [ "$RC" -ne 0 ] && [ "$RC" -ne 2 ] && [ "$RC" -ne 3 ]; then      # (2 = refused, 3 = no box: nothing ran)
+# (a run script of tools/runs/ reports its steps as "[tag] step rc=N": a step that failed inside a call that itself ended
+#  with rc 0 -- a failed test file, a probe that raised -- keeps its record too)
+STEP_FAILED=0
+grep -q -E "^\[[a-z0-9_]+\] .*rc=[1-9]" gpurun_out/${TAG}.gpurun.log && STEP_FAILED=1
+if { [ "$RC" -ne 0 ] && [ "$RC" -ne 2 ] && [ "$RC" -ne 3 ]; } || [ "$STEP_FAILED" -eq 1 ]; then      # (2 = refused, 3 = no box: nothing ran)
   D=profiles/faults/$(date -u +%Y%m%dT%H%M%SZ)_${TAG}
   mkdir -p "$D"
   cp gpurun_out/${TAG}.gpurun.log "$D/" 2>/dev/null
@@ -25,6 +29,6 @@ if [ "$RC" -ne 0 ] && [ "$RC" -ne 2 ] && [ "$RC" -ne 3 ]; then      # (2 = refus
       tail -400 "$f" > "$D/$(basename "$f")"
     fi
   done
-  echo "[gpu.sh] rc=$RC: record kept under $D"
+  echo "[gpu.sh] rc=$RC step_failed=$STEP_FAILED: record kept under $D"
 fi
 exit $RC
