@@ -978,8 +978,10 @@ def rec_predict(dev, precision, n_rows=10000000, chunk=100000, reps=2):
 def rec_knn(dev, n=343455, k=51, precision="f32x3"):
     """The kNN export (faiss_knn.py:82-131 `calc_knn`; the reference's production catalogue: doc_location = 343455,
     faiss_knn.py:389; nearest_num = 51 = 50 neighbours + the query): EXACT self-kNN of n unit 256-d embeddings -- the
-    reference builds an approximate HNSW index on the CPU.  Algorithmic work: 2 n^2 D flop of inner products; the n^2
-    scores are produced and consumed in 128-MiB blocks that stay in the Infinity Cache."""
+    reference builds an approximate HNSW index on the CPU.  Algorithmic work: 2 n^2 D flop of inner products.  Round 6: only the
+    first 32 768 catalogue rows go through score blocks (they give every query its k-th best distance so far); the other
+    90 % of the n^2 scores are never written -- the plane GEMM's epilogue appends the few elements within that distance
+    to the query's candidate list (cdml_knn_filter_x3), one merge per query at the end."""
     from cdml_amd import knn
     g = torch.Generator(device=dev)
     g.manual_seed(0)
@@ -997,8 +999,9 @@ def rec_knn(dev, n=343455, k=51, precision="f32x3"):
                         "inner products + per-query top-k merge, results in HBM" % (n, D, k),
             "precision": precision, "value": round(n / el, 1), "unit": "queries/s", "seconds": round(el, 4),
             "inner_product_tflops": round(flops / el / 1e12, 2), "frac_of_mfma_peak": round(flops / el / 1e12 / peak, 4),
-            "peak_tflops": peak, "score_bytes_through_cache": 2.0 * n * n * 4,
-            "score_stream_TBs": round(2.0 * n * n * 4 / el / 1e12, 2),
+            "peak_tflops": peak,
+            "score_blocks": "the first %d catalogue rows only (%.0f %% of the scores: written and merged out of the Infinity Cache); "
+                            "the rest filtered in the score product's epilogue, nothing written" % (knn.FIRST_BLOCK, 100.0 * knn.FIRST_BLOCK / n),
             "query_is_its_own_first_neighbour": self_first, "mean_second_neighbour_d2": round(float(Dk[:, 1].mean()), 5)}
 
 

@@ -106,6 +106,8 @@ SIGNATURES = {
     "cdml_knn_list_capacity": (_i, []),
     "cdml_row_sqnorm": (_i, [_p, _i64, _i, _i, _p, _p]),
     "cdml_knn_merge": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
+    "cdml_knn_filter_x3": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
+    "cdml_knn_merge_list": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "cdml_gemm_bf16_workspace": (_sz, [_i, _i, _i]),
     "cdml_gemm_bf16_epilogue_supported": (_i, [_i, _i, _i, _i, _i64, _i64, _i64, _i64]),
     "cdml_gemm_bf16_nt": (_i, [_i, _p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _i64, _f, _p, _sz, _p]),

@@ -26,7 +26,11 @@ enum { BE_BIAS_LRELU_BF16 = 0, BE_BIAS_LRELU_F32 = 1, BE_MASK_BF16 = 2, BE_F32 =
        // (BArgs::mine_*; gemm_bf16_256.hip "mine tail", loss.hip cdml_semihard_mine_x3)
        BE_MINE_X3 = 11,
        // ABI-level id of cdml_gemm_bf16x3_nt: 10 (or 7 without a mask) with the planes of the result k8-interleaved
-       BE_MASKBITS_X3_KI = 12 };
+       BE_MASKBITS_X3_KI = 12,
+       // exact kNN (faiss_knn.py:82-131) as the epilogue of the query x catalogue score product: nothing of the scores is
+       // written -- an element whose distance is within its query's current k-th best (BArgs::knn_*) is appended to the
+       // query's candidate list (gemm_bf16_256.hip "knn filter", knn.hip cdml_knn_filter_x3)
+       BE_KNN_X3 = 13 };
 
 // one candidate pair of an anchor over some set of columns: the closest eligible column with d > d_p ("outside"; ties ->
 // smaller column) and the farthest eligible one; c = 0x7fffffff: none
@@ -68,6 +72,11 @@ struct BArgs {
   // mine_sqn[c] = |e_c|^2, mine_ids[c] = the video id of row c, mine_dp[i] = d(anchor i, its positive);
   // mine_out[(tn * 4 + strip) * mine_ld + i] = anchor i's candidates over the 64 columns of strip `strip` of tile column tn
   const float *mine_sqn; const int32_t *mine_ids; const float *mine_dp; MineCand *mine_out; int64_t mine_ld;
+  // BE_KNN_X3: A = the queries' planes, B = a block of the catalogue's planes (column c of the launch = catalogue row
+  // knn_col0 + c; rows >= knn_n_valid are padding), C unused.  d = knn_qsq[row] + knn_bsq[c] - 2 <q, b> (clamped at 0); an
+  // element with d <= knn_tau[row] takes slot atomicAdd(knn_cnt + row, 1) of the row's knn_cap-slot list knn_cand
+  // ((d, id) pairs; a slot beyond the capacity is dropped -- the count says so)
+  const float *knn_qsq, *knn_bsq, *knn_tau; int32_t *knn_cnt; uint2 *knn_cand; int knn_cap, knn_col0, knn_n_valid;
 };
 
 // 256x256x64 kernel: true if the shape can use it (N % 256 == 0, K per split a
@@ -80,6 +89,8 @@ int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t s
 int launch_gemm_bf16_256_x3(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t stream);
 // the score product of semi-hard mining with the selection as its epilogue (BE_MINE_X3; six products, resident-plane walk)
 int launch_gemm_x3_mine(const BArgs &g, hipStream_t stream);
+// the query x catalogue score product of the kNN export with the threshold filter as its epilogue (BE_KNN_X3)
+int launch_gemm_x3_knn(const BArgs &g, hipStream_t stream);
 // the k-strided product on k8-INTERLEAVED operands ([plane][k / 8][column][8 k]; g.lda / g.ldb = elements per k-group,
 // g.x3_plane_* = elements per plane): the resident-plane walk with one 16-B LDS read per fragment
 int launch_gemm_x3_tnk(const BArgs &g, int splits, hipStream_t stream);

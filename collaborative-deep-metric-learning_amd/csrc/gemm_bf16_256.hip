@@ -152,7 +152,8 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
                 "the 128 x 256 half tile exists for the plane-output products of the resident-plane walk and for the fp32 slabs of the narrow layer");
   static_assert(X3 || (EPI != BE_BIAS_LRELU_X3 && EPI != BE_MASK_X3 && EPI != BE_ROWBIAS_LRELU_X3),
                 "plane outputs belong to the split-fp32 form");
-  static_assert(EPI != BE_MINE_X3 || (X3 && S16 && R6 && !TN && !NARROW), "the mining epilogue rides on the resident-plane walk");
+  static_assert((EPI != BE_MINE_X3 && EPI != BE_KNN_X3) || (X3 && S16 && R6 && !TN && !NARROW),
+                "the mining / kNN-filter epilogues ride on the resident-plane walk");
   static_assert(!KI || (TN && X3 && S16 && R6), "the k8-interleaved operands exist for the k-strided resident-plane walk");
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -165,7 +166,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   // four consecutive COLUMNS 4q .. 4q + 3 of the block instead of column l15 and four rows.  An epilogue that works along
   // rows (the miner: the best column per row) then needs no trip through LDS: a lane reduces its own 16 columns of a row,
   // the four lanes that share the row meet in two cross-lane steps.
-  constexpr bool kSwap = EPI == BE_MINE_X3;
+  constexpr bool kSwap = EPI == BE_MINE_X3 || EPI == BE_KNN_X3;
 
   const int k_rows = X3 ? g.x3_tpp * kTileK : g.K;              // k-strided form: rows of the operands in memory
   const i32x4 srd_a = make_srd(g.A, KI ? 3 * g.x3_plane_a * 2 : (int64_t)(TN ? k_rows : g.M) * g.lda * 2);
@@ -1088,6 +1089,48 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
     return;
   }
 
+  // ---- the kNN export's threshold filter as the epilogue of the query x catalogue score product (faiss_knn.py:82-131; exact
+  // search) ---------------------------------------------------------------------------------------------------------------
+  // The tile holds <q_i, b_c> for 256 queries x 256 catalogue rows and writes none of it (rounds 1-5 wrote 128-MiB score
+  // blocks and merged them out of the Infinity Cache).  Every query already has a k-th best distance tau from a first block
+  // of the catalogue; an element within it -- a fraction k / (columns seen) of them: a few per tile -- is appended to its
+  // query's candidate list (atomic slot counter; the lists are merged into the exact top-k by k_knn_merge_list).  Same
+  // operand-swapped register layout as the miner: lane (l15, q) holds row rbb*16 + l15, columns cb*16 + 4q .. + 3.
+  if constexpr (EPI == BE_KNN_X3) {
+    int lane_e = lane;                                       // (opaque: nothing of this is hoisted above the K loop)
+    asm volatile("" : "+v"(lane_e));
+    const int l15 = lane_e & 15, q16 = lane_e >> 4;
+    const int cbase = n0 + wc * 64 + 4 * q16;                // launch-local column of the lane's first element
+    f32x4 bsv[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) bsv[cb] = *reinterpret_cast<const f32x4 *>(g.knn_bsq + cbase + cb * 16);
+    const int row_base = m0 + grp * 128 + l15;
+    float qs8[8], tau8[8];
+#pragma unroll
+    for (int rbb = 0; rbb < 8; ++rbb) {
+      const int i = min(row_base + rbb * 16, g.M - 1);
+      qs8[rbb] = g.knn_qsq[i];
+      tau8[rbb] = g.knn_tau[i];
+    }
+#pragma unroll
+    for (int rbb = 0; rbb < 8; ++rbb) {
+      const int i = row_base + rbb * 16;
+      const float qs = qs8[rbb], tau = tau8[rbb];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int id = g.knn_col0 + cbase + cb * 16 + r;
+          const float d = fmaxf((qs + bsv[cb][r]) - 2.0f * acc16[rbb][cb][r], 0.f);
+          if (d <= tau && id < g.knn_n_valid && i < g.M) {   // rare
+            const int pos = atomicAdd(g.knn_cnt + i, 1);
+            if (pos < g.knn_cap) g.knn_cand[(int64_t)i * g.knn_cap + pos] = make_uint2(__float_as_uint(d), (uint32_t)id);
+          }
+        }
+    }
+    return;
+  }
+
   // ---- epilogue: per wave, 32x64 strips through its private 16 KiB of LDS ----
   float *sC = reinterpret_cast<float *>(smem + wave * 16384);
   const int c4 = lane & 15;
@@ -1417,7 +1460,7 @@ __device__ __forceinline__ void block_of_launch(const BArgs &g, int bid, unsigne
       bid = g.narrow_first + (bid >> 1);
     }
   }
-  if (EPI != BE_MINE_X3 && g.K <= (X3 ? 3072 : 512)) tile_of_block_rowmajor(bid, nwg, g.tiles_n, tm, tn);   // output-bound
+  if (EPI != BE_MINE_X3 && EPI != BE_KNN_X3 && g.K <= (X3 ? 3072 : 512)) tile_of_block_rowmajor(bid, nwg, g.tiles_n, tm, tn);   // output-bound
   else tile_of_block(bid, nwg, g.tiles_m, g.tiles_n, tm, tn);
   const int m0 = tm * kTileM + half * (kTileM / 2), n0 = tn * kTileN;
   const int split = blockIdx.y;
@@ -1715,6 +1758,10 @@ int launch_gemm_x3_tnk(const BArgs &g, int splits, hipStream_t s) {
 
 int launch_gemm_x3_mine(const BArgs &g, hipStream_t s) {
   return launch_x3_1<false, BE_MINE_X3, false, false, true>(g, g.tiles_m * g.tiles_n, 1, s);
+}
+
+int launch_gemm_x3_knn(const BArgs &g, hipStream_t s) {
+  return launch_x3_1<false, BE_KNN_X3, false, false, true>(g, g.tiles_m * g.tiles_n, 1, s);
 }
 
 int launch_gemm_bf16_256_x3(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t s) {

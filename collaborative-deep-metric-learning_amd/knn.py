@@ -18,6 +18,13 @@ from . import ops
 
 Q_BLOCK = 4096      # query rows per GEMM; 4096 x 8192 scores = 128 MiB stay in the 256 MiB Infinity Cache
 B_BLOCK = 8192
+# Round 6 (precision "f32x3"): only the FIRST block of the catalogue goes through score blocks -- it gives every query a k-th
+# best distance tau -- and the rest through ONE launch of the plane GEMM whose epilogue appends every element within tau to
+# its query's candidate list (cdml_knn_filter_x3): no score matrix.  An element of the rest passes with probability
+# ~ k / FIRST_BLOCK for exchangeable rows, so a query collects ~ k * (n - FIRST_BLOCK) / FIRST_BLOCK candidates; the lists
+# have four times that many slots, and a list that overflows anyway (rows sorted so that later ones are closer) sends the
+# whole search back through the score blocks -- nothing is silently lost.
+FIRST_BLOCK = 32768
 
 
 def _round_up(x, m):
@@ -40,11 +47,14 @@ def _planes(x, Dp):
     return out
 
 
-def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK, b_block=B_BLOCK, precision="f32x3"):
+def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK, b_block=B_BLOCK, precision="f32x3",
+               fused=True, first_block=FIRST_BLOCK):
     """Device tensors (D [nq,k] fp32 squared L2 ascending, I [nq,k] int64; -1 where
     the catalogue has fewer than k rows).  ``precision``: "f32x3" (default; round 6) = the inner products on the plane
     kernels -- the headline path's arithmetic: every fp32 operand as three exact bf16 planes, six plane products per fp32
-    product on the bf16 MFMA (csrc/gemm_bf16x3.hip), errors those of the fp32 kernels -- or "f32" = the fp32 MFMA."""
+    product on the bf16 MFMA (csrc/gemm_bf16x3.hip), errors those of the fp32 kernels -- or "f32" = the fp32 MFMA.
+    ``fused`` (precision "f32x3", catalogues of more than two first blocks): everything after the first ``first_block``
+    catalogue rows through the filter epilogue instead of score blocks (False: score blocks throughout, the round-5 form)."""
     if precision not in ("f32x3", "f32"):
         raise ValueError("precision must be 'f32x3' or 'f32'")
     x3 = precision == "f32x3"
@@ -78,9 +88,15 @@ def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK,
     if x3:
         B3 = _planes(B, Dp)
         Q3 = B3 if same else _planes(Q, Dp)
+    n_pad = B.shape[0]
+    first_cols = n_pad
+    use_filter = (x3 and fused and first_block % b_block == 0 and first_block >= 4 * k and nb > 2 * first_block
+                  and (nq + 256) * 3 * Dp * 2 < 2 ** 31 and (n_pad - first_block) * 3 * Dp * 2 < 2 ** 31)
+    if use_filter:
+        first_cols = first_block
     for q0 in range(0, nq, q_block):
         m = min(q_block, nq - q0)
-        for c0 in range(0, B.shape[0], b_block):
+        for c0 in range(0, first_cols, b_block):
             # scores[m, b_block] = Q[q0:q0+m] @ B[c0:c0+b_block]^T
             if x3:
                 ops.gemm_bf16x3_nt(ops.BE_F32, Q3[q0:q0 + m], Dp, B3[c0:c0 + b_block], Dp, scores, m, b_block, Dp)
@@ -88,6 +104,21 @@ def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK,
                 ops.fc_bwd_data(Q[q0:q0 + m], B[c0:c0 + b_block], None, scores, m, b_block, Dp)
             ops.knn_merge(scores, m, b_block, c0, nb, q_sq[q0:q0 + m], b_sq[c0:c0 + b_block], k,
                           best_d[q0:q0 + m], best_i[q0:q0 + m], first=(c0 == 0))
+    if use_filter:
+        expect = k * (nb - first_cols) / float(first_cols)
+        cap = 64
+        while cap < 4 * expect:
+            cap *= 2
+        tau = best_d[:, k - 1].contiguous()
+        cnt = torch.zeros(nq, dtype=torch.int32, device=device)
+        cand = torch.empty((nq, cap, 2), dtype=torch.int32, device=device)
+        overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        ops.knn_filter_x3(Q3, Dp, B3[first_cols:], Dp, nq, n_pad - first_cols, Dp, q_sq, b_sq[first_cols:], tau, first_cols, nb,
+                          cnt, cand, cap)
+        ops.knn_merge_list(cand, cnt, cap, nq, k, best_d, best_i, overflow)
+        if int(overflow.item()):                             # (a sync; the export is not a step path)
+            return knn_search(base, queries, k, l2_norm=l2_norm, device=device, q_block=q_block, b_block=b_block,
+                              precision=precision, fused=False)
     I = best_i[:, :k].to(torch.int64)
     I[I == 0x7fffffff] = -1
     return best_d[:, :k].contiguous(), I

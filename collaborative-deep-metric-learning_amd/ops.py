@@ -346,6 +346,22 @@ def knn_merge(scores, nq, nb, col0, n_valid, q_sq, b_sq, k, best_d, best_i, firs
          _p(best_i, torch.int32), int(bool(first)), _stream())
 
 
+def knn_filter_x3(Q3, plane_q, B3, plane_b, nq, n_cols, D, q_sq, b_sq, tau, col0, n_valid, cnt, cand, cap):
+    """The query x catalogue-block inner products on the plane kernels with the threshold filter as their epilogue: every
+    element with d <= tau[query] is appended to the query's candidate list (cand int32 [nq, cap, 2]: float bits of d, id)."""
+    qp, qld = _mat16(Q3)
+    bp, bld = _mat16(B3)
+    if cand.dtype != torch.int32 or not cand.is_contiguous() or cand.numel() < nq * cap * 2:
+        raise ValueError("cand must be a contiguous int32 buffer of nq * cap * 2 words")
+    call("cdml_knn_filter_x3", qp, qld, plane_q, bp, bld, plane_b, nq, n_cols, D, _p(q_sq), _p(b_sq), _p(tau), col0, n_valid,
+         _p(cnt, torch.int32), _p(cand, torch.int32), cap, _stream())
+
+
+def knn_merge_list(cand, cnt, cap, nq, k, best_d, best_i, overflow):
+    call("cdml_knn_merge_list", _p(cand, torch.int32), _p(cnt, torch.int32), cap, nq, k, _p(best_d), _p(best_i, torch.int32),
+         _p(overflow, torch.int32), _stream())
+
+
 # ------------------------------------------------- fusion towers (N4) ---------
 EW_MUL, EW_MUL_RES, EW_ADD = 0, 1, 2
 

@@ -338,6 +338,21 @@ int cdml_knn_merge(const float *scores, int64_t lds, int nq, int nb, int col0,
                    int n_valid, const float *q_sq, const float *b_sq, int k,
                    float *best_d, int32_t *best_i, int first, cdml_stream_t stream);
 
+/* The same export WITHOUT a score matrix (round 6).  cdml_knn_filter_x3: the query x catalogue-block inner products on
+ * the plane kernels (fp32 operands as three bf16 planes [rows][hi D | mid D | lo D], six plane products per fp32 product)
+ * whose epilogue appends every element with d = |q|^2 + |b|^2 - 2 q.b <= tau[query] as a (float d, int32 id) pair to
+ * slot atomic(cnt[query])++ of the query's `cap`-slot list `cand` (8 B per slot; slots past the capacity are dropped
+ * and counted).  tau = the query's current k-th best distance (from a first block of the catalogue through
+ * cdml_knn_merge); n_cols (a multiple of 256) catalogue rows starting at row col0; rows >= n_valid are padding.
+ * cdml_knn_merge_list: every query's candidates into its sorted list (as cdml_knn_merge keeps it); cnt back to 0;
+ * *overflow = 1 if a list was longer than cap (redo the search with the score-block form: nothing is silently lost). */
+int cdml_knn_filter_x3(const uint16_t *Q, int64_t ldq, int64_t plane_q, const uint16_t *Bk, int64_t ldb,
+                       int64_t plane_b, int nq, int n_cols, int D, const float *q_sq, const float *b_sq,
+                       const float *tau, int col0, int n_valid, int32_t *cnt, void *cand, int cap,
+                       cdml_stream_t stream);
+int cdml_knn_merge_list(const void *cand, int32_t *cnt, int cap, int nq, int k, float *best_d, int32_t *best_i,
+                        int32_t *overflow, cdml_stream_t stream);
+
 /* cdml_adam_step on a weight matrix W[K][N] (row-major, contiguous: ld = N) that also writes the
  * bf16 operand copies the config-4 GEMMs read -- W^T as bf16 [N][ldt] (wt_bf16, nullable) and W as
  * bf16 [K][ldc] (wc_bf16, nullable), round-to-nearest-even of the UPDATED weights: the optimizer

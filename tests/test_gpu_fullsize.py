@@ -354,7 +354,9 @@ def _config3_worker(port, q):
         sel = np.unique(np.concatenate([np.arange(0, 2 * B, 1201), [2 * B - 1]]))
         raw = np.concatenate([osynth.features_philox(int(g), 1, F, 0) for g in rows[sel]])
         want = otower.l2_normalize(raw.astype(np.float64), np.float64)[0]
-        err = float(np.abs(ts.ws.x_hat[sel, :F].cpu().numpy() - want).max())
+        # (TrainStep's default precision is the headline's since round 6: the gathered rows are three bf16 planes there)
+        xh = ts.ws.x_hat_f32() if hasattr(ts.ws, "x_hat_f32") else ts.ws.x_hat
+        err = float(np.abs(xh[sel, :F].cpu().numpy() - want).max())
         if err > 1e-6:
             msgs.append("gathered content off by %g" % err)
         if ((rows.astype(np.int64) - row0) * 6144 > GIB4).sum() < len(rows) // 5:

@@ -71,6 +71,34 @@ def test_bad_k_is_refused():
         knn.calc_knn(embeddings(10, 32, 0), nearest_num=129)
 
 
+def test_filter_epilogue_matches_exact_search_and_falls_back_on_overflow():
+    """Round 6: everything after the first block of the catalogue goes through ONE launch of the plane GEMM whose epilogue
+    appends the elements within a query's k-th best distance to its candidate list (no score matrix).  (i) 70 000 rows,
+    separate queries, exact (D, I) against the fp64 oracle, identical to the score-block form; (ii) a catalogue laid out
+    AGAINST the filter -- the rows after the first block are all closer than anything in it, so every query's list
+    overflows -- still returns the exact answer (the search falls back to score blocks: nothing is silently dropped)."""
+    from cdml_amd import knn
+    base = embeddings(70000, 64, 5)
+    base[40000:40008] = base[123]                               # exact duplicates across the block boundary: ties by id
+    q = np.concatenate([embeddings(200, 64, 6), base[123:124]])
+    D, I = knn.knn_search(torch.from_numpy(base), torch.from_numpy(q), 51)
+    Dr, Ir, dfull = oknn.calc_knn_exact(base, q, 51)
+    check(D.cpu().numpy(), I.cpu().numpy(), Dr, Ir, dfull)
+    assert sorted(I[-1, :9].cpu().tolist()) == [123] + list(range(40000, 40008))
+    D2, I2 = knn.knn_search(torch.from_numpy(base), torch.from_numpy(q), 51, fused=False)
+    assert torch.equal(I, I2) and torch.equal(D, D2)
+    rng = np.random.RandomState(7)
+    centre = rng.randn(64).astype(np.float32)
+    far = rng.randn(33000, 64).astype(np.float32)               # the first block: unrelated directions
+    near = centre + 0.05 * rng.randn(37000, 64).astype(np.float32)   # the rest: a tight cluster around the queries
+    base2 = np.concatenate([far, near])
+    q2 = centre + 0.05 * rng.randn(50, 64).astype(np.float32)
+    D3, I3 = knn.knn_search(torch.from_numpy(base2), torch.from_numpy(q2), 20)
+    Dr3, Ir3, dfull3 = oknn.calc_knn_exact(base2, q2, 20)
+    check(D3.cpu().numpy(), I3.cpu().numpy(), Dr3, Ir3, dfull3)
+    assert (I3.cpu().numpy() >= 33000).all()
+
+
 def test_self_knn_at_the_reference_catalogue_size():
     """the export at the reference's own scale -- doc_location = 343455 embeddings (faiss_knn.py:389), 256-d,
     nearest_num = 51 -- against a blocked EXACT search in fp64 on the device (torch: 2 048 queries x the whole catalogue
