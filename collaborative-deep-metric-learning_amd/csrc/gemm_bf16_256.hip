@@ -166,6 +166,10 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   // four consecutive COLUMNS 4q .. 4q + 3 of the block instead of column l15 and four rows.  An epilogue that works along
   // rows (the miner: the best column per row) then needs no trip through LDS: a lane reduces its own 16 columns of a row,
   // the four lanes that share the row meet in two cross-lane steps.
+  // (The plane-output epilogues were built in this layout too -- one 8-B store per plane straight from the accumulators, no
+  // strip, no barrier -- and measured SLOWER: FC1 + 4 %, the data gradient + 30 %, profiles/r06_swapped_plane_epilogue_ab.txt.
+  // A store instruction then writes 16 rows x 32 B and a 128-B line is assembled from four of them; the LDS transpose of
+  // tail16 below is what makes every store a whole line.  The swapped layout stays where nothing of the tile is stored.)
   constexpr bool kSwap = EPI == BE_MINE_X3 || EPI == BE_KNN_X3;
 
   const int k_rows = X3 ? g.x3_tpp * kTileK : g.K;              // k-strided form: rows of the operands in memory
