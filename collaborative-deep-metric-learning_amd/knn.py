@@ -48,13 +48,15 @@ def _planes(x, Dp):
 
 
 def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK, b_block=B_BLOCK, precision="f32x3",
-               fused=True, first_block=FIRST_BLOCK):
+               fused=True, first_block=FIRST_BLOCK, q_chunk=262144, c_chunk=1048576):
     """Device tensors (D [nq,k] fp32 squared L2 ascending, I [nq,k] int64; -1 where
     the catalogue has fewer than k rows).  ``precision``: "f32x3" (default; round 6) = the inner products on the plane
     kernels -- the headline path's arithmetic: every fp32 operand as three exact bf16 planes, six plane products per fp32
     product on the bf16 MFMA (csrc/gemm_bf16x3.hip), errors those of the fp32 kernels -- or "f32" = the fp32 MFMA.
     ``fused`` (precision "f32x3", catalogues of more than two first blocks): everything after the first ``first_block``
-    catalogue rows through the filter epilogue instead of score blocks (False: score blocks throughout, the round-5 form)."""
+    catalogue rows through the filter epilogue instead of score blocks (False: score blocks throughout, the round-5 form);
+    ``q_chunk`` queries x ``c_chunk`` catalogue rows per filter launch (operands inside a descriptor's 2 GiB window, candidate
+    buffer q_chunk x list capacity x 8 B), the lists merged -- and every query's threshold tightened -- after each."""
     if precision not in ("f32x3", "f32"):
         raise ValueError("precision must be 'f32x3' or 'f32'")
     x3 = precision == "f32x3"
@@ -90,35 +92,51 @@ def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK,
         Q3 = B3 if same else _planes(Q, Dp)
     n_pad = B.shape[0]
     first_cols = n_pad
-    use_filter = (x3 and fused and first_block % b_block == 0 and first_block >= 4 * k and nb > 2 * first_block
-                  and (nq + 256) * 3 * Dp * 2 < 2 ** 31 and (n_pad - first_block) * 3 * Dp * 2 < 2 ** 31)
+    use_filter = x3 and fused and first_block % b_block == 0 and first_block >= 4 * k and nb > 2 * first_block
     if use_filter:
-        first_cols = first_block
-    for q0 in range(0, nq, q_block):
-        m = min(q_block, nq - q0)
-        for c0 in range(0, first_cols, b_block):
-            # scores[m, b_block] = Q[q0:q0+m] @ B[c0:c0+b_block]^T
-            if x3:
-                ops.gemm_bf16x3_nt(ops.BE_F32, Q3[q0:q0 + m], Dp, B3[c0:c0 + b_block], Dp, scores, m, b_block, Dp)
-            else:
-                ops.fc_bwd_data(Q[q0:q0 + m], B[c0:c0 + b_block], None, scores, m, b_block, Dp)
-            ops.knn_merge(scores, m, b_block, c0, nb, q_sq[q0:q0 + m], b_sq[c0:c0 + b_block], k,
-                          best_d[q0:q0 + m], best_i[q0:q0 + m], first=(c0 == 0))
+        # a catalogue so long that a query would collect more than ~512 candidates behind a 32 768-row first block gets a
+        # longer first block (k n / 512 rows: a 10 M-row catalogue sends 10 % of its rows through score blocks)
+        first_cols = min(max(first_block, _round_up(k * nb // 512, b_block)), n_pad)
+        use_filter = first_cols + 256 <= n_pad
+        if not use_filter:
+            first_cols = n_pad
+    # queries and catalogue in chunks: a chunk's operands stay inside the 2 GiB window of a buffer descriptor, and the
+    # candidate lists of a query chunk inside a bounded buffer
+    q_chunk = _round_up(min(q_chunk, nq), q_block) if use_filter else nq
+    c_chunk = _round_up(c_chunk, 256)
+    lim = (2 ** 31) // (3 * Dp * 2) - 512
+    q_chunk, c_chunk = min(q_chunk, lim // q_block * q_block), min(c_chunk, lim // 256 * 256)
     if use_filter:
-        expect = k * (nb - first_cols) / float(first_cols)
-        cap = 64
-        while cap < 4 * expect:
-            cap *= 2
-        tau = best_d[:, k - 1].contiguous()
-        cnt = torch.zeros(nq, dtype=torch.int32, device=device)
-        cand = torch.empty((nq, cap, 2), dtype=torch.int32, device=device)
+        list_cap = 64
+        expect = k * min(nb - first_cols, c_chunk) / float(first_cols)     # per catalogue chunk: merged and tau tightened after each
+        while list_cap < 4 * expect:
+            list_cap *= 2
+        cnt = torch.zeros(q_chunk, dtype=torch.int32, device=device)
+        cand = torch.empty((q_chunk, list_cap, 2), dtype=torch.int32, device=device)
         overflow = torch.zeros(1, dtype=torch.int32, device=device)
-        ops.knn_filter_x3(Q3, Dp, B3[first_cols:], Dp, nq, n_pad - first_cols, Dp, q_sq, b_sq[first_cols:], tau, first_cols, nb,
-                          cnt, cand, cap)
-        ops.knn_merge_list(cand, cnt, cap, nq, k, best_d, best_i, overflow)
-        if int(overflow.item()):                             # (a sync; the export is not a step path)
-            return knn_search(base, queries, k, l2_norm=l2_norm, device=device, q_block=q_block, b_block=b_block,
-                              precision=precision, fused=False)
+    for qs in range(0, nq, q_chunk):
+        mq = min(q_chunk, nq - qs)
+        for q0 in range(qs, qs + mq, q_block):
+            m = min(q_block, qs + mq - q0)
+            for c0 in range(0, first_cols, b_block):
+                # scores[m, b_block] = Q[q0:q0+m] @ B[c0:c0+b_block]^T
+                if x3:
+                    ops.gemm_bf16x3_nt(ops.BE_F32, Q3[q0:q0 + m], Dp, B3[c0:c0 + b_block], Dp, scores, m, b_block, Dp)
+                else:
+                    ops.fc_bwd_data(Q[q0:q0 + m], B[c0:c0 + b_block], None, scores, m, b_block, Dp)
+                ops.knn_merge(scores, m, b_block, c0, nb, q_sq[q0:q0 + m], b_sq[c0:c0 + b_block], k,
+                              best_d[q0:q0 + m], best_i[q0:q0 + m], first=(c0 == 0))
+        if not use_filter:
+            continue
+        for c0 in range(first_cols, n_pad, c_chunk):
+            nc = min(c_chunk, n_pad - c0)
+            tau = best_d[qs:qs + mq, k - 1].contiguous()     # the k-th best so far: every merged chunk tightens it
+            ops.knn_filter_x3(Q3[qs:qs + mq], Dp, B3[c0:c0 + nc], Dp, mq, nc, Dp, q_sq[qs:qs + mq], b_sq[c0:c0 + nc], tau, c0, nb,
+                              cnt, cand, list_cap)
+            ops.knn_merge_list(cand, cnt, list_cap, mq, k, best_d[qs:qs + mq], best_i[qs:qs + mq], overflow)
+    if use_filter and int(overflow.item()):                  # (a sync; the export is not a step path)
+        return knn_search(base, queries, k, l2_norm=l2_norm, device=device, q_block=q_block, b_block=b_block,
+                          precision=precision, fused=False)
     I = best_i[:, :k].to(torch.int64)
     I[I == 0x7fffffff] = -1
     return best_d[:, :k].contiguous(), I

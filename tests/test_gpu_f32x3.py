@@ -51,7 +51,7 @@ def test_split_planes_are_exact(rows, cols, transpose):
 @pytest.mark.parametrize("products", [6, 3])
 def test_gemm_x3_nt_matches_fp64_like_fp32(M, N, K, products):
     if (products * K // 64) % 2:
-        pytest.skip("the general loop (three products) walks K-tiles in pairs: products * K / 64 must be even")
+        K += 64      # the general loop (three products) walks K-tiles in pairs: the nearest legal contraction instead of a skip
     torch.manual_seed(1)
     dev = _dev()
     A = torch.rand(M, K, device=dev)

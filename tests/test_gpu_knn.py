@@ -87,6 +87,9 @@ def test_filter_epilogue_matches_exact_search_and_falls_back_on_overflow():
     assert sorted(I[-1, :9].cpu().tolist()) == [123] + list(range(40000, 40008))
     D2, I2 = knn.knn_search(torch.from_numpy(base), torch.from_numpy(q), 51, fused=False)
     assert torch.equal(I, I2) and torch.equal(D, D2)
+    # queries and catalogue in several chunks (each merged, the thresholds tightened in between): the same answer
+    D4, I4 = knn.knn_search(torch.from_numpy(base), torch.from_numpy(q), 51, q_block=64, q_chunk=128, c_chunk=8192)
+    assert torch.equal(I, I4) and torch.equal(D, D4)
     rng = np.random.RandomState(7)
     centre = rng.randn(64).astype(np.float32)
     far = rng.randn(33000, 64).astype(np.float32)               # the first block: unrelated directions
