@@ -95,6 +95,7 @@ SIGNATURES = {
     "cdml_semihard_select": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _p, _p]),
     "cdml_semihard_mine_x3_workspace": (_sz, [_i]),
     "cdml_semihard_mine_x3": (_i, [_p, _i64, _p, _i, _i, _p, _i64, _i64, _p, _p, _p, _sz, _p, _p]),
+    "cdml_semihard_mine_x3_z": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _i64, _i64, _p, _p, _p, _sz, _p, _p]),
     "cdml_triplet_hinge_indexed": (_i, [_p, _i64, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "cdml_x3_slab_steps": (_i, [_i]),
     "cdml_triplet_hinge_indexed_tail": (_i, [_p, _i64, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _f, _p, _i64,

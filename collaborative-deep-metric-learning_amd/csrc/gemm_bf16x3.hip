@@ -404,12 +404,35 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
 namespace cdml {
 namespace {
 
+// z != null (round 6): the rows arrive UN-normalised (the output layer's z) -- the wave normalises both of its rows first, with
+// cdml_l2norm_fwd's arithmetic (models.py:61: z / sqrt(max(sum z^2, 1e-12))), and writes them to e: one launch and a 2 x 16 MB
+// round trip fewer in BASELINE config 2's step; e as cdml_l2norm_fwd writes it to an ulp (which multiply-adds become fmas differs
+// from kernel to kernel), planes, norms and distances those of the e written here.
 __global__ void __launch_bounds__(kThreads)
-k_mine_prep(const float *__restrict__ e, int64_t lde, int B, int D, bf16 *__restrict__ e3, int64_t ld3, int64_t plane,
-            float *__restrict__ sqn, float *__restrict__ dp) {
+k_mine_prep(const float *__restrict__ e_in, float *__restrict__ e_out, int64_t lde, const float *__restrict__ z, int64_t ldz,
+            int B, int D, bf16 *__restrict__ e3, int64_t ld3, int64_t plane, float *__restrict__ sqn, float *__restrict__ dp) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = D >> 2;
   for (int i = blockIdx.x * (kThreads / 64) + wave; i < B; i += gridDim.x * (kThreads / 64)) {
+    if (z) {
+      const float *za = z + (int64_t)(2 * i) * ldz, *zp = za + ldz;
+      float *ea = e_out + (int64_t)(2 * i) * lde, *ep = ea + lde;
+      float s0 = 0.f, s1 = 0.f;
+      for (int q = lane; q < nq; q += 64) {
+        const f32x4 x = reinterpret_cast<const f32x4 *>(za)[q], y = reinterpret_cast<const f32x4 *>(zp)[q];
+        s0 += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        s1 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+      }
+      s0 = wave_sum(s0);
+      s1 = wave_sum(s1);
+      const float i0 = 1.0f / sqrtf(fmaxf(s0, 1e-12f)), i1 = 1.0f / sqrtf(fmaxf(s1, 1e-12f));
+      for (int q = lane; q < nq; q += 64) {           // (each lane reads back below exactly what it stores here)
+        const f32x4 x = reinterpret_cast<const f32x4 *>(za)[q], y = reinterpret_cast<const f32x4 *>(zp)[q];
+        reinterpret_cast<f32x4 *>(ea)[q] = f32x4{x.x * i0, x.y * i0, x.z * i0, x.w * i0};
+        reinterpret_cast<f32x4 *>(ep)[q] = f32x4{y.x * i1, y.y * i1, y.z * i1, y.w * i1};
+      }
+    }
+    const float *e = z ? e_out : e_in;
     const float *a = e + (int64_t)(2 * i) * lde, *p = a + lde;
     float sa = 0.f, sp = 0.f, ap = 0.f;
     for (int q = lane; q < nq; q += 64) {
@@ -482,11 +505,12 @@ extern "C" size_t cdml_semihard_mine_x3_workspace(int B) {
 // e[2B][lde] fp32 (row 2i = anchor i, 2i+1 = its positive; l2-normalised or not), rows[2B] = video ids.  Scratch the
 // caller owns: e_planes bf16 [2B][ldp] (planes `plane` apart), sqn float[2B], dp float[B], workspace
 // (cdml_semihard_mine_x3_workspace).  neg_row_out[i] as cdml_semihard_select.  2B % 256 == 0, D % 64 == 0.
-extern "C" int cdml_semihard_mine_x3(const float *e, int64_t lde, const int32_t *rows, int B, int D, uint16_t *e_planes,
-                                     int64_t ldp, int64_t plane, float *sqn, float *dp, void *workspace,
-                                     size_t workspace_bytes, int32_t *neg_row_out, cdml_stream_t stream) {
+static int semihard_mine_x3_impl(const float *e, float *e_out, int64_t lde, const float *z, int64_t ldz, const int32_t *rows, int B,
+                                 int D, uint16_t *e_planes, int64_t ldp, int64_t plane, float *sqn, float *dp, void *workspace,
+                                 size_t workspace_bytes, int32_t *neg_row_out, cdml_stream_t stream) {
   CDML_REQUIRE(e && rows && e_planes && sqn && dp && workspace && neg_row_out && B >= 1 && D > 0, CDML_E_BADARG,
                "semihard_mine_x3: bad argument");
+  CDML_REQUIRE(!z || (aligned16(z) && !(ldz & 3) && ldz >= D), CDML_E_ALIGN, "semihard_mine_x3_z: z 16-B aligned, ldz a multiple of 4 and >= D");
   CDML_REQUIRE((2 * (int64_t)B) % 256 == 0 && D % 64 == 0, CDML_E_UNSUPPORTED,
                "semihard_mine_x3: 2 B must be a multiple of 256 and D of 64, got B=%d D=%d", B, D);
   CDML_REQUIRE(aligned16(e) && !(lde & 3) && lde >= D && aligned16(e_planes) && !(ldp & 7) && !(plane & 7) && plane >= D &&
@@ -498,7 +522,7 @@ extern "C" int cdml_semihard_mine_x3(const float *e, int64_t lde, const int32_t 
                "semihard_mine_x3: the embedded rows exceed the 2 GiB buffer-descriptor range");
   hipStream_t s = (hipStream_t)stream;
   bf16 *e3 = reinterpret_cast<bf16 *>(e_planes);
-  hipLaunchKernelGGL(k_mine_prep, dim3(grid1d((int64_t)B * 64)), dim3(kThreads), 0, s, e, lde, B, D, e3, ldp, plane, sqn, dp);
+  hipLaunchKernelGGL(k_mine_prep, dim3(grid1d((int64_t)B * 64)), dim3(kThreads), 0, s, e, e_out, lde, z, ldz, B, D, e3, ldp, plane, sqn, dp);
   int rc = check_launch("semihard_mine_x3 prep");
   if (rc) return rc;
   BArgs g{};
@@ -515,6 +539,23 @@ extern "C" int cdml_semihard_mine_x3(const float *e, int64_t lde, const int32_t 
   hipLaunchKernelGGL(k_semihard_finish, dim3((B + 63) / 64), dim3(kThreads), 0, s, static_cast<const MineCand *>(workspace),
                      (int64_t)B, g.tiles_n * 4, B, neg_row_out);
   return check_launch("semihard_mine_x3 finish");
+}
+
+extern "C" int cdml_semihard_mine_x3(const float *e, int64_t lde, const int32_t *rows, int B, int D, uint16_t *e_planes,
+                                     int64_t ldp, int64_t plane, float *sqn, float *dp, void *workspace,
+                                     size_t workspace_bytes, int32_t *neg_row_out, cdml_stream_t stream) {
+  return semihard_mine_x3_impl(e, nullptr, lde, nullptr, 0, rows, B, D, e_planes, ldp, plane, sqn, dp, workspace, workspace_bytes,
+                               neg_row_out, stream);
+}
+
+// The same from the output layer's UN-normalised rows z: the prep launch normalises them (cdml_l2norm_fwd's arithmetic,
+// models.py:61) and writes e as well -- the first 2 B rows of e are an OUTPUT here.
+extern "C" int cdml_semihard_mine_x3_z(const float *z, int64_t ldz, float *e, int64_t lde, const int32_t *rows, int B, int D,
+                                       uint16_t *e_planes, int64_t ldp, int64_t plane, float *sqn, float *dp,
+                                       void *workspace, size_t workspace_bytes, int32_t *neg_row_out, cdml_stream_t stream) {
+  CDML_REQUIRE(z, CDML_E_BADARG, "semihard_mine_x3_z: z required");
+  return semihard_mine_x3_impl(e, e, lde, z, ldz, rows, B, D, e_planes, ldp, plane, sqn, dp, workspace, workspace_bytes,
+                               neg_row_out, stream);
 }
 
 // ---- k8-interleaved operands for the weight gradients (round 5) ---------------------------------------------------------

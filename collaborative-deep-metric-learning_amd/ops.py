@@ -264,11 +264,17 @@ def semihard_mine_x3_workspace(B):
     return int(load_library().cdml_semihard_mine_x3_workspace(B))
 
 
-def semihard_mine_x3(e, rows, B, D, e_planes, plane, sqn, dp, workspace, neg_row_out):
+def semihard_mine_x3(e, rows, B, D, e_planes, plane, sqn, dp, workspace, neg_row_out, z=None):
     """cdml_semihard_select's result without the score matrix: the B x 2B product on the plane kernels, the selection
-    as its epilogue (csrc/gemm_bf16x3.hip).  e_planes bf16 [2B, >= 3 plane], sqn f32[2B], dp f32[B], workspace f32."""
+    as its epilogue (csrc/gemm_bf16x3.hip).  e_planes bf16 [2B, >= 3 plane], sqn f32[2B], dp f32[B], workspace f32.
+    ``z`` given: the un-normalised output rows -- the prep launch normalises them and WRITES ``e`` (cdml_semihard_mine_x3_z)."""
     ep, eld = _mat(e)
     pp, pld = _mat16(e_planes)
+    if z is not None:
+        zp, zld = _mat(z)
+        call("cdml_semihard_mine_x3_z", zp, zld, ep, eld, _p(rows, torch.int32), B, D, pp, pld, plane, _p(sqn), _p(dp),
+             _p(workspace), workspace.numel() * workspace.element_size(), _p(neg_row_out, torch.int32), _stream())
+        return neg_row_out
     call("cdml_semihard_mine_x3", ep, eld, _p(rows, torch.int32), B, D, pp, pld, plane, _p(sqn), _p(dp),
          _p(workspace), workspace.numel() * workspace.element_size(), _p(neg_row_out, torch.int32), _stream())
     return neg_row_out

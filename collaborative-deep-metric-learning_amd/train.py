@@ -417,8 +417,11 @@ class TrainStep:
         # uniform / in-batch negatives: one launch normalises z, takes the loss and starts the
         # backward pass (semi-hard mining needs every embedded row first: separate kernels)
         fused = with_grad and self.mode != "semihard"
+        # (semi-hard mining on the plane kernels: the miner's prep launch normalises z itself -- round 6)
+        mine_norm = (self.mode == "semihard" and getattr(self, "mine_fused", False)
+                     and os.environ.get("CDML_MINE_NORM", "1") != "0")
         if self.x3:
-            engine_x3.tower_forward(self.params, self.ws, normalize=not fused)
+            engine_x3.tower_forward(self.params, self.ws, normalize=not (fused or mine_norm))
         elif self.bf16:
             engine_bf16.tower_forward(self.params, self.ws, normalize=not fused)
         else:
@@ -440,7 +443,8 @@ class TrainStep:
         elif self.mode == "semihard":
             e = self.ws.e
             if self.mine_fused:
-                ops.semihard_mine_x3(e, self.idx, self.B, L.Dp, self.e3, L.Dp, self.sqn, self.dp, self.mine_ws, self.neg_row)
+                ops.semihard_mine_x3(e, self.idx, self.B, L.Dp, self.e3, L.Dp, self.sqn, self.dp, self.mine_ws, self.neg_row,
+                                     z=self.ws.z if mine_norm else None)
             else:
                 # S[i][c] = <anchor_i, row_c>: the data-gradient GEMM (x @ W^T) with no mask
                 ops.fc_bwd_data(e[0::2], e, None, self.S, self.B, 2 * self.B, L.Dp)

@@ -268,6 +268,13 @@ int cdml_semihard_mine_x3(const float *e, int64_t lde, const int32_t *rows, int 
                           uint16_t *e_planes, int64_t ldp, int64_t plane, float *sqn, float *dp,
                           void *workspace, size_t workspace_bytes, int32_t *neg_row_out,
                           cdml_stream_t stream);
+/* The same from the output layer's UN-normalised rows z (round 6): the prep launch normalises them first (cdml_l2norm_fwd's
+ * arithmetic, models.py:61) and WRITES e (rows 0 .. 2B-1) -- one launch and a round trip of the embedded rows fewer in
+ * BASELINE config 2's step. */
+int cdml_semihard_mine_x3_z(const float *z, int64_t ldz, float *e, int64_t lde, const int32_t *rows, int B, int D,
+                            uint16_t *e_planes, int64_t ldp, int64_t plane, float *sqn, float *dp,
+                            void *workspace, size_t workspace_bytes, int32_t *neg_row_out,
+                            cdml_stream_t stream);
 
 /* Hinge loss + gradient over triplets (row 2i, row 2i+1, row neg_row[i]);
  * neg_row[i] = -1 masks a triplet (hinge 0, still counted in the mean).  Rows

@@ -102,6 +102,23 @@ def test_argument_errors_need_no_gpu(built):
         built.call("cdml_step_advance", None, None)
 
 
+def test_slab_length_pin_is_thread_local_and_needs_no_gpu(built):
+    """cdml_x3_slab_steps (round 6): the pin of the narrow layer's K-slab length -- returns the previous pin, rounds to whole
+    six-step periods, 0 / too short = back to the rule by row-tile class; one pin per thread."""
+    import threading
+    from cdml_amd import _lib
+    lib = _lib.load_library()
+    assert lib.cdml_x3_slab_steps(120) == 0
+    assert lib.cdml_x3_slab_steps(64) == 120                   # 64 -> 60 (whole periods of six K-tile steps)
+    assert lib.cdml_x3_slab_steps(5) == 60                     # too short: no pin
+    assert lib.cdml_x3_slab_steps(120) == 0
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.cdml_x3_slab_steps(60)))
+    t.start(); t.join()
+    assert seen == [0]                                         # another thread starts without a pin
+    assert lib.cdml_x3_slab_steps(0) == 120                    # ... and did not touch this one
+
+
 def test_no_cpu_fallback_and_oracle_not_imported():
     import subprocess
     import sys
