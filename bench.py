@@ -935,13 +935,20 @@ def rec_fusion(dev, args, n_s, n_w):
     n_rows = 1000000
     table = engine.FeatureTable.synthetic(n_rows, 1628, seed=0, device=dev)
     pairs = torch.from_numpy(synth_pairs(n_rows, 300000, seed=0)).to(dev)
-    ts = fusion.FusionTrainStep("ResNet", table, pairs, 1024, device=dev)
-    n = max(n_s, 40)
-    el = timed_steps(ts, n, max(n_w, 5), dev)
-    return {"workload": "ResNet fusion tower (models.py:125-157): %d videos x 1628-d fp32, batch 1024 uniform triplets "
-                        "(3072 rows), Adam, full step" % n_rows,
-            "value": round(1024 * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4), "steps": n,
-            "loss": round(ts.loss(), 6)}
+    out = None
+    for prec in ("auto", "f32"):                     # round 6: the visual branch on the plane kernels; the fp32-MFMA tower beside it
+        ts = fusion.FusionTrainStep("ResNet", table, pairs, 1024, device=dev, precision=prec)
+        n = max(n_s, 100)
+        el = timed_steps(ts, n, max(n_w, 10), dev)
+        r = {"precision": ts.precision, "value": round(1024 * n / el, 1), "ms_per_step": round(el / n * 1e3, 4), "steps": n,
+             "loss": round(ts.loss(), 6)}
+        if out is None:
+            out = dict(r, workload="ResNet fusion tower (models.py:125-157): %d videos x 1628-d fp32, batch 1024 uniform triplets "
+                                   "(3072 rows), Adam, full step" % n_rows, unit="triplets/s")
+        else:
+            out["f32_mfma"] = r
+        del ts
+    return out
 
 
 def rec_predict(dev, precision, n_rows=10000000, chunk=100000, reps=2):

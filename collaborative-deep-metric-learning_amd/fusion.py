@@ -18,7 +18,7 @@ import math
 import numpy as np
 import torch
 
-from . import ops
+from . import engine_x3, ops
 from .engine import round_up
 
 NETS = ("MultiplyNet", "MlpNet", "ResNet", "ResNetV2")
@@ -108,10 +108,37 @@ class FusionParams:
         return out
 
 
-class FusionTower:
-    """Activations + the forward / backward kernel sequences for R rows."""
+class _VisualAsVNet:
+    """The visual branch of a fusion tower IS VNet's two layers (models.py:82-83 against :59-60): this view hands its
+    weights, biases and gradients -- slices of the fusion tower's flat buffers -- to engine_x3's forward / backward under
+    the names they use."""
 
-    def __init__(self, params, n_rows):
+    def __init__(self, fp, n1, n2):
+        L1, L2 = fp.layers[n1], fp.layers[n2]
+        self.layout = engine_x3.layout_x3(L1.K, L1.N, L2.N)
+        self.W1, self.b1, self.W2, self.b2 = fp.W(n1), fp.b(n1), fp.W(n2), fp.b(n2)
+        self.gW1, self.gb1, self.gW2, self.gb2 = fp.gW(n1), fp.gb(n1), fp.gW(n2), fp.gb(n2)
+        self.grad = fp.grad
+
+    @staticmethod
+    def fits(fp, n1, n2, n_rows):
+        L1, L2 = fp.layers[n1], fp.layers[n2]
+        L = engine_x3.layout_x3(L1.K, L1.N, L2.N)
+        return (L.Fp, L.Hp, L.Dp) == (L1.Kp, L1.Np, L2.Np) and L2.Kp == L1.Np and n_rows % 128 == 0
+
+
+class FusionTower:
+    """Activations + the forward / backward kernel sequences for R rows.
+
+    ``precision`` "f32x3" / "auto" (round 6): the VISUAL branch -- 1500 -> 5000 -> 256, VNet's two layers and 97 % of the
+    tower's flop -- runs on the plane kernels (fp32 operands as three exact bf16 planes, six plane products per fp32
+    product on the bf16 MFMA: engine_x3, the headline path's arithmetic and bounds) wherever its padded widths are the
+    plane kernels' (multiples of 256) and the rows a multiple of 128; the doc branch and the fusion layers (a few per
+    cent of the flop) stay on the fp32 MFMA.  "f32": everything on the fp32 MFMA (rounds 1-5)."""
+
+    def __init__(self, params, n_rows, precision="auto"):
+        if precision not in ("auto", "f32x3", "f32"):
+            raise ValueError("precision must be 'auto', 'f32x3' or 'f32'")
         self.p, self.R = params, int(n_rows)
         p, dev, R = params, params.device, self.R
         z = lambda n: torch.zeros((R, n), dtype=torch.float32, device=dev)
@@ -135,6 +162,25 @@ class FusionTower:
             v1, v2 = Ls["layer_visual_1"], Ls["layer_visual_2"]
             self.sk_bytes = ops.fc_bwd_weight2_workspace(R, v1.Kp, v1.Np, v2.Kp, v2.Np)
         self.bw = torch.empty(max(nb, self.sk_bytes, 16) // 4, dtype=torch.float32, device=dev)
+        # the visual branch on the plane kernels
+        self.vx3 = self.vp3 = None
+        if precision != "f32" and "layer_visual_1" in Ls:
+            if _VisualAsVNet.fits(p, "layer_visual_1", "layer_visual_2", R):
+                self.vp3 = _VisualAsVNet(p, "layer_visual_1", "layer_visual_2")
+                ws = engine_x3.TowerWorkspaceX3(self.vp3.layout, R, dev, planes_in=False, kint=False)
+                ws.x_hat = self.xv                                       # the l2-normalised visual rows (fp32: split in the forward pass)
+                self.act["layer_visual_2"] = ws.z                        # the branch's output, where the fusion reads it
+                self.dpre["layer_visual_2"] = ws.dz2                     # ... and where its gradient arrives
+                self.vx3 = ws
+                engine_x3.refresh_weights(self.vp3, ws)
+            elif precision == "f32x3":
+                raise ValueError("precision 'f32x3' needs the visual branch's padded widths to be multiples of 256 and the "
+                                 "rows a multiple of 128")
+
+    def refresh_planes(self):
+        """After an optimizer step on the flat parameter buffer: the visual branch's weight planes follow the new weights."""
+        if self.vx3 is not None:
+            engine_x3.refresh_weights(self.vp3, self.vx3)
 
     def _fc(self, n, x):
         L = self.p.layers[n]
@@ -159,7 +205,11 @@ class FusionTower:
             ops.ew_combine(ops.EW_ADD, self.r2, f2, self.pre, R, D)                     # :241
             ops.l2norm_fwd(self.pre, D, self.e)
             return self.e
-        v2 = self._fc("layer_visual_2", self._fc("layer_visual_1", self.xv))
+        if self.vx3 is not None:
+            engine_x3.tower_forward(self.vp3, self.vx3, normalize=False)         # h1 as planes + sign bits, v2 = vx3.z (fp32)
+            v2 = self.vx3.z
+        else:
+            v2 = self._fc("layer_visual_2", self._fc("layer_visual_1", self.xv))
         d2 = self._fc("layer_doc_2", self._fc("layer_doc_1", self.xd))
         if p.net == "MultiplyNet":
             ops.ew_combine(ops.EW_MUL, v2, d2, self.pre, R, D)                   # models.py:90
@@ -222,7 +272,12 @@ class FusionTower:
             return p.grad
         ops.ew_fusion_bwd(res, dfu, A["layer_visual_2"], A["layer_doc_2"], dp["layer_visual_2"],
                           dp["layer_doc_2"], R, D)
-        if self.sk_bytes and joint_visual:
+        if self.vx3 is not None:
+            # dp["layer_visual_2"] IS vx3.dz2 (the gradient of the branch's output pre-activation): planes, data gradient,
+            # both weight gradients + bias gradients on the plane kernels
+            self.vx3.tail_done, self.vx3.dz2_planes_done = True, False
+            engine_x3.tower_backward(self.vp3, self.vx3)
+        elif self.sk_bytes and joint_visual:
             v1, v2 = p.layers["layer_visual_1"], p.layers["layer_visual_2"]
             ops.fc_bwd_data(dp["layer_visual_2"], p.W("layer_visual_2"), A["layer_visual_1"], dp["layer_visual_1"],
                             R, v2.Kp, v2.Np)
@@ -245,7 +300,7 @@ class FusionTrainStep:
 
     def __init__(self, net, table, pairs, batch_size, margin=0.8, base_learning_rate=0.01, seed=1234,
                  weight_seed=42, device="cuda:0", exchange=None, grad_sync=None, slot0=0, batch_global=None,
-                 **dims):
+                 precision="auto", **dims):
         """``exchange`` (a dist.RowExchange built with ``local_gather=dist.raw_local_gather``) and
         ``grad_sync``: the data-parallel hooks, as for train.TrainStep -- row-sharded table, this
         rank's slice [slot0, slot0+B) of the global batch, averaged gradients."""
@@ -256,7 +311,8 @@ class FusionTrainStep:
         self.table, self.pairs, self.B, self.margin, self.seed = table, pairs, int(batch_size), margin, seed
         doc = table.feature_size - dims.get("visual_size", VISUAL)
         self.params = FusionParams(net, device, doc_size=doc, seed=weight_seed, **dims)
-        self.tower = FusionTower(self.params, 3 * self.B)
+        self.tower = FusionTower(self.params, 3 * self.B, precision=precision)
+        self.precision = "f32x3 (visual branch) + f32" if self.tower.vx3 is not None else "f32"
         dev, f32 = self.device, torch.float32
         self.idx = torch.zeros((self.B, 3), dtype=torch.int32, device=dev)
         self.x = torch.zeros((3 * self.B, table.data.shape[1]), dtype=f32, device=dev)
@@ -274,6 +330,7 @@ class FusionTrainStep:
                             normalize=False)
         else:
             self.exchange.gather(self.table, self.idx.view(-1), self.x)
+        t.refresh_planes()      # (the visual branch's weight planes follow whatever the weights are now: Adam's update, a load())
         t.forward(self.x)
         ops.triplet_hinge(t.e, self.B, self.params.Dp, self.margin, self.pos, self.neg, self.hinge, self.stats, t.de)
         t.backward()

@@ -126,7 +126,9 @@ class _FusionNet(BaseModel):
     def _tower(self, n_rows):
         from . import fusion
         if self._t is None or self._t.R != n_rows:
-            self._t = fusion.FusionTower(self.params, n_rows)
+            # (the facade's weights are the caller's to change between calls: the fp32-MFMA tower reads them as they are;
+            # fusion.FusionTrainStep, which owns its update, runs the visual branch on the plane kernels)
+            self._t = fusion.FusionTower(self.params, n_rows, precision="f32")
         return self._t
 
     def create_model(self, model_input, output_size=256):

@@ -99,3 +99,37 @@ def test_fusion_train_step_learns(cd):
     t = otower.fusion_forward("ResNet", feats[idx.reshape(-1)].astype(np.float64), P, visual=vis)
     loss = otower.hinge_loss(t["l2_norm"].reshape(-1, 3, 32), 0.8, np.float64)
     assert abs(ts2.loss() - float(loss["hinge_loss"])) < TOL
+
+
+@pytest.mark.parametrize("net", ["MultiplyNet", "MlpNet", "ResNet"])
+def test_fusion_visual_branch_on_the_plane_kernels(cd, net):
+    """Round 6: the visual branch of a fusion tower (1500 -> 5000 -> 256: VNet's two layers, 97 % of the tower's flop) on
+    the plane kernels -- fp32 operands as three exact bf16 planes, six plane products per fp32 product -- at production
+    shape, against the fp64 oracle with the fp32 tower's bounds, forward and every gradient; and against the fp32-MFMA
+    tower on the same weights (models.py:65-157)."""
+    R, F = 384, 1628
+    x = np.random.RandomState(1).random_sample((R, F)).astype(np.float32)
+    xt = torch.as_tensor(x).to(cd.dev)
+    params = cd.fusion.FusionParams(net, cd.dev, doc_size=F - 1500, seed=3)
+    tower = cd.fusion.FusionTower(params, R, precision="f32x3")
+    assert tower.vx3 is not None
+    out = tower.forward(xt).clone()
+    P = {k: (w.detach().cpu().numpy().astype(np.float64), b.detach().cpu().numpy().astype(np.float64))
+         for k, (w, b) in params.unpadded().items()}
+    t = otower.fusion_forward(net, x.astype(np.float64), P)
+    assert np.abs(out[:, :256].cpu().numpy() - t["l2_norm"]).max() < TOL
+    dE = np.random.RandomState(2).randn(R, 256).astype(np.float32) * 0.01
+    tower.de.zero_()
+    tower.de[:, :256] = torch.as_tensor(dE).to(cd.dev)
+    params.grad.zero_()
+    tower.backward()
+    g = otower.fusion_backward(net, t, P, dE.astype(np.float64))
+    got = params.unpadded(grads=True)
+    for k in P:
+        for j, nm in ((0, "dW"), (1, "db")):
+            w = g[k][j]
+            d = np.abs(got[k][j].cpu().numpy() - w).max()
+            assert d < max(TOL, 1e-3 * np.abs(w).max()), (k, nm, d, np.abs(w).max())
+    ref = cd.fusion.FusionTower(params, R, precision="f32")
+    assert ref.vx3 is None
+    assert float((ref.forward(xt) - out).abs().max()) < 2e-6
