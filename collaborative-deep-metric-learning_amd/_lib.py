@@ -128,6 +128,11 @@ SIGNATURES = {
     "cdml_gemm_bf16x3_nt": (_i, [_i, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _p, _i64, _i64, _p, _p, _i64, _f,
                                  _p, _p, _sz, _p]),
     "cdml_gemm_bf16x3_tn": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _p, _i64, _p, _f, _p, _p, _sz, _p]),
+    "cdml_split_f32_f16x2": (_i, [_p, _i64, _i, _i, _p, _i64, _i64, _i, _f, _p]),
+    "cdml_gemm_f16x2_workspace": (_sz, [_i, _i, _i, _i]),
+    "cdml_gemm_f16x2_nt": (_i, [_i, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _p, _i64, _i64, _p, _p, _i64, _f, _f, _f,
+                                _p, _sz, _p]),
+    "cdml_gemm_f16x2_tn": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _p, _i64, _f, _p, _f, _p, _sz, _p]),
     "cdml_interleave8_bf16x3": (_i, [_p, _i64, _i64, _i, _i, _p, _p]),
     "cdml_gemm_bf16x3_tnk": (_i, [_p, _i, _i, _p, _i, _i, _i, _i, _i, _p, _i64, _p, _p, _sz, _p]),
     "cdml_transpose_to_bf16": (_i, [_i, _p, _i64, _i, _i, _p, _i64, _p]),

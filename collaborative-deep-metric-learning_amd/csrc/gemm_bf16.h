@@ -77,6 +77,10 @@ struct BArgs {
   // element with d <= knn_tau[row] takes slot atomicAdd(knn_cnt + row, 1) of the row's knn_cap-slot list knn_cand
   // ((d, id) pairs; a slot beyond the capacity is dropped -- the count says so)
   const float *knn_qsq, *knn_bsq, *knn_tau; int32_t *knn_cnt; uint2 *knn_cand; int knn_cap, knn_col0, knn_n_valid;
+  // Two-plane fp16 form ("f16x2": gemm_f16x2_256.hip = this kernel compiled with CDML_F16X2): the operands hold
+  // a 2^sa and b 2^sb as fp16 planes hi | lo, so the accumulator holds 2^(sa + sb) a.b: out_scale = 2^-(sa + sb) multiplies it
+  // before anything else of the epilogue; a plane output is written as the fp16 planes of (value * c_scale), clamped to fp16's range
+  float out_scale, c_scale;
 };
 
 // 256x256x64 kernel: true if the shape can use it (N % 256 == 0, K per split a
@@ -87,6 +91,9 @@ int gemm_bf16_256_splits(int M, int N, int K);
 int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t stream);
 // the split-fp32 forms (g.x3_* set; epilogues 1, 3, 6, 7 k-contiguous, 3 k-strided)
 int launch_gemm_bf16_256_x3(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t stream);
+// the same on two fp16 planes per operand, three plane products (hi.hi + hi.lo + lo.hi) on v_mfma_f32_16x16x32_f16
+// (gemm_f16x2_256.hip; g.x3_products = 3, g.out_scale / g.c_scale set; epilogues 1, 3, 6, 7 k-contiguous, 3 k-strided)
+int launch_gemm_f16x2_256(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t stream);
 // the score product of semi-hard mining with the selection as its epilogue (BE_MINE_X3; six products, resident-plane walk)
 int launch_gemm_x3_mine(const BArgs &g, hipStream_t stream);
 // the query x catalogue score product of the kNN export with the threshold filter as its epilogue (BE_KNN_X3)

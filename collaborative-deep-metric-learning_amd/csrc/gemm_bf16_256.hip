@@ -84,6 +84,27 @@ __device__ __forceinline__ void dma_s(i32x4 srd, uint32_t voff, uint32_t soff, u
 }
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+// CDML_F16X2 (gemm_f16x2_256.hip compiles THIS file with it): the 16-bit operands are fp16 -- v_mfma_f32_16x16x32_f16 -- and
+// the plane-output epilogues write TWO fp16 planes hi | lo of (value * BArgs::c_scale) instead of three bf16 planes.  The
+// tile, images, DMA schedule, fragment layouts and phases are those of the bf16 form (both types are 16 bits wide; a
+// fragment is eight of them in four registers either way).  Only the split-fp32 (X3) launchers are exported from that build.
+#ifdef CDML_F16X2
+constexpr bool kF16 = true;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+#define CDML_MFMA16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0)
+// two fp32 -> one dword of two fp16 (round to nearest even; element 0 in the low half), and the halves back as fp32
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  uint32_t w = __builtin_bit_cast(uint32_t, half2v{(_Float16)a, (_Float16)b});
+  asm("" : "+v"(w));
+  return w;
+}
+__device__ __forceinline__ float lo_of(uint32_t w) { return (float)__builtin_bit_cast(half2v, w)[0]; }
+__device__ __forceinline__ float hi_of(uint32_t w) { return (float)__builtin_bit_cast(half2v, w)[1]; }
+#else
+constexpr bool kF16 = false;
+#define CDML_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 // two fp32 -> one dword of two bf16 (round to nearest even; element 0 in the low half), and the halves back as fp32
 // (the dword is made opaque: hipcc otherwise sees through `pack << 16` and converts the low element a second time on its own)
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
@@ -93,6 +114,8 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 }
 __device__ __forceinline__ float lo_of(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float hi_of(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+#endif
+constexpr int kPlanesOut = kF16 ? 2 : 3;             // planes a plane-output epilogue writes
 __device__ __forceinline__ i32x4 make_srd(const void *base, int64_t bytes) {
   const uint64_t a = (uint64_t)(uintptr_t)base;
   i32x4 r;
@@ -367,6 +390,15 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   // acc + the 8 values of a fragment: four v_dot2c_f32_bf16 against (1, 1) -- no conversions, no temporaries (the
   // shift / mask / add form of rounds 1-3 took 17 VALU instructions and 16 VGPRs of temporaries per owned K-tile pair)
   auto dot_sum = [&](const bf16x8 &f, float acc) {
+#ifdef CDML_F16X2
+    const half8 hf = __builtin_bit_cast(half8, f);
+    const half2v one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const half2v pr = {hf[2 * e], hf[2 * e + 1]};
+      acc = __builtin_amdgcn_fdot2(pr, one, acc, false);
+    }
+#else
     using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
     const bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
@@ -374,6 +406,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       const bf16x2 pr = {f[2 * e], f[2 * e + 1]};
       acc = __builtin_amdgcn_fdot2_f32_bf16(pr, one, acc, false);
     }
+#endif
     return acc;
   };
   // K-tiles until the next one this (tile, row group) owns (0x40000000: none -- no bias gradient asked for)
@@ -450,8 +483,8 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          acc16[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[rb][cb], 0, 0, 0);
-          acc16[rb][2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[rb][2 + cb], 0, 0, 0);
+          acc16[rb][cb] = CDML_MFMA16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[rb][cb]);
+          acc16[rb][2 + cb] = CDML_MFMA16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[rb][2 + cb]);
         }
     __builtin_amdgcn_s_setprio(0);
     CDML_BARRIER();
@@ -477,8 +510,8 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          acc16[4 + rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 + rb][cb], 0, 0, 0);
-          acc16[4 + rb][2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 + rb][2 + cb], 0, 0, 0);
+          acc16[4 + rb][cb] = CDML_MFMA16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 + rb][cb]);
+          acc16[4 + rb][2 + cb] = CDML_MFMA16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 + rb][2 + cb]);
         }
     __builtin_amdgcn_s_setprio(0);
     CDML_BARRIER();
@@ -533,8 +566,8 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          acc16[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[rb][cb], 0, 0, 0);
-          acc16[rb][2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[rb][2 + cb], 0, 0, 0);
+          acc16[rb][cb] = CDML_MFMA16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[rb][cb]);
+          acc16[rb][2 + cb] = CDML_MFMA16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[rb][2 + cb]);
         }
     __builtin_amdgcn_s_setprio(0);
     CDML_BARRIER();
@@ -557,8 +590,8 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          acc16[4 + rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 + rb][cb], 0, 0, 0);
-          acc16[4 + rb][2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 + rb][2 + cb], 0, 0, 0);
+          acc16[4 + rb][cb] = CDML_MFMA16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 + rb][cb]);
+          acc16[4 + rb][2 + cb] = CDML_MFMA16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 + rb][2 + cb]);
         }
     __builtin_amdgcn_s_setprio(0);
     CDML_BARRIER();
@@ -765,14 +798,14 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
             for (int cb = 0; cb < 2; ++cb) {
               if constexpr (kSwap) {
                 acc16[4 * HALF + rb][cb] =
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[2 * cb + ks2], fa[ks2][rb], acc16[4 * HALF + rb][cb], 0, 0, 0);
+                    CDML_MFMA16(fb0[2 * cb + ks2], fa[ks2][rb], acc16[4 * HALF + rb][cb]);
                 acc16[4 * HALF + rb][2 + cb] =
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[2 * cb + ks2], fa[ks2][rb], acc16[4 * HALF + rb][2 + cb], 0, 0, 0);
+                    CDML_MFMA16(fb1[2 * cb + ks2], fa[ks2][rb], acc16[4 * HALF + rb][2 + cb]);
               } else {
               acc16[4 * HALF + rb][cb] =
-                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 * HALF + rb][cb], 0, 0, 0);
+                  CDML_MFMA16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 * HALF + rb][cb]);
               acc16[4 * HALF + rb][2 + cb] =
-                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 * HALF + rb][2 + cb], 0, 0, 0);
+                  CDML_MFMA16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 * HALF + rb][2 + cb]);
               }
             }
         __builtin_amdgcn_s_setprio(0);
@@ -890,8 +923,8 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
           for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-              acc16[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[rb][cb], 0, 0, 0);
-              acc16[rb][2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[rb][2 + cb], 0, 0, 0);
+              acc16[rb][cb] = CDML_MFMA16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[rb][cb]);
+              acc16[rb][2 + cb] = CDML_MFMA16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[rb][2 + cb]);
             }
         __builtin_amdgcn_s_setprio(0);
         CDML_BARRIER();
@@ -1234,6 +1267,10 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
           const f32x4 v0 = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c8 * 8) ^ sw));
           const f32x4 v1 = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c8 * 8 + 4) ^ sw));
           float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          if constexpr (kF16) {                               // the accumulator holds 2^(sa + sb) times the product
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= g.out_scale;
+          }
           if constexpr (kBiasEpi) {
             f32x2 bq[4] = {bb2[0], bb2[1], bb2[2], bb2[3]};
             if constexpr (kRowBias) {
@@ -1268,6 +1305,10 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 #pragma unroll
             for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j]));
           }
+          if constexpr (kF16 && kPlanes) {                    // fp16 planes of value * c_scale (a power of two), inside fp16's range
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j] * g.c_scale, -65504.f, 65504.f);
+          }
           if constexpr (KO) {                                 // back where they came from; the column pass below stores them
             *reinterpret_cast<f32x4 *>(strip + lr * 64 + ((c8 * 8) ^ sw)) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4 *>(strip + lr * 64 + ((c8 * 8 + 4) ^ sw)) = f32x4{v[4], v[5], v[6], v[7]};
@@ -1295,8 +1336,9 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
           *reinterpret_cast<u32x4 *>(ub + lane_c) = o;
           if constexpr (kPlanes) {
             // three roundings to nearest hold the 24 significant bits: hi + mid + lo == v exactly
+            // (fp16 form: hi + lo holds 22 of them -- what the three-product sum keeps anyway)
 #pragma unroll
-            for (int pl = 1; pl < 3; ++pl) {
+            for (int pl = 1; pl < kPlanesOut; ++pl) {
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
                 const f32x2 r = f32x2{v[2 * k], v[2 * k + 1]} - f32x2{lo_of(o[k]), hi_of(o[k])};
@@ -1398,6 +1440,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       const int lr = p * 4 + (lane >> 4);
       const int row = out_row(rt, p);
       f32x4 v = *reinterpret_cast<const f32x4 *>(strip + lr * 64 + ((c4 * 4) ^ (S16 ? (((lr >> 2) & 1) << 4) : 0)));
+      if constexpr (kF16) v *= g.out_scale;                  // the accumulator holds 2^(sa + sb) times the product
       if (EPI == BE_BIAS_LRELU_BF16 || EPI == BE_BIAS_LRELU_F32 || EPI == BE_BIAS_LRELU_X3) {
         v += bias4;
         v.x = fmaxf(v.x, v.x * g.alpha); v.y = fmaxf(v.y, v.y * g.alpha);
@@ -1621,6 +1664,7 @@ int launch(const BArgs &g, int splits, hipStream_t s) {
 
 }  // namespace
 
+#ifndef CDML_F16X2
 bool gemm_bf16_256_usable(int M, int N, int K, int64_t lda, int64_t ldb) {
   if (N % kTileN || K % (2 * kTileK) || M < 1) return false;
   const int64_t lim = (int64_t)1 << 31;
@@ -1650,6 +1694,7 @@ int launch_gemm_bf16_256(const BArgs &g, int epilogue, int splits, hipStream_t s
     default: return launch<false, BE_F32>(g, splits, s);
   }
 }
+#endif
 
 namespace {
 template <bool TN, int EPI, bool F6, bool NTCS = false, bool R6 = false, bool NARROW = false>
@@ -1689,6 +1734,10 @@ int x3_walk() {
 // the unrolled walks need every block's K range to be whole periods of the K-major six-product walk
 template <bool TN, int EPI>
 int launch_x3(const BArgs &g, int splits, hipStream_t s) {
+#ifdef CDML_F16X2
+  // three products: the general K-major loop (the resident-plane walk and its half tiles are schedules of the six-product period)
+  return launch_x3_1<TN, EPI, false>(g, g.tiles_m * g.tiles_n, splits, s);
+#else
   const int kt = g.K / kTileK, per = g.k_per_split / kTileK;
   const bool whole = g.x3_products == 6 && kt % 6 == 0 && per % 6 == 0 && per > 0;
   const int walk = whole ? x3_walk() : 0;
@@ -1743,9 +1792,21 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
     if (walk == 1) return launch_x3_1<TN, EPI, true>(g, tiles, splits, s);
   }
   return launch_x3_1<TN, EPI, false>(g, tiles, splits, s);
+#endif
 }
 }  // namespace
 
+#ifdef CDML_F16X2
+int launch_gemm_f16x2_256(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t s) {
+  if (tn) return launch_x3<true, BE_F32>(g, splits, s);
+  switch (epilogue) {
+    case BE_BIAS_LRELU_F32: return launch_x3<false, BE_BIAS_LRELU_F32>(g, splits, s);
+    case BE_BIAS_LRELU_X3: return launch_x3<false, BE_BIAS_LRELU_X3>(g, splits, s);
+    case BE_MASK_X3: return launch_x3<false, BE_MASK_X3>(g, splits, s);
+    default: return launch_x3<false, BE_F32>(g, splits, s);
+  }
+}
+#else
 // the k-strided product on k8-interleaved operands (resident-plane walk, six products, whole periods per split)
 int launch_gemm_x3_tnk(const BArgs &g, int splits, hipStream_t s) {
   static bool configured = false;
@@ -1845,5 +1906,6 @@ int launch_gemm_bf16_tn2(const BArgs &g1, const BArgs &g2, float *db1, float *db
   hipLaunchKernelGGL(k_sk_fixup_tn, dim3(16 * n_tiles + cs_blocks), dim3(256), 0, s, a, db1, db2);
   return check_launch("gemm_bf16_tn2 fix-up");
 }
+#endif  // !CDML_F16X2
 
 }  // namespace cdml

@@ -79,6 +79,60 @@ k_split3_transpose(const float *__restrict__ src, int64_t lds_, int rows, int co
   }
 }
 
+// ---- two fp16 planes (precision "f16x2"): hi = fp16(v * scale), lo = fp16(v * scale - hi); scale a power of two, the
+// scaled value clamped to fp16's range (a tensor that outgrows its scale saturates instead of turning into infinities:
+// engine_f16x2.py watches the maxima and moves the scales) ----
+using half4v = __attribute__((ext_vector_type(4))) _Float16;
+__device__ __forceinline__ void split2h(float v, float scale, _Float16 &h, _Float16 &l) {
+  const float s = __builtin_amdgcn_fmed3f(v * scale, -65504.f, 65504.f);
+  h = (_Float16)s;
+  l = (_Float16)(s - (float)h);
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_split2h(const float *__restrict__ src, int64_t lds_, int rows, int cols, _Float16 *__restrict__ dst, int64_t ldd,
+          int64_t plane, float scale) {
+  const int c4n = cols >> 2;
+  const int64_t total = (int64_t)rows * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * lds_ + c);
+    half4v h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      _Float16 a, b;
+      split2h(v[j], scale, a, b);
+      h[j] = a; l[j] = b;
+    }
+    _Float16 *d = dst + r * ldd + c;
+    *reinterpret_cast<half4v *>(d) = h;
+    *reinterpret_cast<half4v *>(d + plane) = l;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_split2h_transpose(const float *__restrict__ src, int64_t lds_, int rows, int cols, _Float16 *__restrict__ dst,
+                    int64_t ldd, int64_t plane, float scale) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int j = ty; j < 64; j += 4) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 64; j += 4) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < cols && r < rows) {
+      _Float16 h, l;
+      split2h(tile[tx][j], scale, h, l);
+      _Float16 *d = dst + (int64_t)c * ldd + r;
+      d[0] = h; d[plane] = l;
+    }
+  }
+}
+
 int grid1d(int64_t n) {
   const int64_t b = (n + kThreads - 1) / kThreads;
   return (int)(b < 1 ? 1 : (b > 65535 * 16 ? 65535 * 16 : b));
@@ -110,8 +164,11 @@ bool x3_kmajor() {
 // every call size pins it: cdml_x3_slab_steps(120) (thread-local; catalogue inference does, so an embedding has the same
 // bits in 4 096- and 49 152-row chunks: test_embedding_bits_do_not_depend_on_the_chunk).
 thread_local int tl_slab_steps = 0;                        // 0 = by class
-int x3_nt_splits(int N, int ktiles, int tiles_m) {
+// (half_steps: the two-plane fp16 form walks THREE steps per K-tile where the bf16 form walks six -- its slabs are half as
+// many steps long, so that the partition of K itself is the same: 20 or 10 K-tiles of every plane per slab)
+int x3_nt_splits(int N, int ktiles, int tiles_m, bool half_steps = false) {
   if (N / 256 != 1) return 1;
+  if (half_steps) ktiles *= 2;
   const char *e = getenv("CDML_X3_SLAB_STEPS");            // (A/B runs: one length for everything)
   int steps = e && atoi(e) >= 12 ? atoi(e) / 6 * 6 : tl_slab_steps;
   if (steps < 12) {
@@ -158,6 +215,28 @@ extern "C" int cdml_split_f32_bf16x3(const float *src, int64_t ld_src, int rows,
   return check_launch("split_f32_bf16x3");
 }
 
+// dst = the two fp16 planes hi | lo of src * scale (scale > 0, a power of two for an exact scaling; values beyond fp16's
+// range saturate); layout and `transpose` as cdml_split_f32_bf16x3 with two planes: ld_dst >= plane + columns.
+extern "C" int cdml_split_f32_f16x2(const float *src, int64_t ld_src, int rows, int cols, uint16_t *dst, int64_t ld_dst,
+                                    int64_t plane, int transpose, float scale, cdml_stream_t stream) {
+  CDML_REQUIRE(src && dst && rows > 0 && cols > 0 && scale > 0.f, CDML_E_BADARG, "split_f32_f16x2: bad argument");
+  const int out_cols = transpose ? rows : cols;
+  CDML_REQUIRE(plane >= out_cols && ld_dst >= plane + out_cols && ld_src >= cols, CDML_E_BADARG,
+               "split_f32_f16x2: planes of %d columns need plane >= %d and ld_dst >= plane + %d", out_cols, out_cols, out_cols);
+  hipStream_t s = (hipStream_t)stream;
+  if (transpose) {
+    hipLaunchKernelGGL(k_split2h_transpose, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(kThreads), 0, s, src, ld_src,
+                       rows, cols, reinterpret_cast<_Float16 *>(dst), ld_dst, plane, scale);
+  } else {
+    CDML_REQUIRE((cols & 3) == 0 && (ld_src & 3) == 0 && (ld_dst & 3) == 0 && (plane & 3) == 0 && aligned16(src) &&
+                     (reinterpret_cast<uintptr_t>(dst) & 7) == 0,
+                 CDML_E_ALIGN, "split_f32_f16x2: columns, strides and plane must be multiples of 4");
+    hipLaunchKernelGGL(k_split2h, dim3(grid1d((int64_t)rows * (cols / 4))), dim3(kThreads), 0, s, src, ld_src, rows, cols,
+                       reinterpret_cast<_Float16 *>(dst), ld_dst, plane, scale);
+  }
+  return check_launch("split_f32_f16x2");
+}
+
 extern "C" int cdml_x3_slab_steps(int steps) {
   const int prev = tl_slab_steps;
   tl_slab_steps = steps >= 12 ? steps / 6 * 6 : 0;
@@ -181,11 +260,18 @@ extern "C" size_t cdml_gemm_bf16x3_workspace(int tn, int M, int N, int K, int pr
   return (size_t)splits * M * N * sizeof(float) + cs;       // (a slab even unsplit: the k-strided form's bias pass reads one)
 }
 
+// workspace of cdml_gemm_f16x2_nt / _tn: its slabs partition K as the six-product form's do (k-contiguous form) or as the
+// three-product walk's length asks (k-strided form) -- the larger of the two serves both
+extern "C" size_t cdml_gemm_f16x2_workspace(int tn, int M, int N, int K) {
+  const size_t a = cdml_gemm_bf16x3_workspace(tn, M, N, K, 6), b = cdml_gemm_bf16x3_workspace(tn, M, N, K, 3);
+  return a > b ? a : b;
+}
+
 namespace cdml {
 namespace {
 // colsum[n] = the partial rows added in a fixed order: 16 columns x 16 row lanes per block, four loads in flight per lane
 __device__ __forceinline__ void x3_colsum_block(const float *__restrict__ partial, int n_rows, int N, float *__restrict__ out,
-                                                int blk) {
+                                                int blk, float scale) {
   __shared__ float red[16][17];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blk * 16 + cl;
@@ -206,7 +292,7 @@ __device__ __forceinline__ void x3_colsum_block(const float *__restrict__ partia
     float t = red[0][cl];
 #pragma unroll
     for (int j = 1; j < 16; ++j) t += red[j][cl];
-    out[c] = t;
+    out[c] = t * scale;                                  // (1 on the bf16 planes; 2^-s on fp16 planes holding values times 2^s)
   }
 }
 
@@ -216,9 +302,9 @@ __device__ __forceinline__ void x3_colsum_block(const float *__restrict__ partia
 __global__ void __launch_bounds__(kThreads)
 k_x3_sum_slabs(const float *__restrict__ slabs, int64_t slab_stride, int splits, int rows, int N,
                const float *__restrict__ bias, float alpha, float *__restrict__ out, int64_t ldo, int slab_blocks,
-               const float *__restrict__ cs_partial, int cs_rows, float *__restrict__ cs_out) {
+               const float *__restrict__ cs_partial, int cs_rows, float *__restrict__ cs_out, float cs_scale) {
   if ((int)blockIdx.x >= slab_blocks) {
-    x3_colsum_block(cs_partial, cs_rows, N, cs_out, blockIdx.x - slab_blocks);
+    x3_colsum_block(cs_partial, cs_rows, N, cs_out, blockIdx.x - slab_blocks, cs_scale);
     return;
   }
   const int n4 = N >> 2;
@@ -244,12 +330,17 @@ k_x3_sum_slabs(const float *__restrict__ slabs, int64_t slab_stride, int splits,
 // (bf16 [M][ldc], planes plane_c apart); 7: C = planes of (. times (aux > 0 ? 1 : alpha)), aux = bf16 [M][ldaux];
 // 9 = 6 that ALSO writes the sign bitmask of its result to aux (uint8 [M][ldaux BYTES]: bit j of byte b of row r =
 // C[r][8 b + j] > 0); 10 = 7 reading that bitmask instead of bf16 values (one bit per element instead of two bytes).
-extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
-                                   int64_t ldb, int64_t plane_b, int M, int N, int K, int products, void *C,
-                                   int64_t ldc, int64_t plane_c, const float *bias, const uint16_t *aux,
-                                   int64_t ldaux, float alpha, float *colsum, void *workspace,
-                                   size_t workspace_bytes, cdml_stream_t stream) {
+// (f16: the two-plane fp16 form -- three products, planes hi | lo, out_scale / c_scale as BArgs says; cdml_gemm_f16x2_nt)
+static int gemm_x3_nt_impl(bool f16, float out_scale, float c_scale, int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a,
+                           const uint16_t *B, int64_t ldb, int64_t plane_b, int M, int N, int K, int products, void *C,
+                           int64_t ldc, int64_t plane_c, const float *bias, const uint16_t *aux,
+                           int64_t ldaux, float alpha, float *colsum, void *workspace,
+                           size_t workspace_bytes, cdml_stream_t stream) {
   CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16x3_nt: bad argument");
+  const int np1 = f16 ? 1 : 2;                                // planes after the first
+  CDML_REQUIRE(!f16 || (products == 3 && epilogue != BE_MASKBITS_X3_KI && epilogue != BE_ROWBIAS_LRELU_X3 && !colsum &&
+                        out_scale > 0.f && c_scale > 0.f),
+               CDML_E_UNSUPPORTED, "gemm_f16x2_nt: epilogues 1, 3, 6, 7, 9, 10, positive scales, no column sums");
   const bool kint_out = epilogue == BE_MASKBITS_X3_KI;      // 12 = 10 with the result's planes k8-interleaved
   const bool bits_out = epilogue == BE_BIAS_LRELU_X3_BITS, bits_in = epilogue == BE_MASKBITS_X3 || (kint_out && aux);
   if (bits_out) epilogue = BE_BIAS_LRELU_X3;
@@ -263,12 +354,12 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   CDML_REQUIRE(N % 256 == 0 && K % 64 == 0, CDML_E_UNSUPPORTED,
                "gemm_bf16x3_nt: N must be a multiple of 256 and K of 64, got N=%d K=%d", N, K);
   CDML_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && !(lda & 7) && !(ldb & 7) && !(plane_a & 7) && !(plane_b & 7) &&
-                   plane_a >= K && plane_b >= K && lda >= 2 * plane_a + K && ldb >= 2 * plane_b + K,
-               CDML_E_ALIGN, "gemm_bf16x3_nt: 16-B aligned bases, strides multiples of 8, ld >= 2 plane + K");
+                   plane_a >= K && plane_b >= K && lda >= np1 * plane_a + K && ldb >= np1 * plane_b + K,
+               CDML_E_ALIGN, "gemm_bf16x3_nt: 16-B aligned bases, strides multiples of 8, ld >= 2 plane + K (fp16 form: plane + K)");
   const bool planes_out = epilogue == BE_BIAS_LRELU_X3 || epilogue == BE_MASK_X3 || epilogue == BE_ROWBIAS_LRELU_X3;
   CDML_REQUIRE(kint_out ? (M % 8 == 0 && !(ldc & 7) && ldc >= N && plane_c >= (int64_t)(M / 8) * ldc * 8 &&
                            (int64_t)3 * plane_c * 2 < ((int64_t)1 << 32))
-                        : planes_out ? (!(ldc & 7) && !(plane_c & 7) && plane_c >= N && ldc >= 2 * plane_c + N) : (!(ldc & 3) && ldc >= N),
+                        : planes_out ? (!(ldc & 7) && !(plane_c & 7) && plane_c >= N && ldc >= np1 * plane_c + N) : (!(ldc & 3) && ldc >= N),
                CDML_E_ALIGN, "gemm_bf16x3_nt: ldc (plane outputs: ldc and plane_c multiples of 8, ldc >= 2 plane_c + N; epilogue 12: M a "
                "multiple of 8, ldc = columns per row group >= N, plane_c >= M ldc)");
   CDML_REQUIRE(epilogue != BE_MASK_X3 || !aux || bits_in || (aligned16(aux) && !(ldaux & 7) && ldaux >= N), CDML_E_ALIGN,
@@ -289,14 +380,18 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   g.c_kint = kint_out ? 1 : 0;
   g.M = M; g.N = N;
   g.x3_tpp = K / 64; g.x3_plane_a = plane_a; g.x3_plane_b = plane_b; g.x3_plane_c = plane_c;
-  g.x3_products = x3_kmajor() ? products : 0;
+  g.x3_products = (f16 || x3_kmajor()) ? products : 0;
+  g.out_scale = out_scale; g.c_scale = c_scale;
   const int ktiles = products * g.x3_tpp;
   CDML_REQUIRE(ktiles % 2 == 0, CDML_E_UNSUPPORTED, "gemm_bf16x3_nt: products * K / 64 must be even");
   g.K = ktiles * 64; g.k_per_split = g.K;
   g.tiles_m = (M + 255) / 256; g.tiles_n = N / 256;
   hipStream_t s = (hipStream_t)stream;
-  int splits = planes_out ? 1 : x3_nt_splits(N, ktiles, g.tiles_m), per = ktiles;
-  if (splits > 1) x3_split_geometry(ktiles, splits, 6, per, splits);   // whole six-step periods of the K-major walk (and an even count)
+  auto launch = [&](int epi, int n_splits) {
+    return f16 ? launch_gemm_f16x2_256(g, false, epi, n_splits, s) : launch_gemm_bf16_256_x3(g, false, epi, n_splits, s);
+  };
+  int splits = planes_out ? 1 : x3_nt_splits(N, ktiles, g.tiles_m, f16), per = ktiles;
+  if (splits > 1) x3_split_geometry(ktiles, splits, 6, per, splits);   // whole six-step periods of the K-major walk (and an even count; fp16 form: two K-tiles)
   if (splits > 1) {
     // The slab form needs the workspace.  workspace == NULL is the caller's explicit choice of ONE pass over K (fewer,
     // longer blocks; no slab round trip) -- its sums are associated differently, so the result's last bits differ from
@@ -320,39 +415,63 @@ extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda,
   }
   int rc;
   if (splits == 1) {
-    rc = launch_gemm_bf16_256_x3(g, false, epilogue, 1, s);
+    rc = launch(epilogue, 1);
   } else {
     g.k_per_split = per * 64;
     g.slab_stride = (int64_t)M * N;
     g.C = workspace; g.ldc = N;
-    rc = launch_gemm_bf16_256_x3(g, false, BE_F32, splits, s);
+    rc = launch(BE_F32, splits);                            // (fp16 form: the slabs are written times out_scale already)
     if (rc) return rc;
     const int sb = grid1d((int64_t)M * N / 4), cb = colsum ? (N + 15) / 16 : 0;
     hipLaunchKernelGGL(k_x3_sum_slabs, dim3(sb + cb), dim3(kThreads), 0, s,
                        static_cast<const float *>(workspace), g.slab_stride, splits, M, N,
                        epilogue == BE_BIAS_LRELU_F32 ? bias : nullptr, alpha, static_cast<float *>(C), ldc, sb,
-                       g.colsum_partial, (int)cs_rows, colsum);
+                       g.colsum_partial, (int)cs_rows, colsum, 1.0f);
     return check_launch("gemm_bf16x3_nt combine");
   }
   if (rc || !colsum) return rc;
   hipLaunchKernelGGL(k_x3_sum_slabs, dim3((N + 15) / 16), dim3(kThreads), 0, s, static_cast<const float *>(nullptr), (int64_t)0, 0, 0,
                      N, static_cast<const float *>(nullptr), 0.f, static_cast<float *>(nullptr), (int64_t)0, 0, g.colsum_partial,
-                     (int)cs_rows, colsum);
+                     (int)cs_rows, colsum, 1.0f);
   return check_launch("gemm_bf16x3_nt bias gradient");
+}
+
+extern "C" int cdml_gemm_bf16x3_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
+                                   int64_t ldb, int64_t plane_b, int M, int N, int K, int products, void *C,
+                                   int64_t ldc, int64_t plane_c, const float *bias, const uint16_t *aux,
+                                   int64_t ldaux, float alpha, float *colsum, void *workspace,
+                                   size_t workspace_bytes, cdml_stream_t stream) {
+  return gemm_x3_nt_impl(false, 1.0f, 1.0f, epilogue, A, lda, plane_a, B, ldb, plane_b, M, N, K, products, C, ldc, plane_c, bias, aux,
+                         ldaux, alpha, colsum, workspace, workspace_bytes, stream);
+}
+
+// The same product on TWO fp16 planes per operand (precision "f16x2"; gemm_f16x2_256.hip): A = planes hi | lo of a * 2^sa
+// [M][lda] (plane_a apart), B likewise of b * 2^sb; out_scale = 2^-(sa + sb) multiplies the accumulator before the epilogue;
+// epilogues 6 / 7 / 9 / 10 write C as the two fp16 planes of (result * c_scale), clamped to fp16's range.  Three plane
+// products (hi.hi + hi.lo + lo.hi) on v_mfma_f32_16x16x32_f16.  Epilogues 1, 3, 6, 7, 9, 10; workspace as
+// cdml_gemm_bf16x3_workspace(0, M, N, K, 3).
+extern "C" int cdml_gemm_f16x2_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
+                                  int64_t ldb, int64_t plane_b, int M, int N, int K, void *C, int64_t ldc, int64_t plane_c,
+                                  const float *bias, const uint16_t *aux, int64_t ldaux, float alpha, float out_scale,
+                                  float c_scale, void *workspace, size_t workspace_bytes, cdml_stream_t stream) {
+  return gemm_x3_nt_impl(true, out_scale, c_scale, epilogue, A, lda, plane_a, B, ldb, plane_b, M, N, K, 3, C, ldc, plane_c, bias, aux,
+                         ldaux, alpha, nullptr, workspace, workspace_bytes, stream);
 }
 
 // C[M][N] (fp32) = sum_k A[k][M] B[k][N] for fp32 operands given as planes [K][hi | mid | lo] (plane strides along
 // the columns); colsum[n] = sum_k B[k][n] on request (the bias gradient).
-extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B, int64_t ldb,
-                                   int64_t plane_b, int M, int N, int K, int products, float *C, int64_t ldc,
-                                   const float *bias, float alpha, float *colsum, void *workspace,
-                                   size_t workspace_bytes, cdml_stream_t stream) {
+static int gemm_x3_tn_impl(bool f16, float out_scale, float cs_scale, const uint16_t *A, int64_t lda, int64_t plane_a,
+                           const uint16_t *B, int64_t ldb, int64_t plane_b, int M, int N, int K, int products, float *C, int64_t ldc,
+                           const float *bias, float alpha, float *colsum, void *workspace,
+                           size_t workspace_bytes, cdml_stream_t stream) {
   CDML_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, CDML_E_BADARG, "gemm_bf16x3_tn: bad argument");
+  const int np1 = f16 ? 1 : 2;
+  CDML_REQUIRE(!f16 || (products == 3 && out_scale > 0.f && cs_scale > 0.f), CDML_E_BADARG, "gemm_f16x2_tn: positive scales");
   CDML_REQUIRE(products == 3 || products == 6, CDML_E_BADARG, "gemm_bf16x3_tn: products must be 3 or 6");
   CDML_REQUIRE(M % 256 == 0 && N % 256 == 0 && K % 128 == 0, CDML_E_UNSUPPORTED,
                "gemm_bf16x3_tn: M, N must be multiples of 256 and K of 128, got M=%d N=%d K=%d", M, N, K);
   CDML_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && !(lda & 7) && !(ldb & 7) && !(plane_a & 7) && !(plane_b & 7) &&
-                   !(ldc & 3) && plane_a >= M && plane_b >= N && lda >= 2 * plane_a + M && ldb >= 2 * plane_b + N && ldc >= N,
+                   !(ldc & 3) && plane_a >= M && plane_b >= N && lda >= np1 * plane_a + M && ldb >= np1 * plane_b + N && ldc >= N,
                CDML_E_ALIGN, "gemm_bf16x3_tn: 16-B aligned bases, strides multiples of 8, ld >= 2 plane + columns");
   CDML_REQUIRE((int64_t)K * lda * 2 < ((int64_t)1 << 31) && (int64_t)K * ldb * 2 < ((int64_t)1 << 31), CDML_E_UNSUPPORTED,
                "gemm_bf16x3_tn: an operand exceeds the 2 GiB buffer-descriptor range");
@@ -361,7 +480,8 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
   g.B = reinterpret_cast<const bf16 *>(B); g.ldb = ldb;
   g.M = M; g.N = N;
   g.x3_tpp = K / 64; g.x3_plane_a = plane_a; g.x3_plane_b = plane_b;
-  g.x3_products = x3_kmajor() ? products : 0;
+  g.x3_products = (f16 || x3_kmajor()) ? products : 0;
+  g.out_scale = out_scale; g.c_scale = 1.0f;
   const int ktiles = products * g.x3_tpp;
   g.K = ktiles * 64;
   g.tiles_m = M / 256; g.tiles_n = N / 256;
@@ -380,15 +500,32 @@ extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane
   g.C = slabs ? workspace : static_cast<void *>(C);
   g.ldc = slabs ? N : ldc;
   g.colsum_partial = colsum ? reinterpret_cast<float *>(static_cast<char *>(workspace) + slab_bytes) : nullptr;
-  int rc = launch_gemm_bf16_256_x3(g, true, BE_F32, splits, s);
+  int rc = f16 ? launch_gemm_f16x2_256(g, true, BE_F32, splits, s) : launch_gemm_bf16_256_x3(g, true, BE_F32, splits, s);
   if (rc) return rc;
   if (slabs || colsum) {                                   // one launch: the slab sum and, in extra blocks, the bias gradient
     const int sb = slabs ? grid1d((int64_t)M * N / 4) : 0, cb = colsum ? (N + 15) / 16 : 0;
     hipLaunchKernelGGL(k_x3_sum_slabs, dim3(sb + cb), dim3(kThreads), 0, s, static_cast<const float *>(workspace), g.slab_stride,
-                       splits, M, N, bias, alpha, C, ldc, sb, g.colsum_partial, (int)cs_rows, colsum);
+                       splits, M, N, bias, alpha, C, ldc, sb, g.colsum_partial, (int)cs_rows, colsum, cs_scale);
     rc = check_launch("gemm_bf16x3_tn combine");
   }
   return rc;
+}
+
+extern "C" int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B, int64_t ldb,
+                                   int64_t plane_b, int M, int N, int K, int products, float *C, int64_t ldc,
+                                   const float *bias, float alpha, float *colsum, void *workspace,
+                                   size_t workspace_bytes, cdml_stream_t stream) {
+  return gemm_x3_tn_impl(false, 1.0f, 1.0f, A, lda, plane_a, B, ldb, plane_b, M, N, K, products, C, ldc, bias, alpha, colsum, workspace,
+                         workspace_bytes, stream);
+}
+
+// The k-strided product on two fp16 planes per operand (cdml_gemm_f16x2_nt's form): C = out_scale * sum_k A[k][M] B[k][N],
+// colsum[n] = colsum_scale * sum_k B[k][n] (colsum_scale = 2^-sb).  Workspace: cdml_gemm_bf16x3_workspace(1, M, N, K, 3).
+extern "C" int cdml_gemm_f16x2_tn(const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B, int64_t ldb,
+                                  int64_t plane_b, int M, int N, int K, float *C, int64_t ldc, float out_scale, float *colsum,
+                                  float colsum_scale, void *workspace, size_t workspace_bytes, cdml_stream_t stream) {
+  return gemm_x3_tn_impl(true, out_scale, colsum_scale, A, lda, plane_a, B, ldb, plane_b, M, N, K, 3, C, ldc, nullptr, 0.f, colsum,
+                         workspace, workspace_bytes, stream);
 }
 
 // ---- semi-hard negative mining fused with its score product (BASELINE config 2; build-defined, spec oracle/tower.py
@@ -649,7 +786,7 @@ extern "C" int cdml_gemm_bf16x3_tnk(const uint16_t *A, int ma, int a_col0, const
   if (slabs || colsum) {
     const int sb = slabs ? grid1d((int64_t)M * N / 4) : 0, cb = colsum ? (N + 15) / 16 : 0;
     hipLaunchKernelGGL(k_x3_sum_slabs, dim3(sb + cb), dim3(kThreads), 0, s, static_cast<const float *>(workspace), g.slab_stride,
-                       splits, M, N, static_cast<const float *>(nullptr), 0.f, C, ldc, sb, g.colsum_partial, (int)cs_rows, colsum);
+                       splits, M, N, static_cast<const float *>(nullptr), 0.f, C, ldc, sb, g.colsum_partial, (int)cs_rows, colsum, 1.0f);
     rc = check_launch("gemm_bf16x3_tnk combine");
   }
   return rc;

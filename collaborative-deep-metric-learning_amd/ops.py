@@ -528,6 +528,53 @@ def gemm_bf16x3_tn(A, plane_a, B, plane_b, C, M, N, K, products=6, workspace=Non
     return C
 
 
+# ---- two fp16 planes per fp32 operand, three plane products (precision "f16x2"; csrc/gemm_f16x2_256.hip) ----
+def split_f32_f16x2(src, dst, plane, scale, transpose=False):
+    """dst[r][p*plane + c] = fp16 plane p (hi, lo) of src[r][c] * scale; transpose: dst[c][p*plane + r]."""
+    sp, sld = _mat(src)
+    dp, dld = _mat16(dst)
+    call("cdml_split_f32_f16x2", sp, sld, src.shape[0], src.shape[1], dp, dld, plane, 1 if transpose else 0, float(scale), _stream())
+    return dst
+
+
+def gemm_f16x2_workspace(tn, M, N, K):
+    return int(load_library().cdml_gemm_f16x2_workspace(1 if tn else 0, M, N, K))
+
+
+def gemm_f16x2_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, out_scale, c_scale=1.0, plane_c=0, bias=None, aux=None,
+                  alpha=LRELU_ALPHA, workspace=None, slab_steps=None):
+    """C = epilogue(out_scale * A . B^T) for operands given as fp16 planes [rows][hi K | lo K] of (value * its scale);
+    plane outputs (epilogues 6 / 7 / 9 / 10) are the fp16 planes of (result * c_scale)."""
+    if slab_steps:
+        lib = load_library()
+        prev = lib.cdml_x3_slab_steps(int(slab_steps))
+        try:
+            return gemm_f16x2_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, out_scale, c_scale=c_scale, plane_c=plane_c,
+                                 bias=bias, aux=aux, alpha=alpha, workspace=workspace)
+        finally:
+            lib.cdml_x3_slab_steps(prev)
+    ap, ald = _mat16(A)
+    bp, bld = _mat16(B)
+    if C.dim() != 2 or C.stride(1) != 1:
+        raise ValueError("C must be 2-D with unit inner stride")
+    if aux is not None and (aux.dtype == torch.uint8) != (epilogue in (BE_BIAS_LRELU_X3_BITS, BE_MASKBITS_X3)):
+        raise ValueError("epilogues 9 / 10 take a uint8 bitmask as aux, epilogue 7 16-bit values")
+    call("cdml_gemm_f16x2_nt", epilogue, ap, ald, plane_a, bp, bld, plane_b, M, N, K, _p(C), C.stride(0), plane_c, _p(bias),
+         _p(aux), aux.stride(0) if aux is not None else 0, alpha, float(out_scale), float(c_scale), _p(workspace),
+         0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())
+    return C
+
+
+def gemm_f16x2_tn(A, plane_a, B, plane_b, C, M, N, K, out_scale, workspace=None, colsum=None, colsum_scale=1.0):
+    """C[M][N] f32 = out_scale * sum_k A[k][M] B[k][N] on fp16 planes [K][hi | lo]; colsum[n] = colsum_scale * sum_k B[k][n]."""
+    ap, ald = _mat16(A)
+    bp, bld = _mat16(B)
+    cp, cld = _mat(C)
+    call("cdml_gemm_f16x2_tn", ap, ald, plane_a, bp, bld, plane_b, M, N, K, cp, cld, float(out_scale), _p(colsum, torch.float32),
+         float(colsum_scale), _p(workspace), 0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())
+    return C
+
+
 def gemm_bf16_tn2_workspace(M1, N1, M2, N2, K):
     """0 = shapes the joint launch does not take (use gemm_bf16_tn per product)."""
     return int(load_library().cdml_gemm_bf16_tn2_workspace(M1, N1, M2, N2, K))

@@ -524,6 +524,28 @@ int cdml_gemm_bf16x3_tn(const uint16_t *A, int64_t lda, int64_t plane_a, const u
                         const float *bias, float alpha, float *colsum, void *workspace,
                         size_t workspace_bytes, cdml_stream_t stream);
 
+/* ---- the same five products (models.py:59-60, train.py:141) on TWO fp16 planes per fp32 operand: precision "f16x2"
+ * (round 6; csrc/gemm_f16x2_256.hip).  A tensor x is held as the fp16 planes hi | lo of x * 2^s -- hi = fp16(x 2^s), lo =
+ * fp16(x 2^s - hi), s a per-tensor power of two chosen by the caller (engine_f16x2.py keeps them) -- and a product is the
+ * THREE plane products hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16, accumulated in fp32 and multiplied by out_scale =
+ * 2^-(sa + sb): half the matrix work of cdml_gemm_bf16x3_*, 22 of the 24 significant bits in the operands, fp16's exponent
+ * range (a value beyond it saturates at +-65504).  Error against fp64 at the tower's shapes: at or below the fp32-MFMA
+ * kernels' own (tests/test_gpu_f16x2.py; the probe that decided it: profiles/r06_f16x2_probe.txt).
+ * cdml_split_f32_f16x2: dst = the two planes of src * scale, layout and `transpose` as cdml_split_f32_bf16x3 (ld_dst >=
+ * plane + columns).  cdml_gemm_f16x2_nt: epilogues 1, 3, 6, 7, 9, 10 of cdml_gemm_bf16x3_nt; plane outputs are the fp16
+ * planes of (result * c_scale).  cdml_gemm_f16x2_tn: C = out_scale * A^T B, colsum[n] = colsum_scale * sum_k B[k][n].
+ * The narrow layer's K-slabs partition K exactly as cdml_gemm_bf16x3_nt's do (cdml_x3_slab_steps applies). */
+int cdml_split_f32_f16x2(const float *src, int64_t ld_src, int rows, int cols, uint16_t *dst, int64_t ld_dst,
+                         int64_t plane, int transpose, float scale, cdml_stream_t stream);
+size_t cdml_gemm_f16x2_workspace(int tn, int M, int N, int K);
+int cdml_gemm_f16x2_nt(int epilogue, const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B,
+                       int64_t ldb, int64_t plane_b, int M, int N, int K, void *C, int64_t ldc, int64_t plane_c,
+                       const float *bias, const uint16_t *aux, int64_t ldaux, float alpha, float out_scale,
+                       float c_scale, void *workspace, size_t workspace_bytes, cdml_stream_t stream);
+int cdml_gemm_f16x2_tn(const uint16_t *A, int64_t lda, int64_t plane_a, const uint16_t *B, int64_t ldb,
+                       int64_t plane_b, int M, int N, int K, float *C, int64_t ldc, float out_scale, float *colsum,
+                       float colsum_scale, void *workspace, size_t workspace_bytes, cdml_stream_t stream);
+
 /* dst[c][r] = bf16(src[r][c]) (src fp32 or bf16): k-contiguous copies of weights
  * and of activations for the weight-gradient GEMMs (contraction over batch rows). */
 int cdml_transpose_to_bf16(int src_is_f32, const void *src, int64_t ld_src,
