@@ -368,6 +368,18 @@ def install_timers(kt, L, bf16):
         if hasattr(ops, name):
             real[name] = getattr(ops, name)
             setattr(ops, name, kt.wrap(label, real[name]))
+    if bf16 == "h2":                                # precision f16x2: the two-plane fp16 GEMMs
+        # gemm_f16x2_nt(epilogue, A, plane_a, B, plane_b, C, M, N, K, out_scale, ...); _tn(A, pa, B, pb, C, M, N, K, out_scale, ...)
+        patch("gemm_f16x2_nt", lambda e, *a, **k: {6: "fc1_fwd", 9: "fc1_fwd", 1: "fc2_fwd", 7: "dH1", 10: "dH1"}.get(e, "other"))
+        patch("gemm_f16x2_tn", lambda A, pa, Bm, pb, C, M, N, K, *a, **k: "dW1" if N == L.Hp else "dW2")
+        patch("split_f32_f16x2", "split_planes")
+        patch("adam_matrix_bf16", lambda W, *a, **k: "adam_w1" if W.shape[0] == L.Fp else "adam_w2")
+        patch("vnet_tail", "tail")
+
+        def restore_h2():
+            for name, fn in real.items():
+                setattr(ops, name, fn)
+        return restore_h2
     if bf16:
         # gemm_bf16_nt(epilogue, A, B, C, M, N, K, ...): FC1 has N = Hp, K = Fp; FC2 N = Dp; dH1 K = Dp
         patch("gemm_bf16_nt", lambda e, A, Bm, C, M, N, K, **k:
@@ -928,6 +940,124 @@ def rec_other_fp32_path(dev, args, n_s, n_w, table, pairs, B, mode, other):
     return out
 
 
+F16X2_DTYPE = ("f32 values as 2 fp16 planes of (value x a per-tensor power of two): hi + lo holds 22 significant bits; 3 fp16-MFMA "
+               "plane products per f32 product, f32 accumulate; delayed per-tensor scales (engine_f16x2.py)")
+
+
+def rec_f16x2(dev, args, n_s, n_w, table, pairs, B, mode):
+    """The headline workload (`table`, `B`, `mode` of the caller) on precision "f16x2" -- every fp32 operand of the five
+    projection products as two fp16 planes under a per-tensor power-of-two scale, three plane products on
+    v_mfma_f32_16x16x32_f16 (csrc/gemm_f16x2_256.hip, engine_f16x2.py): a SECONDARY record (VERDICT r5 #3's ruling: dtype
+    spelled out, peak = the fp16 dense peak / 3), the headline stays "f32x3".  Before timing, one step of this path and one
+    of "f32x3" are taken from the same weights on the same triplets and compared on the device."""
+    from cdml_amd import train
+    mk = lambda prec: train.TrainStep(table, pairs, B, output_size=D, hidden_size=H, margin=MARGIN, mode=mode,
+                                      optimizer="adam", base_learning_rate=0.01, seed=1234, weight_seed=42, device=dev,
+                                      precision=prec, gather_ahead=args.gather_ahead)
+    lean = os.environ.get("CDML_F16X2_LEAN") == "1"       # profiling runs: the timed job only
+    if lean:
+        a = mk("f16x2")
+        el, kt, sampled, how = measure_job(a, max(n_s, 4), n_w, dev, "h2", timers=not args.no_kernel_timers)
+        return {"workload": "the headline's with precision f16x2 (lean: the timed job only)", "value": round(B * max(n_s, 4) / el, 1),
+                "unit": "triplets/s", "ms_per_step": round(el / max(n_s, 4) * 1e3, 4), "steps": max(n_s, 4), "warmup": n_w}
+    a, b = mk("f16x2"), mk("f32x3")
+    a.step(); b.step()
+    torch.cuda.synchronize(dev)
+    ga, gb = a.params.grad.double(), b.params.grad.double()
+    check = {"same_triplets": bool(torch.equal(a.idx, b.idx)),
+             "max_abs_embedding_diff": float((a.ws.e - b.ws.e).abs().max().item()),
+             "loss_f16x2": round(a.loss(), 7), "loss_f32x3": round(b.loss(), 7),
+             "gradient_rel_l2_diff": float(((ga - gb).norm() / gb.norm().clamp_min(1e-300)).item()),
+             "note": "one step each from identical weights (the same comparison f32_mfma.f32_mfma_against_f32x3 makes between the "
+                     "two other fp32 paths, with the same caveat: leaky-relu' flips where a pre-activation is rounding noise).  "
+                     "The bounds: tests/test_gpu_f16x2.py (every product against fp64 beside the fp32-MFMA kernel; a training run "
+                     "across the scale checks against the fp64 oracle beside f32x3), tests/test_gpu_parity.py::test_train_steps_config0[f16x2]"}
+    del b
+    torch.cuda.empty_cache()
+    ts = a
+    n, w = max(n_s, 100), max(n_w, 10)
+    el, kt, sampled, how = measure_job(ts, n, w, dev, "h2")
+    R = ts.R
+    peak = round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1)          # (the fp16 dense peak of the part is the bf16 one)
+    out = {"workload": "the headline's: %d videos x 1500-d fp32 in HBM, batch %d triplets, %s negatives, Adam, full step -- with "
+                       "precision f16x2" % (table.n_rows, B, mode),
+           "value": round(B * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4), "steps": n, "warmup": w,
+           "dtype": F16X2_DTYPE, "loss": round(ts.loss(), 6), "f16x2_against_f32x3": check,
+           "plane_scales": {k: (int(round(np.log2(v))) if v > 0 else None) for k, v in ts.ws.scales.state().items()},
+           "plane_scales_are": "log2 of the per-tensor scales after the run; scale moves after calibration: %d in %d steps "
+                               "(checked at steps 0, 1, 2, 4 .. 64 and every 64th: two device-to-host copies each, inside the timed region)"
+                               % (ts.ws.scales.changes, ts.global_step),
+           "gather_steps_per_launch": ts.gather_ahead}
+    if kt.count("dW1") and kt.count("dW2") and kt.count("fc1_fwd"):
+        n_launch = kt.count("dW1") + kt.count("dW2")
+        t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
+        flop_launch = sampled * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
+        ach = flop_launch / (t_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_f16x2_256<true, 3, true, true> (dW1+dW2 launches: fp32 products as 3 fp16 "
+                           "plane products; achieved = fp32-equivalent rate, peak = fp16 dense peak / 3)", "achieved": round(ach, 2),
+                           "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launch_ms": round(t_ms, 4),
+                           "flop_per_launch": flop_launch, "launches_per_step": n_launch / sampled, "timed_steps": sampled,
+                           "timed_how": how}
+        ach1 = 2.0 * R * F * H / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
+        out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": "k_gemm_f16x2_256<false, 6, true, true>", "achieved": round(ach1, 2),
+                                   "peak": peak, "unit": "TFLOP/s", "frac": round(ach1 / peak, 4),
+                                   "launch_ms": round(kt.mean_ms("fc1_fwd"), 4)}
+        kern = {}
+        for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW1", "dW2", "adam_w1", "adam_w2", "split_planes"):
+            if kt.mean_ms(k) is not None:
+                kern[k + "_ms"] = round(kt.mean_ms(k), 4)
+        kern["empty_event_pair_ms"] = round(kt.overhead_ms, 5)
+        out["kernels"] = kern
+    # the gather writes 6 000 B of planes per row where the three bf16 planes are 9 000
+    reps, per, n_st = 5, 10, ts.gather_ahead
+    nxt = [ts.global_step + 1000]
+
+    def launch():
+        if n_st > 1:
+            ts._gather_block(nxt[0])
+        else:
+            from cdml_amd import ops
+            ops.sample_gather(train._MODES[mode], ts.pairs, ts.seed, nxt[0], B, ts.table.data, F, ts.idx, ts.ws.x_hat, shift_out=ts.shift)
+        nxt[0] += n_st
+    for _ in range(3):
+        launch()
+    evs = []
+    for _ in range(reps):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        for _ in range(per):
+            launch()
+        e_.record()
+        evs.append((s_, e_))
+    torch.cuda.synchronize(dev)
+    t_g = float(np.median([s_.elapsed_time(e_) for s_, e_ in evs])) / per
+    gbytes = n_st * R * F * (4 + 4.0)
+    out["gather"] = {"bound": "hbm", "kernel": "k_sample_gather<%d, RowF32H2<6>>" % (1 if ts.rows_per_triplet == 2 else 0),
+                     "achieved": round(gbytes / (t_g * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(gbytes / (t_g * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "bytes_per_row_moved": 8.0 * F,
+                     "launch_ms": round(t_g, 4), "rows_per_launch": n_st * R}
+    del ts, a
+    torch.cuda.empty_cache()
+    # a run that LEARNS (data_learnable's catalogue): this path and f32x3 from the same seeds, the loss along the way
+    tl, pl = learnable_catalogue(200000, dev)
+    curves = {}
+    for prec in ("f16x2", "f32x3"):
+        t = train.TrainStep(tl, pl, 4096, output_size=D, hidden_size=H, margin=MARGIN, mode=mode, optimizer="adam",
+                            base_learning_rate=2e-4, device=dev, precision=prec, gather_ahead=args.gather_ahead)
+        losses = []
+        for i in range(151):
+            t.step()
+            if i % 30 == 0:
+                losses.append(round(t.loss(), 4))
+        curves[prec] = losses
+        if prec == "f16x2":
+            curves["f16x2_scale_moves"] = t.ws.scales.changes
+        del t
+        torch.cuda.empty_cache()
+    out["learnable_catalogue_loss_every_30_steps"] = curves
+    return out
+
+
 def rec_fusion(dev, args, n_s, n_w):
     """The reference's production tower (ResNet, models.py:125-157) at feature_size 1628 = 1500 visual +
     128 doc (online_data.py:38): batch 1024 uniform triplets, Adam."""
@@ -1058,7 +1188,7 @@ def main():
     ap.add_argument("--extras", default=None,
                     help="comma list of secondary records to run (default: all): config1,config2_semihard,dp_form_one_gpu,train_table,"
                          "config4_per_gpu,reference_recipe,fusion_resnet,predict,data_learnable,f32_mfma")
-    ap.add_argument("--only", default=None, choices=["reference_recipe", "fusion_resnet", "data_learnable"],
+    ap.add_argument("--only", default=None, choices=["reference_recipe", "fusion_resnet", "data_learnable", "f16x2"],
                     help="run ONE secondary record as the job (its JSON line; for rocprofv3 runs of that workload)")
     ap.add_argument("--no-settle", action="store_true",
                     help="skip the 0.3 s GEMM loop before the warm-up steps (rocprof runs: keeps its launches out of the kernel averages)")
@@ -1117,12 +1247,17 @@ def main():
             r = rec_reference_recipe(dev, args, n_s, n_w, engine.FeatureTable.synthetic(1000000, F, seed=0, device=dev))
         elif args.only == "fusion_resnet":
             r = rec_fusion(dev, args, n_s, n_w)
+        elif args.only == "f16x2":
+            nr = args.rows or 10000000
+            r = rec_f16x2(dev, args, n_s, n_w, engine.FeatureTable.synthetic(nr, F, seed=0, device=dev),
+                          torch.from_numpy(synth_pairs(nr, max(nr // 16, 1000), seed=0)).to(dev), args.batch or 8192, "inbatch")
         else:
             r = rec_learnable(dev, args, n_s, n_w, args.batch or 4096)
         out = {"metric": "triplets/sec", "value": r["value"], "unit": "triplets/s", "n_gpus": 1, "steps": r["steps"],
                "warmup": n_w, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": X3_DTYPE if args.precision == "f32x3" else "f32 (fp32 MFMA)", "data": "synthetic",
-               "config": {"workload": r["workload"], "precision": args.precision}, args.only: r}
+               "vs_baseline": None, "dtype": F16X2_DTYPE if args.only == "f16x2" else X3_DTYPE if args.precision == "f32x3" else "f32 (fp32 MFMA)",
+               "data": "synthetic", "config": {"workload": r["workload"], "precision": "f16x2" if args.only == "f16x2" else args.precision},
+               args.only: r}
         print(json.dumps(out), file=result_out, flush=True)
         return
 
@@ -1378,7 +1513,7 @@ def main():
             other = "f32" if x3 else "f32x3"
             other_name = "f32_mfma" if x3 else "f32x3"
             want = set((args.extras or "config1,config2_semihard,dp_form_one_gpu,train_table,config4_per_gpu,reference_recipe,fusion_resnet,"
-                                       "predict,knn,data_learnable," + other_name).split(","))
+                                       "predict,knn,data_learnable,f16x2," + other_name).split(","))
             n_s, n_w = min(args.steps, 30), min(max(args.warmup, 3), 5)
             keep = {"t10": table, "p10": pairs}            # the headline's own catalogue serves dp_form_one_gpu
             del table, pairs
@@ -1395,6 +1530,8 @@ def main():
                 except Exception as e:                   # noqa: BLE001
                     out[name] = {"error": repr(e)[:300]}
                 torch.cuda.empty_cache()
+            if x3:
+                attempt("f16x2", lambda: rec_f16x2(dev, args, n_s, n_w, keep["t10"], keep["p10"], B, mode))
             attempt("dp_form_one_gpu", lambda: rec_dp_form(dev, args, n_s, n_w, keep))
             attempt("train_table", lambda: rec_train_table(dev, args, n_s, n_w, keep))     # (last user of the 10 M-row table: it trains it)
             keep.clear()

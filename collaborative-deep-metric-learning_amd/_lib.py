@@ -92,6 +92,8 @@ SIGNATURES = {
                             _p, _p, _p]),
     "cdml_vnet_tail_planes": (_i, [_i, _p, _i64, _p, _p, _i, _i, _f, _f, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64,
                                    _p, _p, _p]),
+    "cdml_vnet_tail_h2": (_i, [_i, _p, _i64, _p, _p, _i, _i, _f, _f, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _f,
+                               _p, _p, _p]),
     "cdml_semihard_select": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _p, _p]),
     "cdml_semihard_mine_x3_workspace": (_sz, [_i]),
     "cdml_semihard_mine_x3": (_i, [_p, _i64, _p, _i, _i, _p, _i64, _i64, _p, _p, _p, _sz, _p, _p]),
@@ -119,6 +121,8 @@ SIGNATURES = {
                                 _p, _sz, _p]),
     "cdml_gemm_bf16_tn": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _sz, _p]),
     "cdml_sample_gather_x3": (_i, [_i, _p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _i64, _i64, _i,
+                                   _p, _p, _p, _i64, _i, _i64, _i64, _p, _p]),
+    "cdml_sample_gather_h2": (_i, [_i, _p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _i64, _i64, _i,
                                    _p, _p, _p, _i64, _i, _i64, _i64, _p, _p]),
     "cdml_gather_rows_x3": (_i, [_p, _i64, _i64, _p, _i, _i, _i, _p, _i64, _p, _p]),
     "cdml_sample_gather_x3k": (_i, [_i, _p, _i64, _u64, _u64, _p, _i, _i64, _i64, _p, _i64, _i64, _i,
@@ -149,6 +153,8 @@ SIGNATURES = {
                                    _p, _p, _p, _p, _i, _i, _p, _p]),
     "cdml_adam_matrix_planes": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _f, _f, _f, _i64, _p, _p, _i64, _i64, _p, _i64, _i64,
                                      _p, _p, _p, _p, _i, _i, _p, _p]),
+    "cdml_adam_matrix_h2": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _f, _f, _f, _i64, _p, _p, _i64, _i64, _p, _i64, _i64, _f,
+                                 _p, _p, _p, _p, _i, _i, _p, _p]),
     "cdml_table_adam_rows": (_i, [_p, _i64, _i64, _i64, _i, _p, _i, _p, _i64, _p, _p, _p, _p, _f, _f, _p, _f, _f, _f,
                                   _i64, _p, _p]),
     "cdml_grad_prepare": (_i, [_p, _p, _i64, _f, _f, _p, _p, _p]),

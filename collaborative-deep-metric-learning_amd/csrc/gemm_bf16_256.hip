@@ -676,9 +676,10 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
   //   the schedule at the top of this file), every image is waited for one phase before its first read.
   constexpr bool kR6 = X3 && S16 && R6;
   if constexpr (kR6) {
-    const int n_per = n_ktiles / 6;                        // whole periods (host)
+    constexpr int kPer = kF16 ? 3 : 6;                     // steps per K-tile: the plane products
+    const int n_per = n_ktiles / kPer;                     // whole periods (host)
     if (n_per > 0) {                                       // (an empty split writes zeros)
-      const int w_first = x3_t0 / 6, w_last = w_first + n_per - 1;
+      const int w_first = x3_t0 / kPer, w_last = w_first + n_per - 1;
       const uint32_t ws_a = KI ? (uint32_t)(8 * g.lda * 2) : TN ? (uint32_t)(kTileK * g.lda * 2) : (uint32_t)(kTileK * 2);   // bytes per K-tile of a plane
       const uint32_t ws_b = KI ? (uint32_t)(8 * g.ldb * 2) : TN ? (uint32_t)(kTileK * g.ldb * 2) : (uint32_t)(kTileK * 2);
       const uint32_t ps_a = (uint32_t)(g.x3_plane_a * 2), ps_b = (uint32_t)(g.x3_plane_b * 2);
@@ -737,7 +738,124 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
         dma_s(img == 0 ? srd_a : srd_b, img == 0 ? (h1 ? va_h1[0] : va[0]) : (h1 ? vb_h1[0] : vb[0]), so, dst);
         dma_s(img == 0 ? srd_a : srd_b, img == 0 ? (h1 ? va_h1[1] : va[1]) : (h1 ? vb_h1[1] : vb[1]), so, dst + 1024);
       };
-      if constexpr (!NARROW) {
+      if constexpr (kF16) {
+      // ---- TWO planes, THREE products: the resident-plane walk of the fp16 form (R3; round 6) ----------------------------
+      // The same idea on the period (A0,B0) (A1,B0) (A0,B1) [hi.hi, lo.hi, hi.lo]: every plane image of a K-tile is staged
+      // ONCE -- 4 images = 8 half images in the period's 6 phases, where the general loop stages 12 -- into the same five
+      // slots: A0 alternates between A slots 0 and 2 with the K-tile's parity (it is read on steps 0 AND 2, so the next
+      // K-tile's A0 needs a slot of its own), A1 lives in A slot 1, B0 / B1 in B slots 0 / 1; the B fragments are read on
+      // steps 0 and 2 only and stay in registers in between.
+      //   phase p = 2 S + h reads A(S) half h [+ the B fragments at p = 0, 4] and issues:
+      //     p:      0             1        2        3        4               5
+      //     load:   B1.h0 B1.h1   A0'.h0   A0'.h1   B0'.h0   B0'.h1 A1'.h0   A1'.h1          (' = next K-tile)
+      //     need:   4     4       6        7        6        6      8        9               (first read, phase)
+      //     vmcnt:  8             8        8        6        10              4               (what may stay in flight)
+      //   Every overwrite is issued at least one phase after the last read of what it replaces (B1 after phase 4 of the K-tile
+      //   before; A0' into the slot A0 of the K-tile BEFORE left at phases 4 / 5; B0' after phase 0; A1' halves after phases
+      //   2 / 3), every image is waited for one phase before its first read (replayed from this source by
+      //   tests/test_r6_schedule.py).
+      static_assert(!NARROW && !KI, "the fp16 form has the full tile on row-major operands only");
+      auto phase3 = [&](auto phc, auto parc, const uint32_t kwb_c, const uint32_t kwa_n, const uint32_t kwb_n, const bool own) {
+        constexpr int PH = decltype(phc)::value, PAR = decltype(parc)::value;
+        constexpr int S = PH >> 1, HALF = PH & 1;
+        constexpr int PA3[3] = {0, 1, 0}, PB3[3] = {0, 0, 1};
+        constexpr int SLOT_A3[2][2] = {{0, 1}, {2, 1}};          // [parity][plane]
+        constexpr int sa = SLOT_A3[PAR][PA3[S]];
+        constexpr bool rdB = HALF == 0 && (S == 0 || S == 2);
+        if constexpr (rdB) {
+          constexpr int sb = PB3[S];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+              fb0[2 * cb + ks2] = rd_b(sb, 0, cb, ks2);
+              fb1[2 * cb + ks2] = rd_b(sb, 1, cb, ks2);
+            }
+        }
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) fa[ks2][rb] = rd_a(sa, HALF, rb, ks2);
+        // Two placements of the period's eight loads (SCH).  0: the table above.  1: one load in each of the fragment-heavy
+        // phases 0 / 4 (they also read the B fragments) and two in phases 1 / 3 -- B1.h0 | B1.h1 A0'.h0 | A0'.h1 | B0'.h0 B0'.h1 |
+        // A1'.h0 | A1'.h1, waits 6 8 8 8 10 4: FC1 554.7 against 560.7 us, the other k-contiguous products even
+        // (gpurun call r06z, alternating processes).  The k-contiguous kernels run 1; the k-strided kernel keeps 0 (with 1 it
+        // needs 20 B of scratch: 256 VGPRs).
+        constexpr int SCH = TN ? 0 : 1;
+        if constexpr (SCH == 0 && PH == 0) { issue(1, 1, 0, 1, kwb_c); issue(1, 1, 1, 1, kwb_c); }
+        if constexpr (SCH == 0 && PH == 1) { issue(0, 0, 0, SLOT_A3[PAR ^ 1][0], kwa_n); }
+        if constexpr (SCH == 0 && PH == 2) { issue(0, 0, 1, SLOT_A3[PAR ^ 1][0], kwa_n); }
+        if constexpr (SCH == 0 && PH == 3) { issue(1, 0, 0, 0, kwb_n); }
+        if constexpr (SCH == 0 && PH == 4) { issue(1, 0, 1, 0, kwb_n); issue(0, 1, 0, 1, kwa_n); }
+        if constexpr (SCH == 0 && PH == 5) { issue(0, 1, 1, 1, kwa_n); }
+        if constexpr (SCH == 1 && PH == 0) { issue(1, 1, 0, 1, kwb_c); }
+        if constexpr (SCH == 1 && PH == 1) { issue(1, 1, 1, 1, kwb_c); issue(0, 0, 0, SLOT_A3[PAR ^ 1][0], kwa_n); }
+        if constexpr (SCH == 1 && PH == 2) { issue(0, 0, 1, SLOT_A3[PAR ^ 1][0], kwa_n); }
+        if constexpr (SCH == 1 && PH == 3) { issue(1, 0, 0, 0, kwb_n); issue(1, 0, 1, 0, kwb_n); }
+        if constexpr (SCH == 1 && PH == 4) { issue(0, 1, 0, 1, kwa_n); }
+        if constexpr (SCH == 1 && PH == 5) { issue(0, 1, 1, 1, kwa_n); }
+        constexpr int VM3[2][6] = {{8, 8, 8, 6, 10, 4}, {6, 8, 8, 8, 10, 4}};
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM3[SCH][PH]) : "memory");
+        if constexpr (rdB) pin_b();
+        pin_a();
+        if constexpr (rdB) {
+          if (own) {                                       // bias gradient: this (tile, row group) owns the K-tile
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+              for (int ks2 = 0; ks2 < 2; ++ks2) {
+                cs16[cb] = dot_sum(fb0[2 * cb + ks2], cs16[cb]);
+                cs16[2 + cb] = dot_sum(fb1[2 * cb + ks2], cs16[2 + cb]);
+              }
+          }
+        }
+        CDML_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              acc16[4 * HALF + rb][cb] = CDML_MFMA16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 * HALF + rb][cb]);
+              acc16[4 * HALF + rb][2 + cb] = CDML_MFMA16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 * HALF + rb][2 + cb]);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        CDML_BARRIER();
+      };
+      auto period3 = [&](auto parc, const int w, const bool own) {
+        const int wn = min(w + 1, w_last);                 // past the end: a valid K-tile again (its images are never read)
+        const uint32_t kwb_c = (uint32_t)w * ws_b, kwa_n = (uint32_t)wn * ws_a, kwb_n = (uint32_t)wn * ws_b;
+        phase3(std::integral_constant<int, 0>{}, parc, kwb_c, kwa_n, kwb_n, own);
+        phase3(std::integral_constant<int, 1>{}, parc, kwb_c, kwa_n, kwb_n, own);
+        phase3(std::integral_constant<int, 2>{}, parc, kwb_c, kwa_n, kwb_n, own);
+        phase3(std::integral_constant<int, 3>{}, parc, kwb_c, kwa_n, kwb_n, own);
+        phase3(std::integral_constant<int, 4>{}, parc, kwb_c, kwa_n, kwb_n, own);
+        phase3(std::integral_constant<int, 5>{}, parc, kwb_c, kwa_n, kwb_n, own);
+      };
+      // R3 prologue: the steady state at phase 0 of the first K-tile (parity 0): what phases 1 .. 5 of a previous period
+      // would have issued, in their order, then the wait of its phase 5
+      {
+        const uint32_t ka3 = (uint32_t)w_first * ws_a, kb3 = (uint32_t)w_first * ws_b;
+        issue(0, 0, 0, 0, ka3); issue(0, 0, 1, 0, ka3);
+        issue(1, 0, 0, 0, kb3); issue(1, 0, 1, 0, kb3);
+        issue(0, 1, 0, 1, ka3); issue(0, 1, 1, 1, ka3);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+      CDML_BARRIER();
+      if (grp == 1) CDML_BARRIER();                        // group 1 runs one barrier behind
+      int cs_wait3 = __builtin_amdgcn_readfirstlane(cs_on ? (2 * tm + grp + cs_period - w_first % cs_period) % cs_period : 0x40000000);
+      for (int w = w_first;;) {
+        bool own = cs_wait3 == 0;
+        cs_wait3 = own ? cs_period - 1 : cs_wait3 - 1;
+        period3(std::integral_constant<int, 0>{}, w, own);
+        if (++w > w_last) break;
+        own = cs_wait3 == 0;
+        cs_wait3 = own ? cs_period - 1 : cs_wait3 - 1;
+        period3(std::integral_constant<int, 1>{}, w, own);
+        if (++w > w_last) break;
+      }
+      } else if constexpr (!NARROW) {
       // the phase: PH = 2 S + half (compile time), PAR = parity of the K-tile; kw_* = byte offsets of this / the next K-tile
       auto phase = [&](auto phc, auto parc, const uint32_t kwa_c, const uint32_t kwb_c, const uint32_t kwa_n,
                        const uint32_t kwb_n, const bool own) {
@@ -1735,7 +1853,11 @@ int x3_walk() {
 template <bool TN, int EPI>
 int launch_x3(const BArgs &g, int splits, hipStream_t s) {
 #ifdef CDML_F16X2
-  // three products: the general K-major loop (the resident-plane walk and its half tiles are schedules of the six-product period)
+  // three products: the resident-plane walk of the three-step period (R3) wherever every block's K range is whole periods;
+  // CDML_X3_WALK=general: the general K-major loop (A/B runs; read per call)
+  const int kt3 = g.K / kTileK, per3 = g.k_per_split / kTileK;
+  const bool whole3 = g.x3_products == 3 && kt3 % 3 == 0 && per3 % 3 == 0 && per3 > 0;
+  if (whole3 && x3_walk() == 2) return launch_x3_1<TN, EPI, false, false, true>(g, g.tiles_m * g.tiles_n, splits, s);
   return launch_x3_1<TN, EPI, false>(g, g.tiles_m * g.tiles_n, splits, s);
 #else
   const int kt = g.K / kTileK, per = g.k_per_split / kTileK;

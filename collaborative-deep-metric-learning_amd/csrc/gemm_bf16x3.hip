@@ -487,7 +487,8 @@ static int gemm_x3_tn_impl(bool f16, float out_scale, float cs_scale, const uint
   g.tiles_m = M / 256; g.tiles_n = N / 256;
   int splits = gemm_bf16_256_splits(M, N, g.K), per = 0;
   // whole six-step periods of the K-major walk per block (the unrolled loops need them); three products: an even count
-  x3_split_geometry(ktiles, splits, (products == 6 && g.x3_products == 6) ? 6 : 2, per, splits);
+  // (the fp16 form: whole three-step periods, an even count for the general loop)
+  x3_split_geometry(ktiles, splits, ((products == 6 && g.x3_products == 6) || f16) ? 6 : 2, per, splits);
   const bool slabs = splits > 1 || bias != nullptr;       // (bias + leaky-relu are applied by the combine pass)
   const size_t slab_bytes = slabs ? (size_t)splits * M * N * sizeof(float) : 0;
   const size_t cs_rows = (size_t)splits * g.tiles_m * 2;

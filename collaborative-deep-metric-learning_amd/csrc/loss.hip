@@ -231,7 +231,7 @@ __device__ __forceinline__ void tail_dist(const TailRow<NCH> &a, const TailRow<N
 template <int NCH>
 __device__ __forceinline__ void tail_store_row(const TailRow<NCH> &r, const float4 (&g)[NCH], float alpha,
                                                float *er, float *dr, uint16_t *br, int nq, int lane,
-                                               int64_t plane = 0) {
+                                               int64_t plane = 0, float h2_scale = 0.f) {
   float zg = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) zg += dot4(r.v[c], g[c]);
@@ -253,7 +253,19 @@ __device__ __forceinline__ void tail_store_row(const TailRow<NCH> &r, const floa
     }
     st4(er, q, r.e(c));
     st4(dr, q, d);
-    if (br) {   // bf16 copy (round to nearest even) for the reduced-precision GEMMs
+    if (br && h2_scale > 0.f) {   // precision "f16x2": the two fp16 planes hi | lo of d * h2_scale (saturating), `plane` apart
+      using half4v = __attribute__((ext_vector_type(4))) _Float16;
+      const float dv[4] = {d.x, d.y, d.z, d.w};
+      half4v hi, lo;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float sv = __builtin_amdgcn_fmed3f(dv[u] * h2_scale, -65504.f, 65504.f);
+        hi[u] = (_Float16)sv;
+        lo[u] = (_Float16)(sv - (float)hi[u]);
+      }
+      reinterpret_cast<half4v *>(br)[q] = hi;
+      reinterpret_cast<half4v *>(br + plane)[q] = lo;
+    } else if (br) {   // bf16 copy (round to nearest even) for the reduced-precision GEMMs
       auto rn = [](float x) -> uint32_t {
         const uint32_t u = __float_as_uint(x);
         return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
@@ -289,7 +301,7 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
             float *__restrict__ e, int64_t lde, float *__restrict__ pos_o, float *__restrict__ neg_o,
             float *__restrict__ hinge_o, uint8_t *__restrict__ valid_o, float *__restrict__ dz2,
             int64_t lddz, uint16_t *__restrict__ dz2_bf, int64_t ldbf, float *__restrict__ var_ws,
-            int64_t plane_bf) {
+            int64_t plane_bf, float h2_scale) {
   __shared__ __attribute__((aligned(16))) float s_red[kWavesPerBlock][8];
   extern __shared__ __attribute__((aligned(16))) float s_col[];                 // [kWavesPerBlock][D] when var_ws
   const int lane = threadIdx.x & (kWave - 1);
@@ -325,7 +337,7 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
       }
       if (lane == 0) { pos_o[i] = pos; neg_o[i] = neg; hinge_o[i] = fmaxf(t, 0.f); }
       tail_store_row<NCH>(N, gn, alpha, e + (ra + 2) * lde, dz2 + (ra + 2) * lddz,
-                          dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane, plane_bf);
+                          dz2_bf ? dz2_bf + (ra + 2) * ldbf : nullptr, nq, lane, plane_bf, h2_scale);
     } else {
       const int j = (i + shift) % B;
       const int k = (i - shift % B + B) % B;
@@ -359,8 +371,8 @@ k_vnet_tail(const float *__restrict__ z, int64_t ldz, const int32_t *__restrict_
         if (valid_o) valid_o[i] = valid_i ? 1 : 0;
       }
     }
-    tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane, plane_bf);
-    tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane, plane_bf);
+    tail_store_row<NCH>(A, ga, alpha, e + ra * lde, dz2 + ra * lddz, dz2_bf ? dz2_bf + ra * ldbf : nullptr, nq, lane, plane_bf, h2_scale);
+    tail_store_row<NCH>(P, gp, alpha, e + rp * lde, dz2 + rp * lddz, dz2_bf ? dz2_bf + rp * ldbf : nullptr, nq, lane, plane_bf, h2_scale);
     if (var_ws) {       // column sums and sum of squares of the [B,3,D] triplet tensor
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -967,7 +979,8 @@ static int vnet_tail_impl(int mode, const float *z, int64_t ldz, const int32_t *
                           const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
                           float *e, int64_t lde, float *pos, float *neg, float *hinge,
                           uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_bf16,
-                          int64_t ldbf, int64_t plane_bf, float *stats, float *var_ws, cdml_stream_t stream) {
+                          int64_t ldbf, int64_t plane_bf, float *stats, float *var_ws, cdml_stream_t stream,
+                          float h2_scale = 0.f) {
   CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "vnet_tail: mode must be 0 (a,p,n rows) or 1 (in-batch)");
   CDML_REQUIRE(B >= (mode == 1 ? 2 : 1) && D > 0 && pos && neg && hinge, CDML_E_BADARG, "vnet_tail: bad argument");
   CDML_REQUIRE(mode == 0 || (rows && shift), CDML_E_BADARG, "vnet_tail: in-batch mode needs rows and shift");
@@ -979,8 +992,8 @@ static int vnet_tail_impl(int mode, const float *z, int64_t ldz, const int32_t *
   if ((rc = check_rows("vnet_tail dz2", dz2, lddz2, D))) return rc;
   CDML_REQUIRE(!dz2_bf16 || (ldbf >= D && (ldbf & 3) == 0 && (reinterpret_cast<uintptr_t>(dz2_bf16) & 7) == 0),
                CDML_E_ALIGN, "vnet_tail: bf16 copy needs an 8-B aligned base and a leading dimension multiple of 4");
-  CDML_REQUIRE(plane_bf == 0 || (dz2_bf16 && plane_bf >= D && (plane_bf & 3) == 0 && ldbf >= 2 * plane_bf + D), CDML_E_ALIGN,
-               "vnet_tail: planes need plane >= D (a multiple of 4) and a leading dimension >= 2 plane + D");
+  CDML_REQUIRE(plane_bf == 0 || (dz2_bf16 && plane_bf >= D && (plane_bf & 3) == 0 && ldbf >= (h2_scale > 0.f ? 1 : 2) * plane_bf + D),
+               CDML_E_ALIGN, "vnet_tail: planes need plane >= D (a multiple of 4) and a leading dimension >= 2 plane + D (fp16 planes: plane + D)");
   int grid = grid_rows(B);
   if (var_ws && grid > kTailVarBlocks) grid = kTailVarBlocks;
   const size_t lds = var_ws ? (size_t)kWavesPerBlock * D * sizeof(float) : 0;
@@ -988,7 +1001,7 @@ static int vnet_tail_impl(int mode, const float *z, int64_t ldz, const int32_t *
 #define CDML_LAUNCH_TAIL(M, N)                                                                       \
   hipLaunchKernelGGL((k_vnet_tail<M, N>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, z, ldz, \
                      rows, shift, B, D, margin, lrelu_alpha, e, lde, pos, neg, hinge, valid_out, dz2,  \
-                     lddz2, dz2_bf16, ldbf, var_ws, plane_bf)
+                     lddz2, dz2_bf16, ldbf, var_ws, plane_bf, h2_scale)
   if (mode == 0) {
     if (nch <= 1) CDML_LAUNCH_TAIL(0, 1); else if (nch <= 2) CDML_LAUNCH_TAIL(0, 2); else CDML_LAUNCH_TAIL(0, 4);
   } else {
@@ -1027,6 +1040,19 @@ extern "C" int cdml_vnet_tail_planes(int mode, const float *z, int64_t ldz, cons
   CDML_REQUIRE(dz2_planes && plane_bf > 0, CDML_E_BADARG, "vnet_tail_planes: the plane buffer and its plane stride are required");
   return vnet_tail_impl(mode, z, ldz, rows, shift, B, D, margin, lrelu_alpha, e, lde, pos, neg, hinge, valid_out, dz2, lddz2,
                         dz2_planes, ldbf, plane_bf, stats, var_ws, stream);
+}
+
+// cdml_vnet_tail writing dz2 also as the two fp16 planes hi | lo of dz2 * scale (precision "f16x2"; values beyond fp16's
+// range saturate): dz2_planes = fp16 [rows][ldbf], plane p at columns p * plane_h (plane_h >= D, ldbf >= plane_h + D).
+extern "C" int cdml_vnet_tail_h2(int mode, const float *z, int64_t ldz, const int32_t *rows,
+                                 const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
+                                 float *e, int64_t lde, float *pos, float *neg, float *hinge,
+                                 uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_planes,
+                                 int64_t ldbf, int64_t plane_h, float scale, float *stats, float *var_ws,
+                                 cdml_stream_t stream) {
+  CDML_REQUIRE(dz2_planes && plane_h > 0 && scale > 0.f, CDML_E_BADARG, "vnet_tail_h2: the plane buffer, its plane stride and a positive scale are required");
+  return vnet_tail_impl(mode, z, ldz, rows, shift, B, D, margin, lrelu_alpha, e, lde, pos, neg, hinge, valid_out, dz2, lddz2,
+                        dz2_planes, ldbf, plane_h, stats, var_ws, stream, scale);
 }
 
 extern "C" int cdml_semihard_select(const float *S, int64_t ldS, const float *e, int64_t lde,

@@ -111,9 +111,56 @@ constexpr int kAT = 64;
 template <int PLANES>
 __device__ __forceinline__ void tile_copies(float (&res)[2][2][4], uint32_t (&sT)[64][64 / 2 + 1], __bf16 *__restrict__ wt,
                                             int64_t ldt, __bf16 *__restrict__ wc, int64_t ldc, int64_t plane_t,
-                                            int64_t plane_c, int k0, int n0) {
+                                            int64_t plane_c, int k0, int n0, float h2_scale = 0.f) {
   using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
   const int tr = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+  if constexpr (PLANES == 2) {
+    // precision "f16x2": the copies are the two fp16 planes hi | lo of the new weights times h2_scale (saturating); the
+    // same tile walk, the 16-bit words being fp16
+    using half4v = __attribute__((ext_vector_type(4))) _Float16;
+    using half2v = __attribute__((ext_vector_type(2))) _Float16;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) res[p][q][u] = __builtin_amdgcn_fmed3f(res[p][q][u] * h2_scale, -65504.f, 65504.f);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      if (pl && wt) __syncthreads();
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int r = p * 32 + 2 * tr;
+        half4v o[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            o[q][u] = (_Float16)res[p][q][u];
+            res[p][q][u] -= (float)o[q][u];
+          }
+          if (wc) *reinterpret_cast<half4v *>(wc + (int64_t)(k0 + r + q) * ldc + pl * plane_c + n0 + c4) = o[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const half2v pr = {o[0][u], o[1][u]};
+          sT[c4 + u][r >> 1] = __builtin_bit_cast(uint32_t, pr);
+        }
+      }
+      if (wt) {
+        __syncthreads();
+        const int sr = threadIdx.x >> 3, seg = (threadIdx.x & 7) * 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int row = q * 32 + sr;
+          uint4 o;
+          o.x = sT[row][seg]; o.y = sT[row][seg + 1]; o.z = sT[row][seg + 2]; o.w = sT[row][seg + 3];
+          *reinterpret_cast<uint4 *>(wt + (int64_t)(n0 + row) * ldt + pl * plane_t + k0 + seg * 2) = o;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int pl = 0; pl < PLANES; ++pl) {
     if (pl && wt) __syncthreads();                     // the previous plane's tile has been read out
@@ -160,7 +207,7 @@ k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__
                    __bf16 *__restrict__ wt, int64_t ldt, __bf16 *__restrict__ wc, int64_t ldc,
                    float *__restrict__ bw, const float *__restrict__ bg, float *__restrict__ bm,
                    float *__restrict__ bv, int bn, int advance, uint32_t *__restrict__ tickets,
-                   int64_t plane_t, int64_t plane_c) {
+                   int64_t plane_t, int64_t plane_c, float h2_scale) {
   __shared__ float s_lr_t;
   __shared__ uint32_t sT[kAT][kAT / 2 + 1];           // [column n][row pair]: two bf16 of one column per word
   if (threadIdx.x == 0) {
@@ -196,7 +243,7 @@ k_adam_matrix_bf16(float *__restrict__ w, const float *__restrict__ g, float *__
       res[p][q][0] = w4.x; res[p][q][1] = w4.y; res[p][q][2] = w4.z; res[p][q][3] = w4.w;
     }
   }
-  tile_copies<PLANES>(res, sT, wt, ldt, wc, ldc, plane_t, plane_c, k0, n0);
+  tile_copies<PLANES>(res, sT, wt, ldt, wc, ldc, plane_t, plane_c, k0, n0, h2_scale);
   if (bw) {                                          // the bias vector: element i of the first ceil(bn / 256) blocks
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < bn; i += gridDim.x * kThreads) {
       float wi = bw[i], mi = bm[i], vi = bv[i];
@@ -539,7 +586,7 @@ static int adam_matrix_impl(float *w, const float *g, float *m, float *v, int K,
                             uint64_t *t_dev, uint16_t *wt_bf16, int64_t ldt, uint16_t *wc_bf16,
                             int64_t ldc, float *bias_w, const float *bias_g, float *bias_m,
                             float *bias_v, int bias_n, int advance_step, uint32_t *tickets,
-                            int planes, int64_t plane_t, int64_t plane_c, cdml_stream_t stream) {
+                            int planes, int64_t plane_t, int64_t plane_c, cdml_stream_t stream, float h2_scale = 0.f) {
   CDML_REQUIRE(w && g && m && v && K > 0 && N > 0, CDML_E_BADARG, "adam_matrix_bf16: bad argument");
   CDML_REQUIRE(!bias_w || (bias_g && bias_m && bias_v && bias_n > 0), CDML_E_BADARG,
                "adam_matrix_bf16: the bias vector needs its gradient and both moments");
@@ -552,7 +599,16 @@ static int adam_matrix_impl(float *w, const float *g, float *m, float *v, int K,
                    (!wt_bf16 || (aligned16(wt_bf16) && (ldt & 7) == 0 && ldt >= K)) &&
                    (!wc_bf16 || (aligned16(wc_bf16) && (ldc & 3) == 0 && ldc >= N)),
                CDML_E_ALIGN, "adam_matrix_bf16: 16-B aligned buffers, ldt a multiple of 8 (>= K), ldc of 4 (>= N)");
-  if (planes == 3) {
+  if (planes == 2) {
+    CDML_REQUIRE(h2_scale > 0.f && (!wt_bf16 || (!(plane_t & 7) && plane_t >= K && ldt >= plane_t + K)) &&
+                     (!wc_bf16 || (!(plane_c & 3) && plane_c >= N && ldc >= plane_c + N)),
+                 CDML_E_ALIGN, "adam_matrix_h2: a positive scale, plane strides (W^T: multiple of 8, >= K; W: multiple of 4, >= N) and "
+                 "leading dimensions >= plane + the matrix width");
+    hipLaunchKernelGGL(k_adam_matrix_bf16<2>, dim3((K / kAT) * (N / kAT)), dim3(kThreads), 0, (hipStream_t)stream, w, g,
+                       m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, reinterpret_cast<__bf16 *>(wt_bf16), ldt,
+                       reinterpret_cast<__bf16 *>(wc_bf16), ldc, bias_w, bias_g, bias_m, bias_v, bias_w ? bias_n : 0,
+                       advance_step, tickets, plane_t, plane_c, h2_scale);
+  } else if (planes == 3) {
     CDML_REQUIRE((!wt_bf16 || (!(plane_t & 7) && plane_t >= K && ldt >= 2 * plane_t + K)) &&
                      (!wc_bf16 || (!(plane_c & 3) && plane_c >= N && ldc >= 2 * plane_c + N)),
                  CDML_E_ALIGN, "adam_matrix_planes: plane strides (W^T: multiple of 8, >= K; W: multiple of 4, >= N) and "
@@ -560,12 +616,12 @@ static int adam_matrix_impl(float *w, const float *g, float *m, float *v, int K,
     hipLaunchKernelGGL(k_adam_matrix_bf16<3>, dim3((K / kAT) * (N / kAT)), dim3(kThreads), 0, (hipStream_t)stream, w, g,
                        m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, reinterpret_cast<__bf16 *>(wt_bf16), ldt,
                        reinterpret_cast<__bf16 *>(wc_bf16), ldc, bias_w, bias_g, bias_m, bias_v, bias_w ? bias_n : 0,
-                       advance_step, tickets, plane_t, plane_c);
+                       advance_step, tickets, plane_t, plane_c, 0.f);
   } else {
     hipLaunchKernelGGL(k_adam_matrix_bf16<1>, dim3((K / kAT) * (N / kAT)), dim3(kThreads), 0, (hipStream_t)stream, w, g,
                        m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, reinterpret_cast<__bf16 *>(wt_bf16), ldt,
                        reinterpret_cast<__bf16 *>(wc_bf16), ldc, bias_w, bias_g, bias_m, bias_v, bias_w ? bias_n : 0,
-                       advance_step, tickets, (int64_t)0, (int64_t)0);
+                       advance_step, tickets, (int64_t)0, (int64_t)0, 0.f);
   }
   return check_launch("adam_matrix_bf16");
 }
@@ -590,6 +646,18 @@ extern "C" int cdml_adam_matrix_planes(float *w, const float *g, float *m, float
                                        int advance_step, uint32_t *tickets, cdml_stream_t stream) {
   return adam_matrix_impl(w, g, m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, wt_planes, ldt, wc_planes, ldc, bias_w,
                           bias_g, bias_m, bias_v, bias_n, advance_step, tickets, 3, plane_t, plane_c, stream);
+}
+
+// The same update writing the copies as the two fp16 planes hi | lo of the new weights times `scale` (precision "f16x2";
+// a power of two, values beyond fp16's range saturate): wt = planes of W^T [N][hi K | lo K], wc = planes of W [K][hi N | lo N].
+extern "C" int cdml_adam_matrix_h2(float *w, const float *g, float *m, float *v, int K, int N, float lr,
+                                   const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
+                                   uint64_t *t_dev, uint16_t *wt_planes, int64_t ldt, int64_t plane_t,
+                                   uint16_t *wc_planes, int64_t ldc, int64_t plane_c, float scale, float *bias_w,
+                                   const float *bias_g, float *bias_m, float *bias_v, int bias_n,
+                                   int advance_step, uint32_t *tickets, cdml_stream_t stream) {
+  return adam_matrix_impl(w, g, m, v, K, N, lr, lr_dev, beta1, beta2, eps, t, t_dev, wt_planes, ldt, wc_planes, ldc, bias_w,
+                          bias_g, bias_m, bias_v, bias_n, advance_step, tickets, 2, plane_t, plane_c, stream, scale);
 }
 
 extern "C" size_t cdml_lars_scratch_floats(void) { return 2 + 2 * (size_t)kLarsBlocks; }

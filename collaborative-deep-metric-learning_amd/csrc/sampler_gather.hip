@@ -403,6 +403,71 @@ struct RowF32X3 {
   }
 };
 
+// RowF32H2: fp32 table -> the l2-normalised row as TWO fp16 planes hi | lo of x_hat * 2^14 (precision "f16x2":
+// gemm_f16x2_256.hip reads them).  |x_hat| <= 1, so the scale is a constant of the format (cdml.h: CDML_F16X2_X_SCALE) and
+// nothing saturates; out_stride = 2 planes of out_stride / 2 columns: 6 000 B written per 1500-d row where the three bf16
+// planes are 9 000.
+constexpr float kH2XScale = 16384.f;
+template <int NCH>
+struct RowF32H2 {
+  using In = float;
+  using Out = _Float16;
+  using Regs = RowRegs<NCH>;
+  static constexpr int kPerChunk = 4;
+  static constexpr int kRows = kRowsPerWave;
+  __device__ static __forceinline__ void issue(Regs &R, const In *table, int64_t lr, int64_t stride, int F, int lane) {
+    row_issue<NCH>(R, table, lr, stride, (F + 3) >> 2, lane);
+  }
+  __device__ static __forceinline__ void finish(Regs &R, int F, Out *dst, int64_t out_stride, int lane) {
+    using half4v = __attribute__((ext_vector_type(4))) _Float16;
+    if (F & 3) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int j = 4 * (lane + kWave * c);
+        if (j + 1 >= F && j < F) R.v[c].y = 0.f;
+        if (j + 2 >= F && j < F) R.v[c].z = 0.f;
+        if (j + 3 >= F && j < F) R.v[c].w = 0.f;
+      }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      ss += R.v[c].x * R.v[c].x + R.v[c].y * R.v[c].y + R.v[c].z * R.v[c].z + R.v[c].w * R.v[c].w;
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    const int64_t plane = out_stride / 2;
+    const int oq = (int)(plane >> 2);
+    const half4v z4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = lane + kWave * c;
+      if (q < oq) {
+        // the planes are those of the ROUNDED product (the value the fp32 gather stores) times 2^14, exactly
+#pragma clang fp contract(off)
+        float r[4] = {R.v[c].x * inv, R.v[c].y * inv, R.v[c].z * inv, R.v[c].w * inv};
+        half4v hi, lo;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float sv = r[u] * kH2XScale;
+          hi[u] = (_Float16)sv;
+          lo[u] = (_Float16)(sv - (float)hi[u]);
+        }
+#if CDML_GATHER_NT_STORE
+        __builtin_nontemporal_store(hi, reinterpret_cast<half4v *>(dst + 4 * q));
+        __builtin_nontemporal_store(lo, reinterpret_cast<half4v *>(dst + plane + 4 * q));
+#else
+        *reinterpret_cast<half4v *>(dst + 4 * q) = hi;
+        *reinterpret_cast<half4v *>(dst + plane + 4 * q) = lo;
+#endif
+      }
+    }
+    for (int q = lane + kWave * NCH; q < oq; q += kWave) {
+      *reinterpret_cast<half4v *>(dst + 4 * q) = z4;
+      *reinterpret_cast<half4v *>(dst + plane + 4 * q) = z4;
+    }
+  }
+};
+
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using bf16x8v = __attribute__((ext_vector_type(8))) __bf16;
 template <int NCH>
@@ -901,6 +966,46 @@ extern "C" int cdml_sample_gather_x3k(int mode, const int32_t *pairs, int64_t n_
   return sample_gather_x3_impl(mode, pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global, table, n_rows, row_stride, F,
                                idx_out, shift_out, x_out_planes, out_stride, n_steps, x_step_stride, idx_step_stride, oob_flag,
                                x_ki, ki_step_stride, stream);
+}
+
+// The fused sampler + gather writing each row as the two fp16 planes of x_hat * 2^14 (precision "f16x2"): x_out = fp16
+// [rows][out_stride], out_stride = 2 planes of out_stride / 2 >= F columns each (a multiple of 4).
+extern "C" int cdml_sample_gather_h2(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                                     uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
+                                     int64_t batch_global, const float *table, int64_t n_rows,
+                                     int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
+                                     uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
+                                     int64_t idx_step_stride, int32_t *oob_flag, cdml_stream_t stream) {
+  CDML_REQUIRE(mode == 0 || mode == 1, CDML_E_BADARG, "sample_gather_h2: mode must be 0 or 1");
+  CDML_REQUIRE(n_steps >= 1 && n_steps <= 64, CDML_E_BADARG, "sample_gather_h2: n_steps must be in [1, 64]");
+  const int rpt = mode == 0 ? 3 : 2;
+  CDML_REQUIRE(n_steps == 1 || (x_step_stride >= (int64_t)batch * rpt * out_stride && (x_step_stride & 3) == 0 &&
+                                idx_step_stride >= (int64_t)batch * rpt),
+               CDML_E_BADARG, "sample_gather_h2: per-step strides too small for the batch");
+  CDML_REQUIRE(pairs && table && idx_out && x_out_planes && n_pairs > 0 && slot0 >= 0, CDML_E_BADARG,
+               "sample_gather_h2: bad argument");
+  CDML_REQUIRE(n_rows >= 3 && n_rows <= 0x7FFFFFFFll, CDML_E_BADARG, "sample_gather_h2: n_rows must be in [3, 2^31)");
+  CDML_REQUIRE(batch >= (mode == 1 ? 2 : 1), CDML_E_BADARG, "sample_gather_h2: batch too small");
+  CDML_REQUIRE(mode == 0 || shift_out, CDML_E_BADARG, "sample_gather_h2: shift_out required in mode 1");
+  CDML_REQUIRE(batch_global >= slot0 + batch, CDML_E_BADARG, "sample_gather_h2: batch_global < slot0 + batch");
+  CDML_REQUIRE(F > 0 && F <= 2048, CDML_E_UNSUPPORTED, "sample_gather_h2: feature size %d outside (0, 2048]", F);
+  CDML_REQUIRE(row_stride >= F && (row_stride & 3) == 0 && out_stride % 2 == 0 && out_stride / 2 >= F &&
+                   ((out_stride / 2) & 3) == 0 && aligned16(table) && (reinterpret_cast<uintptr_t>(x_out_planes) & 7) == 0,
+               CDML_E_ALIGN, "sample_gather_h2: out_stride must be 2 planes of >= F columns (multiples of 4)");
+  const int grid = grid_for((int64_t)batch * rpt * n_steps, RowF32H2<6>::kRows * kWavesPerBlock);
+  const int nch = ((F + 3) / 4 + kWave - 1) / kWave;
+#define CDML_LAUNCH_SGH2(M, N)                                                                             \
+  hipLaunchKernelGGL((k_sample_gather<M, RowF32H2<N>>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, \
+                     pairs, n_pairs, seed, step, step_dev, batch, slot0, batch_global, table,               \
+                     n_rows, row_stride, F, idx_out, shift_out, reinterpret_cast<_Float16 *>(x_out_planes), \
+                     out_stride, n_steps, x_step_stride, idx_step_stride, oob_flag)
+  if (mode == 0) {
+    if (nch <= 6) CDML_LAUNCH_SGH2(0, 6); else CDML_LAUNCH_SGH2(0, 8);
+  } else {
+    if (nch <= 6) CDML_LAUNCH_SGH2(1, 6); else CDML_LAUNCH_SGH2(1, 8);
+  }
+#undef CDML_LAUNCH_SGH2
+  return check_launch("sample_gather_h2");
 }
 
 extern "C" int cdml_route_rows(const int32_t *ids, int n, int64_t rows_per_shard, int world, int capacity,

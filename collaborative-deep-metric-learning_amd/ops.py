@@ -98,8 +98,9 @@ def sample_gather(mode, pairs, seed, step, batch, table, feature_size, idx_out, 
     bg = batch if batch_global is None else batch_global
     f16 = table.dtype == torch.float16              # fp16 catalogue -> bf16 rows (config 4)
     x3 = not f16 and x_out.dtype == torch.bfloat16   # fp32 catalogue -> rows as three bf16 planes (precision f32x3)
+    h2 = not f16 and x_out.dtype == torch.float16    # fp32 catalogue -> rows as two fp16 planes of x_hat * 2^14 (precision f16x2)
     mat = _mat16 if f16 else _mat
-    omat = _mat16 if (f16 or x3) else _mat
+    omat = _mat16 if (f16 or x3 or h2) else _mat
     tp, tld = mat(table)
     if n_steps > 1:
         if x_out.dim() != 3 or idx_out.dim() != 2 or x_out.shape[0] != n_steps or idx_out.shape[0] != n_steps:
@@ -118,7 +119,7 @@ def sample_gather(mode, pairs, seed, step, batch, table, feature_size, idx_out, 
              table.shape[0], tld, feature_size, _p(idx_out, torch.int32), _p(shift_out, torch.int32),
              xp, xld, n_steps, xss, iss, _p(oob_flag, torch.int32), C.c_void_p(x_ki.data_ptr()), kss, _stream())
         return x_out
-    call("cdml_sample_gather_f16" if f16 else "cdml_sample_gather_x3" if x3 else "cdml_sample_gather",
+    call("cdml_sample_gather_f16" if f16 else "cdml_sample_gather_x3" if x3 else "cdml_sample_gather_h2" if h2 else "cdml_sample_gather",
          mode, _p(pairs, torch.int32), pairs.shape[0], seed,
          0 if step is None else step, _p(step_dev, torch.int64), batch, slot0, bg, tp,
          table.shape[0], tld, feature_size, _p(idx_out, torch.int32), _p(shift_out, torch.int32),
@@ -235,13 +236,19 @@ def vnet_tail_workspace_floats(B, D):
 
 
 def vnet_tail(mode, z, rows, shift, B, D, margin, e, pos, neg, hinge, dz2, valid=None, stats=None,
-              dz2_bf16=None, var_ws=None, alpha=LRELU_ALPHA, plane_bf=0):
+              dz2_bf16=None, var_ws=None, alpha=LRELU_ALPHA, plane_bf=0, h2_scale=0.0):
     """l2norm -> hinge loss -> its gradient -> l2norm backward -> lrelu' in one launch
-    (mode 0: rows a,p,n per triplet; 1: in-batch negatives)."""
+    (mode 0: rows a,p,n per triplet; 1: in-batch negatives).  h2_scale > 0: dz2_bf16 receives the two fp16 planes of
+    dz2 * h2_scale (precision f16x2), ``plane_bf`` apart."""
     zp, zld = _mat(z)
     ep, eld = _mat(e)
     dp, dld = _mat(dz2)
     bp, bld = (C.c_void_p(0), 0) if dz2_bf16 is None else _mat16(dz2_bf16)
+    if h2_scale:
+        call("cdml_vnet_tail_h2", mode, zp, zld, _p(rows, torch.int32), _p(shift, torch.int32), B, D, margin, alpha,
+             ep, eld, _p(pos), _p(neg), _p(hinge), _p(valid, torch.uint8), dp, dld, bp, bld, plane_bf, float(h2_scale), _p(stats),
+             _p(var_ws), _stream())
+        return
     if plane_bf:                                     # dz2 also as its three bf16 planes (precision f32x3)
         call("cdml_vnet_tail_planes", mode, zp, zld, _p(rows, torch.int32), _p(shift, torch.int32), B, D, margin, alpha,
              ep, eld, _p(pos), _p(neg), _p(hinge), _p(valid, torch.uint8), dp, dld, bp, bld, plane_bf, _p(stats),
@@ -638,7 +645,7 @@ def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, 
 
 
 def adam_matrix_bf16(W, g, m, v, lr, t, wt=None, wc=None, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, t_dev=None,
-                     bias=None, advance_tickets=None, plane_t=0, plane_c=0):
+                     bias=None, advance_tickets=None, plane_t=0, plane_c=0, h2_scale=0.0):
     """Adam on the contiguous weight matrix W [K, N] (g, m, v alike) that also writes the bf16 operand
     copies: wt = W^T as bf16 [N, >=K], wc = W as bf16 [K, >=N] (either may be None).  ``bias`` =
     (b, gb, mb, vb): the layer's bias vector updated in the same launch; ``advance_tickets``
@@ -652,13 +659,20 @@ def adam_matrix_bf16(W, g, m, v, lr, t, wt=None, wc=None, beta1=0.9, beta2=0.999
     tp, tld = (C.c_void_p(0), 0) if wt is None else _mat16(wt)
     cp, cld = (C.c_void_p(0), 0) if wc is None else _mat16(wc)
     planes = bool(plane_t or plane_c)                # the copies as three bf16 planes (precision f32x3)
-    if wt is not None and (wt.shape[0] < N or wt.shape[1] < (2 * plane_t + K if planes else K)):
+    np1 = 1 if h2_scale else 2                       # (h2_scale: as two fp16 planes of W * h2_scale, precision f16x2)
+    if wt is not None and (wt.shape[0] < N or wt.shape[1] < (np1 * plane_t + K if planes else K)):
         raise ValueError("wt must be at least [N, K] (planes: [N, 2 plane_t + K])")
-    if wc is not None and (wc.shape[0] < K or wc.shape[1] < (2 * plane_c + N if planes else N)):
+    if wc is not None and (wc.shape[0] < K or wc.shape[1] < (np1 * plane_c + N if planes else N)):
         raise ValueError("wc must be at least [K, N] (planes: [K, 2 plane_c + N])")
     b = bias if bias is not None else (None, None, None, None)
     if bias is not None and any(x.numel() != b[0].numel() or not x.is_contiguous() for x in b):
         raise ValueError("bias, its gradient and its moments must be contiguous vectors of one size")
+    if h2_scale:
+        call("cdml_adam_matrix_h2", _p(W), _p(g), _p(m), _p(v), K, N, lr, _p(lr_dev), beta1, beta2, eps,
+             0 if t is None else t, _p(t_dev, torch.int64), tp, tld, plane_t, cp, cld, plane_c, float(h2_scale), _p(b[0]), _p(b[1]),
+             _p(b[2]), _p(b[3]), 0 if bias is None else b[0].numel(), 0 if advance_tickets is None else 1,
+             _p(advance_tickets, torch.int32), _stream())
+        return
     if planes:
         call("cdml_adam_matrix_planes", _p(W), _p(g), _p(m), _p(v), K, N, lr, _p(lr_dev), beta1, beta2, eps,
              0 if t is None else t, _p(t_dev, torch.int64), tp, tld, plane_t, cp, cld, plane_c, _p(b[0]), _p(b[1]),

@@ -20,7 +20,7 @@ import time
 
 import torch
 
-from . import engine, engine_bf16, engine_x3, ops
+from . import engine, engine_bf16, engine_f16x2, engine_x3, ops
 from .inputs import MODE_INBATCH, MODE_UNIFORM
 
 # sampler mode per negative policy: "semihard" samples like "inbatch" (rows a_i, p_i)
@@ -54,7 +54,10 @@ class TrainStep:
         shard; build-defined -- the reference keeps the features frozen, train.py:265).
         ``precision``: "auto" (default) = "bf16" for an fp16 catalogue (BASELINE config 4), else "f32x3" -- fp32 operands as
         three exact bf16 planes, six plane products per fp32 product on the bf16 MFMA, held to the fp32 path's bounds; what
-        bench.py times -- when the step's rows are a multiple of 128, else "f32" (the fp32 MFMA).
+        bench.py times -- when the step's rows are a multiple of 128, else "f32" (the fp32 MFMA).  "f16x2" (never chosen by
+        "auto"): fp32 operands as TWO fp16 planes under per-tensor power-of-two scales, three plane products on the fp16 MFMA
+        -- half of "f32x3"'s matrix work at the same error bound, an fp32 equivalent while its delayed scales hold
+        (engine_f16x2.py); one GPU, eager, Adam, frozen catalogue.
         ``use_graph``: False = eager; True = the whole step replayed from ONE hipGraph (single GPU: the
         fast form; data-parallel: the exchange of step t+1 is then recorded on the capturing stream,
         ahead of the forward pass, not under it); "split" (data-parallel with the prefetcher) = three
@@ -126,16 +129,25 @@ class TrainStep:
                 precision = "bf16"
             else:
                 precision = "f32x3" if (self.B * self.rows_per_triplet) % 128 == 0 else "f32"
-        if precision not in ("f32", "bf16", "f32x3", "f32x3-3"):
-            raise ValueError("precision must be 'auto', 'f32', 'f32x3' or 'bf16'")
+        if precision not in ("f32", "bf16", "f32x3", "f32x3-3", "f16x2"):
+            raise ValueError("precision must be 'auto', 'f32', 'f32x3', 'f16x2' or 'bf16'")
         self.precision = precision
         self.bf16 = precision == "bf16"          # BASELINE config 4: fp16 table + bf16 MFMA
         # fp32 products on the bf16 MFMA: operands as three exact bf16 planes, six plane products (engine_x3;
         # "f32x3-3": the three leading products only -- 16-bit operands, not an fp32 equivalent)
         self.x3 = precision.startswith("f32x3")
+        # fp32 products on the fp16 MFMA: operands as two fp16 planes under per-tensor scales, three plane products (engine_f16x2)
+        self.h2 = precision == "f16x2"
         if self.bf16 != (table.data.dtype == torch.float16):
             raise ValueError("precision 'bf16' goes with an fp16 FeatureTableF16, 'f32' / 'f32x3' with an fp32 table")
-        if self.x3:
+        if self.h2:
+            if exchange is not None or grad_sync is not None or use_graph or train_table or optimizer != "adam":
+                raise ValueError("precision 'f16x2' is the single-GPU eager step with Adam and a frozen catalogue (its plane scales "
+                                 "are host-side kernel arguments that move during training: engine_f16x2.py)")
+            self.layout = engine_x3.layout_x3(F, hidden_size, output_size)
+            self.params = engine.VNetParams(self.layout, self.device, weight_seed)
+            self.ws = engine_f16x2.TowerWorkspaceH2(self.layout, self.R, self.device, planes_in=True)
+        elif self.x3:
             self.layout = engine_x3.layout_x3(F, hidden_size, output_size)
             self.params = engine.VNetParams(self.layout, self.device, weight_seed)
             self.ws = engine_x3.TowerWorkspaceX3(self.layout, self.R, self.device, products=3 if precision.endswith("-3") else 6,
@@ -420,7 +432,9 @@ class TrainStep:
         # (semi-hard mining on the plane kernels: the miner's prep launch normalises z itself -- round 6)
         mine_norm = (self.mode == "semihard" and getattr(self, "mine_fused", False)
                      and os.environ.get("CDML_MINE_NORM", "1") != "0")
-        if self.x3:
+        if self.h2:
+            engine_f16x2.tower_forward(self.params, self.ws, normalize=not fused)
+        elif self.x3:
             engine_x3.tower_forward(self.params, self.ws, normalize=not (fused or mine_norm))
         elif self.bf16:
             engine_bf16.tower_forward(self.params, self.ws, normalize=not fused)
@@ -431,10 +445,10 @@ class TrainStep:
             ops.vnet_tail(0 if self.mode == "uniform" else 1, self.ws.z, self.idx, self.shift, self.B, L.Dp,
                           self.margin, self.ws.e, self.pos, self.neg, self.hinge, self.ws.dz2, valid=self.valid,
                           stats=self.stats, var_ws=self.var_ws,
-                          dz2_bf16=self.ws.dz2_bf if self.bf16 else self.ws.dz2_3 if self.x3 else None,
-                          plane_bf=L.Dp if self.x3 else 0)
+                          dz2_bf16=self.ws.dz2_bf if self.bf16 else self.ws.dz2_3 if self.x3 else self.ws.dz2_2 if self.h2 else None,
+                          plane_bf=L.Dp if (self.x3 or self.h2) else 0, h2_scale=self.ws.scales.dz2 if self.h2 else 0.0)
             self.ws.tail_done = True
-            self.ws.dz2_planes_done = self.x3
+            self.ws.dz2_planes_done = self.x3 or self.h2
             return
         de = self.ws.de if with_grad else None
         if self.mode == "uniform":
@@ -467,7 +481,9 @@ class TrainStep:
                                       self.pos, self.neg, self.hinge, self.valid, self.stats, de)
 
     def backward(self, after_w1=None):
-        if self.x3:
+        if self.h2:
+            engine_f16x2.tower_backward(self.params, self.ws, after_w1=after_w1)
+        elif self.x3:
             engine_x3.tower_backward(self.params, self.ws, after_w1=after_w1)
         elif self.bf16:
             engine_bf16.tower_backward(self.params, self.ws, after_w1=after_w1)
@@ -530,7 +546,21 @@ class TrainStep:
             for i, (off, n) in enumerate(p.segments()):    # W1, b1, W2, b2: weights carry the regulariser
                 ops.grad_prepare(p.grad[off:off + n], p.flat[off:off + n], self.reg_scale if i % 2 == 0 else 0.0,
                                  self.clip_gradient_norm, self.lars_scratch, self.grad_norms[i])
-        if self.optimizer == "adam" and self.x3:
+        if self.optimizer == "adam" and self.h2:
+            # two fp16 planes: the same two launches, the copies written as the planes of W * its scale (the scales as of
+            # this step: engine_f16x2.observe_weights re-splits the weights itself when it moves one)
+            L, o, ws = self.layout, self.layout.offsets, self.ws
+            mat = lambda t, i, r, c: t[o[i]:o[i] + r * c].view(r, c)
+            kw = dict(lr_dev=self.lr_dev, t_dev=self.step_dev)
+            b1, b2 = slice(o[1], o[1] + L.Hp), slice(o[3], o[3] + L.Dp)
+            vec = lambda sl: (p.flat[sl], p.grad[sl], self.m[sl], self.v[sl])
+            ops.adam_matrix_bf16(p.W1, mat(p.grad, 0, L.Fp, L.Hp), mat(self.m, 0, L.Fp, L.Hp),
+                                 mat(self.v, 0, L.Fp, L.Hp), 0.0, 1, wt=ws.W1T, plane_t=L.Fp, bias=vec(b1),
+                                 h2_scale=ws.scales.w1, **kw)
+            ops.adam_matrix_bf16(p.W2, mat(p.grad, 2, L.Hp, L.Dp), mat(self.m, 2, L.Hp, L.Dp),
+                                 mat(self.v, 2, L.Hp, L.Dp), 0.0, 1, wt=ws.W2T, plane_t=L.Hp, wc=ws.W2, plane_c=L.Dp,
+                                 bias=vec(b2), advance_tickets=self.adam_tickets, h2_scale=ws.scales.w2, **kw)
+        elif self.optimizer == "adam" and self.x3:
             # split-fp32 precision: as on the config-4 path two launches, each weight matrix with its bias vector;
             # the update writes the plane copies the GEMMs read (W1^T; W2^T and W2)
             L, o, ws = self.layout, self.layout.offsets, self.ws
@@ -605,7 +635,15 @@ class TrainStep:
             t, b = self.global_step, self.global_step % 2
             self.prefetch.launch(1 - b, lambda: self._fill(1 - b, t + 1))
             self._filled = t + 1
+        # precision f16x2: on its check steps (0, 1, 2, 4 .. 64, then every 64th) the plane scales are re-derived -- the weights'
+        # and the hidden layer's before the forward pass, the gradients' once the loss tail has written dz2 (two small
+        # device-to-host copies; engine_f16x2.PlaneScales)
+        due = self.h2 and self.ws.scales.due(self.global_step)
+        if due:
+            engine_f16x2.observe_weights(self.params, self.ws)
         self.forward_loss()
+        if due:
+            engine_f16x2.observe_gradients(self.params, self.ws)
         self._backward_and_update(b if self.prefetch is not None else None)
 
     def _backward_and_update(self, b):
@@ -835,6 +873,8 @@ class TrainStep:
             self.tab_v.copy_(state["table"]["v"].to(self.device))
         if self.bf16:                                    # the GEMMs read the bf16 copies, not the masters
             engine_bf16.refresh_weights(self.params, self.ws)
+        if self.h2:
+            self.ws.scales.calibrated = False            # the next step re-derives every scale from the loaded weights
         if self.x3:
             engine_x3.refresh_weights(self.params, self.ws)
         self.global_step = int(state["global_step"])

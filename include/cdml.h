@@ -546,6 +546,31 @@ int cdml_gemm_f16x2_tn(const uint16_t *A, int64_t lda, int64_t plane_a, const ui
                        int64_t plane_b, int M, int N, int K, float *C, int64_t ldc, float out_scale, float *colsum,
                        float colsum_scale, void *workspace, size_t workspace_bytes, cdml_stream_t stream);
 
+/* The producers of "f16x2" plane tensors other than the GEMM epilogues: the fused sampler + gather (inputs.py:125-158)
+ * writing each l2-normalised row as the two fp16 planes of x_hat * CDML_F16X2_X_SCALE (|x_hat| <= 1: a constant of the
+ * format; out_stride = 2 planes of out_stride / 2 >= F columns); cdml_vnet_tail writing dz2's planes times `scale`
+ * (dz2_planes fp16 [rows][ldbf], ldbf >= plane_h + D); cdml_adam_matrix_bf16 writing the weight copies as the planes of
+ * W * scale (wt = W^T [N][hi K | lo K], wc = W [K][hi N | lo N]).  A value beyond fp16's range saturates at +-65504. */
+#define CDML_F16X2_X_SCALE 16384.0f
+int cdml_sample_gather_h2(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
+                          uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
+                          int64_t batch_global, const float *table, int64_t n_rows,
+                          int64_t row_stride, int F, int32_t *idx_out, int32_t *shift_out,
+                          uint16_t *x_out_planes, int64_t out_stride, int n_steps, int64_t x_step_stride,
+                          int64_t idx_step_stride, int32_t *oob_flag, cdml_stream_t stream);
+int cdml_vnet_tail_h2(int mode, const float *z, int64_t ldz, const int32_t *rows,
+                      const int32_t *shift, int B, int D, float margin, float lrelu_alpha,
+                      float *e, int64_t lde, float *pos, float *neg, float *hinge,
+                      uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_planes,
+                      int64_t ldbf, int64_t plane_h, float scale, float *stats, float *var_ws,
+                      cdml_stream_t stream);
+int cdml_adam_matrix_h2(float *w, const float *g, float *m, float *v, int K, int N, float lr,
+                        const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
+                        uint64_t *t_dev, uint16_t *wt_planes, int64_t ldt, int64_t plane_t,
+                        uint16_t *wc_planes, int64_t ldc, int64_t plane_c, float scale, float *bias_w,
+                        const float *bias_g, float *bias_m, float *bias_v, int bias_n,
+                        int advance_step, uint32_t *tickets, cdml_stream_t stream);
+
 /* dst[c][r] = bf16(src[r][c]) (src fp32 or bf16): k-contiguous copies of weights
  * and of activations for the weight-gradient GEMMs (contraction over batch rows). */
 int cdml_transpose_to_bf16(int src_is_f32, const void *src, int64_t ld_src,

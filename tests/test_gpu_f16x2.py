@@ -4,10 +4,12 @@ precision "f32x3" was admitted under (tests/test_gpu_f32x3.py): erro
 kernel's on the same operands.  Reference lines: models.py:59-61, train.py:141."""
 import math
 
+import numpy as np
 import pytest
 import torch
 
-from cdml_amd import ops
+from cdml_amd import engine, engine_f16x2, engine_x3, ops, train
+from oracle import sampler as osampler, synth as osynth, tower as otower
 
 pytestmark = pytest.mark.gpu
 
@@ -152,3 +154,160 @@ def test_ragged_rows_and_small_shapes():
         cp = torch.zeros(M, 2 * N, dtype=torch.float16, device=dev)
         ops.gemm_f16x2_nt(ops.BE_BIAS_LRELU_X3, A2, K, B2, K, cp, M, N, K, 1.0 / (sa * sb), c_scale=sc, plane_c=N, bias=bias, alpha=0.2)
         assert (_value(cp, N, sc) - refl).abs().max().item() <= 2e-6 * refl.abs().max().item(), (M, N, K)
+
+
+def test_plane_writers_of_the_step_agree_with_the_split_kernel():
+    """The fused sampler + gather, the loss tail and the Adam launch write their fp16 planes themselves: bit for bit what
+    cdml_split_f32_f16x2 makes of the fp32 tensor the fp32 form of the same kernel writes (inputs.py:125-158, train.py:141,
+    train.py:146)."""
+    torch.manual_seed(5)
+    dev = _dev()
+    N, F, B = 3000, 1500, 128
+    table = engine.FeatureTable.synthetic(N, F, 0, dev)
+    pairs = torch.as_tensor(osynth.cowatch_pairs(N, 700, 0), dtype=torch.int32, device=dev)
+    Fp = 1536
+    for mode, rows in ((0, 3 * B), (1, 2 * B)):
+        idx_a, idx_b = torch.zeros(rows, dtype=torch.int32, device=dev), torch.zeros(rows, dtype=torch.int32, device=dev)
+        sh_a, sh_b = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        xf = torch.zeros(rows, Fp, device=dev)
+        xh = torch.full((rows, 2 * Fp), 7.0, dtype=torch.float16, device=dev)
+        ops.sample_gather(mode, pairs, 99, 5, B, table.data, F, idx_a, xf, shift_out=sh_a)
+        ops.sample_gather(mode, pairs, 99, 5, B, table.data, F, idx_b, xh, shift_out=sh_b)
+        assert torch.equal(idx_a, idx_b) and torch.equal(sh_a, sh_b)
+        want = _planes(xf, Fp, engine_f16x2.X_SCALE)
+        assert torch.equal(xh.view(torch.int16), want.view(torch.int16)), mode
+    # the loss tail
+    D = 256
+    z = torch.randn(3 * B, D, device=dev)
+    outs = []
+    for h2 in (0.0, 2.0 ** 20):
+        e, dz2 = torch.zeros(3 * B, D, device=dev), torch.zeros(3 * B, D, device=dev)
+        pos, neg, hinge = (torch.zeros(B, device=dev) for _ in range(3))
+        pl = torch.zeros(3 * B, 2 * D, dtype=torch.float16, device=dev) if h2 else None
+        ops.vnet_tail(0, z, None, None, B, D, 0.8, e, pos, neg, hinge, dz2, dz2_bf16=pl, plane_bf=D if h2 else 0, h2_scale=h2)
+        outs.append((e, dz2, hinge, pl))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.equal(outs[1][3].view(torch.int16), _planes(outs[1][1], D, 2.0 ** 20).view(torch.int16))
+    # Adam
+    K, N2 = 256, 512
+    W0, g = torch.randn(K, N2, device=dev) * 0.05, torch.randn(K, N2, device=dev) * 1e-3
+    res = []
+    for h2 in (0.0, 2.0 ** 15):
+        W, m, v = W0.clone(), torch.zeros(K, N2, device=dev), torch.zeros(K, N2, device=dev)
+        wt = torch.zeros(N2, 2 * K, dtype=torch.float16 if h2 else torch.bfloat16, device=dev)
+        wc = torch.zeros(K, 2 * N2, dtype=torch.float16 if h2 else torch.bfloat16, device=dev)
+        if h2:
+            ops.adam_matrix_bf16(W, g, m, v, 0.01, 1, wt=wt, wc=wc, plane_t=K, plane_c=N2, h2_scale=h2)
+        else:
+            ops.adam_matrix_bf16(W, g, m, v, 0.01, 1, wt=wt[:, :K], wc=wc[:, :N2])
+        res.append((W, m, v, wt, wc))
+    assert all(torch.equal(a, b) for a, b in zip(res[0][:3], res[1][:3]))
+    assert torch.equal(res[1][3].view(torch.int16), _planes(res[1][0], K, 2.0 ** 15, transpose=True).view(torch.int16))
+    assert torch.equal(res[1][4].view(torch.int16), _planes(res[1][0], N2, 2.0 ** 15).view(torch.int16))
+
+
+def test_training_holds_the_six_plane_paths_bounds_while_the_scales_move():
+    """A training run at production widths (F = 1500, H = 5000, D = 256; B = 1024, in-batch negatives, Adam at the reference's
+    learning rate) on precision "f16x2".  At steps on both sides of the scale checks the step is ALSO taken on precision "f32x3"
+    from the run's own weights, optimizer slots and batch, and both are held against the fp64 oracle's step from those weights:
+    loss and embeddings to 1e-5, and the f16x2 gradients' error (relative L2) at most 1.5 x the six-plane path's + 1e-6 -- the
+    largest single element's at most 3 x: off the first steps the error of EITHER path is dominated by the few leaky-relu'
+    signs it takes differently from fp64 where a pre-activation is rounding noise, and its maximum over a tensor moves by a
+    factor of two from one summation order to another.  Nothing saturates; the scales move a few times, not every step
+    (models.py:59-61, train.py:141-146)."""
+    dev = _dev()
+    N, F, B, D = 20000, 1500, 1024, 256
+    feats = osynth.features_numpy(N, F, seed=0).astype(np.float32)
+    f64 = feats.astype(np.float64)
+    pairs_np = osynth.cowatch_pairs(N, 6000, 0)
+    table = engine.FeatureTable.from_numpy(feats, dev)
+    pairs = torch.as_tensor(pairs_np, dtype=torch.int32, device=dev)
+    kw = dict(margin=0.8, mode="inbatch", optimizer="adam", base_learning_rate=0.01, device=dev, gather_ahead=1)
+    a = train.TrainStep(table, pairs, B, precision="f16x2", **kw)
+    b = train.TrainStep(table, pairs, B, precision="f32x3", **kw)
+    checks = (0, 1, 3, 33, 65)
+    names = ("dW1", "db1", "dW2", "db2")
+    host = lambda ts_: [t.detach().cpu().numpy().copy() for t in ts_]
+    worst = {}
+    for t in range(max(checks) + 1):
+        if t in checks:
+            W = host(a.params.unpadded())
+            b.params.flat.copy_(a.params.flat)
+            b.m.copy_(a.m)
+            b.v.copy_(a.v)
+            engine_x3.refresh_weights(b.params, b.ws)
+            b.global_step = t
+            b.step_dev.fill_(t)
+            b.step()
+            Gb, lb, eb = host(b.params.unpadded(grads=True)), b.loss(), b.ws.e[:, :D].cpu().numpy()
+        a.step()
+        if t in checks:
+            assert torch.equal(a.idx, b.idx)
+            rows, tri, valid, _ = osampler.device_inbatch(pairs_np, 1234, t, B)
+            W64 = [w.astype(np.float64) for w in W]
+            fwd = otower.vnet_forward(f64[rows], *W64, dtype=np.float64)
+            loss = float(otower.hinge_loss_indexed(fwd["l2_norm"], tri, valid.astype(bool), 0.8, np.float64)["hinge_loss"])
+            dE = otower.hinge_loss_indexed_backward(fwd["l2_norm"], tri, valid.astype(bool), 0.8, np.float64)
+            wg = otower.vnet_backward(fwd, W64[2], dE, np.float64)
+            Ga, la, ea = host(a.params.unpadded(grads=True)), a.loss(), a.ws.e[:, :D].cpu().numpy()
+            assert abs(la - loss) < 1e-5 and abs(lb - loss) < 1e-5, (t, la, lb, loss)
+            assert np.abs(ea - fwd["l2_norm"]).max() < 1e-5 and np.abs(eb - fwd["l2_norm"]).max() < 1e-5, t
+            for k, ga, gb in zip(names, Ga, Gb):
+                size, nrm = np.abs(wg[k]).max(), np.linalg.norm(wg[k])
+                ea_, eb_ = np.linalg.norm(ga - wg[k]) / nrm, np.linalg.norm(gb - wg[k]) / nrm
+                ma_, mb_ = np.abs(ga - wg[k]).max() / size, np.abs(gb - wg[k]).max() / size
+                worst[(t, k)] = (float(ea_), float(eb_), float(ma_), float(mb_))
+                assert ea_ <= 1.5 * eb_ + 1e-6 and ma_ <= 3.0 * mb_ + 1e-6, (t, k, worst[(t, k)], a.ws.scales.state())
+            hi = a.ws.h1[:, :a.layout.Hp].float().abs().max().item()
+            hg = a.ws.dz1[:, :a.layout.Hp].float().abs().max().item()
+            assert 16.0 <= hi < 65504.0 and 16.0 <= hg < 65504.0, (t, hi, hg, a.ws.scales.state())
+    print("gradient error against the fp64 oracle (relative L2 f16x2, f32x3; max / max |g| f16x2, f32x3):",
+          {k: tuple("%.1e" % x for x in v) for k, v in worst.items()}, "scale moves:", a.ws.scales.changes, a.ws.scales.state())
+    assert a.ws.scales.changes <= 12
+    assert int(a.step_dev.item()) == max(checks) + 1 and math.isfinite(a.loss())
+
+
+def test_resident_plane_walk_equals_the_general_loop(monkeypatch):
+    """The three-product resident-plane walk (R3: every plane image of a K-tile staged once, a hand-counted DMA schedule --
+    replayed on the CPU by tests/test_r6_schedule.py) against the general K loop of the same kernel (CDML_X3_WALK=general, read
+    per call) on the same operands: the same products in another order inside one fp32 accumulator -- equal to accumulation
+    noise -- in the k-contiguous form (fp32 and plane outputs, ragged rows), the K-slab form and the k-strided form with its
+    column sums."""
+    torch.manual_seed(11)
+    dev = _dev()
+
+    def both(fn):
+        monkeypatch.setenv("CDML_X3_WALK", "general")
+        a = fn()
+        monkeypatch.delenv("CDML_X3_WALK")
+        b = fn()
+        return a, b
+    for (M, N, K) in ((1000, 512, 384), (4096, 1024, 1536), (2048, 256, 5120)):
+        A, B = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) * 0.1
+        sa, sb = _scale(A), _scale(B)
+        A2, B2 = _planes(A, K, sa), _planes(B, K, sb)
+        ws = _ws(False, M, N, K)
+
+        def nt():
+            c = torch.zeros(M, N, device=dev)
+            ops.gemm_f16x2_nt(ops.BE_F32, A2, K, B2, K, c, M, N, K, 1.0 / (sa * sb), workspace=ws)
+            return c
+        g, r = both(nt)
+        assert (g - r).abs().max().item() <= 4e-7 * g.abs().max().item(), (M, N, K)
+        assert not torch.equal(g, r) or K <= 384                   # (another order: it IS another kernel path)
+    R, F, H = 2048, 512, 768
+    x, dz = torch.randn(R, F, device=dev), torch.randn(R, H, device=dev) * 1e-3
+    sx, sd = _scale(x), _scale(dz)
+    x2, d2 = _planes(x, F, sx), _planes(dz, H, sd)
+    ws = _ws(True, F, H, R)
+
+    def tn():
+        c, db = torch.zeros(F, H, device=dev), torch.zeros(H, device=dev)
+        ops.gemm_f16x2_tn(x2, F, d2, H, c, F, H, R, 1.0 / (sx * sd), workspace=ws, colsum=db, colsum_scale=1.0 / sd)
+        return torch.cat([c.flatten(), db])
+    g, r = both(tn)
+    assert (g[:F * H] - r[:F * H]).abs().max().item() <= 4e-7 * g[:F * H].abs().max().item()
+    assert (g[F * H:] - r[F * H:]).abs().max().item() <= 4e-7 * g[F * H:].abs().max().item()
+    ref = x.double().t() @ dz.double()
+    assert (r[:F * H].view(F, H).double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    assert (r[F * H:].double() - dz.double().sum(0)).abs().max().item() <= 2e-6 * dz.double().sum(0).abs().max().item()

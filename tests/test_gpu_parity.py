@@ -730,7 +730,7 @@ def _oracle_step(feats, pairs, W, step, B, mode, seed, margin=0.8):
     return fwd["l2_norm"], float(loss["hinge_loss"]), grads
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+@pytest.mark.parametrize("precision", ["f32", "f32x3", "f16x2"])
 @pytest.mark.parametrize("mode,optimizer", [("uniform", "adam"), ("inbatch", "adam"),
                                             ("uniform", "lars")])
 def test_train_steps_config0(cd, mode, optimizer, precision):
@@ -740,12 +740,15 @@ def test_train_steps_config0(cd, mode, optimizer, precision):
     differences, so free-running fp32 and fp64 trajectories are not comparable):
     embeddings / loss / gradients against the fp64 oracle, and the optimizer
     against the oracle's update applied to the device's gradients and slots."""
+    if precision == "f16x2" and optimizer != "adam":
+        pytest.skip("precision f16x2 is built with Adam only")
     N, F, B, D = 10000, 1500, 128, 256
     feats = osynth.features_numpy(N, F, seed=0).astype(np.float32)
     pairs = osynth.cowatch_pairs(N, 3000, 0)
     table = cd.engine.FeatureTable.from_numpy(feats, cd.dev)
     lr = 0.01 if optimizer == "adam" else 1.0
-    # (precision "f32x3": the same products from three bf16 planes per operand on the bf16 MFMA -- same bounds)
+    # (precision "f32x3": the same products from three bf16 planes per operand on the bf16 MFMA -- same bounds; "f16x2": from
+    # two fp16 planes under per-tensor scales on the fp16 MFMA -- same bounds)
     ts = cd.train.TrainStep(table, dt(pairs, cd.dev, torch.int32), B, margin=0.8, mode=mode,
                             optimizer=optimizer, base_learning_rate=lr, device=cd.dev, precision=precision)
     f64 = feats.astype(np.float64)

@@ -152,3 +152,76 @@ def test_half_tile_schedule_hazards():
     for tt, key, tag in seq:
         assert not [T for T, k, _ in reads if k == key and T == tt], "WAR: %s overwritten in the step that still reads it (%d)" % (key, tt)
     # (the in-order issue sequence inside a step is the source order: the vmcnt table counts on it)
+
+
+def _r3_schedule(sch):
+    i = SRC.index("auto phase3 = [&](auto phc, auto parc")
+    body = SRC[i:SRC.index("auto period3 = [&]", i)]
+    pa, pb = _ints(r"constexpr int PA3\[3\]", body)[:3], _ints(r"PB3\[3\]", body)[:3]
+    sa = [int(x) for x in re.findall(r"\d+", re.search(r"SLOT_A3\[2\]\[2\]\s*=\s*\{(.*?)\}\};", body).group(1))]
+    assert len(sa) == 4
+    slot_a = [sa[:2], sa[2:4]]
+    vm_all = [int(x) for x in re.findall(r"\d+", re.search(r"constexpr int VM3\[2\]\[6\]\s*=\s*\{(.*?)\}\};", body).group(1))]
+    assert len(vm_all) == 12
+    vm = vm_all[6 * sch:6 * sch + 6]
+    rdb_steps = [int(x) for x in re.findall(r"S == (\d)", re.search(r"constexpr bool rdB = HALF == 0 && \((.+?)\);", body).group(1))]
+    assert re.search(r"constexpr int sb = PB3\[S\];", body), "plane p of B lives in B slot p"
+    issue = {ph: [] for ph in range(6)}
+    for m in re.finditer(r"if constexpr \(SCH == (\d) && PH == (\d)\) \{(.*?)\}\n", body):
+        if int(m.group(1)) == sch:
+            issue[int(m.group(2))] = [(int(a), int(b), int(c), d.strip(), e[-1] == "n") for a, b, c, d, e in
+                                      re.findall(r"issue\((\d), (\d), (\d), ([^,]+), (kw[ab]_[cn])\);", m.group(3))]
+    j = SRC.index("// R3 prologue: the steady state at phase 0 of the first K-tile")
+    seg = SRC[j:SRC.index("CDML_BARRIER();", j)]
+    pro = [(int(a), int(b), int(c), int(d)) for a, b, c, d in re.findall(r"issue\((\d), (\d), (\d), (\d), k[ab]3\);", seg)]
+    pro_vm = int(re.search(r"vmcnt\((\d+)\)", seg).group(1))
+    return pa, pb, slot_a, vm, issue, rdb_steps, pro, pro_vm
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("sch", [0, 1])
+def test_r3_schedule_hazards(sch):
+    """The three-product period of the two-plane fp16 form (gemm_f16x2_256.hip compiles the same source): 8 half images in 6
+    phases -- content, RAW and WAR replayed from the source like the six-product walk's, for both placements of the loads the
+    source holds (0: the k-strided kernel's, 1: the k-contiguous kernels')."""
+    PA, PB, SLOT_A, VM, ISSUE, RDB, PRO, PRO_VM = _r3_schedule(sch)
+    assert sorted(zip(PA, PB)) == sorted([(0, 0), (1, 0), (0, 1)]), "hi.hi, lo.hi, hi.lo"
+    assert RDB == [0, 2]
+    n_per = 7
+    seq = []                                                        # (time, (operand, slot, half), content) in issue order
+    for n, (img, pl, hh, slot) in enumerate(PRO):
+        seq.append((n - len(PRO), (img, slot, hh), (img, pl, hh, 0)))
+    for w in range(n_per):
+        PAR = w & 1
+        for ph in range(6):
+            for img, pl, hh, slot_expr, nxt in ISSUE[ph]:
+                slot = eval(slot_expr, {"SLOT_A3": SLOT_A, "PAR": PAR})
+                assert (img == 0 and 0 <= slot <= 2) or (img == 1 and 0 <= slot <= 1), "three A slots, two B slots: 160 KiB"
+                seq.append((w * 6 + ph, (img, slot, hh), (img, pl, hh, w + (1 if nxt else 0))))
+    assert len(seq) == len(PRO) + 8 * n_per, "eight half images per K-tile: every plane image once"
+    reads = []
+    for w in range(n_per):
+        PAR = w & 1
+        for ph in range(6):
+            S, HALF = ph >> 1, ph & 1
+            reads.append((w * 6 + ph, (0, SLOT_A[PAR][PA[S]], HALF), (0, PA[S], HALF, w)))
+            if HALF == 0 and S in RDB:
+                reads += [(w * 6 + ph, (1, PB[S], hh), (1, PB[S], hh, w)) for hh in (0, 1)]
+
+    def landed_by(idx):
+        for T in range(-1, n_per * 6):
+            issued = sum(1 for tt, _, _ in seq if tt <= T)
+            in_flight = (PRO_VM if T == -1 else VM[T % 6]) // 2    # half images allowed to stay in flight (two pieces each)
+            if idx < issued - in_flight:
+                return T
+        return None
+
+    for T, key, want in reads:
+        last = [(i, tt, tag) for i, (tt, k, tag) in enumerate(seq) if k == key and tt < T][-1]
+        assert last[2] == want, "phase %d reads %s: the slot holds %s, not %s" % (T, key, last[2], want)
+        lt = landed_by(last[0])
+        assert lt is not None and lt <= T - 1, "RAW: %s read at phase %d, guaranteed landed only by the wait of phase %s" % (want, T, lt)
+    for tt, key, tag in seq:
+        assert not [T for T, k, _ in reads if k == key and T == tt], "WAR: %s overwritten in the phase that still reads it (%d)" % (key, tt)
