@@ -1090,7 +1090,7 @@ def rec_predict(dev, precision, n_rows=10000000, chunk=100000, reps=2):
     Table = engine_bf16.FeatureTableF16 if bf16 else engine.FeatureTable
     table = Table.synthetic(n_rows, F, seed=0, device=dev)
     from cdml_amd import engine_x3
-    L = (engine_bf16.layout_bf16 if bf16 else engine_x3.layout_x3 if precision == "f32x3" else engine.TowerLayout)(F, H, D)
+    L = (engine_bf16.layout_bf16 if bf16 else engine_x3.layout_x3 if precision in ("f32x3", "f16x2") else engine.TowerLayout)(F, H, D)
     pr = predict.Prediction(params=engine.VNetParams(L, dev, 42), precision=precision)
     out = torch.empty((n_rows, D), dtype=torch.float32, device=dev)
     pr.embed_table(table, chunk, out=out)
@@ -1102,13 +1102,16 @@ def rec_predict(dev, precision, n_rows=10000000, chunk=100000, reps=2):
     el = (time.perf_counter() - t0) / reps
     nrm = float((out[::9973].norm(dim=1) - 1).abs().max())
     flops = n_rows * (2.0 * F * H + 2.0 * H * D)
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if precision == "f32x3" else PEAK_F32_MFMA_TFLOPS
+    peak = (PEAK_BF16_MFMA_TFLOPS if bf16 else round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if precision == "f32x3"
+            else round(PEAK_BF16_MFMA_TFLOPS / 3, 1) if precision == "f16x2" else PEAK_F32_MFMA_TFLOPS)
     return {"workload": "catalogue inference: %d videos x 1500-d %s in HBM -> 256-d unit-norm embeddings in HBM, "
                         "%d-row chunks (l2norm + FC1 + FC2 + l2norm)" % (n_rows, "fp16" if bf16 else "fp32", chunk),
             "value": round(n_rows / el, 1), "unit": "rows/s", "seconds": round(el, 4), "passes_timed": reps,
             "tower_tflops": round(flops / el / 1e12, 2), "frac_of_mfma_peak": round(flops / el / 1e12 / peak, 4),
             "max_abs_norm_error": nrm,
-            "dtype": ("bf16 (fp16 table, f32 accumulate)" if bf16 else "f32" if precision != "f32x3" else
+            "dtype": ("bf16 (fp16 table, f32 accumulate)" if bf16 else
+                      "f32 values as 2 fp16 planes under per-tensor scales, 3 plane products on the fp16 MFMA (peak = fp16 dense peak / 3)"
+                      if precision == "f16x2" else "f32" if precision != "f32x3" else
                       "f32 values as 3 exact bf16 planes, 6 plane products on the bf16 MFMA (peak = bf16 dense peak / 6)")}
 
 
@@ -1549,7 +1552,7 @@ def main():
             attempt("fusion_resnet", lambda: rec_fusion(dev, args, n_s, n_w))
             attempt("config4_per_gpu", lambda: rec_config4(dev, args, n_s, n_w))
             attempt("predict", lambda: {"f32": rec_predict(dev, "f32"), "f32x3": rec_predict(dev, "f32x3"),
-                                        "bf16": rec_predict(dev, "bf16")})
+                                        "f16x2": rec_predict(dev, "f16x2"), "bf16": rec_predict(dev, "bf16")})
             attempt("knn", lambda: rec_knn(dev))
         if world == 1 and not args.no_cpu_baseline:
             set_phase("cpu_baseline")

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from . import engine, engine_bf16, engine_x3, ops
+from . import engine, engine_bf16, engine_f16x2, engine_x3, ops
 
 
 class Prediction():
@@ -25,14 +25,16 @@ class Prediction():
             if ckpt is None or not os.path.exists(ckpt):
                 raise IOError("Prediction __init__ Cannot find %s" % ckpt)      # predict.py:54-55
             state = torch.load(ckpt, map_location="cpu")
-            mk = (engine_bf16.layout_bf16 if precision == "bf16" else engine_x3.layout_x3 if precision == "f32x3"
+            mk = (engine_bf16.layout_bf16 if precision == "bf16" else engine_x3.layout_x3 if precision in ("f32x3", "f16x2")
                   else engine.TowerLayout)
             layout = mk(*state["layout"])
             params = engine.VNetParams(layout, device)
             params.load(*[state["variables"][n] for n in engine.VNetParams.NAMES])
-        if precision not in ("f32", "bf16", "f32x3"):
-            raise ValueError("precision must be 'f32', 'f32x3' or 'bf16'")
-        if precision == "f32x3":
+        if precision not in ("f32", "bf16", "f32x3", "f16x2"):
+            raise ValueError("precision must be 'f32', 'f32x3', 'f16x2' or 'bf16'")
+        if precision in ("f32x3", "f16x2"):
+            # ("f16x2": the same tower from two fp16 planes per operand, three plane products on the fp16 MFMA -- engine_f16x2;
+            # the weights' and the hidden layer's scales are derived from the weights once per pass)
             # the fp32 tower on the bf16 MFMA (engine_x3: three exact bf16 planes per operand, six plane products)
             L = params.layout
             if L.Fp % 256 or L.Hp % 256 or L.Dp % 256:
@@ -48,10 +50,12 @@ class Prediction():
     def _workspace(self, n_rows):
         if self.precision == "bf16":
             n_rows = engine.round_up(n_rows, 64)
-        if self.precision == "f32x3":
+        if self.precision in ("f32x3", "f16x2"):
             n_rows = engine.round_up(n_rows, 128)
         if self._ws is None or self._ws.R < n_rows:
-            if self.precision == "f32x3":
+            if self.precision == "f16x2":
+                self._ws = engine_f16x2.TowerWorkspaceH2(self.params.layout, n_rows, self.device, planes_in=False, backward=False)
+            elif self.precision == "f32x3":
                 self._ws = engine_x3.TowerWorkspaceX3(self.params.layout, n_rows, self.device, planes_in=False, backward=False,
                                                       fc2_single_pass=self.fc2_single_pass)
             elif self.precision == "bf16":
@@ -73,13 +77,17 @@ class Prediction():
         if x.stride(-1) != 1 or (x.stride(0) % 4) or (x.data_ptr() % 16):
             x = x.contiguous()
         n = x.shape[0]
-        if self.precision == "f32x3" and n > self.X3_MAX_ROWS:
+        if self.precision in ("f32x3", "f16x2") and n > self.X3_MAX_ROWS:
             return torch.cat([self.predict(x[lo:lo + self.X3_MAX_ROWS]).clone() for lo in range(0, n, self.X3_MAX_ROWS)])
         ws = self._workspace(n)
         if L.F % 4:
             raise ValueError("feature size must be a multiple of 4")
         ops.l2norm_fwd(x[:, :L.F] if x.shape[1] != L.F else x, L.F, ws.x_hat)      # models.py:58
-        if self.precision == "f32x3":
+        if self.precision == "f16x2":
+            if not getattr(self, "_planes_fresh", False):
+                engine_f16x2.observe_weights(self.params, ws)                      # scales from the weights, then their planes
+            engine_f16x2.tower_forward(self.params, ws)
+        elif self.precision == "f32x3":
             if not getattr(self, "_planes_fresh", False):
                 engine_x3.refresh_weights(self.params, ws)                         # (embed_table: once per pass)
             engine_x3.tower_forward(self.params, ws)
@@ -107,10 +115,13 @@ class Prediction():
                 out[lo:lo + n] = ws.e[:n, :L.D]
             return out
         feats = table.data[:, :table.feature_size] if table.data.shape[1] == table.feature_size else table.data
-        if self.precision == "f32x3":
+        if self.precision in ("f32x3", "f16x2"):
             # h1 as three planes is 30 KB per row: the GEMMs' 2 GiB buffer descriptors take 65 536 rows at a time
             batch_size = min(batch_size, self.X3_MAX_ROWS)
-            engine_x3.refresh_weights(self.params, self._workspace(min(batch_size, N)))
+            if self.precision == "f16x2":
+                engine_f16x2.observe_weights(self.params, self._workspace(min(batch_size, N)))
+            else:
+                engine_x3.refresh_weights(self.params, self._workspace(min(batch_size, N)))
             self._planes_fresh = True
         try:
             for lo in range(0, N, batch_size):

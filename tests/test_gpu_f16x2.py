@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from cdml_amd import engine, engine_f16x2, engine_x3, ops, train
+from cdml_amd import engine, engine_f16x2, engine_x3, ops, predict, train
 from oracle import sampler as osampler, synth as osynth, tower as otower
 
 pytestmark = pytest.mark.gpu
@@ -311,3 +311,21 @@ def test_resident_plane_walk_equals_the_general_loop(monkeypatch):
     ref = x.double().t() @ dz.double()
     assert (r[:F * H].view(F, H).double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
     assert (r[F * H:].double() - dz.double().sum(0)).abs().max().item() <= 2e-6 * dz.double().sum(0).abs().max().item()
+
+
+def test_catalogue_inference_against_fp64():
+    """predict.Prediction(precision="f16x2") (predict.py:45-96): the forward-only tower at production widths on 3 000 catalogue
+    rows in 1 000-row chunks -- scales from the weights, once per pass -- against the fp64 oracle: the fp32 paths' 1e-5."""
+    dev = _dev()
+    N, F = 3000, 1500
+    feats = osynth.features_numpy(N, F, seed=3).astype(np.float32)
+    table = engine.FeatureTable.from_numpy(feats, dev)
+    L = engine_x3.layout_x3(F, 5000, 256)
+    params = engine.VNetParams(L, dev, 42)
+    params.b1[:5000] = torch.randn(5000, device=dev) * 0.05
+    pr = predict.Prediction(params=params, precision="f16x2")
+    out = pr.embed_table(table, 1000).cpu().numpy()
+    W = [t.detach().cpu().numpy().astype(np.float64) for t in params.unpadded()]
+    want = otower.vnet_forward(feats.astype(np.float64), *W, dtype=np.float64)["l2_norm"]
+    assert np.abs(out - want).max() < 1e-5
+    assert pr._ws.scales.h1 >= 2.0 ** 8 and float(pr._ws.h1[:, :L.Hp].float().abs().max()) < 65504.0
