@@ -1055,6 +1055,26 @@ def rec_f16x2(dev, args, n_s, n_w, table, pairs, B, mode):
         del t
         torch.cuda.empty_cache()
     out["learnable_catalogue_loss_every_30_steps"] = curves
+    del tl, pl
+    torch.cuda.empty_cache()
+    # BASELINE configs 1 and 2 on this precision (the 1 M-row catalogue; config 2's miner is the six-plane kernel of
+    # cdml_semihard_mine_x3 -- it splits the fp32 embeddings itself -- its tower the fp16 kernels)
+    from cdml_amd import engine
+    t1 = engine.FeatureTable.synthetic(1000000, F, seed=0, device=dev)
+    p1 = torch.from_numpy(synth_pairs(1000000, 333333, seed=0)).to(dev)
+    others = {}
+    for name, bc, mc, opt, lr_ in (("config1", 4096, "inbatch", "adam", 0.01), ("config2_semihard", 8192, "semihard", "adam", 0.01),
+                                   ("reference_recipe", 1024, "uniform", "lars", 1.0)):      # (train.py:354-364: B = 1024, LARS lr 1.0)
+        t = train.TrainStep(t1, p1, bc, output_size=D, hidden_size=H, margin=MARGIN, mode=mc, optimizer=opt,
+                            base_learning_rate=lr_, seed=1234, weight_seed=42, device=dev, precision="f16x2",
+                            gather_ahead=args.gather_ahead)
+        nn_ = max(n_s, 200 if name == "reference_recipe" else 60)
+        el2, _, _, _ = measure_job(t, nn_, max(n_w, 10), dev, "h2", timers=False)
+        others[name] = {"ms_per_step": round(el2 / nn_ * 1e3, 4), "value": round(bc * nn_ / el2, 1), "unit": "triplets/s",
+                        "steps": nn_, "loss": round(t.loss(), 6), "scale_moves": t.ws.scales.changes}
+        del t
+        torch.cuda.empty_cache()
+    out["baseline_configs_on_f16x2"] = others
     return out
 
 

@@ -168,6 +168,10 @@ SIGNATURES = {
                               _i64, _i64, _i, _p, _p, _p]),
     "cdml_momentum_matrix": (_i, [_p, _p, _p, _i, _i, _f, _p, _f, _i, _p, _i64, _i64, _p, _i64, _i64, _i, _p, _p, _p, _i,
                                   _p, _p, _p]),
+    "cdml_lars_matrix_h2": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _f, _f, _f, _f, _p, _p, _p, _i64, _i64, _p,
+                                 _i64, _i64, _f, _p, _p, _p]),
+    "cdml_momentum_matrix_h2": (_i, [_p, _p, _p, _i, _i, _f, _p, _f, _i, _p, _i64, _i64, _p, _i64, _i64, _f, _p, _p, _p, _i,
+                                     _p, _p, _p]),
 }
 
 _lib = None

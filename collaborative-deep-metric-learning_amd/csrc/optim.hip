@@ -419,6 +419,7 @@ struct MatRule {
   const float *scratch;          // LARS: k_lars_multi_norms' partial pairs
   int blk_w0, blk_w1, blk_b0, blk_b1;   // partial-pair ranges of the matrix' and of the bias' segment
   float *norms_w, *norms_b;      // optional: (|w|, |g|) of the two variables (block 0 writes them)
+  float h2_scale;                // PLANES = 2 (precision "f16x2"): the copies are the fp16 planes of the new weights times this
 };
 
 template <int PLANES, int RULE>
@@ -483,7 +484,7 @@ k_rule_matrix(float *__restrict__ w, const float *__restrict__ g, float *__restr
       res[p][q][0] = w4.x; res[p][q][1] = w4.y; res[p][q][2] = w4.z; res[p][q][3] = w4.w;
     }
   }
-  tile_copies<PLANES>(res, sT, wt, ldt, wc, ldc, plane_t, plane_c, k0, n0);
+  tile_copies<PLANES>(res, sT, wt, ldt, wc, ldc, plane_t, plane_c, k0, n0, R.h2_scale);
   if (bw) {
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < bn; i += gridDim.x * kThreads) {
       float wi = bw[i], ai = bacc[i];
@@ -744,25 +745,26 @@ extern "C" int cdml_lars_multi_norms(const float *w, const float *g, const int64
 
 static int check_copies(const char *who, int K, int N, const uint16_t *wt, int64_t ldt, int64_t plane_t, const uint16_t *wc,
                         int64_t ldc, int64_t plane_c, int planes) {
-  CDML_REQUIRE(planes == 1 || planes == 3, CDML_E_BADARG, "%s: planes must be 1 (bf16 copies) or 3 (hi | mid | lo)", who);
+  CDML_REQUIRE(planes == 1 || planes == 2 || planes == 3, CDML_E_BADARG, "%s: planes must be 1 (bf16 copies), 2 (fp16 hi | lo) or 3 (hi | mid | lo)", who);
   CDML_REQUIRE(K > 0 && N > 0 && K % kAT == 0 && N % kAT == 0, CDML_E_UNSUPPORTED,
                "%s: K and N must be multiples of 64, got K=%d N=%d", who, K, N);
   CDML_REQUIRE((!wt || (aligned16(wt) && (ldt & 7) == 0 && ldt >= K)) && (!wc || (aligned16(wc) && (ldc & 3) == 0 && ldc >= N)),
                CDML_E_ALIGN, "%s: 16-B aligned copies, ldt a multiple of 8 (>= K), ldc of 4 (>= N)", who);
-  if (planes == 3)
-    CDML_REQUIRE((!wt || (!(plane_t & 7) && plane_t >= K && ldt >= 2 * plane_t + K)) &&
-                     (!wc || (!(plane_c & 3) && plane_c >= N && ldc >= 2 * plane_c + N)),
+  if (planes >= 2)
+    CDML_REQUIRE((!wt || (!(plane_t & 7) && plane_t >= K && ldt >= (planes - 1) * plane_t + K)) &&
+                     (!wc || (!(plane_c & 3) && plane_c >= N && ldc >= (planes - 1) * plane_c + N)),
                  CDML_E_ALIGN, "%s: plane strides (W^T: multiple of 8, >= K; W: multiple of 4, >= N) and leading dimensions "
-                 ">= 2 planes + the matrix width", who);
+                 ">= (planes - 1) planes + the matrix width", who);
   return CDML_OK;
 }
 
-extern "C" int cdml_lars_matrix(float *w, const float *g, float *acc, const int64_t *seg_offsets, const int64_t *seg_sizes,
-                                int n_seg, int seg_matrix, int seg_bias, int K, int N, float lr, const float *lr_dev,
-                                float momentum, float weight_decay, float eeta, float eps, const float *scratch,
-                                float *norms_out, uint16_t *wt, int64_t ldt, int64_t plane_t, uint16_t *wc, int64_t ldc,
-                                int64_t plane_c, int planes, uint64_t *step_dev_advance, uint32_t *tickets,
-                                cdml_stream_t stream) {
+static int lars_matrix_impl(float h2_scale, float *w, const float *g, float *acc, const int64_t *seg_offsets, const int64_t *seg_sizes,
+                            int n_seg, int seg_matrix, int seg_bias, int K, int N, float lr, const float *lr_dev,
+                            float momentum, float weight_decay, float eeta, float eps, const float *scratch,
+                            float *norms_out, uint16_t *wt, int64_t ldt, int64_t plane_t, uint16_t *wc, int64_t ldc,
+                            int64_t plane_c, int planes, uint64_t *step_dev_advance, uint32_t *tickets,
+                            cdml_stream_t stream) {
+  CDML_REQUIRE((planes == 2) == (h2_scale > 0.f), CDML_E_BADARG, "lars_matrix: fp16 planes (planes = 2) go with a positive scale");
   CDML_REQUIRE(w && g && acc && scratch, CDML_E_BADARG, "lars_matrix: bad argument");
   CDML_REQUIRE(!step_dev_advance || tickets, CDML_E_BADARG, "lars_matrix: advancing the step counter needs the ticket words");
   CDML_REQUIRE(aligned16(w) && aligned16(g) && aligned16(acc), CDML_E_ALIGN, "lars_matrix: buffers must be 16-B aligned");
@@ -777,7 +779,7 @@ extern "C" int cdml_lars_matrix(float *w, const float *g, float *acc, const int6
   if (int rc = check_copies("lars_matrix", K, N, wt, ldt, plane_t, wc, ldc, plane_c, planes)) return rc;
   MatRule R{};
   R.lr_imm = lr; R.lr_dev = lr_dev; R.momentum = momentum; R.wd = weight_decay; R.eeta = eeta; R.eps = eps;
-  R.scratch = scratch;
+  R.scratch = scratch; R.h2_scale = h2_scale;
   R.blk_w0 = S.blk[seg_matrix]; R.blk_w1 = S.blk[seg_matrix + 1];
   R.norms_w = norms_out ? norms_out + 2 * seg_matrix : nullptr;
   float *bw = nullptr, *bacc = nullptr;
@@ -791,7 +793,11 @@ extern "C" int cdml_lars_matrix(float *w, const float *g, float *acc, const int6
   }
   const int64_t o = S.off[seg_matrix];
   const dim3 grid((K / kAT) * (N / kAT));
-  if (planes == 3)
+  if (planes == 2)
+    hipLaunchKernelGGL((k_rule_matrix<2, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, w + o, g + o, acc + o, K, N, R,
+                       reinterpret_cast<__bf16 *>(wt), ldt, reinterpret_cast<__bf16 *>(wc), ldc, bw, bg, bacc, bn,
+                       step_dev_advance, tickets, plane_t, plane_c);
+  else if (planes == 3)
     hipLaunchKernelGGL((k_rule_matrix<3, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, w + o, g + o, acc + o, K, N, R,
                        reinterpret_cast<__bf16 *>(wt), ldt, reinterpret_cast<__bf16 *>(wc), ldc, bw, bg, bacc, bn,
                        step_dev_advance, tickets, plane_t, plane_c);
@@ -802,13 +808,37 @@ extern "C" int cdml_lars_matrix(float *w, const float *g, float *acc, const int6
   return check_launch("lars_matrix");
 }
 
+extern "C" int cdml_lars_matrix(float *w, const float *g, float *acc, const int64_t *seg_offsets, const int64_t *seg_sizes,
+                                int n_seg, int seg_matrix, int seg_bias, int K, int N, float lr, const float *lr_dev,
+                                float momentum, float weight_decay, float eeta, float eps, const float *scratch,
+                                float *norms_out, uint16_t *wt, int64_t ldt, int64_t plane_t, uint16_t *wc, int64_t ldc,
+                                int64_t plane_c, int planes, uint64_t *step_dev_advance, uint32_t *tickets,
+                                cdml_stream_t stream) {
+  CDML_REQUIRE(planes != 2, CDML_E_BADARG, "lars_matrix: fp16 planes take a scale: cdml_lars_matrix_h2");
+  return lars_matrix_impl(0.f, w, g, acc, seg_offsets, seg_sizes, n_seg, seg_matrix, seg_bias, K, N, lr, lr_dev, momentum, weight_decay,
+                          eeta, eps, scratch, norms_out, wt, ldt, plane_t, wc, ldc, plane_c, planes, step_dev_advance, tickets, stream);
+}
+
+// cdml_lars_matrix / cdml_momentum_matrix writing the copies as the two fp16 planes hi | lo of the new weights times `scale`
+// (precision "f16x2"; as cdml_adam_matrix_h2)
+extern "C" int cdml_lars_matrix_h2(float *w, const float *g, float *acc, const int64_t *seg_offsets, const int64_t *seg_sizes,
+                                   int n_seg, int seg_matrix, int seg_bias, int K, int N, float lr, const float *lr_dev,
+                                   float momentum, float weight_decay, float eeta, float eps, const float *scratch,
+                                   float *norms_out, uint16_t *wt, int64_t ldt, int64_t plane_t, uint16_t *wc, int64_t ldc,
+                                   int64_t plane_c, float scale, uint64_t *step_dev_advance, uint32_t *tickets,
+                                   cdml_stream_t stream) {
+  return lars_matrix_impl(scale, w, g, acc, seg_offsets, seg_sizes, n_seg, seg_matrix, seg_bias, K, N, lr, lr_dev, momentum, weight_decay,
+                          eeta, eps, scratch, norms_out, wt, ldt, plane_t, wc, ldc, plane_c, 2, step_dev_advance, tickets, stream);
+}
+
 // tf.train.MomentumOptimizer on a weight matrix W[K][N] (+ its bias vector), writing the operand copies like
 // cdml_lars_matrix; step_dev_advance (with tickets): also global_step += 1 by the last block.
-extern "C" int cdml_momentum_matrix(float *w, const float *g, float *acc, int K, int N, float lr, const float *lr_dev,
-                                    float momentum, int use_nesterov, uint16_t *wt, int64_t ldt, int64_t plane_t,
-                                    uint16_t *wc, int64_t ldc, int64_t plane_c, int planes, float *bias_w,
-                                    const float *bias_g, float *bias_acc, int bias_n, uint64_t *step_dev_advance,
-                                    uint32_t *tickets, cdml_stream_t stream) {
+static int momentum_matrix_impl(float h2_scale, float *w, const float *g, float *acc, int K, int N, float lr, const float *lr_dev,
+                                float momentum, int use_nesterov, uint16_t *wt, int64_t ldt, int64_t plane_t,
+                                uint16_t *wc, int64_t ldc, int64_t plane_c, int planes, float *bias_w,
+                                const float *bias_g, float *bias_acc, int bias_n, uint64_t *step_dev_advance,
+                                uint32_t *tickets, cdml_stream_t stream) {
+  CDML_REQUIRE((planes == 2) == (h2_scale > 0.f), CDML_E_BADARG, "momentum_matrix: fp16 planes (planes = 2) go with a positive scale");
   CDML_REQUIRE(w && g && acc, CDML_E_BADARG, "momentum_matrix: bad argument");
   CDML_REQUIRE(!bias_w || (bias_g && bias_acc && bias_n > 0), CDML_E_BADARG,
                "momentum_matrix: the bias vector needs its gradient and accumulator");
@@ -816,9 +846,13 @@ extern "C" int cdml_momentum_matrix(float *w, const float *g, float *acc, int K,
   CDML_REQUIRE(aligned16(w) && aligned16(g) && aligned16(acc), CDML_E_ALIGN, "momentum_matrix: buffers must be 16-B aligned");
   if (int rc = check_copies("momentum_matrix", K, N, wt, ldt, plane_t, wc, ldc, plane_c, planes)) return rc;
   MatRule R{};
-  R.lr_imm = lr; R.lr_dev = lr_dev; R.momentum = momentum; R.nesterov = use_nesterov;
+  R.lr_imm = lr; R.lr_dev = lr_dev; R.momentum = momentum; R.nesterov = use_nesterov; R.h2_scale = h2_scale;
   const dim3 grid((K / kAT) * (N / kAT));
-  if (planes == 3)
+  if (planes == 2)
+    hipLaunchKernelGGL((k_rule_matrix<2, 2>), grid, dim3(kThreads), 0, (hipStream_t)stream, w, g, acc, K, N, R,
+                       reinterpret_cast<__bf16 *>(wt), ldt, reinterpret_cast<__bf16 *>(wc), ldc, bias_w, bias_g, bias_acc,
+                       bias_w ? bias_n : 0, step_dev_advance, tickets, plane_t, plane_c);
+  else if (planes == 3)
     hipLaunchKernelGGL((k_rule_matrix<3, 2>), grid, dim3(kThreads), 0, (hipStream_t)stream, w, g, acc, K, N, R,
                        reinterpret_cast<__bf16 *>(wt), ldt, reinterpret_cast<__bf16 *>(wc), ldc, bias_w, bias_g, bias_acc,
                        bias_w ? bias_n : 0, step_dev_advance, tickets, plane_t, plane_c);
@@ -827,6 +861,25 @@ extern "C" int cdml_momentum_matrix(float *w, const float *g, float *acc, int K,
                        reinterpret_cast<__bf16 *>(wt), ldt, reinterpret_cast<__bf16 *>(wc), ldc, bias_w, bias_g, bias_acc,
                        bias_w ? bias_n : 0, step_dev_advance, tickets, (int64_t)0, (int64_t)0);
   return check_launch("momentum_matrix");
+}
+
+extern "C" int cdml_momentum_matrix(float *w, const float *g, float *acc, int K, int N, float lr, const float *lr_dev,
+                                    float momentum, int use_nesterov, uint16_t *wt, int64_t ldt, int64_t plane_t,
+                                    uint16_t *wc, int64_t ldc, int64_t plane_c, int planes, float *bias_w,
+                                    const float *bias_g, float *bias_acc, int bias_n, uint64_t *step_dev_advance,
+                                    uint32_t *tickets, cdml_stream_t stream) {
+  CDML_REQUIRE(planes != 2, CDML_E_BADARG, "momentum_matrix: fp16 planes take a scale: cdml_momentum_matrix_h2");
+  return momentum_matrix_impl(0.f, w, g, acc, K, N, lr, lr_dev, momentum, use_nesterov, wt, ldt, plane_t, wc, ldc, plane_c, planes, bias_w,
+                              bias_g, bias_acc, bias_n, step_dev_advance, tickets, stream);
+}
+
+extern "C" int cdml_momentum_matrix_h2(float *w, const float *g, float *acc, int K, int N, float lr, const float *lr_dev,
+                                       float momentum, int use_nesterov, uint16_t *wt, int64_t ldt, int64_t plane_t,
+                                       uint16_t *wc, int64_t ldc, int64_t plane_c, float scale, float *bias_w,
+                                       const float *bias_g, float *bias_acc, int bias_n, uint64_t *step_dev_advance,
+                                       uint32_t *tickets, cdml_stream_t stream) {
+  return momentum_matrix_impl(scale, w, g, acc, K, N, lr, lr_dev, momentum, use_nesterov, wt, ldt, plane_t, wc, ldc, plane_c, 2, bias_w,
+                              bias_g, bias_acc, bias_n, step_dev_advance, tickets, stream);
 }
 
 extern "C" int cdml_grad_prepare(float *g, const float *w, int64_t n, float l2_scale, float clip_norm,

@@ -749,25 +749,31 @@ def lars_multi_norms(w, g, segments, scratch):
     call("cdml_lars_multi_norms", _p(w), _p(g), C.cast(offs, C.c_void_p), C.cast(sizes, C.c_void_p), n, _p(scratch), _stream())
 
 
-def _copies(wt, wc, K, N, plane_t, plane_c):
+def _copies(wt, wc, K, N, plane_t, plane_c, h2_scale=0.0):
     tp, tld = (C.c_void_p(0), 0) if wt is None else _mat16(wt)
     cp, cld = (C.c_void_p(0), 0) if wc is None else _mat16(wc)
-    planes = 3 if (plane_t or plane_c) else 1
-    if wt is not None and (wt.shape[0] < N or wt.shape[1] < (2 * plane_t + K if planes == 3 else K)):
-        raise ValueError("wt must be at least [N, K] (planes: [N, 2 plane_t + K])")
-    if wc is not None and (wc.shape[0] < K or wc.shape[1] < (2 * plane_c + N if planes == 3 else N)):
-        raise ValueError("wc must be at least [K, N] (planes: [K, 2 plane_c + N])")
+    planes = 2 if h2_scale else 3 if (plane_t or plane_c) else 1
+    if wt is not None and (wt.shape[0] < N or wt.shape[1] < ((planes - 1) * plane_t + K if planes > 1 else K)):
+        raise ValueError("wt must be at least [N, K] (planes: [N, 2 plane_t + K]; fp16 planes: [N, plane_t + K])")
+    if wc is not None and (wc.shape[0] < K or wc.shape[1] < ((planes - 1) * plane_c + N if planes > 1 else N)):
+        raise ValueError("wc must be at least [K, N] (planes: [K, 2 plane_c + N]; fp16 planes: [K, plane_c + N])")
     return tp, tld, cp, cld, planes
 
 
 def lars_matrix(w, g, acc, segments, seg_matrix, seg_bias, K, N, lr, scratch, wt=None, wc=None, plane_t=0, plane_c=0,
                 momentum=0.9, weight_decay=1e-4, eeta=1e-3, eps=0.0, lr_dev=None, norms_out=None, step_dev=None,
-                tickets=None):
+                tickets=None, h2_scale=0.0):
     """LARS on the K x N weight matrix in segment ``seg_matrix`` of the flat buffers (+ the bias vector in segment
     ``seg_bias``, or None), after ``lars_multi_norms`` on the same segments; also writes the operand copies wt = W^T,
     wc = W as bf16 (plane_t / plane_c > 0: as three bf16 planes).  step_dev (with tickets): also global_step += 1."""
     n, offs, sizes = _seg_arrays(segments)
-    tp, tld, cp, cld, planes = _copies(wt, wc, K, N, plane_t, plane_c)
+    tp, tld, cp, cld, planes = _copies(wt, wc, K, N, plane_t, plane_c, h2_scale)
+    if h2_scale:                                     # the copies as two fp16 planes of W * h2_scale (precision f16x2)
+        call("cdml_lars_matrix_h2", _p(w), _p(g), _p(acc), C.cast(offs, C.c_void_p), C.cast(sizes, C.c_void_p), n, seg_matrix,
+             -1 if seg_bias is None else seg_bias, K, N, lr, _p(lr_dev), momentum, weight_decay, eeta, eps, _p(scratch),
+             _p(norms_out), tp, tld, plane_t, cp, cld, plane_c, float(h2_scale), _p(step_dev, torch.int64),
+             _p(tickets, torch.int32), _stream())
+        return
     call("cdml_lars_matrix", _p(w), _p(g), _p(acc), C.cast(offs, C.c_void_p), C.cast(sizes, C.c_void_p), n, seg_matrix,
          -1 if seg_bias is None else seg_bias, K, N, lr, _p(lr_dev), momentum, weight_decay, eeta, eps, _p(scratch),
          _p(norms_out), tp, tld, plane_t, cp, cld, plane_c, planes, _p(step_dev, torch.int64), _p(tickets, torch.int32),
@@ -775,14 +781,19 @@ def lars_matrix(w, g, acc, segments, seg_matrix, seg_bias, K, N, lr, scratch, wt
 
 
 def momentum_matrix(W, g, acc, lr, wt=None, wc=None, plane_t=0, plane_c=0, momentum=0.9, use_nesterov=True, lr_dev=None,
-                    bias=None, step_dev=None, tickets=None):
+                    bias=None, step_dev=None, tickets=None, h2_scale=0.0):
     """ApplyMomentum on the contiguous weight matrix W [K, N] (g, acc alike) + ``bias`` = (b, gb, accb), writing the
     operand copies like ``lars_matrix``."""
     if W.dim() != 2 or not W.is_contiguous() or W.dtype != torch.float32:
         raise ValueError("W must be a contiguous fp32 matrix")
     K, N = W.shape
-    tp, tld, cp, cld, planes = _copies(wt, wc, K, N, plane_t, plane_c)
+    tp, tld, cp, cld, planes = _copies(wt, wc, K, N, plane_t, plane_c, h2_scale)
     b = bias if bias is not None else (None, None, None)
+    if h2_scale:
+        call("cdml_momentum_matrix_h2", _p(W), _p(g), _p(acc), K, N, lr, _p(lr_dev), momentum, 1 if use_nesterov else 0, tp, tld,
+             plane_t, cp, cld, plane_c, float(h2_scale), _p(b[0]), _p(b[1]), _p(b[2]), 0 if bias is None else b[0].numel(),
+             _p(step_dev, torch.int64), _p(tickets, torch.int32), _stream())
+        return
     call("cdml_momentum_matrix", _p(W), _p(g), _p(acc), K, N, lr, _p(lr_dev), momentum, 1 if use_nesterov else 0, tp, tld,
          plane_t, cp, cld, plane_c, planes, _p(b[0]), _p(b[1]), _p(b[2]), 0 if bias is None else b[0].numel(),
          _p(step_dev, torch.int64), _p(tickets, torch.int32), _stream())

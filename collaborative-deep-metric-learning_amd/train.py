@@ -57,7 +57,7 @@ class TrainStep:
         bench.py times -- when the step's rows are a multiple of 128, else "f32" (the fp32 MFMA).  "f16x2" (never chosen by
         "auto"): fp32 operands as TWO fp16 planes under per-tensor power-of-two scales, three plane products on the fp16 MFMA
         -- half of "f32x3"'s matrix work at the same error bound, an fp32 equivalent while its delayed scales hold
-        (engine_f16x2.py); one GPU, eager, Adam, frozen catalogue.
+        (engine_f16x2.py); one GPU, eager, frozen catalogue.
         ``use_graph``: False = eager; True = the whole step replayed from ONE hipGraph (single GPU: the
         fast form; data-parallel: the exchange of step t+1 is then recorded on the capturing stream,
         ahead of the forward pass, not under it); "split" (data-parallel with the prefetcher) = three
@@ -141,8 +141,8 @@ class TrainStep:
         if self.bf16 != (table.data.dtype == torch.float16):
             raise ValueError("precision 'bf16' goes with an fp16 FeatureTableF16, 'f32' / 'f32x3' with an fp32 table")
         if self.h2:
-            if exchange is not None or grad_sync is not None or use_graph or train_table or optimizer != "adam":
-                raise ValueError("precision 'f16x2' is the single-GPU eager step with Adam and a frozen catalogue (its plane scales "
+            if exchange is not None or grad_sync is not None or use_graph or train_table:
+                raise ValueError("precision 'f16x2' is the single-GPU eager step with a frozen catalogue (its plane scales "
                                  "are host-side kernel arguments that move during training: engine_f16x2.py)")
             self.layout = engine_x3.layout_x3(F, hidden_size, output_size)
             self.params = engine.VNetParams(self.layout, self.device, weight_seed)
@@ -184,7 +184,8 @@ class TrainStep:
             # precision f32x3: the score product on the plane kernels with the selection as its epilogue -- no B x 2B
             # score matrix (537 MB at B = 8192) is written or scanned (csrc/gemm_bf16x3.hip; CDML_MINE_FUSED=0: the
             # round-2 form, for A/B runs); the fp32-MFMA and bf16 paths keep the score matrix
-            self.mine_fused = (self.x3 and precision == "f32x3" and (2 * self.B) % 256 == 0 and self.layout.Dp % 64 == 0
+            # (precision f16x2 mines on the same six-plane kernel: the miner makes its own bf16 planes of the fp32 embeddings)
+            self.mine_fused = ((precision == "f32x3" or self.h2) and (2 * self.B) % 256 == 0 and self.layout.Dp % 64 == 0
                                and os.environ.get("CDML_MINE_FUSED", "1") != "0")
             if self.mine_fused:
                 Dp = self.layout.Dp
@@ -426,6 +427,17 @@ class TrainStep:
         return float(self.stats[4].item())
 
     def forward_loss(self, with_grad=True):
+        # precision f16x2: on its check steps (0, 1, 2, 4 .. 64, then every 64th) the plane scales are re-derived -- the weights'
+        # and the hidden layer's before the forward pass, the gradients' once the loss tail has written dz2 (two small
+        # device-to-host copies; engine_f16x2.PlaneScales)
+        due = self.h2 and self.ws.scales.due(self.global_step)
+        if due:
+            engine_f16x2.observe_weights(self.params, self.ws)
+        self._forward_loss(with_grad)
+        if due and with_grad:
+            engine_f16x2.observe_gradients(self.params, self.ws)
+
+    def _forward_loss(self, with_grad=True):
         # uniform / in-batch negatives: one launch normalises z, takes the loss and starts the
         # backward pass (semi-hard mining needs every embedded row first: separate kernels)
         fused = with_grad and self.mode != "semihard"
@@ -433,7 +445,7 @@ class TrainStep:
         mine_norm = (self.mode == "semihard" and getattr(self, "mine_fused", False)
                      and os.environ.get("CDML_MINE_NORM", "1") != "0")
         if self.h2:
-            engine_f16x2.tower_forward(self.params, self.ws, normalize=not fused)
+            engine_f16x2.tower_forward(self.params, self.ws, normalize=not (fused or mine_norm))
         elif self.x3:
             engine_x3.tower_forward(self.params, self.ws, normalize=not (fused or mine_norm))
         elif self.bf16:
@@ -593,29 +605,30 @@ class TrainStep:
             # the step counter advances inside the same launch
             ops.adam_step(p.flat, p.grad, self.m, self.v, 0.0, 1, lr_dev=self.lr_dev,
                           t_dev=self.step_dev, advance_tickets=self.adam_tickets)
-        elif self.x3 or self.bf16:
-            # LARS / momentum on the plane (f32x3) or bf16 (config 4) paths: two matrix launches, each weight matrix with
+        elif self.x3 or self.bf16 or self.h2:
+            # LARS / momentum on the plane (f32x3, f16x2) or bf16 (config 4) paths: two matrix launches, each weight matrix with
             # its bias vector, writing the operand copies the GEMMs read with the update (as the Adam launches above do --
             # round 3 ran separate split / transpose launches after the optimizer); the last one advances the step counter
             L, o, ws = self.layout, self.layout.offsets, self.ws
-            pt1, pt2, pc2 = (L.Fp, L.Hp, L.Dp) if self.x3 else (0, 0, 0)
+            pt1, pt2, pc2 = (L.Fp, L.Hp, L.Dp) if (self.x3 or self.h2) else (0, 0, 0)
+            s1, s2 = (ws.scales.w1, ws.scales.w2) if self.h2 else (0.0, 0.0)     # (f16x2: fp16 planes of W * its scale)
             if self.optimizer == "lars":
                 segs = p.segments()
                 ops.lars_multi_norms(p.flat, p.grad, segs, self.lars_scratch)
                 kw = dict(lr_dev=self.lr_dev)
                 ops.lars_matrix(p.flat, p.grad, self.acc, segs, 0, 1, L.Fp, L.Hp, 0.0, self.lars_scratch, wt=ws.W1T,
-                                plane_t=pt1, **kw)
+                                plane_t=pt1, h2_scale=s1, **kw)
                 ops.lars_matrix(p.flat, p.grad, self.acc, segs, 2, 3, L.Hp, L.Dp, 0.0, self.lars_scratch, wt=ws.W2T, wc=ws.W2,
-                                plane_t=pt2, plane_c=pc2, step_dev=self.step_dev, tickets=self.adam_tickets, **kw)
+                                plane_t=pt2, plane_c=pc2, step_dev=self.step_dev, tickets=self.adam_tickets, h2_scale=s2, **kw)
             else:
                 mat = lambda t, i, r, c: t[o[i]:o[i] + r * c].view(r, c)
                 b1, b2 = slice(o[1], o[1] + L.Hp), slice(o[3], o[3] + L.Dp)
                 vec = lambda sl: (p.flat[sl], p.grad[sl], self.acc[sl])
                 ops.momentum_matrix(p.W1, mat(p.grad, 0, L.Fp, L.Hp), mat(self.acc, 0, L.Fp, L.Hp), 0.0, wt=ws.W1T,
-                                    plane_t=pt1, lr_dev=self.lr_dev, bias=vec(b1))
+                                    plane_t=pt1, lr_dev=self.lr_dev, bias=vec(b1), h2_scale=s1)
                 ops.momentum_matrix(p.W2, mat(p.grad, 2, L.Hp, L.Dp), mat(self.acc, 2, L.Hp, L.Dp), 0.0, wt=ws.W2T, wc=ws.W2,
                                     plane_t=pt2, plane_c=pc2, lr_dev=self.lr_dev, bias=vec(b2), step_dev=self.step_dev,
-                                    tickets=self.adam_tickets)
+                                    tickets=self.adam_tickets, h2_scale=s2)
         elif self.optimizer == "momentum":
             ops.momentum_step(p.flat, p.grad, self.acc, 0.0, 0.9, True, lr_dev=self.lr_dev)
             ops.step_advance(self.step_dev)
@@ -635,15 +648,7 @@ class TrainStep:
             t, b = self.global_step, self.global_step % 2
             self.prefetch.launch(1 - b, lambda: self._fill(1 - b, t + 1))
             self._filled = t + 1
-        # precision f16x2: on its check steps (0, 1, 2, 4 .. 64, then every 64th) the plane scales are re-derived -- the weights'
-        # and the hidden layer's before the forward pass, the gradients' once the loss tail has written dz2 (two small
-        # device-to-host copies; engine_f16x2.PlaneScales)
-        due = self.h2 and self.ws.scales.due(self.global_step)
-        if due:
-            engine_f16x2.observe_weights(self.params, self.ws)
         self.forward_loss()
-        if due:
-            engine_f16x2.observe_gradients(self.params, self.ws)
         self._backward_and_update(b if self.prefetch is not None else None)
 
     def _backward_and_update(self, b):

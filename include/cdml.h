@@ -549,8 +549,9 @@ int cdml_gemm_f16x2_tn(const uint16_t *A, int64_t lda, int64_t plane_a, const ui
 /* The producers of "f16x2" plane tensors other than the GEMM epilogues: the fused sampler + gather (inputs.py:125-158)
  * writing each l2-normalised row as the two fp16 planes of x_hat * CDML_F16X2_X_SCALE (|x_hat| <= 1: a constant of the
  * format; out_stride = 2 planes of out_stride / 2 >= F columns); cdml_vnet_tail writing dz2's planes times `scale`
- * (dz2_planes fp16 [rows][ldbf], ldbf >= plane_h + D); cdml_adam_matrix_bf16 writing the weight copies as the planes of
- * W * scale (wt = W^T [N][hi K | lo K], wc = W [K][hi N | lo N]).  A value beyond fp16's range saturates at +-65504. */
+ * (dz2_planes fp16 [rows][ldbf], ldbf >= plane_h + D); cdml_adam_matrix_bf16 / cdml_lars_matrix / cdml_momentum_matrix
+ * (train.py:146, :354, :115) writing the weight copies as the planes of W * scale (wt = W^T [N][hi K | lo K], wc = W
+ * [K][hi N | lo N]).  A value beyond fp16's range saturates at +-65504. */
 #define CDML_F16X2_X_SCALE 16384.0f
 int cdml_sample_gather_h2(int mode, const int32_t *pairs, int64_t n_pairs, uint64_t seed,
                           uint64_t step, const uint64_t *step_dev, int batch, int64_t slot0,
@@ -564,6 +565,17 @@ int cdml_vnet_tail_h2(int mode, const float *z, int64_t ldz, const int32_t *rows
                       uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_planes,
                       int64_t ldbf, int64_t plane_h, float scale, float *stats, float *var_ws,
                       cdml_stream_t stream);
+int cdml_lars_matrix_h2(float *w, const float *g, float *acc, const int64_t *seg_offsets, const int64_t *seg_sizes,
+                        int n_seg, int seg_matrix, int seg_bias, int K, int N, float lr, const float *lr_dev,
+                        float momentum, float weight_decay, float eeta, float eps, const float *scratch,
+                        float *norms_out, uint16_t *wt_planes, int64_t ldt, int64_t plane_t, uint16_t *wc_planes,
+                        int64_t ldc, int64_t plane_c, float scale, uint64_t *step_dev_advance, uint32_t *tickets,
+                        cdml_stream_t stream);
+int cdml_momentum_matrix_h2(float *w, const float *g, float *acc, int K, int N, float lr, const float *lr_dev,
+                            float momentum, int use_nesterov, uint16_t *wt_planes, int64_t ldt, int64_t plane_t,
+                            uint16_t *wc_planes, int64_t ldc, int64_t plane_c, float scale, float *bias_w,
+                            const float *bias_g, float *bias_acc, int bias_n, uint64_t *step_dev_advance,
+                            uint32_t *tickets, cdml_stream_t stream);
 int cdml_adam_matrix_h2(float *w, const float *g, float *m, float *v, int K, int N, float lr,
                         const float *lr_dev, float beta1, float beta2, float eps, int64_t t,
                         uint64_t *t_dev, uint16_t *wt_planes, int64_t ldt, int64_t plane_t,

@@ -329,3 +329,58 @@ def test_catalogue_inference_against_fp64():
     want = otower.vnet_forward(feats.astype(np.float64), *W, dtype=np.float64)["l2_norm"]
     assert np.abs(out - want).max() < 1e-5
     assert pr._ws.scales.h1 >= 2.0 ** 8 and float(pr._ws.h1[:, :L.Hp].float().abs().max()) < 65504.0
+
+
+@pytest.mark.parametrize("rule", ["lars", "momentum"])
+def test_lars_and_momentum_write_the_fp16_planes_with_the_update(rule):
+    """The reference's own optimizer (LARS, train.py:354) and Nesterov momentum (train.py:115-116) with the GEMMs' fp16 plane
+    copies written by the update itself (cdml_lars_matrix_h2 / cdml_momentum_matrix_h2): weights and slots bit-equal to the flat
+    kernels, the planes bit-equal to cdml_split_f32_f16x2 of the new weights at the same scale, the step counter advanced once."""
+    torch.manual_seed(11)
+    dev = _dev()
+    Fp, Hp, Dp = 256, 512, 256
+    sizes = [Fp * Hp, Hp, Hp * Dp, Dp]
+    segs, o = [], 0
+    for n in sizes:
+        segs.append((o, n))
+        o += n
+    w0 = torch.randn(o, device=dev) * 0.05
+    g = torch.randn(o, device=dev) * 1e-3
+    acc0 = torch.randn(o, device=dev) * 1e-4
+    lr_dev = torch.full((1,), 0.5, device=dev)
+    wa, acca = w0.clone(), acc0.clone()
+    step_a = torch.zeros(1, dtype=torch.int64, device=dev)
+    scratch = torch.zeros(max(ops.lars_scratch_floats(), ops.lars_multi_scratch_floats()), device=dev)
+    if rule == "lars":
+        ops.lars_multi(wa, g, acca, segs, 0.0, scratch, lr_dev=lr_dev, step_dev=step_a, tickets=ops.new_tickets(dev))
+    else:
+        ops.momentum_step(wa, g, acca, 0.0, 0.9, True, lr_dev=lr_dev)
+        ops.step_advance(step_a)
+    wb, accb = w0.clone(), acc0.clone()
+    step_b = torch.zeros(1, dtype=torch.int64, device=dev)
+    tick = ops.new_tickets(dev)
+    s1, s2 = 2.0 ** 13, 2.0 ** 12
+    W1T = torch.zeros(Hp, 2 * Fp, dtype=torch.float16, device=dev)
+    W2T = torch.zeros(Dp, 2 * Hp, dtype=torch.float16, device=dev)
+    W2 = torch.zeros(Hp, 2 * Dp, dtype=torch.float16, device=dev)
+    if rule == "lars":
+        scratch2 = torch.zeros_like(scratch)
+        ops.lars_multi_norms(wb, g, segs, scratch2)
+        ops.lars_matrix(wb, g, accb, segs, 0, 1, Fp, Hp, 0.0, scratch2, wt=W1T, plane_t=Fp, lr_dev=lr_dev, h2_scale=s1)
+        ops.lars_matrix(wb, g, accb, segs, 2, 3, Hp, Dp, 0.0, scratch2, wt=W2T, wc=W2, plane_t=Hp, plane_c=Dp, lr_dev=lr_dev,
+                        step_dev=step_b, tickets=tick, h2_scale=s2)
+    else:
+        v = lambda t, i, r, c: t[segs[i][0]:segs[i][0] + r * c].view(r, c)
+        b = lambda i: tuple(t[segs[i][0]:segs[i][0] + segs[i][1]] for t in (wb, g, accb))
+        ops.momentum_matrix(v(wb, 0, Fp, Hp), v(g, 0, Fp, Hp), v(accb, 0, Fp, Hp), 0.0, wt=W1T, plane_t=Fp, lr_dev=lr_dev,
+                            bias=b(1), h2_scale=s1)
+        ops.momentum_matrix(v(wb, 2, Hp, Dp), v(g, 2, Hp, Dp), v(accb, 2, Hp, Dp), 0.0, wt=W2T, wc=W2, plane_t=Hp, plane_c=Dp,
+                            lr_dev=lr_dev, bias=b(3), step_dev=step_b, tickets=tick, h2_scale=s2)
+    torch.cuda.synchronize()
+    assert torch.equal(wa, wb) and torch.equal(acca, accb), "matrix form differs from the flat kernel"
+    assert int(step_a.item()) == 1 and int(step_b.item()) == 1
+    W1 = wb[:Fp * Hp].view(Fp, Hp)
+    W2m = wb[segs[2][0]:segs[2][0] + Hp * Dp].view(Hp, Dp)
+    i16 = lambda t: t.view(torch.int16)
+    assert torch.equal(i16(W1T), i16(_planes(W1, Fp, s1, transpose=True)))
+    assert torch.equal(i16(W2T), i16(_planes(W2m, Hp, s2, transpose=True))) and torch.equal(i16(W2), i16(_planes(W2m, Dp, s2)))
