@@ -1153,7 +1153,8 @@ def rec_knn(dev, n=343455, k=51, precision="f32x3"):
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
     flops = 2.0 * n * n * D
-    peak = round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if precision == "f32x3" else PEAK_F32_MFMA_TFLOPS
+    peak = (round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if precision == "f32x3" else round(PEAK_BF16_MFMA_TFLOPS / 3, 1) if precision == "f16x2"
+            else PEAK_F32_MFMA_TFLOPS)
     self_first = bool((Ik[:, 0] == torch.arange(n, device=dev)).all())
     return {"workload": "exact self-kNN export: %d unit embeddings x %d-d, k = %d (faiss_knn.py:82-131, :389), l2-normalise + "
                         "inner products + per-query top-k merge, results in HBM" % (n, D, k),
@@ -1573,7 +1574,7 @@ def main():
             attempt("config4_per_gpu", lambda: rec_config4(dev, args, n_s, n_w))
             attempt("predict", lambda: {"f32": rec_predict(dev, "f32"), "f32x3": rec_predict(dev, "f32x3"),
                                         "f16x2": rec_predict(dev, "f16x2"), "bf16": rec_predict(dev, "bf16")})
-            attempt("knn", lambda: rec_knn(dev))
+            attempt("knn", lambda: dict(rec_knn(dev), f16x2=rec_knn(dev, precision="f16x2")))
         if world == 1 and not args.no_cpu_baseline:
             set_phase("cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)

@@ -98,6 +98,7 @@ SIGNATURES = {
     "cdml_semihard_mine_x3_workspace": (_sz, [_i]),
     "cdml_semihard_mine_x3": (_i, [_p, _i64, _p, _i, _i, _p, _i64, _i64, _p, _p, _p, _sz, _p, _p]),
     "cdml_semihard_mine_x3_z": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _i64, _i64, _p, _p, _p, _sz, _p, _p]),
+    "cdml_semihard_mine_h2": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _i64, _i64, _f, _p, _p, _p, _sz, _p, _p]),
     "cdml_triplet_hinge_indexed": (_i, [_p, _i64, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "cdml_x3_slab_steps": (_i, [_i]),
     "cdml_triplet_hinge_indexed_tail": (_i, [_p, _i64, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _f, _p, _i64,
@@ -110,6 +111,7 @@ SIGNATURES = {
     "cdml_row_sqnorm": (_i, [_p, _i64, _i, _i, _p, _p]),
     "cdml_knn_merge": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
     "cdml_knn_filter_x3": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
+    "cdml_knn_filter_h2": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _f, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "cdml_knn_merge_list": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "cdml_gemm_bf16_workspace": (_sz, [_i, _i, _i]),
     "cdml_gemm_bf16_epilogue_supported": (_i, [_i, _i, _i, _i, _i64, _i64, _i64, _i64]),

@@ -94,6 +94,8 @@ int launch_gemm_bf16_256_x3(const BArgs &g, bool tn, int epilogue, int splits, h
 // the same on two fp16 planes per operand, three plane products (hi.hi + hi.lo + lo.hi) on v_mfma_f32_16x16x32_f16
 // (gemm_f16x2_256.hip; g.x3_products = 3, g.out_scale / g.c_scale set; epilogues 1, 3, 6, 7 k-contiguous, 3 k-strided)
 int launch_gemm_f16x2_256(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t stream);
+int launch_gemm_f16x2_mine(const BArgs &g, hipStream_t stream);     // BE_MINE_X3 on fp16 planes (g.out_scale set)
+int launch_gemm_f16x2_knn(const BArgs &g, hipStream_t stream);      // BE_KNN_X3 on fp16 planes
 // the score product of semi-hard mining with the selection as its epilogue (BE_MINE_X3; six products, resident-plane walk)
 int launch_gemm_x3_mine(const BArgs &g, hipStream_t stream);
 // the query x catalogue score product of the kNN export with the threshold filter as its epilogue (BE_KNN_X3)

@@ -817,8 +817,13 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
           for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-              acc16[4 * HALF + rb][cb] = CDML_MFMA16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 * HALF + rb][cb]);
-              acc16[4 * HALF + rb][2 + cb] = CDML_MFMA16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 * HALF + rb][2 + cb]);
+              if constexpr (kSwap) {                       // (the miner / kNN filter: the transposed block, a row's columns per lane)
+                acc16[4 * HALF + rb][cb] = CDML_MFMA16(fb0[2 * cb + ks2], fa[ks2][rb], acc16[4 * HALF + rb][cb]);
+                acc16[4 * HALF + rb][2 + cb] = CDML_MFMA16(fb1[2 * cb + ks2], fa[ks2][rb], acc16[4 * HALF + rb][2 + cb]);
+              } else {
+                acc16[4 * HALF + rb][cb] = CDML_MFMA16(fa[ks2][rb], fb0[2 * cb + ks2], acc16[4 * HALF + rb][cb]);
+                acc16[4 * HALF + rb][2 + cb] = CDML_MFMA16(fa[ks2][rb], fb1[2 * cb + ks2], acc16[4 * HALF + rb][2 + cb]);
+              }
             }
         __builtin_amdgcn_s_setprio(0);
         CDML_BARRIER();
@@ -1189,6 +1194,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
       va8[rbb] = g.mine_ids[2 * i];
       vp8[rbb] = g.mine_ids[2 * i + 1];
     }
+    const float two_s = kF16 ? 2.0f * g.out_scale : 2.0f;     // (fp16 planes: the accumulator holds 2^(sa + sb) <a, c>)
     auto closer = [](float d, int c, float bd, int bc) { return d < bd || (d == bd && c < bc); };
     auto farther = [](float d, int c, float bd, int bc) { return d > bd || (d == bd && c < bc); };
     MineCand *dst = g.mine_out + (int64_t)((n0 / kTileN) * 4 + wc) * g.mine_ld;
@@ -1210,7 +1216,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                        // columns ascending: a tie keeps the smaller column without a test
           const int c = cbase + cb * 16 + r;
-          const float d = (sa + ncv[cb][r]) - 2.0f * acc16[rbb][cb][r];
+          const float d = (sa + ncv[cb][r]) - two_s * acc16[rbb][cb][r];
           const int vid = idv[cb][r];
           if (vid != va && vid != vp && d > dpv && d < od) { od = d; oc = c; }
         }
@@ -1226,7 +1232,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int c = cbase + cb * 16 + r;
-            const float d = (sa + ncv[cb][r]) - 2.0f * acc16[rbb][cb][r];
+            const float d = (sa + ncv[cb][r]) - two_s * acc16[rbb][cb][r];
             const int vid = idv[cb][r];
             if (vid != va && vid != vp && d > id_) { id_ = d; ic = c; }
           }
@@ -1276,7 +1282,7 @@ __device__ __forceinline__ void run_tile(const BArgs &g, const int tm, const int
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int id = g.knn_col0 + cbase + cb * 16 + r;
-          const float d = fmaxf((qs + bsv[cb][r]) - 2.0f * acc16[rbb][cb][r], 0.f);
+          const float d = fmaxf((qs + bsv[cb][r]) - (kF16 ? 2.0f * g.out_scale : 2.0f) * acc16[rbb][cb][r], 0.f);
           if (d <= tau && id < g.knn_n_valid && i < g.M) {   // rare
             const int pos = atomicAdd(g.knn_cnt + i, 1);
             if (pos < g.knn_cap) g.knn_cand[(int64_t)i * g.knn_cap + pos] = make_uint2(__float_as_uint(d), (uint32_t)id);
@@ -1919,6 +1925,14 @@ int launch_x3(const BArgs &g, int splits, hipStream_t s) {
 }  // namespace
 
 #ifdef CDML_F16X2
+// the score products whose epilogue is the selection (semi-hard mining) / the threshold filter (kNN export), on fp16 planes:
+// three products, the three-step resident-plane walk (K = D: whole periods always)
+int launch_gemm_f16x2_mine(const BArgs &g, hipStream_t s) {
+  return launch_x3_1<false, BE_MINE_X3, false, false, true>(g, g.tiles_m * g.tiles_n, 1, s);
+}
+int launch_gemm_f16x2_knn(const BArgs &g, hipStream_t s) {
+  return launch_x3_1<false, BE_KNN_X3, false, false, true>(g, g.tiles_m * g.tiles_n, 1, s);
+}
 int launch_gemm_f16x2_256(const BArgs &g, bool tn, int epilogue, int splits, hipStream_t s) {
   if (tn) return launch_x3<true, BE_F32>(g, splits, s);
   switch (epilogue) {

@@ -548,7 +548,8 @@ namespace {
 // from kernel to kernel), planes, norms and distances those of the e written here.
 __global__ void __launch_bounds__(kThreads)
 k_mine_prep(const float *__restrict__ e_in, float *__restrict__ e_out, int64_t lde, const float *__restrict__ z, int64_t ldz,
-            int B, int D, bf16 *__restrict__ e3, int64_t ld3, int64_t plane, float *__restrict__ sqn, float *__restrict__ dp) {
+            int B, int D, bf16 *__restrict__ e3, int64_t ld3, int64_t plane, float *__restrict__ sqn, float *__restrict__ dp,
+            float h2_scale) {      // h2_scale > 0: the rows as TWO fp16 planes of e * h2_scale instead of three bf16 planes
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = D >> 2;
   for (int i = blockIdx.x * (kThreads / 64) + wave; i < B; i += gridDim.x * (kThreads / 64)) {
@@ -582,6 +583,19 @@ k_mine_prep(const float *__restrict__ e_in, float *__restrict__ e_out, int64_t l
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const f32x4 v = r ? y : x;
+        if (h2_scale > 0.f) {                              // (uniform)
+          half4v hh, hl;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            _Float16 a, b;
+            split2h(v[j], h2_scale, a, b);
+            hh[j] = a; hl[j] = b;
+          }
+          _Float16 *d = reinterpret_cast<_Float16 *>(e3) + (int64_t)(2 * i + r) * ld3 + 4 * q;
+          *reinterpret_cast<half4v *>(d) = hh;
+          *reinterpret_cast<half4v *>(d + plane) = hl;
+          continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           bf16 b0, b1, b2;
@@ -645,14 +659,14 @@ extern "C" size_t cdml_semihard_mine_x3_workspace(int B) {
 // (cdml_semihard_mine_x3_workspace).  neg_row_out[i] as cdml_semihard_select.  2B % 256 == 0, D % 64 == 0.
 static int semihard_mine_x3_impl(const float *e, float *e_out, int64_t lde, const float *z, int64_t ldz, const int32_t *rows, int B,
                                  int D, uint16_t *e_planes, int64_t ldp, int64_t plane, float *sqn, float *dp, void *workspace,
-                                 size_t workspace_bytes, int32_t *neg_row_out, cdml_stream_t stream) {
+                                 size_t workspace_bytes, int32_t *neg_row_out, cdml_stream_t stream, float h2_scale = 0.f) {
   CDML_REQUIRE(e && rows && e_planes && sqn && dp && workspace && neg_row_out && B >= 1 && D > 0, CDML_E_BADARG,
                "semihard_mine_x3: bad argument");
   CDML_REQUIRE(!z || (aligned16(z) && !(ldz & 3) && ldz >= D), CDML_E_ALIGN, "semihard_mine_x3_z: z 16-B aligned, ldz a multiple of 4 and >= D");
   CDML_REQUIRE((2 * (int64_t)B) % 256 == 0 && D % 64 == 0, CDML_E_UNSUPPORTED,
                "semihard_mine_x3: 2 B must be a multiple of 256 and D of 64, got B=%d D=%d", B, D);
   CDML_REQUIRE(aligned16(e) && !(lde & 3) && lde >= D && aligned16(e_planes) && !(ldp & 7) && !(plane & 7) && plane >= D &&
-                   ldp >= 2 * plane + D && aligned16(workspace) && aligned16(rows) && aligned16(sqn),
+                   ldp >= (h2_scale > 0.f ? 1 : 2) * plane + D && aligned16(workspace) && aligned16(rows) && aligned16(sqn),
                CDML_E_ALIGN, "semihard_mine_x3: 16-B aligned bases, lde a multiple of 4, ldp / plane multiples of 8, ldp >= 2 plane + D");
   CDML_REQUIRE(workspace_bytes >= cdml_semihard_mine_x3_workspace(B), CDML_E_BADARG,
                "semihard_mine_x3: workspace of %zu bytes required", cdml_semihard_mine_x3_workspace(B));
@@ -660,19 +674,22 @@ static int semihard_mine_x3_impl(const float *e, float *e_out, int64_t lde, cons
                "semihard_mine_x3: the embedded rows exceed the 2 GiB buffer-descriptor range");
   hipStream_t s = (hipStream_t)stream;
   bf16 *e3 = reinterpret_cast<bf16 *>(e_planes);
-  hipLaunchKernelGGL(k_mine_prep, dim3(grid1d((int64_t)B * 64)), dim3(kThreads), 0, s, e, e_out, lde, z, ldz, B, D, e3, ldp, plane, sqn, dp);
+  hipLaunchKernelGGL(k_mine_prep, dim3(grid1d((int64_t)B * 64)), dim3(kThreads), 0, s, e, e_out, lde, z, ldz, B, D, e3, ldp, plane, sqn, dp,
+                     h2_scale);
   int rc = check_launch("semihard_mine_x3 prep");
   if (rc) return rc;
   BArgs g{};
   g.A = e3; g.lda = 2 * ldp;                                // anchors = even rows
   g.B = e3; g.ldb = ldp;
   g.M = B; g.N = 2 * B;
-  g.x3_tpp = D / 64; g.x3_plane_a = plane; g.x3_plane_b = plane; g.x3_products = 6;
-  g.K = 6 * g.x3_tpp * 64; g.k_per_split = g.K;
+  const int prod = h2_scale > 0.f ? 3 : 6;
+  g.x3_tpp = D / 64; g.x3_plane_a = plane; g.x3_plane_b = plane; g.x3_products = prod;
+  g.K = prod * g.x3_tpp * 64; g.k_per_split = g.K;
   g.tiles_m = (B + 255) / 256; g.tiles_n = 2 * B / 256;
   g.mine_sqn = sqn; g.mine_ids = rows; g.mine_dp = dp;
   g.mine_out = static_cast<MineCand *>(workspace); g.mine_ld = B;
-  rc = launch_gemm_x3_mine(g, s);
+  g.out_scale = h2_scale > 0.f ? 1.0f / (h2_scale * h2_scale) : 1.0f; g.c_scale = 1.0f;
+  rc = h2_scale > 0.f ? launch_gemm_f16x2_mine(g, s) : launch_gemm_x3_mine(g, s);
   if (rc) return rc;
   hipLaunchKernelGGL(k_semihard_finish, dim3((B + 63) / 64), dim3(kThreads), 0, s, static_cast<const MineCand *>(workspace),
                      (int64_t)B, g.tiles_n * 4, B, neg_row_out);
@@ -694,6 +711,17 @@ extern "C" int cdml_semihard_mine_x3_z(const float *z, int64_t ldz, float *e, in
   CDML_REQUIRE(z, CDML_E_BADARG, "semihard_mine_x3_z: z required");
   return semihard_mine_x3_impl(e, e, lde, z, ldz, rows, B, D, e_planes, ldp, plane, sqn, dp, workspace, workspace_bytes,
                                neg_row_out, stream);
+}
+
+// cdml_semihard_mine_x3 / _z (z nullable: e given when it is) with the score product on TWO fp16 planes per row -- the rows
+// times `scale` (a power of two; 2^14 for unit rows), three plane products on the fp16 MFMA (precision "f16x2"): e_planes =
+// fp16 [2B][ldp], ldp >= plane + D.
+extern "C" int cdml_semihard_mine_h2(const float *z, int64_t ldz, float *e, int64_t lde, const int32_t *rows, int B, int D,
+                                     uint16_t *e_planes, int64_t ldp, int64_t plane, float scale, float *sqn, float *dp,
+                                     void *workspace, size_t workspace_bytes, int32_t *neg_row_out, cdml_stream_t stream) {
+  CDML_REQUIRE(scale > 0.f, CDML_E_BADARG, "semihard_mine_h2: a positive scale");
+  return semihard_mine_x3_impl(e, z ? e : nullptr, lde, z, ldz, rows, B, D, e_planes, ldp, plane, sqn, dp, workspace, workspace_bytes,
+                               neg_row_out, stream, scale);
 }
 
 // ---- k8-interleaved operands for the weight gradients (round 5) ---------------------------------------------------------

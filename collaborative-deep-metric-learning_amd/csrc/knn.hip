@@ -222,16 +222,18 @@ extern "C" int cdml_knn_list_capacity(void) { return kListCap; }
 // kernels (six bf16 plane products per fp32 product) whose epilogue appends every element with d <= tau[query] to the
 // query's candidate list.  Q, Bk: fp32 rows as three bf16 planes [rows][hi D | mid D | lo D] (plane strides plane_q /
 // plane_b); n_cols (multiple of 256) catalogue rows starting at catalogue row col0, rows >= n_valid are padding.
-extern "C" int cdml_knn_filter_x3(const uint16_t *Q, int64_t ldq, int64_t plane_q, const uint16_t *Bk, int64_t ldb,
-                                  int64_t plane_b, int nq, int n_cols, int D, const float *q_sq, const float *b_sq,
-                                  const float *tau, int col0, int n_valid, int32_t *cnt, void *cand, int cap,
-                                  cdml_stream_t stream) {
+static int knn_filter_impl(float out_scale, const uint16_t *Q, int64_t ldq, int64_t plane_q, const uint16_t *Bk, int64_t ldb,
+                           int64_t plane_b, int nq, int n_cols, int D, const float *q_sq, const float *b_sq,
+                           const float *tau, int col0, int n_valid, int32_t *cnt, void *cand, int cap,
+                           cdml_stream_t stream) {
+  const bool h2 = out_scale > 0.f;                           // two fp16 planes per row, three products (cdml_knn_filter_h2)
+  const int np1 = h2 ? 1 : 2;
   CDML_REQUIRE(Q && Bk && q_sq && b_sq && tau && cnt && cand, CDML_E_BADARG, "knn_filter_x3: null pointer");
   CDML_REQUIRE(nq > 0 && n_cols > 0 && D > 0 && cap > 0 && col0 >= 0 && n_valid > 0, CDML_E_BADARG, "knn_filter_x3: bad size");
   CDML_REQUIRE(n_cols % 256 == 0 && D % 64 == 0, CDML_E_UNSUPPORTED,
                "knn_filter_x3: the catalogue block must be a multiple of 256 rows and D of 64, got %d, %d", n_cols, D);
   CDML_REQUIRE(aligned16(Q) && aligned16(Bk) && aligned16(b_sq) && !(ldq & 7) && !(ldb & 7) && !(plane_q & 7) && !(plane_b & 7) &&
-                   plane_q >= D && plane_b >= D && ldq >= 2 * plane_q + D && ldb >= 2 * plane_b + D &&
+                   plane_q >= D && plane_b >= D && ldq >= np1 * plane_q + D && ldb >= np1 * plane_b + D &&
                    (reinterpret_cast<uintptr_t>(cand) & 7) == 0,
                CDML_E_ALIGN, "knn_filter_x3: 16-B aligned operands, strides multiples of 8, ld >= 2 plane + D");
   CDML_REQUIRE(((int64_t)nq + 256) * ldq * 2 < ((int64_t)1 << 31) && (int64_t)n_cols * ldb * 2 < ((int64_t)1 << 31), CDML_E_UNSUPPORTED,
@@ -241,12 +243,31 @@ extern "C" int cdml_knn_filter_x3(const uint16_t *Q, int64_t ldq, int64_t plane_
   g.A = reinterpret_cast<const bf16 *>(Q); g.lda = ldq;
   g.B = reinterpret_cast<const bf16 *>(Bk); g.ldb = ldb;
   g.M = nq; g.N = n_cols;
-  g.x3_tpp = D / 64; g.x3_plane_a = plane_q; g.x3_plane_b = plane_b; g.x3_products = 6;
-  g.K = 6 * g.x3_tpp * 64; g.k_per_split = g.K;
+  const int prod = h2 ? 3 : 6;
+  g.x3_tpp = D / 64; g.x3_plane_a = plane_q; g.x3_plane_b = plane_b; g.x3_products = prod;
+  g.K = prod * g.x3_tpp * 64; g.k_per_split = g.K;
+  g.out_scale = h2 ? out_scale : 1.0f; g.c_scale = 1.0f;
   g.tiles_m = (nq + 255) / 256; g.tiles_n = n_cols / 256;
   g.knn_qsq = q_sq; g.knn_bsq = b_sq; g.knn_tau = tau; g.knn_cnt = cnt; g.knn_cand = static_cast<uint2 *>(cand);
   g.knn_cap = cap; g.knn_col0 = col0; g.knn_n_valid = n_valid;
-  return launch_gemm_x3_knn(g, (hipStream_t)stream);
+  return h2 ? launch_gemm_f16x2_knn(g, (hipStream_t)stream) : launch_gemm_x3_knn(g, (hipStream_t)stream);
+}
+
+extern "C" int cdml_knn_filter_x3(const uint16_t *Q, int64_t ldq, int64_t plane_q, const uint16_t *Bk, int64_t ldb,
+                                  int64_t plane_b, int nq, int n_cols, int D, const float *q_sq, const float *b_sq,
+                                  const float *tau, int col0, int n_valid, int32_t *cnt, void *cand, int cap,
+                                  cdml_stream_t stream) {
+  return knn_filter_impl(0.f, Q, ldq, plane_q, Bk, ldb, plane_b, nq, n_cols, D, q_sq, b_sq, tau, col0, n_valid, cnt, cand, cap, stream);
+}
+
+// The same filter on TWO fp16 planes per row (cdml_split_f32_f16x2 of the queries at scale sq, of the catalogue at sb):
+// out_scale = 1 / (sq sb) multiplies the accumulated inner product; three plane products on the fp16 MFMA.
+extern "C" int cdml_knn_filter_h2(const uint16_t *Q, int64_t ldq, int64_t plane_q, const uint16_t *Bk, int64_t ldb,
+                                  int64_t plane_b, int nq, int n_cols, int D, float out_scale, const float *q_sq,
+                                  const float *b_sq, const float *tau, int col0, int n_valid, int32_t *cnt, void *cand, int cap,
+                                  cdml_stream_t stream) {
+  CDML_REQUIRE(out_scale > 0.f, CDML_E_BADARG, "knn_filter_h2: a positive out_scale");
+  return knn_filter_impl(out_scale, Q, ldq, plane_q, Bk, ldb, plane_b, nq, n_cols, D, q_sq, b_sq, tau, col0, n_valid, cnt, cand, cap, stream);
 }
 
 // Merge every query's candidate list (cdml_knn_filter_x3) into its running top-k list (best_d / best_i: [nq][list capacity],

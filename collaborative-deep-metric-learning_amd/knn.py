@@ -47,19 +47,31 @@ def _planes(x, Dp):
     return out
 
 
+def _planes_h2(x, Dp):
+    """two fp16 planes of x * 2^s, s from the tensor's maximum (a host read: the export is not a step path); (planes, scale)"""
+    from .engine_f16x2 import pow2_for
+    scale = pow2_for(float(x.abs().amax()), 2.0 ** 13) or 1.0
+    out = torch.empty((x.shape[0], 2 * Dp), dtype=torch.float16, device=x.device)
+    ops.split_f32_f16x2(x, out, Dp, scale)
+    return out, scale
+
+
 def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK, b_block=B_BLOCK, precision="f32x3",
                fused=True, first_block=FIRST_BLOCK, q_chunk=262144, c_chunk=1048576):
     """Device tensors (D [nq,k] fp32 squared L2 ascending, I [nq,k] int64; -1 where
     the catalogue has fewer than k rows).  ``precision``: "f32x3" (default; round 6) = the inner products on the plane
     kernels -- the headline path's arithmetic: every fp32 operand as three exact bf16 planes, six plane products per fp32
-    product on the bf16 MFMA (csrc/gemm_bf16x3.hip), errors those of the fp32 kernels -- or "f32" = the fp32 MFMA.
+    product on the bf16 MFMA (csrc/gemm_bf16x3.hip), errors those of the fp32 kernels -- "f16x2" = two fp16 planes per
+    operand under one scale per tensor, three products on the fp16 MFMA (csrc/gemm_f16x2_256.hip; unit rows need no range
+    management) -- or "f32" = the fp32 MFMA.
     ``fused`` (precision "f32x3", catalogues of more than two first blocks): everything after the first ``first_block``
     catalogue rows through the filter epilogue instead of score blocks (False: score blocks throughout, the round-5 form);
     ``q_chunk`` queries x ``c_chunk`` catalogue rows per filter launch (operands inside a descriptor's 2 GiB window, candidate
     buffer q_chunk x list capacity x 8 B), the lists merged -- and every query's threshold tightened -- after each."""
-    if precision not in ("f32x3", "f32"):
-        raise ValueError("precision must be 'f32x3' or 'f32'")
-    x3 = precision == "f32x3"
+    if precision not in ("f32x3", "f32", "f16x2"):
+        raise ValueError("precision must be 'f32x3', 'f16x2' or 'f32'")
+    h2 = precision == "f16x2"
+    x3 = precision == "f32x3" or h2                          # (the plane forms)
     cap = ops.knn_list_capacity()
     if not 1 <= k <= cap:
         raise ValueError("nearest_num must be in [1, %d]" % cap)
@@ -68,9 +80,10 @@ def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK,
     if queries.shape[1] != D:
         raise ValueError("query / catalogue dimension mismatch")
     b_block = _round_up(min(b_block, _round_up(nb, 64)), 256 if x3 else 64)
-    B = _device_matrix(base, device, b_block, 64 if x3 else 32)
+    colm = 128 if h2 else 64 if x3 else 32
+    B = _device_matrix(base, device, b_block, colm)
     same = queries is base
-    Q = B if same else _device_matrix(queries, device, 1, 64 if x3 else 32)
+    Q = B if same else _device_matrix(queries, device, 1, colm)
     Dp = B.shape[1]
     if l2_norm:                                              # faiss_knn.py:99-104
         ops.l2norm_fwd(B[:nb], Dp, B)
@@ -87,7 +100,11 @@ def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK,
     best_i = torch.empty((nq, cap), dtype=torch.int32, device=device)
     q_block = min(q_block, nq)
     scores = torch.empty((q_block, b_block), dtype=torch.float32, device=device)
-    if x3:
+    if h2:
+        B3, sb = _planes_h2(B, Dp)
+        Q3, sq = (B3, sb) if same else _planes_h2(Q, Dp)
+        osc = 1.0 / (sq * sb)
+    elif x3:
         B3 = _planes(B, Dp)
         Q3 = B3 if same else _planes(Q, Dp)
     n_pad = B.shape[0]
@@ -120,7 +137,9 @@ def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK,
             m = min(q_block, qs + mq - q0)
             for c0 in range(0, first_cols, b_block):
                 # scores[m, b_block] = Q[q0:q0+m] @ B[c0:c0+b_block]^T
-                if x3:
+                if h2:
+                    ops.gemm_f16x2_nt(ops.BE_F32, Q3[q0:q0 + m], Dp, B3[c0:c0 + b_block], Dp, scores, m, b_block, Dp, osc)
+                elif x3:
                     ops.gemm_bf16x3_nt(ops.BE_F32, Q3[q0:q0 + m], Dp, B3[c0:c0 + b_block], Dp, scores, m, b_block, Dp)
                 else:
                     ops.fc_bwd_data(Q[q0:q0 + m], B[c0:c0 + b_block], None, scores, m, b_block, Dp)
@@ -131,8 +150,12 @@ def knn_search(base, queries, k, l2_norm=True, device="cuda:0", q_block=Q_BLOCK,
         for c0 in range(first_cols, n_pad, c_chunk):
             nc = min(c_chunk, n_pad - c0)
             tau = best_d[qs:qs + mq, k - 1].contiguous()     # the k-th best so far: every merged chunk tightens it
-            ops.knn_filter_x3(Q3[qs:qs + mq], Dp, B3[c0:c0 + nc], Dp, mq, nc, Dp, q_sq[qs:qs + mq], b_sq[c0:c0 + nc], tau, c0, nb,
-                              cnt, cand, list_cap)
+            if h2:
+                ops.knn_filter_h2(Q3[qs:qs + mq], Dp, B3[c0:c0 + nc], Dp, mq, nc, Dp, osc, q_sq[qs:qs + mq], b_sq[c0:c0 + nc], tau, c0,
+                                  nb, cnt, cand, list_cap)
+            else:
+                ops.knn_filter_x3(Q3[qs:qs + mq], Dp, B3[c0:c0 + nc], Dp, mq, nc, Dp, q_sq[qs:qs + mq], b_sq[c0:c0 + nc], tau, c0, nb,
+                                  cnt, cand, list_cap)
             ops.knn_merge_list(cand, cnt, list_cap, mq, k, best_d[qs:qs + mq], best_i[qs:qs + mq], overflow)
     if use_filter and int(overflow.item()):                  # (a sync; the export is not a step path)
         return knn_search(base, queries, k, l2_norm=l2_norm, device=device, q_block=q_block, b_block=b_block,

@@ -271,12 +271,18 @@ def semihard_mine_x3_workspace(B):
     return int(load_library().cdml_semihard_mine_x3_workspace(B))
 
 
-def semihard_mine_x3(e, rows, B, D, e_planes, plane, sqn, dp, workspace, neg_row_out, z=None):
+def semihard_mine_x3(e, rows, B, D, e_planes, plane, sqn, dp, workspace, neg_row_out, z=None, h2_scale=0.0):
     """cdml_semihard_select's result without the score matrix: the B x 2B product on the plane kernels, the selection
     as its epilogue (csrc/gemm_bf16x3.hip).  e_planes bf16 [2B, >= 3 plane], sqn f32[2B], dp f32[B], workspace f32.
-    ``z`` given: the un-normalised output rows -- the prep launch normalises them and WRITES ``e`` (cdml_semihard_mine_x3_z)."""
+    ``z`` given: the un-normalised output rows -- the prep launch normalises them and WRITES ``e`` (cdml_semihard_mine_x3_z).
+    ``h2_scale`` > 0: the score product on two fp16 planes of e * h2_scale (e_planes fp16 [2B, >= 2 plane]; cdml_semihard_mine_h2)."""
     ep, eld = _mat(e)
     pp, pld = _mat16(e_planes)
+    if h2_scale:
+        zp, zld = (C.c_void_p(0), 0) if z is None else _mat(z)
+        call("cdml_semihard_mine_h2", zp, zld, ep, eld, _p(rows, torch.int32), B, D, pp, pld, plane, float(h2_scale), _p(sqn), _p(dp),
+             _p(workspace), workspace.numel() * workspace.element_size(), _p(neg_row_out, torch.int32), _stream())
+        return neg_row_out
     if z is not None:
         zp, zld = _mat(z)
         call("cdml_semihard_mine_x3_z", zp, zld, ep, eld, _p(rows, torch.int32), B, D, pp, pld, plane, _p(sqn), _p(dp),
@@ -368,6 +374,16 @@ def knn_filter_x3(Q3, plane_q, B3, plane_b, nq, n_cols, D, q_sq, b_sq, tau, col0
         raise ValueError("cand must be a contiguous int32 buffer of nq * cap * 2 words")
     call("cdml_knn_filter_x3", qp, qld, plane_q, bp, bld, plane_b, nq, n_cols, D, _p(q_sq), _p(b_sq), _p(tau), col0, n_valid,
          _p(cnt, torch.int32), _p(cand, torch.int32), cap, _stream())
+
+
+def knn_filter_h2(Q2, plane_q, B2, plane_b, nq, n_cols, D, out_scale, q_sq, b_sq, tau, col0, n_valid, cnt, cand, cap):
+    """knn_filter_x3 on two fp16 planes per row (split_f32_f16x2 at scales sq / sb; out_scale = 1 / (sq sb))."""
+    qp, qld = _mat16(Q2)
+    bp, bld = _mat16(B2)
+    if cand.dtype != torch.int32 or not cand.is_contiguous() or cand.numel() < nq * cap * 2:
+        raise ValueError("cand must be a contiguous int32 buffer of nq * cap * 2 words")
+    call("cdml_knn_filter_h2", qp, qld, plane_q, bp, bld, plane_b, nq, n_cols, D, float(out_scale), _p(q_sq), _p(b_sq), _p(tau), col0,
+         n_valid, _p(cnt, torch.int32), _p(cand, torch.int32), cap, _stream())
 
 
 def knn_merge_list(cand, cnt, cap, nq, k, best_d, best_i, overflow):

@@ -184,12 +184,14 @@ class TrainStep:
             # precision f32x3: the score product on the plane kernels with the selection as its epilogue -- no B x 2B
             # score matrix (537 MB at B = 8192) is written or scanned (csrc/gemm_bf16x3.hip; CDML_MINE_FUSED=0: the
             # round-2 form, for A/B runs); the fp32-MFMA and bf16 paths keep the score matrix
-            # (precision f16x2 mines on the same six-plane kernel: the miner makes its own bf16 planes of the fp32 embeddings)
+            # (precision f16x2: the same epilogue on the fp16 build of the kernel, cdml_semihard_mine_h2)
             self.mine_fused = ((precision == "f32x3" or self.h2) and (2 * self.B) % 256 == 0 and self.layout.Dp % 64 == 0
                                and os.environ.get("CDML_MINE_FUSED", "1") != "0")
             if self.mine_fused:
                 Dp = self.layout.Dp
-                self.e3 = torch.zeros((2 * self.B, 3 * Dp), dtype=torch.bfloat16, device=dev)
+                # (f16x2: the miner's score product on two fp16 planes of the unit rows times 2^14 -- no range to manage)
+                self.e3 = (torch.zeros((2 * self.B, 2 * Dp), dtype=torch.float16, device=dev) if self.h2
+                           else torch.zeros((2 * self.B, 3 * Dp), dtype=torch.bfloat16, device=dev))
                 self.dp = torch.zeros(self.B, dtype=f32, device=dev)
                 self.mine_ws = torch.zeros(ops.semihard_mine_x3_workspace(self.B) // 4, dtype=f32, device=dev)
             else:
@@ -470,7 +472,7 @@ class TrainStep:
             e = self.ws.e
             if self.mine_fused:
                 ops.semihard_mine_x3(e, self.idx, self.B, L.Dp, self.e3, L.Dp, self.sqn, self.dp, self.mine_ws, self.neg_row,
-                                     z=self.ws.z if mine_norm else None)
+                                     z=self.ws.z if mine_norm else None, h2_scale=engine_f16x2.X_SCALE if self.h2 else 0.0)
             else:
                 # S[i][c] = <anchor_i, row_c>: the data-gradient GEMM (x @ W^T) with no mask
                 ops.fc_bwd_data(e[0::2], e, None, self.S, self.B, 2 * self.B, L.Dp)

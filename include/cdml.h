@@ -565,6 +565,17 @@ int cdml_vnet_tail_h2(int mode, const float *z, int64_t ldz, const int32_t *rows
                       uint8_t *valid_out, float *dz2, int64_t lddz2, uint16_t *dz2_planes,
                       int64_t ldbf, int64_t plane_h, float scale, float *stats, float *var_ws,
                       cdml_stream_t stream);
+/* cdml_semihard_mine_x3 / _z (z nullable) and cdml_knn_filter_x3 with their score products on two fp16 planes per row --
+ * the rows times `scale` (unit rows: 2^14), three plane products on the fp16 MFMA; e_planes = fp16 [2B][ldp >= plane + D];
+ * cdml_knn_filter_h2: Q / Bk from cdml_split_f32_f16x2 at scales sq / sb, out_scale = 1 / (sq sb). */
+int cdml_semihard_mine_h2(const float *z, int64_t ldz, float *e, int64_t lde, const int32_t *rows, int B, int D,
+                          uint16_t *e_planes, int64_t ldp, int64_t plane, float scale, float *sqn_scratch,
+                          float *dp_scratch, void *workspace, size_t workspace_bytes, int32_t *neg_row_out,
+                          cdml_stream_t stream);
+int cdml_knn_filter_h2(const uint16_t *Q, int64_t ldq, int64_t plane_q, const uint16_t *Bk, int64_t ldb,
+                       int64_t plane_b, int nq, int n_cols, int D, float out_scale, const float *q_sq,
+                       const float *b_sq, const float *tau, int col0, int n_valid, int32_t *cnt, void *cand,
+                       int cap, cdml_stream_t stream);
 int cdml_lars_matrix_h2(float *w, const float *g, float *acc, const int64_t *seg_offsets, const int64_t *seg_sizes,
                         int n_seg, int seg_matrix, int seg_bias, int K, int N, float lr, const float *lr_dev,
                         float momentum, float weight_decay, float eeta, float eps, const float *scratch,

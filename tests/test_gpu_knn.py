@@ -32,11 +32,15 @@ def embeddings(n, D, seed):
     return rng.randn(n, D).astype(np.float32)
 
 
+PLANE_FORMS = ["f32x3", "f16x2"]      # three bf16 planes x six products | two fp16 planes x three products (round 6)
+
+
+@pytest.mark.parametrize("precision", PLANE_FORMS)
 @pytest.mark.parametrize("n,D,k", [(1000, 256, 51), (333, 48, 128), (20, 256, 51), (64, 32, 1)])
-def test_self_knn_matches_exact_search(n, D, k):
+def test_self_knn_matches_exact_search(n, D, k, precision):
     from cdml_amd import knn
     e = embeddings(n, D, 0)
-    Dg, Ig = knn.calc_knn(e.copy(), nearest_num=k)
+    Dg, Ig = knn.calc_knn(e.copy(), nearest_num=k, precision=precision)
     Dr, Ir, dfull = oknn.calc_knn_exact(e, nearest_num=k)
     assert Dg.dtype == np.float32 and Ig.dtype == np.int64 and Dg.shape == (n, k)
     check(Dg, Ig, Dr, Ir, dfull)
@@ -71,7 +75,8 @@ def test_bad_k_is_refused():
         knn.calc_knn(embeddings(10, 32, 0), nearest_num=129)
 
 
-def test_filter_epilogue_matches_exact_search_and_falls_back_on_overflow():
+@pytest.mark.parametrize("precision", PLANE_FORMS)
+def test_filter_epilogue_matches_exact_search_and_falls_back_on_overflow(precision):
     """Round 6: everything after the first block of the catalogue goes through ONE launch of the plane GEMM whose epilogue
     appends the elements within a query's k-th best distance to its candidate list (no score matrix).  (i) 70 000 rows,
     separate queries, exact (D, I) against the fp64 oracle, identical to the score-block form; (ii) a catalogue laid out
@@ -81,14 +86,14 @@ def test_filter_epilogue_matches_exact_search_and_falls_back_on_overflow():
     base = embeddings(70000, 64, 5)
     base[40000:40008] = base[123]                               # exact duplicates across the block boundary: ties by id
     q = np.concatenate([embeddings(200, 64, 6), base[123:124]])
-    D, I = knn.knn_search(torch.from_numpy(base), torch.from_numpy(q), 51)
+    D, I = knn.knn_search(torch.from_numpy(base), torch.from_numpy(q), 51, precision=precision)
     Dr, Ir, dfull = oknn.calc_knn_exact(base, q, 51)
     check(D.cpu().numpy(), I.cpu().numpy(), Dr, Ir, dfull)
     assert sorted(I[-1, :9].cpu().tolist()) == [123] + list(range(40000, 40008))
-    D2, I2 = knn.knn_search(torch.from_numpy(base), torch.from_numpy(q), 51, fused=False)
+    D2, I2 = knn.knn_search(torch.from_numpy(base), torch.from_numpy(q), 51, fused=False, precision=precision)
     assert torch.equal(I, I2) and torch.equal(D, D2)
     # queries and catalogue in several chunks (each merged, the thresholds tightened in between): the same answer
-    D4, I4 = knn.knn_search(torch.from_numpy(base), torch.from_numpy(q), 51, q_block=64, q_chunk=128, c_chunk=8192)
+    D4, I4 = knn.knn_search(torch.from_numpy(base), torch.from_numpy(q), 51, q_block=64, q_chunk=128, c_chunk=8192, precision=precision)
     assert torch.equal(I, I4) and torch.equal(D, D4)
     rng = np.random.RandomState(7)
     centre = rng.randn(64).astype(np.float32)
@@ -96,13 +101,14 @@ def test_filter_epilogue_matches_exact_search_and_falls_back_on_overflow():
     near = centre + 0.05 * rng.randn(37000, 64).astype(np.float32)   # the rest: a tight cluster around the queries
     base2 = np.concatenate([far, near])
     q2 = centre + 0.05 * rng.randn(50, 64).astype(np.float32)
-    D3, I3 = knn.knn_search(torch.from_numpy(base2), torch.from_numpy(q2), 20)
+    D3, I3 = knn.knn_search(torch.from_numpy(base2), torch.from_numpy(q2), 20, precision=precision)
     Dr3, Ir3, dfull3 = oknn.calc_knn_exact(base2, q2, 20)
     check(D3.cpu().numpy(), I3.cpu().numpy(), Dr3, Ir3, dfull3)
     assert (I3.cpu().numpy() >= 33000).all()
 
 
-def test_self_knn_at_the_reference_catalogue_size():
+@pytest.mark.parametrize("precision", PLANE_FORMS)
+def test_self_knn_at_the_reference_catalogue_size(precision):
     """the export at the reference's own scale -- doc_location = 343455 embeddings (faiss_knn.py:389), 256-d,
     nearest_num = 51 -- against a blocked EXACT search in fp64 on the device (torch: 2 048 queries x the whole catalogue
     per block).  Every returned neighbour's true distance lies within tolerance of the exact k-th distance (ids may swap
@@ -114,7 +120,7 @@ def test_self_knn_at_the_reference_catalogue_size():
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     e = torch.randn(n, D, device=dev, generator=g)
-    Dg, Ig = knn.knn_search(e, e, k)
+    Dg, Ig = knn.knn_search(e, e, k, precision=precision)
     torch.cuda.synchronize()
     assert Dg.shape == (n, k) and Ig.dtype == torch.int64
     assert bool((Ig[:, 0] == torch.arange(n, device=dev)).all())

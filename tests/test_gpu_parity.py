@@ -1107,12 +1107,15 @@ def _check_semihard_choice(got, want, dist, rows, B, tol=2e-6):
             assert dist[i, got[i]] >= dist[i][elig].max() - tol
 
 
+@pytest.mark.parametrize("h2", [False, True])
 @pytest.mark.parametrize("B,D", [(128, 64), (384, 256), (640, 128)])
-def test_semihard_mine_fused_into_the_score_product(cd, B, D):
+def test_semihard_mine_fused_into_the_score_product(cd, B, D, h2):
     """BASELINE config 2 on the plane kernels: cdml_semihard_mine_x3 computes the B x 2B score product as six bf16 plane
     products per fp32 product and selects in its epilogue -- no score matrix.  Spec = oracle.tower.semihard_select, checked
     with the tolerance of the unfused kernel's test; B = 384 / 640: a last row tile of 128 anchors; few videos: rows with
-    nothing eligible (-1) and the farthest-eligible fallback."""
+    nothing eligible (-1) and the farthest-eligible fallback.  h2: the same on the fp16 build of the kernel -- two fp16 planes of
+    the unit rows times 2^14, three plane products (cdml_semihard_mine_h2; precision "f16x2")."""
+    hs = 2.0 ** 14 if h2 else 0.0
     rng = np.random.RandomState(B + D)
     for trial, n_videos in enumerate((5000, 12)):
         E = otower.l2_normalize(rng.randn(2 * B, D) + (0.0 if trial else 2.0), np.float64)[0].astype(np.float32)
@@ -1120,17 +1123,21 @@ def test_semihard_mine_fused_into_the_score_product(cd, B, D):
         if trial:
             rows[:8] = 0; rows[8:] = rng.randint(0, 2, size=2 * B - 8)
         de_, dr = dt(E, cd.dev), dt(rows, cd.dev, torch.int32)
-        e3 = torch.zeros((2 * B, 3 * D), dtype=torch.bfloat16, device=cd.dev)
+        e3 = (torch.zeros((2 * B, 2 * D), dtype=torch.float16, device=cd.dev) if h2
+              else torch.zeros((2 * B, 3 * D), dtype=torch.bfloat16, device=cd.dev))
         sqn, dpd = torch.zeros(2 * B, device=cd.dev), torch.zeros(B, device=cd.dev)
         wsb = cd.ops.semihard_mine_x3_workspace(B)
         assert wsb == (2 * B // 256) * 4 * B * 16
         wsp = torch.full((wsb // 4,), float("nan"), device=cd.dev)
         neg_row = torch.full((B,), -7, dtype=torch.int32, device=cd.dev)
-        cd.ops.semihard_mine_x3(de_, dr, B, D, e3, D, sqn, dpd, wsp, neg_row)
+        cd.ops.semihard_mine_x3(de_, dr, B, D, e3, D, sqn, dpd, wsp, neg_row, h2_scale=hs)
         got = neg_row.cpu().numpy()
         want, dist = otower.semihard_select(E.astype(np.float64), rows)
-        # the prep pass: exact planes, squared norms and positive distances
-        assert torch.equal(e3[:, :D].float() + e3[:, D:2 * D].float() + e3[:, 2 * D:].float(), de_)
+        # the prep pass: exact planes (fp16 pair: 22 bits of them), squared norms and positive distances
+        if h2:
+            assert ((e3[:, :D].double() + e3[:, D:].double()) / hs - de_.double()).abs().max().item() <= 2.0 ** -22
+        else:
+            assert torch.equal(e3[:, :D].float() + e3[:, D:2 * D].float() + e3[:, 2 * D:].float(), de_)
         np.testing.assert_allclose(sqn.cpu().numpy(), (E.astype(np.float64) ** 2).sum(1), atol=1e-6)
         np.testing.assert_allclose(dpd.cpu().numpy(), dist[np.arange(B), 2 * np.arange(B) + 1], atol=2e-6)
         _check_semihard_choice(got, want, dist, rows, B)
@@ -1146,7 +1153,7 @@ def test_semihard_mine_fused_into_the_score_product(cd, B, D):
             assert (old.cpu().numpy() == got).mean() > 0.95
         # deterministic
         again = torch.empty_like(neg_row)
-        cd.ops.semihard_mine_x3(de_, dr, B, D, e3, D, sqn, dpd, wsp, again)
+        cd.ops.semihard_mine_x3(de_, dr, B, D, e3, D, sqn, dpd, wsp, again, h2_scale=hs)
         assert torch.equal(again, neg_row)
 
 
