@@ -512,12 +512,16 @@ def gather_record(ts, mode, bf16, dev, pmc_name=None, workload=None):
     gk = "k_sample_gather<%d," % (1 if rpt == 2 else 0)       # <mode, RowF32<6>> / <mode, RowF16<3>>
     gbytes = n_st * R * F * (2 + 2.0) if bf16 else n_st * 2.0 * R * F * 4     # rows read + normalised rows written
     x3 = (not bf16) and ts.ws.x_hat.dtype == torch.bfloat16
+    h2 = (not bf16) and ts.ws.x_hat.dtype == torch.float16      # precision f16x2: fp32 rows read, two fp16 planes written
     ki = x3 and getattr(ts.ws, "xk", None) is not None
     if x3:
         # fp32 rows read, three bf16 planes written -- twice where the launch also writes the k8-interleaved copy the
         # first layer's weight gradient reads (round 5)
         gbytes = n_st * R * F * (4 + (12.0 if ki else 6.0))
         gk = "k_sample_gather<%d, RowF32X3" % (1 if rpt == 2 else 0)
+    if h2:
+        gbytes = n_st * R * F * (4 + 4.0)
+        gk = "k_sample_gather<%d, RowF32H2" % (1 if rpt == 2 else 0)
     nxt = [ts.global_step + 1000]                   # fresh steps every launch: re-reading the same rows
                                                     # would be served from the 256 MB Infinity Cache
 
@@ -541,7 +545,8 @@ def gather_record(ts, mode, bf16, dev, pmc_name=None, workload=None):
     torch.cuda.synchronize(dev)
     t_g = float(np.median([s.elapsed_time(e) for s, e in evs])) / per
     g_ach = gbytes / (t_g * 1e-3) / 1e9
-    tr, src = (pmc_traffic("k_sample_gather<%d," % (1 if rpt == 2 else 0), name=pmc_name or "latest_pmc_x3", workload=workload) if x3
+    tr, src = ((None, None) if h2 else
+               pmc_traffic("k_sample_gather<%d," % (1 if rpt == 2 else 0), name=pmc_name or "latest_pmc_x3", workload=workload) if x3
                else pmc_traffic(gk, bf16, name=pmc_name, workload=workload))
     # Which bytes.  `achieved` / `frac` divide the bytes the launch MOVES (rows read + the operand form
     # written: three bf16 planes on the split-fp32 path) by its time -- the HBM figure, what PMC FETCH + WRITE confirms.
@@ -552,7 +557,7 @@ def gather_record(ts, mode, bf16, dev, pmc_name=None, workload=None):
     row_moved = gbytes / (n_st * R)
     row_alg = 2.0 * F * elt
     alg_ach = n_st * R * row_alg / (t_g * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": gk + ("<6>, true> (row-major planes + the k8-interleaved copy)" if ki else "<6>>" if x3 else " RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1),
+    return {"bound": "hbm", "kernel": gk + ("<6>, true> (row-major planes + the k8-interleaved copy)" if ki else "<6>>" if (x3 or h2) else " RowF16<3>>" if bf16 else " RowF32<6>>"), "achieved": round(g_ach, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(g_ach / PEAK_HBM_GBS, 4), "traffic": tr,
             "traffic_source": src, "bytes_per_launch": gbytes, "launch_ms": round(t_g, 4), "steps_per_launch": n_st,
             "bytes_per_row_moved": row_moved, "bytes_per_row_algorithmic_8d": row_alg,
@@ -940,6 +945,37 @@ def rec_other_fp32_path(dev, args, n_s, n_w, table, pairs, B, mode, other):
     return out
 
 
+def h2_records(kt, R, sampled, how):
+    """roofline / roofline_fc1_fwd / kernels of a precision-"f16x2" step from its event-timed launches (peak = the fp16 dense
+    peak / 3: three fp16 MFMA flops per algorithmic fp32 flop)."""
+    out = {}
+    if not (kt.count("dW1") and kt.count("dW2") and kt.count("fc1_fwd")):
+        return out
+    peak = round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1)          # (the fp16 dense peak of the part is the bf16 one)
+    n_launch = kt.count("dW1") + kt.count("dW2")
+    t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
+    flop_launch = sampled * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
+    ach = flop_launch / (t_ms * 1e-3) / 1e12
+    out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_f16x2_256<true, 3, true, true> (dW1+dW2 launches: fp32 products as 3 fp16 "
+                       "plane products; achieved = fp32-equivalent rate, peak = fp16 dense peak / 3)", "achieved": round(ach, 2),
+                       "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launch_ms": round(t_ms, 4),
+                       "flop_per_launch": flop_launch, "launches_per_step": n_launch / sampled, "timed_steps": sampled,
+                       "timed_how": how}
+    ach1 = 2.0 * R * F * H / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
+    out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": "k_gemm_f16x2_256<false, 6, true, true>", "achieved": round(ach1, 2),
+                               "peak": peak, "unit": "TFLOP/s", "frac": round(ach1 / peak, 4),
+                               "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": 2.0 * R * F * H}
+    kern = {}
+    for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW1", "dW2", "adam_w1", "adam_w2", "split_planes"):
+        if kt.mean_ms(k) is not None:
+            kern[k + "_ms"] = round(kt.mean_ms(k), 4)
+            if kt.count(k) != sampled:
+                kern[k + "_launches_per_step"] = round(kt.count(k) / sampled, 2)
+    kern["empty_event_pair_ms"] = round(kt.overhead_ms, 5)
+    out["kernels"] = kern
+    return out
+
+
 F16X2_DTYPE = ("f32 values as 2 fp16 planes of (value x a per-tensor power of two): hi + lo holds 22 significant bits; 3 fp16-MFMA "
                "plane products per f32 product, f32 accumulate; delayed per-tensor scales (engine_f16x2.py)")
 
@@ -978,7 +1014,6 @@ def rec_f16x2(dev, args, n_s, n_w, table, pairs, B, mode):
     n, w = max(n_s, 100), max(n_w, 10)
     el, kt, sampled, how = measure_job(ts, n, w, dev, "h2")
     R = ts.R
-    peak = round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1)          # (the fp16 dense peak of the part is the bf16 one)
     out = {"workload": "the headline's: %d videos x 1500-d fp32 in HBM, batch %d triplets, %s negatives, Adam, full step -- with "
                        "precision f16x2" % (table.n_rows, B, mode),
            "value": round(B * n / el, 1), "unit": "triplets/s", "ms_per_step": round(el / n * 1e3, 4), "steps": n, "warmup": w,
@@ -988,26 +1023,7 @@ def rec_f16x2(dev, args, n_s, n_w, table, pairs, B, mode):
                                "(checked at steps 0, 1, 2, 4 .. 64 and every 64th: two device-to-host copies each, inside the timed region)"
                                % (ts.ws.scales.changes, ts.global_step),
            "gather_steps_per_launch": ts.gather_ahead}
-    if kt.count("dW1") and kt.count("dW2") and kt.count("fc1_fwd"):
-        n_launch = kt.count("dW1") + kt.count("dW2")
-        t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
-        flop_launch = sampled * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
-        ach = flop_launch / (t_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_f16x2_256<true, 3, true, true> (dW1+dW2 launches: fp32 products as 3 fp16 "
-                           "plane products; achieved = fp32-equivalent rate, peak = fp16 dense peak / 3)", "achieved": round(ach, 2),
-                           "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launch_ms": round(t_ms, 4),
-                           "flop_per_launch": flop_launch, "launches_per_step": n_launch / sampled, "timed_steps": sampled,
-                           "timed_how": how}
-        ach1 = 2.0 * R * F * H / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
-        out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": "k_gemm_f16x2_256<false, 6, true, true>", "achieved": round(ach1, 2),
-                                   "peak": peak, "unit": "TFLOP/s", "frac": round(ach1 / peak, 4),
-                                   "launch_ms": round(kt.mean_ms("fc1_fwd"), 4)}
-        kern = {}
-        for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW1", "dW2", "adam_w1", "adam_w2", "split_planes"):
-            if kt.mean_ms(k) is not None:
-                kern[k + "_ms"] = round(kt.mean_ms(k), 4)
-        kern["empty_event_pair_ms"] = round(kt.overhead_ms, 5)
-        out["kernels"] = kern
+    out.update(h2_records(kt, R, sampled, how))
     # the gather writes 6 000 B of planes per row where the three bf16 planes are 9 000
     reps, per, n_st = 5, 10, ts.gather_ahead
     nxt = [ts.global_step + 1000]
@@ -1192,10 +1208,12 @@ def main():
     ap.add_argument("--mode", default=None, choices=["inbatch", "uniform", "semihard", "predict"])
     ap.add_argument("--batch", type=int, default=None, help="triplets per GPU per step (default 8192)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
-    ap.add_argument("--precision", default="f32x3", choices=["f32x3", "f32", "bf16", "f32x3-3"],
+    ap.add_argument("--precision", default="f32x3", choices=["f32x3", "f32", "bf16", "f32x3-3", "f16x2"],
                     help="f32x3 (default): fp32 operands as three exact bf16 planes, six plane products per fp32 product on "
                          "the bf16 MFMA, f32 accumulate; f32: the fp32 MFMA; bf16 = BASELINE config 4 path (fp16 table + "
-                         "bf16 MFMA), not the headline metric; f32x3-3: three products (16-bit operands), measurement only")
+                         "bf16 MFMA), not the headline metric; f32x3-3: three products (16-bit operands), measurement only; "
+                         "f16x2: fp32 operands as two fp16 planes under per-tensor scales, three products on the fp16 MFMA -- a "
+                         "secondary path (DESIGN section 5), the job of this line only when asked for")
     ap.add_argument("--train-table", action="store_true",
                     help="also train the catalogue rows (lazy Adam; build-defined, not the headline metric)")
     ap.add_argument("--gather-ahead", type=int, default=0,
@@ -1244,6 +1262,9 @@ def main():
     from cdml_amd import dist as cdist, engine, engine_bf16, train
     bf16 = args.precision == "bf16"
     x3 = 0 if not args.precision.startswith("f32x3") else (3 if args.precision.endswith("-3") else 6)
+    h2 = args.precision == "f16x2"
+    if h2 and (args.graph or args.train_table):
+        sys.exit("--precision f16x2 is the eager step with a frozen catalogue")
     Table = engine_bf16.FeatureTableF16 if bf16 else engine.FeatureTable
 
     if args.mode == "predict":                           # catalogue inference throughput (N = 1)
@@ -1395,7 +1416,7 @@ def main():
             if ts.prefetch is not None:
                 ts.prefetch.acquire = comm_kt.wrap("exchange_wait", ts.prefetch.acquire)
             comm_kt.on = True
-        elapsed, kt, sampled, how = measure_job(ts, args.steps, args.warmup, dev, None if x3 else bf16, timers_on,
+        elapsed, kt, sampled, how = measure_job(ts, args.steps, args.warmup, dev, "h2" if h2 else None if x3 else bf16, timers_on,
                                                 barrier if world > 1 else None)
         if comm_kt is not None:
             comm_kt.on = False
@@ -1445,7 +1466,7 @@ def main():
             "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("bf16 (fp16 table, f32 accumulate)" if bf16 else "f32 (fp32 MFMA)" if not x3 else X3_DTYPE if x3 == 6 else
+            "dtype": ("bf16 (fp16 table, f32 accumulate)" if bf16 else F16X2_DTYPE if h2 else "f32 (fp32 MFMA)" if not x3 else X3_DTYPE if x3 == 6 else
                       "f32 values as 3 bf16 planes, 3 plane products per f32 product on the bf16 MFMA (16-bit operands: NOT "
                       "an fp32 equivalent; measurement only)"),
             "data": "synthetic",
@@ -1491,7 +1512,9 @@ def main():
                                "capacity_factor": args.capacity_factor, "mean_share_per_peer": ts.R / world,
                                "overflow_flag_max": max(r["exchange_overflow_flag"] for r in per_rank),
                                "overflow_flag_bits": "1 = a peer segment was full (rows came back NaN), 2 = an id outside the catalogue"}
-        if timers_on:
+        if timers_on and h2:
+            out.update(h2_records(kt, R, sampled, how))
+        elif timers_on:
             out.update(gemm_records(kt, R, bf16, sampled, how, world == 1, x3_products=x3, workload=wkey))
         if world == 1 and not args.train_table:
             set_phase("gather record")
@@ -1530,7 +1553,7 @@ def main():
                         % ("" if args.no_settle else "0.3 s settle loop (%s), " % settle_how))
 
         # ---- secondary records (after the headline; the failure of one must not cost the line) ----
-        run_extras = default_job and not args.no_extras and not args.train_table and x3 in (0, 6)
+        run_extras = default_job and not args.no_extras and not args.train_table and x3 in (0, 6) and not h2
         if run_extras:
             del ts
             torch.cuda.empty_cache()

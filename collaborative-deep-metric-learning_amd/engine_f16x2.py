@@ -22,7 +22,9 @@ profiles/r06_f16x2_kernels_rate.txt).  What it costs:
   steps 0, 1, 2, 4, ... 64 and every 64th step after (two small device-to-host copies each), and changes one only when its
   tensor has left a window of 2^8 around its place -- delayed scaling, as fp8 training does.  Between two checks a tensor
   may grow 8 .. 32 x before anything saturates, and what saturates is clamped at +-65504, not turned into infinities.
-  This is an fp32 EQUIVALENT only while that holds: a secondary path (the headline stays "f32x3"), single GPU, eager.
+  This is an fp32 EQUIVALENT only while that holds: a secondary path (the headline stays "f32x3"), eager (a scale is an argument
+  baked into a captured graph).  Data-parallel runs need no agreement on the scales: the weights are replicated (same maxima on
+  every rank), the gradient scales are local to a rank's batch, and what crosses the wire -- rows, fp32 gradients -- carries none.
 
 Reference lines: models.py:59-61 (forward), train.py:141 (its autodiff)."""
 import math
@@ -186,8 +188,10 @@ def tower_forward(p, ws, normalize=True):
     return ws.e
 
 
-def tower_backward(p, ws, after_w1=None):
-    """ws.dz2 (from the fused tail) or ws.de -> p.grad (fp32).  train.py:141; no dX."""
+def tower_backward(p, ws, after_w1=None, w1_chunks=1, after_w1_chunk=None):
+    """ws.dz2 (from the fused tail) or ws.de -> p.grad (fp32).  train.py:141; no dX.  ``after_w1`` / ``w1_chunks`` /
+    ``after_w1_chunk``: the data-parallel hooks of engine_x3.tower_backward (the first layer's weight gradient first, whole or
+    in row blocks of W1, a hook after each -- flat-gradient ranges, the last one ends after db1)."""
     L, R, s = p.layout, ws.R, ws.scales
     if not ws.tail_done:
         ops.l2norm_bwd(ws.z, ws.de, L.Dp, ws.dz2, lrelu_alpha=ops.LRELU_ALPHA)
@@ -195,14 +199,28 @@ def tower_backward(p, ws, after_w1=None):
         ops.split_f32_f16x2(ws.dz2, ws.dz2_2, L.Dp, s.dz2)
     w2 = lambda: ops.gemm_f16x2_tn(ws.h1, L.Hp, ws.dz2_2, L.Dp, p.gW2, L.Hp, L.Dp, R, 1.0 / (s.h1 * s.dz2), workspace=ws.gemm_ws,
                                    colsum=p.gb2, colsum_scale=1.0 / s.dz2)
-    if after_w1 is None:
+    single = after_w1 is None and after_w1_chunk is None
+    if single:
         w2()
     # dz1 = (dz2 . W2^T) * lrelu'(h1), written as planes; the sign from FC1's bitmask
     ops.gemm_f16x2_nt(ops.BE_MASKBITS_X3, ws.dz2_2, L.Dp, ws.W2, L.Dp, ws.dz1, R, L.Hp, L.Dp, 1.0 / (s.dz2 * s.w2), c_scale=s.dz1,
                       plane_c=L.Hp, aux=ws.h1_bits)
-    ops.gemm_f16x2_tn(ws.x2, L.Fp, ws.dz1, L.Hp, p.gW1, L.Fp, L.Hp, R, 1.0 / (s.x * s.dz1), workspace=ws.gemm_ws, colsum=p.gb1,
-                      colsum_scale=1.0 / s.dz1)
+
+    def dw1(lo, hi, db):      # columns lo .. hi of both planes of x_hat: the same plane stride, the base moved by lo
+        ops.gemm_f16x2_tn(ws.x2[:, lo:], L.Fp, ws.dz1, L.Hp, p.gW1[lo:hi], hi - lo, L.Hp, R, 1.0 / (s.x * s.dz1), workspace=ws.gemm_ws,
+                          colsum=db, colsum_scale=1.0 / s.dz1)
+    rows = L.Fp // w1_chunks if w1_chunks > 1 else 0
+    if after_w1_chunk is not None and w1_chunks > 1 and rows * w1_chunks == L.Fp and rows % 256 == 0:
+        for c in range(w1_chunks):
+            last = c == w1_chunks - 1
+            dw1(c * rows, (c + 1) * rows, p.gb1 if last else None)
+            after_w1_chunk(c * rows * L.Hp, (c + 1) * rows * L.Hp + (L.Hp if last else 0))
+    else:
+        dw1(0, L.Fp, p.gb1)
+        if after_w1_chunk is not None:
+            after_w1_chunk(0, L.Fp * L.Hp + L.Hp)
     if after_w1 is not None:
         after_w1()
+    if not single:
         w2()
     return p.grad

@@ -57,7 +57,7 @@ class TrainStep:
         bench.py times -- when the step's rows are a multiple of 128, else "f32" (the fp32 MFMA).  "f16x2" (never chosen by
         "auto"): fp32 operands as TWO fp16 planes under per-tensor power-of-two scales, three plane products on the fp16 MFMA
         -- half of "f32x3"'s matrix work at the same error bound, an fp32 equivalent while its delayed scales hold
-        (engine_f16x2.py); one GPU, eager, frozen catalogue.
+        (engine_f16x2.py); eager, frozen catalogue.
         ``use_graph``: False = eager; True = the whole step replayed from ONE hipGraph (single GPU: the
         fast form; data-parallel: the exchange of step t+1 is then recorded on the capturing stream,
         ahead of the forward pass, not under it); "split" (data-parallel with the prefetcher) = three
@@ -141,12 +141,14 @@ class TrainStep:
         if self.bf16 != (table.data.dtype == torch.float16):
             raise ValueError("precision 'bf16' goes with an fp16 FeatureTableF16, 'f32' / 'f32x3' with an fp32 table")
         if self.h2:
-            if exchange is not None or grad_sync is not None or use_graph or train_table:
-                raise ValueError("precision 'f16x2' is the single-GPU eager step with a frozen catalogue (its plane scales "
-                                 "are host-side kernel arguments that move during training: engine_f16x2.py)")
+            if use_graph or train_table:
+                raise ValueError("precision 'f16x2' is the eager step with a frozen catalogue (its plane scales are host-side "
+                                 "kernel arguments that move during training: engine_f16x2.py)")
             self.layout = engine_x3.layout_x3(F, hidden_size, output_size)
             self.params = engine.VNetParams(self.layout, self.device, weight_seed)
-            self.ws = engine_f16x2.TowerWorkspaceH2(self.layout, self.R, self.device, planes_in=True)
+            # one GPU: the fused sampler + gather writes the fp16 planes; sharded catalogue: the rows arrive in fp32 through the
+            # exchange and the forward pass splits them
+            self.ws = engine_f16x2.TowerWorkspaceH2(self.layout, self.R, self.device, planes_in=exchange is None)
         elif self.x3:
             self.layout = engine_x3.layout_x3(F, hidden_size, output_size)
             self.params = engine.VNetParams(self.layout, self.device, weight_seed)
@@ -670,7 +672,7 @@ class TrainStep:
                 self.prefetch.wait_ready(1 - b)
             n1 = self.layout.offsets[2]
             handles = []
-            (engine_x3 if self.x3 else engine_bf16 if self.bf16 else engine).tower_backward(
+            (engine_f16x2 if self.h2 else engine_x3 if self.x3 else engine_bf16 if self.bf16 else engine).tower_backward(
                 self.params, self.ws, after_w1=lambda: handles.append(self.grad_sync.start(self.params.grad, 0, n1)))
             handles.append(self.grad_sync.start(self.params.grad, n1, self.layout.numel))
             self.grad_sync.finish(handles)
@@ -682,7 +684,7 @@ class TrainStep:
             # GEMM -- and [dW2|db2] right after its GEMM; the optimizer waits for all of them
             n1 = self.layout.offsets[2]
             handles = []
-            (engine_x3 if self.x3 else engine_bf16 if self.bf16 else engine).tower_backward(
+            (engine_f16x2 if self.h2 else engine_x3 if self.x3 else engine_bf16 if self.bf16 else engine).tower_backward(
                 self.params, self.ws, w1_chunks=2,
                 after_w1_chunk=lambda lo, hi: handles.append(self.grad_sync.start(self.params.grad, lo, hi)))
             handles.append(self.grad_sync.start(self.params.grad, n1, self.layout.numel))

@@ -27,6 +27,10 @@ CFG_TABLE_X3 = dict(CFG, F=250, H=500, D=256, B=128, precision="f32x3", train_ta
 # the fp32 tower on the bf16 MFMA (three exact planes per operand): rows cross the wire in fp32 and are split on arrival
 CFG_X3 = dict(CFG, F=250, H=500, D=256, B=128, precision="f32x3")
 CFG_X3_BUCKETS = dict(CFG_X3, F=500)              # F padded to 512: dW1 in two 256-row blocks, an all-reduce after each
+# the fp32 tower on the fp16 MFMA (two planes per operand under per-tensor scales, round 6): rows cross the wire in fp32; the
+# weights' scales are the same on every rank (replicated weights), the gradients' are local to a rank's batch
+CFG_H2 = dict(CFG, F=250, H=500, D=256, B=128, precision="f16x2")
+CFG_H2_BUCKETS = dict(CFG_H2, F=500)
 # four ranks on the card: uneven shards (3000 = 4 x 750 here, 3001 rows -> 751/751/751/748), every
 # pair of ranks exchanging rows, the 1/4 gradient average
 CFG_W4 = dict(CFG, world=4, n_rows=3001, B=16)
@@ -91,9 +95,9 @@ def _worker(rank, world, port, q, CFG=CFG):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_X3, CFG_X3_BUCKETS, CFG_TABLE, CFG_TABLE_X3, CFG_W4, CFG_C3, CFG_C3_X3, CFG_C4, CFG_C3_W4, CFG_C3_TWO,
+@pytest.mark.parametrize("CFG", [CFG, CFG_BF16, CFG_X3, CFG_X3_BUCKETS, CFG_H2, CFG_H2_BUCKETS, CFG_TABLE, CFG_TABLE_X3, CFG_W4, CFG_C3, CFG_C3_X3, CFG_C4, CFG_C3_W4, CFG_C3_TWO,
                                  CFG_C3_SINGLE, CFG_C4_SINGLE],
-                         ids=["f32", "bf16", "f32x3", "f32x3-bucketed", "trainable-table", "trainable-table-f32x3", "4-ranks", "config3-full-size",
+                         ids=["f32", "bf16", "f32x3", "f32x3-bucketed", "f16x2", "f16x2-bucketed", "trainable-table", "trainable-table-f32x3", "4-ranks", "config3-full-size",
                               "config3-full-size-f32x3", "config4-full-size",
                               "config3-full-size-4-ranks", "config3-full-size-sync-two", "config3-full-size-sync-single",
                               "config4-full-size-sync-single"])
@@ -426,6 +430,27 @@ def test_bench_two_rank_rehearsal(gpu, launcher):
     assert ex["capacity_slots_per_peer"] * 2 * (4 + 1536 * 4) == comm["exchange_bytes"]
     assert "env" in out["comm_backend"] and "algo" in out["comm_backend"]
     assert out["config"]["rows_per_triplet"] == 2 and abs(out["config"]["value_three_row_equivalent"] - out["value"] * 2 / 3) < 0.2
+
+
+def test_bench_two_rank_rehearsal_on_f16x2(gpu):
+    """`python bench.py --gpus 2 --precision f16x2` (round 6: the secondary precision through the N > 1 code path, two ranks
+    sharing the card, gloo-staged collectives): rows arrive in fp32 through the exchange and are split into fp16 planes on
+    arrival, every gradient-sync form runs in the probe, the line says which precision it timed."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["CDML_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "40000",
+           "--batch", "256", "--precision", "f16x2"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["precision"] == "f16x2"
+    assert out["dtype"].startswith("f32 values as 2 fp16 planes") and out["roofline"]["peak"] == round(2500.0 / 3, 1)
+    assert out["comm"]["grad_sync"] == out["comm"]["grad_sync_probe"]["picked"]
+    assert all(r_["exchange_overflow_flag"] == 0 for r_ in out["ranks"]) and np.isfinite(out["loss"])
 
 
 def test_bench_four_rank_full_size_rehearsal(gpu):
