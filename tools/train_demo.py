@@ -2,8 +2,8 @@
 """End-to-end training at the production dimensions (1500 -> 5000 -> 256, B = 4096) on a
 LEARNABLE synthetic catalogue: co-watched videos share a cluster (imitation_data's iid features
 carry nothing to learn, so the benchmark's loss stays at the margin).  Prints the loss and the
-held-out mean positive distance (evaluate.py:57-73) as training goes, for fp32 and for the
-config-4 precision.  usage: python tools/train_demo.py [steps] [rows]"""
+held-out mean positive distance (evaluate.py:57-73) as training goes, for the fp32 paths (fp32 MFMA,
+"f32x3", "f16x2") and for the config-4 precision.  usage: python tools/train_demo.py [steps] [rows]"""
 import os
 import sys
 
@@ -30,7 +30,8 @@ pairs = pairs[torch.randperm(pairs.shape[0], device=dev, generator=g)]
 eval_pairs, train_pairs = pairs[:2000], pairs[2000:].contiguous()
 print("catalogue %d x %d, %d clusters, %d training pairs, %d held-out pairs" % (N, F, C, len(train_pairs), len(eval_pairs)))
 combos = [tuple(c.split(":")) for c in (sys.argv[3].split(",") if len(sys.argv) > 3 else
-                                        ["f32:inbatch", "f32x3:inbatch", "f32x3:semihard", "bf16:inbatch"])]
+                                        ["f32:inbatch", "f32x3:inbatch", "f32x3:semihard", "f16x2:inbatch", "f16x2:semihard",
+                                         "bf16:inbatch"])]
 for prec, mode in combos:
     if prec != "bf16":
         table = engine.FeatureTable(torch.zeros((N, 1536), device=dev), F)
@@ -39,7 +40,7 @@ for prec, mode in combos:
         table = engine_bf16.FeatureTableF16.from_numpy(feats.cpu().numpy(), dev)
     ts = train.TrainStep(table, train_pairs, B, mode=mode, optimizer="adam", base_learning_rate=2e-4,
                          precision=prec, device=dev)
-    pred = predict.Prediction(params=ts.params, device=dev, precision="f32x3" if prec == "f32x3" else "f32")
+    pred = predict.Prediction(params=ts.params, device=dev, precision=prec if prec in ("f32x3", "f16x2") else "f32")
     ev_rows = torch.unique(eval_pairs.reshape(-1).to(torch.int64))
     remap = torch.full((N,), -1, dtype=torch.int64, device=dev)
     remap[ev_rows] = torch.arange(len(ev_rows), device=dev)
@@ -59,7 +60,8 @@ for prec, mode in combos:
     for s in range(1, steps + 1):
         ts.step()
         if s % (steps // 6) == 0:
-            print("step %4d  loss %.4f  held-out mean positive distance %.4f  (%.0f triplets/s so far)"
-                  % (s, ts.loss(), held_out(), s * B / (time.perf_counter() - t0)))
+            print("step %4d  loss %.4f  held-out mean positive distance %.4f  (%.0f triplets/s so far)%s"
+                  % (s, ts.loss(), held_out(), s * B / (time.perf_counter() - t0),
+                     "  [plane scales moved %d times]" % ts.ws.scales.changes if prec == "f16x2" else ""))
     del ts, table
     torch.cuda.empty_cache()
