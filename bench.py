@@ -945,7 +945,7 @@ def rec_other_fp32_path(dev, args, n_s, n_w, table, pairs, B, mode, other):
     return out
 
 
-def h2_records(kt, R, sampled, how):
+def h2_records(kt, R, sampled, how, workload=None):
     """roofline / roofline_fc1_fwd / kernels of a precision-"f16x2" step from its event-timed launches (peak = the fp16 dense
     peak / 3: three fp16 MFMA flops per algorithmic fp32 flop)."""
     out = {}
@@ -956,14 +956,18 @@ def h2_records(kt, R, sampled, how):
     t_ms = (kt.mean_ms("dW1") * kt.count("dW1") + kt.mean_ms("dW2") * kt.count("dW2")) / n_launch
     flop_launch = sampled * (2.0 * R * F * H + 2.0 * R * H * D) / n_launch
     ach = flop_launch / (t_ms * 1e-3) / 1e12
+    # (HBM-side bytes per launch from the committed PMC passes of the f16x2 step, when they are of these kernels and this workload)
+    tr, src = pmc_traffic("k_gemm_f16x2_256<true, 3, true, true", name="latest_pmc_f16x2", workload=workload) if workload else (None, None)
     out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_f16x2_256<true, 3, true, true> (dW1+dW2 launches: fp32 products as 3 fp16 "
                        "plane products; achieved = fp32-equivalent rate, peak = fp16 dense peak / 3)", "achieved": round(ach, 2),
-                       "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launch_ms": round(t_ms, 4),
+                       "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": tr, "traffic_source": src,
+                       "launch_ms": round(t_ms, 4),
                        "flop_per_launch": flop_launch, "launches_per_step": n_launch / sampled, "timed_steps": sampled,
                        "timed_how": how}
     ach1 = 2.0 * R * F * H / (kt.mean_ms("fc1_fwd") * 1e-3) / 1e12
+    tr1, src1 = pmc_traffic("k_gemm_f16x2_256<false, 6, true, true", name="latest_pmc_f16x2", workload=workload) if workload else (None, None)
     out["roofline_fc1_fwd"] = {"bound": "mfma", "kernel": "k_gemm_f16x2_256<false, 6, true, true>", "achieved": round(ach1, 2),
-                               "peak": peak, "unit": "TFLOP/s", "frac": round(ach1 / peak, 4),
+                               "peak": peak, "unit": "TFLOP/s", "frac": round(ach1 / peak, 4), "traffic": tr1, "traffic_source": src1,
                                "launch_ms": round(kt.mean_ms("fc1_fwd"), 4), "flop_per_launch": 2.0 * R * F * H}
     kern = {}
     for k in ("fc1_fwd", "fc2_fwd", "tail", "dH1", "dW1", "dW2", "adam_w1", "adam_w2", "split_planes"):
@@ -1023,7 +1027,7 @@ def rec_f16x2(dev, args, n_s, n_w, table, pairs, B, mode):
                                "(checked at steps 0, 1, 2, 4 .. 64 and every 64th: two device-to-host copies each, inside the timed region)"
                                % (ts.ws.scales.changes, ts.global_step),
            "gather_steps_per_launch": ts.gather_ahead}
-    out.update(h2_records(kt, R, sampled, how))
+    out.update(h2_records(kt, R, sampled, how, workload=workload_key(table.n_rows, B, mode)))
     # the gather writes 6 000 B of planes per row where the three bf16 planes are 9 000
     reps, per, n_st = 5, 10, ts.gather_ahead
     nxt = [ts.global_step + 1000]
@@ -1513,7 +1517,7 @@ def main():
                                "overflow_flag_max": max(r["exchange_overflow_flag"] for r in per_rank),
                                "overflow_flag_bits": "1 = a peer segment was full (rows came back NaN), 2 = an id outside the catalogue"}
         if timers_on and h2:
-            out.update(h2_records(kt, R, sampled, how))
+            out.update(h2_records(kt, R, sampled, how, workload=wkey if world == 1 else None))
         elif timers_on:
             out.update(gemm_records(kt, R, bf16, sampled, how, world == 1, x3_products=x3, workload=wkey))
         if world == 1 and not args.train_table:
