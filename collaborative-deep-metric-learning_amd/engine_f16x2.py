@@ -167,7 +167,8 @@ def observe_gradients(p, ws):
     if s._move("dz2", hst[0], s.TOP_MAX):
         ws.dz2_planes_done = False
     s._move("dz1", hst[1] * s.last.get("w2_row", 1.0), s.TOP_BOUND)      # |dz2[r] . W2[j]| <= |dz2[r]| |W2[j]|
-    s.calibrated = True
+    if hst[0] > 0.0:                                       # (a batch without one active triplet says nothing about the gradients'
+        s.calibrated = True                                #  size: the next step calibrates again)
 
 
 def tower_forward(p, ws, normalize=True):

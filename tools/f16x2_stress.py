@@ -7,7 +7,7 @@ test is the range management: the scales must follow, nothing may saturate).  Ev
 on "f32x3", the plane scales (log2), how often they moved, the largest magnitude in the hi plane of every plane tensor
 (65504 = something saturated).  After each run the two paths take ONE step from the f16x2 run's final weights on the same
 batch: the gradients' relative L2 difference (two fp32-accurate paths: 1e-4 .. 1e-3, as f32 against f32x3).
-usage: python tools/f16x2_stress.py [steps]"""
+usage: python tools/f16x2_stress.py [steps [long_steps]]"""
 import math
 import os
 import sys
@@ -21,18 +21,19 @@ from cdml_amd import engine_x3, train  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 dev = torch.device("cuda:0")
 table, pairs = bench.learnable_catalogue(200000, dev)
-for lr in (1e-3, 1e-2):
-    mk = lambda prec: train.TrainStep(table, pairs, 1024, mode="inbatch", optimizer="adam", base_learning_rate=lr, device=dev,
+long_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # a third, LONG run at the demo's settings (B = 4096, lr 2e-4) when asked for
+for lr, batch, steps in ((1e-3, 1024, steps), (1e-2, 1024, steps)) + (((2e-4, 4096, long_steps),) if long_steps else ()):
+    mk = lambda prec: train.TrainStep(table, pairs, batch, mode="inbatch", optimizer="adam", base_learning_rate=lr, device=dev,
                                       precision=prec, gather_ahead=1)
     a, b = mk("f16x2"), mk("f32x3")
     L = a.layout
     worst = 0.0
-    print("## Adam, learning rate %g" % lr)
+    print("## Adam, learning rate %g, batch %d, %d steps" % (lr, batch, steps))
     print("# step  loss f16x2  loss f32x3 | log2 scales w1 w2 h1 dz2 dz1 | moves | max |hi plane| of W1T W2 h1 dz2 dz1 | max |W1|")
     for t in range(1, steps + 1):
         a.step()
         b.step()
-        if t % 100 == 0 or t in (1, 10, 30):
+        if t % max(100, steps // 15) == 0 or t in (1, 10, 30):
             s = a.ws.scales
             hi = [float(x[:, :w].float().abs().max()) for x, w in ((a.ws.W1T, L.Fp), (a.ws.W2, L.Dp), (a.ws.h1, L.Hp), (a.ws.dz2_2, L.Dp),
                                                                     (a.ws.dz1, L.Hp))]
