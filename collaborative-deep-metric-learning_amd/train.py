@@ -864,6 +864,9 @@ class TrainStep:
         if self.train_table:                             # this rank's shard and its Adam states
             state["table"] = {"row0": self.table.row0, "rows": self.table.data.detach().cpu().clone(),
                               "m": self.tab_m.detach().cpu().clone(), "v": self.tab_v.detach().cpu().clone()}
+        if self.h2:                                      # precision f16x2: the plane scales are state (a resumed run keeps the
+            sc = self.ws.scales                          # straight run's bits only with the scales that run would hold)
+            state["plane_scales"] = dict(sc.state(), calibrated=sc.calibrated, changes=sc.changes, last=dict(sc.last))
         return state
 
     def load_state_dict(self, state):
@@ -883,7 +886,14 @@ class TrainStep:
         if self.bf16:                                    # the GEMMs read the bf16 copies, not the masters
             engine_bf16.refresh_weights(self.params, self.ws)
         if self.h2:
-            self.ws.scales.calibrated = False            # the next step re-derives every scale from the loaded weights
+            sc, saved = self.ws.scales, state.get("plane_scales")
+            if saved:                                    # the checkpointed run's scales, and the weights' planes at them
+                for k in ("w1", "w2", "h1", "dz2", "dz1"):
+                    setattr(sc, k, float(saved[k]))
+                sc.calibrated, sc.changes, sc.last = bool(saved["calibrated"]), int(saved["changes"]), dict(saved["last"])
+                engine_f16x2.refresh_weights(self.params, self.ws)
+            else:
+                sc.calibrated = False                    # (a checkpoint of another precision: the next step calibrates)
         if self.x3:
             engine_x3.refresh_weights(self.params, self.ws)
         self.global_step = int(state["global_step"])

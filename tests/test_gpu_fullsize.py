@@ -174,7 +174,7 @@ def test_sample_gather_f16_content_past_4gib(cd, table_f16_15m, mode):
 
 def _f32_views(ts):
     """(x_hat, dz1) as fp32 tensors: the fp32 path holds them so, precision "f32x3" as three bf16 planes"""
-    if ts.x3:
+    if ts.x3 or getattr(ts, "h2", False):
         return ts.ws.x_hat_f32(), ts.ws.dz1_f32()
     return ts.ws.x_hat, ts.ws.dz1
 
@@ -200,7 +200,7 @@ def _check_step_properties(cd, ts, pairs_np, B, rows_per_triplet):
     assert np.abs(ts.ws.e[:64, :D].cpu().numpy() - sub["l2_norm"]).max() < 1e-5
 
 
-@pytest.mark.parametrize("precision", ["f32x3", "f32"])
+@pytest.mark.parametrize("precision", ["f32x3", "f32", "f16x2"])
 def test_config1_step_on_1m_rows(cd, table_1m, precision):
     """BASELINE config 1 as stated: 1 M x 1500 fp32 in HBM, B = 4096, in-batch negatives -- on the headline's path
     (precision "f32x3": fp32 values as three exact bf16 planes, six plane products per fp32 product) and on the
@@ -221,7 +221,7 @@ def test_config1_step_on_1m_rows(cd, table_1m, precision):
     assert np.isfinite(ts.loss()) and int(ts.step_dev.item()) == 2
 
 
-@pytest.mark.parametrize("precision", ["f32x3", "f32"])
+@pytest.mark.parametrize("precision", ["f32x3", "f32", "f16x2"])
 def test_config2_step_on_1m_rows(cd, table_1m, precision):
     """BASELINE config 2 as stated: same catalogue, semi-hard mining over the batch, B = 8192 (both fp32 paths)."""
     B = 8192
@@ -444,7 +444,7 @@ def _rel_l2(got, want):
 
 
 @pytest.mark.parametrize("mode", ["uniform", "inbatch"])
-@pytest.mark.parametrize("precision,bar", [("f32", 1e-4), ("f32x3", 1e-4), ("bf16", 1e-2)])
+@pytest.mark.parametrize("precision,bar", [("f32", 1e-4), ("f32x3", 1e-4), ("f16x2", 1e-4), ("bf16", 1e-2)])
 def test_gradients_well_conditioned_production_shape(cd, mode, precision, bar):
     """Per-tensor relative L2 error of dW1, db1, dW2, db2 against the fp64 oracle at F=1500 /
     H=5000 / D=256, B=256, over several Adam steps (each step checked from the device's own
@@ -463,7 +463,7 @@ def test_gradients_well_conditioned_production_shape(cd, mode, precision, bar):
     f64 = feats.astype(np.float64)
     names = ("dW1", "db1", "dW2", "db2")
     worst, checked = {}, 0
-    f32like = precision in ("f32", "f32x3")          # the split-fp32 path is held to the fp32 path's bounds
+    f32like = precision in ("f32", "f32x3", "f16x2")      # the plane paths are held to the fp32 path's bounds
     band = 1e-6 if f32like else 2e-4
     for step in range(4):
         W = [t.detach().cpu().numpy().astype(np.float64) for t in ts.params.unpadded()]
@@ -471,7 +471,7 @@ def test_gradients_well_conditioned_production_shape(cd, mode, precision, bar):
         torch.cuda.synchronize()
         dev_t = (ts.pos - ts.neg + 0.8).cpu().numpy().astype(np.float64)
         fwd, loss, grads, n_amb, n_amb_t = _oracle_grads(f64, pairs, W, step, B, mode, N,
-                                                         (ts.ws.h1_f32() if precision == "f32x3" else ts.ws.h1)[:, :H].float().cpu().numpy(),
+                                                         (ts.ws.h1_f32() if precision in ("f32x3", "f16x2") else ts.ws.h1)[:, :H].float().cpu().numpy(),
                                                          ts.ws.z[:, :D].float().cpu().numpy(), dev_t, band,
                                                          1e-5 if f32like else 1e-2)
         e = ts.ws.e[:, :D].cpu().numpy()
@@ -491,9 +491,10 @@ def test_gradients_well_conditioned_production_shape(cd, mode, precision, bar):
     print("worst relative L2 error per tensor (%s, %s):" % (precision, mode), worst)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "f32x3"])
+@pytest.mark.parametrize("precision", ["bf16", "f32x3", "f16x2"])
 def test_resume_bf16_is_bit_exact(cd, tmp_path, precision):
-    """load_state_dict must refresh the bf16 operand copies of the weights (f32x3: their planes) --
+    """load_state_dict must refresh the bf16 operand copies of the weights (f32x3: their planes; f16x2: the plane
+    SCALES are state too) --
     5 steps + save/load into a fresh TrainStep + 5 steps == 10 straight steps."""
     N = 4000
     Table = cd.ebf.FeatureTableF16 if precision == "bf16" else cd.engine.FeatureTable
