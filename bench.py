@@ -821,6 +821,14 @@ def rec_train_table(dev, args, n_s, n_w, keep):
         out["table_adam"] = {"launch_ms": round(kt.mean_ms("table_adam"), 4),
                              "bytes_bound": "<= %d rows x (6 KB gradient + 6 x 6 KB of row / m / v)" % R,
                              "achieved_GBs_upper": round(R * 7 * F * 4 / (kt.mean_ms("table_adam") * 1e-3) / 1e9, 1)}
+    if x3:      # the same step on precision "f16x2" (the sixth product on the fp16 planes too), the rows as this run left them
+        del ts
+        torch.cuda.empty_cache()
+        t2 = train.TrainStep(t10, p10, 8192, output_size=D, hidden_size=H, margin=MARGIN, mode="inbatch", optimizer="adam",
+                             base_learning_rate=0.01, seed=1234, weight_seed=42, device=dev, precision="f16x2", train_table=True)
+        el2, _, _, _ = measure_job(t2, n, w, dev, "h2", timers=False)
+        out["f16x2"] = {"ms_per_step": round(el2 / n * 1e3, 4), "value": round(8192 * n / el2, 1), "unit": "triplets/s", "steps": n,
+                        "loss": round(t2.loss(), 6), "scale_moves": t2.ws.scales.changes}
     return out
 
 
@@ -1024,8 +1032,9 @@ def rec_f16x2(dev, args, n_s, n_w, table, pairs, B, mode):
            "dtype": F16X2_DTYPE, "loss": round(ts.loss(), 6), "f16x2_against_f32x3": check,
            "plane_scales": {k: (int(round(np.log2(v))) if v > 0 else None) for k, v in ts.ws.scales.state().items()},
            "plane_scales_are": "log2 of the per-tensor scales after the run; scale moves after calibration: %d in %d steps "
-                               "(checked at steps 0, 1, 2, 4 .. 64 and every 64th: two device-to-host copies each, inside the timed region)"
-                               % (ts.ws.scales.changes, ts.global_step),
+                               "(checked at steps 0, 1, 2, 4 .. 64 and every 64th: two device-to-host copies each, inside the timed "
+                               "region); checks that found a plane tensor clamped at fp16's largest value: %d"
+                               % (ts.ws.scales.changes, ts.global_step, ts.ws.scales.saturated),
            "gather_steps_per_launch": ts.gather_ahead}
     out.update(h2_records(kt, R, sampled, how, workload=workload_key(table.n_rows, B, mode)))
     # the gather writes 6 000 B of planes per row where the three bf16 planes are 9 000

@@ -21,7 +21,8 @@ profiles/r06_f16x2_kernels_rate.txt).  What it costs:
   W2), dz2's its maximum.  The scales live on the HOST (they are kernel arguments): ``PlaneScales`` re-derives them at
   steps 0, 1, 2, 4, ... 64 and every 64th step after (two small device-to-host copies each), and changes one only when its
   tensor has left a window of 2^8 around its place -- delayed scaling, as fp8 training does.  Between two checks a tensor
-  may grow 8 .. 32 x before anything saturates, and what saturates is clamped at +-65504, not turned into infinities.
+  may grow 8 .. 32 x before anything saturates, and what saturates is clamped at +-65504, not turned into infinities -- every
+  check also looks for that value in the hi planes of h1 and dz1 and counts / logs it (``PlaneScales.saturated``).
   This is an fp32 EQUIVALENT only while that holds: a secondary path (the headline stays "f32x3"), eager (a scale is an argument
   baked into a captured graph).  Data-parallel runs need no agreement on the scales: the weights are replicated (same maxima on
   every rank), the gradient scales are local to a rank's batch, and what crosses the wire -- rows, fp32 gradients -- carries none.
@@ -56,6 +57,7 @@ class PlaneScales:
         self.calibrated = False
         self.check_every = int(check_every)
         self.changes = 0                             # how many times a scale moved after calibration
+        self.saturated = 0                           # checks that found a plane tensor AT fp16's largest value (it should never)
         self.last = {}                               # the maxima / bounds of the last check (host floats)
 
     def due(self, step):
@@ -132,6 +134,8 @@ def refresh_weights(p, ws):
     ops.split_f32_f16x2(p.W1, ws.W1T, L.Fp, s.w1, transpose=True)        # [Hp][2 Fp]
     ops.split_f32_f16x2(p.W2, ws.W2T, L.Hp, s.w2, transpose=True)        # [Dp][2 Hp]
     ops.split_f32_f16x2(p.W2, ws.W2, L.Dp, s.w2)                         # [Hp][2 Dp]
+    if getattr(ws, "W1n", None) is not None:                              # trainable catalogue: dx_hat = dz1 . W1^T reads W1 as it is
+        ops.split_f32_f16x2(p.W1, ws.W1n, L.Hp, s.w1)                     # [Fp][2 Hp]
 
 
 def observe_weights(p, ws):
@@ -162,8 +166,21 @@ def observe_gradients(p, ws):
         ws.tail_done, ws.dz2_planes_done = True, False
     o[4] = ws.dz2.abs().amax()
     o[5] = torch.linalg.vector_norm(ws.dz2, dim=1).amax()
-    hst = [float(v) for v in o[4:6].cpu()]
-    s.last.update(dz2=hst[0], dz2_row=hst[1])
+    # the watch on the rule itself: the largest magnitude in the hi planes of this step's h1 and of the LAST step's dz1 -- a value
+    # at 65504 means a tensor outgrew its scale between two checks and was clamped (counted and logged; the bounds below re-place
+    # the scales either way)
+    lo_h, hi_h = torch.aminmax(ws.h1[:, :p.layout.Hp])
+    lo_g, hi_g = torch.aminmax(ws.dz1[:, :p.layout.Hp])
+    o[6] = torch.maximum(hi_h.float(), -lo_h.float())
+    o[7] = torch.maximum(hi_g.float(), -lo_g.float())
+    hst = [float(v) for v in o[4:8].cpu()]
+    s.last.update(dz2=hst[0], dz2_row=hst[1], h1_hi_plane=hst[2], dz1_hi_plane=hst[3])
+    if s.calibrated and max(hst[2], hst[3]) >= 65504.0:
+        s.saturated += 1
+        import logging
+        logging.getLogger("cdml.f16x2").warning("a plane tensor reached fp16's largest value (|h1| hi plane %.0f, |dz1| hi plane %.0f): it "
+                                                "outgrew its scale between two checks and was clamped; check more often "
+                                                "(PlaneScales.check_every)", hst[2], hst[3])
     if s._move("dz2", hst[0], s.TOP_MAX):
         ws.dz2_planes_done = False
     s._move("dz1", hst[1] * s.last.get("w2_row", 1.0), s.TOP_BOUND)      # |dz2[r] . W2[j]| <= |dz2[r]| |W2[j]|

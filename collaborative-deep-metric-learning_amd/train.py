@@ -57,7 +57,7 @@ class TrainStep:
         bench.py times -- when the step's rows are a multiple of 128, else "f32" (the fp32 MFMA).  "f16x2" (never chosen by
         "auto"): fp32 operands as TWO fp16 planes under per-tensor power-of-two scales, three plane products on the fp16 MFMA
         -- half of "f32x3"'s matrix work at the same error bound, an fp32 equivalent while its delayed scales hold
-        (engine_f16x2.py); eager, frozen catalogue.
+        (engine_f16x2.py); eager.
         ``use_graph``: False = eager; True = the whole step replayed from ONE hipGraph (single GPU: the
         fast form; data-parallel: the exchange of step t+1 is then recorded on the capturing stream,
         ahead of the forward pass, not under it); "split" (data-parallel with the prefetcher) = three
@@ -141,9 +141,9 @@ class TrainStep:
         if self.bf16 != (table.data.dtype == torch.float16):
             raise ValueError("precision 'bf16' goes with an fp16 FeatureTableF16, 'f32' / 'f32x3' with an fp32 table")
         if self.h2:
-            if use_graph or train_table:
-                raise ValueError("precision 'f16x2' is the eager step with a frozen catalogue (its plane scales are host-side "
-                                 "kernel arguments that move during training: engine_f16x2.py)")
+            if use_graph:
+                raise ValueError("precision 'f16x2' is the eager step (its plane scales are host-side kernel arguments that "
+                                 "move during training: engine_f16x2.py)")
             self.layout = engine_x3.layout_x3(F, hidden_size, output_size)
             self.params = engine.VNetParams(self.layout, self.device, weight_seed)
             # one GPU: the fused sampler + gather writes the fp16 planes; sharded catalogue: the rows arrive in fp32 through the
@@ -230,6 +230,8 @@ class TrainStep:
                     raise ValueError("train_table needs the row-major activation layout of the f32x3 path")
                 self.ws.W1n = torch.zeros((self.layout.Fp, 3 * self.layout.Hp), dtype=torch.bfloat16, device=dev)
                 engine_x3.refresh_weights(self.params, self.ws)
+            elif self.h2:      # the same sixth product on the fp16 planes: W1 [F][hi H | lo H] at the weights' scale
+                self.ws.W1n = torch.zeros((self.layout.Fp, 2 * self.layout.Hp), dtype=torch.float16, device=dev)
             self.tab_m = torch.zeros_like(table.data)
             self.tab_v = torch.zeros_like(table.data)
             self.tab_head = torch.full((table.n_rows,), -1, dtype=i32, device=dev)
@@ -511,7 +513,11 @@ class TrainStep:
         catalogue rows they came from (on their owners when the table is sharded).  Runs
         before the dense update: it needs this step's W1 and step counter."""
         L, p, t = self.layout, self.params, self.table
-        if self.x3:
+        if self.h2:
+            sc = self.ws.scales
+            ops.gemm_f16x2_nt(ops.BE_F32, self.ws.dz1, L.Hp, self.ws.W1n, L.Hp, self.dxh, self.R, L.Fp, L.Hp,
+                              1.0 / (sc.dz1 * sc.w1))
+        elif self.x3:
             ops.gemm_bf16x3_nt(ops.BE_F32, self.ws.dz1, L.Hp, self.ws.W1n, L.Hp, self.dxh, self.R, L.Fp, L.Hp,
                                products=self.ws.products)
         else:
@@ -570,9 +576,10 @@ class TrainStep:
             kw = dict(lr_dev=self.lr_dev, t_dev=self.step_dev)
             b1, b2 = slice(o[1], o[1] + L.Hp), slice(o[3], o[3] + L.Dp)
             vec = lambda sl: (p.flat[sl], p.grad[sl], self.m[sl], self.v[sl])
+            w1n = getattr(ws, "W1n", None)                 # trainable table: W1's planes in their natural orientation too
             ops.adam_matrix_bf16(p.W1, mat(p.grad, 0, L.Fp, L.Hp), mat(self.m, 0, L.Fp, L.Hp),
                                  mat(self.v, 0, L.Fp, L.Hp), 0.0, 1, wt=ws.W1T, plane_t=L.Fp, bias=vec(b1),
-                                 h2_scale=ws.scales.w1, **kw)
+                                 h2_scale=ws.scales.w1, **(dict(kw, wc=w1n, plane_c=L.Hp) if w1n is not None else kw))
             ops.adam_matrix_bf16(p.W2, mat(p.grad, 2, L.Hp, L.Dp), mat(self.m, 2, L.Hp, L.Dp),
                                  mat(self.v, 2, L.Hp, L.Dp), 0.0, 1, wt=ws.W2T, plane_t=L.Hp, wc=ws.W2, plane_c=L.Dp,
                                  bias=vec(b2), advance_tickets=self.adam_tickets, h2_scale=ws.scales.w2, **kw)

@@ -263,7 +263,7 @@ def test_training_holds_the_six_plane_paths_bounds_while_the_scales_move():
             assert 16.0 <= hi < 65504.0 and 16.0 <= hg < 65504.0, (t, hi, hg, a.ws.scales.state())
     print("gradient error against the fp64 oracle (relative L2 f16x2, f32x3; max / max |g| f16x2, f32x3):",
           {k: tuple("%.1e" % x for x in v) for k, v in worst.items()}, "scale moves:", a.ws.scales.changes, a.ws.scales.state())
-    assert a.ws.scales.changes <= 12
+    assert a.ws.scales.changes <= 12 and a.ws.scales.saturated == 0
     assert int(a.step_dev.item()) == max(checks) + 1 and math.isfinite(a.loss())
 
 

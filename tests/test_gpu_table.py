@@ -69,7 +69,7 @@ def test_table_adam_rows_vs_oracle(cd, F, stride):
     assert not np.allclose(m3.cpu().numpy()[touched, :F], got_m[touched, :F], atol=1e-7)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+@pytest.mark.parametrize("precision", ["f32", "f32x3", "f16x2"])
 def test_train_step_with_trainable_table(cd, precision):
     """The step's table update = oracle update fed with the device's own dz1 and W1 -- on both fp32 paths (round 6: on the
     split-fp32 path the row gradient dz1 . W1^T is a sixth product on the plane kernels, W1's planes in their natural
@@ -82,7 +82,7 @@ def test_train_step_with_trainable_table(cd, precision):
     before = table.data.clone()
     ts.fetch(); ts.forward_loss(); ts.backward()
     W1 = ts.params.unpadded()[0].cpu().numpy().astype(np.float64)
-    dz1 = (ts.ws.dz1_f32() if precision == "f32x3" else ts.ws.dz1)[:, :H].cpu().numpy().astype(np.float64)
+    dz1 = (ts.ws.dz1_f32() if precision in ("f32x3", "f16x2") else ts.ws.dz1)[:, :H].cpu().numpy().astype(np.float64)
     idx = ts.idx.cpu().numpy()
     ts.update_table()
     torch.cuda.synchronize()
@@ -99,6 +99,14 @@ def test_train_step_with_trainable_table(cd, precision):
     assert np.abs(got[touched] - before[touched, :F].cpu().numpy()).max() > 0.005
     untouched = np.setdiff1d(np.arange(N), touched)
     assert np.array_equal(got[untouched], before[untouched, :F].cpu().numpy())
+    if precision == "f16x2":                               # (an eager path: its scales are kernel arguments)
+        for _ in range(3):
+            ts.step()
+        assert np.isfinite(ts.loss())
+        L, sw = ts.layout, ts.ws.scales.w1                  # the natural-orientation planes hold the updated W1 (22 bits of it)
+        w1n = (ts.ws.W1n[:, :L.Hp].double() + ts.ws.W1n[:, L.Hp:].double()) / sw
+        assert (w1n - ts.params.W1.double()).abs().max().item() <= 2.0 ** -22 * ts.params.W1.abs().max().item()
+        return
     # and the whole step runs, eagerly and from a captured graph, to the same bits
     mk = lambda g: cd.train.TrainStep(cd.engine.FeatureTable.synthetic(N, F, 0, cd.dev), pairs, B, hidden_size=H,
                                       output_size=D, mode="uniform", device=cd.dev, train_table=True, use_graph=g,
@@ -115,7 +123,7 @@ def test_train_step_with_trainable_table(cd, precision):
         assert torch.equal(w1n, a.params.W1)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+@pytest.mark.parametrize("precision", ["f32", "f32x3", "f16x2"])
 def test_trainable_table_production_width(cd, precision):
     """the trainable catalogue at PRODUCTION width (F = 1500, H = 5000, D = 256), 120 000 rows, batch 512
     triplets (1 536 gathered rows, duplicates included), on both fp32 paths: the row gradient dz1 . W1^T (K = 5 000) against
@@ -133,7 +141,7 @@ def test_trainable_table_production_width(cd, precision):
     probe = torch.arange(0, N, 997, device=cd.dev)                        # a sample of the whole table for the "untouched" check
     before_probe = table.data[probe].clone()
     W1 = ts.params.unpadded()[0].cpu().numpy().astype(np.float64)
-    dz1 = (ts.ws.dz1_f32() if precision == "f32x3" else ts.ws.dz1)[:, :H].cpu().numpy().astype(np.float64)
+    dz1 = (ts.ws.dz1_f32() if precision in ("f32x3", "f16x2") else ts.ws.dz1)[:, :H].cpu().numpy().astype(np.float64)
     ts.update_table()
     torch.cuda.synchronize()
     G = otable.grad_xhat(dz1, W1)

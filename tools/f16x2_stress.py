@@ -53,6 +53,6 @@ for lr, batch, steps in ((1e-3, 1024, steps), (1e-2, 1024, steps)) + (((2e-4, 40
     print("# largest hi-plane magnitude seen: %.0f (fp16 max 65504); scale moves after calibration: %d in %d steps; from the run's final "
           "weights, one step on each path: loss %.6f / %.6f, gradient relative L2 difference %.2e"
           % (worst, a.ws.scales.changes, steps, a.loss(), b.loss(), float((ga - gb).norm() / gb.norm().clamp_min(1e-300))))
-    assert worst < 65504.0 and math.isfinite(a.loss()) and torch.equal(a.idx, b.idx)
+    assert worst < 65504.0 and a.ws.scales.saturated == 0 and math.isfinite(a.loss()) and torch.equal(a.idx, b.idx)
     del a, b
     torch.cuda.empty_cache()
