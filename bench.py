@@ -1276,8 +1276,8 @@ def main():
     bf16 = args.precision == "bf16"
     x3 = 0 if not args.precision.startswith("f32x3") else (3 if args.precision.endswith("-3") else 6)
     h2 = args.precision == "f16x2"
-    if h2 and (args.graph or args.train_table):
-        sys.exit("--precision f16x2 is the eager step with a frozen catalogue")
+    if h2 and args.graph and args.gpus > 1:
+        sys.exit("--precision f16x2 replays from a hipGraph on one GPU only")
     Table = engine_bf16.FeatureTableF16 if bf16 else engine.FeatureTable
 
     if args.mode == "predict":                           # catalogue inference throughput (N = 1)

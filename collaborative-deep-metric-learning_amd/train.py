@@ -57,7 +57,7 @@ class TrainStep:
         bench.py times -- when the step's rows are a multiple of 128, else "f32" (the fp32 MFMA).  "f16x2" (never chosen by
         "auto"): fp32 operands as TWO fp16 planes under per-tensor power-of-two scales, three plane products on the fp16 MFMA
         -- half of "f32x3"'s matrix work at the same error bound, an fp32 equivalent while its delayed scales hold
-        (engine_f16x2.py); eager.
+        (engine_f16x2.py); under ``use_graph`` (one GPU) its check steps run eagerly and a moved scale re-captures.
         ``use_graph``: False = eager; True = the whole step replayed from ONE hipGraph (single GPU: the
         fast form; data-parallel: the exchange of step t+1 is then recorded on the capturing stream,
         ahead of the forward pass, not under it); "split" (data-parallel with the prefetcher) = three
@@ -141,9 +141,10 @@ class TrainStep:
         if self.bf16 != (table.data.dtype == torch.float16):
             raise ValueError("precision 'bf16' goes with an fp16 FeatureTableF16, 'f32' / 'f32x3' with an fp32 table")
         if self.h2:
-            if use_graph:
-                raise ValueError("precision 'f16x2' is the eager step (its plane scales are host-side kernel arguments that "
-                                 "move during training: engine_f16x2.py)")
+            if use_graph and (use_graph == "split" or exchange is not None or grad_sync is not None):
+                raise ValueError("precision 'f16x2' replays from a hipGraph on one GPU only (its plane scales are kernel arguments "
+                                 "baked into a capture: the check steps run eagerly and a moved scale re-captures, engine_f16x2.py)")
+            self._h2_sig = None                          # the scales the captured graphs were recorded with
             self.layout = engine_x3.layout_x3(F, hidden_size, output_size)
             self.params = engine.VNetParams(self.layout, self.device, weight_seed)
             # one GPU: the fused sampler + gather writes the fp16 planes; sharded catalogue: the rows arrive in fp32 through the
@@ -710,10 +711,13 @@ class TrainStep:
         if lr != self._lr_host:                         # staircase: rare
             self.lr_dev.fill_(lr)
             self._lr_host = lr
+        # precision f16x2 under use_graph: a check step of the plane scales (host reads) runs eagerly, and graphs recorded with
+        # scales that have moved since are dropped (re-captured on the next replay step)
+        h2_eager = self.h2 and bool(self.use_graph) and self.ws.scales.due(self.global_step)
         if self.use_graph == "split" and self._warmed and self.prefetch is not None:
             self._step_split(self.global_step)
             self._replayed = True
-        elif self.use_graph and self._warmed:            # the first step of a process runs eagerly
+        elif self.use_graph and self._warmed and not h2_eager:   # the first step of a process runs eagerly
             t = self.global_step                         # (it loads the kernels), also after a resume
             if self.prefetch is not None:
                 # one graph per prefetch buffer; the rows of step t were fetched by step t-1 (an
@@ -743,6 +747,10 @@ class TrainStep:
             self._replayed = False
             self._enqueue()
             self._warmed = True
+            if self.h2 and self.use_graph:
+                sig = tuple(sorted(self.ws.scales.state().items()))
+                if sig != self._h2_sig:
+                    self._graphs, self._h2_sig = {}, sig
         self.global_step += 1
 
     def _capture(self, fn=None, origin=None):
