@@ -1115,7 +1115,7 @@ def rec_fusion(dev, args, n_s, n_w):
     table = engine.FeatureTable.synthetic(n_rows, 1628, seed=0, device=dev)
     pairs = torch.from_numpy(synth_pairs(n_rows, 300000, seed=0)).to(dev)
     out = None
-    for prec in ("auto", "f32"):                     # round 6: the visual branch on the plane kernels; the fp32-MFMA tower beside it
+    for prec in ("auto", "f32", "f16x2"):            # round 6: the visual branch on the plane kernels; the fp32-MFMA tower and the fp16 planes beside it
         ts = fusion.FusionTrainStep("ResNet", table, pairs, 1024, device=dev, precision=prec)
         n = max(n_s, 100)
         el = timed_steps(ts, n, max(n_w, 10), dev)
@@ -1125,7 +1125,7 @@ def rec_fusion(dev, args, n_s, n_w):
             out = dict(r, workload="ResNet fusion tower (models.py:125-157): %d videos x 1628-d fp32, batch 1024 uniform triplets "
                                    "(3072 rows), Adam, full step" % n_rows, unit="triplets/s")
         else:
-            out["f32_mfma"] = r
+            out["f32_mfma" if prec == "f32" else prec] = r
         del ts
     return out
 

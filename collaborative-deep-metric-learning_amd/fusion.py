@@ -18,7 +18,7 @@ import math
 import numpy as np
 import torch
 
-from . import engine_x3, ops
+from . import engine_f16x2, engine_x3, ops
 from .engine import round_up
 
 NETS = ("MultiplyNet", "MlpNet", "ResNet", "ResNetV2")
@@ -134,11 +134,13 @@ class FusionTower:
     tower's flop -- runs on the plane kernels (fp32 operands as three exact bf16 planes, six plane products per fp32
     product on the bf16 MFMA: engine_x3, the headline path's arithmetic and bounds) wherever its padded widths are the
     plane kernels' (multiples of 256) and the rows a multiple of 128; the doc branch and the fusion layers (a few per
-    cent of the flop) stay on the fp32 MFMA.  "f32": everything on the fp32 MFMA (rounds 1-5)."""
+    cent of the flop) stay on the fp32 MFMA.  "f32": everything on the fp32 MFMA (rounds 1-5).  "f16x2" (never chosen by
+    "auto"): the visual branch on the fp16 build of the plane kernels -- two fp16 planes per operand under delayed per-tensor
+    scales, three plane products (engine_f16x2: what it watches and when)."""
 
     def __init__(self, params, n_rows, precision="auto"):
-        if precision not in ("auto", "f32x3", "f32"):
-            raise ValueError("precision must be 'auto', 'f32x3' or 'f32'")
+        if precision not in ("auto", "f32x3", "f32", "f16x2"):
+            raise ValueError("precision must be 'auto', 'f32x3', 'f16x2' or 'f32'")
         self.p, self.R = params, int(n_rows)
         p, dev, R = params, params.device, self.R
         z = lambda n: torch.zeros((R, n), dtype=torch.float32, device=dev)
@@ -164,22 +166,36 @@ class FusionTower:
         self.bw = torch.empty(max(nb, self.sk_bytes, 16) // 4, dtype=torch.float32, device=dev)
         # the visual branch on the plane kernels
         self.vx3 = self.vp3 = None
+        self.vh2, self._h2_check = False, False
         if precision != "f32" and "layer_visual_1" in Ls:
             if _VisualAsVNet.fits(p, "layer_visual_1", "layer_visual_2", R):
                 self.vp3 = _VisualAsVNet(p, "layer_visual_1", "layer_visual_2")
-                ws = engine_x3.TowerWorkspaceX3(self.vp3.layout, R, dev, planes_in=False, kint=False)
+                self.vh2 = precision == "f16x2"
+                ws = (engine_f16x2.TowerWorkspaceH2(self.vp3.layout, R, dev, planes_in=False) if self.vh2 else
+                      engine_x3.TowerWorkspaceX3(self.vp3.layout, R, dev, planes_in=False, kint=False))
                 ws.x_hat = self.xv                                       # the l2-normalised visual rows (fp32: split in the forward pass)
                 self.act["layer_visual_2"] = ws.z                        # the branch's output, where the fusion reads it
                 self.dpre["layer_visual_2"] = ws.dz2                     # ... and where its gradient arrives
                 self.vx3 = ws
-                engine_x3.refresh_weights(self.vp3, ws)
-            elif precision == "f32x3":
-                raise ValueError("precision 'f32x3' needs the visual branch's padded widths to be multiples of 256 and the "
-                                 "rows a multiple of 128")
+                if not self.vh2:
+                    engine_x3.refresh_weights(self.vp3, ws)
+            elif precision in ("f32x3", "f16x2"):
+                raise ValueError("precision '%s' needs the visual branch's padded widths to be multiples of 256 and the "
+                                 "rows a multiple of 128" % precision)
 
-    def refresh_planes(self):
-        """After an optimizer step on the flat parameter buffer: the visual branch's weight planes follow the new weights."""
-        if self.vx3 is not None:
+    def refresh_planes(self, step=None):
+        """After an optimizer step on the flat parameter buffer: the visual branch's weight planes follow the new weights.
+        Precision "f16x2": on a check step of its plane scales (``step`` None: always) the weights' and the hidden layer's
+        scales are re-derived first, and backward() re-derives the gradients' once the fusion layers have produced them."""
+        if self.vx3 is None:
+            return
+        if self.vh2:
+            sc = self.vx3.scales
+            self._h2_check = step is None or sc.due(step)
+            if self._h2_check:
+                engine_f16x2.observe_weights(self.vp3, self.vx3)
+            engine_f16x2.refresh_weights(self.vp3, self.vx3)
+        else:
             engine_x3.refresh_weights(self.vp3, self.vx3)
 
     def _fc(self, n, x):
@@ -206,7 +222,12 @@ class FusionTower:
             ops.l2norm_fwd(self.pre, D, self.e)
             return self.e
         if self.vx3 is not None:
-            engine_x3.tower_forward(self.vp3, self.vx3, normalize=False)         # h1 as planes + sign bits, v2 = vx3.z (fp32)
+            if self.vh2:
+                if not (self.vx3.scales.calibrated or self._h2_check):
+                    self.refresh_planes()                                        # a first pass nobody prepared: calibrate
+                engine_f16x2.tower_forward(self.vp3, self.vx3, normalize=False)
+            else:
+                engine_x3.tower_forward(self.vp3, self.vx3, normalize=False)     # h1 as planes + sign bits, v2 = vx3.z (fp32)
             v2 = self.vx3.z
         else:
             v2 = self._fc("layer_visual_2", self._fc("layer_visual_1", self.xv))
@@ -276,7 +297,13 @@ class FusionTower:
             # dp["layer_visual_2"] IS vx3.dz2 (the gradient of the branch's output pre-activation): planes, data gradient,
             # both weight gradients + bias gradients on the plane kernels
             self.vx3.tail_done, self.vx3.dz2_planes_done = True, False
-            engine_x3.tower_backward(self.vp3, self.vx3)
+            if self.vh2:
+                if self._h2_check:                                               # the gradients' scales, from dz2 as it stands
+                    engine_f16x2.observe_gradients(self.vp3, self.vx3)
+                    self._h2_check = False
+                engine_f16x2.tower_backward(self.vp3, self.vx3)
+            else:
+                engine_x3.tower_backward(self.vp3, self.vx3)
         elif self.sk_bytes and joint_visual:
             v1, v2 = p.layers["layer_visual_1"], p.layers["layer_visual_2"]
             ops.fc_bwd_data(dp["layer_visual_2"], p.W("layer_visual_2"), A["layer_visual_1"], dp["layer_visual_1"],
@@ -312,7 +339,8 @@ class FusionTrainStep:
         doc = table.feature_size - dims.get("visual_size", VISUAL)
         self.params = FusionParams(net, device, doc_size=doc, seed=weight_seed, **dims)
         self.tower = FusionTower(self.params, 3 * self.B, precision=precision)
-        self.precision = "f32x3 (visual branch) + f32" if self.tower.vx3 is not None else "f32"
+        self.precision = ("f32" if self.tower.vx3 is None else
+                          "f16x2 (visual branch) + f32" if self.tower.vh2 else "f32x3 (visual branch) + f32")
         dev, f32 = self.device, torch.float32
         self.idx = torch.zeros((self.B, 3), dtype=torch.int32, device=dev)
         self.x = torch.zeros((3 * self.B, table.data.shape[1]), dtype=f32, device=dev)
@@ -330,7 +358,7 @@ class FusionTrainStep:
                             normalize=False)
         else:
             self.exchange.gather(self.table, self.idx.view(-1), self.x)
-        t.refresh_planes()      # (the visual branch's weight planes follow whatever the weights are now: Adam's update, a load())
+        t.refresh_planes(self.global_step)      # (the visual branch's weight planes follow whatever the weights are now: Adam's update, a load())
         t.forward(self.x)
         ops.triplet_hinge(t.e, self.B, self.params.Dp, self.margin, self.pos, self.neg, self.hinge, self.stats, t.de)
         t.backward()

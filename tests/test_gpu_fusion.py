@@ -101,8 +101,9 @@ def test_fusion_train_step_learns(cd):
     assert abs(ts2.loss() - float(loss["hinge_loss"])) < TOL
 
 
+@pytest.mark.parametrize("precision", ["f32x3", "f16x2"])
 @pytest.mark.parametrize("net", ["MultiplyNet", "MlpNet", "ResNet"])
-def test_fusion_visual_branch_on_the_plane_kernels(cd, net):
+def test_fusion_visual_branch_on_the_plane_kernels(cd, net, precision):
     """Round 6: the visual branch of a fusion tower (1500 -> 5000 -> 256: VNet's two layers, 97 % of the tower's flop) on
     the plane kernels -- fp32 operands as three exact bf16 planes, six plane products per fp32 product -- at production
     shape, against the fp64 oracle with the fp32 tower's bounds, forward and every gradient; and against the fp32-MFMA
@@ -111,8 +112,8 @@ def test_fusion_visual_branch_on_the_plane_kernels(cd, net):
     x = np.random.RandomState(1).random_sample((R, F)).astype(np.float32)
     xt = torch.as_tensor(x).to(cd.dev)
     params = cd.fusion.FusionParams(net, cd.dev, doc_size=F - 1500, seed=3)
-    tower = cd.fusion.FusionTower(params, R, precision="f32x3")
-    assert tower.vx3 is not None
+    tower = cd.fusion.FusionTower(params, R, precision=precision)      # (f16x2: two fp16 planes, three products, its scales calibrated by this first pass)
+    assert tower.vx3 is not None and tower.vh2 == (precision == "f16x2")
     out = tower.forward(xt).clone()
     P = {k: (w.detach().cpu().numpy().astype(np.float64), b.detach().cpu().numpy().astype(np.float64))
          for k, (w, b) in params.unpadded().items()}
