@@ -431,7 +431,10 @@ class TrainStep:
     def variance(self):
         if self.var_ws is None:
             raise RuntimeError("call enable_variance() before the step")
-        return float(self.stats[4].item())
+        # (the tail kernel averages over the PADDED embedding width it is given, L.Dp; the reference's calc_var over the D real
+        # columns -- the padding columns are zero, so the two differ by exactly Dp / D where a layout pads D: the plane layouts
+        # at D < 256.  Found by running build_graph's switches on the plane paths, round 6.)
+        return float(self.stats[4].item()) * self.layout.Dp / self.layout.D
 
     def forward_loss(self, with_grad=True):
         # precision f16x2: on its check steps (0, 1, 2, 4 .. 64, then every 64th) the plane scales are re-derived -- the weights'
@@ -559,7 +562,7 @@ class TrainStep:
         self._wsq[:8].copy_(self.stats)
         h = self._wsq.cpu().double()
         return {"loss": float(h[0]), "reg_loss": float(self.l2_penalty * h[8:].sum() / 2.0),
-                "variance": float(h[4]) if self.var_ws is not None else None,
+                "variance": float(h[4]) * L.Dp / L.D if self.var_ws is not None else None,
                 "final_learning_rate": float(self._lr_host), "mean_pos_dist": float(h[1]), "mean_neg_dist": float(h[2]),
                 "active_triplets": float(h[3])}
 

@@ -594,17 +594,19 @@ def test_grad_prepare_and_momentum_vs_oracle(cd):
         np.testing.assert_allclose(dw.cpu().numpy(), ww, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("precision,B", [("auto", 64), ("f32x3", 128), ("f16x2", 128)])
 @pytest.mark.parametrize("optimizer", ["adam", "momentum"])
-def test_train_step_build_graph_switches(cd, optimizer):
+def test_train_step_build_graph_switches(cd, optimizer, precision, B):
     """clip_gradient_norm, regularization_penalty, the variance summary and the Nesterov
     momentum branch of build_graph (train.py:67-71,108-151) through TrainStep, against the oracle
-    applied to the device's own raw gradients."""
-    N, F, H, D, B = 3000, 200, 300, 64, 64
+    applied to the device's own raw gradients -- on the fp32 MFMA (B = 64: "auto" picks it) and on both plane forms."""
+    N, F, H, D = 3000, 200, 300, 64
     feats, pairs = _clustered(N, F, 12, 3)
     table = cd.engine.FeatureTable.from_numpy(feats, cd.dev)
     ts = cd.train.TrainStep(table, dt(pairs, cd.dev, torch.int32), B, hidden_size=H, output_size=D, mode="uniform",
                             optimizer=optimizer, base_learning_rate=0.01, clip_gradient_norm=0.05,
-                            regularization_penalty=1e5, device=cd.dev)      # penalty*1e-8 = 1e-3: visible
+                            regularization_penalty=1e5, device=cd.dev, precision=precision)      # penalty*1e-8 = 1e-3: visible
+    assert ts.precision == ("f32" if precision == "auto" else precision)
     ts.enable_variance()
     host = lambda ts_: [t.detach().cpu().numpy().astype(np.float64) for t in ts_]
     clipped = 0
