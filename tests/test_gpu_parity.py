@@ -1288,22 +1288,24 @@ def _clustered(n_videos, F, n_clusters, seed):
     return feats, pairs[pairs[:, 0] != pairs[:, 1]].astype(np.int32)
 
 
-def test_trainer_learns_evaluates_checkpoints_and_resumes(cd, tmp_path):
+@pytest.mark.parametrize("precision,B", [("auto", 64), ("f32x3", 128), ("f16x2", 128)])
+def test_trainer_learns_evaluates_checkpoints_and_resumes(cd, tmp_path, precision, B):
     """train.py:224-309 policy on a learnable synthetic set (co-watched videos share
     a cluster): the loss and the held-out mean_dist go down, the best model is
-    checkpointed (one file kept), and a resumed run continues bit-exactly."""
+    checkpointed (one file kept), and a resumed run continues bit-exactly -- on the fp32 MFMA (B = 64: what "auto" picks
+    there) and on both plane forms (B = 128, twice the epochs: the same number of steps)."""
     feats, pairs = _clustered(2000, 64, 10, 0)
     eval_pairs, train_pairs = pairs[:200], pairs[200:]
     table = cd.engine.FeatureTable.from_numpy(feats, cd.dev)
     kw = dict(hidden_size=128, output_size=32, margin=0.8, mode="uniform", optimizer="adam",
-              base_learning_rate=0.002, device=cd.dev)
-    B = 64
+              base_learning_rate=0.002, device=cd.dev, precision=precision)
     mk = lambda: cd.train.TrainStep(table, dt(train_pairs, cd.dev, torch.int32), B, **kw)
     ts = mk()
-    tr = cd.train.Trainer(ts, num_epochs=2, n_pairs=len(train_pairs), checkpoint_dir=str(tmp_path),
+    assert ts.precision == ("f32" if precision == "auto" else precision)
+    tr = cd.train.Trainer(ts, num_epochs=2 * (B // 64), n_pairs=len(train_pairs), checkpoint_dir=str(tmp_path),
                           eval_features=feats, eval_cowatches=eval_pairs.tolist(), check_stop_epoch=0.2,
                           best_eval_dist=10.0, eval_per_epoch=8, require_improve_num=100)
-    assert tr.num_batches == (len(train_pairs) * 2) // B
+    assert tr.num_batches == (len(train_pairs) * 2 * (B // 64)) // B
     hist = tr.run()
     assert tr.stopped == "end of data" and ts.global_step == tr.num_batches
     assert hist[-1][1] < 0.6 * hist[0][1], hist                 # loss went down
