@@ -384,3 +384,20 @@ def test_lars_and_momentum_write_the_fp16_planes_with_the_update(rule):
     i16 = lambda t: t.view(torch.int16)
     assert torch.equal(i16(W1T), i16(_planes(W1, Fp, s1, transpose=True)))
     assert torch.equal(i16(W2T), i16(_planes(W2m, Hp, s2, transpose=True))) and torch.equal(i16(W2), i16(_planes(W2m, Dp, s2)))
+
+
+def test_embedding_bits_do_not_depend_on_the_chunk():
+    """Catalogue inference on the fp16 planes keeps the six-plane path's property: an embedding has the same bits in a
+    49 152-row chunk and in 4 096-row chunks -- the narrow layer's K-slabs partition K alone (pinned for forward-only
+    workspaces), and the plane scales come from the WEIGHTS (once per pass), never from a chunk's rows."""
+    dev = _dev()
+    F, H, D, N = 64, 2560, 32, 49152
+    L = engine_x3.layout_x3(F, H, D)
+    params = engine.VNetParams(L, dev, 42)
+    table = engine.FeatureTable.synthetic(N, F, seed=0, device=dev)
+    big = predict.Prediction(params=params, precision="f16x2").embed_table(table, N).clone()
+    small = predict.Prediction(params=params, precision="f16x2").embed_table(table, 4096)
+    torch.cuda.synchronize()
+    assert torch.equal(big, small)
+    ref = predict.Prediction(params=params, precision="f32x3").embed_table(table, 8192)
+    assert (big - ref).abs().max().item() < 2e-6
